@@ -1,0 +1,39 @@
+"""Constructors that assemble oracle modules the way the expt/ configs do.
+
+TEST INFRASTRUCTURE - see oracle/__init__.py.
+"""
+from .decoders import CONTEXTS_FACES_OBJECTS, CONTEXTS_FLATTENED, DynamicConvDecoder
+from .models import CaptionModel
+from .modules import (AdaptiveEmbedding, AdaptiveLoss, SinusoidalPositionalEmbedding,
+                      SumTextFieldEmbedder)
+
+
+def build_embedder(vocab_size=50265, dim=1024, cutoff=(5000, 20000), init_size=512):
+    """expt/nytimes/9_transformer_objects/config.yaml:28-50."""
+    return SumTextFieldEmbedder(
+        {'adaptive': AdaptiveEmbedding(vocab_size, 0, dim, 1, dim, list(cutoff), scale_embeds=True),
+         'position': SinusoidalPositionalEmbedding(dim, 1, False, init_size=init_size)},
+        embedder_to_indexer_map={'adaptive': ['roberta'], 'position': ['roberta']},
+        allow_unmatched_keys=True)
+
+
+def build_decoder(kind='faces_objects', vocab_size=50265, dim=1024, heads=16, ffn=4096,
+                  kernels=(3, 7, 15, 31), cutoff=(5000, 20000), article_dim=1024, **overrides):
+    """config.yaml:26-76 (`dynamic_conv_decoder_faces_objects`) or
+    expt/nytimes/5_transformer_roberta (`dynamic_conv_decoder_flattened`)."""
+    if kind == 'faces_objects':
+        contexts = CONTEXTS_FACES_OBJECTS
+    else:
+        contexts = (CONTEXTS_FLATTENED[0], ('article', article_dim))
+    kw = dict(decoder_conv_dim=dim, decoder_attention_heads=heads, decoder_ffn_embed_dim=ffn,
+              decoder_kernel_size_list=tuple(kernels), adaptive_softmax_cutoff=tuple(cutoff),
+              decoder_layers=len(kernels), vocab_size=vocab_size)
+    kw.update(overrides)
+    return DynamicConvDecoder(build_embedder(vocab_size, dim, cutoff), contexts, **kw)
+
+
+def build_model(kind, resnet, roberta, n_bert_layers=25, **decoder_kw):
+    dec = build_decoder(kind, **decoder_kw)
+    return CaptionModel(dec, AdaptiveLoss(padding_idx=1), resnet, roberta,
+                        use_faces_objects=(kind == 'faces_objects'), weigh_bert=True,
+                        n_bert_layers=n_bert_layers)
