@@ -1,0 +1,184 @@
+/* tell_hip.h - C ABI of libtell_hip.so: the MI355X (gfx950) kernels of the
+ * Transform-and-Tell caption hot path.
+ *
+ * The reference (alasdairtran/transform-and-tell) is pure Python: it has no FFI.
+ * Each entry point below replaces the ATen/cuDNN/cuBLAS op *sequence* that the
+ * cited reference lines issue; the Python host modules in
+ * `transform-and-tell_amd/` (same class names, constructor arguments and
+ * state_dict keys as the reference) call these through ctypes.  INTEGRATION.md
+ * shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; caller owns all memory; the library
+ *     allocates nothing and keeps no state except a thread-local error string;
+ *   - every call is asynchronous on `stream` (pass torch's current stream);
+ *   - return 0 on success, <0 on error (tell_last_error() explains);
+ *   - `dtype`: TELL_F32 = 0 (exact-f32 parity mode, f32 MFMA), TELL_BF16 = 1;
+ *     activations / working copies of weights are in `dtype`, statistics, biases,
+ *     norm parameters, losses, master weights and gradients of weights are fp32;
+ *   - `*_dev` pointers are DEVICE scalars read by the kernel (static shapes, no
+ *     host synchronisation: row counts of vocabulary bands, learning rate, ...);
+ *   - dropout: keep(idx) = hash(seed, salt, idx) >= p*2^32, scaled by 1/(1-p);
+ *     the same (seed, salt) given to the backward call reproduces the mask.
+ * All file:line citations are relative to the reference root.
+ */
+#ifndef TELL_HIP_H
+#define TELL_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TELL_F32 0
+#define TELL_BF16 1
+typedef struct ihipStream_t* tell_stream_t; /* hipStream_t */
+
+/* ---- library ------------------------------------------------------------ */
+int tell_abi_version(void);
+int tell_device_count(void);
+const char* tell_last_error(void);
+void tell_set_error(const char* msg);
+
+/* ---- GEMM (every nn.Linear / F.linear / 1x1 conv on the path) --------------
+ * C[M,N] = act((A[M,K] . B[N,K]^T + bias) * alpha) (+ C if accumulate)
+ * Replaces F.linear in tell/modules/linear.py:8-33 (GehringLinear),
+ * multi_head.py:488-526 (in_proj_q/k/v, out_proj), dynamic.py:300 (weight_linear),
+ * softmax.py:24-40,182-189 (head / tail projections), adaptive.py:73 (band
+ * projections) and the convolutions of resnet.py:92-108 (NHWC rows).
+ * bias_mode 0 none | 1 bias[n] | 2 bias[m];  act 0 none | 1 relu | 2 gelu(erf) |
+ * 3 multiply by (aux[m,n] > 0) (relu backward);  m_dev: optional device row count. */
+int tell_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                 int in_dtype, int out_dtype, const float* bias, int bias_mode, int act, const void* aux,
+                 float alpha, int accumulate, const int* m_dev, tell_stream_t stream);
+
+/* ---- casts / transposes / weight norm -------------------------------------- */
+int tell_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, tell_stream_t stream);
+/* dst_t[c][r] = src[r][c] * row_scale[r]; optional dst_plain[r][c] = same value (either may be NULL) */
+int tell_transpose(const void* src, long ld_src, int src_dtype, void* dst_t, long ld_t, void* dst_plain,
+                   long ld_p, int dst_dtype, const float* row_scale, int rows, int cols, tell_stream_t stream);
+/* weight norm, tell/modules/linear.py:33 (torch weight_norm dim=0): scale[r] = g[r]/||v[r]||, norms[r] = ||v[r]|| */
+int tell_wn_rowscale(const float* g, const float* v, int rows, int cols, float* scale, float* norms,
+                     tell_stream_t stream);
+int tell_wn_backward(const float* dW, const float* g, const float* v, const float* norms, int rows, int cols,
+                     float* dg, float* dv, tell_stream_t stream);
+
+/* ---- elementwise ------------------------------------------------------------ */
+/* nn.GLU, decoder_faces_objects.py:194-195,259-261: h = [a | gate] */
+int tell_glu_fwd(const void* h, void* y, long rows, int C, int dtype, tell_stream_t stream);
+int tell_glu_bwd(const void* h, const void* dy, void* dh, long rows, int C, int dtype, tell_stream_t stream);
+/* F.dropout, decoder_faces_objects.py:106,257 */
+int tell_dropout(const void* x, void* y, long n, float p, uint32_t seed, uint32_t salt, int dtype,
+                 tell_stream_t stream);
+/* bias gradients: out[c] (+)= sum_r x[r][c] */
+int tell_colsum(const void* x, long ld, int rows, int C, int dtype, float* out, int accumulate,
+                const int* m_dev, float scale, tell_stream_t stream);
+/* F.relu backward (decoder_faces_objects.py:360): dx = dy * (y > 0) */
+int tell_relu_bwd(const void* dy, const void* y, void* dx, long n, int dtype, tell_stream_t stream);
+int tell_axpy(const void* x, void* y, long n, float alpha, int dtype, tell_stream_t stream);
+int tell_fill_f32(float* x, long n, float value, tell_stream_t stream);
+int tell_sum_f32(const float* x, int n, const int* m_dev, float* out, int accumulate, tell_stream_t stream);
+/* X.index_select(0, idx) / inverse, softmax.py:184-189 */
+int tell_gather_rows(const void* src, long ld_src, const int* idx, const int* count_dev, int cap, void* dst,
+                     long ld_dst, int C, int dtype, tell_stream_t stream);
+int tell_scatter_add_rows(const void* src, long ld_src, const int* idx, const int* count_dev, int cap, void* dst,
+                          long ld_dst, int C, int dtype, tell_stream_t stream);
+/* NaN-padded face/object rows -> mask + zeros, transformer_faces_objects.py:373-379 */
+int tell_nan_rows(const float* x, int rows, int C, void* y, int out_dtype, uint8_t* mask, tell_stream_t stream);
+/* softmax(bert_weight)-weighted sum of the 25 RoBERTa layers, transformer_faces_objects.py:355-364 */
+int tell_mix_fwd(const void* H, const float* w, int L, long n, void* out, int dtype, tell_stream_t stream);
+int tell_mix_bwd(const void* H, const void* dOut, int L, long n, float* partial, int n_blocks, int dtype,
+                 tell_stream_t stream);
+
+/* ---- LayerNorm: y = LN(res + dropout(x)), decoder_faces_objects.py:263-266,367-372 */
+int tell_layernorm_fwd(const void* x, long ld_x, const void* res, long ld_r, const float* gamma,
+                       const float* beta, void* y, long ld_y, float* mean, float* rstd, int rows, int C,
+                       float eps, float p, uint32_t seed, uint32_t salt, int dtype, tell_stream_t stream);
+int tell_layernorm_bwd_blocks(int rows);
+int tell_layernorm_bwd(const void* dy, long ld_dy, const void* x, long ld_x, const void* res, long ld_r,
+                       const float* gamma, const float* mean, const float* rstd, void* dx, long ld_dx,
+                       void* dres, long ld_dres, int dres_accumulate, float* dgamma, float* dbeta,
+                       int dparam_accumulate, float* partial, int rows, int C, float p, uint32_t seed,
+                       uint32_t salt, int dtype, tell_stream_t stream);
+
+/* ---- DynamicConv1dTBC core, tell/modules/convolutions/dynamic.py:285-336 (T x B x C)
+ * taps = softmax_K(logits) (:302-304), DropConnect (:305), causal K-tap weighted sum;
+ * replaces the band-matrix build + bmm (:318-335).  taps: [T*B*H, K] fp32 (saved for backward). */
+int tell_dynconv_fwd(const void* x, const void* logits, void* y, float* taps, int T, int B, int H, int K,
+                     int R, float p, uint32_t seed, uint32_t salt, int dtype, tell_stream_t stream);
+int tell_dynconv_bwd(const void* x, const void* dy, const float* taps, void* dx, int dx_accumulate,
+                     void* dlogits, int T, int B, int H, int K, int R, float p, uint32_t seed, uint32_t salt,
+                     int dtype, tell_stream_t stream);
+
+/* ---- MultiHeadAttention core, tell/modules/attention/multi_head.py:376-475
+ * element (b,h,t,d) of q at q + t*q_st + b*q_sb + h*D + d (k, v, out likewise);
+ * bias_k/bias_v (:355-364) and the zero row (:416-421) are virtual keys S, S+1;
+ * mask [B,S] uint8 (:442-458); fp32 softmax (:460-462); prob dropout (:463). */
+int tell_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, const uint8_t* mask,
+                  const void* bias_k, const void* bias_v, int B, int H, int Tq, int S, int D, long q_st,
+                  long q_sb, long k_ss, long k_sb, long v_ss, long v_sb, long o_st, long o_sb, int has_zero,
+                  float p, uint32_t seed, uint32_t salt, int dtype, tell_stream_t stream);
+int tell_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                  const float* lse, const uint8_t* mask, const void* bias_k, const void* bias_v, void* dq,
+                  void* dk, void* dv, float* dbias_k, float* dbias_v, int B, int H, int Tq, int S, int D,
+                  long q_st, long q_sb, long k_ss, long k_sb, long v_ss, long v_sb, long o_st, long o_sb,
+                  int has_zero, float p, uint32_t seed, uint32_t salt, int dtype, tell_stream_t stream);
+
+/* head-averaged attention weights [B,Tq,S'] for need_weights (multi_head.py:478-482), eval/demo only */
+int tell_attn_avg_weights(const void* q, const void* k, const float* lse, const uint8_t* mask,
+                          const void* bias_k, float* w, int B, int H, int Tq, int S, int D, long q_st, long q_sb,
+                          long k_ss, long k_sb, int has_zero, int dtype, tell_stream_t stream);
+
+/* ---- adaptive input embedding / adaptive softmax ----------------------------
+ * tell_adaptive_partition: device-side replacement of the boolean-mask / nonzero()
+ * logic of adaptive.py:64-74 and softmax.py:144-167 (adapt_target). */
+int tell_adaptive_partition(const long* ids, int N, const int* cutoffs_host, int n_bands, int pad_idx,
+                            int* band_rows, int* band_local, int* band_count, int* slot, int* head_target,
+                            int* n_valid, tell_stream_t stream);
+/* out = scale * band_out[slot] + sinusoid[pos], positional.py:167-211,231-268, sum_text_field_embedder.py:117-118 */
+int tell_embed_finalize(const void* band_out, const int* slot, const long* ids, const float* pos_table,
+                        int pos_rows, void* out, int B, int T, int E, float scale, int pos_pad, int start_pos,
+                        int tbc, int dtype, tell_stream_t stream);
+int tell_embed_finalize_bwd(const void* dout, const int* slot, void* dband, int B, int T, int E, float scale,
+                            int tbc, int dtype, tell_stream_t stream);
+int tell_embed_table_grad(const void* drows, long ld, const int* local, const int* count_dev, int cap,
+                          float* demb, int dim, int padding_idx, int dtype, tell_stream_t stream);
+/* F.cross_entropy(ignore_index, reduction='sum') per cluster, adaptive_loss.py:55-60 */
+int tell_ce_fwd(const float* logits, long ld, int M, int V, const int* targets, const int* row_idx,
+                const int* m_dev, int ignore_index, float* lse, float* loss, tell_stream_t stream);
+int tell_ce_bwd(const float* logits, long ld, int M, int V, const int* targets, const int* row_idx,
+                const int* m_dev, int ignore_index, const float* lse, const float* gscale_dev, void* dlogits,
+                long ld_d, int dtype, tell_stream_t stream);
+/* get_log_prob + topk(1), softmax.py:193-222, transformer_faces_objects.py:443-464 */
+int tell_adaptive_logprob_argmax(const float* head, long ld_head, int c0, int n_tails, const float* tail0,
+                                 long ld0, int n0, const float* tail1, long ld1, int n1, const float* tail2,
+                                 long ld2, int n2, int rows, float* log_probs, long ld_lp, int* token,
+                                 float* token_lp, tell_stream_t stream);
+
+/* ---- BertAdam (config.yaml:126-149), flat fp32 buffers, tensors CHUNK-aligned */
+int tell_opt_chunk(void);
+int tell_bertadam_step(float* param, const float* grad, float* m, float* v, const int* chunk_tensor,
+                       const long* chunk_begin, long n_chunks, int n_tensors, float* partial, float* norms,
+                       const float* lr_dev, float b1, float b2, float eps, float wd, float max_norm,
+                       float grad_scale, tell_stream_t stream);
+
+/* ---- ResNet-152 trunk helpers, tell/models/resnet.py:92-108 (NHWC) ----------- */
+int tell_nchw_to_nhwc(const float* x, void* y, int B, int C, int H, int W, int out_dtype, tell_stream_t stream);
+int tell_im2col(const void* x, void* col, int B, int H, int W, int Cin, int KH, int KW, int stride, int pad,
+                int OH, int OW, int Kp, int dtype, tell_stream_t stream);
+long tell_bn_chunks(long M);
+int tell_bn_stats(const void* x, long M, int C, float eps, float momentum, float* mean, float* invstd,
+                  float* running_mean, float* running_var, float* workspace, int dtype, tell_stream_t stream);
+int tell_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                  const void* residual, void* y, long M, int C, int relu, int dtype, tell_stream_t stream);
+int tell_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int OH, int OW, int dtype,
+                      tell_stream_t stream);
+
+/* ---- RoBERTa input embedding (fairseq roberta.large, call site transformer_faces_objects.py:352) */
+int tell_roberta_embed(const long* ids, int B, int S, int pad, const void* word, const void* posemb, int* pos_ws,
+                       void* out, int E, int dtype, tell_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TELL_HIP_H */

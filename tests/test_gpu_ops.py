@@ -1,0 +1,376 @@
+"""GPU parity tests of the HIP ops (through the C ABI) against the CPU oracle.
+Run on the MI355X box:  python -m pytest tests -m gpu
+fp32 mode: tight tolerances (f32 MFMA == fmaf chain).  bf16 mode: bf16-level tolerances."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+@pytest.fixture(autouse=True)
+def _gpu():
+    import tell_amd
+    tell_amd.hip.require_gpu()
+    yield
+    torch.cuda.synchronize()
+
+
+def tol(dtype):
+    return dict(rtol=2e-4, atol=2e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+
+
+def close(a, b, dtype=torch.float32, scale=1.0, **kw):
+    t = tol(dtype)
+    t['atol'] *= scale
+    t.update(kw)
+    torch.testing.assert_close(a.detach().float().cpu(), b.detach().float().cpu(), **t)
+
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('M,N,K', [(64, 64, 64), (130, 70, 96), (512, 1024, 1024), (37, 5002, 128),
+                                   (1000, 48, 1024), (300, 300, 2048), (2048, 2048, 512)])
+def test_gemm_nt(dtype, M, N, K):
+    from tell_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g)       # asymmetric operands -> detects transposed outputs
+    bias = torch.randn(N, generator=g)
+    ad, bd = a.to(DEV, dtype), b.to(DEV, dtype)
+    ref = (ad.float().cpu() @ bd.float().cpu().t())
+    out = ops.gemm(ad, bd, out_dtype=torch.float32)
+    close(out, ref, dtype, scale=math.sqrt(K))
+    out2 = ops.gemm(ad, bd, bias=bias.to(DEV), bias_mode=1, act=1, alpha=0.5)
+    close(out2, torch.relu((ref + bias) * 0.5), dtype, scale=math.sqrt(K))
+    out3 = ops.gemm(ad, bd, out_dtype=torch.float32, bias=torch.arange(M, dtype=torch.float32, device=DEV),
+                    bias_mode=2, act=2)
+    close(out3, torch.nn.functional.gelu(ref + torch.arange(M, dtype=torch.float32)[:, None]), dtype,
+          scale=math.sqrt(K))
+    acc = torch.ones(M, N, device=DEV)
+    ops.gemm(ad, bd, out=acc, accumulate=True)
+    close(acc, ref + 1, dtype, scale=math.sqrt(K))
+    mdev = torch.tensor([M // 2], dtype=torch.int32, device=DEV)
+    part = torch.full((M, N), 7.0, device=DEV)
+    ops.gemm(ad, bd, out=part, m_dev=mdev)
+    close(part[:M // 2], ref[:M // 2], dtype, scale=math.sqrt(K))
+    assert (part[M // 2:] == 7).all()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_transpose_and_weight_norm(dtype):
+    from tell_amd import ops
+    x = torch.randn(70, 130)
+    xt, plain = ops.transpose(x.to(DEV), out_dtype=dtype, want_plain=True)
+    close(xt[:, :70], x.t(), dtype)
+    close(plain, x, dtype)
+    assert (xt[:, 70:] == 0).all()
+    from oracle import functional as OF
+    g = torch.rand(40, 1) + 0.5
+    v = torch.randn(40, 24)
+    gp = torch.nn.Parameter(g.to(DEV))
+    vp = torch.nn.Parameter(v.to(DEV))
+    import tell_amd
+    tell_amd.set_compute_dtype(dtype)
+    w, wt, norms = ops.wn_weight(gp, vp)
+    close(w, OF.weight_norm_weight(g, v), dtype)
+    close(wt[:, :40], OF.weight_norm_weight(g, v).t(), dtype)
+    close(norms, v.norm(dim=1))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_gehring_linear_golden(golden, dtype):
+    import tell_amd
+    from tell_amd import ops
+    tell_amd.set_compute_dtype(dtype)
+    fx = golden('gehring_linear')
+    g = torch.nn.Parameter(fx['sd']['weight_g'].to(DEV))
+    v = torch.nn.Parameter(fx['sd']['weight_v'].to(DEV))
+    b = torch.nn.Parameter(fx['sd']['bias'].to(DEV))
+    x = fx['in']['x'].to(DEV, dtype).requires_grad_(True)
+    y = ops.wn_linear(x, g, v, b)
+    y.backward(fx['in']['gy'].to(DEV, dtype))
+    close(y, fx['out']['y'], dtype)
+    close(x.grad, fx['out']['gx'], dtype)
+    close(g.grad, fx['out']['g_weight_g'], dtype, scale=4)
+    close(v.grad, fx['out']['g_weight_v'], dtype, scale=4)
+    close(b.grad, fx['out']['g_bias'], dtype, scale=4)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_glu_dropout_layernorm(dtype):
+    import tell_amd
+    from tell_amd import ops, rng
+    tell_amd.manual_seed(123)
+    h = torch.randn(6, 5, 64)
+    hd = h.to(DEV, dtype).requires_grad_(True)
+    y = ops.glu(hd)
+    hc = hd.detach().float().cpu().requires_grad_(True)
+    yr = torch.nn.functional.glu(hc, dim=-1)
+    gy = torch.randn_like(yr)
+    y.backward(gy.to(DEV, dtype))
+    yr.backward(gy)
+    close(y, yr, dtype)
+    close(hd.grad, hc.grad, dtype)
+    # dropout mask == numpy restatement of the device hash
+    x = torch.ones(1000, device=DEV, dtype=dtype)
+    yd = ops.dropout(x, 0.3, True, salt=77)
+    mask = rng.keep_mask(123, 77, 1000, 0.3)
+    close(yd, torch.from_numpy(mask) / 0.7, dtype)
+    assert 0.6 < mask.mean() < 0.8
+    # y = LN(res + dropout(x))
+    C = 64
+    xx, rr = torch.randn(10, 3, C), torch.randn(10, 3, C)
+    gam = torch.nn.Parameter((torch.rand(C) + 0.5).to(DEV))
+    bet = torch.nn.Parameter(torch.randn(C).to(DEV))
+    for p in (0.0, 0.25):
+        gam.grad = bet.grad = None
+        xd = xx.to(DEV, dtype).requires_grad_(True)
+        rd = rr.to(DEV, dtype).requires_grad_(True)
+        tell_amd.manual_seed(5, salt=10)
+        out = ops.layer_norm(xd, rd, gam, bet, 1e-5, p, training=True)
+        keep = torch.from_numpy(rng.keep_mask(5, 11, 30 * C, p)).view(10, 3, C) / (1 - p) if p > 0 else 1.0
+        xc = xd.detach().float().cpu().requires_grad_(True)
+        rc = rd.detach().float().cpu().requires_grad_(True)
+        gc = gam.detach().cpu().requires_grad_(True)
+        bc = bet.detach().cpu().requires_grad_(True)
+        ref = torch.nn.functional.layer_norm(rc + xc * keep, (C,), gc, bc, 1e-5)
+        go = torch.randn_like(ref)
+        out.backward(go.to(DEV, dtype))
+        ref.backward(go)
+        close(out, ref, dtype)
+        close(xd.grad, xc.grad, dtype)
+        close(rd.grad, rc.grad, dtype)
+        close(gam.grad, gc.grad, dtype, scale=8)
+        close(bet.grad, bc.grad, dtype, scale=8)
+
+
+# ------------------------------------------------------------------ DynamicConv
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('K,T', [(3, 6), (7, 4), (31, 12), (15, 40)])
+def test_dynamic_conv_golden(golden, dtype, K, T):
+    """kernel vs what the REFERENCE produced (fixtures), incl. K > T."""
+    import tell_amd
+    from tell_amd import ops
+    tell_amd.set_compute_dtype(dtype)
+    fx = golden('dynconv_K%d_T%d' % (K, T))
+    w = torch.nn.Parameter(fx['sd']['weight_linear.weight'].to(DEV))
+    x = fx['in']['x'].to(DEV, dtype).requires_grad_(True)
+    logits = ops.linear(x, w)
+    y = ops.dynamic_conv(x, logits, 4, K)
+    y.backward(fx['in']['gy'].to(DEV, dtype))
+    close(y, fx['out']['y'], dtype)
+    close(x.grad, fx['out']['gx'], dtype, scale=4)
+    close(w.grad, fx['out']['g_weight'], dtype, scale=8)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_dynamic_conv_full_size_dropconnect(dtype):
+    """decoder shapes (T=32,B=16,C=1024,H=16,K=31) with DropConnect, vs the oracle with the same mask."""
+    import tell_amd
+    from tell_amd import ops, rng
+    from oracle import functional as OF
+    T, B, C, H, K, p = 32, 16, 1024, 16, 31, 0.1
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(T, B, C, generator=g)
+    lg = torch.randn(T, B, H * K, generator=g)
+    xd = x.to(DEV, dtype).requires_grad_(True)
+    ld = lg.to(DEV, dtype).requires_grad_(True)
+    tell_amd.manual_seed(9, salt=100)
+    y = ops.dynamic_conv(xd, ld, H, K, p, training=True)
+    mask = torch.from_numpy(rng.keep_mask(9, 101, T * B * H * K, p)).view(T, B, H, K)
+    xc = xd.detach().float().cpu().requires_grad_(True)
+    lc = ld.detach().float().cpu().requires_grad_(True)
+    ref = OF.dynamic_conv_apply(xc, OF.dynamic_conv_taps(lc, H, K, mask, p))
+    gy = torch.randn(T, B, C, generator=g)
+    y.backward(gy.to(DEV, dtype))
+    ref.backward(gy)
+    close(y, ref, dtype)
+    close(xd.grad, xc.grad, dtype, scale=2)
+    close(ld.grad, lc.grad, dtype, scale=2)
+
+
+# ------------------------------------------------------------------ attention
+def _attn_case(dtype, T, B, E, H, S, kdim, use_mask, p, seed, has_bias=True):
+    import tell_amd
+    from tell_amd import ops, rng
+    from oracle import functional as OF
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(T, B, E, generator=g) * 0.5
+    k = torch.randn(S, B, E, generator=g)
+    v = torch.randn(S, B, E, generator=g)
+    bias_k = torch.randn(1, 1, E, generator=g)
+    bias_v = torch.randn(1, 1, E, generator=g)
+    mask = None
+    if use_mask:
+        mask = torch.rand(B, S, generator=g) < 0.3
+    qd = q.to(DEV, dtype).requires_grad_(True)
+    kd = k.to(DEV, dtype).requires_grad_(True)
+    vd = v.to(DEV, dtype).requires_grad_(True)
+    bk = torch.nn.Parameter(bias_k.to(DEV))
+    bv = torch.nn.Parameter(bias_v.to(DEV))
+    tell_amd.manual_seed(21, salt=40)
+    md = mask.to(DEV).to(torch.uint8).contiguous() if mask is not None else None
+    out = ops.attention(qd, kd, vd, md, bk if has_bias else None, bv if has_bias else None, H, True, p, training=True)
+    # ---- reference: same math in fp32 on CPU, using the kernel's dropout mask
+    qc = qd.detach().float().cpu().requires_grad_(True)
+    kc = kd.detach().float().cpu().requires_grad_(True)
+    vc = vd.detach().float().cpu().requires_grad_(True)
+    bkc = bias_k.to(dtype).float().requires_grad_(True)
+    bvc = bias_v.to(dtype).float().requires_grad_(True)
+    hd = E // H
+    S1 = S + (1 if has_bias else 0) + 1
+    kk = torch.cat([kc] + ([bkc.expand(1, B, E)] if has_bias else []) + [torch.zeros(1, B, E)], 0)
+    vv = torch.cat([vc] + ([bvc.expand(1, B, E)] if has_bias else []) + [torch.zeros(1, B, E)], 0)
+    qh = qc.reshape(T, B * H, hd).transpose(0, 1)
+    kh = kk.reshape(S1, B * H, hd).transpose(0, 1)
+    vh = vv.reshape(S1, B * H, hd).transpose(0, 1)
+    sc = torch.bmm(qh, kh.transpose(1, 2))
+    if mask is not None:
+        full = torch.cat([mask, torch.zeros(B, S1 - S, dtype=torch.bool)], 1)
+        sc = sc.view(B, H, T, S1).masked_fill(full[:, None, None, :], float('-inf')).view(B * H, T, S1)
+    pr = torch.softmax(sc, -1)
+    if p > 0:
+        keep = torch.from_numpy(rng.keep_mask(21, 41, B * H * T * S1, p)).view(B * H, T, S1) / (1 - p)
+        pr = pr * keep
+    ref = torch.bmm(pr, vh).transpose(0, 1).reshape(T, B, E)
+    go = torch.randn(T, B, E, generator=g)
+    out.backward(go.to(DEV, dtype))
+    ref.backward(go)
+    close(out, ref, dtype)
+    close(qd.grad, qc.grad, dtype, scale=2)
+    close(kd.grad, kc.grad, dtype, scale=2)
+    close(vd.grad, vc.grad, dtype, scale=2)
+    if has_bias:
+        close(bk.grad, bkc.grad, dtype, scale=4)
+        close(bv.grad, bvc.grad, dtype, scale=4)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('T,B,E,H,S,mask,p', [
+    (3, 2, 64, 4, 6, True, 0.0),        # reduced dims (head_dim 16), like the fixtures
+    (9, 2, 64, 4, 40, True, 0.2),
+    (32, 4, 1024, 16, 49, False, 0.0),  # image context
+    (32, 3, 1024, 16, 512, True, 0.1),  # article context, padding + dropout
+    (32, 2, 1024, 16, 4, True, 0.0),    # faces
+    (33, 2, 1024, 16, 64, True, 0.0),   # T not a multiple of 32 -> 2 query blocks
+    (1, 5, 1024, 16, 100, True, 0.0),   # generation step
+    (70, 2, 1024, 16, 130, True, 0.1),
+])
+def test_attention_core(dtype, T, B, E, H, S, mask, p):
+    _attn_case(dtype, T, B, E, H, S, E, mask, p, seed=T * 131 + S)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_attention_self_no_extra_rows(dtype):
+    """RoBERTa-style self attention: no bias row, no zero row, T = S = 128, padded keys."""
+    import tell_amd
+    from tell_amd import ops
+    T = S = 128
+    B, E, H = 2, 1024, 16
+    g = torch.Generator().manual_seed(8)
+    qkv = torch.randn(T, B, 3 * E, generator=g).to(DEV, dtype)
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    mask[1, 100:] = True
+    q, k, v = qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:]
+    out = ops.attention(q, k, v, mask.to(DEV).to(torch.uint8), None, None, H, has_zero=False)
+    hd = E // H
+    qc, kc, vc = [t.float().cpu().reshape(T, B * H, hd).transpose(0, 1) for t in (q, k, v)]
+    sc = torch.bmm(qc, kc.transpose(1, 2)).view(B, H, T, S).masked_fill(mask[:, None, None, :], float('-inf'))
+    ref = torch.bmm(torch.softmax(sc, -1).view(B * H, T, S), vc).transpose(0, 1).reshape(T, B, E)
+    close(out, ref, dtype)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('tag', ['sep', 'same', 'nomask', 'empty'])
+def test_mha_module_golden(golden, dtype, tag):
+    import tell_amd
+    from tell_amd.modules import MultiHeadAttention
+    tell_amd.set_compute_dtype(dtype)
+    fx = golden('mha_' + tag)
+    kdim = int(fx['in']['kdim'])
+    m = MultiHeadAttention(64, 4, kdim=kdim if kdim else 16, vdim=kdim if kdim else 16, dropout=0.1).eval()
+    m.load_state_dict(fx['sd'])
+    m.to(DEV)
+    q = fx['in']['q'].to(DEV, dtype).requires_grad_(True)
+    key = fx['in']['key'].to(DEV, dtype)
+    mask = fx['in'].get('mask')
+    y, w = m(q, key, key, key_padding_mask=mask.to(DEV) if mask is not None else None, need_weights=True)
+    y.backward(fx['in']['gy'].to(DEV, dtype))
+    close(y, fx['out']['y'], dtype)
+    close(w, fx['out']['w'], dtype)
+    close(q.grad, fx['out']['gq'], dtype, scale=2)
+    import seeded
+    for name, p in m.named_parameters():
+        key_ = 'g_' + name
+        if key_ in fx['out']:
+            close(p.grad, fx['out'][key_], dtype, scale=8)
+        elif key_ in fx.get('sub', {}):
+            close(torch.from_numpy(seeded.subsample(p.grad.float().cpu().numpy())), fx['sub'][key_], dtype, scale=8)
+
+
+# ------------------------------------------------------------------ embedder / adaptive softmax
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_embedder_golden(golden, dtype):
+    import tell_amd
+    from tell_amd.build import build_embedder
+    tell_amd.set_compute_dtype(dtype)
+    fx = golden('embedder')
+    emb = build_embedder(600, 32, (100, 300), init_size=8)
+    emb.load_state_dict(fx['sd'], strict=False)
+    emb.to(DEV)
+    ids = fx['in']['ids'].to(DEV)
+    y = emb({'roberta': ids})
+    y.backward(fx['in']['gy'].to(DEV, dtype))
+    close(y, fx['out']['y'], dtype, scale=4)
+    for name, p in emb.named_parameters():
+        close(p.grad, fx['out']['g_' + name], dtype, scale=16)
+    st = {}
+    inc = torch.cat([emb({'roberta': ids[:, t:t + 1]}, incremental_state=st) for t in range(ids.shape[1])], 1)
+    close(inc, fx['out']['y_incremental'], dtype, scale=4)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_adaptive_softmax_golden(golden, dtype):
+    import tell_amd
+    from tell_amd.build import build_embedder
+    from tell_amd.modules import AdaptiveLoss, AdaptiveSoftmax
+    tell_amd.set_compute_dtype(dtype)
+    fx = golden('adaptive_softmax')
+    emb = build_embedder(600, 32, (100, 300))
+    asm = AdaptiveSoftmax(600, 32, [100, 300], emb.token_embedder_adaptive)
+    asm.load_state_dict(fx['sd'], strict=False)
+    asm.to(DEV)
+    crit = AdaptiveLoss(1)
+    x = fx['in']['x'].to(DEV, dtype).requires_grad_(True)
+    loss, n = crit(asm, (x, None), fx['in']['target'].to(DEV))
+    loss.backward()
+    assert int(n) == fx['out']['sample_size']
+    close(loss.reshape(1), fx['out']['loss'], dtype, rtol=1e-3 if dtype == torch.float32 else 2e-2)
+    close(x.grad, fx['out']['gx'], dtype)
+    import seeded
+    for name, p in asm.named_parameters():
+        if p.grad is None:
+            continue
+        k = 'g_' + name
+        if k in fx['out']:
+            close(p.grad, fx['out'][k], dtype, scale=8)
+        elif k in fx.get('sub', {}):
+            close(torch.from_numpy(seeded.subsample(p.grad.float().cpu().numpy())), fx['sub'][k], dtype, scale=8)
+    loss2, n2 = crit(asm, (x.detach(), None), fx['in']['target2'].to(DEV))     # a band with no rows
+    assert int(n2) == fx['out']['sample_size2']
+    close(loss2.reshape(1), fx['out']['loss2'], dtype, rtol=1e-3 if dtype == torch.float32 else 2e-2)
+    lp = asm.get_log_prob(x.detach())
+    close(lp, fx['out']['log_probs'], dtype, scale=4)
+    tok, tlp = asm.greedy(x.detach())
+    ref = fx['out']['log_probs'].view(-1, 600)
+    if dtype == torch.float32:
+        assert torch.equal(tok.cpu().long().view(-1), ref.argmax(dim=1))
+    close(tlp.view(-1), ref.max(dim=1).values, dtype, scale=4)

@@ -1,0 +1,19 @@
+// Error reporting + misc entry points of libtell_hip.so.
+#include "common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+extern "C" void tell_set_error(const char* msg) {
+  strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);
+  g_err[sizeof(g_err) - 1] = 0;
+}
+extern "C" const char* tell_last_error(void) { return g_err; }
+extern "C" int tell_abi_version(void) { return 1; }
+
+// number of visible HIP devices (0 on a CPU-only box); never throws
+extern "C" int tell_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}

@@ -1,0 +1,545 @@
+// Multi-head cross/self attention on the CDNA4 matrix cores
+// (tell/modules/attention/multi_head.py:288-486; also RoBERTa self-attention).
+//
+//   scores = q.k^T (q pre-scaled by the projection GEMM), key-padding mask -> -inf,
+//   the learned bias_k/bias_v row and the all-zero row (add_bias_kv / add_zero_attn,
+//   :355-374, :416-427) are *virtual* keys S and S+1 synthesised while staging a
+//   tile - K/V are never concatenated or copied; fp32 online softmax (:460-462);
+//   dropout on the probabilities (:463); out = P.V.
+//
+// Every contraction runs through one primitive, mma32: a 32x32 output tile from
+// two LDS tiles stored [row][k] with k contiguous (bf16: v_mfma_f32_32x32x16_bf16
+// fed by ds_read_b128; f32: v_mfma_f32_32x32x2_f32 fed by ds_read_b32).  Tiles are
+// staged so that the contraction index is contiguous (V and K^T/Q^T/dO^T tiles
+// are transposed on the way into LDS).  Scores are produced TRANSPOSED
+// (S^T[key][q] = K.Q^T) so that each lane owns one query column: the softmax
+// row-reduction is 16 in-register values + one cross-half wavefront shuffle.
+#include "common.h"
+
+template <typename T, int D> struct ACfg {
+  static constexpr int VEC = Elem<T>::VEC;
+  static constexpr int PAD = sizeof(T) == 2 ? 8 : 1;
+  static constexpr int DS = D + PAD;          // stride of [32 rows][D] tiles
+  static constexpr int SS = 32 + PAD;         // stride of [rows][32] tiles
+  static constexpr int DP = D < 32 ? 32 : D;  // rows of [d][32] tiles (zero padded)
+  static constexpr int DF = DP / 32;
+};
+
+template <typename T, int KD>
+__device__ __forceinline__ f32x16 mma32(f32x16 acc, const T* a, int as, const T* b, int bs, int lane) {
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int ks = 0; ks < KD; ks += 16) {
+      bf16x8 av = *reinterpret_cast<const bf16x8*>(a + (lane & 31) * as + ks + ((lane >> 5) << 3));
+      bf16x8 bv = *reinterpret_cast<const bf16x8*>(b + (lane & 31) * bs + ks + ((lane >> 5) << 3));
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < KD; ks += 2) {
+      float av = a[(lane & 31) * as + ks + (lane >> 5)];
+      float bv = b[(lane & 31) * bs + ks + (lane >> 5)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+  }
+  return acc;
+}
+// row index (A-tile row) held in accumulator register r of this lane
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// Stage 32 rows x D of a row-major source into tile[row][D] and/or tileT[d][row].
+// rowptr(row) returns the row's base pointer or nullptr (-> zeros).
+template <typename T, int D, typename RowPtr>
+__device__ __forceinline__ void stage32(T* tile, int stride, T* tileT, int strideT, int tid, int nthr,
+                                        RowPtr rowptr) {
+  constexpr int VEC = Elem<T>::VEC, CPR = D / VEC;
+  for (int c = tid; c < 32 * CPR; c += nthr) {
+    const int row = c / CPR, ch = c % CPR;
+    const T* p = rowptr(row);
+    uint4 v = p ? *reinterpret_cast<const uint4*>(p + ch * VEC) : make_uint4(0, 0, 0, 0);
+    if (tile) {
+      if constexpr (sizeof(T) == 2) {
+        *reinterpret_cast<uint4*>(tile + row * stride + ch * VEC) = v;
+      } else {
+        float* q = reinterpret_cast<float*>(tile) + row * stride + ch * VEC;
+        q[0] = __uint_as_float(v.x); q[1] = __uint_as_float(v.y);
+        q[2] = __uint_as_float(v.z); q[3] = __uint_as_float(v.w);
+      }
+    }
+    if (tileT) {
+      const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) tileT[(ch * VEC + k) * strideT + row] = e[k];
+    }
+  }
+}
+template <typename T>
+__device__ __forceinline__ void zero_lds(T* p, int n, int tid, int nthr) {
+  for (int i = tid; i < n; i += nthr) p[i] = (T)0;
+}
+
+struct AttnArgs {
+  const void *q, *k, *v;          // element (b,h,t,d) at q + t*q_st + b*q_sb + h*D + d, etc.
+  void* out;
+  float* lse;                     // [B*H, Tq]
+  const uint8_t* mask;            // [B, S] key padding (1 = masked) or null
+  const void *bias_k, *bias_v;    // [H*D] in the compute dtype, or null
+  long q_st, q_sb, k_ss, k_sb, v_ss, v_sb, o_st, o_sb;
+  int B, H, Tq, S;
+  int has_bias, has_zero;
+  uint32_t thr; float inv_keep; uint32_t seed, salt;
+  // backward only
+  const void *dout, *o;           // same layout as out
+  void *dq, *dk, *dv;             // same layouts as q, k, v
+  float *dbias_k, *dbias_v;       // [B, H*D] fp32 partials (summed over b by the caller)
+};
+
+// ------------------------------------------------------------------ forward
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
+  using C_ = ACfg<T, D>;
+  constexpr int DS = C_::DS, SS = C_::SS, DP = C_::DP, DF = C_::DF;
+  constexpr int WAVE_ELEMS = 2 * 32 * DS + DP * SS + 32 * SS;   // Qs, Ks, Vt, Ps
+  static_assert(WAVE_ELEMS * sizeof(T) >= (2 + 16 * DF) * 64 * sizeof(float), "combine buffer must fit");
+  __shared__ __attribute__((aligned(16))) T smem[NW * WAVE_ELEMS];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+  const int QB = (p.Tq + 31) / 32;
+  const int KSPLIT = (QB == 1) ? NW : 1;         // decoder / generation: waves split the keys
+  const int qb = (QB == 1) ? 0 : blockIdx.x * NW + wave;
+  const int ks = (QB == 1) ? wave : 0;
+  const bool active = qb < QB;
+  const int q0 = qb * 32;
+  const int S_total = p.S + p.has_bias + p.has_zero;
+  const int nkt = (S_total + 31) / 32;
+  const int iters = (nkt + KSPLIT - 1) / KSPLIT;
+
+  T* Qs = smem + wave * WAVE_ELEMS;
+  T* Ks = Qs + 32 * DS;
+  T* Vt = Ks + 32 * DS;
+  T* Ps = Vt + DP * SS;
+  const T* qg = static_cast<const T*>(p.q);
+  const T* kg = static_cast<const T*>(p.k);
+  const T* vg = static_cast<const T*>(p.v);
+  const T* bk = static_cast<const T*>(p.bias_k);
+  const T* bv = static_cast<const T*>(p.bias_v);
+
+  stage32<T, D>(Qs, DS, (T*)nullptr, 0, lane, 64, [&](int row) -> const T* {
+    int t = q0 + row;
+    return (active && t < p.Tq) ? qg + t * p.q_st + b * p.q_sb + (long)h * D : nullptr;
+  });
+  if (DP > D) zero_lds(Vt, DP * SS, lane, 64);   // rows d >= D stay zero
+
+  f32x16 o[DF];
+#pragma unroll
+  for (int f = 0; f < DF; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[f][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int qi = lane & 31;
+
+  for (int it = 0; it < iters; ++it) {
+    const int kt = it * KSPLIT + ks;
+    const bool tv = active && kt < nkt;
+    const int s0 = kt * 32;
+    __syncthreads();                              // previous tile fully consumed
+    if (tv) {
+      stage32<T, D>(Ks, DS, (T*)nullptr, 0, lane, 64, [&](int row) -> const T* {
+        int s = s0 + row;
+        if (s < p.S) return kg + s * p.k_ss + b * p.k_sb + (long)h * D;
+        if (s == p.S && p.has_bias) return bk + (long)h * D;
+        return nullptr;
+      });
+      stage32<T, D>((T*)nullptr, 0, Vt, SS, lane, 64, [&](int row) -> const T* {
+        int s = s0 + row;
+        if (s < p.S) return vg + s * p.v_ss + b * p.v_sb + (long)h * D;
+        if (s == p.S && p.has_bias) return bv + (long)h * D;
+        return nullptr;
+      });
+    }
+    __syncthreads();
+    float pr[16];
+    if (tv) {
+      f32x16 st;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = 0.f;
+      st = mma32<T, D>(st, Ks, DS, Qs, DS, lane);            // S^T[key][q]
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int s = s0 + acc_row(r, lane);
+        bool ok = s < S_total;
+        if (ok && s < p.S && p.mask) ok = p.mask[(long)b * p.S + s] == 0;
+        st[r] = ok ? st[r] : -INFINITY;
+        mx = fmaxf(mx, st[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+      float ls = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pr[r] = (st[r] == -INFINITY) ? 0.f : __expf(st[r] - m_new);
+        ls += pr[r];
+      }
+      ls += __shfl_xor(ls, 32, 64);
+      l_run = l_run * alpha + ls;
+      m_run = m_new;
+#pragma unroll
+      for (int f = 0; f < DF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[f][r] *= alpha;
+      const int t = q0 + qi;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kk = acc_row(r, lane);
+        float v = pr[r];
+        if (p.thr)
+          v *= tell_keep(p.seed, p.salt, ((uint64_t)bh * p.Tq + t) * S_total + (s0 + kk), p.thr, p.inv_keep);
+        Elem<T>::st(Ps + qi * SS + kk, v);                    // P[q][key], key contiguous
+      }
+    }
+    __syncthreads();
+    if (tv) {
+#pragma unroll
+      for (int f = 0; f < DF; ++f) o[f] = mma32<T, 32>(o[f], Vt + f * 32 * SS, SS, Ps, SS, lane);  // O^T[d][q]
+    }
+  }
+  __syncthreads();
+
+  // ---- combine the key splits (only when QB == 1) and write out
+  float* comb = reinterpret_cast<float*>(smem + wave * WAVE_ELEMS);
+  if (KSPLIT > 1) {
+    comb[0 * 64 + lane] = m_run;
+    comb[1 * 64 + lane] = l_run;
+#pragma unroll
+    for (int f = 0; f < DF; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) comb[(2 + f * 16 + r) * 64 + lane] = o[f][r];
+  }
+  __syncthreads();
+  if (KSPLIT > 1) {
+    if (wave != 0) return;
+    float mm = m_run;
+    for (int w = 1; w < NW; ++w) {
+      const float* cw = reinterpret_cast<const float*>(smem + w * WAVE_ELEMS);
+      mm = fmaxf(mm, cw[lane]);
+    }
+    float ltot = 0.f;
+    f32x16 acc[DF];
+#pragma unroll
+    for (int f = 0; f < DF; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+    for (int w = 0; w < NW; ++w) {
+      const float* cw = reinterpret_cast<const float*>(smem + w * WAVE_ELEMS);
+      const float mw = cw[lane];
+      const float sc = (mw == -INFINITY) ? 0.f : __expf(mw - mm);
+      ltot += cw[64 + lane] * sc;
+#pragma unroll
+      for (int f = 0; f < DF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] += cw[(2 + f * 16 + r) * 64 + lane] * sc;
+    }
+    m_run = mm; l_run = ltot;
+#pragma unroll
+    for (int f = 0; f < DF; ++f) o[f] = acc[f];
+  }
+  if (!active) return;
+  const int t = q0 + qi;
+  if (t >= p.Tq) return;
+  const float inv_l = l_run > 0.f ? 1.f / l_run : 0.f;
+  T* og = static_cast<T*>(p.out) + t * p.o_st + b * p.o_sb + (long)h * D;
+#pragma unroll
+  for (int f = 0; f < DF; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int d = f * 32 + acc_row(r, lane);
+      if (d < D) Elem<T>::st(og + d, o[f][r] * inv_l);
+    }
+  if (lane < 32 && p.lse) p.lse[(long)bh * p.Tq + t] = l_run > 0.f ? m_run + __logf(l_run) : INFINITY;
+}
+
+// ------------------------------------------------------------------ backward
+// One workgroup per (b,h); its NW waves split the key tiles.  Query blocks of 32 are
+// the outer loop (Q-side tiles shared by the waves); dQ is reduced across waves in LDS;
+// each key tile is owned by exactly one wave, so dK/dV need no atomics.
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(AttnArgs p) {
+  using C_ = ACfg<T, D>;
+  constexpr int DS = C_::DS, SS = C_::SS, DP = C_::DP, DF = C_::DF;
+  constexpr int SHARED_ELEMS = 2 * 32 * DS + 2 * DP * SS;       // Qs, dOs, Qt, dOt
+  constexpr int WAVE_ELEMS = 2 * 32 * DS + DP * SS + 3 * 32 * SS;  // Ks, Vs, Kt, PdT, dST, dS
+  static_assert(WAVE_ELEMS * sizeof(T) >= 16 * DF * 64 * sizeof(float), "dQ combine buffer must fit");
+  __shared__ __attribute__((aligned(16))) T smem[SHARED_ELEMS + NW * WAVE_ELEMS];
+  __shared__ float lse_s[32], delta_s[32];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
+  const int QB = (p.Tq + 31) / 32;
+  const int S_total = p.S + p.has_bias + p.has_zero;
+  const int nkt = (S_total + 31) / 32;
+  const int iters = (nkt + NW - 1) / NW;
+  const int qi = lane & 31;
+
+  T* Qs = smem;
+  T* dOs = Qs + 32 * DS;
+  T* Qt = dOs + 32 * DS;
+  T* dOt = Qt + DP * SS;
+  T* Ks = smem + SHARED_ELEMS + wave * WAVE_ELEMS;
+  T* Vs = Ks + 32 * DS;
+  T* Kt = Vs + 32 * DS;
+  T* PdT = Kt + DP * SS;
+  T* dST = PdT + 32 * SS;
+  T* dSs = dST + 32 * SS;
+  const T* qg = static_cast<const T*>(p.q);
+  const T* kg = static_cast<const T*>(p.k);
+  const T* vg = static_cast<const T*>(p.v);
+  const T* og = static_cast<const T*>(p.o);
+  const T* dog = static_cast<const T*>(p.dout);
+  const T* bk = static_cast<const T*>(p.bias_k);
+  const T* bv = static_cast<const T*>(p.bias_v);
+
+  if (DP > D) {
+    zero_lds(Qt, 2 * DP * SS, tid, 64 * NW);
+    zero_lds(Kt, DP * SS, lane, 64);
+  }
+
+  for (int qb = 0; qb < QB; ++qb) {
+    const int q0 = qb * 32;
+    __syncthreads();                              // all waves done with the previous q block
+    auto qrow = [&](const T* base, long st, long sb) {
+      return [=](int row) -> const T* {
+        int t = q0 + row;
+        return t < p.Tq ? base + t * st + b * sb + (long)h * D : nullptr;
+      };
+    };
+    stage32<T, D>(Qs, DS, Qt, SS, tid, 64 * NW, qrow(qg, p.q_st, p.q_sb));
+    stage32<T, D>(dOs, DS, dOt, SS, tid, 64 * NW, qrow(dog, p.o_st, p.o_sb));
+    for (int row = wave; row < 32; row += NW) {   // delta[q] = <dO[q], O[q]>
+      const int t = q0 + row;
+      float s = 0.f;
+      if (t < p.Tq)
+        for (int d = lane; d < D; d += 64)
+          s += Elem<T>::ld(dog + t * p.o_st + b * p.o_sb + (long)h * D + d) *
+               Elem<T>::ld(og + t * p.o_st + b * p.o_sb + (long)h * D + d);
+      s = wave_sum(s);
+      if (lane == 0) {
+        delta_s[row] = s;
+        lse_s[row] = t < p.Tq ? p.lse[(long)bh * p.Tq + t] : INFINITY;
+      }
+    }
+    f32x16 dq[DF];
+#pragma unroll
+    for (int f = 0; f < DF; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[f][r] = 0.f;
+
+    for (int it = 0; it < iters; ++it) {
+      const int kt = it * NW + wave;
+      const bool tv = kt < nkt;
+      const int s0 = kt * 32;
+      __syncthreads();
+      if (tv) {
+        stage32<T, D>(Ks, DS, Kt, SS, lane, 64, [&](int row) -> const T* {
+          int s = s0 + row;
+          if (s < p.S) return kg + s * p.k_ss + b * p.k_sb + (long)h * D;
+          if (s == p.S && p.has_bias) return bk + (long)h * D;
+          return nullptr;
+        });
+        stage32<T, D>(Vs, DS, (T*)nullptr, 0, lane, 64, [&](int row) -> const T* {
+          int s = s0 + row;
+          if (s < p.S) return vg + s * p.v_ss + b * p.v_sb + (long)h * D;
+          if (s == p.S && p.has_bias) return bv + (long)h * D;
+          return nullptr;
+        });
+      }
+      __syncthreads();
+      if (tv) {
+        f32x16 st, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+        st = mma32<T, D>(st, Ks, DS, Qs, DS, lane);           // S^T[key][q]
+        dp = mma32<T, D>(dp, Vs, DS, dOs, DS, lane);          // dPd^T[key][q] = V.dO^T
+        const float lse = lse_s[qi], delta = delta_s[qi];
+        const int t = q0 + qi;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kk = acc_row(r, lane), s = s0 + kk;
+          bool ok = s < S_total && t < p.Tq;
+          if (ok && s < p.S && p.mask) ok = p.mask[(long)b * p.S + s] == 0;
+          const float pv = ok ? __expf(st[r] - lse) : 0.f;
+          float keep = 1.f;
+          if (p.thr)
+            keep = tell_keep(p.seed, p.salt, ((uint64_t)bh * p.Tq + t) * S_total + s, p.thr, p.inv_keep);
+          const float ds = pv * (dp[r] * keep - delta);
+          Elem<T>::st(PdT + kk * SS + qi, pv * keep);         // Pd^T[key][q]
+          Elem<T>::st(dST + kk * SS + qi, ds);                // dS^T[key][q]
+          Elem<T>::st(dSs + qi * SS + kk, ds);                // dS[q][key]
+        }
+      }
+      __syncthreads();
+      if (tv) {
+#pragma unroll
+        for (int f = 0; f < DF; ++f) {
+          f32x16 dv, dk;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { dv[r] = 0.f; dk[r] = 0.f; }
+          dv = mma32<T, 32>(dv, PdT, SS, dOt + f * 32 * SS, SS, lane);   // dV[key][d]
+          dk = mma32<T, 32>(dk, dST, SS, Qt + f * 32 * SS, SS, lane);    // dK[key][d]
+          dq[f] = mma32<T, 32>(dq[f], dSs, SS, Kt + f * 32 * SS, SS, lane);  // dQ[q][d]
+          const int d = f * 32 + (lane & 31);
+          if (d < D) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int s = s0 + acc_row(r, lane);
+              if (s < p.S) {
+                T* pk = static_cast<T*>(p.dk) + s * p.k_ss + b * p.k_sb + (long)h * D + d;
+                T* pv_ = static_cast<T*>(p.dv) + s * p.v_ss + b * p.v_sb + (long)h * D + d;
+                if (qb == 0) { Elem<T>::st(pk, dk[r]); Elem<T>::st(pv_, dv[r]); }
+                else { Elem<T>::st(pk, Elem<T>::ld(pk) + dk[r]); Elem<T>::st(pv_, Elem<T>::ld(pv_) + dv[r]); }
+              } else if (s == p.S && p.has_bias) {
+                float* gk = p.dbias_k + (long)b * p.H * D + (long)h * D + d;
+                float* gv = p.dbias_v + (long)b * p.H * D + (long)h * D + d;
+                if (qb == 0) { *gk = dk[r]; *gv = dv[r]; }
+                else { *gk += dk[r]; *gv += dv[r]; }
+              }
+            }
+          }
+        }
+      }
+    }
+    // ---- reduce dQ over the waves and store
+    __syncthreads();
+    float* comb = reinterpret_cast<float*>(smem + SHARED_ELEMS + wave * WAVE_ELEMS);
+#pragma unroll
+    for (int f = 0; f < DF; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) comb[(f * 16 + r) * 64 + lane] = dq[f][r];
+    __syncthreads();
+    for (int item = wave; item < DF * 16; item += NW) {
+      float s = 0.f;
+      for (int w = 0; w < NW; ++w)
+        s += reinterpret_cast<const float*>(smem + SHARED_ELEMS + w * WAVE_ELEMS)[item * 64 + lane];
+      const int f = item / 16, r = item % 16;
+      const int t = q0 + acc_row(r, lane), d = f * 32 + (lane & 31);
+      if (t < p.Tq && d < D)
+        Elem<T>::st(static_cast<T*>(p.dq) + t * p.q_st + b * p.q_sb + (long)h * D + d, s);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ head-averaged weights (need_weights, eval only)
+// w[b,t,s] = (1/H) sum_h exp(q_h . k_h[s] - lse[b,h,t])   (multi_head.py:478-482)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_avg_weights_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                               const float* __restrict__ lse,
+                                                               const uint8_t* __restrict__ mask,
+                                                               const T* __restrict__ bias_k,
+                                                               float* __restrict__ w, int B, int H, int Tq,
+                                                               int S, int D, long q_st, long q_sb, long k_ss,
+                                                               long k_sb, int has_bias, int has_zero) {
+  const int t = blockIdx.x, b = blockIdx.y;
+  const int S_total = S + has_bias + has_zero;
+  for (int s = threadIdx.x; s < S_total; s += 256) {
+    float acc = 0.f;
+    const bool masked = s < S && mask && mask[(long)b * S + s];
+    if (!masked) {
+      for (int h = 0; h < H; ++h) {
+        const T* qp = q + t * q_st + b * q_sb + (long)h * D;
+        const T* kp = s < S ? k + s * k_ss + b * k_sb + (long)h * D
+                            : (s == S && has_bias ? bias_k + (long)h * D : nullptr);
+        float dot = 0.f;
+        if (kp) for (int d = 0; d < D; ++d) dot += Elem<T>::ld(qp + d) * Elem<T>::ld(kp + d);
+        acc += __expf(dot - lse[((long)b * H + h) * Tq + t]);
+      }
+    }
+    w[((long)b * Tq + t) * S_total + s] = acc / H;
+  }
+}
+extern "C" int tell_attn_avg_weights(const void* q, const void* k, const float* lse, const uint8_t* mask,
+                                     const void* bias_k, float* w, int B, int H, int Tq, int S, int D,
+                                     long q_st, long q_sb, long k_ss, long k_sb, int has_zero, int dtype,
+                                     hipStream_t stream) {
+  if (B * Tq <= 0) return TELL_OK;
+  dim3 grid(Tq, B);
+  if (dtype == TELL_BF16)
+    hipLaunchKernelGGL((attn_avg_weights_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)q, (const uint16_t*)k, lse, mask, (const uint16_t*)bias_k, w, B, H, Tq, S, D, q_st, q_sb, k_ss, k_sb, bias_k ? 1 : 0, has_zero);
+  else
+    hipLaunchKernelGGL((attn_avg_weights_kernel<float>), grid, dim3(256), 0, stream, (const float*)q, (const float*)k, lse, mask, (const float*)bias_k, w, B, H, Tq, S, D, q_st, q_sb, k_ss, k_sb, bias_k ? 1 : 0, has_zero);
+  return tell_check_launch("attn_avg_weights");
+}
+
+// ------------------------------------------------------------------ C ABI
+static int fill_args(AttnArgs& a, const void* q, const void* k, const void* v, void* out, float* lse,
+                     const uint8_t* mask, const void* bias_k, const void* bias_v, int B, int H, int Tq,
+                     int S, int D, long q_st, long q_sb, long k_ss, long k_sb, long v_ss, long v_sb,
+                     long o_st, long o_sb, int has_zero, float p, uint32_t seed, uint32_t salt, int dtype) {
+  TELL_REQUIRE(D == 64 || D == 16, "attention: head_dim must be 64 (or 16 for the reduced-size tests)");
+  TELL_REQUIRE(B > 0 && H > 0 && Tq > 0 && S >= 0, "attention: bad sizes");
+  TELL_REQUIRE((bias_k == nullptr) == (bias_v == nullptr), "attention: bias_k and bias_v go together");
+  TELL_REQUIRE(S + (bias_k ? 1 : 0) + has_zero > 0, "attention: no keys");
+  TELL_REQUIRE(p >= 0.f && p < 1.f, "attention: dropout p must be in [0,1)");
+  const int vec = dtype == TELL_BF16 ? 8 : 4;
+  TELL_REQUIRE(q_st % vec == 0 && q_sb % vec == 0 && k_ss % vec == 0 && k_sb % vec == 0 &&
+               v_ss % vec == 0 && v_sb % vec == 0, "attention: strides must be multiples of a 16-byte chunk");
+  TELL_REQUIRE(((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0,
+               "attention: q/k/v must be 16-byte aligned");
+  a.q = q; a.k = k; a.v = v; a.out = out; a.lse = lse; a.mask = mask; a.bias_k = bias_k; a.bias_v = bias_v;
+  a.q_st = q_st; a.q_sb = q_sb; a.k_ss = k_ss; a.k_sb = k_sb; a.v_ss = v_ss; a.v_sb = v_sb;
+  a.o_st = o_st; a.o_sb = o_sb; a.B = B; a.H = H; a.Tq = Tq; a.S = S;
+  a.has_bias = bias_k ? 1 : 0; a.has_zero = has_zero;
+  a.thr = p > 0.f ? tell_drop_threshold(p) : 0u; a.inv_keep = 1.f / (1.f - p); a.seed = seed; a.salt = salt;
+  a.dout = nullptr; a.o = nullptr; a.dq = a.dk = a.dv = nullptr; a.dbias_k = a.dbias_v = nullptr;
+  return TELL_OK;
+}
+
+extern "C" int tell_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
+                             const uint8_t* mask, const void* bias_k, const void* bias_v, int B, int H,
+                             int Tq, int S, int D, long q_st, long q_sb, long k_ss, long k_sb, long v_ss,
+                             long v_sb, long o_st, long o_sb, int has_zero, float p, uint32_t seed,
+                             uint32_t salt, int dtype, hipStream_t stream) {
+  AttnArgs a;
+  int rc = fill_args(a, q, k, v, out, lse, mask, bias_k, bias_v, B, H, Tq, S, D, q_st, q_sb, k_ss, k_sb,
+                     v_ss, v_sb, o_st, o_sb, has_zero, p, seed, salt, dtype);
+  if (rc) return rc;
+  const int QB = (Tq + 31) / 32;
+  if (dtype == TELL_BF16) {
+    constexpr int NW = 4;
+    dim3 grid(QB == 1 ? 1 : (QB + NW - 1) / NW, B * H);
+    if (D == 64) hipLaunchKernelGGL((attn_fwd_kernel<uint16_t, 64, NW>), grid, dim3(64 * NW), 0, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<uint16_t, 16, NW>), grid, dim3(64 * NW), 0, stream, a);
+  } else {
+    constexpr int NW = 4;
+    dim3 grid(QB == 1 ? 1 : (QB + NW - 1) / NW, B * H);
+    if (D == 64) hipLaunchKernelGGL((attn_fwd_kernel<float, 64, NW>), grid, dim3(64 * NW), 0, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<float, 16, NW>), grid, dim3(64 * NW), 0, stream, a);
+  }
+  return tell_check_launch("attn_fwd");
+}
+
+extern "C" int tell_attn_bwd(const void* q, const void* k, const void* v, const void* out,
+                             const void* dout, const float* lse, const uint8_t* mask, const void* bias_k,
+                             const void* bias_v, void* dq, void* dk, void* dv, float* dbias_k,
+                             float* dbias_v, int B, int H, int Tq, int S, int D, long q_st, long q_sb,
+                             long k_ss, long k_sb, long v_ss, long v_sb, long o_st, long o_sb,
+                             int has_zero, float p, uint32_t seed, uint32_t salt, int dtype,
+                             hipStream_t stream) {
+  AttnArgs a;
+  int rc = fill_args(a, q, k, v, const_cast<void*>(out), const_cast<float*>(lse), mask, bias_k, bias_v, B,
+                     H, Tq, S, D, q_st, q_sb, k_ss, k_sb, v_ss, v_sb, o_st, o_sb, has_zero, p, seed, salt,
+                     dtype);
+  if (rc) return rc;
+  TELL_REQUIRE(!bias_k || (dbias_k && dbias_v), "attention bwd: dbias buffers required with bias rows");
+  a.dout = dout; a.o = out; a.dq = dq; a.dk = dk; a.dv = dv; a.dbias_k = dbias_k; a.dbias_v = dbias_v;
+  dim3 grid(B * H);
+  if (dtype == TELL_BF16) {
+    if (D == 64) hipLaunchKernelGGL((attn_bwd_kernel<uint16_t, 64, 4>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((attn_bwd_kernel<uint16_t, 16, 4>), grid, dim3(256), 0, stream, a);
+  } else {
+    if (D == 64) hipLaunchKernelGGL((attn_bwd_kernel<float, 64, 2>), grid, dim3(128), 0, stream, a);
+    else hipLaunchKernelGGL((attn_bwd_kernel<float, 16, 2>), grid, dim3(128), 0, stream, a);
+  }
+  return tell_check_launch("attn_bwd");
+}

@@ -1,0 +1,195 @@
+// ResNet-152 trunk helpers (tell/models/resnet.py:92-108), NHWC activations so that
+// every convolution is an NT GEMM on the matrix cores: 1x1/s1 convs read the
+// activation matrix [B*H*W, Cin] directly; 3x3, 7x7 and strided 1x1 convs go
+// through im2col rows [B*OH*OW, KH*KW*Cin] (K padded to a 16-byte multiple) against
+// weights stored [Cout, KH, KW, Cin].  BatchNorm runs with BATCH statistics in
+// training (callback_apex_trainer.py:259 puts the frozen trunk in train mode).
+#include "common.h"
+
+template <typename S, typename D>
+__global__ void nchw_to_nhwc_kernel(const S* __restrict__ x, D* __restrict__ y, int B, int C, int H, int W) {
+  const long n = (long)B * C * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int b = (int)(r / H);
+    Elem<D>::st(y + i, Elem<S>::ld(x + (((long)b * C + c) * H + h) * W + w));
+  }
+}
+extern "C" int tell_nchw_to_nhwc(const float* x, void* y, int B, int C, int H, int W, int out_dtype,
+                                 hipStream_t stream) {
+  long n = (long)B * C * H * W;
+  if (n <= 0) return TELL_OK;
+  int g = (int)((n + 1023) / 1024 > 4096 ? 4096 : (n + 1023) / 1024);
+  if (out_dtype == TELL_BF16) hipLaunchKernelGGL((nchw_to_nhwc_kernel<float, uint16_t>), dim3(g), dim3(256), 0, stream, x, (uint16_t*)y, B, C, H, W);
+  else hipLaunchKernelGGL((nchw_to_nhwc_kernel<float, float>), dim3(g), dim3(256), 0, stream, x, (float*)y, B, C, H, W);
+  return tell_check_launch("nchw_to_nhwc");
+}
+
+// col[m][(kh*KW + kw)*Cin + c] = x[b, oh*s - pad + kh, ow*s - pad + kw, c]  (0 outside / K padding)
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ x, T* __restrict__ col, int B, int H,
+                                                     int W, int Cin, int KH, int KW, int stride, int pad,
+                                                     int OH, int OW, int Kp) {
+  const long M = (long)B * OH * OW;
+  const int Kreal = KH * KW * Cin;
+  const long n = M * Kp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % Kp);
+    const long m = i / Kp;
+    T v = (T)0;
+    if (k < Kreal) {
+      const int c = k % Cin, kk = k / Cin, kw = kk % KW, kh = kk / KW;
+      const int ow = (int)(m % OW);
+      const long r = m / OW;
+      const int oh = (int)(r % OH), b = (int)(r / OH);
+      const int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
+      if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = x[(((long)b * H + ih) * W + iw) * Cin + c];
+    }
+    col[i] = v;
+  }
+}
+extern "C" int tell_im2col(const void* x, void* col, int B, int H, int W, int Cin, int KH, int KW, int stride,
+                           int pad, int OH, int OW, int Kp, int dtype, hipStream_t stream) {
+  long n = (long)B * OH * OW * Kp;
+  if (n <= 0) return TELL_OK;
+  TELL_REQUIRE(Kp >= KH * KW * Cin, "im2col: padded K smaller than KH*KW*Cin");
+  int g = (int)((n + 1023) / 1024 > 8192 ? 8192 : (n + 1023) / 1024);
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((im2col_kernel<uint16_t>), dim3(g), dim3(256), 0, stream, (const uint16_t*)x, (uint16_t*)col, B, H, W, Cin, KH, KW, stride, pad, OH, OW, Kp);
+  else hipLaunchKernelGGL((im2col_kernel<float>), dim3(g), dim3(256), 0, stream, (const float*)x, (float*)col, B, H, W, Cin, KH, KW, stride, pad, OH, OW, Kp);
+  return tell_check_launch("im2col");
+}
+
+// ---------------------------------------------------------------- BatchNorm (batch statistics)
+// stage 1: per (row chunk, 32-column group): count, mean, M2 of the chunk (fp32, two-pass inside the chunk)
+#define BN_ROWS 256
+template <typename T>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x, long M, int C,
+                                                         float* __restrict__ pmean, float* __restrict__ pm2) {
+  __shared__ float red[8][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  const long r0 = (long)blockIdx.y * BN_ROWS;
+  const long r1 = r0 + BN_ROWS < M ? r0 + BN_ROWS : M;
+  const float cnt = (float)(r1 - r0);
+  float s = 0.f;
+  if (c < C) for (long r = r0 + ry; r < r1; r += 8) s += Elem<T>::ld(x + r * C + c);
+  red[ry][cx] = s;
+  __syncthreads();
+  float mean = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) mean += red[k][cx];
+  mean /= cnt;
+  __syncthreads();
+  float q = 0.f;
+  if (c < C) for (long r = r0 + ry; r < r1; r += 8) { float d = Elem<T>::ld(x + r * C + c) - mean; q += d * d; }
+  red[ry][cx] = q;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    float m2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m2 += red[k][cx];
+    pmean[(long)blockIdx.y * C + c] = mean;
+    pm2[(long)blockIdx.y * C + c] = m2;
+  }
+}
+// stage 2: Chan combine over chunks -> mean, invstd (biased var); running stats with unbiased var
+__global__ void bn_finish_kernel(const float* __restrict__ pmean, const float* __restrict__ pm2, long M, int C,
+                                 int n_chunks, float eps, float momentum, float* __restrict__ mean,
+                                 float* __restrict__ invstd, float* __restrict__ running_mean,
+                                 float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float n = 0.f, mu = 0.f, m2 = 0.f;
+  for (int k = 0; k < n_chunks; ++k) {
+    const long r0 = (long)k * BN_ROWS;
+    const float nb = (float)((r0 + BN_ROWS < M ? r0 + BN_ROWS : M) - r0);
+    const float mb = pmean[(long)k * C + c], qb = pm2[(long)k * C + c];
+    const float nt = n + nb, delta = mb - mu;
+    mu += delta * nb / nt;
+    m2 += qb + delta * delta * n * nb / nt;
+    n = nt;
+  }
+  const float var = m2 / n;
+  mean[c] = mu;
+  invstd[c] = rsqrtf(var + eps);
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
+  }
+}
+extern "C" long tell_bn_chunks(long M) { return (M + BN_ROWS - 1) / BN_ROWS; }
+// workspace: 2 * tell_bn_chunks(M) * C floats
+extern "C" int tell_bn_stats(const void* x, long M, int C, float eps, float momentum, float* mean, float* invstd,
+                             float* running_mean, float* running_var, float* workspace, int dtype,
+                             hipStream_t stream) {
+  if (M <= 0 || C <= 0) return TELL_OK;
+  const long nch = tell_bn_chunks(M);
+  TELL_REQUIRE(nch <= 65535, "bn_stats: too many row chunks");
+  float* pmean = workspace;
+  float* pm2 = workspace + nch * C;
+  dim3 grid((C + 31) / 32, (unsigned)nch);
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((bn_partial_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)x, M, C, pmean, pm2);
+  else hipLaunchKernelGGL((bn_partial_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, M, C, pmean, pm2);
+  hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, pmean, pm2, M, C, (int)nch, eps, momentum, mean, invstd, running_mean, running_var);
+  return tell_check_launch("bn_stats");
+}
+
+// y = [relu]( (x - mean) * invstd * gamma + beta [+ residual] )
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, const T* __restrict__ residual,
+                                T* __restrict__ y, long M, int C, int relu) {
+  const long n = M * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    float v = (Elem<T>::ld(x + i) - mean[c]) * invstd[c] * gamma[c] + beta[c];
+    if (residual) v += Elem<T>::ld(residual + i);
+    if (relu) v = fmaxf(v, 0.f);
+    Elem<T>::st(y + i, v);
+  }
+}
+extern "C" int tell_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma,
+                             const float* beta, const void* residual, void* y, long M, int C, int relu,
+                             int dtype, hipStream_t stream) {
+  long n = M * C;
+  if (n <= 0) return TELL_OK;
+  int g = (int)((n + 1023) / 1024 > 8192 ? 8192 : (n + 1023) / 1024);
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((bn_apply_kernel<uint16_t>), dim3(g), dim3(256), 0, stream, (const uint16_t*)x, mean, invstd, gamma, beta, (const uint16_t*)residual, (uint16_t*)y, M, C, relu);
+  else hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(g), dim3(256), 0, stream, (const float*)x, mean, invstd, gamma, beta, (const float*)residual, (float*)y, M, C, relu);
+  return tell_check_launch("bn_apply");
+}
+
+// 3x3 / stride 2 / pad 1 max pooling, NHWC
+template <typename T>
+__global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int OH,
+                               int OW) {
+  const long n = (long)B * OH * OW * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int ow = (int)(r % OW); r /= OW;
+    const int oh = (int)(r % OH);
+    const int b = (int)(r / OH);
+    float m = -INFINITY;
+    for (int kh = 0; kh < 3; ++kh)
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
+        if (ih >= 0 && ih < H && iw >= 0 && iw < W)
+          m = fmaxf(m, Elem<T>::ld(x + (((long)b * H + ih) * W + iw) * C + c));
+      }
+    Elem<T>::st(y + i, m);
+  }
+}
+extern "C" int tell_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int OH, int OW, int dtype,
+                                 hipStream_t stream) {
+  long n = (long)B * OH * OW * C;
+  if (n <= 0) return TELL_OK;
+  int g = (int)((n + 1023) / 1024 > 8192 ? 8192 : (n + 1023) / 1024);
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((maxpool_kernel<uint16_t>), dim3(g), dim3(256), 0, stream, (const uint16_t*)x, (uint16_t*)y, B, H, W, C, OH, OW);
+  else hipLaunchKernelGGL((maxpool_kernel<float>), dim3(g), dim3(256), 0, stream, (const float*)x, (float*)y, B, H, W, C, OH, OW);
+  return tell_check_launch("maxpool");
+}

@@ -1,0 +1,387 @@
+// HBM-bound helpers: cast / transpose (with optional per-row scale = weight-norm
+// materialisation), weight-norm backward, GLU, dropout, column sums, row
+// gather / scatter, NaN-row masking, RoBERTa layer mix.
+// All loops are grid-stride over 16-byte chunks where the layout allows.
+#include "common.h"
+
+static inline int grid_for(long work, int per_block) {
+  long g = (work + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > 256 * 16) g = 256 * 16;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------- cast
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) Elem<D>::st(dst + i, Elem<S>::ld(src + i));
+}
+
+extern "C" int tell_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n,
+                         hipStream_t stream) {
+  if (n <= 0) return TELL_OK;
+  int g = grid_for(n, 256 * 4);
+  if (src_dtype == TELL_F32 && dst_dtype == TELL_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, uint16_t>), dim3(g), dim3(256), 0, stream, (const float*)src, (uint16_t*)dst, n);
+  else if (src_dtype == TELL_BF16 && dst_dtype == TELL_F32)
+    hipLaunchKernelGGL((cast_kernel<uint16_t, float>), dim3(g), dim3(256), 0, stream, (const uint16_t*)src, (float*)dst, n);
+  else if (src_dtype == TELL_F32 && dst_dtype == TELL_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(256), 0, stream, (const float*)src, (float*)dst, n);
+  else if (src_dtype == TELL_BF16 && dst_dtype == TELL_BF16)
+    hipLaunchKernelGGL((cast_kernel<uint16_t, uint16_t>), dim3(g), dim3(256), 0, stream, (const uint16_t*)src, (uint16_t*)dst, n);
+  else { tell_set_error("cast: bad dtype"); return TELL_ERR_ARG; }
+  return tell_check_launch("cast");
+}
+
+// ---------------------------------------------------------------- transpose (+cast, +row scale)
+// dst_t[c][r] = src[r][c] * row_scale[r];  optional dst_plain[r][c] = same value.
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void transpose_kernel(const S* __restrict__ src, long ld_src,
+                                                        D* __restrict__ dst_t, long ld_t,
+                                                        D* __restrict__ dst_plain, long ld_p,
+                                                        const float* __restrict__ row_scale,
+                                                        int rows, int cols) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+  for (int i = ty; i < 64; i += 4) {
+    int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < rows && c < cols) {
+      v = Elem<S>::ld(src + (long)r * ld_src + c);
+      if (row_scale) v *= row_scale[r];
+      if (dst_plain) Elem<D>::st(dst_plain + (long)r * ld_p + c, v);
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  if (dst_t) {
+    for (int i = ty; i < 64; i += 4) {
+      int c = c0 + i, r = r0 + tx;
+      if (r < rows && c < cols) Elem<D>::st(dst_t + (long)c * ld_t + r, tile[tx][i]);
+    }
+  }
+}
+
+extern "C" int tell_transpose(const void* src, long ld_src, int src_dtype, void* dst_t, long ld_t,
+                              void* dst_plain, long ld_p, int dst_dtype, const float* row_scale,
+                              int rows, int cols, hipStream_t stream) {
+  if (rows <= 0 || cols <= 0) return TELL_OK;
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+#define TL(S, D) hipLaunchKernelGGL((transpose_kernel<S, D>), grid, dim3(256), 0, stream, (const S*)src, ld_src, \
+                                    (D*)dst_t, ld_t, (D*)dst_plain, ld_p, row_scale, rows, cols)
+  if (src_dtype == TELL_F32 && dst_dtype == TELL_F32) TL(float, float);
+  else if (src_dtype == TELL_F32 && dst_dtype == TELL_BF16) TL(float, uint16_t);
+  else if (src_dtype == TELL_BF16 && dst_dtype == TELL_BF16) TL(uint16_t, uint16_t);
+  else if (src_dtype == TELL_BF16 && dst_dtype == TELL_F32) TL(uint16_t, float);
+  else { tell_set_error("transpose: bad dtype"); return TELL_ERR_ARG; }
+#undef TL
+  return tell_check_launch("transpose");
+}
+
+// ---------------------------------------------------------------- weight norm
+// scale[r] = g[r] / ||v[r,:]||, norms[r] = ||v[r,:]||   (one wave per row)
+__global__ __launch_bounds__(256) void wn_rowscale_kernel(const float* __restrict__ g,
+                                                          const float* __restrict__ v, int rows,
+                                                          int cols, float* __restrict__ scale,
+                                                          float* __restrict__ norms) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* vr = v + (long)row * cols;
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) { float x = vr[c]; s += x * x; }
+  s = wave_sum(s);
+  if (lane == 0) {
+    float nrm = sqrtf(s);
+    norms[row] = nrm;
+    scale[row] = g[row] / nrm;
+  }
+}
+
+extern "C" int tell_wn_rowscale(const float* g, const float* v, int rows, int cols, float* scale,
+                                float* norms, hipStream_t stream) {
+  if (rows <= 0) return TELL_OK;
+  hipLaunchKernelGGL(wn_rowscale_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, g, v, rows, cols, scale, norms);
+  return tell_check_launch("wn_rowscale");
+}
+
+// dg[r] += <dW[r], v[r]> / ||v||;  dv[r] += (g/||v||) * (dW[r] - v[r] * <dW[r],v[r]> / ||v||^2)
+__global__ __launch_bounds__(256) void wn_backward_kernel(const float* __restrict__ dW,
+                                                          const float* __restrict__ g,
+                                                          const float* __restrict__ v,
+                                                          const float* __restrict__ norms, int rows,
+                                                          int cols, float* __restrict__ dg,
+                                                          float* __restrict__ dv) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* vr = v + (long)row * cols;
+  const float* dr = dW + (long)row * cols;
+  float dot = 0.f;
+  for (int c = lane; c < cols; c += 64) dot += dr[c] * vr[c];
+  dot = wave_sum(dot);
+  const float nrm = norms[row], gs = g[row] / nrm, k = dot / (nrm * nrm);
+  if (lane == 0) dg[row] += dot / nrm;             // accumulate into the (zeroed) grad buffers
+  float* o = dv + (long)row * cols;
+  for (int c = lane; c < cols; c += 64) o[c] += gs * (dr[c] - vr[c] * k);
+}
+
+extern "C" int tell_wn_backward(const float* dW, const float* g, const float* v, const float* norms,
+                                int rows, int cols, float* dg, float* dv, hipStream_t stream) {
+  if (rows <= 0) return TELL_OK;
+  hipLaunchKernelGGL(wn_backward_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, dW, g, v, norms, rows, cols, dg, dv);
+  return tell_check_launch("wn_backward");
+}
+
+// ---------------------------------------------------------------- GLU  (h = [a | gate], y = a * sigmoid(gate))
+template <typename T>
+__global__ void glu_fwd_kernel(const T* __restrict__ h, T* __restrict__ y, long rows, int C) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = rows * C, stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    long r = i / C; int c = (int)(i % C);
+    float a = Elem<T>::ld(h + r * 2 * C + c), g = Elem<T>::ld(h + r * 2 * C + C + c);
+    Elem<T>::st(y + i, a / (1.f + __expf(-g)));
+  }
+}
+template <typename T>
+__global__ void glu_bwd_kernel(const T* __restrict__ h, const T* __restrict__ dy, T* __restrict__ dh,
+                               long rows, int C) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = rows * C, stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    long r = i / C; int c = (int)(i % C);
+    float a = Elem<T>::ld(h + r * 2 * C + c), g = Elem<T>::ld(h + r * 2 * C + C + c);
+    float s = 1.f / (1.f + __expf(-g)), d = Elem<T>::ld(dy + i);
+    Elem<T>::st(dh + r * 2 * C + c, d * s);
+    Elem<T>::st(dh + r * 2 * C + C + c, d * a * s * (1.f - s));
+  }
+}
+extern "C" int tell_glu_fwd(const void* h, void* y, long rows, int C, int dtype, hipStream_t stream) {
+  if (rows <= 0) return TELL_OK;
+  int g = grid_for(rows * C, 256 * 2);
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((glu_fwd_kernel<uint16_t>), dim3(g), dim3(256), 0, stream, (const uint16_t*)h, (uint16_t*)y, rows, C);
+  else hipLaunchKernelGGL((glu_fwd_kernel<float>), dim3(g), dim3(256), 0, stream, (const float*)h, (float*)y, rows, C);
+  return tell_check_launch("glu_fwd");
+}
+extern "C" int tell_glu_bwd(const void* h, const void* dy, void* dh, long rows, int C, int dtype,
+                            hipStream_t stream) {
+  if (rows <= 0) return TELL_OK;
+  int g = grid_for(rows * C, 256 * 2);
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((glu_bwd_kernel<uint16_t>), dim3(g), dim3(256), 0, stream, (const uint16_t*)h, (const uint16_t*)dy, (uint16_t*)dh, rows, C);
+  else hipLaunchKernelGGL((glu_bwd_kernel<float>), dim3(g), dim3(256), 0, stream, (const float*)h, (const float*)dy, (float*)dh, rows, C);
+  return tell_check_launch("glu_bwd");
+}
+
+// ---------------------------------------------------------------- dropout  y = x * keep(idx)
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long n, uint32_t thr,
+                               float inv_keep, uint32_t seed, uint32_t salt) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride)
+    Elem<T>::st(y + i, Elem<T>::ld(x + i) * tell_keep(seed, salt, (uint64_t)i, thr, inv_keep));
+}
+extern "C" int tell_dropout(const void* x, void* y, long n, float p, uint32_t seed, uint32_t salt,
+                            int dtype, hipStream_t stream) {
+  if (n <= 0) return TELL_OK;
+  TELL_REQUIRE(p >= 0.f && p < 1.f, "dropout: p must be in [0,1)");
+  int g = grid_for(n, 256 * 4);
+  uint32_t thr = tell_drop_threshold(p);
+  float ik = 1.f / (1.f - p);
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((dropout_kernel<uint16_t>), dim3(g), dim3(256), 0, stream, (const uint16_t*)x, (uint16_t*)y, n, thr, ik, seed, salt);
+  else hipLaunchKernelGGL((dropout_kernel<float>), dim3(g), dim3(256), 0, stream, (const float*)x, (float*)y, n, thr, ik, seed, salt);
+  return tell_check_launch("dropout");
+}
+
+// ---------------------------------------------------------------- column sums (bias grads): out[c] (+)= sum_r x[r][c]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long ld, int rows, int C,
+                                                     float* __restrict__ out, int accumulate,
+                                                     const int* __restrict__ m_dev, float scale) {
+  __shared__ float part[8][33];
+  if (m_dev) { int md = *m_dev; rows = md < rows ? md : rows; }
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  float s = 0.f;
+  if (c < C)
+    for (int r = ry; r < rows; r += 8) s += Elem<T>::ld(x + (long)r * ld + c);
+  part[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += part[k][cx];
+    t *= scale;
+    out[c] = accumulate ? out[c] + t : t;
+  }
+}
+extern "C" int tell_colsum(const void* x, long ld, int rows, int C, int dtype, float* out,
+                           int accumulate, const int* m_dev, float scale, hipStream_t stream) {
+  if (C <= 0) return TELL_OK;
+  dim3 grid((C + 31) / 32);
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((colsum_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)x, ld, rows, C, out, accumulate, m_dev, scale);
+  else hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, ld, rows, C, out, accumulate, m_dev, scale);
+  return tell_check_launch("colsum");
+}
+
+// ---------------------------------------------------------------- row gather / scatter-add (compacted cluster rows)
+template <typename T>
+__global__ void gather_rows_kernel(const T* __restrict__ src, long ld_src, const int* __restrict__ idx,
+                                   const int* __restrict__ count_dev, int cap, T* __restrict__ dst,
+                                   long ld_dst, int C) {
+  int n = count_dev ? *count_dev : cap;
+  if (n > cap) n = cap;
+  for (int r = blockIdx.x; r < n; r += gridDim.x) {
+    const T* s = src + (long)idx[r] * ld_src;
+    T* d = dst + (long)r * ld_dst;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) d[c] = s[c];
+  }
+}
+// dst[idx[r]] += src[r] * scale   (indices unique -> no atomics)
+template <typename T>
+__global__ void scatter_add_rows_kernel(const T* __restrict__ src, long ld_src, const int* __restrict__ idx,
+                                        const int* __restrict__ count_dev, int cap, T* __restrict__ dst,
+                                        long ld_dst, int C) {
+  int n = count_dev ? *count_dev : cap;
+  if (n > cap) n = cap;
+  for (int r = blockIdx.x; r < n; r += gridDim.x) {
+    const T* s = src + (long)r * ld_src;
+    T* d = dst + (long)idx[r] * ld_dst;
+    for (int c = threadIdx.x; c < C; c += blockDim.x)
+      Elem<T>::st(d + c, Elem<T>::ld(d + c) + Elem<T>::ld(s + c));
+  }
+}
+extern "C" int tell_gather_rows(const void* src, long ld_src, const int* idx, const int* count_dev,
+                                int cap, void* dst, long ld_dst, int C, int dtype, hipStream_t stream) {
+  if (cap <= 0) return TELL_OK;
+  int g = cap < 2048 ? cap : 2048;
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((gather_rows_kernel<uint16_t>), dim3(g), dim3(256), 0, stream, (const uint16_t*)src, ld_src, idx, count_dev, cap, (uint16_t*)dst, ld_dst, C);
+  else hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(g), dim3(256), 0, stream, (const float*)src, ld_src, idx, count_dev, cap, (float*)dst, ld_dst, C);
+  return tell_check_launch("gather_rows");
+}
+extern "C" int tell_scatter_add_rows(const void* src, long ld_src, const int* idx, const int* count_dev,
+                                     int cap, void* dst, long ld_dst, int C, int dtype,
+                                     hipStream_t stream) {
+  if (cap <= 0) return TELL_OK;
+  int g = cap < 2048 ? cap : 2048;
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((scatter_add_rows_kernel<uint16_t>), dim3(g), dim3(256), 0, stream, (const uint16_t*)src, ld_src, idx, count_dev, cap, (uint16_t*)dst, ld_dst, C);
+  else hipLaunchKernelGGL((scatter_add_rows_kernel<float>), dim3(g), dim3(256), 0, stream, (const float*)src, ld_src, idx, count_dev, cap, (float*)dst, ld_dst, C);
+  return tell_check_launch("scatter_add_rows");
+}
+
+// ---------------------------------------------------------------- NaN-padded rows -> mask + zeros (+cast)
+// transformer_faces_objects.py:373-379: mask[r] = any(isnan(x[r,:])); x[r,:] = 0 where masked.
+template <typename D>
+__global__ __launch_bounds__(256) void nan_rows_kernel(const float* __restrict__ x, int rows, int C,
+                                                       D* __restrict__ y, uint8_t* __restrict__ mask) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (long)row * C;
+  int bad = 0;
+  for (int c = lane; c < C; c += 64) bad |= (xr[c] != xr[c]);
+  bad = __any(bad);
+  if (lane == 0) mask[row] = bad ? 1 : 0;
+  D* yr = y + (long)row * C;
+  for (int c = lane; c < C; c += 64) Elem<D>::st(yr + c, bad ? 0.f : xr[c]);
+}
+extern "C" int tell_nan_rows(const float* x, int rows, int C, void* y, int out_dtype, uint8_t* mask,
+                             hipStream_t stream) {
+  if (rows <= 0) return TELL_OK;
+  dim3 grid((rows + 3) / 4);
+  if (out_dtype == TELL_BF16) hipLaunchKernelGGL((nan_rows_kernel<uint16_t>), grid, dim3(256), 0, stream, x, rows, C, (uint16_t*)y, mask);
+  else hipLaunchKernelGGL((nan_rows_kernel<float>), grid, dim3(256), 0, stream, x, rows, C, (float*)y, mask);
+  return tell_check_launch("nan_rows");
+}
+
+// ---------------------------------------------------------------- RoBERTa layer mix (transformer_faces_objects.py:355-364)
+// out[i] = sum_l softmax(w)[l] * H[l][i];   H is a contiguous stack [L][n]
+template <typename T>
+__global__ __launch_bounds__(256) void mix_fwd_kernel(const T* __restrict__ H, const float* __restrict__ w,
+                                                      int L, long n, T* __restrict__ out) {
+  __shared__ float sw[64];
+  if (threadIdx.x < 64) {
+    float v = threadIdx.x < L ? w[threadIdx.x] : -INFINITY;
+    float m = wave_max(v);
+    float e = threadIdx.x < L ? __expf(v - m) : 0.f;
+    float s = wave_sum(e);
+    sw[threadIdx.x] = e / s;
+  }
+  __syncthreads();
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float acc = 0.f;
+    for (int l = 0; l < L; ++l) acc += sw[l] * Elem<T>::ld(H + (long)l * n + i);
+    Elem<T>::st(out + i, acc);
+  }
+}
+// partial[b][l] = sum over this block's elements of dOut[i] * H[l][i]
+template <typename T>
+__global__ __launch_bounds__(256) void mix_bwd_kernel(const T* __restrict__ H, const T* __restrict__ dOut,
+                                                      int L, long n, float* __restrict__ partial) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int l = 0; l < L; ++l) {
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+      acc += Elem<T>::ld(dOut + i) * Elem<T>::ld(H + (long)l * n + i);
+    acc = wave_sum(acc);
+    if (lane == 0) red[wave][l] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < L)
+    partial[(long)blockIdx.x * L + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+extern "C" int tell_mix_fwd(const void* H, const float* w, int L, long n, void* out, int dtype,
+                            hipStream_t stream) {
+  TELL_REQUIRE(L >= 1 && L <= 64, "mix_fwd: L must be in [1,64]");
+  int g = grid_for(n, 256 * 4);
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((mix_fwd_kernel<uint16_t>), dim3(g), dim3(256), 0, stream, (const uint16_t*)H, w, L, n, (uint16_t*)out);
+  else hipLaunchKernelGGL((mix_fwd_kernel<float>), dim3(g), dim3(256), 0, stream, (const float*)H, w, L, n, (float*)out);
+  return tell_check_launch("mix_fwd");
+}
+// partial must hold n_blocks*L floats; returns n_blocks through *n_blocks_out
+extern "C" int tell_mix_bwd(const void* H, const void* dOut, int L, long n, float* partial,
+                            int n_blocks, int dtype, hipStream_t stream) {
+  TELL_REQUIRE(L >= 1 && L <= 64, "mix_bwd: L must be in [1,64]");
+  TELL_REQUIRE(n_blocks >= 1, "mix_bwd: n_blocks");
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((mix_bwd_kernel<uint16_t>), dim3(n_blocks), dim3(256), 0, stream, (const uint16_t*)H, (const uint16_t*)dOut, L, n, partial);
+  else hipLaunchKernelGGL((mix_bwd_kernel<float>), dim3(n_blocks), dim3(256), 0, stream, (const float*)H, (const float*)dOut, L, n, partial);
+  return tell_check_launch("mix_bwd");
+}
+
+// ---------------------------------------------------------------- y += alpha * x (fp32 or T), used for grad accumulation of tied weights
+template <typename T>
+__global__ void axpy_kernel(const T* __restrict__ x, T* __restrict__ y, long n, float alpha) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) Elem<T>::st(y + i, Elem<T>::ld(y + i) + alpha * Elem<T>::ld(x + i));
+}
+extern "C" int tell_axpy(const void* x, void* y, long n, float alpha, int dtype, hipStream_t stream) {
+  if (n <= 0) return TELL_OK;
+  int g = grid_for(n, 256 * 4);
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((axpy_kernel<uint16_t>), dim3(g), dim3(256), 0, stream, (const uint16_t*)x, (uint16_t*)y, n, alpha);
+  else hipLaunchKernelGGL((axpy_kernel<float>), dim3(g), dim3(256), 0, stream, (const float*)x, (float*)y, n, alpha);
+  return tell_check_launch("axpy");
+}
+
+// ---------------------------------------------------------------- relu backward: dx = dy * (y > 0)
+template <typename T>
+__global__ void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) Elem<T>::st(dx + i, Elem<T>::ld(y + i) > 0.f ? Elem<T>::ld(dy + i) : 0.f);
+}
+extern "C" int tell_relu_bwd(const void* dy, const void* y, void* dx, long n, int dtype, hipStream_t stream) {
+  if (n <= 0) return TELL_OK;
+  int g = grid_for(n, 256 * 4);
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((relu_bwd_kernel<uint16_t>), dim3(g), dim3(256), 0, stream, (const uint16_t*)dy, (const uint16_t*)y, (uint16_t*)dx, n);
+  else hipLaunchKernelGGL((relu_bwd_kernel<float>), dim3(g), dim3(256), 0, stream, (const float*)dy, (const float*)y, (float*)dx, n);
+  return tell_check_launch("relu_bwd");
+}

@@ -1,0 +1,154 @@
+// Fused  y = LayerNorm(res + dropout(x)) * gamma + beta   (post-LN blocks of the
+// decoder, decoder_faces_objects.py:263-266, and RoBERTa's post-LN encoder).
+// One wave per row, fp32 statistics, two-pass variance.  Rows are re-read from
+// L1/L2 (a 1024-wide bf16 row is 2 KB), so HBM traffic is one read + one write.
+#include "common.h"
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, long ld_x,
+                                                     const T* __restrict__ res, long ld_r,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     long ld_y, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int rows, int C,
+                                                     float eps, uint32_t thr, float inv_keep,
+                                                     uint32_t seed, uint32_t salt) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + (long)row * ld_x;
+  const T* rr = res ? res + (long)row * ld_r : nullptr;
+  auto z = [&](int c) -> float {
+    float v = Elem<T>::ld(xr + c);
+    if (thr) v *= tell_keep(seed, salt, (uint64_t)row * C + c, thr, inv_keep);
+    if (rr) v += Elem<T>::ld(rr + c);
+    return v;
+  };
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += z(c);
+  const float mu = wave_sum(s) / C;
+  float q = 0.f;
+  for (int c = lane; c < C; c += 64) { float d = z(c) - mu; q += d * d; }
+  const float rs = rsqrtf(wave_sum(q) / C + eps);
+  if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+  T* yr = y + (long)row * ld_y;
+  for (int c = lane; c < C; c += 64) Elem<T>::st(yr + c, (z(c) - mu) * rs * gamma[c] + beta[c]);
+}
+
+extern "C" int tell_layernorm_fwd(const void* x, long ld_x, const void* res, long ld_r,
+                                  const float* gamma, const float* beta, void* y, long ld_y,
+                                  float* mean, float* rstd, int rows, int C, float eps, float p,
+                                  uint32_t seed, uint32_t salt, int dtype, hipStream_t stream) {
+  if (rows <= 0) return TELL_OK;
+  TELL_REQUIRE(p >= 0.f && p < 1.f, "layernorm_fwd: p must be in [0,1)");
+  uint32_t thr = p > 0.f ? tell_drop_threshold(p) : 0u;
+  float ik = 1.f / (1.f - p);
+  dim3 grid((rows + 3) / 4);
+  if (dtype == TELL_BF16)
+    hipLaunchKernelGGL((ln_fwd_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)x, ld_x, (const uint16_t*)res, ld_r, gamma, beta, (uint16_t*)y, ld_y, mean, rstd, rows, C, eps, thr, ik, seed, salt);
+  else
+    hipLaunchKernelGGL((ln_fwd_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, ld_x, (const float*)res, ld_r, gamma, beta, (float*)y, ld_y, mean, rstd, rows, C, eps, thr, ik, seed, salt);
+  return tell_check_launch("layernorm_fwd");
+}
+
+// Backward.  z = res + dropout(x) is recomputed from the saved inputs.
+//   dz = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma
+//   dres = dz (optionally accumulated into an existing buffer), dx = dz * keep
+// dgamma / dbeta: each block reduces its ROWS_PER_BLOCK rows into partial[block][2][C];
+// tell_ln_bwd_finish sums the partials (deterministic, no atomics).
+#define LN_BWD_ROWS 32
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, long ld_dy,
+                                                     const T* __restrict__ x, long ld_x,
+                                                     const T* __restrict__ res, long ld_r,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd,
+                                                     T* __restrict__ dx, long ld_dx,
+                                                     T* __restrict__ dres, long ld_dres, int dres_acc,
+                                                     float* __restrict__ partial, int rows, int C,
+                                                     uint32_t thr, float inv_keep, uint32_t seed,
+                                                     uint32_t salt) {
+  extern __shared__ float sm[];                 // [4 waves][2][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* my_g = sm + (long)wave * 2 * C;
+  float* my_b = my_g + C;
+  for (int c = lane; c < C; c += 64) { my_g[c] = 0.f; my_b[c] = 0.f; }
+  const int r_begin = blockIdx.x * LN_BWD_ROWS;
+  for (int rr_ = wave; rr_ < LN_BWD_ROWS; rr_ += 4) {
+    const int row = r_begin + rr_;
+    if (row >= rows) break;
+    const T* xr = x + (long)row * ld_x;
+    const T* rr = res ? res + (long)row * ld_r : nullptr;
+    const T* dyr = dy + (long)row * ld_dy;
+    const float mu = mean[row], rs = rstd[row];
+    auto xhat = [&](int c, float& keep) -> float {
+      float v = Elem<T>::ld(xr + c);
+      keep = thr ? tell_keep(seed, salt, (uint64_t)row * C + c, thr, inv_keep) : 1.f;
+      v *= keep;
+      if (rr) v += Elem<T>::ld(rr + c);
+      return (v - mu) * rs;
+    };
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      float k; float xh = xhat(c, k);
+      float d = Elem<T>::ld(dyr + c);
+      float g = d * gamma[c];
+      s1 += g; s2 += g * xh;
+      my_g[c] += d * xh;                        // lane-private columns -> no race
+      my_b[c] += d;
+    }
+    s1 = wave_sum(s1) / C; s2 = wave_sum(s2) / C;
+    for (int c = lane; c < C; c += 64) {
+      float k; float xh = xhat(c, k);
+      float g = Elem<T>::ld(dyr + c) * gamma[c];
+      float dz = rs * (g - s1 - xh * s2);
+      if (dres) {
+        T* d = dres + (long)row * ld_dres + c;
+        Elem<T>::st(d, dres_acc ? Elem<T>::ld(d) + dz : dz);
+      }
+      if (dx) Elem<T>::st(dx + (long)row * ld_dx + c, dz * k);
+    }
+  }
+  __syncthreads();
+  float* out = partial + (long)blockIdx.x * 2 * C;
+  for (int c = threadIdx.x; c < 2 * C; c += 256)
+    out[c] = sm[c] + sm[2 * C + c] + sm[4 * C + c] + sm[6 * C + c];
+}
+
+__global__ void ln_bwd_finish_kernel(const float* __restrict__ partial, int n_blocks, int C,
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                     int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * C) return;
+  float s = 0.f;
+  for (int b = 0; b < n_blocks; ++b) s += partial[(long)b * 2 * C + c];
+  float* dst = c < C ? dgamma + c : dbeta + (c - C);
+  *dst = accumulate ? *dst + s : s;
+}
+
+extern "C" int tell_layernorm_bwd_blocks(int rows) { return (rows + LN_BWD_ROWS - 1) / LN_BWD_ROWS; }
+
+// partial: workspace of tell_layernorm_bwd_blocks(rows) * 2 * C floats
+extern "C" int tell_layernorm_bwd(const void* dy, long ld_dy, const void* x, long ld_x, const void* res,
+                                  long ld_r, const float* gamma, const float* mean, const float* rstd,
+                                  void* dx, long ld_dx, void* dres, long ld_dres, int dres_accumulate,
+                                  float* dgamma, float* dbeta, int dparam_accumulate, float* partial,
+                                  int rows, int C, float p, uint32_t seed, uint32_t salt, int dtype,
+                                  hipStream_t stream) {
+  if (rows <= 0) return TELL_OK;
+  TELL_REQUIRE(p >= 0.f && p < 1.f, "layernorm_bwd: p must be in [0,1)");
+  TELL_REQUIRE((long)C * 8 * sizeof(float) <= 64 * 1024, "layernorm_bwd: C too large for LDS partials");
+  uint32_t thr = p > 0.f ? tell_drop_threshold(p) : 0u;
+  float ik = 1.f / (1.f - p);
+  int nb = tell_layernorm_bwd_blocks(rows);
+  size_t smem = (size_t)C * 8 * sizeof(float);
+  if (dtype == TELL_BF16)
+    hipLaunchKernelGGL((ln_bwd_kernel<uint16_t>), dim3(nb), dim3(256), smem, stream, (const uint16_t*)dy, ld_dy, (const uint16_t*)x, ld_x, (const uint16_t*)res, ld_r, gamma, mean, rstd, (uint16_t*)dx, ld_dx, (uint16_t*)dres, ld_dres, dres_accumulate, partial, rows, C, thr, ik, seed, salt);
+  else
+    hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(nb), dim3(256), smem, stream, (const float*)dy, ld_dy, (const float*)x, ld_x, (const float*)res, ld_r, gamma, mean, rstd, (float*)dx, ld_dx, (float*)dres, ld_dres, dres_accumulate, partial, rows, C, thr, ik, seed, salt);
+  int rc = tell_check_launch("layernorm_bwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, partial, nb, C, dgamma, dbeta, dparam_accumulate);
+  return tell_check_launch("layernorm_bwd_finish");
+}

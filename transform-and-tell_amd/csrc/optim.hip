@@ -1,0 +1,103 @@
+// Multi-tensor BertAdam over flat fp32 buffers (optimizer `bert_adam` of
+// expt/nytimes/9_transformer_objects/config.yaml:126-149; update rule of
+// pytorch_pretrained_bert.BertAdam - third-party, restated, parity unpinned):
+//   per tensor:  g <- g * min(1, max_grad_norm / (||g||_2 + 1e-6))       (per-TENSOR clip)
+//   m <- b1 m + (1-b1) g ;  v <- b2 v + (1-b2) g^2      (no bias correction)
+//   p <- p - lr_t * ( m / (sqrt(v) + eps) + wd * p )
+// Layout: every tensor starts at a multiple of CHUNK elements inside the flat
+// buffers (zero padded), so a chunk belongs to exactly one tensor.  HBM-bound:
+// 4 reads + 3 writes of fp32 per element.
+#include "common.h"
+
+#define OPT_CHUNK 1024
+
+// partial[c] = sum of squares of (grad * grad_scale) over chunk c
+__global__ __launch_bounds__(256) void sqsum_chunks_kernel(const float* __restrict__ grad, long n_chunks,
+                                                           float grad_scale, float* __restrict__ partial) {
+  __shared__ float red[4];
+  for (long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const float4 g = reinterpret_cast<const float4*>(grad + c * OPT_CHUNK)[threadIdx.x];
+    float s = (g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w) * grad_scale * grad_scale;
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[c] = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+  }
+}
+// norms[t] = sqrt(sum of the tensor's chunk partials); one wave per tensor (fixed order -> deterministic)
+__global__ __launch_bounds__(256) void tensor_norms_kernel(const float* __restrict__ partial,
+                                                           const long* __restrict__ chunk_begin,
+                                                           int n_tensors, float* __restrict__ norms) {
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (t >= n_tensors) return;
+  float s = 0.f;
+  for (long c = chunk_begin[t] + lane; c < chunk_begin[t + 1]; c += 64) s += partial[c];
+  s = wave_sum(s);
+  if (lane == 0) norms[t] = sqrtf(s);
+}
+__global__ __launch_bounds__(256) void bertadam_update_kernel(float* __restrict__ param,
+                                                              const float* __restrict__ grad,
+                                                              float* __restrict__ m, float* __restrict__ v,
+                                                              const int* __restrict__ chunk_tensor,
+                                                              const float* __restrict__ norms, long n_chunks,
+                                                              const float* __restrict__ lr_dev, float b1,
+                                                              float b2, float eps, float wd, float max_norm,
+                                                              float grad_scale) {
+  const float lr = *lr_dev;
+  for (long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    float coef = grad_scale;
+    if (max_norm > 0.f) {
+      const float cc = max_norm / (norms[chunk_tensor[c]] + 1e-6f);
+      if (cc < 1.f) coef *= cc;
+    }
+    const long o = c * OPT_CHUNK / 4 + threadIdx.x;
+    float4 g = reinterpret_cast<const float4*>(grad)[o];
+    float4 p = reinterpret_cast<float4*>(param)[o];
+    float4 mm = reinterpret_cast<float4*>(m)[o];
+    float4 vv = reinterpret_cast<float4*>(v)[o];
+#define UPD(f)                                                   \
+    { const float gg = g.f * coef;                               \
+      mm.f = b1 * mm.f + (1.f - b1) * gg;                        \
+      vv.f = b2 * vv.f + (1.f - b2) * gg * gg;                   \
+      p.f -= lr * (mm.f / (sqrtf(vv.f) + eps) + wd * p.f); }
+    UPD(x) UPD(y) UPD(z) UPD(w)
+#undef UPD
+    reinterpret_cast<float4*>(param)[o] = p;
+    reinterpret_cast<float4*>(m)[o] = mm;
+    reinterpret_cast<float4*>(v)[o] = vv;
+  }
+}
+
+extern "C" int tell_opt_chunk(void) { return OPT_CHUNK; }
+
+// workspace `partial`: n_chunks floats; `norms`: n_tensors floats
+extern "C" int tell_bertadam_step(float* param, const float* grad, float* m, float* v,
+                                  const int* chunk_tensor, const long* chunk_begin, long n_chunks,
+                                  int n_tensors, float* partial, float* norms, const float* lr_dev,
+                                  float b1, float b2, float eps, float wd, float max_norm,
+                                  float grad_scale, hipStream_t stream) {
+  if (n_chunks <= 0) return TELL_OK;
+  TELL_REQUIRE(((uintptr_t)param & 15) == 0 && ((uintptr_t)grad & 15) == 0, "bertadam: buffers must be 16-byte aligned");
+  int g = n_chunks < 4096 ? (int)n_chunks : 4096;
+  if (max_norm > 0.f) {
+    hipLaunchKernelGGL(sqsum_chunks_kernel, dim3(g), dim3(256), 0, stream, grad, n_chunks, grad_scale, partial);
+    hipLaunchKernelGGL(tensor_norms_kernel, dim3((n_tensors + 3) / 4), dim3(256), 0, stream, partial, chunk_begin, n_tensors, norms);
+  }
+  hipLaunchKernelGGL(bertadam_update_kernel, dim3(g), dim3(256), 0, stream, param, grad, m, v, chunk_tensor, norms, n_chunks, lr_dev, b1, b2, eps, wd, max_norm, grad_scale);
+  return tell_check_launch("bertadam_step");
+}
+
+// fill n floats with a value (grad zeroing without a memset node per tensor)
+__global__ void fill_kernel(float* __restrict__ x, long n, float value) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) x[i] = value;
+}
+extern "C" int tell_fill_f32(float* x, long n, float value, hipStream_t stream) {
+  if (n <= 0) return TELL_OK;
+  long g = (n + 1023) / 1024;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(fill_kernel, dim3((int)g), dim3(256), 0, stream, x, n, value);
+  return tell_check_launch("fill_f32");
+}

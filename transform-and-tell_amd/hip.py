@@ -1,0 +1,102 @@
+"""ctypes binding of libtell_hip.so (C ABI declared in include/tell_hip.h).
+
+The prototypes are parsed from the header itself, so the binding cannot drift
+from the ABI.  There is NO fallback: if the library is missing or a kernel
+fails, a RuntimeError is raised - the product never silently runs on CPU.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libtell_hip.so')
+HEADER_PATH = os.path.join(_ROOT, 'include', 'tell_hip.h')
+
+F32, BF16 = 0, 1
+
+_CTYPES = {
+    'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float,
+    'uint32_t': ctypes.c_uint32, 'tell_stream_t': ctypes.c_void_p, 'void': None,
+}
+
+
+def _ctype(decl):
+    decl = decl.strip()
+    if decl == 'const char*':
+        return ctypes.c_char_p
+    if '*' in decl:
+        return ctypes.c_void_p
+    return _CTYPES[decl.replace('const ', '')]
+
+
+def parse_header(path=HEADER_PATH):
+    """-> {name: (restype, [argtypes], [argnames])} for every `tell_*` prototype."""
+    src = open(path).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r'([A-Za-z_][\w\s\*]*?)\b(tell_\w+)\s*\(([^)]*)\)\s*;', src):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        argtypes, argnames = [], []
+        if args and args != 'void':
+            for a in args.split(','):
+                a = ' '.join(a.split())
+                mm = re.match(r'(.*?)(\w+)$', a)
+                argtypes.append(_ctype(mm.group(1)))
+                argnames.append(mm.group(2))
+        protos[name] = (_ctype(ret), argtypes, argnames)
+    return protos
+
+
+_lib = None
+_protos = None
+
+
+def lib():
+    global _lib, _protos
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'tell_amd: %s not found - build it with `python __graft_entry__.py build` '
+                '(or transform-and-tell_amd/csrc/build.sh). There is no CPU fallback.' % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        _protos = parse_header()
+        for name, (res, argtypes, _) in _protos.items():
+            fn = getattr(_lib, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = argtypes
+    return _lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError('tell_amd: no HIP device visible (torch.cuda.is_available() is False); '
+                           'the MI355X kernels have no CPU fallback')
+    lib()
+
+
+def dt(t):
+    """dtype code of a tensor / torch dtype."""
+    d = t.dtype if isinstance(t, torch.Tensor) else t
+    if d == torch.float32:
+        return F32
+    if d == torch.bfloat16:
+        return BF16
+    raise TypeError('tell_amd: unsupported dtype %s (float32 / bfloat16 only)' % d)
+
+
+def _conv(a):
+    if isinstance(a, torch.Tensor):
+        return a.data_ptr()
+    return a
+
+
+def call(name, *args):
+    """Call a C-ABI entry point; tensors -> device pointers; last arg (stream) added here."""
+    fn = getattr(lib(), name)
+    stream = torch.cuda.current_stream().cuda_stream
+    rc = fn(*[_conv(a) for a in args], stream)
+    if rc != 0:
+        raise RuntimeError('%s failed (%d): %s' % (name, rc, lib().tell_last_error().decode()))

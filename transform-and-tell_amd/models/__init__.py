@@ -1,0 +1,5 @@
+"""Host-side mirrors of tell/models (decoders + caption models) on the MI355X path."""
+from .decoders import (Decoder, DecoderLayer, DynamicConvDecoder,  # noqa: F401
+                       DynamicConvFacesObjectsDecoder, DynamicConvDecoderLayer)
+from .transformer import (TransformerFacesObjectModel, TransformerFlattenedModel,  # noqa: F401
+                          CaptionModel)

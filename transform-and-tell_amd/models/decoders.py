@@ -1,0 +1,192 @@
+"""tell/models/decoder_faces_objects.py:22-379 and tell/models/decoder_flattened.py:23-333
+on the MI355X path.  The two reference files are the same block structure over a
+different list of contexts; here one table-driven implementation answers to both
+registration names and keeps both sets of constructor arguments / state_dict keys."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..common.registrable import Registrable
+from ..modules import AdaptiveSoftmax, DynamicConv1dTBC, GehringLinear, MultiHeadAttention
+from ..modules.token_embedders import AdaptiveEmbedding
+
+
+def eval_str_list(x, type=float):
+    """tell/utils/options.py:1-9"""
+    if x is None:
+        return None
+    if isinstance(x, str):
+        x = eval(x)
+    try:
+        return list(map(type, x))
+    except TypeError:
+        return [type(x)]
+
+
+class Decoder(nn.Module, Registrable):
+    pass
+
+
+class DecoderLayer(nn.Module, Registrable):
+    pass
+
+
+class DynamicConvDecoderLayer(DecoderLayer):
+    """decoder_faces_objects.py:184-372 / decoder_flattened.py:185-326 (post-LN only:
+    every expt/ config has decoder_normalize_before: false)."""
+
+    def __init__(self, decoder_embed_dim, decoder_conv_dim, decoder_glu, decoder_conv_type, weight_softmax,
+                 decoder_attention_heads, weight_dropout, dropout, relu_dropout, input_dropout,
+                 decoder_normalize_before, attention_dropout, decoder_ffn_embed_dim, contexts, kernel_size=0):
+        super().__init__()
+        if decoder_conv_type != 'dynamic' or not decoder_glu or decoder_normalize_before:
+            raise NotImplementedError('HIP path implements decoder_conv_type=dynamic, decoder_glu=true, '
+                                      'decoder_normalize_before=false (all 19 dynamic-conv configs)')
+        E = self.embed_dim = decoder_embed_dim
+        self.conv_dim = decoder_conv_dim
+        self.linear1 = GehringLinear(E, 2 * self.conv_dim)
+        self.conv = DynamicConv1dTBC(self.conv_dim, kernel_size, padding_l=kernel_size - 1,
+                                     weight_softmax=weight_softmax, num_heads=decoder_attention_heads,
+                                     weight_dropout=weight_dropout)
+        self.linear2 = GehringLinear(self.conv_dim, E)
+        self.dropout, self.relu_dropout, self.input_dropout = dropout, relu_dropout, input_dropout
+        self.normalize_before = decoder_normalize_before
+        self.conv_layer_norm = nn.LayerNorm(E)
+        self.context_attns = nn.ModuleDict()
+        self.context_attn_lns = nn.ModuleDict()
+        self.context_names = [n for n, _ in contexts]
+        for name, kdim in contexts:
+            self.context_attns[name] = MultiHeadAttention(E, decoder_attention_heads, kdim=kdim, vdim=kdim,
+                                                          dropout=attention_dropout)
+            self.context_attn_lns[name] = nn.LayerNorm(E)
+        self.context_fc = GehringLinear(E * len(contexts), E)
+        self.fc1 = GehringLinear(E, decoder_ffn_embed_dim)
+        self.fc2 = GehringLinear(decoder_ffn_embed_dim, E)
+        self.final_layer_norm = nn.LayerNorm(E)
+        self.need_attn = False      # attention-weight export is opt-in (make_generation_fast_, :374-375)
+
+    @staticmethod
+    def _ln(ln, x, res, p, training):
+        return ops.layer_norm(x, res, ln.weight, ln.bias, ln.eps, p, training)
+
+    def forward(self, X, contexts, incremental_state, contexts_t=None):
+        tr = self.training
+        res = X                                                            # :256-266
+        h = ops.dropout(X, self.input_dropout, tr)
+        h = ops.glu(self.linear1(h))
+        h = self.conv(h, incremental_state=incremental_state)
+        h = self.linear2(h)
+        X = self._ln(self.conv_layer_norm, h, res, self.dropout, tr)      # LN(res + dropout(h))
+
+        attns, outs = {}, []
+        for name in self.context_names:                                   # :271-352
+            a, w = self.context_attns[name](
+                X, contexts[name], contexts[name], key_padding_mask=contexts[name + '_mask'],
+                need_weights=(not tr and self.need_attn),
+                key_t=None if contexts_t is None else contexts_t.get(name))
+            outs.append(self._ln(self.context_attn_lns[name], a, X, self.dropout, tr))
+            if w is not None:
+                attns[name] = w.cpu().numpy()
+        X = self.context_fc(torch.cat(outs, dim=-1))                       # :354-355
+
+        res = X                                                            # :357-364
+        h = self.fc1(X, act=1)
+        h = ops.dropout(h, self.relu_dropout, tr)
+        h = self.fc2(h)
+        return self._ln(self.final_layer_norm, h, res, self.dropout, tr), attns
+
+    def make_generation_fast_(self, need_attn=False, **kwargs):
+        self.need_attn = need_attn
+
+
+class _DynamicConvDecoderBase(Decoder):
+    CONTEXTS = ()
+
+    def __init__(self, vocab, embedder, max_target_positions, dropout, share_decoder_input_output_embed,
+                 decoder_output_dim, decoder_conv_dim, decoder_glu, decoder_conv_type, weight_softmax,
+                 decoder_attention_heads, weight_dropout, relu_dropout, input_dropout, decoder_normalize_before,
+                 attention_dropout, decoder_ffn_embed_dim, decoder_kernel_size_list, adaptive_softmax_cutoff=None,
+                 tie_adaptive_weights=False, adaptive_softmax_dropout=0, tie_adaptive_proj=False,
+                 adaptive_softmax_factor=0, decoder_layers=6, final_norm=True, padding_idx=0,
+                 namespace='target_tokens', vocab_size=None, section_attn=False, swap=False,
+                 article_embed_size=1024):
+        super().__init__()
+        self.vocab = vocab
+        vocab_size = vocab_size or vocab.get_vocab_size(namespace)
+        self.dropout = dropout
+        self.share_input_output_embed = share_decoder_input_output_embed
+        E = embedder.get_output_dim()
+        self.max_target_positions = max_target_positions
+        self.embedder = embedder
+        self.project_in_dim = None
+        contexts = tuple((n, article_embed_size if n == 'article' and self.ARTICLE_DIM_FROM_ARG else k)
+                         for n, k in self.CONTEXTS)
+        self.layers = nn.ModuleList([
+            DynamicConvDecoderLayer(E, decoder_conv_dim, decoder_glu, decoder_conv_type, weight_softmax,
+                                    decoder_attention_heads, weight_dropout, dropout, relu_dropout,
+                                    input_dropout, decoder_normalize_before, attention_dropout,
+                                    decoder_ffn_embed_dim, contexts, kernel_size=decoder_kernel_size_list[i])
+            for i in range(decoder_layers)])
+        if adaptive_softmax_cutoff is None or not tie_adaptive_weights:
+            raise NotImplementedError('HIP path implements the tied adaptive-softmax head of the configs')
+        adaptive_inputs = embedder if isinstance(embedder, AdaptiveEmbedding) else embedder.token_embedder_adaptive
+        self.project_out_dim = None
+        self.adaptive_softmax = AdaptiveSoftmax(vocab_size, E, eval_str_list(adaptive_softmax_cutoff, type=int),
+                                                dropout=adaptive_softmax_dropout, adaptive_inputs=adaptive_inputs,
+                                                factor=adaptive_softmax_factor, tie_proj=tie_adaptive_proj)
+        self.register_buffer('version', torch.Tensor([2]))
+        self.normalize = decoder_normalize_before and final_norm
+
+    def forward(self, prev_target, contexts, incremental_state=None, use_layers=None, **kwargs):
+        X = self.embedder(prev_target, incremental_state=incremental_state)      # :98  [B,T,E] view
+        X = X.transpose(0, 1)                                                      # :109 T x B x C (contiguous)
+        X = ops.dropout(X, self.dropout, self.training)                            # :106
+        contexts_t = None
+        if torch.is_grad_enabled() and self.training:
+            # one transpose per context per step, shared by the K and V weight-gradient GEMMs of all layers
+            contexts_t = contexts.get('_transposed')
+            if contexts_t is None:
+                contexts_t = {}
+                for name, _ in self.CONTEXTS:
+                    c = contexts[name]
+                    if c.shape[0] > 0 and c.shape[2] > 0:
+                        bm = c.transpose(0, 1)
+                        src = bm if (bm.is_contiguous() and not c.is_contiguous()) else c.contiguous()
+                        contexts_t[name] = ops.transpose(ops.as2d(src))[0]
+                contexts['_transposed'] = contexts_t
+        attns, inner_states = [], [X]
+        for i, layer in enumerate(self.layers):
+            if not use_layers or i in use_layers:
+                X, attn = layer(X, contexts, incremental_state, contexts_t)
+                inner_states.append(X)
+            attns.append(attn)
+        X = X.transpose(0, 1)                                                      # :129 B x T x C
+        return X, {'attn': attns, 'inner_states': inner_states}
+
+    def max_positions(self):
+        return self.max_target_positions
+
+    def get_normalized_probs(self, net_output, log_probs, sample=None):            # :160-173
+        out = self.adaptive_softmax.get_log_prob(net_output[0])
+        return out if log_probs else out.exp()
+
+    def filter_incremental_state(self, incremental_state, active_idx):             # :175-180
+        if incremental_state is None:
+            return
+        for key in incremental_state:
+            if 'DynamicConv1dTBC' in key:
+                incremental_state[key] = incremental_state[key][:, active_idx]
+
+
+@Decoder.register('dynamic_conv_decoder_faces_objects')
+class DynamicConvFacesObjectsDecoder(_DynamicConvDecoderBase):
+    """tell/models/decoder_faces_objects.py:22 (`contexts['image'|'article'|'faces'|'obj']`)."""
+    CONTEXTS = (('image', 2048), ('article', 1024), ('faces', 512), ('obj', 2048))
+    ARTICLE_DIM_FROM_ARG = False
+
+
+@Decoder.register('dynamic_conv_decoder_flattened')
+class DynamicConvDecoder(_DynamicConvDecoderBase):
+    """tell/models/decoder_flattened.py:23 (`contexts['image'|'article']`)."""
+    CONTEXTS = (('image', 2048), ('article', 1024))
+    ARTICLE_DIM_FROM_ARG = True

@@ -1,0 +1,181 @@
+"""tell/models/transformer_faces_objects.py:23-517 and tell/models/transformer_flattened.py:24-443
+on the MI355X path (training forward + loss, greedy generation)."""
+import math
+from collections import defaultdict
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..common.registrable import Registrable
+
+
+class Model(nn.Module, Registrable):
+    """Stand-in for allennlp.models.Model (forward(**batch) -> dict with 'loss')."""
+
+    def __init__(self, vocab=None):
+        super().__init__()
+        self.vocab = vocab
+
+    def get_metrics(self, reset=False):
+        return {}
+
+    def decode(self, output_dict):
+        return output_dict
+
+
+class CaptionModel(Model):
+    USE_FACES_OBJECTS = False
+
+    def __init__(self, vocab, decoder, criterion, evaluate_mode=False, attention_dim=1024, hidden_size=1024,
+                 dropout=0.1, vocab_size=50264, model_name='roberta-base', namespace='bpe', index='roberta',
+                 padding_value=1, use_context=True, sampling_topk=1, sampling_temp=1.0, weigh_bert=False,
+                 initializer=None, resnet=None, roberta=None, n_bert_layers=25):
+        super().__init__(vocab)
+        self.decoder, self.criterion = decoder, criterion
+        self.index, self.namespace = index, namespace
+        if resnet is None:
+            from .resnet import resnet152
+            resnet = resnet152()
+        if roberta is None:
+            from .roberta import roberta_large
+            roberta = roberta_large()
+        self.resnet, self.roberta = resnet, roberta
+        self.use_context = use_context
+        self.padding_idx = padding_value
+        self.evaluate_mode = evaluate_mode
+        self.sampling_topk, self.sampling_temp = sampling_topk, sampling_temp
+        if sampling_topk != 1:
+            raise NotImplementedError('generation is greedy (sampling_topk: 1 in every config)')
+        self.weigh_bert = weigh_bert
+        if weigh_bert:
+            self.bert_weight = nn.Parameter(torch.rand(n_bert_layers))      # nn.init.uniform_, :57-59
+        self.n_batches = 0
+        self.n_samples = 0
+        self.sample_history = defaultdict(float)
+
+    # ---- :311-397 -----------------------------------------------------------------
+    def _forward(self, context, image, caption, face_embeds=None, obj_embeds=None):
+        dtype = ops.rt.compute_dtype()
+        cap = caption[self.index]
+        target_ids = cap[:, 1:].contiguous()                               # :321-328
+        caption_ids = cap[:, :-1].contiguous()
+        caption[self.index] = caption_ids                                  # :329
+
+        with torch.no_grad():                                              # frozen encoders (config :150-152)
+            x_image = self.resnet(image)                                   # [B,49,2048] (NHWC == :335-341)
+            B, P, _ = x_image.shape
+            article_ids = context[self.index]
+            article_mask = article_ids == self.padding_idx                 # :347
+            stack = self.roberta.extract_features(article_ids, return_all_hiddens=True)   # [L,B,S,E]
+        if self.weigh_bert:
+            x_article = ops.mix_layers(stack, self.bert_weight)            # :355-364
+        else:
+            x_article = stack[-1]
+        contexts = {
+            'image': x_image.transpose(0, 1),
+            'image_mask': torch.zeros(B, P, dtype=torch.bool, device=image.device),   # :371
+            'article': x_article.transpose(0, 1),
+            'article_mask': article_mask,
+        }
+        if self.USE_FACES_OBJECTS:                                         # :373-379
+            for key, emb in (('faces', face_embeds), ('obj', obj_embeds)):
+                Bf, n, dim = emb.shape
+                if n == 0 or dim == 0:
+                    contexts[key] = emb.new_zeros(n, Bf, dim).to(dtype)
+                    contexts[key + '_mask'] = torch.zeros(Bf, n, dtype=torch.bool, device=emb.device)
+                    continue
+                clean = torch.empty(Bf, n, dim, dtype=dtype, device=emb.device)
+                mask = torch.empty(Bf, n, dtype=torch.uint8, device=emb.device)
+                ops.call('tell_nan_rows', emb.float().contiguous(), Bf * n, dim, clean, ops.hip.dt(dtype), mask)
+                contexts[key] = clean.transpose(0, 1)
+                contexts[key + '_mask'] = mask.bool()
+        return caption_ids, target_ids, contexts
+
+    # ---- :67-140 ------------------------------------------------------------------
+    def forward(self, context, image, caption, face_embeds=None, obj_embeds=None, metadata=None, names=None,
+                attn_idx=None):
+        caption_ids, target_ids, contexts = self._forward(context, image, caption, face_embeds, obj_embeds)
+        decoder_out = self.decoder(caption, contexts)
+        loss_sum, sample_size = self.criterion(self.decoder.adaptive_softmax, decoder_out, target_ids)
+        n = sample_size.to(torch.float32)
+        loss = (loss_sum / math.log(2) / n).reshape(())                    # :85-88, bits per token
+        output_dict = {'loss': loss, 'sample_size': sample_size.reshape(())}
+        if not self.training and self.evaluate_mode:
+            _, gen_ids, attns = self._generate(caption_ids, contexts)
+            output_dict['gen_ids'] = gen_ids.cpu().numpy()
+            output_dict['attns'] = attns
+            if metadata is not None:
+                output_dict['captions'] = [m.get('caption') for m in metadata]
+                output_dict['metadata'] = metadata
+        self.n_samples += caption_ids.shape[0]
+        self.n_batches += 1
+        return output_dict
+
+    def generate(self, context, image, caption, face_embeds=None, obj_embeds=None, metadata=None, names=None,
+                 attn_idx=None):
+        caption_ids, _, contexts = self._forward(context, image, caption, face_embeds, obj_embeds)
+        log_probs, gen_ids, attns = self._generate(caption_ids, contexts, attn_idx)
+        return {'gen_ids': gen_ids, 'log_probs': log_probs, 'attns': attns}
+
+    # ---- :399-494 -----------------------------------------------------------------
+    @torch.no_grad()
+    def _generate(self, caption_ids, contexts, attn_idx=None, gen_len=100, eos=2):
+        """Greedy decoding with the reference's semantics (finished rows leave the batch, pad=1 after
+        EOS, loop ends when no row is active).  The arg-max over the 50 265-way adaptive softmax is
+        fused (no [B, vocab] log-prob tensor)."""
+        state = {}
+        B = caption_ids.shape[0]
+        dev = caption_ids.device
+        seed = caption_ids[:, 0:1]
+        alive = seed[:, -1] != eos
+        keep = alive
+        cur = seed
+        log_probs, paths, attns = [], [seed], []
+        names = [k for k in contexts if not k.endswith('_mask') and not k.startswith('_')]
+        for _ in range(gen_len):
+            self.decoder.filter_incremental_state(state, keep)                      # :417
+            ctx_i = {}
+            for n in names:                                                         # :420-431
+                ctx_i[n] = contexts[n][:, alive]
+                ctx_i[n + '_mask'] = contexts[n + '_mask'][alive]
+            dec_out = self.decoder({self.index: cur[:, -1:]}, ctx_i, incremental_state=state)
+            attns.append(dec_out[1]['attn'])
+            tok, lp = self.decoder.adaptive_softmax.greedy(dec_out[0][:, -1:])      # :443-464
+            sel_ix = tok.long()
+            sel_lp = lp / self.sampling_temp
+            full_lp = sel_lp.new_zeros(B, 1)
+            full_lp[alive] = sel_lp
+            full_ix = sel_ix.new_full((B, 1), self.padding_idx)
+            full_ix[alive] = sel_ix
+            log_probs.append(full_lp)
+            paths.append(full_ix)
+            keep = sel_ix.squeeze(-1) != eos                                        # :476-483
+            alive = alive.clone()
+            alive[alive.nonzero().squeeze(1)[~keep]] = False
+            cur = torch.cat([cur, sel_ix], dim=1)[keep]
+            if int(keep.sum()) == 0:                                                # :485
+                break
+        return torch.cat(log_probs, dim=-1), torch.cat(paths, dim=-1), attns
+
+    def get_metrics(self, reset=False):                                             # :504-517
+        metrics = {'_n_batches': self.n_batches, '_n_samples': self.n_samples}
+        for key, value in self.sample_history.items():
+            metrics[key] = value / max(self.n_samples, 1)
+        if reset:
+            self.n_batches = 0
+            self.n_samples = 0
+            self.sample_history = defaultdict(float)
+        return metrics
+
+
+@Model.register('transformer_faces_objects')
+class TransformerFacesObjectModel(CaptionModel):
+    """tell/models/transformer_faces_objects.py:22-23"""
+    USE_FACES_OBJECTS = True
+
+
+@Model.register('transformer_flattened')
+class TransformerFlattenedModel(CaptionModel):
+    """tell/models/transformer_flattened.py:23-24"""
+    USE_FACES_OBJECTS = False

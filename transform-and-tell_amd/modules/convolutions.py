@@ -1,0 +1,46 @@
+"""tell/modules/convolutions/dynamic.py:25-361 on the MI355X path."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .linear import Linear
+
+_INSTANCES = [0]
+
+
+class DynamicConv1dTBC(nn.Module):
+    """Dynamic lightweight convolution, T x B x C, as the decoders configure it
+    (weight_softmax=True, padding_l=K-1 i.e. causal, no in_proj / renorm / conv bias)."""
+
+    def __init__(self, input_size, kernel_size=1, padding_l=None, num_heads=1, weight_dropout=0.,
+                 weight_softmax=True, renorm_padding=False, bias=False, conv_bias=False,
+                 query_size=None, in_proj=False):
+        super().__init__()
+        if not weight_softmax or renorm_padding or conv_bias or in_proj or query_size is not None \
+                or (padding_l is not None and padding_l != kernel_size - 1):
+            raise NotImplementedError('only the causal weight_softmax configuration used by the '
+                                      'expt/ decoders is implemented on the HIP path')
+        self.input_size, self.kernel_size, self.num_heads = input_size, kernel_size, num_heads
+        self.padding_l = kernel_size - 1
+        self.weight_dropout = weight_dropout
+        self.weight_linear = Linear(input_size, num_heads * kernel_size, bias=bias)
+        _INSTANCES[0] += 1
+        self._state_key = 'DynamicConv1dTBC.%d.input_buffer' % _INSTANCES[0]   # tell/utils/state.py:21-34
+
+    def forward(self, X, incremental_state=None, query=None, unfold=None):
+        assert query is None
+        n_hist = 0
+        if incremental_state is not None:                            # dynamic.py:94-99
+            prev = incremental_state.get(self._state_key)
+            if prev is not None:
+                n_hist = prev.shape[0]
+                X = torch.cat([prev, X], dim=0)
+            incremental_state[self._state_key] = X[-self.kernel_size + 1:] if self.kernel_size > 1 else X[:0]
+        logits = self.weight_linear(X)
+        out = ops.dynamic_conv(X, logits, self.num_heads, self.kernel_size, self.weight_dropout, self.training)
+        return out[n_hist:] if n_hist else out                       # dynamic.py:115-116
+
+    def reorder_incremental_state(self, incremental_state, new_order):
+        buf = incremental_state.get(self._state_key)
+        if buf is not None:
+            incremental_state[self._state_key] = buf.index_select(1, new_order)

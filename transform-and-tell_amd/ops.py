@@ -1,0 +1,736 @@
+"""Functional ops of the MI355X path: thin `torch.autograd.Function`s whose forward
+and backward are sequences of C-ABI kernel launches (hip.call).  torch supplies
+device memory, the current stream and the autograd graph; no arithmetic of the
+hot path is done by ATen here.
+
+Gradient convention: parameters are fp32 masters.  Backward kernels accumulate
+weight gradients *directly* into the parameter's fp32 gradient buffer
+(`grad_buffer(p)`, which is `p.grad`), the way fused wgrad accumulation works in
+large-model trainers; the Functions therefore return None for parameters.
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import hip
+from . import runtime as rt
+
+call = hip.call
+
+
+def _vec(dtype):
+    return 8 if dtype == torch.bfloat16 else 4
+
+
+def _round_up(n, m):
+    return (n + m - 1) // m * m
+
+
+def as2d(x):
+    """[..., C] -> [rows, C] with unit inner stride (row stride may exceed C)."""
+    x2 = x.reshape(-1, x.shape[-1])
+    return x2 if x2.stride(-1) == 1 else x2.contiguous()
+
+
+def as2dc(x):
+    return x.reshape(-1, x.shape[-1]).contiguous()
+
+
+def grad_buffer(p):
+    """fp32 gradient accumulator of a parameter (== p.grad)."""
+    if p.grad is None:
+        g = getattr(p, '_tell_grad', None)
+        if g is None or g.shape != p.shape or g.device != p.device:
+            g = torch.zeros_like(p)
+        else:
+            g.zero_()
+        p._tell_grad = g
+        p.grad = g
+    return p.grad
+
+
+# --------------------------------------------------------------------------- #
+# raw kernels
+# --------------------------------------------------------------------------- #
+def gemm(a, b, out=None, out_dtype=None, bias=None, bias_mode=0, act=0, aux=None, alpha=1.0,
+         accumulate=False, m_dev=None):
+    """out[M,N] = act((a[M,K] @ b[N,K]^T + bias) * alpha) (+ out).  K is zero padded to a
+    16-byte multiple when needed (only reduced-size test shapes take that path)."""
+    assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1] and a.dtype == b.dtype, \
+        (a.shape, b.shape, a.dtype, b.dtype)
+    M, K = a.shape
+    N = b.shape[0]
+    v = _vec(a.dtype)
+
+    def fix(t):
+        if t.stride(1) != 1 or t.stride(0) % v or t.shape[1] % v or t.data_ptr() % 16:
+            tp = torch.zeros(t.shape[0], _round_up(t.shape[1], v), dtype=t.dtype, device=t.device)
+            tp[:, :t.shape[1]] = t
+            return tp
+        return t
+    a, b = fix(a), fix(b)
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype or a.dtype, device=a.device)
+    assert out.stride(1) == 1
+    call('tell_gemm_nt', a, a.stride(0), b, b.stride(0), out, out.stride(0), M, N, a.shape[1], hip.dt(a),
+         hip.dt(out), bias, bias_mode, act, aux, float(alpha), int(accumulate), m_dev)
+    return out
+
+
+def transpose(x, out_dtype=None, row_scale=None, want_plain=False, want_t=True):
+    """-> (x^T [C, R padded to a chunk multiple, zero filled], plain copy or None)."""
+    R, C = x.shape
+    od = out_dtype or x.dtype
+    v = _vec(od)
+    xt = None
+    if want_t:
+        Rp = _round_up(R, v)
+        xt = (torch.zeros if Rp != R else torch.empty)(C, Rp, dtype=od, device=x.device)
+    plain = torch.empty(R, C, dtype=od, device=x.device) if want_plain else None
+    call('tell_transpose', x, x.stride(0), hip.dt(x), xt, xt.stride(0) if want_t else 0, plain,
+         plain.stride(0) if want_plain else 0, hip.dt(od), row_scale, R, C)
+    return xt, plain
+
+
+def cast(x, dtype):
+    if x.dtype == dtype:
+        return x
+    x = x.contiguous()
+    y = torch.empty_like(x, dtype=dtype)
+    call('tell_cast', x, hip.dt(x), y, hip.dt(y), x.numel())
+    return y
+
+
+def colsum_into(x2, out, scale=1.0, m_dev=None):
+    call('tell_colsum', x2, x2.stride(0), x2.shape[0], x2.shape[1], hip.dt(x2), out, 1, m_dev, float(scale))
+
+
+# --------------------------------------------------------------------------- #
+# working copies of weights (compute dtype), cached per weights epoch
+# --------------------------------------------------------------------------- #
+_wcache = {}
+
+
+def _cached(p, key, maker):
+    k = (id(p), key)
+    stamp = (rt.weights_epoch(), rt.compute_dtype(), p._version, p.data_ptr())
+    e = _wcache.get(k)
+    if e is None or e[0] != stamp:
+        e = (stamp, maker())
+        _wcache[k] = e
+    return e[1]
+
+
+def clear_weight_cache():
+    _wcache.clear()
+
+
+def weight(p, rows=None):
+    """Working copy [N,K] (compute dtype) of fp32 parameter rows p[r0:r1]."""
+    def make():
+        src = p.detach() if rows is None else p.detach()[rows[0]:rows[1]]
+        src = src.reshape(src.shape[0], -1)
+        return cast(src, rt.compute_dtype()) if rt.compute_dtype() != torch.float32 else src.contiguous()
+    return _cached(p, ('w', rows), make)
+
+
+def weight_t(p, rows=None):
+    """Transposed working copy [K, N padded] for dX = dY . W."""
+    def make():
+        src = p.detach() if rows is None else p.detach()[rows[0]:rows[1]]
+        return transpose(src.reshape(src.shape[0], -1), out_dtype=rt.compute_dtype())[0]
+    return _cached(p, ('wt', rows), make)
+
+
+def wn_weight(g, v):
+    """Weight-normalised working weight (tell/modules/linear.py:33): (w, w^T, norms)."""
+    def make():
+        R, C = v.shape
+        scale = torch.empty(R, dtype=torch.float32, device=v.device)
+        norms = torch.empty(R, dtype=torch.float32, device=v.device)
+        call('tell_wn_rowscale', g.detach(), v.detach(), R, C, scale, norms)
+        wt, w = transpose(v.detach(), out_dtype=rt.compute_dtype(), row_scale=scale, want_plain=True)
+        return w, wt, norms
+    return _cached(v, ('wn', g._version, g.data_ptr()), make)
+
+
+# --------------------------------------------------------------------------- #
+# Linear layers
+# --------------------------------------------------------------------------- #
+class LinearFn(Function):
+    """y = act((x W[rows]^T + b[rows]) * alpha); plain (xavier) weights: attention
+    projections (multi_head.py:488-526), DynamicConv tap projection (dynamic.py:300)."""
+
+    @staticmethod
+    def forward(ctx, x, w_param, b_param, rows, act, alpha, need_dx, x_t=None, b_rows=None):
+        x2 = as2d(x)
+        w = weight(w_param, rows)
+        if b_rows is None:
+            b_rows = rows
+        b = None
+        if b_param is not None:
+            b = b_param.detach() if b_rows is None else b_param.detach()[b_rows[0]:b_rows[1]]
+        y = gemm(x2, w, bias=b, bias_mode=1 if b is not None else 0, act=act, alpha=alpha)
+        ctx.save_for_backward(x2, y if act == 1 else None, x_t)
+        ctx.meta = (w_param, b_param, rows, act, alpha, need_dx, x.shape, b_rows)
+        return y.view(*x.shape[:-1], y.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, y, x_t = ctx.saved_tensors
+        w_param, b_param, rows, act, alpha, need_dx, xshape, b_rows = ctx.meta
+        dy2 = as2dc(dy) if act == 1 else as2d(dy)
+        if act == 1:
+            d = torch.empty_like(dy2)
+            call('tell_relu_bwd', dy2, y, d, dy2.numel(), hip.dt(dy2))
+            dy2 = d
+        r0, r1 = rows if rows is not None else (0, w_param.shape[0])
+        if w_param.requires_grad:
+            dyT, _ = transpose(dy2)
+            xT = x_t if x_t is not None else transpose(x2)[0]
+            gw = grad_buffer(w_param)
+            gemm(dyT, xT, out=gw.view(gw.shape[0], -1)[r0:r1], alpha=alpha, accumulate=True)
+        if b_param is not None and b_param.requires_grad:
+            gb = grad_buffer(b_param)
+            colsum_into(dy2, gb if b_rows is None else gb[b_rows[0]:b_rows[1]], scale=alpha)
+        dx = None
+        if need_dx:
+            dx = gemm(dy2, weight_t(w_param, rows), alpha=alpha)[:, :x2.shape[1]]
+            dx = dx.reshape(xshape) if dx.is_contiguous() else dx.contiguous().view(xshape)
+        return dx, None, None, None, None, None, None, None, None
+
+
+def linear(x, w_param, b_param=None, rows=None, act=0, alpha=1.0, x_t=None, b_rows=None):
+    """x_t: optional precomputed transpose of as2d(x) (shared by several projections of one context)."""
+    return LinearFn.apply(x, w_param, b_param, rows, act, alpha, x.requires_grad, x_t, b_rows)
+
+
+class WNLinearFn(Function):
+    """GehringLinear (tell/modules/linear.py:8-33): y = act(x (g v/||v||)^T + b)."""
+
+    @staticmethod
+    def forward(ctx, x, g, v, b, act, need_dx):
+        x2 = as2d(x)
+        w, _, norms = wn_weight(g, v)
+        y = gemm(x2, w, bias=b.detach() if b is not None else None, bias_mode=1 if b is not None else 0,
+                 act=act)
+        ctx.save_for_backward(x2, y if act == 1 else None)
+        ctx.meta = (g, v, b, act, need_dx, x.shape)
+        return y.view(*x.shape[:-1], y.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, y = ctx.saved_tensors
+        g, v, b, act, need_dx, xshape = ctx.meta
+        dy2 = as2dc(dy) if act == 1 else as2d(dy)
+        if act == 1:
+            d = torch.empty_like(dy2)
+            call('tell_relu_bwd', dy2, y, d, dy2.numel(), hip.dt(dy2))
+            dy2 = d
+        _, wt, norms = wn_weight(g, v)
+        if v.requires_grad:
+            dyT, _ = transpose(dy2)
+            xT, _ = transpose(x2)
+            dW = gemm(dyT, xT, out_dtype=torch.float32)
+            call('tell_wn_backward', dW, g.detach(), v.detach(), norms, v.shape[0], v.shape[1],
+                 grad_buffer(g), grad_buffer(v))
+        if b is not None and b.requires_grad:
+            colsum_into(dy2, grad_buffer(b))
+        dx = None
+        if need_dx:
+            dx = gemm(dy2, wt)[:, :x2.shape[1]]
+            dx = dx.reshape(xshape) if dx.is_contiguous() else dx.contiguous().view(xshape)
+        return dx, None, None, None, None, None
+
+
+def wn_linear(x, g, v, b=None, act=0):
+    return WNLinearFn.apply(x, g, v, b, act, x.requires_grad)
+
+
+# --------------------------------------------------------------------------- #
+# elementwise
+# --------------------------------------------------------------------------- #
+class GLUFn(Function):
+    @staticmethod
+    def forward(ctx, h):
+        h2 = as2dc(h)
+        C = h2.shape[1] // 2
+        y = torch.empty(h2.shape[0], C, dtype=h.dtype, device=h.device)
+        call('tell_glu_fwd', h2, y, h2.shape[0], C, hip.dt(h2))
+        ctx.save_for_backward(h2)
+        ctx.shape = h.shape
+        return y.view(*h.shape[:-1], C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        h2, = ctx.saved_tensors
+        dy2 = as2dc(dy)
+        dh = torch.empty_like(h2)
+        call('tell_glu_bwd', h2, dy2, dh, h2.shape[0], h2.shape[1] // 2, hip.dt(h2))
+        return dh.view(ctx.shape)
+
+
+def glu(h):
+    return GLUFn.apply(h)
+
+
+class DropoutFn(Function):
+    @staticmethod
+    def forward(ctx, x, p, salt):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        call('tell_dropout', x, y, x.numel(), float(p), rt.seed(), salt, hip.dt(x))
+        ctx.p, ctx.salt = p, salt
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        call('tell_dropout', dy, dx, dy.numel(), float(ctx.p), rt.seed(), ctx.salt, hip.dt(dy))
+        return dx, None, None
+
+
+def dropout(x, p, training, salt=None):
+    if not training or p <= 0:
+        return x
+    return DropoutFn.apply(x, p, rt.next_salt() if salt is None else salt)
+
+
+class LayerNormFn(Function):
+    """y = LayerNorm(res + dropout(x)) (post-LN residual blocks,
+    decoder_faces_objects.py:263-266 and :283-287)."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps, p, salt):
+        x2 = as2d(x)
+        r2 = as2d(res) if res is not None else None
+        rows, C = x2.shape
+        y = torch.empty(rows, C, dtype=x.dtype, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        call('tell_layernorm_fwd', x2, x2.stride(0), r2, r2.stride(0) if r2 is not None else 0,
+             gamma.detach(), beta.detach(), y, y.stride(0), mean, rstd, rows, C, float(eps), float(p),
+             rt.seed(), salt, hip.dt(x2))
+        ctx.save_for_backward(x2, r2, mean, rstd)
+        ctx.meta = (gamma, beta, p, salt, x.shape, res is not None and res.requires_grad, x.requires_grad)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, r2, mean, rstd = ctx.saved_tensors
+        gamma, beta, p, salt, shape, need_dres, need_dx = ctx.meta
+        dy2 = as2d(dy)
+        rows, C = x2.shape
+        nb = hip.lib().tell_layernorm_bwd_blocks(rows)
+        partial = torch.empty(nb * 2 * C, dtype=torch.float32, device=x2.device)
+        dx = torch.empty_like(x2) if need_dx else None
+        same = (p <= 0) and need_dx
+        dres = None
+        if need_dres and r2 is not None:
+            dres = dx if same else torch.empty_like(x2)
+        call('tell_layernorm_bwd', dy2, dy2.stride(0), x2, x2.stride(0), r2,
+             r2.stride(0) if r2 is not None else 0, gamma.detach(), mean, rstd,
+             dx, dx.stride(0) if dx is not None else 0,
+             None if (dres is None or same) else dres, dres.stride(0) if dres is not None else 0, 0,
+             grad_buffer(gamma), grad_buffer(beta), 1, partial, rows, C, float(p), rt.seed(), salt,
+             hip.dt(x2))
+        return (dx.view(shape) if dx is not None else None,
+                dres.view(shape) if dres is not None else None, None, None, None, None, None)
+
+
+def layer_norm(x, res, gamma, beta, eps=1e-5, p=0.0, training=False):
+    p = p if training else 0.0
+    return LayerNormFn.apply(x, res, gamma, beta, eps, p, rt.next_salt() if p > 0 else 0)
+
+
+# --------------------------------------------------------------------------- #
+# DynamicConv core
+# --------------------------------------------------------------------------- #
+class DynConvFn(Function):
+    @staticmethod
+    def forward(ctx, x, logits, H, K, p, salt):
+        x = x.contiguous()
+        logits = logits.contiguous()
+        T, B, C = x.shape
+        y = torch.empty_like(x)
+        taps = torch.empty(T * B * H, K, dtype=torch.float32, device=x.device)
+        call('tell_dynconv_fwd', x, logits, y, taps, T, B, H, K, C // H, float(p), rt.seed(), salt, hip.dt(x))
+        ctx.save_for_backward(x, taps)
+        ctx.meta = (H, K, p, salt)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, taps = ctx.saved_tensors
+        H, K, p, salt = ctx.meta
+        T, B, C = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dlogits = torch.empty(T, B, H * K, dtype=x.dtype, device=x.device)
+        call('tell_dynconv_bwd', x, dy, taps, dx, 0, dlogits, T, B, H, K, C // H, float(p), rt.seed(), salt,
+             hip.dt(x))
+        return dx, dlogits, None, None, None, None
+
+
+def dynamic_conv(x, logits, H, K, p=0.0, training=False):
+    p = p if training else 0.0
+    return DynConvFn.apply(x, logits, H, K, p, rt.next_salt() if p > 0 else 0)
+
+
+# --------------------------------------------------------------------------- #
+# attention core
+# --------------------------------------------------------------------------- #
+def _kv_strides(t, S, B):
+    """t: [S, B, E] view (any strides, last dim contiguous) -> (ptr tensor, s-stride, b-stride)."""
+    assert t.stride(2) == 1
+    return t.stride(0), t.stride(1)
+
+
+class AttnFn(Function):
+    """softmax(q k^T + mask) v with the virtual bias_k/bias_v row and zero row.
+    q: [T,B,E] (already scaled); k, v: [S,B,E] views; mask: [B,S] uint8 or None."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, bias_k, bias_v, H, has_zero, p, salt):
+        T, B, E = q.shape
+        S = k.shape[0]
+        D = E // H
+        if q.stride(2) != 1:
+            q = q.contiguous()
+        out = torch.empty(T, B, E, dtype=q.dtype, device=q.device)
+        lse = torch.empty(B * H, T, dtype=torch.float32, device=q.device)
+        bk = cast(bias_k.detach().reshape(-1), q.dtype) if bias_k is not None else None
+        bv = cast(bias_v.detach().reshape(-1), q.dtype) if bias_v is not None else None
+        if S == 0:      # empty context (multi_head.py:349-374): only the virtual rows remain
+            k = v = q.new_zeros(1, B, E)
+        call('tell_attn_fwd', q, k, v, out, lse, mask, bk, bv, B, H, T, S, D, q.stride(0), q.stride(1),
+             k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1),
+             int(has_zero), float(p), rt.seed(), salt, hip.dt(q))
+        ctx.save_for_backward(q, k, v, out, lse, mask, bk, bv)
+        ctx.meta = (bias_k, bias_v, H, has_zero, p, salt, S)
+        ctx.mark_non_differentiable(lse)
+        return out, lse
+
+    @staticmethod
+    def backward(ctx, dout, _dlse):
+        q, k, v, out, lse, mask, bk, bv = ctx.saved_tensors
+        bias_k, bias_v, H, has_zero, p, salt, S = ctx.meta
+        T, B, E = q.shape
+        D = E // H
+        dout = dout.contiguous()
+        dq = torch.empty_like(q)
+        dbk = torch.zeros(B, E, dtype=torch.float32, device=q.device) if bk is not None else None
+        dbv = torch.zeros(B, E, dtype=torch.float32, device=q.device) if bk is not None else None
+        # dk/dv share k's / v's strides (the kernel uses one stride set for K and dK);
+        # empty_like keeps the strides of dense permuted views ([B,S,E] storage seen as [S,B,E])
+        kc, vc = k, v
+        dk, dv = torch.empty_like(kc), torch.empty_like(vc)
+        if dk.stride() != kc.stride():
+            kc = k.contiguous()
+            dk = torch.empty_like(kc)
+        if dv.stride() != vc.stride():
+            vc = v.contiguous()
+            dv = torch.empty_like(vc)
+        call('tell_attn_bwd', q, kc, vc, out, dout, lse, mask, bk, bv, dq, dk, dv, dbk, dbv, B, H, T, S, D,
+             q.stride(0), q.stride(1), kc.stride(0), kc.stride(1), vc.stride(0), vc.stride(1),
+             out.stride(0), out.stride(1), int(has_zero), float(p), rt.seed(), salt, hip.dt(q))
+        if bias_k is not None and bias_k.requires_grad:
+            colsum_into(dbk, grad_buffer(bias_k).view(-1))
+            colsum_into(dbv, grad_buffer(bias_v).view(-1))
+        return dq, dk if S > 0 else None, dv if S > 0 else None, None, None, None, None, None, None, None
+
+
+def attention_avg_weights(q, k, mask, bias_k, lse, H, has_zero=True):
+    """Head-averaged attention weights [B,T,S'] (multi_head.py:478-482), recomputed from q, k and
+    the saved log-sum-exp; evaluation / demo only (need_weights)."""
+    T, B, E = q.shape
+    S = k.shape[0]
+    S_total = S + (1 if bias_k is not None else 0) + int(has_zero)
+    w = torch.empty(B, T, S_total, dtype=torch.float32, device=q.device)
+    bk = cast(bias_k.detach().reshape(-1), q.dtype) if bias_k is not None else None
+    call('tell_attn_avg_weights', q, k, lse, mask, bk, w, B, H, T, S, E // H, q.stride(0), q.stride(1),
+         k.stride(0), k.stride(1), int(has_zero), hip.dt(q))
+    return w
+
+
+def attention(q, k, v, mask, bias_k, bias_v, H, has_zero=True, p=0.0, training=False, return_lse=False):
+    p = p if training else 0.0
+    out, lse = AttnFn.apply(q, k, v, mask, bias_k, bias_v, H, has_zero, p, rt.next_salt() if p > 0 else 0)
+    return (out, lse) if return_lse else out
+
+
+# --------------------------------------------------------------------------- #
+# RoBERTa layer mix
+# --------------------------------------------------------------------------- #
+class MixFn(Function):
+    """sum_l softmax(w)[l] * H[l]  (transformer_faces_objects.py:355-364)."""
+
+    @staticmethod
+    def forward(ctx, stack, w):
+        L = stack.shape[0]
+        n = stack[0].numel()
+        out = torch.empty_like(stack[0])
+        call('tell_mix_fwd', stack, w.detach(), L, n, out, hip.dt(stack))
+        ctx.save_for_backward(stack)
+        ctx.w = w
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        stack, = ctx.saved_tensors
+        w = ctx.w
+        L = stack.shape[0]
+        n = stack[0].numel()
+        nb = 512
+        partial = torch.empty(nb, L, dtype=torch.float32, device=stack.device)
+        call('tell_mix_bwd', stack, dout.contiguous(), L, n, partial, nb, hip.dt(stack))
+        dsm = torch.zeros(L, dtype=torch.float32, device=stack.device)       # d loss / d softmax(w)
+        colsum_into(partial, dsm)
+        # softmax backward over 25 scalars: host-side plumbing on a 25-vector
+        sm = torch.softmax(w.detach().float(), dim=0)
+        gw = grad_buffer(w)
+        gw.add_(sm * (dsm - (sm * dsm).sum()))
+        return None, None
+
+
+def mix_layers(stack, w):
+    return MixFn.apply(stack, w)
+
+
+# --------------------------------------------------------------------------- #
+# adaptive input embedding (+ sinusoidal positions)
+# --------------------------------------------------------------------------- #
+def partition_ids(ids_flat, cutoffs, pad_idx, want_slot=True, want_head_target=False):
+    """Device-side band partition of int64 ids (replaces the mask/nonzero logic of
+    adaptive.py:64-74 and softmax.py:144-167).  No host synchronisation."""
+    import ctypes
+    N = ids_flat.numel()
+    nb = len(cutoffs)
+    dev = ids_flat.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    part = {
+        'rows': torch.empty(nb, N, **i32), 'local': torch.empty(nb, N, **i32),
+        'count': torch.empty(nb, **i32), 'slot': torch.empty(N, **i32) if want_slot else None,
+        'head_target': torch.empty(N, **i32) if want_head_target else None,
+        'n_valid': torch.empty(1, **i32), 'N': N,
+    }
+    cut = (ctypes.c_int * nb)(*[int(c) for c in cutoffs])
+    call('tell_adaptive_partition', ids_flat, N, ctypes.cast(cut, ctypes.c_void_p).value, nb, int(pad_idx),
+         part['rows'], part['local'], part['count'], part['slot'], part['head_target'], part['n_valid'])
+    return part
+
+
+class AdaptiveEmbedFn(Function):
+    """scale * proj_band(emb_band[id - lo]) + sinusoid[position]  written directly in the
+    decoder's T x B x C layout (adaptive.py:61-76, positional.py:167-211,
+    sum_text_field_embedder.py:117-118)."""
+
+    @staticmethod
+    def forward(ctx, ids, pos_table, cutoffs, scale, pos_pad, start_pos, padding_idx, *tables):
+        # tables = emb_0, proj_0, emb_1, proj_1, ...
+        B, T = ids.shape
+        N = B * T
+        nb = len(cutoffs)
+        dtype = rt.compute_dtype()
+        E = tables[1].shape[0]
+        ids_flat = ids.reshape(-1).contiguous()
+        part = partition_ids(ids_flat, cutoffs, pad_idx=-1)
+        band_out = torch.empty(nb * N, E, dtype=dtype, device=ids.device)
+        rows_saved = []
+        for b in range(nb):
+            emb, proj = tables[2 * b], tables[2 * b + 1]
+            dim = emb.shape[1]
+            rows_b = torch.zeros(N, dim, dtype=dtype, device=ids.device)   # rows >= count must be 0, not garbage
+            call('tell_gather_rows', weight(emb), dim, part['local'][b], part['count'][b:b + 1], N, rows_b, dim,
+                 dim, hip.dt(dtype))
+            gemm(rows_b, weight(proj), out=band_out[b * N:(b + 1) * N], m_dev=part['count'][b:b + 1])
+            rows_saved.append(rows_b)
+        out = torch.empty(T, B, E, dtype=dtype, device=ids.device)
+        call('tell_embed_finalize', band_out, part['slot'], ids_flat, pos_table, pos_table.shape[0], out, B, T, E,
+             float(scale), int(pos_pad), int(start_pos), 1, hip.dt(dtype))
+        ctx.part, ctx.rows_saved, ctx.tables = part, rows_saved, tables
+        ctx.meta = (B, T, E, nb, scale, padding_idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        part, rows_saved, tables = ctx.part, ctx.rows_saved, ctx.tables
+        B, T, E, nb, scale, padding_idx = ctx.meta
+        N = B * T
+        dout = dout.contiguous()
+        dband = torch.zeros(nb * N, E, dtype=dout.dtype, device=dout.device)
+        call('tell_embed_finalize_bwd', dout, part['slot'], dband, B, T, E, float(scale), 1, hip.dt(dout))
+        for b in range(nb):
+            emb, proj = tables[2 * b], tables[2 * b + 1]
+            dim = emb.shape[1]
+            cnt = part['count'][b:b + 1]
+            dy = dband[b * N:(b + 1) * N]                      # rows >= count are zero
+            if proj.requires_grad:
+                dyT, _ = transpose(dy)
+                rT, _ = transpose(rows_saved[b])
+                gemm(dyT, rT, out=grad_buffer(proj), accumulate=True)
+            if emb.requires_grad:
+                drows = gemm(dy, weight_t(proj), m_dev=cnt)[:, :dim]
+                if not drows.is_contiguous():
+                    drows = drows.contiguous()
+                call('tell_embed_table_grad', drows, drows.stride(0), part['local'][b], cnt, N,
+                     grad_buffer(emb), dim, int(padding_idx), hip.dt(drows))
+        return (None,) * (7 + len(tables))
+
+
+def adaptive_embed(ids, pos_table, cutoffs, scale, pos_pad, start_pos, padding_idx, tables):
+    return AdaptiveEmbedFn.apply(ids, pos_table, tuple(cutoffs), scale, pos_pad, start_pos, padding_idx,
+                                 *tables)
+
+
+# --------------------------------------------------------------------------- #
+# adaptive softmax loss
+# --------------------------------------------------------------------------- #
+def _pad8(n):
+    return _round_up(n, 8)
+
+
+class AdaptiveLossFn(Function):
+    """sum of per-cluster cross entropies (softmax.py:144-191 + adaptive_loss.py:27-73),
+    returned in nats together with sample_size as DEVICE scalars.  Static shapes:
+    tail rows are compacted on the device, tail GEMMs run with a device row count."""
+
+    @staticmethod
+    def forward(ctx, x, target, cutoffs, pad_idx, emb0, class_proj, *tails):
+        # tails = proj_0, emb_1, proj_1, emb_2, ...   (tail i: logits = emb_{i+1} (proj_i x))
+        N, E = x.shape[0] * x.shape[1], x.shape[2]
+        dtype = x.dtype
+        dev = x.device
+        x2 = as2dc(x)
+        n_tails = len(tails) // 2
+        c0 = cutoffs[0]
+        tflat = target.reshape(-1).contiguous()
+        part = partition_ids(tflat, cutoffs, pad_idx=pad_idx, want_slot=False, want_head_target=True)
+        # ---- head: [emb0 ; class_proj] x
+        n_head = c0 + n_tails
+        w_head = torch.empty(n_head, E, dtype=dtype, device=dev)
+        w_head[:c0] = weight(emb0)
+        w_head[c0:] = weight(class_proj)
+        head_logits = gemm(x2, w_head, out_dtype=torch.float32)
+        lse_h = torch.empty(N, dtype=torch.float32, device=dev)
+        loss_rows = torch.empty(N, dtype=torch.float32, device=dev)
+        call('tell_ce_fwd', head_logits, head_logits.stride(0), N, n_head, part['head_target'], None, None,
+             int(pad_idx), lse_h, loss_rows)
+        total = torch.zeros(1, dtype=torch.float32, device=dev)
+        call('tell_sum_f32', loss_rows, N, None, total, 1)
+        saved_tails = []
+        for i in range(n_tails):
+            proj, emb = tails[2 * i], tails[2 * i + 1]
+            band = i + 1
+            cnt = part['count'][band:band + 1]
+            xg = torch.zeros(N, E, dtype=dtype, device=dev)
+            call('tell_gather_rows', x2, E, part['rows'][band], cnt, N, xg, E, E, hip.dt(dtype))
+            h = torch.zeros(N, proj.shape[0], dtype=dtype, device=dev)
+            gemm(xg, weight(proj), out=h, m_dev=cnt)
+            V = emb.shape[0]
+            logits = torch.empty(N, V, dtype=torch.float32, device=dev)
+            gemm(h, weight(emb), out=logits, m_dev=cnt)
+            lse_t = torch.empty(N, dtype=torch.float32, device=dev)
+            lrow = torch.empty(N, dtype=torch.float32, device=dev)
+            # target of compacted row j is local[band][j]; quirk: ignore_index also applies here
+            call('tell_ce_fwd', logits, logits.stride(0), N, V, part['local'][band], None, cnt, int(pad_idx),
+                 lse_t, lrow)
+            call('tell_sum_f32', lrow, N, cnt, total, 1)
+            saved_tails.append((xg, h, logits, lse_t))
+        ctx.saved = (x2, w_head, head_logits, lse_h, part, saved_tails)
+        ctx.params = (emb0, class_proj, tails, cutoffs, pad_idx)
+        ctx.xshape = x.shape
+        ctx.mark_non_differentiable(part['n_valid'])
+        return total, part['n_valid']
+
+    @staticmethod
+    def backward(ctx, gtotal, _gn):
+        x2, w_head, head_logits, lse_h, part, saved_tails = ctx.saved
+        emb0, class_proj, tails, cutoffs, pad_idx = ctx.params
+        N, E = x2.shape
+        dtype, dev = x2.dtype, x2.device
+        c0 = cutoffs[0]
+        n_tails = len(tails) // 2
+        n_head = c0 + n_tails
+        gscale = gtotal.reshape(1).float().contiguous()
+        # ---- head
+        dl = torch.zeros(N, _round_up(n_head, _vec(dtype)), dtype=dtype, device=dev)
+        call('tell_ce_bwd', head_logits, head_logits.stride(0), N, n_head, part['head_target'], None, None,
+             int(pad_idx), lse_h, gscale, dl, dl.stride(0), hip.dt(dtype))
+        w_head_t, _ = transpose(w_head)                           # [E, n_head padded]
+        if w_head_t.shape[1] != dl.shape[1]:
+            wt2 = torch.zeros(E, dl.shape[1], dtype=dtype, device=dev)
+            wt2[:, :w_head_t.shape[1]] = w_head_t
+            w_head_t = wt2
+        dx = gemm(dl, w_head_t)                                   # [N, E]
+        dlT, _ = transpose(dl[:, :n_head])                        # [n_head, N]
+        xT, _ = transpose(x2)
+        if emb0.requires_grad:
+            gemm(dlT[:c0], xT, out=grad_buffer(emb0), accumulate=True)
+        if class_proj.requires_grad:
+            gemm(dlT[c0:n_head], xT, out=grad_buffer(class_proj), accumulate=True)
+        # ---- tails
+        for i in range(n_tails):
+            proj, emb = tails[2 * i], tails[2 * i + 1]
+            band = i + 1
+            cnt = part['count'][band:band + 1]
+            xg, h, logits, lse_t = saved_tails[i]
+            V = emb.shape[0]
+            dlt = torch.zeros(N, _round_up(V, _vec(dtype)), dtype=dtype, device=dev)
+            call('tell_ce_bwd', logits, logits.stride(0), N, V, part['local'][band], None, cnt, int(pad_idx),
+                 lse_t, gscale, dlt, dlt.stride(0), hip.dt(dtype))
+            emb_t = weight_t(emb)                                  # [dim, V padded]
+            if emb_t.shape[1] != dlt.shape[1]:
+                et = torch.zeros(emb_t.shape[0], dlt.shape[1], dtype=dtype, device=dev)
+                et[:, :emb_t.shape[1]] = emb_t
+                emb_t = et
+            dh = torch.zeros(N, proj.shape[0], dtype=dtype, device=dev)
+            gemm(dlt, emb_t, out=dh, m_dev=cnt)
+            dltT, _ = transpose(dlt[:, :V])                        # [V, N]; rows >= count of dlt are zero
+            hT, _ = transpose(h)
+            if emb.requires_grad:
+                gemm(dltT, hT, out=grad_buffer(emb), accumulate=True)
+            if proj.requires_grad:
+                dhT, _ = transpose(dh)
+                xgT, _ = transpose(xg)
+                gemm(dhT, xgT, out=grad_buffer(proj), accumulate=True)
+            dxg = gemm(dh, weight_t(proj), m_dev=cnt)[:, :E]
+            if not dxg.is_contiguous():
+                dxg = dxg.contiguous()
+            call('tell_scatter_add_rows', dxg, dxg.stride(0), part['rows'][band], cnt, N, dx, dx.stride(0), E,
+                 hip.dt(dtype))
+        return (dx.view(ctx.xshape),) + (None,) * (5 + len(tails))
+
+
+def adaptive_loss(x, target, cutoffs, pad_idx, emb0, class_proj, tails):
+    """-> (loss_sum_nats [1] fp32 device tensor, n_valid [1] int32 device tensor)."""
+    return AdaptiveLossFn.apply(x, target, tuple(cutoffs), pad_idx, emb0, class_proj, *tails)
+
+
+def adaptive_log_probs(x2, cutoffs, emb0, class_proj, tails, want_full=False):
+    """Generation head (softmax.py:193-222 + topk(1)): -> (token int32 [N], logprob fp32 [N], full or None)."""
+    N, E = x2.shape
+    dev = x2.device
+    c0 = cutoffs[0]
+    n_tails = len(tails) // 2
+    w_head = _cached(emb0, ('whead', class_proj._version, class_proj.data_ptr()), lambda: torch.cat(
+        [weight(emb0), weight(class_proj)], dim=0).contiguous())
+    head = gemm(x2, w_head, out_dtype=torch.float32)
+    tl, ld, nn_ = [None] * 3, [0] * 3, [0] * 3
+    for i in range(n_tails):
+        proj, emb = tails[2 * i], tails[2 * i + 1]
+        h = gemm(x2, weight(proj))
+        tl[i] = gemm(h, weight(emb), out_dtype=torch.float32)
+        ld[i], nn_[i] = tl[i].stride(0), tl[i].shape[1]
+    vocab = c0 + sum(nn_)
+    full = torch.empty(N, vocab, dtype=torch.float32, device=dev) if want_full else None
+    token = torch.empty(N, dtype=torch.int32, device=dev)
+    token_lp = torch.empty(N, dtype=torch.float32, device=dev)
+    call('tell_adaptive_logprob_argmax', head, head.stride(0), c0, n_tails, tl[0], ld[0], nn_[0], tl[1], ld[1],
+         nn_[1], tl[2], ld[2], nn_[2], N, full, vocab if want_full else 0, token, token_lp)
+    return token, token_lp, full
+
+
+LN2 = math.log(2.0)

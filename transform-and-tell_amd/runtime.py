@@ -1,0 +1,45 @@
+"""Process-wide runtime state of the MI355X path: compute dtype, dropout RNG
+counters, weight-cache epoch.  PyTorch is used only as the device-memory /
+stream / autograd-graph plumbing around the HIP kernels."""
+import torch
+
+_state = {
+    'dtype': torch.bfloat16,   # activations / working weights; torch.float32 = exact parity mode
+    'seed': 0x5EED,
+    'salt': 0,
+    'epoch': 0,                # bumped whenever master weights change (optimizer step / load)
+}
+
+
+def compute_dtype():
+    return _state['dtype']
+
+
+def set_compute_dtype(dtype):
+    assert dtype in (torch.float32, torch.bfloat16)
+    _state['dtype'] = dtype
+    bump_weights_epoch()
+
+
+def manual_seed(seed, salt=0):
+    """Seed of the counter-based dropout RNG (csrc/common.h tell_hash32)."""
+    _state['seed'] = int(seed) & 0xFFFFFFFF
+    _state['salt'] = int(salt) & 0xFFFFFFFF
+
+
+def next_salt():
+    """A fresh salt per dropout site per forward call; backward re-uses it."""
+    _state['salt'] = (_state['salt'] + 1) & 0xFFFFFFFF
+    return _state['salt']
+
+
+def seed():
+    return _state['seed']
+
+
+def weights_epoch():
+    return _state['epoch']
+
+
+def bump_weights_epoch():
+    _state['epoch'] += 1
