@@ -178,6 +178,8 @@ int tell_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int OH
 int tell_roberta_embed(const long* ids, int B, int S, int pad, const void* word, const void* posemb, int* pos_ws,
                        void* out, int E, int dtype, tell_stream_t stream);
 
+int tell_mask_rows(void* x, const uint8_t* mask, long rows, int C, int dtype, tell_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,93 @@
+"""GPU parity of the HIP ResNet / RoBERTa encoders against the oracle restatements (same weights)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(autouse=True)
+def _gpu():
+    import tell_amd
+    tell_amd.hip.require_gpu()
+    yield
+    torch.cuda.synchronize()
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-9)).item()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('train', [False, True])
+def test_resnet_matches_oracle(dtype, train):
+    import tell_amd
+    from oracle.encoders import ResNetFeatureExtractor as ORes
+    from tell_amd.models.resnet import ResNetFeatureExtractor as HRes
+    tell_amd.set_compute_dtype(dtype)
+    torch.manual_seed(0)
+    ora = ORes((2, 2, 1, 1), width=16)
+    for m in ora.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+            m.running_mean.normal_(0, 0.3)
+            m.running_var.uniform_(0.5, 2.0)
+    hipm = HRes((2, 2, 1, 1), width=16)
+    hipm.load_state_dict(ora.state_dict())
+    hipm.to(DEV)
+    ora.train(train)
+    hipm.train(train)
+    img = torch.randn(3, 3, 224, 224)
+    with torch.no_grad():
+        ref = ora(img).permute(0, 2, 3, 1).reshape(3, 49, -1)
+    out = hipm(img.to(DEV))
+    assert out.shape == ref.shape
+    r = rel(out, ref)
+    assert r < (2e-4 if dtype == torch.float32 else (0.12 if train else 6e-2)), r
+    if train:      # batch statistics also update the running buffers (momentum 0.1, unbiased variance)
+        r2 = rel(hipm.layer1[0].bn2.running_var, ora.layer1[0].bn2.running_var)
+        r3 = rel(hipm.bn1.running_mean, ora.bn1.running_mean)
+        assert r2 < (1e-4 if dtype == torch.float32 else 3e-2) and r3 < (1e-4 if dtype == torch.float32 else 3e-2)
+
+
+def test_resnet152_full_shape():
+    import tell_amd
+    from tell_amd.models.resnet import resnet152
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    m = resnet152().to(DEV).train()
+    assert sum(p.numel() for p in m.parameters()) == 60192808
+    out = m(torch.randn(2, 3, 224, 224, device=DEV))
+    assert out.shape == (2, 49, 2048) and torch.isfinite(out.float()).all()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_roberta_matches_oracle(dtype):
+    import tell_amd
+    from oracle.encoders import RobertaEncoder as ORob
+    from tell_amd.models.roberta import RobertaEncoder as HRob
+    tell_amd.set_compute_dtype(dtype)
+    torch.manual_seed(1)
+    kw = dict(vocab=300, dim=128, ffn=256, layers=3, heads=2, max_positions=80)     # head_dim 64
+    ora = ORob(**kw).eval()
+    for p in ora.parameters():
+        if p.dim() == 1:
+            p.data.add_(0.1 * torch.randn_like(p))
+    hipm = HRob(**kw).eval()
+    hipm.load_state_dict(ora.state_dict())
+    hipm.to(DEV)
+    ids = torch.randint(3, 300, (3, 70))
+    ids[:, 0] = 0
+    ids[1, 50:] = 1
+    ids[2, 9:] = 1
+    with torch.no_grad():
+        ref = torch.stack(ora.extract_features(ids, return_all_hiddens=True))
+    out = hipm.extract_features(ids.to(DEV), return_all_hiddens=True)
+    assert out.shape == ref.shape
+    keep = (ids != 1)
+    for l in range(ref.shape[0]):
+        r = rel(out[l].cpu()[keep], ref[l][keep])
+        assert r < (2e-4 if dtype == torch.float32 else 4e-2), (l, r)
+    assert (out[0].cpu()[~keep] == 0).all()            # fairseq zeroes padded positions after the embedding LN

@@ -25,10 +25,30 @@ def tol(dtype):
 
 
 def close(a, b, dtype=torch.float32, scale=1.0, **kw):
-    t = tol(dtype)
-    t['atol'] *= scale
-    t.update(kw)
-    torch.testing.assert_close(a.detach().float().cpu(), b.detach().float().cpu(), **t)
+    a, b = torch.as_tensor(a).detach().float().cpu(), torch.as_tensor(b).detach().float().cpu()
+    if dtype == torch.float32:
+        t = tol(dtype)
+        t['atol'] *= scale
+        t.update(kw)
+        torch.testing.assert_close(a, b, **t)
+    else:
+        # bf16 compute: compare in norm (relative Frobenius error) + a loose element-wise bound
+        assert a.shape == b.shape, (a.shape, b.shape)
+        denom = b.norm().item() + 1e-6
+        rel = (a - b).norm().item() / denom
+        assert rel < kw.get('rtol', 3e-2), 'relative error %.4g' % rel
+        bound = 0.08 * (b.abs().max().item() + 1e-6) * max(scale, 1.0) ** 0.5 + 1e-3
+        assert (a - b).abs().max().item() < bound, ((a - b).abs().max().item(), bound)
+
+
+def check_fx(fx, key, got, dtype, scale=1.0, **kw):
+    """compare with a fixture entry, stored either in full ('out') or subsampled ('sub')"""
+    import seeded
+    if key in fx.get('out', {}):
+        close(got, fx['out'][key], dtype, scale, **kw)
+    else:
+        close(torch.from_numpy(seeded.subsample(got.detach().float().cpu().numpy())), fx['sub'][key], dtype,
+              scale, **kw)
 
 
 DTYPES = [torch.float32, torch.bfloat16]
@@ -166,9 +186,9 @@ def test_dynamic_conv_golden(golden, dtype, K, T):
     logits = ops.linear(x, w)
     y = ops.dynamic_conv(x, logits, 4, K)
     y.backward(fx['in']['gy'].to(DEV, dtype))
-    close(y, fx['out']['y'], dtype)
-    close(x.grad, fx['out']['gx'], dtype, scale=4)
-    close(w.grad, fx['out']['g_weight'], dtype, scale=8)
+    check_fx(fx, 'y', y, dtype)
+    check_fx(fx, 'gx', x.grad, dtype, scale=4)
+    check_fx(fx, 'g_weight', w.grad, dtype, scale=8)
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
@@ -331,7 +351,7 @@ def test_embedder_golden(golden, dtype):
     y.backward(fx['in']['gy'].to(DEV, dtype))
     close(y, fx['out']['y'], dtype, scale=4)
     for name, p in emb.named_parameters():
-        close(p.grad, fx['out']['g_' + name], dtype, scale=16)
+        check_fx(fx, 'g_' + name, p.grad, dtype, scale=16)
     st = {}
     inc = torch.cat([emb({'roberta': ids[:, t:t + 1]}, incremental_state=st) for t in range(ids.shape[1])], 1)
     close(inc, fx['out']['y_incremental'], dtype, scale=4)
@@ -345,7 +365,7 @@ def test_adaptive_softmax_golden(golden, dtype):
     tell_amd.set_compute_dtype(dtype)
     fx = golden('adaptive_softmax')
     emb = build_embedder(600, 32, (100, 300))
-    asm = AdaptiveSoftmax(600, 32, [100, 300], emb.token_embedder_adaptive)
+    asm = AdaptiveSoftmax(600, 32, [100, 300], adaptive_inputs=emb.token_embedder_adaptive)
     asm.load_state_dict(fx['sd'], strict=False)
     asm.to(DEV)
     crit = AdaptiveLoss(1)
@@ -368,9 +388,14 @@ def test_adaptive_softmax_golden(golden, dtype):
     assert int(n2) == fx['out']['sample_size2']
     close(loss2.reshape(1), fx['out']['loss2'], dtype, rtol=1e-3 if dtype == torch.float32 else 2e-2)
     lp = asm.get_log_prob(x.detach())
-    close(lp, fx['out']['log_probs'], dtype, scale=4)
+    check_fx(fx, 'log_probs', lp, dtype, scale=4)
     tok, tlp = asm.greedy(x.detach())
-    ref = fx['out']['log_probs'].view(-1, 600)
+    # full reference log-probs from the (golden-pinned) oracle on the same weights
+    from oracle.build import build_embedder as o_emb
+    from oracle.modules import AdaptiveSoftmax as OASM
+    oasm = OASM(600, 32, [100, 300], o_emb(600, 32, (100, 300)).token_embedder_adaptive)
+    oasm.load_state_dict({k: v for k, v in fx['sd'].items() if k in oasm.state_dict()}, strict=False)
+    ref = oasm.get_log_prob(x.detach().float().cpu()).view(-1, 600)
     if dtype == torch.float32:
         assert torch.equal(tok.cpu().long().view(-1), ref.argmax(dim=1))
     close(tlp.view(-1), ref.max(dim=1).values, dtype, scale=4)

@@ -36,3 +36,19 @@ extern "C" int tell_roberta_embed(const long* ids, int B, int S, int pad, const 
   else hipLaunchKernelGGL((embed2_kernel<float>), dim3(B * S), dim3(256), 0, stream, ids, pos_ws, (const float*)word, (const float*)posemb, (float*)out, E);
   return tell_check_launch("roberta_embed");
 }
+
+// zero the rows whose mask byte is set (fairseq: x *= 1 - padding_mask after the embedding LayerNorm)
+template <typename T>
+__global__ __launch_bounds__(256) void mask_rows_kernel(T* __restrict__ x, const uint8_t* __restrict__ mask,
+                                                        long rows, int C) {
+  for (long r = blockIdx.x; r < rows; r += gridDim.x)
+    if (mask[r])
+      for (int c = threadIdx.x; c < C; c += 256) x[r * C + c] = (T)0;
+}
+extern "C" int tell_mask_rows(void* x, const uint8_t* mask, long rows, int C, int dtype, hipStream_t stream) {
+  if (rows <= 0) return TELL_OK;
+  int g = rows < 4096 ? (int)rows : 4096;
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((mask_rows_kernel<uint16_t>), dim3(g), dim3(256), 0, stream, (uint16_t*)x, mask, rows, C);
+  else hipLaunchKernelGGL((mask_rows_kernel<float>), dim3(g), dim3(256), 0, stream, (float*)x, mask, rows, C);
+  return tell_check_launch("mask_rows");
+}

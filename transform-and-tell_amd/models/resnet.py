@@ -1,0 +1,150 @@
+"""ResNet-152 trunk (tell/models/resnet.py:12-192) on the MI355X path.
+
+NHWC activations: 1x1/s1 convolutions are NT GEMMs straight on the activation matrix
+[B*H*W, Cin]; 3x3, 7x7 and strided 1x1 go through im2col rows; BatchNorm uses batch
+statistics when `self.training` (the reference trains with the frozen trunk in train mode,
+callback_apex_trainer.py:259) and running statistics in eval.  Parameter / buffer names are
+torchvision's so that the reference's `resnet.*` checkpoint entries load.
+Returns the region features as [B, 49, 2048] (== permute(0,2,3,1).view(B,49,2048),
+transformer_faces_objects.py:335-341)."""
+import torch
+import torch.nn as nn
+
+from .. import hip, ops
+from .. import runtime as rt
+
+call = hip.call
+
+
+def _conv_param(cout, cin, k):
+    w = torch.empty(cout, cin, k, k)
+    nn.init.kaiming_normal_(w, mode='fan_out', nonlinearity='relu')        # resnet.py:50-53
+    return nn.Parameter(w)
+
+
+class _BN(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer('running_mean', torch.zeros(c))
+        self.register_buffer('running_var', torch.ones(c))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+        self.eps, self.momentum = 1e-5, 0.1
+
+
+class _Conv(nn.Module):
+    def __init__(self, cin, cout, k, stride=1, padding=0):
+        super().__init__()
+        self.weight = _conv_param(cout, cin, k)
+        self.k, self.stride, self.padding, self.cin, self.cout = k, stride, padding, cin, cout
+
+    def gemm_weight(self):
+        """[Cout, KH*KW*Cin padded] working copy (compute dtype), cached per weights epoch."""
+        def make():
+            w = self.weight.detach().permute(0, 2, 3, 1).reshape(self.cout, -1)     # [Cout, KH, KW, Cin]
+            K = w.shape[1]
+            Kp = ops._round_up(K, 8)
+            wp = torch.zeros(self.cout, Kp, dtype=torch.float32, device=w.device)
+            wp[:, :K] = w
+            return ops.cast(wp, rt.compute_dtype())
+        return ops._cached(self.weight, ('convw',), make)
+
+
+def conv_bn_act(x, B, H, W, conv, bn, relu, residual, training):
+    """x: [B*H*W, Cin] NHWC rows -> ([B*OH*OW, Cout], OH, OW) with BN (+residual) (+ReLU) applied."""
+    k, s, p = conv.k, conv.stride, conv.padding
+    OH = (H + 2 * p - k) // s + 1
+    OW = (W + 2 * p - k) // s + 1
+    wq = conv.gemm_weight()
+    dtype = x.dtype
+    if k == 1 and s == 1:
+        a = x
+    else:
+        a = torch.empty(B * OH * OW, wq.shape[1], dtype=dtype, device=x.device)
+        call('tell_im2col', x, a, B, H, W, conv.cin, k, k, s, p, OH, OW, wq.shape[1], hip.dt(dtype))
+    y = ops.gemm(a, wq)
+    M, C = y.shape
+    if training:
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = torch.empty(2 * hip.lib().tell_bn_chunks(M) * C, dtype=torch.float32, device=x.device)
+        call('tell_bn_stats', y, M, C, bn.eps, bn.momentum, mean, invstd, bn.running_mean, bn.running_var, ws,
+             hip.dt(dtype))
+    else:
+        mean = bn.running_mean
+        invstd = ops._cached(bn.running_var, ('invstd',), lambda: torch.rsqrt(bn.running_var + bn.eps))
+    call('tell_bn_apply', y, mean, invstd, bn.weight.detach(), bn.bias.detach(), residual, y, M, C, int(relu),
+         hip.dt(dtype))
+    return y, OH, OW
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = _Conv(inplanes, planes, 1)
+        self.bn1 = _BN(planes)
+        self.conv2 = _Conv(planes, planes, 3, stride=stride, padding=1)
+        self.bn2 = _BN(planes)
+        self.conv3 = _Conv(planes, planes * 4, 1)
+        self.bn3 = _BN(planes * 4)
+        self.downsample = downsample
+
+    def run(self, x, B, H, W, training):
+        idt = x
+        if self.downsample is not None:
+            idt, _, _ = conv_bn_act(x, B, H, W, self.downsample[0], self.downsample[1], False, None, training)
+        y, _, _ = conv_bn_act(x, B, H, W, self.conv1, self.bn1, True, None, training)
+        y, OH, OW = conv_bn_act(y, B, H, W, self.conv2, self.bn2, True, None, training)
+        y, _, _ = conv_bn_act(y, B, OH, OW, self.conv3, self.bn3, True, idt, training)
+        return y, OH, OW
+
+
+class ResNetFeatureExtractor(nn.Module):
+    def __init__(self, layers=(3, 8, 36, 3), width=64, num_classes=1000):
+        super().__init__()
+        self.inplanes = width
+        self.conv1 = _Conv(3, width, 7, stride=2, padding=3)
+        self.bn1 = _BN(width)
+        self.layer1 = self._make(width, layers[0], 1)
+        self.layer2 = self._make(width * 2, layers[1], 2)
+        self.layer3 = self._make(width * 4, layers[2], 2)
+        self.layer4 = self._make(width * 8, layers[3], 2)
+        self.fc = nn.Linear(width * 8 * 4, num_classes)          # kept for state_dict compatibility (:48)
+        self.out_channels = width * 8 * 4
+
+    def _make(self, planes, blocks, stride):
+        down = None
+        if stride != 1 or self.inplanes != planes * 4:
+            down = nn.Sequential(_Conv(self.inplanes, planes * 4, 1, stride=stride), _BN(planes * 4))
+        seq = [Bottleneck(self.inplanes, planes, stride, down)]
+        self.inplanes = planes * 4
+        seq += [Bottleneck(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*seq)
+
+    @torch.no_grad()
+    def forward(self, image, pool=False):
+        assert not pool
+        hip.require_gpu()
+        dtype = rt.compute_dtype()
+        B, C, H, W = image.shape
+        x = torch.empty(B * H * W, C, dtype=dtype, device=image.device)
+        call('tell_nchw_to_nhwc', image.float().contiguous(), x, B, C, H, W, hip.dt(dtype))
+        tr = self.training
+        x, H, W = conv_bn_act(x, B, H, W, self.conv1, self.bn1, True, None, tr)        # :94-97
+        OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        y = torch.empty(B * OH * OW, x.shape[1], dtype=dtype, device=x.device)
+        call('tell_maxpool3x3s2', x, y, B, H, W, x.shape[1], OH, OW, hip.dt(dtype))    # :98
+        x, H, W = y, OH, OW
+        for stage in (self.layer1, self.layer2, self.layer3, self.layer4):              # :101-108
+            for block in stage:
+                x, H, W = block.run(x, B, H, W, tr)
+        return x.view(B, H * W, self.out_channels)
+
+
+def resnet152(**kwargs):
+    """resnet.py:184-192 without the pretrained-weight download (no network here): weights are
+    the reference's own initialisers unless a checkpoint is loaded."""
+    return ResNetFeatureExtractor((3, 8, 36, 3), **kwargs)

@@ -57,15 +57,16 @@ def gemm(a, b, out=None, out_dtype=None, bias=None, bias_mode=0, act=0, aux=None
          accumulate=False, m_dev=None):
     """out[M,N] = act((a[M,K] @ b[N,K]^T + bias) * alpha) (+ out).  K is zero padded to a
     16-byte multiple when needed (only reduced-size test shapes take that path)."""
-    assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1] and a.dtype == b.dtype, \
-        (a.shape, b.shape, a.dtype, b.dtype)
-    M, K = a.shape
-    N = b.shape[0]
     v = _vec(a.dtype)
+    Kp = _round_up(max(a.shape[1], b.shape[1]), v)
+    assert a.dim() == 2 and b.dim() == 2 and a.dtype == b.dtype and \
+        _round_up(a.shape[1], v) == _round_up(b.shape[1], v), (a.shape, b.shape, a.dtype, b.dtype)
+    M = a.shape[0]
+    N = b.shape[0]
 
     def fix(t):
-        if t.stride(1) != 1 or t.stride(0) % v or t.shape[1] % v or t.data_ptr() % 16:
-            tp = torch.zeros(t.shape[0], _round_up(t.shape[1], v), dtype=t.dtype, device=t.device)
+        if t.stride(1) != 1 or t.stride(0) % v or t.shape[1] != Kp or t.data_ptr() % 16:
+            tp = torch.zeros(t.shape[0], Kp, dtype=t.dtype, device=t.device)
             tp[:, :t.shape[1]] = t
             return tp
         return t
