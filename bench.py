@@ -1,0 +1,160 @@
+#!/usr/bin/env python
+"""bench.py - training samples/s of the caption hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = the complete optimisation step of BASELINE.json configs[1] on one synthetic batch:
+ResNet-152 trunk (batch-stat BN) + RoBERTa-large (24 layers, 512 tokens) forward, 2-context
+4-layer DynamicConv decoder forward + adaptive-softmax loss + backward, gradient all-reduce
+(N > 1, RCCL) and BertAdam.  bf16 compute, fp32 master weights, random-init weights,
+synthetic data of NYTimes800k shape (no network for datasets / checkpoints).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def cpu_baseline(sample_b=2, threads=None):
+    """The oracle (CPU restatement of the reference, fp32) timed on a bounded sample of the same
+    workload: the full configs[1] model, one optimisation step on `sample_b` samples."""
+    from oracle.build import build_model
+    from oracle.encoders import resnet152, roberta_large
+    from oracle.optim import BertAdam
+    import tell_amd  # noqa: F401  (only for the synthetic batch generator)
+    from tell_amd.data import synthetic_batch
+    if threads:
+        torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    model = build_model('flattened', resnet152(), roberta_large(), n_bert_layers=25).train()
+    model.weigh_bert = False
+    for n, p in model.named_parameters():
+        if n.startswith('resnet') or n.startswith('roberta'):
+            p.requires_grad_(False)
+    opt = BertAdam([p for p in model.parameters()])
+    batch = synthetic_batch(B=sample_b, article_len=512, caption_len=33, seed=1234)
+
+    def step():
+        opt.zero_grad()
+        with torch.no_grad():
+            pass
+        out = model(context={'roberta': batch['context']['roberta'].clone()}, image=batch['image'],
+                    caption={'roberta': batch['caption']['roberta'].clone()})
+        out['loss'].backward()
+        opt.step()
+    t0 = time.time()
+    step()
+    dt = time.time() - t0
+    return {'value': round(sample_b / dt, 4), 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '1 full optimisation step (ResNet-152 + RoBERTa-large fwd, 2-ctx decoder fwd+loss+bwd, '
+                      'BertAdam) of the fp32 CPU oracle on %d samples, %.1f s' % (sample_b, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=16, help='samples per GPU (configs[1]: 16)')
+    ap.add_argument('--model', default='flattened', choices=['flattened', 'faces_objects'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=2)
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)       # RCCL on ROCm
+    import tell_amd
+    from tell_amd import prof
+    from tell_amd.build import build_model
+    from tell_amd.data import synthetic_batch
+    from tell_amd.training import Trainer
+    tell_amd.hip.require_gpu()
+    tell_amd.set_compute_dtype(torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
+    tell_amd.manual_seed(1234 + rank)
+    torch.manual_seed(0)                                     # same initial weights on all ranks
+
+    model = build_model(args.model, weigh_bert=(args.model == 'faces_objects'))
+    trainer = Trainer(model, device=dev)
+    batches = [synthetic_batch(args.batch, 512, 33, args.model == 'faces_objects', seed=1234 + rank + 97 * i,
+                               device=dev) for i in range(2)]
+
+    def fresh(b):
+        return {k: (dict(v) if isinstance(v, dict) else v) for k, v in b.items()}
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.train_one_batch(fresh(batches[i % 2]))
+    sync()
+    if not args.no_roofline:
+        prof.enable(True)
+    t0 = time.perf_counter()
+    loss = None
+    for i in range(args.steps):
+        loss = trainer.train_one_batch(fresh(batches[i % 2]))
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof_summary = prof.summary() if not args.no_roofline else {}
+    prof.enable(False)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        value = world * args.batch * args.steps / elapsed
+        result = {
+            'metric': 'training samples/sec (img+article->caption)', 'value': round(value, 2),
+            'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.dtype, 'data': 'synthetic (random pixels, random BPE ids; random-init weights)',
+            'config': {'workload': 'BASELINE configs[1]: 4-layer DynamicConv decoder (2 contexts: ResNet-152 '
+                                   'image regions + RoBERTa-large article), batch %d/GPU, 512-token articles, '
+                                   '32 caption steps; full step = frozen encoders fwd + decoder fwd/loss/bwd '
+                                   '+ BertAdam' % args.batch if args.model == 'flattened' else
+                                   'BASELINE configs[2] shape: faces+objects model, batch %d/GPU' % args.batch,
+                       'global_batch': world * args.batch, 'article_len': 512, 'caption_len': 33,
+                       'parallelism': 'dp%d' % world, 'final_loss_bits': round(float(loss), 4)},
+        }
+        if prof_summary:
+            name, d = max(prof_summary.items(), key=lambda kv: kv[1]['total_ms'])
+            achieved = d['work'] / (d['total_ms'] * 1e-3) / 1e12
+            peak = 2500.0 if 'bf16' in name.split(',')[0] else 157.3
+            result['roofline'] = {
+                'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': round(achieved / peak, 4), 'traffic': None, 'launches_per_step': d['launches'] // args.steps,
+                'avg_launch_us': round(d['avg_us'], 2),
+                'step_share': round(d['total_ms'] / (1e3 * elapsed), 4),
+                'all_gemm_kernels': {k: {'avg_us': round(v['avg_us'], 2), 'launches_per_step': v['launches'] // args.steps,
+                                         'tflops': round(v['work'] / (v['total_ms'] * 1e-3) / 1e12, 2)}
+                                     for k, v in prof_summary.items()}}
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(args.cpu_sample)
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

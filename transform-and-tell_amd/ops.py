@@ -13,7 +13,7 @@ import math
 import torch
 from torch.autograd import Function
 
-from . import hip
+from . import hip, prof
 from . import runtime as rt
 
 call = hip.call
@@ -74,8 +74,15 @@ def gemm(a, b, out=None, out_dtype=None, bias=None, bias_mode=0, act=0, aux=None
     if out is None:
         out = torch.empty(M, N, dtype=out_dtype or a.dtype, device=a.device)
     assert out.stride(1) == 1
+    rec = None
+    if prof.enabled() and m_dev is None:
+        tile = 128 if ((M + 127) // 128) * ((N + 127) // 128) >= 256 else 64       # mirrors launch_gemm()
+        rec = prof.begin('gemm_nt_kernel<%s,%s,%d,%d>' % (('f32', 'bf16')[hip.dt(a)], ('f32', 'bf16')[hip.dt(out)],
+                                                         tile, tile), 2.0 * M * N * a.shape[1])
     call('tell_gemm_nt', a, a.stride(0), b, b.stride(0), out, out.stride(0), M, N, a.shape[1], hip.dt(a),
          hip.dt(out), bias, bias_mode, act, aux, float(alpha), int(accumulate), m_dev)
+    if rec is not None:
+        prof.end(rec)
     return out
 
 

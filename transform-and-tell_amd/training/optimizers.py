@@ -1,0 +1,109 @@
+"""Optimizer `bert_adam` (expt/nytimes/9_transformer_objects/config.yaml:126-149) as one
+multi-tensor HIP kernel over flat fp32 buffers.  Update rule restated from
+pytorch_pretrained_bert.BertAdam (third-party, absent here; parity unpinned):
+per-tensor gradient-norm clipping, no bias correction, decoupled-style weight decay added
+to the update, `warmup_linear` schedule evaluated at the step count BEFORE the increment."""
+import re
+
+import torch
+
+from .. import hip
+from .. import runtime as rt
+
+
+def warmup_linear(progress, warmup):
+    """pytorch_pretrained_bert WarmupLinearSchedule.get_lr_"""
+    if progress < warmup:
+        return progress / warmup
+    return max((progress - 1.0) / (warmup - 1.0), 0.0)
+
+
+class FlatParams:
+    """Trainable parameters re-homed into one flat fp32 buffer (+ matching grad / m / v
+    buffers).  Every tensor starts on a CHUNK boundary so a chunk belongs to one tensor
+    (per-tensor norms without atomics); `p.data` and `p.grad` become views."""
+
+    def __init__(self, named_params, device):
+        chunk = hip.lib().tell_opt_chunk()
+        self.names, self.params, offs = [], [], []
+        total = 0
+        seen = set()
+        for name, p in named_params:
+            if not p.requires_grad or id(p) in seen:
+                continue
+            seen.add(id(p))
+            self.names.append(name)
+            self.params.append(p)
+            offs.append(total)
+            total += (p.numel() + chunk - 1) // chunk * chunk
+        self.total, self.chunk, self.offsets = total, chunk, offs
+        self.n_chunks = total // chunk
+        self.flat = torch.zeros(total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self.m = torch.zeros(total, dtype=torch.float32, device=device)
+        self.v = torch.zeros(total, dtype=torch.float32, device=device)
+        chunk_tensor = torch.empty(self.n_chunks, dtype=torch.int32)
+        begins = []
+        for i, (p, o) in enumerate(zip(self.params, offs)):
+            n = p.numel()
+            self.flat[o:o + n].copy_(p.data.reshape(-1).to(device=device, dtype=torch.float32))
+            p.data = self.flat[o:o + n].view(p.shape)
+            g = self.grad[o:o + n].view(p.shape)
+            p.grad = g
+            p._tell_grad = g
+            c0, c1 = o // chunk, (o + (n + chunk - 1) // chunk * chunk) // chunk
+            chunk_tensor[c0:c1] = i
+            begins.append(c0)
+        begins.append(self.n_chunks)
+        self.chunk_tensor = chunk_tensor.to(device)
+        self.chunk_begin = torch.tensor(begins, dtype=torch.int64, device=device)
+        self.partial = torch.empty(max(self.n_chunks, 1), dtype=torch.float32, device=device)
+        self.norms = torch.zeros(len(self.params), dtype=torch.float32, device=device)
+        rt.bump_weights_epoch()
+
+    def zero_grad(self):
+        hip.call('tell_fill_f32', self.grad, self.total, 0.0)
+
+    def numel(self):
+        return sum(p.numel() for p in self.params)
+
+
+class BertAdam:
+    def __init__(self, flat, lr=1e-4, warmup=-1, t_total=-1, schedule='warmup_linear', b1=0.9, b2=0.999,
+                 e=1e-6, weight_decay=0.01, max_grad_norm=1.0, parameter_groups=None):
+        assert schedule == 'warmup_linear'
+        self.flat = flat
+        self.lr, self.warmup, self.t_total = lr, warmup, t_total
+        self.b1, self.b2, self.e, self.weight_decay, self.max_grad_norm = b1, b2, e, weight_decay, max_grad_norm
+        self.step_count = 0
+        self.lr_dev = torch.zeros(1, dtype=torch.float32, device=flat.flat.device)
+        self.parameter_groups = parameter_groups    # all groups of the configs carry `{}` overrides
+
+    def current_lr(self):
+        if self.t_total != -1:
+            return self.lr * warmup_linear(self.step_count / self.t_total, self.warmup)
+        return self.lr
+
+    def step(self, grad_scale=1.0):
+        f = self.flat
+        self.lr_dev.fill_(self.current_lr())
+        hip.call('tell_bertadam_step', f.flat, f.grad, f.m, f.v, f.chunk_tensor, f.chunk_begin, f.n_chunks,
+                 len(f.params), f.partial, f.norms, self.lr_dev, self.b1, self.b2, self.e, self.weight_decay,
+                 self.max_grad_norm, float(grad_scale))
+        self.step_count += 1
+        rt.bump_weights_epoch()
+
+    def state_dict(self):
+        return {'step': self.step_count, 'm': self.flat.m, 'v': self.flat.v}
+
+    def load_state_dict(self, sd):
+        self.step_count = sd['step']
+        self.flat.m.copy_(sd['m'])
+        self.flat.v.copy_(sd['v'])
+
+
+def apply_no_grad(model, patterns):
+    """trainer `no_grad` regex list (config.yaml:150-152)."""
+    for name, p in model.named_parameters():
+        if any(re.search(rx, name) for rx in patterns):
+            p.requires_grad_(False)

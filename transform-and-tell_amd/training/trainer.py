@@ -1,0 +1,96 @@
+"""The optimisation step of tell/training/callback_apex_trainer.py:208-247 on the MI355X path,
+data-parallel over one process per GPU (new functionality - the reference never runs
+multi-process).
+
+  zero_grad -> forward (model(**batch)) -> backward -> [RCCL all-reduce of the flat fp32
+  gradient buffer over xGMI] -> BertAdam.
+
+bf16 compute with fp32 master weights replaces apex amp O2 (no loss scaling needed).
+DP equivalence with a single-GPU run on the concatenated batch: every rank's loss is
+re-weighted by n_local*world/n_global (token counts all-reduced on the device) before
+backward, then gradients are averaged.  Ranks that see no target of a tail cluster still
+contribute zeros: the flat buffer is always reduced as a whole."""
+import torch
+
+from .. import runtime as rt
+from ..common.registrable import Registrable
+from .optimizers import BertAdam, FlatParams, apply_no_grad
+
+
+class TrainerBase(Registrable):
+    pass
+
+
+class Trainer:
+    def __init__(self, model, optimizer_cfg=None, no_grad=(r'^resnet', r'^roberta'), device='cuda',
+                 nan_check=False, bucket_mb=256):
+        import torch.distributed as dist
+        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.world = self.dist.get_world_size() if self.dist else 1
+        self.rank = self.dist.get_rank() if self.dist else 0
+        self.model = model.to(device)
+        apply_no_grad(model, no_grad)
+        self.flat = FlatParams(model.named_parameters(), device)
+        cfg = dict(lr=1e-4, warmup=0.05, t_total=437600, schedule='warmup_linear', b1=0.9, b2=0.98, e=1e-6,
+                   weight_decay=1e-5, max_grad_norm=0.1)                 # config.yaml:126-136
+        cfg.update(optimizer_cfg or {})
+        cfg.pop('type', None)
+        self.optimizer = BertAdam(self.flat, **cfg)
+        self.nan_check = nan_check
+        self.bucket_elems = bucket_mb * (1 << 20) // 4
+        self.batch_num_total = 0
+        if self.world > 1:                    # identical initial weights on every rank
+            self.dist.broadcast(self.flat.flat, src=0)
+            rt.bump_weights_epoch()
+
+    def train_one_batch(self, batch):
+        """callback_apex_trainer.py:208-247 for one batch; returns the (detached) loss tensor."""
+        self.model.train()
+        self.flat.zero_grad()                                            # :214
+        out = self.model(**batch)                                        # :220 / :194
+        loss = out['loss']
+        if self.world > 1:
+            n_local = out['sample_size'].to(torch.float32)
+            n_global = n_local.clone()
+            self.dist.all_reduce(n_global)
+            scaled = loss * (n_local * self.world / n_global)
+        else:
+            scaled = loss
+        if self.nan_check:                                               # :225-227 (host sync, collective)
+            bad = torch.isnan(loss.detach()).to(torch.float32)
+            if self.world > 1:
+                self.dist.all_reduce(bad)
+            if bad.item() > 0:
+                return None
+        scaled.backward()                                                # :229-231
+        if self.world > 1:
+            self._all_reduce_grads()
+        self.optimizer.step(grad_scale=1.0 / self.world)                 # :238
+        self.batch_num_total += 1
+        return loss.detach()
+
+    def _all_reduce_grads(self):
+        g = self.flat.grad
+        handles = []
+        for s in range(0, g.numel(), self.bucket_elems):                 # few, large buckets: xGMI ring is per-link bound
+            handles.append(self.dist.all_reduce(g[s:s + self.bucket_elems], async_op=True))
+        for h in handles:
+            h.wait()
+
+
+@TrainerBase.register('callback_apex')
+class CallbackApexTrainer(Trainer):
+    """Registration name of the reference trainer (callback_apex_trainer.py:51).  The AllenNLP
+    callback machinery (checkpoint / tensorboard / validation callbacks) is out of scope;
+    `apex_opt_level` / `keep_batchnorm_fp32` are accepted and ignored (bf16 + fp32 masters)."""
+
+    def __init__(self, model, optimizer=None, no_grad=(r'^resnet', r'^roberta'), apex_opt_level=None,
+                 keep_batchnorm_fp32=None, num_epochs=1, shuffle=True, cuda_device=0, callbacks=None, **kw):
+        super().__init__(model, optimizer, no_grad, device='cuda' if cuda_device is not None else 'cpu')
+        self.num_epochs = num_epochs
+
+    def train(self, batches):
+        losses = []
+        for batch in batches:
+            losses.append(self.train_one_batch(batch))
+        return losses
