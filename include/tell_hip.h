@@ -71,8 +71,9 @@ int tell_glu_bwd(const void* h, const void* dy, void* dh, long rows, int C, int 
 int tell_dropout(const void* x, void* y, long n, float p, uint32_t seed, uint32_t salt, int dtype,
                  tell_stream_t stream);
 /* bias gradients: out[c] (+)= sum_r x[r][c] */
+int tell_colsum_chunks(int rows);
 int tell_colsum(const void* x, long ld, int rows, int C, int dtype, float* out, int accumulate,
-                const int* m_dev, float scale, tell_stream_t stream);
+                const int* m_dev, float scale, float* workspace, tell_stream_t stream);
 /* F.relu backward (decoder_faces_objects.py:360): dx = dy * (y > 0) */
 int tell_relu_bwd(const void* dy, const void* y, void* dx, long n, int dtype, tell_stream_t stream);
 int tell_axpy(const void* x, void* y, long n, float alpha, int dtype, tell_stream_t stream);

@@ -51,11 +51,45 @@ __global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ x, T*
     col[i] = v;
   }
 }
+// 16-byte-chunk variant for Cin % VEC == 0 (every conv except the 3-channel stem)
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_vec_kernel(const T* __restrict__ x, T* __restrict__ col, int B, int H,
+                                                         int W, int Cin, int KH, int KW, int stride, int pad,
+                                                         int OH, int OW) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cpk = Cin / VEC;                       // chunks per (kh,kw) tap
+  const long M = (long)B * OH * OW;
+  const long n = M * KH * KW * cpk;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cpk);
+    long r = i / cpk;
+    const int kw = (int)(r % KW); r /= KW;
+    const int kh = (int)(r % KH); r /= KH;
+    const long m = r;
+    const int ow = (int)(m % OW);
+    const long r2 = m / OW;
+    const int oh = (int)(r2 % OH), b = (int)(r2 / OH);
+    const int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ih >= 0 && ih < H && iw >= 0 && iw < W)
+      v = *reinterpret_cast<const uint4*>(x + (((long)b * H + ih) * W + iw) * Cin + cc * VEC);
+    *reinterpret_cast<uint4*>(col + i * VEC) = v;
+  }
+}
+
 extern "C" int tell_im2col(const void* x, void* col, int B, int H, int W, int Cin, int KH, int KW, int stride,
                            int pad, int OH, int OW, int Kp, int dtype, hipStream_t stream) {
   long n = (long)B * OH * OW * Kp;
   if (n <= 0) return TELL_OK;
   TELL_REQUIRE(Kp >= KH * KW * Cin, "im2col: padded K smaller than KH*KW*Cin");
+  const int vec = dtype == TELL_BF16 ? 8 : 4;
+  if (Cin % vec == 0 && Kp == KH * KW * Cin && ((uintptr_t)x & 15) == 0 && ((uintptr_t)col & 15) == 0) {
+    long nv = n / vec;
+    int gv = (int)((nv + 255) / 256 > 16384 ? 16384 : (nv + 255) / 256);
+    if (dtype == TELL_BF16) hipLaunchKernelGGL((im2col_vec_kernel<uint16_t>), dim3(gv), dim3(256), 0, stream, (const uint16_t*)x, (uint16_t*)col, B, H, W, Cin, KH, KW, stride, pad, OH, OW);
+    else hipLaunchKernelGGL((im2col_vec_kernel<float>), dim3(gv), dim3(256), 0, stream, (const float*)x, (float*)col, B, H, W, Cin, KH, KW, stride, pad, OH, OW);
+    return tell_check_launch("im2col_vec");
+  }
   int g = (int)((n + 1023) / 1024 > 8192 ? 8192 : (n + 1023) / 1024);
   if (dtype == TELL_BF16) hipLaunchKernelGGL((im2col_kernel<uint16_t>), dim3(g), dim3(256), 0, stream, (const uint16_t*)x, (uint16_t*)col, B, H, W, Cin, KH, KW, stride, pad, OH, OW, Kp);
   else hipLaunchKernelGGL((im2col_kernel<float>), dim3(g), dim3(256), 0, stream, (const float*)x, (float*)col, B, H, W, Cin, KH, KW, stride, pad, OH, OW, Kp);
@@ -64,9 +98,8 @@ extern "C" int tell_im2col(const void* x, void* col, int B, int H, int W, int Ci
 
 // ---------------------------------------------------------------- BatchNorm (batch statistics)
 // stage 1: per (row chunk, 32-column group): count, mean, M2 of the chunk (fp32, two-pass inside the chunk)
-#define BN_ROWS 256
 template <typename T>
-__global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x, long M, int C,
+__global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x, long M, int C, int BN_ROWS,
                                                          float* __restrict__ pmean, float* __restrict__ pm2) {
   __shared__ float red[8][33];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
@@ -95,45 +128,62 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x
     pm2[(long)blockIdx.y * C + c] = m2;
   }
 }
-// stage 2: Chan combine over chunks -> mean, invstd (biased var); running stats with unbiased var
-__global__ void bn_finish_kernel(const float* __restrict__ pmean, const float* __restrict__ pm2, long M, int C,
-                                 int n_chunks, float eps, float momentum, float* __restrict__ mean,
-                                 float* __restrict__ invstd, float* __restrict__ running_mean,
-                                 float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// stage 2: Chan combine over the (<= 64) chunks, one wave per channel, butterfly over lanes
+__global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict__ pmean, const float* __restrict__ pm2,
+                                                        long M, int C, int n_chunks, int BN_ROWS, float eps,
+                                                        float momentum, float* __restrict__ mean,
+                                                        float* __restrict__ invstd, float* __restrict__ running_mean,
+                                                        float* __restrict__ running_var) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
   float n = 0.f, mu = 0.f, m2 = 0.f;
-  for (int k = 0; k < n_chunks; ++k) {
-    const long r0 = (long)k * BN_ROWS;
-    const float nb = (float)((r0 + BN_ROWS < M ? r0 + BN_ROWS : M) - r0);
-    const float mb = pmean[(long)k * C + c], qb = pm2[(long)k * C + c];
-    const float nt = n + nb, delta = mb - mu;
-    mu += delta * nb / nt;
-    m2 += qb + delta * delta * n * nb / nt;
+  if (lane < n_chunks) {
+    const long r0 = (long)lane * BN_ROWS;
+    n = (float)((r0 + BN_ROWS < M ? r0 + BN_ROWS : M) - r0);
+    mu = pmean[(long)lane * C + c];
+    m2 = pm2[(long)lane * C + c];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mu, o, 64), qb = __shfl_xor(m2, o, 64);
+    const float nt = n + nb;
+    if (nt > 0.f) {
+      const float delta = mb - mu;
+      mu = (n * mu + nb * mb) / nt;           // symmetric form: both partners compute the same value
+      m2 = m2 + qb + delta * delta * n * nb / nt;
+    }
     n = nt;
   }
-  const float var = m2 / n;
-  mean[c] = mu;
-  invstd[c] = rsqrtf(var + eps);
-  if (running_mean) {
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
+  if (lane == 0) {
+    const float var = m2 / n;
+    mean[c] = mu;
+    invstd[c] = rsqrtf(var + eps);
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
+    }
   }
 }
-extern "C" long tell_bn_chunks(long M) { return (M + BN_ROWS - 1) / BN_ROWS; }
+static inline int bn_rows_per_chunk(long M) {
+  long r = (M + 63) / 64;                     // at most 64 chunks
+  if (r < 256) r = 256;
+  return (int)((r + 7) / 8 * 8);
+}
+extern "C" long tell_bn_chunks(long M) { const int r = bn_rows_per_chunk(M); return (M + r - 1) / r; }
 // workspace: 2 * tell_bn_chunks(M) * C floats
 extern "C" int tell_bn_stats(const void* x, long M, int C, float eps, float momentum, float* mean, float* invstd,
                              float* running_mean, float* running_var, float* workspace, int dtype,
                              hipStream_t stream) {
   if (M <= 0 || C <= 0) return TELL_OK;
+  const int rpc = bn_rows_per_chunk(M);
   const long nch = tell_bn_chunks(M);
-  TELL_REQUIRE(nch <= 65535, "bn_stats: too many row chunks");
   float* pmean = workspace;
   float* pm2 = workspace + nch * C;
   dim3 grid((C + 31) / 32, (unsigned)nch);
-  if (dtype == TELL_BF16) hipLaunchKernelGGL((bn_partial_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)x, M, C, pmean, pm2);
-  else hipLaunchKernelGGL((bn_partial_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, M, C, pmean, pm2);
-  hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, pmean, pm2, M, C, (int)nch, eps, momentum, mean, invstd, running_mean, running_var);
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((bn_partial_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)x, M, C, rpc, pmean, pm2);
+  else hipLaunchKernelGGL((bn_partial_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, M, C, rpc, pmean, pm2);
+  hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, pmean, pm2, M, C, (int)nch, rpc, eps, momentum, mean, invstd, running_mean, running_var);
   return tell_check_launch("bn_stats");
 }
 

@@ -197,34 +197,46 @@ extern "C" int tell_dropout(const void* x, void* y, long n, float p, uint32_t se
   return tell_check_launch("dropout");
 }
 
-// ---------------------------------------------------------------- column sums (bias grads): out[c] (+)= sum_r x[r][c]
+// ---------------------------------------------------------------- column sums (bias grads): out[c] (+)= scale * sum_r x[r][c]
+// stage 1: grid (C/64, n_chunks); 256 threads = 64 columns x 4 row lanes; stage 2 sums the chunk partials
+// in a fixed order (deterministic, no atomics).
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long ld, int rows, int C,
-                                                     float* __restrict__ out, int accumulate,
-                                                     const int* __restrict__ m_dev, float scale) {
-  __shared__ float part[8][33];
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, long ld, int rows, int C,
+                                                             int rows_per_chunk, float* __restrict__ partial,
+                                                             const int* __restrict__ m_dev) {
+  __shared__ float part[4][65];
   if (m_dev) { int md = *m_dev; rows = md < rows ? md : rows; }
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cx;
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  const int r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
   float s = 0.f;
   if (c < C)
-    for (int r = ry; r < rows; r += 8) s += Elem<T>::ld(x + (long)r * ld + c);
+    for (int r = r0 + ry; r < r1; r += 4) s += Elem<T>::ld(x + (long)r * ld + c);
   part[ry][cx] = s;
   __syncthreads();
-  if (ry == 0 && c < C) {
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t += part[k][cx];
-    t *= scale;
-    out[c] = accumulate ? out[c] + t : t;
-  }
+  if (ry == 0 && c < C) partial[(long)blockIdx.y * C + c] = part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx];
 }
+__global__ void colsum_finish_kernel(const float* __restrict__ partial, int n_chunks, int C, float* __restrict__ out,
+                                     int accumulate, float scale) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float t = 0.f;
+  for (int k = 0; k < n_chunks; ++k) t += partial[(long)k * C + c];
+  t *= scale;
+  out[c] = accumulate ? out[c] + t : t;
+}
+extern "C" int tell_colsum_chunks(int rows) { int n = (rows + 127) / 128; return n < 1 ? 1 : (n > 128 ? 128 : n); }
+// workspace: tell_colsum_chunks(rows) * C floats
 extern "C" int tell_colsum(const void* x, long ld, int rows, int C, int dtype, float* out,
-                           int accumulate, const int* m_dev, float scale, hipStream_t stream) {
+                           int accumulate, const int* m_dev, float scale, float* workspace, hipStream_t stream) {
   if (C <= 0) return TELL_OK;
-  dim3 grid((C + 31) / 32);
-  if (dtype == TELL_BF16) hipLaunchKernelGGL((colsum_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)x, ld, rows, C, out, accumulate, m_dev, scale);
-  else hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, ld, rows, C, out, accumulate, m_dev, scale);
+  const int nch = tell_colsum_chunks(rows);
+  const int rpc = (rows + nch - 1) / nch;
+  dim3 grid((C + 63) / 64, nch);
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((colsum_partial_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)x, ld, rows, C, rpc, workspace, m_dev);
+  else hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, ld, rows, C, rpc, workspace, m_dev);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, workspace, nch, C, out, accumulate, scale);
   return tell_check_launch("colsum");
 }
 

@@ -14,6 +14,9 @@
 // double-buffered LDS; LDS rows padded (bf16: 144 B stride -> conflict-free
 // ds_read_b128 per 16-lane service group; f32: 33-dword stride).
 #include "common.h"
+#include <type_traits>
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // 16-byte staging chunk (native vector: stays in VGPRs)
 
 struct GemmArgs {
   const void* A; const void* B; void* C;
@@ -38,8 +41,8 @@ template <> struct Mma<uint16_t> {
   __device__ static __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
-  __device__ static __forceinline__ void store_chunk(uint16_t* tile, int row, int ch, const uint4& v) {
-    *reinterpret_cast<uint4*>(tile + row * STRIDE + ch * 8) = v;
+  __device__ static __forceinline__ void store_chunk(uint16_t* tile, int row, int ch, const u32x4& v) {
+    *reinterpret_cast<u32x4*>(tile + row * STRIDE + ch * 8) = v;
   }
 };
 template <> struct Mma<float> {
@@ -51,23 +54,33 @@ template <> struct Mma<float> {
   __device__ static __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
   }
-  __device__ static __forceinline__ void store_chunk(float* tile, int row, int ch, const uint4& v) {
+  __device__ static __forceinline__ void store_chunk(float* tile, int row, int ch, const u32x4& v) {
     float* p = tile + row * STRIDE + ch * 4;
-    p[0] = __uint_as_float(v.x); p[1] = __uint_as_float(v.y);
-    p[2] = __uint_as_float(v.z); p[3] = __uint_as_float(v.w);
+    p[0] = __uint_as_float(v[0]); p[1] = __uint_as_float(v[1]);
+    p[2] = __uint_as_float(v[2]); p[3] = __uint_as_float(v[3]);
   }
 };
 
+// compile-time loop: the register stage index must be a constant or the stages land in scratch
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
-template <typename T, typename OutT, int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
+template <typename T, typename OutT, int BM, int BN, int PF>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   using M_ = Mma<T>;
   constexpr int BK = M_::BK, STRIDE = M_::STRIDE, VEC = Elem<T>::VEC;
   constexpr int CPR = BK / VEC;                 // 16-byte chunks per tile row (= 8)
   constexpr int CHA = BM * CPR / 256, CHB = BN * CPR / 256;
   constexpr int WM = BM / 2, WN = BN / 2;       // per-wave tile
   constexpr int MI = WM / 32, NI = WN / 32;
+  static_assert(PF == 2 || PF == 4, "prefetch depth 2 or 4 (even: LDS double-buffer parity)");
 
   __shared__ __attribute__((aligned(16))) T As[2][BM * STRIDE];
   __shared__ __attribute__((aligned(16))) T Bs[2][BN * STRIDE];
@@ -77,7 +90,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   int M = p.M;
   if (p.m_dev) { int md = *p.m_dev; M = md < M ? md : M; }
   const int N = p.N, K = p.K;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  // XCD-aware tile mapping: hardware places workgroup b on XCD b % 8; give every XCD a
+  // contiguous range of tiles (row-major over (m-tile, n-tile)) so that neighbouring tiles,
+  // which share an A row-panel, hit the same per-XCD L2.  Bijective for any grid size.
+  const int tiles_n = (N + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  int tile_id;
+  {
+    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int m0 = (tile_id / tiles_n) * BM, n0 = (tile_id % tiles_n) * BN;
   if (m0 >= M) return;                          // uniform per block
 
   const T* A = static_cast<const T*>(p.A);
@@ -91,59 +115,73 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  uint4 ra[CHA], rb[CHB];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
-  auto gload = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < CHA; ++i) {
-      int c = tid + i * 256, row = c / CPR, ch = c % CPR;
-      int gm = m0 + row, gk = kt * BK + ch * VEC;
-      ra[i] = (gm < M && gk < K) ? *reinterpret_cast<const uint4*>(A + (long)gm * p.lda + gk) : zero4;
-    }
-#pragma unroll
-    for (int i = 0; i < CHB; ++i) {
-      int c = tid + i * 256, row = c / CPR, ch = c % CPR;
-      int gn = n0 + row, gk = kt * BK + ch * VEC;
-      rb[i] = (gn < N && gk < K) ? *reinterpret_cast<const uint4*>(B + (long)gn * p.ldb + gk) : zero4;
-    }
-  };
-  auto sstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < CHA; ++i) {
-      int c = tid + i * 256;
-      M_::store_chunk(As[buf], c / CPR, c % CPR, ra[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < CHB; ++i) {
-      int c = tid + i * 256;
-      M_::store_chunk(Bs[buf], c / CPR, c % CPR, rb[i]);
-    }
-  };
+  // PF register stages: tiles kt .. kt+PF-1 are in flight from HBM/L2 while tile kt is multiplied
+  u32x4 ra[PF][CHA], rb[PF][CHB];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#define GLOAD(KT, S)                                                                              \
+  {                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < CHA; ++i) {                                             \
+      int c = tid + i * 256, row = c / CPR, ch = c % CPR;                                         \
+      int gm = m0 + row, gk = (KT) * BK + ch * VEC;                                               \
+      ra[S][i] = (gm < M && gk < K) ? *reinterpret_cast<const u32x4*>(A + (long)gm * p.lda + gk) : zero4; \
+    }                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < CHB; ++i) {                                             \
+      int c = tid + i * 256, row = c / CPR, ch = c % CPR;                                         \
+      int gn = n0 + row, gk = (KT) * BK + ch * VEC;                                               \
+      rb[S][i] = (gn < N && gk < K) ? *reinterpret_cast<const u32x4*>(B + (long)gn * p.ldb + gk) : zero4; \
+    }                                                                                             \
+  }
+#define SSTORE(S, BUF)                                                                            \
+  {                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < CHA; ++i) {                                             \
+      int c = tid + i * 256;                                                                      \
+      M_::store_chunk(As[BUF], c / CPR, c % CPR, ra[S][i]);                                       \
+    }                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < CHB; ++i) {                                             \
+      int c = tid + i * 256;                                                                      \
+      M_::store_chunk(Bs[BUF], c / CPR, c % CPR, rb[S][i]);                                       \
+    }                                                                                             \
+  }
 
   const int nk = (K + BK - 1) / BK;
-  gload(0);
-  sstore(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);             // global loads in flight under the MFMAs
-    const T* at = As[buf] + (wm * WM) * STRIDE;
-    const T* bt = Bs[buf] + (wn * WN) * STRIDE;
-#pragma unroll
-    for (int ks = 0; ks < BK; ks += M_::KSTEP) {
-      typename M_::frag a[MI], b[NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) a[i] = M_::load(at, i * 32 + (lane & 31), ks, lane);
-#pragma unroll
-      for (int j = 0; j < NI; ++j) b[j] = M_::load(bt, j * 32 + (lane & 31), ks, lane);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = M_::mma(a[i], b[j], acc[i][j]);
-    }
-    if (kt + 1 < nk) sstore(buf ^ 1);
-    __syncthreads();
+  // one pipeline step with a LITERAL stage index S (register stages must be statically indexed)
+#define STEP(S)                                                                                   \
+  {                                                                                               \
+    const int kt = kt0 + (S);                                                                     \
+    if (kt < nk) {                                                                                \
+      if (kt + PF < nk) GLOAD(kt + PF, S)                                                         \
+      const T* at = As[(S) & 1] + (wm * WM) * STRIDE;                                             \
+      const T* bt = Bs[(S) & 1] + (wn * WN) * STRIDE;                                             \
+      _Pragma("unroll") for (int ks = 0; ks < BK; ks += M_::KSTEP) {                              \
+        typename M_::frag a[MI], b[NI];                                                           \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i) a[i] = M_::load(at, i * 32 + (lane & 31), ks, lane); \
+        _Pragma("unroll") for (int j = 0; j < NI; ++j) b[j] = M_::load(bt, j * 32 + (lane & 31), ks, lane); \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                            \
+          _Pragma("unroll") for (int j = 0; j < NI; ++j) acc[i][j] = M_::mma(a[i], b[j], acc[i][j]); \
+      }                                                                                           \
+      if (kt + 1 < nk) SSTORE(((S) + 1) % PF, ((S) + 1) & 1)                                      \
+      __syncthreads();                                                                            \
+    }                                                                                             \
   }
+  GLOAD(0, 0)
+  if (1 < nk) GLOAD(1, 1)
+  if constexpr (PF == 4) {
+    if (2 < nk) GLOAD(2, 2)
+    if (3 < nk) GLOAD(3, 3)
+  }
+  SSTORE(0, 0)
+  __syncthreads();
+  for (int kt0 = 0; kt0 < nk; kt0 += PF) {
+    STEP(0)
+    STEP(1)
+    if constexpr (PF == 4) {
+      STEP(2)
+      STEP(3)
+    }
+  }
+#undef STEP
+#undef GLOAD
+#undef SSTORE
 
   // ------------------------------------------------------------- epilogue
   OutT* C = static_cast<OutT*>(p.C);
@@ -175,14 +213,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
 
 template <typename T, typename OutT>
 static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
-  // large tile only when it still fills the 256 CUs
+  // large tile only when it still fills the 256 CUs; the small tile gets a deeper prefetch
+  // (its per-tile MFMA time is too short to cover HBM latency with 2 tiles in flight)
   long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
   if (tiles128 >= 256) {
-    dim3 grid((a.N + 127) / 128, (a.M + 127) / 128);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, 128, 128>), grid, dim3(256), 0, stream, a);
+    dim3 grid((unsigned)tiles128);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, 128, 128, 2>), grid, dim3(256), 0, stream, a);
   } else {
-    dim3 grid((a.N + 63) / 64, (a.M + 63) / 64);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, 64, 64>), grid, dim3(256), 0, stream, a);
+    long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+    dim3 grid((unsigned)tiles64);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, 64, 64, 4>), grid, dim3(256), 0, stream, a);
   }
   return tell_check_launch("gemm_nt");
 }

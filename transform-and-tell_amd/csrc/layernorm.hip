@@ -35,6 +35,58 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, lo
   for (int c = lane; c < C; c += 64) Elem<T>::st(yr + c, (z(c) - mu) * rs * gamma[c] + beta[c]);
 }
 
+// Fast path: C == 64 * VEC * NCH; every lane keeps its NCH 16-byte chunks in registers:
+// one coalesced read of x (+res), statistics from registers, one coalesced write.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x, long ld_x,
+                                                         const T* __restrict__ res, long ld_r,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, T* __restrict__ y,
+                                                         long ld_y, float* __restrict__ mean,
+                                                         float* __restrict__ rstd, int rows, float eps,
+                                                         uint32_t thr, float inv_keep, uint32_t seed,
+                                                         uint32_t salt) {
+  constexpr int VEC = Elem<T>::VEC, C = 64 * VEC * NCH;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[NCH][VEC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c0 = (lane + 64 * i) * VEC;
+    unpack16(*reinterpret_cast<const uint4*>(x + (long)row * ld_x + c0), v[i], (const T*)nullptr);
+    if (thr) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) v[i][k] *= tell_keep(seed, salt, (uint64_t)row * C + c0 + k, thr, inv_keep);
+    }
+    if (res) {
+      float r[VEC];
+      unpack16(*reinterpret_cast<const uint4*>(res + (long)row * ld_r + c0), r, (const T*)nullptr);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) v[i][k] += r[k];
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) s += v[i][k];
+  }
+  const float mu = wave_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { const float d = v[i][k] - mu; q += d * d; }
+  const float rs = rsqrtf(wave_sum(q) / C + eps);
+  if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c0 = (lane + 64 * i) * VEC;
+    float o[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) o[k] = (v[i][k] - mu) * rs * gamma[c0 + k] + beta[c0 + k];
+    *reinterpret_cast<uint4*>(y + (long)row * ld_y + c0) = pack16(o, (const T*)nullptr);
+  }
+}
+
 extern "C" int tell_layernorm_fwd(const void* x, long ld_x, const void* res, long ld_r,
                                   const float* gamma, const float* beta, void* y, long ld_y,
                                   float* mean, float* rstd, int rows, int C, float eps, float p,
@@ -44,6 +96,18 @@ extern "C" int tell_layernorm_fwd(const void* x, long ld_x, const void* res, lon
   uint32_t thr = p > 0.f ? tell_drop_threshold(p) : 0u;
   float ik = 1.f / (1.f - p);
   dim3 grid((rows + 3) / 4);
+  const int vec = dtype == TELL_BF16 ? 8 : 4;
+  const bool aligned = ld_x % vec == 0 && ld_y % vec == 0 && (res == nullptr || ld_r % vec == 0) &&
+                       ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)res & 15) == 0;
+#define LNV(T, NCH) hipLaunchKernelGGL((ln_fwd_vec_kernel<T, NCH>), grid, dim3(256), 0, stream, (const T*)x, ld_x, \
+    (const T*)res, ld_r, gamma, beta, (T*)y, ld_y, mean, rstd, rows, eps, thr, ik, seed, salt)
+  if (aligned && C % (64 * vec) == 0 && C / (64 * vec) <= 4 && C / (64 * vec) != 3) {
+    const int nch = C / (64 * vec);
+    if (dtype == TELL_BF16) { if (nch == 1) LNV(uint16_t, 1); else if (nch == 2) LNV(uint16_t, 2); else LNV(uint16_t, 4); }
+    else { if (nch == 1) LNV(float, 1); else if (nch == 2) LNV(float, 2); else LNV(float, 4); }
+    return tell_check_launch("layernorm_fwd_vec");
+  }
+#undef LNV
   if (dtype == TELL_BF16)
     hipLaunchKernelGGL((ln_fwd_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)x, ld_x, (const uint16_t*)res, ld_r, gamma, beta, (uint16_t*)y, ld_y, mean, rstd, rows, C, eps, thr, ik, seed, salt);
   else
@@ -56,7 +120,7 @@ extern "C" int tell_layernorm_fwd(const void* x, long ld_x, const void* res, lon
 //   dres = dz (optionally accumulated into an existing buffer), dx = dz * keep
 // dgamma / dbeta: each block reduces its ROWS_PER_BLOCK rows into partial[block][2][C];
 // tell_ln_bwd_finish sums the partials (deterministic, no atomics).
-#define LN_BWD_ROWS 32
+#define LN_BWD_ROWS 4
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, long ld_dy,
                                                      const T* __restrict__ x, long ld_x,

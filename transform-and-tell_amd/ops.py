@@ -111,7 +111,8 @@ def cast(x, dtype):
 
 
 def colsum_into(x2, out, scale=1.0, m_dev=None):
-    call('tell_colsum', x2, x2.stride(0), x2.shape[0], x2.shape[1], hip.dt(x2), out, 1, m_dev, float(scale))
+    ws = torch.empty(hip.lib().tell_colsum_chunks(x2.shape[0]) * x2.shape[1], dtype=torch.float32, device=x2.device)
+    call('tell_colsum', x2, x2.stride(0), x2.shape[0], x2.shape[1], hip.dt(x2), out, 1, m_dev, float(scale), ws)
 
 
 # --------------------------------------------------------------------------- #
