@@ -70,7 +70,7 @@ def test_roberta_matches_oracle(dtype):
     from tell_amd.models.roberta import RobertaEncoder as HRob
     tell_amd.set_compute_dtype(dtype)
     torch.manual_seed(1)
-    kw = dict(vocab=300, dim=128, ffn=256, layers=3, heads=2, max_positions=80)     # head_dim 64
+    kw = dict(vocab=300, dim=128, ffn=256, layers=3, heads=2, max_positions=160)     # head_dim 64
     ora = ORob(**kw).eval()
     for p in ora.parameters():
         if p.dim() == 1:
@@ -78,9 +78,9 @@ def test_roberta_matches_oracle(dtype):
     hipm = HRob(**kw).eval()
     hipm.load_state_dict(ora.state_dict())
     hipm.to(DEV)
-    ids = torch.randint(3, 300, (3, 70))
+    ids = torch.randint(3, 300, (3, 150))      # 5 query blocks -> long-sequence attention kernel
     ids[:, 0] = 0
-    ids[1, 50:] = 1
+    ids[1, 100:] = 1
     ids[2, 9:] = 1
     with torch.no_grad():
         ref = torch.stack(ora.extract_features(ids, return_all_hiddens=True))

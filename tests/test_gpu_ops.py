@@ -283,6 +283,8 @@ def _attn_case(dtype, T, B, E, H, S, kdim, use_mask, p, seed, has_bias=True):
     (33, 2, 1024, 16, 64, True, 0.0),   # T not a multiple of 32 -> 2 query blocks
     (1, 5, 1024, 16, 100, True, 0.0),   # generation step
     (70, 2, 1024, 16, 130, True, 0.1),
+    (160, 2, 1024, 16, 200, True, 0.1),  # >= 4 query blocks: shared 64-key-tile forward kernel
+    (128, 1, 1024, 16, 64, False, 0.0),
 ])
 def test_attention_core(dtype, T, B, E, H, S, mask, p):
     _attn_case(dtype, T, B, E, H, S, E, mask, p, seed=T * 131 + S)

@@ -102,6 +102,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
   constexpr int WAVE_ELEMS = 2 * 32 * DS + DP * SS + 32 * SS;   // Qs, Ks, Vt, Ps
   static_assert(WAVE_ELEMS * sizeof(T) >= (2 + 16 * DF) * 64 * sizeof(float), "combine buffer must fit");
   __shared__ __attribute__((aligned(16))) T smem[NW * WAVE_ELEMS];
+  __shared__ float key_bias[NW][32];                 // 0 / -inf per key of the wave's current tile
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
@@ -157,6 +158,12 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
         if (s == p.S && p.has_bias) return bv + (long)h * D;
         return nullptr;
       });
+      if (lane < 32) {                              // key-padding mask + range, branch-free in the softmax
+        const int s = s0 + lane;
+        bool ok = s < S_total;
+        if (ok && s < p.S && p.mask) ok = p.mask[(long)b * p.S + s] == 0;
+        key_bias[wave][lane] = ok ? 0.f : -INFINITY;
+      }
     }
     __syncthreads();
     float pr[16];
@@ -168,10 +175,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
       float mx = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int s = s0 + acc_row(r, lane);
-        bool ok = s < S_total;
-        if (ok && s < p.S && p.mask) ok = p.mask[(long)b * p.S + s] == 0;
-        st[r] = ok ? st[r] : -INFINITY;
+        st[r] += key_bias[wave][acc_row(r, lane)];
         mx = fmaxf(mx, st[r]);
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -261,6 +265,188 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
   if (lane < 32 && p.lse) p.lse[(long)bh * p.Tq + t] = l_run > 0.f ? m_run + __logf(l_run) : INFINITY;
 }
 
+// ------------------------------------------------------------------ forward, long sequences (Tq >= 128, D = 64)
+// RoBERTa self-attention shape.  One workgroup = 4 waves = 128 query rows of one (b,h); the 64-key
+// K tile and the transposed V tile are staged ONCE per workgroup (all 256 threads, next tile
+// prefetched into registers under the MFMAs) and shared by the 4 waves; each wave keeps its own
+// Q tile, probability tile and O^T accumulators.  Per 64 keys and wave: 16 MFMA 32x32x16.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_tile64_kernel(AttnArgs p) {
+  constexpr int D = 64, KT = 64, NW = 4;
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int PAD = sizeof(T) == 2 ? 8 : 1;
+  constexpr int DS = 64 + PAD;                       // stride of every [rows][64] tile
+  constexpr int CPR = D / VEC;                       // 16-byte chunks per row
+  constexpr int CPT = KT * CPR / 256;                // chunks per thread per tile (bf16 2, f32 4)
+  __shared__ __attribute__((aligned(16))) T Ks[KT * DS];
+  __shared__ __attribute__((aligned(16))) T Vt[D * DS];
+  __shared__ __attribute__((aligned(16))) T Qs[NW][32 * DS];
+  __shared__ __attribute__((aligned(16))) T Ps[NW][32 * DS];
+  __shared__ float key_bias[KT];                     // 0 for a valid key, -inf for padded / out-of-range keys
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+  const int QB = (p.Tq + 31) / 32;
+  const int qb = blockIdx.x * NW + wave;
+  const bool active = qb < QB;
+  const int q0 = qb * 32;
+  const int S_total = p.S + p.has_bias + p.has_zero;
+  const int nkt = (S_total + KT - 1) / KT;
+  const T* qg = static_cast<const T*>(p.q);
+  const T* kg = static_cast<const T*>(p.k);
+  const T* vg = static_cast<const T*>(p.v);
+  const T* bk = static_cast<const T*>(p.bias_k);
+  const T* bv = static_cast<const T*>(p.bias_v);
+
+  stage32<T, D>(Qs[wave], DS, (T*)nullptr, 0, lane, 64, [&](int row) -> const T* {
+    int t = q0 + row;
+    return (active && t < p.Tq) ? qg + t * p.q_st + b * p.q_sb + (long)h * D : nullptr;
+  });
+
+  // chunk -> (key row, 16-byte column).  bf16: a thread owns the SAME column of two adjacent keys so
+  // the transposed V store packs key pairs into 32-bit words; f32: plain round-robin.
+  auto chunk_row = [&](int i) -> int { return sizeof(T) == 2 ? 2 * (tid / CPR) + i : (tid + 256 * i) / CPR; };
+  auto chunk_col = [&](int i) -> int { return sizeof(T) == 2 ? tid % CPR : (tid + 256 * i) % CPR; };
+  u32x4 rk[CPT], rv[CPT];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#define LOAD_TILE(KTI)                                                                          \
+  {                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < CPT; ++i) {                                           \
+      const int s = (KTI) * KT + chunk_row(i), ch = chunk_col(i);                               \
+      const T* kp = s < p.S ? kg + s * p.k_ss + b * p.k_sb + (long)h * D                        \
+                            : (s == p.S && p.has_bias ? bk + (long)h * D : nullptr);            \
+      const T* vp = s < p.S ? vg + s * p.v_ss + b * p.v_sb + (long)h * D                        \
+                            : (s == p.S && p.has_bias ? bv + (long)h * D : nullptr);            \
+      rk[i] = kp ? *reinterpret_cast<const u32x4*>(kp + ch * VEC) : zero4;                      \
+      rv[i] = vp ? *reinterpret_cast<const u32x4*>(vp + ch * VEC) : zero4;                      \
+    }                                                                                           \
+  }
+  LOAD_TILE(0)
+
+  f32x16 o[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[f][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int qi = lane & 31;
+  T* myP = Ps[wave];
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int s0 = kt * KT;
+    __syncthreads();                                  // every wave is done with the previous tile
+    // ---- registers -> LDS: K rows as they are, V transposed (Vt[d][key])
+    if constexpr (sizeof(T) == 2) {
+      const int key = chunk_row(0), ch = chunk_col(0);
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) *reinterpret_cast<u32x4*>(Ks + (key + i) * DS + ch * VEC) = rk[i];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {                   // 8 d-values, 2 per 32-bit register
+        const unsigned a0 = rv[0][w], a1 = rv[1][w];
+        const unsigned lo = (a0 & 0xffffu) | (a1 << 16);          // d = ch*8 + 2w    : keys (key, key+1)
+        const unsigned hi = (a0 >> 16) | (a1 & 0xffff0000u);      // d = ch*8 + 2w + 1
+        *reinterpret_cast<unsigned*>(Vt + (ch * VEC + 2 * w) * DS + key) = lo;
+        *reinterpret_cast<unsigned*>(Vt + (ch * VEC + 2 * w + 1) * DS + key) = hi;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) {
+        const int key = chunk_row(i), ch = chunk_col(i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          Ks[key * DS + ch * VEC + e] = __uint_as_float(rk[i][e]);
+          Vt[(ch * VEC + e) * DS + key] = __uint_as_float(rv[i][e]);
+        }
+      }
+    }
+    if (tid < KT) {                                   // key-padding mask + range check, once per tile
+      const int s = s0 + tid;
+      bool ok = s < S_total;
+      if (ok && s < p.S && p.mask) ok = p.mask[(long)b * p.S + s] == 0;
+      key_bias[tid] = ok ? 0.f : -INFINITY;
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) LOAD_TILE(kt + 1)               // next tile streams in under the MFMAs
+    if (active) {
+      f32x16 st[2];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[f][r] = 0.f;
+        st[f] = mma32<T, D>(st[f], Ks + f * 32 * DS, DS, Qs[wave], DS, lane);     // S^T[key][q]
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          st[f][r] += key_bias[f * 32 + acc_row(r, lane)];
+          mx = fmaxf(mx, st[f][r]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+      float ls = 0.f;
+      const int t = q0 + qi;
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float pv = (st[f][r] == -INFINITY) ? 0.f : __expf(st[f][r] - m_new);
+          ls += pv;
+          if (p.thr)
+            pv *= tell_keep(p.seed, p.salt, ((uint64_t)bh * p.Tq + t) * S_total + (s0 + f * 32 + acc_row(r, lane)),
+                            p.thr, p.inv_keep);
+          st[f][r] = pv;
+        }
+      ls += __shfl_xor(ls, 32, 64);
+      l_run = l_run * alpha + ls;
+      m_run = m_new;
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[f][r] *= alpha;
+      // P[q][key]: registers r = 4g..4g+3 are 4 consecutive keys -> one 8-byte (bf16) store
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int k0 = f * 32 + 8 * g + 4 * (lane >> 5);
+          if constexpr (sizeof(T) == 2) {
+            uint2 w;
+            w.x = (unsigned)f2bf(st[f][4 * g]) | ((unsigned)f2bf(st[f][4 * g + 1]) << 16);
+            w.y = (unsigned)f2bf(st[f][4 * g + 2]) | ((unsigned)f2bf(st[f][4 * g + 3]) << 16);
+            *reinterpret_cast<uint2*>(myP + qi * DS + k0) = w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) myP[qi * DS + k0 + e] = st[f][4 * g + e];
+          }
+        }
+    }
+    __syncthreads();                                  // P visible to the whole wave (and block-uniform)
+    if (active) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f) o[f] = mma32<T, KT>(o[f], Vt + f * 32 * DS, DS, myP, DS, lane);  // O^T[d][q]
+    }
+  }
+#undef LOAD_TILE
+  if (!active) return;
+  const int t = q0 + qi;
+  if (t >= p.Tq) return;
+  const float inv_l = l_run > 0.f ? 1.f / l_run : 0.f;
+  T* og = static_cast<T*>(p.out) + t * p.o_st + b * p.o_sb + (long)h * D;
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {                     // 4 consecutive d per register group
+      const int d0 = f * 32 + 8 * g + 4 * (lane >> 5);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Elem<T>::st(og + d0 + e, o[f][4 * g + e] * inv_l);
+    }
+  if (lane < 32 && p.lse) p.lse[(long)bh * p.Tq + t] = l_run > 0.f ? m_run + __logf(l_run) : INFINITY;
+}
+
 // ------------------------------------------------------------------ backward
 // One workgroup per (b,h); its NW waves split the key tiles.  Query blocks of 32 are
 // the outer loop (Q-side tiles shared by the waves); dQ is reduced across waves in LDS;
@@ -274,6 +460,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(AttnArgs p) {
   static_assert(WAVE_ELEMS * sizeof(T) >= 16 * DF * 64 * sizeof(float), "dQ combine buffer must fit");
   __shared__ __attribute__((aligned(16))) T smem[SHARED_ELEMS + NW * WAVE_ELEMS];
   __shared__ float lse_s[32], delta_s[32];
+  __shared__ float key_ok[NW][32];                   // 1 / 0 per key of the wave's current tile
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
@@ -354,6 +541,12 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(AttnArgs p) {
           if (s == p.S && p.has_bias) return bv + (long)h * D;
           return nullptr;
         });
+        if (lane < 32) {
+          const int s = s0 + lane;
+          bool ok = s < S_total;
+          if (ok && s < p.S && p.mask) ok = p.mask[(long)b * p.S + s] == 0;
+          key_ok[wave][lane] = ok ? 1.f : 0.f;
+        }
       }
       __syncthreads();
       if (tv) {
@@ -367,8 +560,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int kk = acc_row(r, lane), s = s0 + kk;
-          bool ok = s < S_total && t < p.Tq;
-          if (ok && s < p.S && p.mask) ok = p.mask[(long)b * p.S + s] == 0;
+          const bool ok = key_ok[wave][kk] != 0.f && t < p.Tq;
           const float pv = ok ? __expf(st[r] - lse) : 0.f;
           float keep = 1.f;
           if (p.thr)
@@ -505,6 +697,12 @@ extern "C" int tell_attn_fwd(const void* q, const void* k, const void* v, void* 
                      v_ss, v_sb, o_st, o_sb, has_zero, p, seed, salt, dtype);
   if (rc) return rc;
   const int QB = (Tq + 31) / 32;
+  if (D == 64 && QB >= 4) {            // long sequences: shared 64-key tiles
+    dim3 grid((QB + 3) / 4, B * H);
+    if (dtype == TELL_BF16) hipLaunchKernelGGL((attn_fwd_tile64_kernel<uint16_t>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_tile64_kernel<float>), grid, dim3(256), 0, stream, a);
+    return tell_check_launch("attn_fwd_tile64");
+  }
   if (dtype == TELL_BF16) {
     constexpr int NW = 4;
     dim3 grid(QB == 1 ? 1 : (QB + NW - 1) / NW, B * H);
