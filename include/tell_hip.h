@@ -39,6 +39,9 @@ int tell_abi_version(void);
 int tell_device_count(void);
 const char* tell_last_error(void);
 void tell_set_error(const char* msg);
+/* host evaluation of the dropout hash / threshold used by every kernel (csrc/common.h) */
+uint32_t tell_hash32_host(uint32_t seed, uint32_t salt, uint64_t idx);
+uint32_t tell_drop_threshold_host(float p);
 
 /* ---- GEMM (every nn.Linear / F.linear / 1x1 conv on the path) --------------
  * C[M,N] = act((A[M,K] . B[N,K]^T + bias) * alpha) (+ C if accumulate)

@@ -1,0 +1,132 @@
+"""CPU checks: the C-ABI library loads and exports every symbol include/tell_hip.h declares,
+host-side logic (schedules, flat-buffer layout, RNG restatement, config shim, registries)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import tell_amd
+    protos = tell_amd.hip.parse_header()
+    assert len(protos) >= 45
+    lib = ctypes.CDLL(tell_amd.hip.LIB_PATH)
+    missing = [n for n in protos if not hasattr(lib, n)]
+    assert not missing, missing
+    bound = tell_amd.hip.lib()                       # binds restype/argtypes for all of them
+    assert bound.tell_abi_version() == 1
+    assert bound.tell_opt_chunk() == 1024
+    assert bound.tell_last_error() is not None
+    for must in ['tell_gemm_nt', 'tell_attn_fwd', 'tell_attn_bwd', 'tell_dynconv_fwd', 'tell_dynconv_bwd',
+                 'tell_layernorm_fwd', 'tell_ce_fwd', 'tell_adaptive_partition', 'tell_bertadam_step',
+                 'tell_adaptive_logprob_argmax', 'tell_im2col', 'tell_bn_stats']:
+        assert must in protos
+
+
+def test_product_fails_loudly_without_gpu():
+    import tell_amd
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(RuntimeError):
+        tell_amd.hip.require_gpu()
+    from tell_amd.models.resnet import ResNetFeatureExtractor
+    m = ResNetFeatureExtractor((1, 1, 1, 1), width=8)
+    with pytest.raises(RuntimeError):
+        m(torch.randn(1, 3, 224, 224))             # no CPU fallback
+
+
+def test_rng_restatement_matches_c():
+    import tell_amd
+    from tell_amd import rng
+    lib = tell_amd.hip.lib()
+    idx = np.array([0, 1, 2, 63, 64, 1000, 2 ** 31 - 1, 2 ** 32 + 5, 2 ** 40 + 123, 2 ** 63 - 1], dtype=np.uint64)
+    for seed, salt in [(0, 0), (0x5EED, 1), (123456789, 4000000000), (0xFFFFFFFF, 0xFFFFFFFF)]:
+        want = np.array([lib.tell_hash32_host(seed, salt, int(i)) for i in idx], dtype=np.uint64)
+        got = rng.hash32(seed, salt, idx)
+        assert (got == want).all(), (seed, salt)
+    for p in (0.0, 0.1, 0.25, 0.5, 0.999):
+        assert int(rng.threshold(p)) == lib.tell_drop_threshold_host(p)
+    m = rng.keep_mask(7, 9, 200000, 0.1)
+    assert abs(m.mean() - 0.9) < 5e-3
+
+
+def test_warmup_linear_and_flat_layout():
+    from tell_amd.training.optimizers import FlatParams, warmup_linear
+    assert warmup_linear(0.0, 0.05) == 0.0                  # first BertAdam step has lr 0
+    assert abs(warmup_linear(0.025, 0.05) - 0.5) < 1e-12
+    assert abs(warmup_linear(0.05, 0.05) - 1.0) < 1e-12
+    assert abs(warmup_linear(0.525, 0.05) - 0.5) < 1e-12
+    assert warmup_linear(1.5, 0.05) == 0.0
+    lin = torch.nn.Linear(5, 3)
+    tied = torch.nn.Linear(5, 3)
+    tied.weight = lin.weight
+    frozen = torch.nn.Parameter(torch.ones(7), requires_grad=False)
+    named = [('a.weight', lin.weight), ('a.bias', lin.bias), ('b.weight', tied.weight), ('f', frozen)]
+    before = lin.weight.detach().clone()
+    flat = FlatParams(named, 'cpu')
+    assert flat.names == ['a.weight', 'a.bias']             # tied + frozen parameters appear once / never
+    assert flat.total == 2048 and flat.n_chunks == 2        # CHUNK-aligned starts
+    assert torch.equal(lin.weight.detach(), before)
+    assert lin.weight.data_ptr() == flat.flat.data_ptr()
+    assert lin.weight.grad.data_ptr() == flat.grad.data_ptr()
+    assert flat.chunk_tensor.tolist() == [0, 1] and flat.chunk_begin.tolist() == [0, 1, 2]
+
+
+def _write_cfg(tmp_path, kind):
+    import yaml
+    from tell_amd.build import decoder_kwargs
+    dec = decoder_kwargs(vocab_size=600, dim=64, heads=4, ffn=128, cutoff=(100, 300))
+    dec['type'] = 'dynamic_conv_decoder_' + kind
+    dec['embedder'] = {
+        'type': 'sum',
+        'token_embedders': {
+            'adaptive': {'type': 'adaptive', 'vocab_size': 600, 'namespace': 'bpe', 'initial_dim': 64,
+                         'output_dim': 64, 'factor': 1, 'cutoff': [100, 300], 'padding_idx': 0, 'scale_embeds': True},
+            'position': {'type': 'sinusoidal_positional', 'init_size': 512, 'embedding_dim': 64, 'padding_idx': 1,
+                         'left_pad': False}},
+        'embedder_to_indexer_map': {'adaptive': ['roberta'], 'position': ['roberta']}, 'allow_unmatched_keys': True}
+    cfg = {'model': {'type': 'transformer_' + ('faces_objects' if kind == 'faces_objects' else 'flattened'),
+                     'decoder': dec, 'criterion': {'type': 'adaptive_loss', 'padding_idx': 1},
+                     'evaluate_mode': False, 'sampling_topk': 1, 'vocab_size': 600, 'weigh_bert': True,
+                     'padding_value': 1, 'index': 'roberta', 'namespace': 'bpe'},
+           'trainer': {'type': 'callback_apex', 'optimizer': {'type': 'bert_adam', 'lr': 1e-4},
+                       'no_grad': ['^resnet', '^roberta']}}
+    path = tmp_path / 'config.yaml'
+    path.write_text(yaml.safe_dump(cfg))
+    return str(path)
+
+
+@pytest.mark.parametrize('kind', ['flattened', 'faces_objects'])
+def test_from_params_shim(tmp_path, kind):
+    from tell_amd import config
+    from tell_amd.models import DynamicConvDecoder, DynamicConvFacesObjectsDecoder
+    model, params = config.from_config(_write_cfg(tmp_path, kind), overrides='{"model": {"weigh_bert": false}}',
+                                       resnet=object(), roberta=object())
+    assert isinstance(model.decoder, DynamicConvFacesObjectsDecoder if kind == 'faces_objects' else DynamicConvDecoder)
+    assert model.weigh_bert is False and params['trainer']['type'] == 'callback_apex'
+    keys = set(model.state_dict())
+    assert 'decoder.layers.3.context_attns.article.bias_k' in keys
+    assert 'decoder.adaptive_softmax.tail.1.2.weight' in keys
+    assert ('decoder.layers.0.context_attns.obj.k_proj_weight' in keys) == (kind == 'faces_objects')
+
+
+REF_CFG = '/root/reference/expt/nytimes/9_transformer_objects/config.yaml'
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CFG), reason='reference tree only exists in the authoring container')
+def test_reference_expt_configs_instantiate_unmodified():
+    from tell_amd import config
+    model, params = config.from_config(REF_CFG, resnet=object(), roberta=object())
+    assert sum(p.numel() for p in model.decoder.parameters()) == 200461312
+    assert model.weigh_bert and model.bert_weight.numel() == 25
+    m2, _ = config.from_config(REF_CFG.replace('9_transformer_objects', '5_transformer_roberta'),
+                               resnet=object(), roberta=object())
+    assert m2.decoder.layers[0].context_names == ['image', 'article']
+    from tell_amd.common.registrable import Registrable
+    from tell_amd.training.trainer import TrainerBase
+    assert TrainerBase.by_name(params['trainer']['type']).__name__ == 'CallbackApexTrainer'
+    assert isinstance(model, Registrable)

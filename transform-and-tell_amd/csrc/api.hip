@@ -17,3 +17,8 @@ extern "C" int tell_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
   return n;
 }
+
+// host-side evaluation of the dropout hash (same function the kernels use) - lets CPU tests pin
+// the numpy restatement in tell_amd/rng.py without a GPU
+extern "C" uint32_t tell_hash32_host(uint32_t seed, uint32_t salt, uint64_t idx) { return tell_hash32(seed, salt, idx); }
+extern "C" uint32_t tell_drop_threshold_host(float p) { return tell_drop_threshold(p); }

@@ -19,7 +19,7 @@ F32, BF16 = 0, 1
 
 _CTYPES = {
     'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float,
-    'uint32_t': ctypes.c_uint32, 'tell_stream_t': ctypes.c_void_p, 'void': None,
+    'uint32_t': ctypes.c_uint32, 'uint64_t': ctypes.c_uint64, 'tell_stream_t': ctypes.c_void_p, 'void': None,
 }
 
 

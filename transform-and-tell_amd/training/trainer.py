@@ -14,6 +14,7 @@ import torch
 
 from .. import runtime as rt
 from ..common.registrable import Registrable
+from . import dp
 from .optimizers import BertAdam, FlatParams, apply_no_grad
 
 
@@ -50,10 +51,8 @@ class Trainer:
         out = self.model(**batch)                                        # :220 / :194
         loss = out['loss']
         if self.world > 1:
-            n_local = out['sample_size'].to(torch.float32)
-            n_global = n_local.clone()
-            self.dist.all_reduce(n_global)
-            scaled = loss * (n_local * self.world / n_global)
+            scaled = loss * dp.loss_weight(out['sample_size'].to(torch.float32).reshape(1), self.dist,
+                                           self.world).reshape(())
         else:
             scaled = loss
         if self.nan_check:                                               # :225-227 (host sync, collective)
@@ -70,12 +69,7 @@ class Trainer:
         return loss.detach()
 
     def _all_reduce_grads(self):
-        g = self.flat.grad
-        handles = []
-        for s in range(0, g.numel(), self.bucket_elems):                 # few, large buckets: xGMI ring is per-link bound
-            handles.append(self.dist.all_reduce(g[s:s + self.bucket_elems], async_op=True))
-        for h in handles:
-            h.wait()
+        dp.all_reduce_flat(self.flat.grad, self.dist, self.bucket_elems)
 
 
 @TrainerBase.register('callback_apex')
