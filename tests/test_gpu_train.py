@@ -1,0 +1,135 @@
+"""GPU: multi-tensor BertAdam kernel and whole optimisation steps vs the CPU oracle."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+KW = dict(vocab_size=600, dim=64, heads=4, ffn=128, cutoff=(100, 300))
+
+
+@pytest.fixture(autouse=True)
+def _gpu():
+    import tell_amd
+    tell_amd.hip.require_gpu()
+    yield
+    torch.cuda.synchronize()
+
+
+def test_bertadam_kernel_matches_oracle():
+    from oracle.optim import BertAdam as OAdam
+    from tell_amd.training.optimizers import BertAdam, FlatParams
+    torch.manual_seed(0)
+    shapes = [(300, 70), (5,), (1024,), (33, 1), (2049,)]
+    cpu = [torch.nn.Parameter(torch.randn(*s)) for s in shapes]
+    gpu = [torch.nn.Parameter(p.detach().clone()) for p in cpu]
+    flat = FlatParams([('p%d' % i, p) for i, p in enumerate(gpu)], DEV)
+    cfg = dict(lr=1e-2, warmup=0.2, t_total=10, b1=0.9, b2=0.98, e=1e-6, weight_decay=1e-2, max_grad_norm=0.5)
+    opt = BertAdam(flat, **cfg)
+    ref = OAdam(cpu, **cfg)
+    for step in range(4):
+        for i, (a, b) in enumerate(zip(cpu, gpu)):
+            g = torch.randn_like(a) * (0.001 if i == 1 else 1.0)      # tensor 1 stays below the clip threshold
+            a.grad = g.clone()
+            b.grad.copy_(g.to(DEV))
+        ref.step()
+        opt.step()
+        for a, b in zip(cpu, gpu):
+            torch.testing.assert_close(b.detach().cpu(), a.detach(), rtol=1e-5, atol=1e-6)
+    assert opt.step_count == 4
+
+
+class _Rob(torch.nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        g = torch.Generator().manual_seed(3)
+        self.register_buffer('tab', torch.randn(3, 64, dim, generator=g) * 0.5)
+
+    def extract_features(self, ids, return_all_hiddens=False):
+        import tell_amd
+        out = self.tab[:, ids % 64]
+        if out.is_cuda:
+            return out.to(tell_amd.compute_dtype())
+        return list(out)
+
+
+class _Res(torch.nn.Module):
+    def __init__(self, nhwc):
+        super().__init__()
+        g = torch.Generator().manual_seed(4)
+        self.register_buffer('proj', torch.randn(2048, 3, generator=g) * 0.3)
+        self.nhwc = nhwc
+
+    def forward(self, image):
+        import tell_amd
+        f = torch.relu(torch.einsum('oc,bchw->bohw', self.proj, torch.nn.functional.avg_pool2d(image.float(), 32)))
+        if not self.nhwc:
+            return f
+        return f.permute(0, 2, 3, 1).reshape(f.shape[0], 49, 2048).to(tell_amd.compute_dtype()).contiguous()
+
+
+def _no_dropout(model):
+    for m in model.modules():
+        for a in ('dropout', 'input_dropout', 'relu_dropout', 'weight_dropout'):
+            if isinstance(getattr(m, a, None), float):
+                setattr(m, a, 0.0)
+
+
+@pytest.mark.parametrize('kind', ['flattened', 'faces_objects'])
+def test_two_training_steps_match_oracle_fp32(kind):
+    """forward + loss + backward + BertAdam, twice, parameters compared after each step."""
+    import tell_amd
+    from oracle.build import build_model as obuild
+    from oracle.optim import BertAdam as OAdam
+    from tell_amd.build import build_model
+    from tell_amd.data import synthetic_batch
+    from tell_amd.training import Trainer
+    tell_amd.set_compute_dtype(torch.float32)
+    torch.manual_seed(0)
+    adim = 64 if kind == 'flattened' else 1024
+    gpu = build_model(kind, _Res(True), _Rob(adim), n_bert_layers=3, article_dim=adim, **KW)
+    cpu = obuild(kind, _Res(False), _Rob(adim), n_bert_layers=3, article_dim=adim, **KW).train()
+    cpu.load_state_dict({k: v for k, v in gpu.state_dict().items() if k in cpu.state_dict()}, strict=False)
+    _no_dropout(gpu)
+    _no_dropout(cpu)
+    ocfg = dict(lr=5e-3, warmup=0.5, t_total=4, b1=0.9, b2=0.98, e=1e-6, weight_decay=1e-5, max_grad_norm=0.1)
+    trainer = Trainer(gpu, dict(ocfg), device=DEV)
+    ref_opt = OAdam([p for n, p in cpu.named_parameters() if not n.startswith(('resnet', 'roberta'))], **ocfg)
+    for step in range(3):
+        batch = synthetic_batch(B=3, article_len=20, caption_len=9, faces_objects=(kind == 'faces_objects'),
+                                vocab=600, cutoffs=(100, 300), seed=50 + step, variable=True)
+        ref_opt.zero_grad()
+        ref = cpu(**{k: (dict(v) if isinstance(v, dict) else v.clone()) for k, v in batch.items()})
+        ref['loss'].backward()
+        ref_opt.step()
+        dev_batch = {k: ({kk: vv.to(DEV) for kk, vv in v.items()} if isinstance(v, dict) else v.to(DEV))
+                     for k, v in batch.items()}
+        loss = trainer.train_one_batch(dev_batch)
+        assert abs(float(loss) - float(ref['loss'])) <= 1e-3 * abs(float(ref['loss'])), (step, float(loss), float(ref['loss']))
+    cp = dict(cpu.named_parameters())
+    worst = 0.0
+    for n, p in gpu.named_parameters():
+        if n.startswith(('resnet', 'roberta')):
+            continue
+        d = (p.detach().cpu() - cp[n].detach()).abs().max().item()
+        worst = max(worst, d / (cp[n].detach().abs().max().item() + 1e-6))
+    assert worst < 2e-3, worst
+
+
+def test_bf16_training_reduces_loss_with_dropout():
+    import tell_amd
+    from tell_amd.build import build_model
+    from tell_amd.data import synthetic_batch
+    from tell_amd.training import Trainer
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    tell_amd.manual_seed(11)
+    torch.manual_seed(1)
+    model = build_model('faces_objects', _Res(True), _Rob(1024), n_bert_layers=3, **KW)
+    trainer = Trainer(model, dict(lr=3e-3, warmup=0.1, t_total=60, max_grad_norm=1.0, weight_decay=0.0), device=DEV)
+    batch = synthetic_batch(B=4, article_len=24, caption_len=12, faces_objects=True, vocab=600, cutoffs=(100, 300), seed=7)
+    dev_batch = {k: ({kk: vv.to(DEV) for kk, vv in v.items()} if isinstance(v, dict) else v.to(DEV)) for k, v in batch.items()}
+    losses = []
+    for _ in range(40):
+        b = {k: (dict(v) if isinstance(v, dict) else v.clone()) for k, v in dev_batch.items()}
+        losses.append(float(trainer.train_one_batch(b)))
+    assert all(l == l for l in losses)                   # no NaN
+    assert sum(losses[-5:]) / 5 < 0.6 * sum(losses[:3]) / 3, losses

@@ -33,8 +33,8 @@ def synthetic_batch(B=16, article_len=512, caption_len=33, faces_objects=False, 
                     variable=False, device='cpu', cutoffs=(5000, 20000)):
     g = torch.Generator().manual_seed(seed)
     if variable:
-        alen = torch.randint(128, article_len + 1, (B,), generator=g)
-        clen = torch.randint(9, caption_len + 1, (B,), generator=g)
+        alen = torch.randint(min(128, max(article_len // 4, 3)), article_len + 1, (B,), generator=g)
+        clen = torch.randint(min(9, max(caption_len // 2, 3)), caption_len + 1, (B,), generator=g)
     else:
         alen = torch.full((B,), article_len)
         clen = torch.full((B,), caption_len)
