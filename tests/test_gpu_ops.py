@@ -57,7 +57,8 @@ DTYPES = [torch.float32, torch.bfloat16]
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('M,N,K', [(64, 64, 64), (130, 70, 96), (512, 1024, 1024), (37, 5002, 128),
-                                   (1000, 48, 1024), (300, 300, 2048), (2048, 2048, 512)])
+                                   (1000, 48, 1024), (300, 300, 2048), (2048, 2048, 512),
+                                   (4096, 4096, 256), (5000, 6200, 128), (8192, 4096, 320)])   # 256x128 / 256x256 tiles, ragged
 def test_gemm_nt(dtype, M, N, K):
     from tell_amd import ops
     g = torch.Generator().manual_seed(M * 7 + N)

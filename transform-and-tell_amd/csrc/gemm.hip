@@ -15,6 +15,7 @@
 // ds_read_b128 per 16-lane service group; f32: 33-dword stride).
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // 16-byte staging chunk (native vector: stays in VGPRs)
 
@@ -72,13 +73,201 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
-template <typename T, typename OutT, int BM, int BN, int PF>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
+// ------------------------------------------------------------- epilogue (shared by both GEMM kernels)
+// acc[i][j][r] holds C[mw + i*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)][nw + j*32 + (lane&31)]
+template <typename OutT, int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& p, int mw, int nw, int lane,
+                                              int M, int N) {
+  OutT* C = static_cast<OutT*>(p.C);
+  const OutT* aux = static_cast<const OutT*>(p.aux);
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = nw + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < M && n < N) {
+          float v = acc[i][j][r];
+          if (p.bias_mode == 1) v += p.bias[n];
+          else if (p.bias_mode == 2) v += p.bias[m];
+          v *= p.alpha;
+          if (p.act == 1) v = fmaxf(v, 0.f);
+          else if (p.act == 2) v = gelu_erf(v);
+          else if (p.act == 3) v = Elem<OutT>::ld(aux + (long)m * p.ldc + n) > 0.f ? v : 0.f;
+          OutT* dst = C + (long)m * p.ldc + n;
+          if (p.accumulate) v += Elem<OutT>::ld(dst);
+          Elem<OutT>::st(dst, v);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------- direct-to-LDS kernel (bf16, K % 64 == 0)
+// global_load_lds_dwordx4: every lane's 16 bytes go straight from L2/HBM into LDS (no VGPR staging, no
+// ds_write), the next K tile streams into the other LDS buffer while the MFMAs run on the current one.
+// The LDS image of a tile must be lane-linear (wave-uniform base + lane*16), so the bank-conflict
+// swizzle is applied on the SOURCE side: slot s (16 B) of the image holds row 2p + (l>>3), chunk l&7 with
+// p = s>>4 and l = (s&15) ^ (p&15); fragment reads apply the same involution.  A 16-lane service group
+// of ds_read_b128 then touches 16 distinct 16-byte slots of the 256-byte bank row (conflict-free).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+template <typename OutT, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(GemmArgs p) {
+  constexpr int NW = WAVES_M * WAVES_N, BK = 64;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int IA = BM / 8 / NW, IB = BN / 8 / NW;   // wave-instructions (1 KiB each) per wave per tile
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 32, NI = WN / 32;
+  static_assert(IA >= 1 && IB >= 1, "tile too small for the wave count");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  int M = p.M;
+  if (p.m_dev) { int md = *p.m_dev; M = md < M ? md : M; }
+  const int N = p.N, K = p.K;
+  const int tiles_n = (N + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  int tile_id;
+  {
+    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int m0 = (tile_id / tiles_n) * BM, n0 = (tile_id % tiles_n) * BN;
+  if (m0 >= M) return;
+
+  const uint16_t* A = static_cast<const uint16_t*>(p.A);
+  const uint16_t* B = static_cast<const uint16_t*>(p.B);
+  // per-lane source pointers (row clamped: rows past M/N only feed outputs that are never stored)
+  const uint16_t* asrc[IA];
+  const uint16_t* bsrc[IB];
+#pragma unroll
+  for (int j = 0; j < IA; ++j) {
+    const int s = (wave * IA + j) * 64 + lane, pr = s >> 4, l16 = (s & 15) ^ (pr & 15);
+    int row = m0 + 2 * pr + (l16 >> 3);
+    row = row < M ? row : M - 1;
+    asrc[j] = A + (long)row * p.lda + (l16 & 7) * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < IB; ++j) {
+    const int s = (wave * IB + j) * 64 + lane, pr = s >> 4, l16 = (s & 15) ^ (pr & 15);
+    int row = n0 + 2 * pr + (l16 >> 3);
+    row = row < N ? row : N - 1;
+    bsrc[j] = B + (long)row * p.ldb + (l16 & 7) * 8;
+  }
+  auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+    unsigned char* sa = smem + stage * STAGE + (wave * IA) * 1024;
+    unsigned char* sb = smem + stage * STAGE + A_BYTES + (wave * IB) * 1024;
+#pragma unroll
+    for (int j = 0; j < IA; ++j)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[j] + kt * BK), (lds_ptr_t)(sa + j * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < IB; ++j)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(bsrc[j] + kt * BK), (lds_ptr_t)(sb + j * 1024), 16, 0, 0);
+  };
+
+  // fragment addressing: row r of a tile, 16-byte k-chunk c (0..7): byte = (r>>1)*256 + ((((r&1)<<3)|c) ^ ((r>>1)&15))*16
+  int a_base[MI], a_x[MI], a_hi[MI], b_base[NI], b_x[NI], b_hi[NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int r = wm * WM + i * 32 + (lane & 31);
+    a_base[i] = (r >> 1) * 256; a_x[i] = (r >> 1) & 15; a_hi[i] = (r & 1) << 3;
+  }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int r = wn * WN + j * 32 + (lane & 31);
+    b_base[j] = (r >> 1) * 256; b_x[j] = (r >> 1) & 15; b_hi[j] = (r & 1) << 3;
+  }
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = K / BK;
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int st = kt & 1;
+    if (kt + 1 < nk) issue(kt + 1, st ^ 1);          // streams in under the MFMAs below
+    const unsigned char* ta = smem + st * STAGE;
+    const unsigned char* tb = ta + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = ks * 2 + (lane >> 5);
+      bf16x8 a[MI], b[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        a[i] = *reinterpret_cast<const bf16x8*>(ta + a_base[i] + (((a_hi[i] | c) ^ a_x[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        b[j] = *reinterpret_cast<const bf16x8*>(tb + b_base[j] + (((b_hi[j] | c) ^ b_x[j]) << 4));
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMA pieces of tile kt+1 have landed
+    __syncthreads();                                     // everyone's have, and buffer `st` is free again
+  }
+  // ---- epilogue.  Full interior bf16 tiles go through LDS (the tile buffers are free now): the MFMA
+  // C layout gives each lane ONE column of 16 rows, so direct stores are 2-byte scatters; staged, every
+  // lane writes 16 contiguous bytes and a row of the tile leaves as whole 128-byte lines.
+  if constexpr (sizeof(OutT) == 2) {
+    constexpr int CS = BN + 8;                           // padded row (elements)
+    static_assert(BM * CS * 2 <= 2 * STAGE, "output tile must fit the freed tile buffers");
+    const bool fast = !p.accumulate && p.act != 3 && m0 + BM <= M && n0 + BN <= N && (p.ldc & 7) == 0 &&
+                      (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
+    if (fast) {                                          // block-uniform
+      uint16_t* Cs = reinterpret_cast<uint16_t*>(smem);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int col = wn * WN + j * 32 + (lane & 31);
+          const float bn_ = p.bias_mode == 1 ? p.bias[n0 + col] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float v = acc[i][j][r] + bn_;
+            if (p.bias_mode == 2) v += p.bias[m0 + row];
+            v *= p.alpha;
+            if (p.act == 1) v = fmaxf(v, 0.f);
+            else if (p.act == 2) v = gelu_erf(v);
+            Cs[row * CS + col] = f2bf(v);
+          }
+        }
+      __syncthreads();
+      constexpr int CPRW = BN / 8, NT = 64 * NW;         // 16-byte chunks per tile row
+      uint16_t* C = static_cast<uint16_t*>(p.C);
+#pragma unroll
+      for (int i = 0; i < BM * CPRW / NT; ++i) {
+        const int c = tid + i * NT, row = c / CPRW, ch = c % CPRW;
+        *reinterpret_cast<u32x4*>(C + (long)(m0 + row) * p.ldc + n0 + ch * 8) =
+            *reinterpret_cast<const u32x4*>(Cs + row * CS + ch * 8);
+      }
+      return;
+    }
+  }
+  gemm_epilogue<OutT, MI, NI>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, M, N);
+}
+
+template <typename T, typename OutT, int BM, int BN, int WAVES_M, int WAVES_N, int PF>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 4 * (BM * BN >= 256 * 128 ? 1 : 2))
+void gemm_nt_kernel(GemmArgs p) {
   using M_ = Mma<T>;
+  constexpr int NT = 64 * WAVES_M * WAVES_N;    // threads per workgroup
   constexpr int BK = M_::BK, STRIDE = M_::STRIDE, VEC = Elem<T>::VEC;
   constexpr int CPR = BK / VEC;                 // 16-byte chunks per tile row (= 8)
-  constexpr int CHA = BM * CPR / 256, CHB = BN * CPR / 256;
-  constexpr int WM = BM / 2, WN = BN / 2;       // per-wave tile
+  constexpr int CHA = BM * CPR / NT, CHB = BN * CPR / NT;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // per-wave tile
   constexpr int MI = WM / 32, NI = WN / 32;
   static_assert(PF == 2 || PF == 4, "prefetch depth 2 or 4 (even: LDS double-buffer parity)");
 
@@ -86,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) T Bs[2][BN * STRIDE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   int M = p.M;
   if (p.m_dev) { int md = *p.m_dev; M = md < M ? md : M; }
   const int N = p.N, K = p.K;
@@ -117,61 +306,69 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 
   // PF register stages: tiles kt .. kt+PF-1 are in flight from HBM/L2 while tile kt is multiplied
   u32x4 ra[PF][CHA], rb[PF][CHB];
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  // Pipeline discipline (keeps hipcc's s_waitcnt vmcnt COUNTED instead of vmcnt(0)):
+  //  * every stage issues its global loads unconditionally, in straight-line code, from a clamped
+  //    in-range address (no divergent branch, no uniform guard, plain global_load);
+  //  * the loaded registers have no consumer until SSTORE, where out-of-range chunks are replaced
+  //    by zeros (select at the point where the data is needed anyway);
+  //  * steps past the last K tile run on all-zero tiles (they add 0 to the accumulators).
+  const int Mc = M - 1, Nc = N - 1;
 #define GLOAD(KT, S)                                                                              \
   {                                                                                               \
     _Pragma("unroll") for (int i = 0; i < CHA; ++i) {                                             \
-      int c = tid + i * 256, row = c / CPR, ch = c % CPR;                                         \
-      int gm = m0 + row, gk = (KT) * BK + ch * VEC;                                               \
-      ra[S][i] = (gm < M && gk < K) ? *reinterpret_cast<const u32x4*>(A + (long)gm * p.lda + gk) : zero4; \
+      const int c = tid + i * NT, row = c / CPR, ch = c % CPR;                                   \
+      const int gm = m0 + row, gk = (KT) * BK + ch * VEC;                                         \
+      ra[S][i] = *reinterpret_cast<const u32x4*>(A + (long)(gm < M ? gm : Mc) * p.lda + (gk < K ? gk : 0)); \
     }                                                                                             \
     _Pragma("unroll") for (int i = 0; i < CHB; ++i) {                                             \
-      int c = tid + i * 256, row = c / CPR, ch = c % CPR;                                         \
-      int gn = n0 + row, gk = (KT) * BK + ch * VEC;                                               \
-      rb[S][i] = (gn < N && gk < K) ? *reinterpret_cast<const u32x4*>(B + (long)gn * p.ldb + gk) : zero4; \
+      const int c = tid + i * NT, row = c / CPR, ch = c % CPR;                                   \
+      const int gn = n0 + row, gk = (KT) * BK + ch * VEC;                                         \
+      rb[S][i] = *reinterpret_cast<const u32x4*>(B + (long)(gn < N ? gn : Nc) * p.ldb + (gk < K ? gk : 0)); \
     }                                                                                             \
   }
-#define SSTORE(S, BUF)                                                                            \
+#define SSTORE(S, BUF, KT)                                                                        \
   {                                                                                               \
     _Pragma("unroll") for (int i = 0; i < CHA; ++i) {                                             \
-      int c = tid + i * 256;                                                                      \
-      M_::store_chunk(As[BUF], c / CPR, c % CPR, ra[S][i]);                                       \
+      const int c = tid + i * NT, row = c / CPR, ch = c % CPR;                                   \
+      const bool ok = (m0 + row) < M && ((KT) * BK + ch * VEC) < K;                               \
+      M_::store_chunk(As[BUF], row, ch, ok ? ra[S][i] : zero4);                                   \
     }                                                                                             \
     _Pragma("unroll") for (int i = 0; i < CHB; ++i) {                                             \
-      int c = tid + i * 256;                                                                      \
-      M_::store_chunk(Bs[BUF], c / CPR, c % CPR, rb[S][i]);                                       \
+      const int c = tid + i * NT, row = c / CPR, ch = c % CPR;                                   \
+      const bool ok = (n0 + row) < N && ((KT) * BK + ch * VEC) < K;                               \
+      M_::store_chunk(Bs[BUF], row, ch, ok ? rb[S][i] : zero4);                                   \
     }                                                                                             \
   }
 
   const int nk = (K + BK - 1) / BK;
+  const int nk_pad = (nk + PF - 1) / PF * PF;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
   // one pipeline step with a LITERAL stage index S (register stages must be statically indexed)
 #define STEP(S)                                                                                   \
   {                                                                                               \
     const int kt = kt0 + (S);                                                                     \
-    if (kt < nk) {                                                                                \
-      if (kt + PF < nk) GLOAD(kt + PF, S)                                                         \
-      const T* at = As[(S) & 1] + (wm * WM) * STRIDE;                                             \
-      const T* bt = Bs[(S) & 1] + (wn * WN) * STRIDE;                                             \
-      _Pragma("unroll") for (int ks = 0; ks < BK; ks += M_::KSTEP) {                              \
-        typename M_::frag a[MI], b[NI];                                                           \
-        _Pragma("unroll") for (int i = 0; i < MI; ++i) a[i] = M_::load(at, i * 32 + (lane & 31), ks, lane); \
-        _Pragma("unroll") for (int j = 0; j < NI; ++j) b[j] = M_::load(bt, j * 32 + (lane & 31), ks, lane); \
-        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                            \
-          _Pragma("unroll") for (int j = 0; j < NI; ++j) acc[i][j] = M_::mma(a[i], b[j], acc[i][j]); \
-      }                                                                                           \
-      if (kt + 1 < nk) SSTORE(((S) + 1) % PF, ((S) + 1) & 1)                                      \
-      __syncthreads();                                                                            \
+    GLOAD(kt + PF, S)                                                                             \
+    const T* at = As[(S) & 1] + (wm * WM) * STRIDE;                                               \
+    const T* bt = Bs[(S) & 1] + (wn * WN) * STRIDE;                                               \
+    _Pragma("unroll") for (int ks = 0; ks < BK; ks += M_::KSTEP) {                                \
+      typename M_::frag a[MI], b[NI];                                                             \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i) a[i] = M_::load(at, i * 32 + (lane & 31), ks, lane); \
+      _Pragma("unroll") for (int j = 0; j < NI; ++j) b[j] = M_::load(bt, j * 32 + (lane & 31), ks, lane); \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                              \
+        _Pragma("unroll") for (int j = 0; j < NI; ++j) acc[i][j] = M_::mma(a[i], b[j], acc[i][j]); \
     }                                                                                             \
+    SSTORE(((S) + 1) % PF, ((S) + 1) & 1, kt + 1)                                                 \
+    __syncthreads();                                                                              \
   }
   GLOAD(0, 0)
-  if (1 < nk) GLOAD(1, 1)
+  GLOAD(1, 1)
   if constexpr (PF == 4) {
-    if (2 < nk) GLOAD(2, 2)
-    if (3 < nk) GLOAD(3, 3)
+    GLOAD(2, 2)
+    GLOAD(3, 3)
   }
-  SSTORE(0, 0)
+  SSTORE(0, 0, 0)
   __syncthreads();
-  for (int kt0 = 0; kt0 < nk; kt0 += PF) {
+  for (int kt0 = 0; kt0 < nk_pad; kt0 += PF) {
     STEP(0)
     STEP(1)
     if constexpr (PF == 4) {
@@ -183,46 +380,34 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 #undef GLOAD
 #undef SSTORE
 
-  // ------------------------------------------------------------- epilogue
-  OutT* C = static_cast<OutT*>(p.C);
-  const OutT* aux = static_cast<const OutT*>(p.aux);
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int n = n0 + wn * WN + j * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < M && n < N) {
-          float v = acc[i][j][r];
-          if (p.bias_mode == 1) v += p.bias[n];
-          else if (p.bias_mode == 2) v += p.bias[m];
-          v *= p.alpha;
-          if (p.act == 1) v = fmaxf(v, 0.f);
-          else if (p.act == 2) v = gelu_erf(v);
-          else if (p.act == 3) v = Elem<OutT>::ld(aux + (long)m * p.ldc + n) > 0.f ? v : 0.f;
-          OutT* dst = C + (long)m * p.ldc + n;
-          if (p.accumulate) v += Elem<OutT>::ld(dst);
-          Elem<OutT>::st(dst, v);
-        }
-      }
-    }
-  }
+  gemm_epilogue<OutT, MI, NI>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, M, N);
 }
 
 template <typename T, typename OutT>
 static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
-  // large tile only when it still fills the 256 CUs; the small tile gets a deeper prefetch
-  // (its per-tile MFMA time is too short to cover HBM latency with 2 tiles in flight)
-  long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-  if (tiles128 >= 256) {
-    dim3 grid((unsigned)tiles128);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, 128, 128, 2>), grid, dim3(256), 0, stream, a);
+  // Tile choice: the kernel is bound by operand re-reads from L2 (flop/byte of a tile =
+  // BM*BN/(BM+BN) per 2-byte element), so take the largest tile that still gives every CU work.
+  auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+  if constexpr (sizeof(T) == 2) {
+    if (a.K % 64 == 0 && tiles(128, 128) >= 256) {       // direct-to-LDS path
+      static const int force = getenv("TELL_GEMM_TILE") ? atoi(getenv("TELL_GEMM_TILE")) : 0;   // tuning aid
+      if (force == 2)     // 256x128 (8 waves, 1 workgroup/CU) ties 128x128 (2 workgroups/CU) on MI355X: opt-in only
+        hipLaunchKernelGGL((gemm_nt_glds_kernel<OutT, 256, 128, 4, 2>), dim3((unsigned)tiles(256, 128)), dim3(512), 0, stream, a);
+      else
+        hipLaunchKernelGGL((gemm_nt_glds_kernel<OutT, 128, 128, 2, 2>), dim3((unsigned)tiles(128, 128)), dim3(256), 0, stream, a);
+      return tell_check_launch("gemm_nt_glds");
+    }
+  }
+  // (256x256 with 8 waves measured SLOWER than 256x128 on MI355X - 394 vs 552 TFLOP/s on the RoBERTa
+  //  shapes: 236 VGPRs, one workgroup per CU - so it is compiled but not selected)
+  if (sizeof(T) == 2 && tiles(256, 256) >= (1L << 40)) {
+    hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, 256, 256, 2, 4, 2>), dim3((unsigned)tiles(256, 256)), dim3(512), 0, stream, a);
+  } else if (sizeof(T) == 2 && tiles(256, 128) >= 256) {
+    hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, 256, 128, 4, 2, 2>), dim3((unsigned)tiles(256, 128)), dim3(512), 0, stream, a);
+  } else if (tiles(128, 128) >= 256) {
+    hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, 128, 128, 2, 2, 2>), dim3((unsigned)tiles(128, 128)), dim3(256), 0, stream, a);
   } else {
-    long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
-    dim3 grid((unsigned)tiles64);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, 64, 64, 4>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, 64, 64, 2, 2, 4>), dim3((unsigned)tiles(64, 64)), dim3(256), 0, stream, a);
   }
   return tell_check_launch("gemm_nt");
 }

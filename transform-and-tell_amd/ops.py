@@ -76,9 +76,18 @@ def gemm(a, b, out=None, out_dtype=None, bias=None, bias_mode=0, act=0, aux=None
     assert out.stride(1) == 1
     rec = None
     if prof.enabled() and m_dev is None:
-        tile = 128 if ((M + 127) // 128) * ((N + 127) // 128) >= 256 else 64       # mirrors launch_gemm()
-        rec = prof.begin('gemm_nt_kernel<%s,%s,%d,%d>' % (('f32', 'bf16')[hip.dt(a)], ('f32', 'bf16')[hip.dt(out)],
-                                                         tile, tile), 2.0 * M * N * a.shape[1])
+        def tiles(bm, bn):
+            return ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
+        bf = hip.dt(a) == hip.BF16                                                 # mirrors launch_gemm()
+        names = ('f32', 'bf16')[hip.dt(a)], ('f32', 'bf16')[hip.dt(out)]
+        if bf and a.shape[1] % 64 == 0 and tiles(128, 128) >= 256:
+            tile = (128, 128)
+            kname = 'gemm_nt_glds_kernel<%s,%d,%d>' % (names[1], tile[0], tile[1])
+        else:
+            tile = ((256, 128) if bf and tiles(256, 128) >= 256 else (128, 128) if tiles(128, 128) >= 256
+                    else (64, 64))
+            kname = 'gemm_nt_kernel<%s,%s,%d,%d>' % (names[0], names[1], tile[0], tile[1])
+        rec = prof.begin(kname, 2.0 * M * N * a.shape[1])
     call('tell_gemm_nt', a, a.stride(0), b, b.stride(0), out, out.stride(0), M, N, a.shape[1], hip.dt(a),
          hip.dt(out), bias, bias_mode, act, aux, float(alpha), int(accumulate), m_dev)
     if rec is not None:
@@ -123,7 +132,10 @@ _wcache = {}
 
 def _cached(p, key, maker):
     k = (id(p), key)
-    stamp = (rt.weights_epoch(), rt.compute_dtype(), p._version, p.data_ptr())
+    # trainable masters are rewritten by the optimizer kernel (which bypasses torch's version counter) ->
+    # keyed on the weights epoch; frozen tensors (encoders, buffers) only change through torch ops
+    epoch = rt.weights_epoch() if p.requires_grad else -1
+    stamp = (epoch, rt.compute_dtype(), p._version, p.data_ptr())
     e = _wcache.get(k)
     if e is None or e[0] != stamp:
         e = (stamp, maker())
