@@ -128,7 +128,45 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x
     pm2[(long)blockIdx.y * C + c] = m2;
   }
 }
-// stage 2: Chan combine over the (<= 64) chunks, one wave per channel, butterfly over lanes
+// stage 1 (vectorised): each thread owns one 16-byte column chunk and walks rows; statistics are
+// accumulated SHIFTED by the chunk's first row (sum(x-s), sum((x-s)^2)) so the single pass stays
+// accurate in fp32; row lanes are reduced through LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_partial_vec_kernel(const T* __restrict__ x, long M, int C, int BN_ROWS,
+                                                             float* __restrict__ pmean, float* __restrict__ pm2) {
+  constexpr int VEC = Elem<T>::VEC;
+  __shared__ float red_s[256 * VEC], red_q[256 * VEC];
+  const int cpr = C / VEC;
+  const int CB = cpr < 256 ? cpr : 256, RL = 256 / CB;
+  const int tid = threadIdx.x, cl = tid % CB, rl = tid / CB;
+  const int cc = blockIdx.x * CB + cl;
+  const long r0 = (long)blockIdx.y * BN_ROWS;
+  const long r1 = r0 + BN_ROWS < M ? r0 + BN_ROWS : M;
+  float sh[VEC], s[VEC], q[VEC];
+  unpack16(*reinterpret_cast<const uint4*>(x + r0 * C + (long)cc * VEC), sh, (const T*)nullptr);
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) { s[k] = 0.f; q[k] = 0.f; }
+  for (long r = r0 + rl; r < r1; r += RL) {
+    float v[VEC];
+    unpack16(*reinterpret_cast<const uint4*>(x + r * C + (long)cc * VEC), v, (const T*)nullptr);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { const float d = v[k] - sh[k]; s[k] += d; q[k] += d * d; }
+  }
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) { red_s[(rl * CB + cl) * VEC + k] = s[k]; red_q[(rl * CB + cl) * VEC + k] = q[k]; }
+  __syncthreads();
+  if (rl == 0) {
+    const float n = (float)(r1 - r0);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      float ts = 0.f, tq = 0.f;
+      for (int j = 0; j < RL; ++j) { ts += red_s[(j * CB + cl) * VEC + k]; tq += red_q[(j * CB + cl) * VEC + k]; }
+      pmean[(long)blockIdx.y * C + cc * VEC + k] = sh[k] + ts / n;
+      pm2[(long)blockIdx.y * C + cc * VEC + k] = tq - ts * ts / n;
+    }
+  }
+}
+// stage 2: Chan combine over the chunks, one wave per channel (lanes stride the chunks, then butterfly)
 __global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict__ pmean, const float* __restrict__ pm2,
                                                         long M, int C, int n_chunks, int BN_ROWS, float eps,
                                                         float momentum, float* __restrict__ mean,
@@ -138,11 +176,14 @@ __global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict_
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
   float n = 0.f, mu = 0.f, m2 = 0.f;
-  if (lane < n_chunks) {
-    const long r0 = (long)lane * BN_ROWS;
-    n = (float)((r0 + BN_ROWS < M ? r0 + BN_ROWS : M) - r0);
-    mu = pmean[(long)lane * C + c];
-    m2 = pm2[(long)lane * C + c];
+  for (int k = lane; k < n_chunks; k += 64) {
+    const long r0 = (long)k * BN_ROWS;
+    const float nb = (float)((r0 + BN_ROWS < M ? r0 + BN_ROWS : M) - r0);
+    const float mb = pmean[(long)k * C + c], qb = pm2[(long)k * C + c];
+    const float nt = n + nb, delta = mb - mu;
+    mu = (n * mu + nb * mb) / nt;
+    m2 = m2 + qb + delta * delta * n * nb / nt;
+    n = nt;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -166,8 +207,8 @@ __global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict_
   }
 }
 static inline int bn_rows_per_chunk(long M) {
-  long r = (M + 63) / 64;                     // at most 64 chunks
-  if (r < 256) r = 256;
+  long r = (M + 255) / 256;                   // ~256 row chunks -> enough workgroups for every layer shape
+  if (r < 8) r = 8;
   return (int)((r + 7) / 8 * 8);
 }
 extern "C" long tell_bn_chunks(long M) { const int r = bn_rows_per_chunk(M); return (M + r - 1) / r; }
@@ -180,9 +221,18 @@ extern "C" int tell_bn_stats(const void* x, long M, int C, float eps, float mome
   const long nch = tell_bn_chunks(M);
   float* pmean = workspace;
   float* pm2 = workspace + nch * C;
-  dim3 grid((C + 31) / 32, (unsigned)nch);
-  if (dtype == TELL_BF16) hipLaunchKernelGGL((bn_partial_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)x, M, C, rpc, pmean, pm2);
-  else hipLaunchKernelGGL((bn_partial_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, M, C, rpc, pmean, pm2);
+  const int vec = dtype == TELL_BF16 ? 8 : 4;
+  const int cpr = C / vec;
+  const bool pow2 = cpr > 0 && (cpr & (cpr - 1)) == 0;
+  if (C % vec == 0 && pow2 && ((uintptr_t)x & 15) == 0 && (cpr <= 256 || cpr % 256 == 0)) {
+    dim3 grid(cpr <= 256 ? 1 : cpr / 256, (unsigned)nch);
+    if (dtype == TELL_BF16) hipLaunchKernelGGL((bn_partial_vec_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)x, M, C, rpc, pmean, pm2);
+    else hipLaunchKernelGGL((bn_partial_vec_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, M, C, rpc, pmean, pm2);
+  } else {
+    dim3 grid((C + 31) / 32, (unsigned)nch);
+    if (dtype == TELL_BF16) hipLaunchKernelGGL((bn_partial_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)x, M, C, rpc, pmean, pm2);
+    else hipLaunchKernelGGL((bn_partial_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, M, C, rpc, pmean, pm2);
+  }
   hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, pmean, pm2, M, C, (int)nch, rpc, eps, momentum, mean, invstd, running_mean, running_var);
   return tell_check_launch("bn_stats");
 }
@@ -202,11 +252,44 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
     Elem<T>::st(y + i, v);
   }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_vec_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const T* __restrict__ residual, T* __restrict__ y, long M,
+                                                           int C, int relu) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cpr = C / VEC;
+  const long n = M * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cpr) * VEC;
+    float v[VEC], r[VEC];
+    unpack16(*reinterpret_cast<const uint4*>(x + i * VEC), v, (const T*)nullptr);
+    if (residual) unpack16(*reinterpret_cast<const uint4*>(residual + i * VEC), r, (const T*)nullptr);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      float o = (v[k] - mean[c0 + k]) * invstd[c0 + k] * gamma[c0 + k] + beta[c0 + k];
+      if (residual) o += r[k];
+      v[k] = relu ? fmaxf(o, 0.f) : o;
+    }
+    *reinterpret_cast<uint4*>(y + i * VEC) = pack16(v, (const T*)nullptr);
+  }
+}
+
 extern "C" int tell_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma,
                              const float* beta, const void* residual, void* y, long M, int C, int relu,
                              int dtype, hipStream_t stream) {
   long n = M * C;
   if (n <= 0) return TELL_OK;
+  const int vec = dtype == TELL_BF16 ? 8 : 4;
+  if (C % vec == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)residual & 15) == 0) {
+    long nv = n / vec;
+    int gv = (int)((nv + 255) / 256 > 16384 ? 16384 : (nv + 255) / 256);
+    if (dtype == TELL_BF16) hipLaunchKernelGGL((bn_apply_vec_kernel<uint16_t>), dim3(gv), dim3(256), 0, stream, (const uint16_t*)x, mean, invstd, gamma, beta, (const uint16_t*)residual, (uint16_t*)y, M, C, relu);
+    else hipLaunchKernelGGL((bn_apply_vec_kernel<float>), dim3(gv), dim3(256), 0, stream, (const float*)x, mean, invstd, gamma, beta, (const float*)residual, (float*)y, M, C, relu);
+    return tell_check_launch("bn_apply_vec");
+  }
   int g = (int)((n + 1023) / 1024 > 8192 ? 8192 : (n + 1023) / 1024);
   if (dtype == TELL_BF16) hipLaunchKernelGGL((bn_apply_kernel<uint16_t>), dim3(g), dim3(256), 0, stream, (const uint16_t*)x, mean, invstd, gamma, beta, (const uint16_t*)residual, (uint16_t*)y, M, C, relu);
   else hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(g), dim3(256), 0, stream, (const float*)x, mean, invstd, gamma, beta, (const float*)residual, (float*)y, M, C, relu);
