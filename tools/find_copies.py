@@ -1,4 +1,4 @@
-import sys, collections, torch
+import sys, collections, traceback, torch
 sys.path.insert(0, '.')
 import tell_amd
 from tell_amd.build import build_model
@@ -13,14 +13,28 @@ fresh = lambda b: {k: (dict(v) if isinstance(v, dict) else v) for k, v in b.item
 for _ in range(2):
     trainer.train_one_batch(fresh(batch))
 torch.cuda.synchronize()
-from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-    trainer.train_one_batch(fresh(batch))
-    torch.cuda.synchronize()
 cnt = collections.Counter()
-for e in prof.events():
-    if e.name in ('aten::copy_', 'aten::clone', 'aten::contiguous', 'aten::fill_', 'aten::zero_', 'aten::zeros', 'aten::cat'):
-        frames = [s for s in e.stack if 'transform-and-tell_amd' in s or 'bench' in s][:2]
-        cnt[(e.name, tuple(frames))] += 1
-for (name, frames), n in cnt.most_common(25):
-    print(n, name, ' <- '.join(f.split('transform-and-tell_amd/')[-1] for f in frames))
+def wrap(name):
+    orig = getattr(torch.Tensor, name)
+    def f(self, *a, **k):
+        st = [s for s in traceback.extract_stack()[:-1] if 'transform-and-tell_amd' in s.filename]
+        key = (name, tuple('%s:%d' % (s.filename.split('transform-and-tell_amd/')[-1], s.lineno) for s in st[-2:]))
+        if name != 'contiguous' or not self.is_contiguous():
+            cnt[key] += 1
+        return orig(self, *a, **k)
+    setattr(torch.Tensor, name, f)
+for n in ['copy_', 'clone', 'contiguous', 'to', '__setitem__', 'float', 'fill_', 'zero_']:
+    wrap(n)
+for fn in ['zeros', 'zeros_like', 'cat', 'full']:
+    orig = getattr(torch, fn)
+    def mk(orig, fn):
+        def f(*a, **k):
+            st = [s for s in traceback.extract_stack()[:-1] if 'transform-and-tell_amd' in s.filename]
+            cnt[(fn, tuple('%s:%d' % (s.filename.split('transform-and-tell_amd/')[-1], s.lineno) for s in st[-2:]))] += 1
+            return orig(*a, **k)
+        return f
+    setattr(torch, fn, mk(orig, fn))
+trainer.train_one_batch(fresh(batch))
+torch.cuda.synchronize()
+for (name, frames), n in cnt.most_common(30):
+    print(n, name, ' <- '.join(frames))

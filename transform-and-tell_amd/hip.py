@@ -93,10 +93,32 @@ def _conv(a):
     return a
 
 
+_bound_stream = None      # raw hipStream_t bound for a whole step (avoids a torch lookup per launch)
+_fns = {}
+
+
+class bound_stream:
+    """`with hip.bound_stream():` pins torch's CURRENT stream for every launch inside the block
+    (one lookup per training step instead of one per kernel)."""
+
+    def __enter__(self):
+        global _bound_stream
+        self.prev = _bound_stream
+        _bound_stream = torch.cuda.current_stream().cuda_stream
+        return self
+
+    def __exit__(self, *exc):
+        global _bound_stream
+        _bound_stream = self.prev
+        return False
+
+
 def call(name, *args):
     """Call a C-ABI entry point; tensors -> device pointers; last arg (stream) added here."""
-    fn = getattr(lib(), name)
-    stream = torch.cuda.current_stream().cuda_stream
-    rc = fn(*[_conv(a) for a in args], stream)
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(lib(), name)
+    stream = _bound_stream if _bound_stream is not None else torch.cuda.current_stream().cuda_stream
+    rc = fn(*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args], stream)
     if rc != 0:
         raise RuntimeError('%s failed (%d): %s' % (name, rc, lib().tell_last_error().decode()))

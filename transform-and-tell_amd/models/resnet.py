@@ -51,6 +51,9 @@ class _Conv(nn.Module):
         return ops._cached(self.weight, ('convw',), make)
 
 
+_BN_WS = {}
+
+
 def conv_bn_act(x, B, H, W, conv, bn, relu, residual, training):
     """x: [B*H*W, Cin] NHWC rows -> ([B*OH*OW, Cout], OH, OW) with BN (+residual) (+ReLU) applied."""
     k, s, p = conv.k, conv.stride, conv.padding
@@ -66,9 +69,13 @@ def conv_bn_act(x, B, H, W, conv, bn, relu, residual, training):
     y = ops.gemm(a, wq)
     M, C = y.shape
     if training:
-        mean = torch.empty(C, dtype=torch.float32, device=x.device)
-        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
-        ws = torch.empty(2 * hip.lib().tell_bn_chunks(M) * C, dtype=torch.float32, device=x.device)
+        need = 2 * hip.lib().tell_bn_chunks(M) * C
+        buf = _BN_WS.get(x.device)
+        if buf is None or buf[0].numel() < need or buf[1].numel() < 2 * C:
+            buf = (torch.empty(max(need, 1 << 20), dtype=torch.float32, device=x.device),
+                   torch.empty(2 * max(C, 4096), dtype=torch.float32, device=x.device))
+            _BN_WS[x.device] = buf
+        ws, mean, invstd = buf[0], buf[1][:C], buf[1][C:2 * C]      # stream-ordered reuse across layers
         call('tell_bn_stats', y, M, C, bn.eps, bn.momentum, mean, invstd, bn.running_mean, bn.running_var, ws,
              hip.dt(dtype))
     else:

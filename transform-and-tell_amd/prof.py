@@ -3,6 +3,7 @@ bench.py for the `roofline` object.  Disabled (zero overhead) unless `enable()` 
 import torch
 
 _enabled = False
+MIN_WORK = 2e9        # only launches with >= 2 GFLOP are timed (keeps the instrumentation out of the small kernels)
 _records = []   # (kernel name, work, start event, end event)
 
 

@@ -12,6 +12,7 @@ backward, then gradients are averaged.  Ranks that see no target of a tail clust
 contribute zeros: the flat buffer is always reduced as a whole."""
 import torch
 
+from .. import hip
 from .. import runtime as rt
 from ..common.registrable import Registrable
 from . import dp
@@ -46,6 +47,10 @@ class Trainer:
 
     def train_one_batch(self, batch):
         """callback_apex_trainer.py:208-247 for one batch; returns the (detached) loss tensor."""
+        with hip.bound_stream():
+            return self._train_one_batch(batch)
+
+    def _train_one_batch(self, batch):
         self.model.train()
         self.flat.zero_grad()                                            # :214
         out = self.model(**batch)                                        # :220 / :194
