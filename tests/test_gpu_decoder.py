@@ -149,13 +149,15 @@ def test_model_loss_and_greedy_generation_golden(golden, dtype, kind):
         out = model(**batch())
     assert int(out['sample_size']) == fx['out']['sample_size']
     close(out['loss'].reshape(1), fx['out']['loss'], dtype, rtol=1e-3 if dtype == torch.float32 else 3e-2)
-    gen = model.generate(**batch())
     ref_ids = fx['out']['gen_ids']
-    got = gen['gen_ids'].cpu()
-    if dtype == torch.float32:
-        assert got.shape == ref_ids.shape and torch.equal(got, ref_ids)        # bit-exact greedy token ids
-        close(gen['log_probs'], fx['out']['gen_log_probs'], dtype, atol=2e-4)
-    else:
-        n = min(got.shape[1], ref_ids.shape[1])
-        agree = (got[:, :n] == ref_ids[:, :n]).float().mean().item()
-        assert agree > 0.5, agree
+    for fast in (True, False):          # K/V-cached static-batch generator and the reference's control flow
+        model.fast_generation = fast
+        gen = model.generate(**batch())
+        got = gen['gen_ids'].cpu()
+        if dtype == torch.float32:
+            assert got.shape == ref_ids.shape and torch.equal(got, ref_ids), fast    # bit-exact greedy token ids
+            close(gen['log_probs'], fx['out']['gen_log_probs'], dtype, atol=2e-4)
+        else:
+            n = min(got.shape[1], ref_ids.shape[1])
+            agree = (got[:, :n] == ref_ids[:, :n]).float().mean().item()
+            assert agree > 0.5, agree

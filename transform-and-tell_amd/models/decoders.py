@@ -69,7 +69,7 @@ class DynamicConvDecoderLayer(DecoderLayer):
     def _ln(ln, x, res, p, training):
         return ops.layer_norm(x, res, ln.weight, ln.bias, ln.eps, p, training)
 
-    def forward(self, X, contexts, incremental_state, contexts_t=None):
+    def forward(self, X, contexts, incremental_state, contexts_t=None, kv=None):
         tr = self.training
         res = X                                                            # :256-266
         h = ops.dropout(X, self.input_dropout, tr)
@@ -83,7 +83,8 @@ class DynamicConvDecoderLayer(DecoderLayer):
             a, w = self.context_attns[name](
                 X, contexts[name], contexts[name], key_padding_mask=contexts[name + '_mask'],
                 need_weights=(not tr and self.need_attn),
-                key_t=None if contexts_t is None else contexts_t.get(name))
+                key_t=None if contexts_t is None else contexts_t.get(name),
+                kv=None if kv is None else kv[name])
             outs.append(self._ln(self.context_attn_lns[name], a, X, self.dropout, tr))
             if w is not None:
                 attns[name] = w.cpu().numpy()
@@ -137,7 +138,7 @@ class _DynamicConvDecoderBase(Decoder):
         self.register_buffer('version', torch.Tensor([2]))
         self.normalize = decoder_normalize_before and final_norm
 
-    def forward(self, prev_target, contexts, incremental_state=None, use_layers=None, **kwargs):
+    def forward(self, prev_target, contexts, incremental_state=None, use_layers=None, kv_cache=None, **kwargs):
         X = self.embedder(prev_target, incremental_state=incremental_state)      # :98  [B,T,E] view
         X = X.transpose(0, 1)                                                      # :109 T x B x C (contiguous)
         X = ops.dropout(X, self.dropout, self.training)                            # :106
@@ -157,11 +158,19 @@ class _DynamicConvDecoderBase(Decoder):
         attns, inner_states = [], [X]
         for i, layer in enumerate(self.layers):
             if not use_layers or i in use_layers:
-                X, attn = layer(X, contexts, incremental_state, contexts_t)
+                X, attn = layer(X, contexts, incremental_state, contexts_t,
+                                None if kv_cache is None else kv_cache[i])
                 inner_states.append(X)
             attns.append(attn)
         X = X.transpose(0, 1)                                                      # :129 B x T x C
         return X, {'attn': attns, 'inner_states': inner_states}
+
+    def project_contexts(self, contexts):
+        """Per layer, per context: the K and V projections (multi_head.py:500-518).  The reference
+        recomputes these 12.4 GFLOP/sample for every generated token (decoder_faces_objects.py:280
+        passes incremental_state=None); they only depend on the static contexts."""
+        return [{name: layer.context_attns[name].project_kv(contexts[name]) for name in layer.context_names}
+                for layer in self.layers]
 
     def max_positions(self):
         return self.max_target_positions

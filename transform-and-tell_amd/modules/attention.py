@@ -68,13 +68,15 @@ class MultiHeadAttention(nn.Module):
         return k, v
 
     def forward(self, query, key, value=None, key_padding_mask=None, incremental_state=None,
-                need_weights=True, static_kv=True, attn_mask=None, key_t=None):
+                need_weights=True, static_kv=True, attn_mask=None, key_t=None, kv=None):
+        """kv: optional (k, v) already projected by `project_kv` - the contexts are static during
+        generation, so they are projected once per caption instead of once per generated token."""
         assert attn_mask is None and incremental_state is None
         T, B, E = query.shape
         assert E == self.embed_dim
         wq, rq = self._wrows(0)
         q = ops.linear(query, wq, self.in_proj_bias, rows=rq, b_rows=(0, E), alpha=self.scaling)  # :348-353
-        k, v = self.project_kv(key, key_t)
+        k, v = kv if kv is not None else self.project_kv(key, key_t)
         mask = None
         if key_padding_mask is not None and k.shape[0] > 0:
             mask = key_padding_mask.to(torch.uint8).contiguous()
