@@ -136,8 +136,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(Ge
     const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
-  const int m0 = (tile_id / tiles_n) * BM, n0 = (tile_id % tiles_n) * BN;
-  if (m0 >= M) return;
+  // grouped traversal inside the XCD's contiguous range: GROUP_M m-tiles share one sweep over n, so the
+  // ~64 workgroups resident on an XCD touch 8 A panels + 8 B panels (<= 4 MiB L2) instead of streaming
+  // the whole B matrix once per pair of m-tiles (PMC: FETCH_SIZE 7.5x the operand bytes before).
+  int tm, tn;
+  {
+    constexpr int GROUP_M = 8;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int per_group = GROUP_M * tiles_n;
+    const int g = tile_id / per_group, first_m = g * GROUP_M;
+    const int gm = tiles_m - first_m < GROUP_M ? tiles_m - first_m : GROUP_M;
+    const int in_g = tile_id - g * per_group;
+    tm = first_m + in_g % gm;
+    tn = in_g / gm;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  if (tile_id >= ((M + BM - 1) / BM) * tiles_n) return;
 
   const uint16_t* A = static_cast<const uint16_t*>(p.A);
   const uint16_t* B = static_cast<const uint16_t*>(p.B);
@@ -290,8 +304,22 @@ void gemm_nt_kernel(GemmArgs p) {
     const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
-  const int m0 = (tile_id / tiles_n) * BM, n0 = (tile_id % tiles_n) * BN;
-  if (m0 >= M) return;                          // uniform per block
+  // grouped traversal inside the XCD's contiguous range: GROUP_M m-tiles share one sweep over n, so the
+  // ~64 workgroups resident on an XCD touch 8 A panels + 8 B panels (<= 4 MiB L2) instead of streaming
+  // the whole B matrix once per pair of m-tiles (PMC: FETCH_SIZE 7.5x the operand bytes before).
+  int tm, tn;
+  {
+    constexpr int GROUP_M = 8;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int per_group = GROUP_M * tiles_n;
+    const int g = tile_id / per_group, first_m = g * GROUP_M;
+    const int gm = tiles_m - first_m < GROUP_M ? tiles_m - first_m : GROUP_M;
+    const int in_g = tile_id - g * per_group;
+    tm = first_m + in_g % gm;
+    tn = in_g / gm;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  if (tile_id >= ((M + BM - 1) / BM) * tiles_n) return;                          // uniform per block
 
   const T* A = static_cast<const T*>(p.A);
   const T* B = static_cast<const T*>(p.B);
