@@ -141,9 +141,18 @@ def main():
             name, d = max(prof_summary.items(), key=lambda kv: kv[1]['total_ms'])
             achieved = d['work'] / (d['total_ms'] * 1e-3) / 1e12
             peak = 2500.0 if 'bf16' in name.split(',')[0] else 157.3
+            traffic = None
+            pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_gemm_traffic.json')
+            if os.path.exists(pmc):      # HBM bytes per launch of this kernel from the committed PMC passes
+                j = json.load(open(pmc))
+                if j.get('kernel') == name:
+                    traffic = j['traffic_bytes_per_launch']
             result['roofline'] = {
                 'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': round(achieved / peak, 4), 'traffic': None, 'launches_per_step': d['launches'] // args.steps,
+                'frac': round(achieved / peak, 4), 'traffic': traffic,
+                'traffic_note': 'bytes/launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE on this '
+                                'command, profiles/r01_pmc_gemm_traffic.json',
+                'launches_per_step': d['launches'] // args.steps,
                 'avg_launch_us': round(d['avg_us'], 2),
                 'step_share': round(d['total_ms'] / (1e3 * elapsed), 4),
                 'all_gemm_kernels': {k: {'avg_us': round(v['avg_us'], 2), 'launches_per_step': v['launches'] // args.steps,

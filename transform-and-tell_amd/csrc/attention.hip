@@ -48,15 +48,19 @@ __device__ __forceinline__ f32x16 mma32(f32x16 acc, const T* a, int as, const T*
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // Stage 32 rows x D of a row-major source into tile[row][D] and/or tileT[d][row].
-// rowptr(row) returns the row's base pointer or nullptr (-> zeros).
+// rowptr(row) returns the row's base pointer or nullptr (-> zeros).  The load itself is unconditional
+// (nullptr rows read `dummy`, any valid 16-byte-aligned address) and the zero is selected afterwards:
+// loads inside divergent branches make hipcc serialise them with s_waitcnt vmcnt(0).
 template <typename T, int D, typename RowPtr>
 __device__ __forceinline__ void stage32(T* tile, int stride, T* tileT, int strideT, int tid, int nthr,
-                                        RowPtr rowptr) {
+                                        RowPtr rowptr, const T* dummy) {
   constexpr int VEC = Elem<T>::VEC, CPR = D / VEC;
   for (int c = tid; c < 32 * CPR; c += nthr) {
     const int row = c / CPR, ch = c % CPR;
     const T* p = rowptr(row);
-    uint4 v = p ? *reinterpret_cast<const uint4*>(p + ch * VEC) : make_uint4(0, 0, 0, 0);
+    const bool ok = p != nullptr;
+    uint4 v = *reinterpret_cast<const uint4*>((ok ? p : dummy) + (ok ? ch * VEC : 0));
+    if (!ok) v = make_uint4(0, 0, 0, 0);
     if (tile) {
       if constexpr (sizeof(T) == 2) {
         *reinterpret_cast<uint4*>(tile + row * stride + ch * VEC) = v;
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
   stage32<T, D>(Qs, DS, (T*)nullptr, 0, lane, 64, [&](int row) -> const T* {
     int t = q0 + row;
     return (active && t < p.Tq) ? qg + t * p.q_st + b * p.q_sb + (long)h * D : nullptr;
-  });
+  }, qg);
   if (DP > D) zero_lds(Vt, DP * SS, lane, 64);   // rows d >= D stay zero
 
   f32x16 o[DF];
@@ -151,13 +155,13 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
         if (s < p.S) return kg + s * p.k_ss + b * p.k_sb + (long)h * D;
         if (s == p.S && p.has_bias) return bk + (long)h * D;
         return nullptr;
-      });
+      }, qg);
       stage32<T, D>((T*)nullptr, 0, Vt, SS, lane, 64, [&](int row) -> const T* {
         int s = s0 + row;
         if (s < p.S) return vg + s * p.v_ss + b * p.v_sb + (long)h * D;
         if (s == p.S && p.has_bias) return bv + (long)h * D;
         return nullptr;
-      });
+      }, qg);
       if (lane < 32) {                              // key-padding mask + range, branch-free in the softmax
         const int s = s0 + lane;
         bool ok = s < S_total;
@@ -270,7 +274,15 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
 // K tile and the transposed V tile are staged ONCE per workgroup (all 256 threads, next tile
 // prefetched into registers under the MFMAs) and shared by the 4 waves; each wave keeps its own
 // Q tile, probability tile and O^T accumulators.  Per 64 keys and wave: 16 MFMA 32x32x16.
-template <typename T>
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {   // -> v_cvt_pk_bf16_f32 (RNE)
+  f32x2_t f = {lo, hi};
+  bf16x2_t h = __builtin_convertvector(f, bf16x2_t);
+  return *reinterpret_cast<unsigned*>(&h);
+}
+
+template <typename T, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_tile64_kernel(AttnArgs p) {
   constexpr int D = 64, KT = 64, NW = 4;
   constexpr int VEC = Elem<T>::VEC;
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(256) void attn_fwd_tile64_kernel(AttnArgs p) {
   stage32<T, D>(Qs[wave], DS, (T*)nullptr, 0, lane, 64, [&](int row) -> const T* {
     int t = q0 + row;
     return (active && t < p.Tq) ? qg + t * p.q_st + b * p.q_sb + (long)h * D : nullptr;
-  });
+  }, qg);
 
   // chunk -> (key row, 16-byte column).  bf16: a thread owns the SAME column of two adjacent keys so
   // the transposed V store packs key pairs into 32-bit words; f32: plain round-robin.
@@ -314,14 +326,15 @@ __global__ __launch_bounds__(256) void attn_fwd_tile64_kernel(AttnArgs p) {
   {                                                                                             \
     _Pragma("unroll") for (int i = 0; i < CPT; ++i) {                                           \
       const int s = (KTI) * KT + chunk_row(i), ch = chunk_col(i);                               \
-      const T* kp = s < p.S ? kg + s * p.k_ss + b * p.k_sb + (long)h * D                        \
-                            : (s == p.S && p.has_bias ? bk + (long)h * D : nullptr);            \
-      const T* vp = s < p.S ? vg + s * p.v_ss + b * p.v_sb + (long)h * D                        \
-                            : (s == p.S && p.has_bias ? bv + (long)h * D : nullptr);            \
-      rk[i] = kp ? *reinterpret_cast<const u32x4*>(kp + ch * VEC) : zero4;                      \
-      rv[i] = vp ? *reinterpret_cast<const u32x4*>(vp + ch * VEC) : zero4;                      \
+      const bool real = s < p.S, isb = (s == p.S) && p.has_bias;                                \
+      const T* kp = real ? kg + s * p.k_ss + b * p.k_sb + (long)h * D : (isb ? bk + (long)h * D : qg); \
+      const T* vp = real ? vg + s * p.v_ss + b * p.v_sb + (long)h * D : (isb ? bv + (long)h * D : qg); \
+      const int off = (real || isb) ? ch * VEC : 0;                                             \
+      rk[i] = *reinterpret_cast<const u32x4*>(kp + off);   /* unconditional; zeroed at the LDS store */ \
+      rv[i] = *reinterpret_cast<const u32x4*>(vp + off);                                        \
     }                                                                                           \
   }
+#define TILE_ROW_OK(KTI, I) ((((KTI) * KT + chunk_row(I)) < p.S) || ((((KTI) * KT + chunk_row(I)) == p.S) && p.has_bias))
   LOAD_TILE(0)
 
   f32x16 o[2];
@@ -337,6 +350,9 @@ __global__ __launch_bounds__(256) void attn_fwd_tile64_kernel(AttnArgs p) {
     const int s0 = kt * KT;
     __syncthreads();                                  // every wave is done with the previous tile
     // ---- registers -> LDS: K rows as they are, V transposed (Vt[d][key])
+#pragma unroll
+    for (int i = 0; i < CPT; ++i)
+      if (!TILE_ROW_OK(kt, i)) { rk[i] = zero4; rv[i] = zero4; }        // virtual zero row / past the end
     if constexpr (sizeof(T) == 2) {
       const int key = chunk_row(0), ch = chunk_col(0);
 #pragma unroll
@@ -386,6 +402,7 @@ __global__ __launch_bounds__(256) void attn_fwd_tile64_kernel(AttnArgs p) {
         }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
+      const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;        // all keys masked so far: exp(-inf - 0) = 0
       const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
       float ls = 0.f;
       const int t = q0 + qi;
@@ -393,9 +410,9 @@ __global__ __launch_bounds__(256) void attn_fwd_tile64_kernel(AttnArgs p) {
       for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float pv = (st[f][r] == -INFINITY) ? 0.f : __expf(st[f][r] - m_new);
+          float pv = __expf(st[f][r] - m_safe);                        // masked keys: exp(-inf) = 0, branch-free
           ls += pv;
-          if (p.thr)
+          if constexpr (DROP)
             pv *= tell_keep(p.seed, p.salt, ((uint64_t)bh * p.Tq + t) * S_total + (s0 + f * 32 + acc_row(r, lane)),
                             p.thr, p.inv_keep);
           st[f][r] = pv;
@@ -403,10 +420,12 @@ __global__ __launch_bounds__(256) void attn_fwd_tile64_kernel(AttnArgs p) {
       ls += __shfl_xor(ls, 32, 64);
       l_run = l_run * alpha + ls;
       m_run = m_new;
+      if (__any(alpha != 1.f)) {                                       // wave-uniform: the running max moved
 #pragma unroll
-      for (int f = 0; f < 2; ++f)
+        for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[f][r] *= alpha;
+          for (int r = 0; r < 16; ++r) o[f][r] *= alpha;
+      }
       // P[q][key]: registers r = 4g..4g+3 are 4 consecutive keys -> one 8-byte (bf16) store
 #pragma unroll
       for (int f = 0; f < 2; ++f)
@@ -415,8 +434,8 @@ __global__ __launch_bounds__(256) void attn_fwd_tile64_kernel(AttnArgs p) {
           const int k0 = f * 32 + 8 * g + 4 * (lane >> 5);
           if constexpr (sizeof(T) == 2) {
             uint2 w;
-            w.x = (unsigned)f2bf(st[f][4 * g]) | ((unsigned)f2bf(st[f][4 * g + 1]) << 16);
-            w.y = (unsigned)f2bf(st[f][4 * g + 2]) | ((unsigned)f2bf(st[f][4 * g + 3]) << 16);
+            w.x = pack_bf16x2(st[f][4 * g], st[f][4 * g + 1]);
+            w.y = pack_bf16x2(st[f][4 * g + 2], st[f][4 * g + 3]);
             *reinterpret_cast<uint2*>(myP + qi * DS + k0) = w;
           } else {
 #pragma unroll
@@ -431,6 +450,7 @@ __global__ __launch_bounds__(256) void attn_fwd_tile64_kernel(AttnArgs p) {
     }
   }
 #undef LOAD_TILE
+#undef TILE_ROW_OK
   if (!active) return;
   const int t = q0 + qi;
   if (t >= p.Tq) return;
@@ -502,8 +522,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(AttnArgs p) {
         return t < p.Tq ? base + t * st + b * sb + (long)h * D : nullptr;
       };
     };
-    stage32<T, D>(Qs, DS, Qt, SS, tid, 64 * NW, qrow(qg, p.q_st, p.q_sb));
-    stage32<T, D>(dOs, DS, dOt, SS, tid, 64 * NW, qrow(dog, p.o_st, p.o_sb));
+    stage32<T, D>(Qs, DS, Qt, SS, tid, 64 * NW, qrow(qg, p.q_st, p.q_sb), qg);
+    stage32<T, D>(dOs, DS, dOt, SS, tid, 64 * NW, qrow(dog, p.o_st, p.o_sb), qg);
     for (int row = wave; row < 32; row += NW) {   // delta[q] = <dO[q], O[q]>
       const int t = q0 + row;
       float s = 0.f;
@@ -534,13 +554,13 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(AttnArgs p) {
           if (s < p.S) return kg + s * p.k_ss + b * p.k_sb + (long)h * D;
           if (s == p.S && p.has_bias) return bk + (long)h * D;
           return nullptr;
-        });
+        }, qg);
         stage32<T, D>(Vs, DS, (T*)nullptr, 0, lane, 64, [&](int row) -> const T* {
           int s = s0 + row;
           if (s < p.S) return vg + s * p.v_ss + b * p.v_sb + (long)h * D;
           if (s == p.S && p.has_bias) return bv + (long)h * D;
           return nullptr;
-        });
+        }, qg);
         if (lane < 32) {
           const int s = s0 + lane;
           bool ok = s < S_total;
@@ -699,8 +719,13 @@ extern "C" int tell_attn_fwd(const void* q, const void* k, const void* v, void* 
   const int QB = (Tq + 31) / 32;
   if (D == 64 && QB >= 4) {            // long sequences: shared 64-key tiles
     dim3 grid((QB + 3) / 4, B * H);
-    if (dtype == TELL_BF16) hipLaunchKernelGGL((attn_fwd_tile64_kernel<uint16_t>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_tile64_kernel<float>), grid, dim3(256), 0, stream, a);
+    if (dtype == TELL_BF16) {
+      if (a.thr) hipLaunchKernelGGL((attn_fwd_tile64_kernel<uint16_t, true>), grid, dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((attn_fwd_tile64_kernel<uint16_t, false>), grid, dim3(256), 0, stream, a);
+    } else {
+      if (a.thr) hipLaunchKernelGGL((attn_fwd_tile64_kernel<float, true>), grid, dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((attn_fwd_tile64_kernel<float, false>), grid, dim3(256), 0, stream, a);
+    }
     return tell_check_launch("attn_fwd_tile64");
   }
   if (dtype == TELL_BF16) {

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(Ge
   // C layout gives each lane ONE column of 16 rows, so direct stores are 2-byte scatters; staged, every
   // lane writes 16 contiguous bytes and a row of the tile leaves as whole 128-byte lines.
   if constexpr (sizeof(OutT) == 2) {
-    constexpr int CS = BN + 8;                           // padded row (elements)
+    constexpr int CS = (BM * (BN + 8) * 2 <= 2 * STAGE) ? BN + 8 : BN;   // padded row (elements) when it fits
     static_assert(BM * CS * 2 <= 2 * STAGE, "output tile must fit the freed tile buffers");
     const bool fast = !p.accumulate && p.act != 3 && m0 + BM <= M && n0 + BN <= N && (p.ldc & 7) == 0 &&
                       (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
@@ -260,6 +260,169 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(Ge
         }
       __syncthreads();
       constexpr int CPRW = BN / 8, NT = 64 * NW;         // 16-byte chunks per tile row
+      uint16_t* C = static_cast<uint16_t*>(p.C);
+#pragma unroll
+      for (int i = 0; i < BM * CPRW / NT; ++i) {
+        const int c = tid + i * NT, row = c / CPRW, ch = c % CPRW;
+        *reinterpret_cast<u32x4*>(C + (long)(m0 + row) * p.ldc + n0 + ch * 8) =
+            *reinterpret_cast<const u32x4*>(Cs + row * CS + ch * 8);
+      }
+      return;
+    }
+  }
+  gemm_epilogue<OutT, MI, NI>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, M, N);
+}
+
+// ------------------------------------------------------------- direct-to-LDS, 3-stage ring, counted vmcnt
+// Same tile image / swizzle as gemm_nt_glds_kernel, but the K loop keeps TWO tiles in flight: tile kt+2 is
+// issued while tile kt is multiplied, and the wave only waits until its pieces of tile kt have landed
+// (s_waitcnt vmcnt(<pieces per tile>), never 0 in steady state).  One raw s_barrier per K step
+// (__syncthreads would emit vmcnt(0) and drain the LDS-DMA queue).
+template <typename OutT, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds3_kernel(GemmArgs p) {
+  constexpr int NW = WAVES_M * WAVES_N, BK = 64, NSTAGE = 3;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int IA = BM / 8 / NW, IB = BN / 8 / NW, PIECES = IA + IB;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 32, NI = WN / 32;
+  static_assert(NSTAGE * STAGE <= 160 * 1024, "LDS ring must fit one CU");
+  static_assert(PIECES == 6 || PIECES == 8 || PIECES == 4, "vmcnt literals below");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  int M = p.M;
+  if (p.m_dev) { int md = *p.m_dev; M = md < M ? md : M; }
+  const int N = p.N, K = p.K;
+  const int tiles_n = (N + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  int tile_id;
+  {
+    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  int tm, tn;
+  {
+    constexpr int GROUP_M = 8;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int per_group = GROUP_M * tiles_n;
+    const int g = tile_id / per_group, first_m = g * GROUP_M;
+    const int gm = tiles_m - first_m < GROUP_M ? tiles_m - first_m : GROUP_M;
+    const int in_g = tile_id - g * per_group;
+    tm = first_m + in_g % gm;
+    tn = in_g / gm;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  if (tile_id >= ((M + BM - 1) / BM) * tiles_n) return;
+
+  const uint16_t* A = static_cast<const uint16_t*>(p.A);
+  const uint16_t* B = static_cast<const uint16_t*>(p.B);
+  const uint16_t* asrc[IA];
+  const uint16_t* bsrc[IB];
+#pragma unroll
+  for (int j = 0; j < IA; ++j) {
+    const int s = (wave * IA + j) * 64 + lane, pr = s >> 4, l16 = (s & 15) ^ (pr & 15);
+    int row = m0 + 2 * pr + (l16 >> 3);
+    row = row < M ? row : M - 1;
+    asrc[j] = A + (long)row * p.lda + (l16 & 7) * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < IB; ++j) {
+    const int s = (wave * IB + j) * 64 + lane, pr = s >> 4, l16 = (s & 15) ^ (pr & 15);
+    int row = n0 + 2 * pr + (l16 >> 3);
+    row = row < N ? row : N - 1;
+    bsrc[j] = B + (long)row * p.ldb + (l16 & 7) * 8;
+  }
+  auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+    unsigned char* sa = smem + stage * STAGE + (wave * IA) * 1024;
+    unsigned char* sb = smem + stage * STAGE + A_BYTES + (wave * IB) * 1024;
+#pragma unroll
+    for (int j = 0; j < IA; ++j)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[j] + kt * BK), (lds_ptr_t)(sa + j * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < IB; ++j)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(bsrc[j] + kt * BK), (lds_ptr_t)(sb + j * 1024), 16, 0, 0);
+  };
+  int a_base[MI], a_x[MI], a_hi[MI], b_base[NI], b_x[NI], b_hi[NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int r = wm * WM + i * 32 + (lane & 31);
+    a_base[i] = (r >> 1) * 256; a_x[i] = (r >> 1) & 15; a_hi[i] = (r & 1) << 3;
+  }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int r = wn * WN + j * 32 + (lane & 31);
+    b_base[j] = (r >> 1) * 256; b_x[j] = (r >> 1) & 15; b_hi[j] = (r & 1) << 3;
+  }
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = K / BK;
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  int st = 0;                                           // stage of tile kt
+  for (int kt = 0; kt < nk; ++kt) {
+    // wait until this wave's pieces of tile kt landed; the (newer) pieces of tile kt+1 stay in flight
+    if (kt + 1 < nk) {
+      if constexpr (PIECES == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if constexpr (PIECES == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                       // all pieces of tile kt landed; stage of tile kt-1 is free
+    asm volatile("" ::: "memory");
+    if (kt + 2 < nk) issue(kt + 2, st == 0 ? 2 : st - 1);   // (kt+2) % 3
+    const unsigned char* ta = smem + st * STAGE;
+    const unsigned char* tb = ta + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = ks * 2 + (lane >> 5);
+      bf16x8 a[MI], b[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        a[i] = *reinterpret_cast<const bf16x8*>(ta + a_base[i] + (((a_hi[i] | c) ^ a_x[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        b[j] = *reinterpret_cast<const bf16x8*>(tb + b_base[j] + (((b_hi[j] | c) ^ b_x[j]) << 4));
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    st = st == 2 ? 0 : st + 1;
+  }
+  __syncthreads();                                      // every wave is done reading before the epilogue reuses LDS
+  if constexpr (sizeof(OutT) == 2) {
+    constexpr int CS = BN + 8;
+    static_assert(BM * CS * 2 <= NSTAGE * STAGE, "output tile must fit the freed tile buffers");
+    const bool fast = !p.accumulate && p.act != 3 && m0 + BM <= M && n0 + BN <= N && (p.ldc & 7) == 0 &&
+                      (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
+    if (fast) {
+      uint16_t* Cs = reinterpret_cast<uint16_t*>(smem);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int col = wn * WN + j * 32 + (lane & 31);
+          const float bn_ = p.bias_mode == 1 ? p.bias[n0 + col] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float v = acc[i][j][r] + bn_;
+            if (p.bias_mode == 2) v += p.bias[m0 + row];
+            v *= p.alpha;
+            if (p.act == 1) v = fmaxf(v, 0.f);
+            else if (p.act == 2) v = gelu_erf(v);
+            Cs[row * CS + col] = f2bf(v);
+          }
+        }
+      __syncthreads();
+      constexpr int CPRW = BN / 8, NT = 64 * NW;
       uint16_t* C = static_cast<uint16_t*>(p.C);
 #pragma unroll
       for (int i = 0; i < BM * CPRW / NT; ++i) {
@@ -419,6 +582,18 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   if constexpr (sizeof(T) == 2) {
     if (a.K % 64 == 0 && tiles(128, 128) >= 256) {       // direct-to-LDS path
       static const int force = getenv("TELL_GEMM_TILE") ? atoi(getenv("TELL_GEMM_TILE")) : 0;   // tuning aid
+      if (force == 5) {   // 256x256, 8 waves (128x64 per wave), 2-stage
+        hipLaunchKernelGGL((gemm_nt_glds_kernel<OutT, 256, 256, 2, 4>), dim3((unsigned)tiles(256, 256)), dim3(512), 0, stream, a);
+        return tell_check_launch("gemm_nt_glds");
+      }
+      if (force == 3) {   // 3-stage ring, counted vmcnt, 256x128, 8 waves
+        hipLaunchKernelGGL((gemm_nt_glds3_kernel<OutT, 256, 128, 4, 2>), dim3((unsigned)tiles(256, 128)), dim3(512), 0, stream, a);
+        return tell_check_launch("gemm_nt_glds3");
+      }
+      if (force == 4) {   // 3-stage ring, 128x128, 4 waves
+        hipLaunchKernelGGL((gemm_nt_glds3_kernel<OutT, 128, 128, 2, 2>), dim3((unsigned)tiles(128, 128)), dim3(256), 0, stream, a);
+        return tell_check_launch("gemm_nt_glds3");
+      }
       if (force == 2)     // 256x128 (8 waves, 1 workgroup/CU) ties 128x128 (2 workgroups/CU) on MI355X: opt-in only
         hipLaunchKernelGGL((gemm_nt_glds_kernel<OutT, 256, 128, 4, 2>), dim3((unsigned)tiles(256, 128)), dim3(512), 0, stream, a);
       else
