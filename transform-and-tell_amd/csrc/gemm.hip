@@ -30,6 +30,7 @@ struct GemmArgs {
   int act;                // 0 none, 1 relu, 2 gelu(erf), 3 multiply by (aux > 0)
   int accumulate;         // C = C + result  (beta = 1)
   float alpha;            // result = act((acc + bias) * alpha)
+  int dbg;                // tuning aid (TELL_GEMM_DEBUG): 1 = skip the epilogue, 2 = one K step only
 };
 
 template <typename T> struct Mma;
@@ -71,38 +72,174 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
-// ------------------------------------------------------------- epilogue (shared by both GEMM kernels)
-// acc[i][j][r] holds C[mw + i*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)][nw + j*32 + (lane&31)]
+// ------------------------------------------------------------- epilogue (shared by all GEMM kernels)
+// Every kernel issues its MFMAs with the operands swapped (B fragment first), so the accumulator tile is
+// C^T: lane l owns ONE output row and 4 consecutive output columns per register quad,
+//   acc[i][j][4g+e] = C[mw + i*32 + (l&31)][nw + j*32 + 8g + 4*(l>>5) + e].
+// That makes the stores 8-byte (bf16) / 16-byte (fp32) vectors instead of 2-byte column scatters, and the
+// bf16 conversion a packed v_cvt_pk_bf16_f32.  The activation is a template parameter (one block-uniform
+// switch per tile instead of branches per element).
+
+// erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, branch-free: one rcp + one exp + 6 fma)
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+  float y = fmaf(1.061405429f, t, -1.453152027f);
+  y = fmaf(y, t, 1.421413741f);
+  y = fmaf(y, t, -0.284496736f);
+  y = fmaf(y, t, 0.254829592f);
+  y = 1.f - y * t * __expf(-ax * ax);
+  return copysignf(y, x);
+}
+template <int ACT> __device__ __forceinline__ float epi_act(float v) {
+  if constexpr (ACT == 1) return fmaxf(v, 0.f);
+  else if constexpr (ACT == 2) return 0.5f * v * (1.f + erf_as(v * 0.70710678118654752f));
+  else return v;
+}
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2e_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2e_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {      // v_cvt_pk_bf16_f32 (RNE)
+  f32x2e_t f = {lo, hi};
+  bf16x2e_t h = __builtin_convertvector(f, bf16x2e_t);
+  return *reinterpret_cast<unsigned*>(&h);
+}
+template <typename OutT> struct Vec4;
+template <> struct Vec4<float> {
+  __device__ static __forceinline__ f32x4_t ld(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
+  __device__ static __forceinline__ void st(float* p, f32x4_t v) { *reinterpret_cast<f32x4_t*>(p) = v; }
+};
+template <> struct Vec4<uint16_t> {
+  __device__ static __forceinline__ f32x4_t ld(const uint16_t* p) {
+    const u32x2 w = *reinterpret_cast<const u32x2*>(p);
+    f32x4_t v = {__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u),
+                 __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)};
+    return v;
+  }
+  __device__ static __forceinline__ void st(uint16_t* p, f32x4_t v) {
+    u32x2 w = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
+    *reinterpret_cast<u32x2*>(p) = w;
+  }
+};
+
+template <typename OutT, int MI, int NI, int ACT>
+__device__ __forceinline__ void gemm_epilogue_act(f32x16 (&acc)[MI][NI], const GemmArgs& p, int mw, int nw, int lane,
+                                                  int M, int N) {
+  OutT* C = static_cast<OutT*>(p.C);
+  const OutT* aux = static_cast<const OutT*>(p.aux);
+  constexpr uintptr_t AL = 4 * sizeof(OutT) - 1;
+  const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & AL) == 0 &&
+                      (ACT != 3 || (reinterpret_cast<uintptr_t>(aux) & AL) == 0);
+  f32x4_t bn[NI][4];                                               // per-column bias of this lane's 4-column groups
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = nw + j * 32 + 8 * g + 4 * (lane >> 5);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bn[j][g][e] = (p.bias_mode == 1 && n + e < N) ? p.bias[n + e] : 0.f;
+    }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = mw + i * 32 + (lane & 31);
+    if (m >= M) continue;
+    const float bm = p.bias_mode == 2 ? p.bias[m] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = nw + j * 32 + 8 * g + 4 * (lane >> 5);
+        if (n >= N) continue;
+        f32x4_t v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = epi_act<ACT>((acc[i][j][4 * g + e] + bn[j][g][e] + bm) * p.alpha);
+        OutT* dst = C + (long)m * p.ldc + n;
+        if (vec_ok && n + 3 < N) {
+          if constexpr (ACT == 3) {
+            const f32x4_t mk = Vec4<OutT>::ld(aux + (long)m * p.ldc + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+          }
+          if (p.accumulate) v += Vec4<OutT>::ld(dst);
+          Vec4<OutT>::st(dst, v);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < N) {
+              float x = v[e];
+              if constexpr (ACT == 3) x = Elem<OutT>::ld(aux + (long)m * p.ldc + n + e) > 0.f ? x : 0.f;
+              if (p.accumulate) x += Elem<OutT>::ld(dst + e);
+              Elem<OutT>::st(dst + e, x);
+            }
+        }
+      }
+  }
+}
 template <typename OutT, int MI, int NI>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& p, int mw, int nw, int lane,
                                               int M, int N) {
-  OutT* C = static_cast<OutT*>(p.C);
-  const OutT* aux = static_cast<const OutT*>(p.aux);
+  switch (p.act) {                                                 // block-uniform
+    case 1: gemm_epilogue_act<OutT, MI, NI, 1>(acc, p, mw, nw, lane, M, N); break;
+    case 2: gemm_epilogue_act<OutT, MI, NI, 2>(acc, p, mw, nw, lane, M, N); break;
+    case 3: gemm_epilogue_act<OutT, MI, NI, 3>(acc, p, mw, nw, lane, M, N); break;
+    default: gemm_epilogue_act<OutT, MI, NI, 0>(acc, p, mw, nw, lane, M, N); break;
+  }
+}
+
+// Full interior bf16 tile of a direct-to-LDS kernel: staged through free LDS (`cs`, BM rows of CS elements;
+// CS == BN means unpadded with the 16-byte chunk index XOR-swizzled by the row), so every output row
+// leaves as whole 128-byte lines.  Needs a block barrier BEFORE (cs no longer read as a tile) by the caller.
+template <int BM, int BN, int WM, int WN, int MI, int NI, int CS, int NT, int ACT>
+__device__ __forceinline__ void glds_store_tile_act(f32x16 (&acc)[MI][NI], const GemmArgs& p, int m0, int n0, int wm,
+                                                    int wn, int lane, int tid, uint16_t* cs) {
+  constexpr bool SWZ = CS == BN;
+  constexpr int CPRW = BN / 8;                                     // 16-byte chunks per tile row
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
+    const int row = wm * WM + i * 32 + (lane & 31);
+    const float bm = p.bias_mode == 2 ? p.bias[m0 + row] : 0.f;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int n = nw + j * 32 + (lane & 31);
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < M && n < N) {
-          float v = acc[i][j][r];
-          if (p.bias_mode == 1) v += p.bias[n];
-          else if (p.bias_mode == 2) v += p.bias[m];
-          v *= p.alpha;
-          if (p.act == 1) v = fmaxf(v, 0.f);
-          else if (p.act == 2) v = gelu_erf(v);
-          else if (p.act == 3) v = Elem<OutT>::ld(aux + (long)m * p.ldc + n) > 0.f ? v : 0.f;
-          OutT* dst = C + (long)m * p.ldc + n;
-          if (p.accumulate) v += Elem<OutT>::ld(dst);
-          Elem<OutT>::st(dst, v);
-        }
+      for (int g = 0; g < 4; ++g) {
+        const int col = wn * WN + j * 32 + 8 * g + 4 * (lane >> 5);
+        f32x4_t b4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias_mode == 1) b4 = *reinterpret_cast<const f32x4_t*>(p.bias + n0 + col);
+        f32x4_t v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = epi_act<ACT>((acc[i][j][4 * g + e] + b4[e] + bm) * p.alpha);
+        int ch = col >> 3;
+        if constexpr (SWZ) ch ^= row & (CPRW - 1) & 15;
+        u32x2 w = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(cs + row * CS + ch * 8 + (col & 7)) = w;
       }
-    }
   }
+  __syncthreads();
+  uint16_t* C = static_cast<uint16_t*>(p.C);
+#pragma unroll
+  for (int i = 0; i < BM * CPRW / NT; ++i) {
+    const int c = tid + i * NT, row = c / CPRW;
+    int ch = c % CPRW;
+    const int sch = SWZ ? ch ^ (row & (CPRW - 1) & 15) : ch;
+    *reinterpret_cast<u32x4*>(C + (long)(m0 + row) * p.ldc + n0 + ch * 8) =
+        *reinterpret_cast<const u32x4*>(cs + row * CS + sch * 8);
+  }
+}
+template <int BM, int BN, int WM, int WN, int MI, int NI, int CS, int NT>
+__device__ __forceinline__ void glds_store_tile(f32x16 (&acc)[MI][NI], const GemmArgs& p, int m0, int n0, int wm,
+                                                int wn, int lane, int tid, uint16_t* cs) {
+  switch (p.act) {
+    case 1: glds_store_tile_act<BM, BN, WM, WN, MI, NI, CS, NT, 1>(acc, p, m0, n0, wm, wn, lane, tid, cs); break;
+    case 2: glds_store_tile_act<BM, BN, WM, WN, MI, NI, CS, NT, 2>(acc, p, m0, n0, wm, wn, lane, tid, cs); break;
+    default: glds_store_tile_act<BM, BN, WM, WN, MI, NI, CS, NT, 0>(acc, p, m0, n0, wm, wn, lane, tid, cs); break;
+  }
+}
+__device__ __forceinline__ bool glds_fast_tile(const GemmArgs& p, int m0, int n0, int BM, int BN, int M, int N) {
+  return !p.accumulate && p.act != 3 && m0 + BM <= M && n0 + BN <= N && (p.ldc & 7) == 0 &&
+         (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 &&
+         (p.bias_mode != 1 || ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0 && (n0 & 3) == 0));
 }
 
 // ------------------------------------------------------------- direct-to-LDS kernel (bf16, K % 64 == 0)
@@ -226,112 +363,94 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(Ge
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMA pieces of tile kt+1 have landed
     __syncthreads();                                     // everyone's have, and buffer `st` is free again
   }
-  // ---- epilogue.  Full interior bf16 tiles go through LDS (the tile buffers are free now): the MFMA
-  // C layout gives each lane ONE column of 16 rows, so direct stores are 2-byte scatters; staged, every
-  // lane writes 16 contiguous bytes and a row of the tile leaves as whole 128-byte lines.
+  // ---- epilogue.  Full interior bf16 tiles go through LDS (the tile buffers are free now).
   if constexpr (sizeof(OutT) == 2) {
     constexpr int CS = (BM * (BN + 8) * 2 <= 2 * STAGE) ? BN + 8 : BN;   // padded row (elements) when it fits
     static_assert(BM * CS * 2 <= 2 * STAGE, "output tile must fit the freed tile buffers");
-    const bool fast = !p.accumulate && p.act != 3 && m0 + BM <= M && n0 + BN <= N && (p.ldc & 7) == 0 &&
-                      (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
-    if (fast) {                                          // block-uniform
-      uint16_t* Cs = reinterpret_cast<uint16_t*>(smem);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          const int col = wn * WN + j * 32 + (lane & 31);
-          const float bn_ = p.bias_mode == 1 ? p.bias[n0 + col] : 0.f;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            float v = acc[i][j][r] + bn_;
-            if (p.bias_mode == 2) v += p.bias[m0 + row];
-            v *= p.alpha;
-            if (p.act == 1) v = fmaxf(v, 0.f);
-            else if (p.act == 2) v = gelu_erf(v);
-            Cs[row * CS + col] = f2bf(v);
-          }
-        }
-      __syncthreads();
-      constexpr int CPRW = BN / 8, NT = 64 * NW;         // 16-byte chunks per tile row
-      uint16_t* C = static_cast<uint16_t*>(p.C);
-#pragma unroll
-      for (int i = 0; i < BM * CPRW / NT; ++i) {
-        const int c = tid + i * NT, row = c / CPRW, ch = c % CPRW;
-        *reinterpret_cast<u32x4*>(C + (long)(m0 + row) * p.ldc + n0 + ch * 8) =
-            *reinterpret_cast<const u32x4*>(Cs + row * CS + ch * 8);
-      }
+    if (glds_fast_tile(p, m0, n0, BM, BN, M, N)) {       // block-uniform
+      glds_store_tile<BM, BN, WM, WN, MI, NI, CS, 64 * NW>(acc, p, m0, n0, wm, wn, lane, tid,
+                                                           reinterpret_cast<uint16_t*>(smem));
       return;
     }
   }
   gemm_epilogue<OutT, MI, NI>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, M, N);
 }
 
-// ------------------------------------------------------------- direct-to-LDS, 3-stage ring, counted vmcnt
-// Same tile image / swizzle as gemm_nt_glds_kernel, but the K loop keeps TWO tiles in flight: tile kt+2 is
-// issued while tile kt is multiplied, and the wave only waits until its pieces of tile kt have landed
-// (s_waitcnt vmcnt(<pieces per tile>), never 0 in steady state).  One raw s_barrier per K step
-// (__syncthreads would emit vmcnt(0) and drain the LDS-DMA queue).
+// ------------------------------------------------------------- direct-to-LDS, persistent workgroups
+// Short-K GEMMs (K = 1024: 16 K steps per 128x128 tile) spend a quarter of a one-tile workgroup's life
+// in launch, the exposed first-tile load and the epilogue.  Here 2 workgroups per CU stay resident and
+// walk their XCD's tile range with a stride; the first K step of the NEXT tile is issued into the free
+// LDS stage during the last K step of the current one, so it lands under that step's MFMAs and the
+// epilogue (which stages C through the stage just consumed).
 template <typename OutT, int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds3_kernel(GemmArgs p) {
-  constexpr int NW = WAVES_M * WAVES_N, BK = 64, NSTAGE = 3;
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_nt_glds_persist_kernel(GemmArgs p) {
+  constexpr int NW = WAVES_M * WAVES_N, BK = 64;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int IA = BM / 8 / NW, IB = BN / 8 / NW, PIECES = IA + IB;
+  constexpr int IA = BM / 8 / NW, IB = BN / 8 / NW;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 32, NI = WN / 32;
-  static_assert(NSTAGE * STAGE <= 160 * 1024, "LDS ring must fit one CU");
-  static_assert(PIECES == 6 || PIECES == 8 || PIECES == 4, "vmcnt literals below");
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
+  static_assert(BM * BN * 2 <= STAGE, "C tile is staged through ONE consumed stage");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   int M = p.M;
   if (p.m_dev) { int md = *p.m_dev; M = md < M ? md : M; }
   const int N = p.N, K = p.K;
-  const int tiles_n = (N + BN - 1) / BN;
-  const int nwg = gridDim.x;
-  int tile_id;
-  {
-    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  }
-  int tm, tn;
-  {
-    constexpr int GROUP_M = 8;
-    const int tiles_m = (M + BM - 1) / BM;
-    const int per_group = GROUP_M * tiles_n;
-    const int g = tile_id / per_group, first_m = g * GROUP_M;
-    const int gm = tiles_m - first_m < GROUP_M ? tiles_m - first_m : GROUP_M;
-    const int in_g = tile_id - g * per_group;
-    tm = first_m + in_g % gm;
-    tn = in_g / gm;
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
-  if (tile_id >= ((M + BM - 1) / BM) * tiles_n) return;
+  const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  const int ntiles = tiles_m * tiles_n;
+  // XCD x (= blockIdx & 7) owns a contiguous range of the grouped tile order; its gridDim/8 resident
+  // workgroups sweep that range together, so they share A/B panels in the XCD's L2.
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, stride = gridDim.x >> 3;
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int count = xcd < r ? q + 1 : q;
+  if (local >= count) return;
 
   const uint16_t* A = static_cast<const uint16_t*>(p.A);
   const uint16_t* B = static_cast<const uint16_t*>(p.B);
+  int a_row[IA], b_row[IB];                            // tile-relative source row of each of this lane's pieces
+  int a_col, b_col;                                    // k offset (elements) - identical for all pieces of a lane?
   const uint16_t* asrc[IA];
   const uint16_t* bsrc[IB];
+  int a_k[IA], b_k[IB];
 #pragma unroll
   for (int j = 0; j < IA; ++j) {
     const int s = (wave * IA + j) * 64 + lane, pr = s >> 4, l16 = (s & 15) ^ (pr & 15);
-    int row = m0 + 2 * pr + (l16 >> 3);
-    row = row < M ? row : M - 1;
-    asrc[j] = A + (long)row * p.lda + (l16 & 7) * 8;
+    a_row[j] = 2 * pr + (l16 >> 3); a_k[j] = (l16 & 7) * 8;
   }
 #pragma unroll
   for (int j = 0; j < IB; ++j) {
     const int s = (wave * IB + j) * 64 + lane, pr = s >> 4, l16 = (s & 15) ^ (pr & 15);
-    int row = n0 + 2 * pr + (l16 >> 3);
-    row = row < N ? row : N - 1;
-    bsrc[j] = B + (long)row * p.ldb + (l16 & 7) * 8;
+    b_row[j] = 2 * pr + (l16 >> 3); b_k[j] = (l16 & 7) * 8;
   }
+  (void)a_col; (void)b_col;
+  int m0, n0;
+  auto locate = [&](int t) __attribute__((always_inline)) {      // grouped (GROUP_M m-tiles per n sweep) order
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * tiles_n;
+    const int g = t / per_group, first_m = g * GROUP_M;
+    const int gm = tiles_m - first_m < GROUP_M ? tiles_m - first_m : GROUP_M;
+    const int in_g = t - g * per_group;
+    m0 = (first_m + in_g % gm) * BM;
+    n0 = (in_g / gm) * BN;
+#pragma unroll
+    for (int j = 0; j < IA; ++j) {
+      int row = m0 + a_row[j];
+      row = row < M ? row : M - 1;
+      asrc[j] = A + (long)row * p.lda + a_k[j];
+    }
+#pragma unroll
+    for (int j = 0; j < IB; ++j) {
+      int row = n0 + b_row[j];
+      row = row < N ? row : N - 1;
+      bsrc[j] = B + (long)row * p.ldb + b_k[j];
+    }
+  };
   auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
     unsigned char* sa = smem + stage * STAGE + (wave * IA) * 1024;
     unsigned char* sb = smem + stage * STAGE + A_BYTES + (wave * IB) * 1024;
@@ -342,98 +461,80 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds3_kernel(G
     for (int j = 0; j < IB; ++j)
       __builtin_amdgcn_global_load_lds((glb_ptr_t)(bsrc[j] + kt * BK), (lds_ptr_t)(sb + j * 1024), 16, 0, 0);
   };
+
   int a_base[MI], a_x[MI], a_hi[MI], b_base[NI], b_x[NI], b_hi[NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const int r = wm * WM + i * 32 + (lane & 31);
-    a_base[i] = (r >> 1) * 256; a_x[i] = (r >> 1) & 15; a_hi[i] = (r & 1) << 3;
+    const int rr = wm * WM + i * 32 + (lane & 31);
+    a_base[i] = (rr >> 1) * 256; a_x[i] = (rr >> 1) & 15; a_hi[i] = (rr & 1) << 3;
   }
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
-    const int r = wn * WN + j * 32 + (lane & 31);
-    b_base[j] = (r >> 1) * 256; b_x[j] = (r >> 1) & 15; b_hi[j] = (r & 1) << 3;
+    const int rr = wn * WN + j * 32 + (lane & 31);
+    b_base[j] = (rr >> 1) * 256; b_x[j] = (rr >> 1) & 15; b_hi[j] = (rr & 1) << 3;
   }
-  f32x16 acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = K / BK;
+  const int nk = (p.dbg & 2) ? 1 : K / BK;
+  int st = 0;                                          // stage holding the K step about to be used
+  locate(first + local);
   issue(0, 0);
-  if (nk > 1) issue(1, 1);
-  int st = 0;                                           // stage of tile kt
-  for (int kt = 0; kt < nk; ++kt) {
-    // wait until this wave's pieces of tile kt landed; the (newer) pieces of tile kt+1 stay in flight
-    if (kt + 1 < nk) {
-      if constexpr (PIECES == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if constexpr (PIECES == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();                       // all pieces of tile kt landed; stage of tile kt-1 is free
-    asm volatile("" ::: "memory");
-    if (kt + 2 < nk) issue(kt + 2, st == 0 ? 2 : st - 1);   // (kt+2) % 3
-    const unsigned char* ta = smem + st * STAGE;
-    const unsigned char* tb = ta + A_BYTES;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = local; t < count; t += stride) {
+    const int cm0 = m0, cn0 = n0;                      // this tile's origin (m0/n0 move on at the prefetch)
+    const bool has_next = t + stride < count;
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int c = ks * 2 + (lane >> 5);
-      bf16x8 a[MI], b[NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-        a[i] = *reinterpret_cast<const bf16x8*>(ta + a_base[i] + (((a_hi[i] | c) ^ a_x[i]) << 4));
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NI; ++j)
-        b[j] = *reinterpret_cast<const bf16x8*>(tb + b_base[j] + (((b_hi[j] | c) ^ b_x[j]) << 4));
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    st = st == 2 ? 0 : st + 1;
-  }
-  __syncthreads();                                      // every wave is done reading before the epilogue reuses LDS
-  if constexpr (sizeof(OutT) == 2) {
-    constexpr int CS = BN + 8;
-    static_assert(BM * CS * 2 <= NSTAGE * STAGE, "output tile must fit the freed tile buffers");
-    const bool fast = !p.accumulate && p.act != 3 && m0 + BM <= M && n0 + BN <= N && (p.ldc & 7) == 0 &&
-                      (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
-    if (fast) {
-      uint16_t* Cs = reinterpret_cast<uint16_t*>(smem);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          const int col = wn * WN + j * 32 + (lane & 31);
-          const float bn_ = p.bias_mode == 1 ? p.bias[n0 + col] : 0.f;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            float v = acc[i][j][r] + bn_;
-            if (p.bias_mode == 2) v += p.bias[m0 + row];
-            v *= p.alpha;
-            if (p.act == 1) v = fmaxf(v, 0.f);
-            else if (p.act == 2) v = gelu_erf(v);
-            Cs[row * CS + col] = f2bf(v);
-          }
-        }
-      __syncthreads();
-      constexpr int CPRW = BN / 8, NT = 64 * NW;
-      uint16_t* C = static_cast<uint16_t*>(p.C);
-#pragma unroll
-      for (int i = 0; i < BM * CPRW / NT; ++i) {
-        const int c = tid + i * NT, row = c / CPRW, ch = c % CPRW;
-        *reinterpret_cast<u32x4*>(C + (long)(m0 + row) * p.ldc + n0 + ch * 8) =
-            *reinterpret_cast<const u32x4*>(Cs + row * CS + ch * 8);
+        for (int rr = 0; rr < 16; ++rr) acc[i][j][rr] = 0.f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) {
+        issue(kt + 1, st ^ 1);                             // streams in under the MFMAs below
+      } else if (has_next) {
+        locate(first + t + stride);
+        issue(0, st ^ 1);                                  // next tile's first K step, under this step's MFMAs
       }
-      return;
+      const unsigned char* ta = smem + st * STAGE;
+      const unsigned char* tb = ta + A_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int c = ks * 2 + (lane >> 5);
+        bf16x8 av[MI], bv[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          av[i] = *reinterpret_cast<const bf16x8*>(ta + a_base[i] + (((a_hi[i] | c) ^ a_x[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          bv[j] = *reinterpret_cast<const bf16x8*>(tb + b_base[j] + (((b_hi[j] | c) ^ b_x[j]) << 4));
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j], av[i], acc[i][j], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMA pieces of the next K step have landed
+      __syncthreads();                                     // everyone's have, and stage `st` is free again
+      st ^= 1;
     }
+    // stage st^1 was consumed last (all waves are past its reads); stage st holds the next tile's first K step.
+    bool fast = false;
+    if (p.dbg & 1) {
+      if (acc[0][0][0] == 12345.678f) static_cast<float*>(p.C)[0] = 1.f;
+      continue;
+    }
+    if constexpr (sizeof(OutT) == 2) {
+      fast = glds_fast_tile(p, cm0, cn0, BM, BN, M, N);
+      if (fast) {                                          // block-uniform
+        glds_store_tile<BM, BN, WM, WN, MI, NI, BN, 64 * NW>(acc, p, cm0, cn0, wm, wn, lane, tid,
+                                                             reinterpret_cast<uint16_t*>(smem + (st ^ 1) * STAGE));
+        if (has_next) __syncthreads();                     // copy-out reads done before the next DMA into this stage
+      }
+    }
+    if (!fast) gemm_epilogue<OutT, MI, NI>(acc, p, cm0 + wm * WM, cn0 + wn * WN, lane, M, N);
   }
-  gemm_epilogue<OutT, MI, NI>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, M, N);
 }
 
 template <typename T, typename OutT, int BM, int BN, int WAVES_M, int WAVES_N, int PF>
@@ -546,7 +647,7 @@ void gemm_nt_kernel(GemmArgs p) {
       _Pragma("unroll") for (int i = 0; i < MI; ++i) a[i] = M_::load(at, i * 32 + (lane & 31), ks, lane); \
       _Pragma("unroll") for (int j = 0; j < NI; ++j) b[j] = M_::load(bt, j * 32 + (lane & 31), ks, lane); \
       _Pragma("unroll") for (int i = 0; i < MI; ++i)                                              \
-        _Pragma("unroll") for (int j = 0; j < NI; ++j) acc[i][j] = M_::mma(a[i], b[j], acc[i][j]); \
+        _Pragma("unroll") for (int j = 0; j < NI; ++j) acc[i][j] = M_::mma(b[j], a[i], acc[i][j]); \
     }                                                                                             \
     SSTORE(((S) + 1) % PF, ((S) + 1) & 1, kt + 1)                                                 \
     __syncthreads();                                                                              \
@@ -582,17 +683,16 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   if constexpr (sizeof(T) == 2) {
     if (a.K % 64 == 0 && tiles(128, 128) >= 256) {       // direct-to-LDS path
       static const int force = getenv("TELL_GEMM_TILE") ? atoi(getenv("TELL_GEMM_TILE")) : 0;   // tuning aid
+      static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); (void)hipGetDeviceProperties(&pr, d); return pr.multiProcessorCount; }();
+      if (force == 6) {   // persistent 128x128, 2 workgroups/CU, cross-tile prefetch
+        long g = tiles(128, 128) < 2L * n_cu ? tiles(128, 128) : 2L * n_cu;
+        g = (g + 7) / 8 * 8;
+        hipLaunchKernelGGL((gemm_nt_glds_persist_kernel<OutT, 128, 128, 2, 2>), dim3((unsigned)g), dim3(256), 0, stream, a);
+        return tell_check_launch("gemm_nt_glds_persist");
+      }
       if (force == 5) {   // 256x256, 8 waves (128x64 per wave), 2-stage
         hipLaunchKernelGGL((gemm_nt_glds_kernel<OutT, 256, 256, 2, 4>), dim3((unsigned)tiles(256, 256)), dim3(512), 0, stream, a);
         return tell_check_launch("gemm_nt_glds");
-      }
-      if (force == 3) {   // 3-stage ring, counted vmcnt, 256x128, 8 waves
-        hipLaunchKernelGGL((gemm_nt_glds3_kernel<OutT, 256, 128, 4, 2>), dim3((unsigned)tiles(256, 128)), dim3(512), 0, stream, a);
-        return tell_check_launch("gemm_nt_glds3");
-      }
-      if (force == 4) {   // 3-stage ring, 128x128, 4 waves
-        hipLaunchKernelGGL((gemm_nt_glds3_kernel<OutT, 128, 128, 2, 2>), dim3((unsigned)tiles(128, 128)), dim3(256), 0, stream, a);
-        return tell_check_launch("gemm_nt_glds3");
       }
       if (force == 2)     // 256x128 (8 waves, 1 workgroup/CU) ties 128x128 (2 workgroups/CU) on MI355X: opt-in only
         hipLaunchKernelGGL((gemm_nt_glds_kernel<OutT, 256, 128, 4, 2>), dim3((unsigned)tiles(256, 128)), dim3(512), 0, stream, a);
@@ -634,6 +734,8 @@ extern "C" int tell_gemm_nt(const void* A, long lda, const void* B, long ldb, vo
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux; a.m_dev = m_dev;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
   a.bias_mode = bias_mode; a.act = act; a.accumulate = accumulate; a.alpha = alpha;
+  static const int dbg = getenv("TELL_GEMM_DEBUG") ? atoi(getenv("TELL_GEMM_DEBUG")) : 0;
+  a.dbg = dbg;
   if (in_dtype == TELL_BF16)
     return out_dtype == TELL_BF16 ? launch_gemm<uint16_t, uint16_t>(a, stream)
                                   : launch_gemm<uint16_t, float>(a, stream);

@@ -1,6 +1,7 @@
 """tell/models/transformer_faces_objects.py:23-517 and tell/models/transformer_flattened.py:24-443
 on the MI355X path (training forward + loss, greedy generation)."""
 import math
+import os
 from collections import defaultdict
 
 import torch
@@ -8,6 +9,17 @@ import torch.nn as nn
 
 from .. import ops
 from ..common.registrable import Registrable
+
+
+_OVERLAP = os.environ.get('TELL_ENCODER_OVERLAP', '1') != '0'
+_side_streams = {}
+
+
+def _side_stream(device):
+    s = _side_streams.get(device)
+    if s is None:
+        s = _side_streams[device] = torch.cuda.Stream(device=device)
+    return s
 
 
 class Model(nn.Module, Registrable):
@@ -63,11 +75,23 @@ class CaptionModel(Model):
         caption[self.index] = caption_ids                                  # :329
 
         with torch.no_grad():                                              # frozen encoders (config :150-152)
-            x_image = self.resnet(image)                                   # [B,49,2048] (NHWC == :335-341)
+            # The two encoders are independent: ResNet's many small launches run on a side stream
+            # underneath RoBERTa's chip-filling GEMMs (TELL_ENCODER_OVERLAP=0 serialises them).
+            main = torch.cuda.current_stream()
+            side = _side_stream(image.device) if _OVERLAP else None
+            if side is not None:
+                side.wait_stream(main)
+                with torch.cuda.stream(side), ops.hip.bound_stream():
+                    x_image = self.resnet(image)                           # [B,49,2048] (NHWC == :335-341)
+            else:
+                x_image = self.resnet(image)
             B, P, _ = x_image.shape
             article_ids = context[self.index]
             article_mask = article_ids == self.padding_idx                 # :347
             stack = self.roberta.extract_features(article_ids, return_all_hiddens=True)   # [L,B,S,E]
+            if side is not None:
+                main.wait_stream(side)
+                x_image.record_stream(main)
         if self.weigh_bert:
             x_article = ops.mix_layers(stack, self.bert_weight)            # :355-364
         else:
