@@ -410,13 +410,32 @@ __global__ __launch_bounds__(256) void attn_fwd_tile64_kernel(AttnArgs p) {
       for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float pv = __expf(st[f][r] - m_safe);                        // masked keys: exp(-inf) = 0, branch-free
+          const float pv = __expf(st[f][r] - m_safe);                  // masked keys: exp(-inf) = 0, branch-free
           ls += pv;
-          if constexpr (DROP)
-            pv *= tell_keep(p.seed, p.salt, ((uint64_t)bh * p.Tq + t) * S_total + (s0 + f * 32 + acc_row(r, lane)),
-                            p.thr, p.inv_keep);
           st[f][r] = pv;
         }
+      if constexpr (DROP) {
+        // element index of P[bh][t][key]; this lane's keys come in aligned pairs (r, r+1), so with an even
+        // row length one hash decides two probabilities (common.h tell_keep2)
+        const uint64_t base = ((uint64_t)bh * p.Tq + t) * S_total + s0 + 4 * (lane >> 5);
+        if ((S_total & 1) == 0) {
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              float k0, k1;
+              tell_keep2(p.seed, p.salt, base + (f * 32 + (r & 3) + 8 * (r >> 2)), p.thr, p.inv_keep, k0, k1);
+              st[f][r] *= k0;
+              st[f][r + 1] *= k1;
+            }
+        } else {
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              st[f][r] *= tell_keep(p.seed, p.salt, base + (f * 32 + (r & 3) + 8 * (r >> 2)), p.thr, p.inv_keep);
+        }
+      }
       ls += __shfl_xor(ls, 32, 64);
       l_run = l_run * alpha + ls;
       m_run = m_new;

@@ -93,23 +93,33 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---------------------------------------------------------------- counter-based RNG for dropout
-// Stateless: keep = hash(seed, salt, element index) >= p * 2^32.  The same
-// function is restated in numpy (tell_amd/rng.py) so tests can rebuild masks.
+// Stateless.  One 32-bit hash serves an aligned PAIR of element indices (2i, 2i+1): element idx keeps iff
+// the 16-bit half (idx & 1) of hash(seed, salt, idx >> 1) is >= floor(p * 2^16).  Kernels whose lanes own
+// consecutive elements (attention probabilities, vectorised rows) so pay one hash per two decisions.  The
+// same functions are restated in numpy (tell_amd/rng.py) so tests can rebuild masks.
 __device__ __host__ __forceinline__ uint32_t tell_hash32(uint32_t seed, uint32_t salt, uint64_t idx) {
   uint32_t x = (uint32_t)idx * 0x9E3779B1u + seed;
-  uint32_t y = (uint32_t)(idx >> 32) * 0x85EBCA77u + salt * 0xC2B2AE3Du + 0x27D4EB2Fu;
+  const uint32_t y = (uint32_t)(idx >> 32) * 0x85EBCA77u + salt * 0xC2B2AE3Du + 0x27D4EB2Fu;
   x ^= y; x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-  x += y;  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
   return x;
 }
-__device__ __host__ __forceinline__ uint32_t tell_drop_threshold(float p) {
-  double t = (double)p * 4294967296.0;
+__device__ __host__ __forceinline__ uint32_t tell_drop_threshold(float p) {   // 16-bit: 0 = no dropout
+  double t = (double)p * 65536.0;
   if (t < 0) t = 0;
-  if (t > 4294967295.0) t = 4294967295.0;
+  if (t > 65535.0) t = 65535.0;
   return (uint32_t)t;
 }
 // returns the multiplicative keep factor: 0 or 1/(1-p)
 __device__ __forceinline__ float tell_keep(uint32_t seed, uint32_t salt, uint64_t idx, uint32_t thr,
                                            float inv_keep) {
-  return tell_hash32(seed, salt, idx) >= thr ? inv_keep : 0.f;
+  const uint32_t h = tell_hash32(seed, salt, idx >> 1);
+  const uint32_t bits = (idx & 1) ? (h >> 16) : (h & 0xffffu);
+  return bits >= thr ? inv_keep : 0.f;
+}
+// both decisions of the aligned pair starting at the EVEN index idx_even
+__device__ __forceinline__ void tell_keep2(uint32_t seed, uint32_t salt, uint64_t idx_even, uint32_t thr,
+                                           float inv_keep, float& k0, float& k1) {
+  const uint32_t h = tell_hash32(seed, salt, idx_even >> 1);
+  k0 = (h & 0xffffu) >= thr ? inv_keep : 0.f;
+  k1 = (h >> 16) >= thr ? inv_keep : 0.f;
 }

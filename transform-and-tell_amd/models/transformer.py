@@ -79,19 +79,23 @@ class CaptionModel(Model):
             # underneath RoBERTa's chip-filling GEMMs (TELL_ENCODER_OVERLAP=0 serialises them).
             main = torch.cuda.current_stream()
             side = _side_stream(image.device) if _OVERLAP else None
+            article_ids = context[self.index]
+            article_mask = article_ids == self.padding_idx                 # :347
             if side is not None:
-                side.wait_stream(main)
+                start = torch.cuda.Event()
+                start.record(main)
+            # RoBERTa is issued FIRST: its ~300 launches keep the main stream busy for ~10 ms of GPU time
+            # while the host is still issuing ResNet's ~800 small launches onto the side stream.
+            stack = self.roberta.extract_features(article_ids, return_all_hiddens=True)   # [L,B,S,E]
+            if side is not None:
+                side.wait_event(start)
                 with torch.cuda.stream(side), ops.hip.bound_stream():
                     x_image = self.resnet(image)                           # [B,49,2048] (NHWC == :335-341)
+                main.wait_stream(side)
+                x_image.record_stream(main)
             else:
                 x_image = self.resnet(image)
             B, P, _ = x_image.shape
-            article_ids = context[self.index]
-            article_mask = article_ids == self.padding_idx                 # :347
-            stack = self.roberta.extract_features(article_ids, return_all_hiddens=True)   # [L,B,S,E]
-            if side is not None:
-                main.wait_stream(side)
-                x_image.record_stream(main)
         if self.weigh_bert:
             x_article = ops.mix_layers(stack, self.bert_weight)            # :355-364
         else:

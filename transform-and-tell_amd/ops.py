@@ -87,7 +87,8 @@ def gemm(a, b, out=None, out_dtype=None, bias=None, bias_mode=0, act=0, aux=None
             tile = ((256, 128) if bf and tiles(256, 128) >= 256 else (128, 128) if tiles(128, 128) >= 256
                     else (64, 64))
             kname = 'gemm_nt_kernel<%s,%s,%d,%d>' % (names[0], names[1], tile[0], tile[1])
-        rec = prof.begin(kname, 2.0 * M * N * a.shape[1])
+        if prof.sampled(kname):
+            rec = prof.begin(kname, 2.0 * M * N * a.shape[1])
     call('tell_gemm_nt', a, a.stride(0), b, b.stride(0), out, out.stride(0), M, N, a.shape[1], hip.dt(a),
          hip.dt(out), bias, bias_mode, act, aux, float(alpha), int(accumulate), m_dev)
     if rec is not None:

@@ -4,7 +4,10 @@ import torch
 
 _enabled = False
 MIN_WORK = 2e9        # only launches with >= 2 GFLOP are timed (keeps the instrumentation out of the small kernels)
+SAMPLE = 3           # time every 3rd qualifying launch of a kernel (timed events fence the stream, keep them
+                     # sparse; 3 is coprime to the 4-GEMM period of a RoBERTa layer, so every shape is sampled)
 _records = []   # (kernel name, work, start event, end event)
+_seen = {}
 
 
 def enable(flag=True):
@@ -12,10 +15,18 @@ def enable(flag=True):
     _enabled = flag
     if flag:
         _records.clear()
+        _seen.clear()
 
 
 def enabled():
     return _enabled
+
+
+def sampled(name):
+    """True for the launches of `name` that get an event bracket (1 in SAMPLE)."""
+    n = _seen.get(name, 0)
+    _seen[name] = n + 1
+    return n % SAMPLE == 0
 
 
 def begin(name, work):
@@ -31,13 +42,14 @@ def end(rec):
 
 
 def summary():
-    """-> {kernel: dict(launches, total_ms, avg_us, work)}; call after torch.cuda.synchronize()."""
+    """-> {kernel: dict(launches, timed, total_ms, avg_us, work)}; call after torch.cuda.synchronize()."""
     out = {}
     for name, work, e0, e1 in _records:
-        d = out.setdefault(name, dict(launches=0, total_ms=0.0, work=0.0))
-        d['launches'] += 1
+        d = out.setdefault(name, dict(timed=0, total_ms=0.0, work=0.0))
+        d['timed'] += 1
         d['total_ms'] += e0.elapsed_time(e1)
-        d['work'] += work
-    for d in out.values():
-        d['avg_us'] = 1e3 * d['total_ms'] / max(d['launches'], 1)
+        d['work'] += work                                   # work of the TIMED launches only
+    for name, d in out.items():
+        d['launches'] = _seen.get(name, d['timed'])         # all qualifying launches, timed or not
+        d['avg_us'] = 1e3 * d['total_ms'] / max(d['timed'], 1)
     return out
