@@ -55,6 +55,42 @@ DTYPES = [torch.float32, torch.bfloat16]
 
 
 # ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize('M,N,K', [(64, 64, 64), (96, 200, 72), (1024, 1024, 512), (496, 1024, 512),
+                                   (2, 1024, 300), (5000, 128, 40), (2048, 2304, 130), (1000, 1000, 8192)])
+def test_gemm_kmajor_forms(M, N, K):
+    """tell_gemm_bf16: TN (wgrad) and NN (dgrad) read K-major operands in place (ds_read_b64_tr_b16)."""
+    from tell_amd import ops
+    g = torch.Generator().manual_seed(M * 13 + N + K)
+    Mp, Np = (M + 7) // 8 * 8, (N + 7) // 8 * 8
+    a_km = torch.zeros(K, Mp).bfloat16()
+    a_km[:, :M] = torch.randn(K, M, generator=g).bfloat16()
+    b_kn = torch.zeros(K, Np).bfloat16()
+    b_kn[:, :N] = torch.randn(K, N, generator=g).bfloat16()
+    ad, bd = a_km.to(DEV), b_kn.to(DEV)
+    ref = a_km[:, :M].float().t() @ b_kn[:, :N].float()
+    # TN, fp32 output accumulated onto ones (the fused wgrad form)
+    out = torch.ones(M, N, device=DEV)
+    ops.gemm_tn(ad[:, :M], bd[:, :N], out=out, accumulate=True, alpha=0.5)
+    close(out, 0.5 * ref + 1, torch.bfloat16, scale=math.sqrt(K))
+    # TN, bf16 output
+    out2 = ops.gemm_tn(ad[:, :M], bd[:, :N])
+    assert out2.dtype == torch.bfloat16
+    close(out2, ref, torch.bfloat16, scale=math.sqrt(K))
+    # NN: x[M2,K] @ b_kn[K,N]; K not a multiple of 8 -> zero padded columns in x
+    M2 = 200
+    Kp = (K + 7) // 8 * 8
+    x = torch.zeros(M2, Kp).bfloat16()
+    x[:, :K] = torch.randn(M2, K, generator=g).bfloat16()
+    ref2 = x[:, :K].float() @ b_kn[:, :N].float()
+    out3 = ops.gemm_nn(x.to(DEV), bd[:, :N])
+    close(out3, ref2, torch.bfloat16, scale=math.sqrt(K))
+    mdev = torch.tensor([M2 // 2], dtype=torch.int32, device=DEV)
+    out4 = torch.full((M2, N), 3.0, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_nn(x.to(DEV), bd[:, :N], out=out4, m_dev=mdev)
+    close(out4[:M2 // 2], ref2[:M2 // 2], torch.bfloat16, scale=math.sqrt(K))
+    assert (out4[M2 // 2:] == 3).all()
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('M,N,K', [(64, 64, 64), (130, 70, 96), (512, 1024, 1024), (37, 5002, 128),
                                    (1000, 48, 1024), (300, 300, 2048), (2048, 2048, 512),
@@ -100,7 +136,8 @@ def test_transpose_and_weight_norm(dtype):
     vp = torch.nn.Parameter(v.to(DEV))
     import tell_amd
     tell_amd.set_compute_dtype(dtype)
-    w, wt, norms = ops.wn_weight(gp, vp)
+    w, norms = ops.wn_weight(gp, vp)
+    wt = ops.wn_weight_t(gp, vp)
     close(w, OF.weight_norm_weight(g, v), dtype)
     close(wt[:, :40], OF.weight_norm_weight(g, v).t(), dtype)
     close(norms, v.norm(dim=1))

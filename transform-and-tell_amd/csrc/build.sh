@@ -1,8 +1,21 @@
 #!/bin/bash
 # Build libtell_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+# One object per source, compiled in parallel and only when the source (or a header) is newer.
 set -e
 cd "$(dirname "$0")"
 OUT=${1:-libtell_hip.so}
-SRCS="api.hip gemm.hip elementwise.hip layernorm.hip dynconv.hip attention.hip adaptive.hip optim.hip conv.hip encoders.hip"
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-result $SRCS -o "$OUT"
+SRCS="api gemm elementwise layernorm dynconv attention adaptive optim conv encoders"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value"
+mkdir -p _obj
+pids=""
+for s in $SRCS; do
+  if [ ! -f _obj/$s.o ] || [ $s.hip -nt _obj/$s.o ] || [ common.h -nt _obj/$s.o ] || [ ../../include/tell_hip.h -nt _obj/$s.o ]; then
+    hipcc $FLAGS -c $s.hip -o _obj/$s.o &
+    pids="$pids $!"
+  fi
+done
+for p in $pids; do wait $p; done
+objs=""
+for s in $SRCS; do objs="$objs _obj/$s.o"; done
+hipcc --offload-arch=gfx950 -shared -fPIC $objs -o "$OUT"
 echo "built $(pwd)/$OUT"

@@ -675,6 +675,160 @@ void gemm_nt_kernel(GemmArgs p) {
   gemm_epilogue<OutT, MI, NI>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, M, N);
 }
 
+// ------------------------------------------------------------- K-major operands (bf16): TN / NN forms
+// Backward GEMMs read activations and weights exactly as the forward pass left them:
+//   wgrad  dW[n][k] = sum_t dY[t][n] * X[t][k]   (both operands K-major: the reduction index is the ROW)
+//   dgrad  dX[t][k] = sum_n dY[t][n] * W[n][k]   (B operand K-major)
+// A K-major tile is staged row-major [k][m] (the global layout, 16-byte chunks along m) with a row stride
+// of (BM*2 + 64) bytes, and the MFMA fragments (8 consecutive k for one m per lane) come out of
+// ds_read_b64_tr_b16, gfx950's LDS transpose read: lane i of a 16-lane group supplies the address of row
+// i>>2, 8-byte piece i&3 of a [4 k][16 m] block and receives column i (probe: tools/probes/tr_read_probe.hip).
+// Two reads (k 0-3, 4-7) make one bf16x8 fragment.  The 64-byte row skew puts the 4 rows of a 32-lane access
+// on disjoint bank quarters.  No separate transpose kernels, no second copy of the operands in HBM.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+__device__ __forceinline__ bf16x8 tr_frag(const uint16_t* p0, const uint16_t* p1) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p1);
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <typename OutT, int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tx_kernel(GemmArgs p) {
+  using T = uint16_t;
+  constexpr int NT = 64 * WAVES_M * WAVES_N, BK = 64, PF = 2;
+  constexpr int SA = TA ? BM + 32 : 72, SB = TB ? BN + 32 : 72;      // LDS row strides (elements)
+  constexpr int ROWS_A = TA ? BK : BM, ROWS_B = TB ? BK : BN;
+  constexpr int CPA = TA ? BM / 8 : 8, CPB = TB ? BN / 8 : 8;        // 16-byte chunks per LDS row
+  constexpr int CHA = BM * 8 / NT, CHB = BN * 8 / NT;                // chunks per thread per tile
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 32, NI = WN / 32;
+  __shared__ __attribute__((aligned(16))) T As[2][ROWS_A * SA];
+  __shared__ __attribute__((aligned(16))) T Bs[2][ROWS_B * SB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  int M = p.M;
+  if (p.m_dev) { int md = *p.m_dev; M = md < M ? md : M; }
+  const int N = p.N, K = p.K;
+  const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  int tile_id;
+  {
+    const int orig = blockIdx.x, xcd = orig & 7, q = gridDim.x >> 3, r = gridDim.x & 7;
+    tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  if (tile_id >= tiles_m * tiles_n) return;
+  const int tm = tile_id / tiles_n, tn = tile_id % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const T* A = static_cast<const T*>(p.A);
+  const T* B = static_cast<const T*>(p.B);
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4 ra[PF][CHA], rb[PF][CHB];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  // chunk c of an operand tile: (LDS row, 16-byte chunk in the row).  Normal operand: row = m, chunk = k/8;
+  // K-major operand: row = k, chunk = m/8.  Loads are unconditional from clamped in-range addresses, the
+  // zero fill for k >= K happens at the LDS store (same pipeline discipline as gemm_nt_kernel).
+#define TX_GLOAD(KT, S)                                                                            \
+  {                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < CHA; ++i) {                                              \
+      const int c = tid + i * NT, row = c / CPA, ch = c % CPA;                                     \
+      if constexpr (TA) {                                                                          \
+        const int gk = (KT) * BK + row, gm = m0 + ch * 8;                                          \
+        ra[S][i] = *reinterpret_cast<const u32x4*>(A + (long)(gk < K ? gk : 0) * p.lda + (gm < M ? gm : 0)); \
+      } else {                                                                                     \
+        const int gm = m0 + row, gk = (KT) * BK + ch * 8;                                          \
+        ra[S][i] = *reinterpret_cast<const u32x4*>(A + (long)(gm < M ? gm : M - 1) * p.lda + (gk < K ? gk : 0)); \
+      }                                                                                            \
+    }                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < CHB; ++i) {                                              \
+      const int c = tid + i * NT, row = c / CPB, ch = c % CPB;                                     \
+      if constexpr (TB) {                                                                          \
+        const int gk = (KT) * BK + row, gn = n0 + ch * 8;                                          \
+        rb[S][i] = *reinterpret_cast<const u32x4*>(B + (long)(gk < K ? gk : 0) * p.ldb + (gn < N ? gn : 0)); \
+      } else {                                                                                     \
+        const int gn = n0 + row, gk = (KT) * BK + ch * 8;                                          \
+        rb[S][i] = *reinterpret_cast<const u32x4*>(B + (long)(gn < N ? gn : N - 1) * p.ldb + (gk < K ? gk : 0)); \
+      }                                                                                            \
+    }                                                                                              \
+  }
+#define TX_SSTORE(S, BUF, KT)                                                                      \
+  {                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < CHA; ++i) {                                              \
+      const int c = tid + i * NT, row = c / CPA, ch = c % CPA;                                     \
+      const bool ok = TA ? ((KT) * BK + row) < K : ((m0 + row) < M && ((KT) * BK + ch * 8) < K);   \
+      *reinterpret_cast<u32x4*>(As[BUF] + row * SA + ch * 8) = ok ? ra[S][i] : zero4;              \
+    }                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < CHB; ++i) {                                              \
+      const int c = tid + i * NT, row = c / CPB, ch = c % CPB;                                     \
+      const bool ok = TB ? ((KT) * BK + row) < K : ((n0 + row) < N && ((KT) * BK + ch * 8) < K);   \
+      *reinterpret_cast<u32x4*>(Bs[BUF] + row * SB + ch * 8) = ok ? rb[S][i] : zero4;              \
+    }                                                                                              \
+  }
+  // per-lane fragment origins
+  //  normal  : row (lane&31) of the wave tile, k chunk 8*(lane>>5)
+  //  K-major : tr-read address of this lane: k row 8*(lane>>5) + ((lane&15)>>2), m col 16*((lane>>4)&1) + 4*(lane&3)
+  const int a_off = TA ? (8 * (lane >> 5) + ((lane & 15) >> 2)) * SA + wm * WM + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)
+                       : (wm * WM + (lane & 31)) * SA + 8 * (lane >> 5);
+  const int b_off = TB ? (8 * (lane >> 5) + ((lane & 15) >> 2)) * SB + wn * WN + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)
+                       : (wn * WN + (lane & 31)) * SB + 8 * (lane >> 5);
+#define TX_STEP(S)                                                                                 \
+  {                                                                                                \
+    const int kt = kt0 + (S);                                                                      \
+    TX_GLOAD(kt + PF, S)                                                                           \
+    const T* at = As[(S) & 1] + a_off;                                                             \
+    const T* bt = Bs[(S) & 1] + b_off;                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < BK; ks += 16) {                                        \
+      bf16x8 a[MI], b[NI];                                                                         \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                             \
+        if constexpr (TA) a[i] = tr_frag(at + ks * SA + i * 32, at + (ks + 4) * SA + i * 32);      \
+        else a[i] = *reinterpret_cast<const bf16x8*>(at + i * 32 * SA + ks);                       \
+      }                                                                                            \
+      _Pragma("unroll") for (int j = 0; j < NI; ++j) {                                             \
+        if constexpr (TB) b[j] = tr_frag(bt + ks * SB + j * 32, bt + (ks + 4) * SB + j * 32);      \
+        else b[j] = *reinterpret_cast<const bf16x8*>(bt + j * 32 * SB + ks);                       \
+      }                                                                                            \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                               \
+        _Pragma("unroll") for (int j = 0; j < NI; ++j)                                             \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);     \
+    }                                                                                              \
+    TX_SSTORE(((S) + 1) % PF, ((S) + 1) & 1, kt + 1)                                               \
+    __syncthreads();                                                                               \
+  }
+  const int nk = (K + BK - 1) / BK;
+  const int nk_pad = (nk + PF - 1) / PF * PF;
+  TX_GLOAD(0, 0)
+  TX_GLOAD(1, 1)
+  TX_SSTORE(0, 0, 0)
+  __syncthreads();
+  for (int kt0 = 0; kt0 < nk_pad; kt0 += PF) {
+    TX_STEP(0)
+    TX_STEP(1)
+  }
+#undef TX_STEP
+#undef TX_GLOAD
+#undef TX_SSTORE
+  gemm_epilogue<OutT, MI, NI>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, M, N);
+}
+
+template <typename OutT, bool TA, bool TB>
+static int launch_gemm_tx(const GemmArgs& a, hipStream_t stream) {
+  auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+  if (tiles(128, 128) >= 256)
+    hipLaunchKernelGGL((gemm_tx_kernel<OutT, 128, 128, 2, 2, TA, TB>), dim3((unsigned)tiles(128, 128)), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL((gemm_tx_kernel<OutT, 64, 64, 2, 2, TA, TB>), dim3((unsigned)tiles(64, 64)), dim3(256), 0, stream, a);
+  return tell_check_launch("gemm_tx");
+}
+
 template <typename T, typename OutT>
 static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   // Tile choice: the kernel is bound by operand re-reads from L2 (flop/byte of a tile =
@@ -701,11 +855,9 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
       return tell_check_launch("gemm_nt_glds");
     }
   }
-  // (256x256 with 8 waves measured SLOWER than 256x128 on MI355X - 394 vs 552 TFLOP/s on the RoBERTa
-  //  shapes: 236 VGPRs, one workgroup per CU - so it is compiled but not selected)
-  if (sizeof(T) == 2 && tiles(256, 256) >= (1L << 40)) {
-    hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, 256, 256, 2, 4, 2>), dim3((unsigned)tiles(256, 256)), dim3(512), 0, stream, a);
-  } else if (sizeof(T) == 2 && tiles(256, 128) >= 256) {
+  // (a 256x256 register-staged tile measured slower than 256x128 - 236 VGPRs, one workgroup per CU - and
+  //  was removed)
+  if (sizeof(T) == 2 && tiles(256, 128) >= 256) {
     hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, 256, 128, 4, 2, 2>), dim3((unsigned)tiles(256, 128)), dim3(512), 0, stream, a);
   } else if (tiles(128, 128) >= 256) {
     hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, 128, 128, 2, 2, 2>), dim3((unsigned)tiles(128, 128)), dim3(256), 0, stream, a);
@@ -741,4 +893,36 @@ extern "C" int tell_gemm_nt(const void* A, long lda, const void* B, long ldb, vo
                                   : launch_gemm<uint16_t, float>(a, stream);
   return out_dtype == TELL_BF16 ? launch_gemm<float, uint16_t>(a, stream)
                                 : launch_gemm<float, float>(a, stream);
+}
+
+// C[M,N] = act((op(A) . op(B) + bias) * alpha) (+ C), bf16 operands.  trans_a: A is stored [K][M] (K-major,
+// row stride lda >= M); otherwise [M][K].  trans_b: B is stored [K][N]; otherwise [N][K] (the tell_gemm_nt form).
+extern "C" int tell_gemm_bf16(const void* A, long lda, int trans_a, const void* B, long ldb, int trans_b, void* C,
+                              long ldc, int M, int N, int K, int out_dtype, const float* bias, int bias_mode,
+                              int act, const void* aux, float alpha, int accumulate, const int* m_dev,
+                              hipStream_t stream) {
+  if (!trans_a && !trans_b)
+    return tell_gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, TELL_BF16, out_dtype, bias, bias_mode, act, aux, alpha,
+                        accumulate, m_dev, stream);
+  TELL_REQUIRE(M >= 0 && N >= 0 && K > 0, "gemm_bf16: bad dimension");
+  if (M == 0 || N == 0) return TELL_OK;
+  TELL_REQUIRE(out_dtype == TELL_BF16 || out_dtype == TELL_F32, "gemm_bf16: bad out_dtype");
+  TELL_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "gemm_bf16: lda, ldb must be multiples of 8 elements");
+  // a row-major operand is read in 8-element chunks along k: its rows must extend to round_up(K, 8), and the
+  // columns K.. of that last chunk must hold zeros (they meet zero-filled rows of the K-major operand)
+  const long k8 = ((long)K + 7) / 8 * 8;
+  TELL_REQUIRE((trans_a ? lda >= M : lda >= k8) && (trans_b ? ldb >= N : ldb >= k8),
+               "gemm_bf16: K-major operands need ld >= extent, row-major ones ld >= round_up(K, 8)");
+  TELL_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "gemm_bf16: A/B must be 16-byte aligned");
+  TELL_REQUIRE(bias_mode == 0 || bias != nullptr, "gemm_bf16: bias_mode set without bias");
+  TELL_REQUIRE(act != 3 || aux != nullptr, "gemm_bf16: act=3 needs aux");
+  GemmArgs a;
+  a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux; a.m_dev = m_dev;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+  a.bias_mode = bias_mode; a.act = act; a.accumulate = accumulate; a.alpha = alpha; a.dbg = 0;
+  if (trans_a && trans_b)
+    return out_dtype == TELL_BF16 ? launch_gemm_tx<uint16_t, true, true>(a, stream) : launch_gemm_tx<float, true, true>(a, stream);
+  if (trans_b)
+    return out_dtype == TELL_BF16 ? launch_gemm_tx<uint16_t, false, true>(a, stream) : launch_gemm_tx<float, false, true>(a, stream);
+  return out_dtype == TELL_BF16 ? launch_gemm_tx<uint16_t, true, false>(a, stream) : launch_gemm_tx<float, true, false>(a, stream);
 }

@@ -143,8 +143,9 @@ class _DynamicConvDecoderBase(Decoder):
         X = X.transpose(0, 1)                                                      # :109 T x B x C (contiguous)
         X = ops.dropout(X, self.dropout, self.training)                            # :106
         contexts_t = None
-        if torch.is_grad_enabled() and self.training:
-            # one transpose per context per step, shared by the K and V weight-gradient GEMMs of all layers
+        if torch.is_grad_enabled() and self.training and ops.rt.compute_dtype() == torch.float32:
+            # fp32 parity mode only (the bf16 wgrad GEMM reads K-major operands in place): one transpose per
+            # context per step, shared by the K and V weight-gradient GEMMs of all layers
             contexts_t = contexts.get('_transposed')
             if contexts_t is None:
                 contexts_t = {}

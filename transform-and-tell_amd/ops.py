@@ -96,6 +96,60 @@ def gemm(a, b, out=None, out_dtype=None, bias=None, bias_mode=0, act=0, aux=None
     return out
 
 
+def _kmajor_ok(t):
+    """bf16 [K, X] operand usable in place by the K-major GEMM forms (tell_gemm_bf16)."""
+    return (t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 8 == 0 and
+            t.data_ptr() % 16 == 0)
+
+
+def gemm_tn(a_km, b_kn, out=None, out_dtype=None, accumulate=False, alpha=1.0, m_dev=None):
+    """out[M,N] = alpha * sum_k a_km[k,m] * b_kn[k,n] (+ out): both operands K-major, as the forward pass left
+    them (wgrad: a_km = dY [T,N_out], b_kn = X [T,K_in]).  bf16 operands go to the LDS-transpose-read kernel;
+    anything else (fp32 parity mode, unaligned strides) takes explicit transposes + the NT kernel."""
+    K, M = a_km.shape
+    N = b_kn.shape[1]
+    if _kmajor_ok(a_km) and _kmajor_ok(b_kn) and m_dev is None:
+        if out is None:
+            out = torch.empty(M, N, dtype=out_dtype or a_km.dtype, device=a_km.device)
+        assert out.stride(1) == 1
+        call('tell_gemm_bf16', a_km, a_km.stride(0), 1, b_kn, b_kn.stride(0), 1, out, out.stride(0), M, N, K,
+             hip.dt(out), None, 0, 0, None, float(alpha), int(accumulate), None)
+        return out
+    at, _ = transpose(a_km)
+    bt, _ = transpose(b_kn)
+    return gemm(at, bt, out=out, out_dtype=out_dtype, accumulate=accumulate, alpha=alpha, m_dev=m_dev)
+
+
+def gemm_nn(a, b_kn, b_t=None, out=None, out_dtype=None, alpha=1.0, act=0, aux=None, m_dev=None):
+    """out[M,N] = act(alpha * a[M,K] @ b_kn[K,N]) (dgrad: a = dY, b_kn = the weight as stored [N_out, K_in]).
+    `b_t`: callable returning b_kn^T [N, K] for the fallback path."""
+    M = a.shape[0]
+    K, N = b_kn.shape                  # `a` may carry zero padding columns beyond K (never garbage: 0 * NaN)
+    assert a.shape[1] >= K
+    big = ((M + 127) // 128) * ((N + 127) // 128) >= 256 and K % 64 == 0     # direct-to-LDS NT kernel territory
+    if (_kmajor_ok(b_kn) and a.dtype == torch.bfloat16 and a.stride(1) == 1 and a.stride(0) % 8 == 0 and
+            (K % 8 == 0 or a.shape[1] >= _round_up(K, 8)) and a.data_ptr() % 16 == 0 and
+            not (big and b_t is not None)):
+        if out is None:
+            out = torch.empty(M, N, dtype=out_dtype or a.dtype, device=a.device)
+        call('tell_gemm_bf16', a, a.stride(0), 0, b_kn, b_kn.stride(0), 1, out, out.stride(0), M, N, K,
+             hip.dt(out), None, 0, act, aux, float(alpha), 0, m_dev)
+        return out
+    bt = b_t() if b_t is not None else transpose(b_kn)[0]
+    if bt.shape[1] != a.shape[1]:                       # bring both to one (zero padded) K width
+        Kp = max(bt.shape[1], a.shape[1])
+        if bt.shape[1] != Kp:
+            b2 = torch.zeros(bt.shape[0], Kp, dtype=bt.dtype, device=bt.device)
+            b2[:, :bt.shape[1]] = bt
+            bt = b2
+        if a.shape[1] != Kp:
+            a2 = torch.zeros(a.shape[0], Kp, dtype=a.dtype, device=a.device)
+            a2[:, :a.shape[1]] = a
+            a = a2
+    res = gemm(a, bt, out=out, out_dtype=out_dtype, alpha=alpha, act=act, aux=aux, m_dev=m_dev)
+    return res if out is not None else res[:, :N]
+
+
 def transpose(x, out_dtype=None, row_scale=None, want_plain=False, want_t=True):
     """-> (x^T [C, R padded to a chunk multiple, zero filled], plain copy or None)."""
     R, C = x.shape
@@ -166,15 +220,20 @@ def weight_t(p, rows=None):
 
 
 def wn_weight(g, v):
-    """Weight-normalised working weight (tell/modules/linear.py:33): (w, w^T, norms)."""
+    """Weight-normalised working weight (tell/modules/linear.py:33): (w [N,K] compute dtype, norms)."""
     def make():
         R, C = v.shape
         scale = torch.empty(R, dtype=torch.float32, device=v.device)
         norms = torch.empty(R, dtype=torch.float32, device=v.device)
         call('tell_wn_rowscale', g.detach(), v.detach(), R, C, scale, norms)
-        wt, w = transpose(v.detach(), out_dtype=rt.compute_dtype(), row_scale=scale, want_plain=True)
-        return w, wt, norms
+        _, w = transpose(v.detach(), out_dtype=rt.compute_dtype(), row_scale=scale, want_plain=True, want_t=False)
+        return w, norms
     return _cached(v, ('wn', g._version, g.data_ptr()), make)
+
+
+def wn_weight_t(g, v):
+    """w^T of wn_weight (only the fp32 / unaligned fallback of the dgrad GEMM needs it)."""
+    return _cached(v, ('wn_t', g._version, g.data_ptr()), lambda: transpose(wn_weight(g, v)[0])[0])
 
 
 # --------------------------------------------------------------------------- #
@@ -209,16 +268,18 @@ class LinearFn(Function):
             dy2 = d
         r0, r1 = rows if rows is not None else (0, w_param.shape[0])
         if w_param.requires_grad:
-            dyT, _ = transpose(dy2)
-            xT = x_t if x_t is not None else transpose(x2)[0]
             gw = grad_buffer(w_param)
-            gemm(dyT, xT, out=gw.view(gw.shape[0], -1)[r0:r1], alpha=alpha, accumulate=True)
+            gw2 = gw.view(gw.shape[0], -1)[r0:r1]
+            if x_t is not None:                      # fp32 parity mode: the caller shared one transpose of x
+                gemm(transpose(dy2)[0], x_t, out=gw2, alpha=alpha, accumulate=True)
+            else:
+                gemm_tn(dy2, x2, out=gw2, alpha=alpha, accumulate=True)
         if b_param is not None and b_param.requires_grad:
             gb = grad_buffer(b_param)
             colsum_into(dy2, gb if b_rows is None else gb[b_rows[0]:b_rows[1]], scale=alpha)
         dx = None
         if need_dx:
-            dx = gemm(dy2, weight_t(w_param, rows), alpha=alpha)[:, :x2.shape[1]]
+            dx = gemm_nn(dy2, weight(w_param, rows), b_t=lambda: weight_t(w_param, rows), alpha=alpha)
             dx = dx.reshape(xshape) if dx.is_contiguous() else dx.contiguous().view(xshape)
         return dx, None, None, None, None, None, None, None, None
 
@@ -234,7 +295,7 @@ class WNLinearFn(Function):
     @staticmethod
     def forward(ctx, x, g, v, b, act, need_dx):
         x2 = as2d(x)
-        w, _, norms = wn_weight(g, v)
+        w, norms = wn_weight(g, v)
         y = gemm(x2, w, bias=b.detach() if b is not None else None, bias_mode=1 if b is not None else 0,
                  act=act)
         ctx.save_for_backward(x2, y if act == 1 else None)
@@ -250,18 +311,16 @@ class WNLinearFn(Function):
             d = torch.empty_like(dy2)
             call('tell_relu_bwd', dy2, y, d, dy2.numel(), hip.dt(dy2))
             dy2 = d
-        _, wt, norms = wn_weight(g, v)
+        w, norms = wn_weight(g, v)
         if v.requires_grad:
-            dyT, _ = transpose(dy2)
-            xT, _ = transpose(x2)
-            dW = gemm(dyT, xT, out_dtype=torch.float32)
+            dW = gemm_tn(dy2, x2, out_dtype=torch.float32)
             call('tell_wn_backward', dW, g.detach(), v.detach(), norms, v.shape[0], v.shape[1],
                  grad_buffer(g), grad_buffer(v))
         if b is not None and b.requires_grad:
             colsum_into(dy2, grad_buffer(b))
         dx = None
         if need_dx:
-            dx = gemm(dy2, wt)[:, :x2.shape[1]]
+            dx = gemm_nn(dy2, w, b_t=lambda: wn_weight_t(g, v))
             dx = dx.reshape(xshape) if dx.is_contiguous() else dx.contiguous().view(xshape)
         return dx, None, None, None, None, None
 
@@ -590,11 +649,9 @@ class AdaptiveEmbedFn(Function):
             cnt = part['count'][b:b + 1]
             dy = dband[b * N:(b + 1) * N]                      # rows >= count are zero
             if proj.requires_grad:
-                dyT, _ = transpose(dy)
-                rT, _ = transpose(rows_saved[b])
-                gemm(dyT, rT, out=grad_buffer(proj), accumulate=True)
+                gemm_tn(dy, rows_saved[b], out=grad_buffer(proj), accumulate=True)
             if emb.requires_grad:
-                drows = gemm(dy, weight_t(proj), m_dev=cnt)[:, :dim]
+                drows = gemm_nn(dy, weight(proj), b_t=lambda: weight_t(proj), m_dev=cnt)[:, :dim]
                 if not drows.is_contiguous():
                     drows = drows.contiguous()
                 call('tell_embed_table_grad', drows, drows.stride(0), part['local'][b], cnt, N,
@@ -681,18 +738,13 @@ class AdaptiveLossFn(Function):
         dl = torch.zeros(N, _round_up(n_head, _vec(dtype)), dtype=dtype, device=dev)
         call('tell_ce_bwd', head_logits, head_logits.stride(0), N, n_head, part['head_target'], None, None,
              int(pad_idx), lse_h, gscale, dl, dl.stride(0), hip.dt(dtype))
-        w_head_t, _ = transpose(w_head)                           # [E, n_head padded]
-        if w_head_t.shape[1] != dl.shape[1]:
-            wt2 = torch.zeros(E, dl.shape[1], dtype=dtype, device=dev)
-            wt2[:, :w_head_t.shape[1]] = w_head_t
-            w_head_t = wt2
-        dx = gemm(dl, w_head_t)                                   # [N, E]
-        dlT, _ = transpose(dl[:, :n_head])                        # [n_head, N]
-        xT, _ = transpose(x2)
+        dx = gemm_nn(dl, w_head)                                  # [N, E]; dl's padding columns are zero
+        if not dx.is_contiguous():
+            dx = dx.contiguous()
         if emb0.requires_grad:
-            gemm(dlT[:c0], xT, out=grad_buffer(emb0), accumulate=True)
+            gemm_tn(dl[:, :c0], x2, out=grad_buffer(emb0), accumulate=True)
         if class_proj.requires_grad:
-            gemm(dlT[c0:n_head], xT, out=grad_buffer(class_proj), accumulate=True)
+            gemm_tn(dl[:, c0:n_head], x2, out=grad_buffer(class_proj), accumulate=True)
         # ---- tails
         for i in range(n_tails):
             proj, emb = tails[2 * i], tails[2 * i + 1]
@@ -703,22 +755,13 @@ class AdaptiveLossFn(Function):
             dlt = torch.zeros(N, _round_up(V, _vec(dtype)), dtype=dtype, device=dev)
             call('tell_ce_bwd', logits, logits.stride(0), N, V, part['local'][band], None, cnt, int(pad_idx),
                  lse_t, gscale, dlt, dlt.stride(0), hip.dt(dtype))
-            emb_t = weight_t(emb)                                  # [dim, V padded]
-            if emb_t.shape[1] != dlt.shape[1]:
-                et = torch.zeros(emb_t.shape[0], dlt.shape[1], dtype=dtype, device=dev)
-                et[:, :emb_t.shape[1]] = emb_t
-                emb_t = et
             dh = torch.zeros(N, proj.shape[0], dtype=dtype, device=dev)
-            gemm(dlt, emb_t, out=dh, m_dev=cnt)
-            dltT, _ = transpose(dlt[:, :V])                        # [V, N]; rows >= count of dlt are zero
-            hT, _ = transpose(h)
-            if emb.requires_grad:
-                gemm(dltT, hT, out=grad_buffer(emb), accumulate=True)
+            gemm_nn(dlt, weight(emb), b_t=lambda emb=emb: weight_t(emb), out=dh, m_dev=cnt)
+            if emb.requires_grad:                                  # rows >= count of dlt are zero
+                gemm_tn(dlt[:, :V], h, out=grad_buffer(emb), accumulate=True)
             if proj.requires_grad:
-                dhT, _ = transpose(dh)
-                xgT, _ = transpose(xg)
-                gemm(dhT, xgT, out=grad_buffer(proj), accumulate=True)
-            dxg = gemm(dh, weight_t(proj), m_dev=cnt)[:, :E]
+                gemm_tn(dh, xg, out=grad_buffer(proj), accumulate=True)
+            dxg = gemm_nn(dh, weight(proj), b_t=lambda proj=proj: weight_t(proj), m_dev=cnt)
             if not dxg.is_contiguous():
                 dxg = dxg.contiguous()
             call('tell_scatter_add_rows', dxg, dxg.stride(0), part['rows'][band], cnt, N, dx, dx.stride(0), E,
