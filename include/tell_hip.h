@@ -57,10 +57,13 @@ int tell_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, long
 
 /* bf16 GEMM with K-major operands (no transposed copies in HBM): trans_a -> A stored [K][M] (lda >= M),
  * trans_b -> B stored [K][N].  The backward forms of the same reference lines: autograd of F.linear gives
- * grad_weight = grad_out^T . x (trans_a = trans_b = 1) and grad_in = grad_out . W (trans_b = 1). */
+ * grad_weight = grad_out^T . x (trans_a = trans_b = 1) and grad_in = grad_out . W (trans_b = 1).
+ * a_colsum (trans_a only, may be NULL): a_colsum[m] += a_colsum_scale * sum_k A[k][m] - grad_bias = column sums
+ * of grad_out, taken from the tiles the wgrad GEMM stages anyway. */
 int tell_gemm_bf16(const void* A, long lda, int trans_a, const void* B, long ldb, int trans_b, void* C, long ldc,
                    int M, int N, int K, int out_dtype, const float* bias, int bias_mode, int act, const void* aux,
-                   float alpha, int accumulate, const int* m_dev, tell_stream_t stream);
+                   float alpha, int accumulate, const int* m_dev, float* a_colsum, float a_colsum_scale,
+                   tell_stream_t stream);
 
 /* ---- casts / transposes / weight norm -------------------------------------- */
 int tell_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, tell_stream_t stream);

@@ -70,8 +70,10 @@ def test_gemm_kmajor_forms(M, N, K):
     ref = a_km[:, :M].float().t() @ b_kn[:, :N].float()
     # TN, fp32 output accumulated onto ones (the fused wgrad form)
     out = torch.ones(M, N, device=DEV)
-    ops.gemm_tn(ad[:, :M], bd[:, :N], out=out, accumulate=True, alpha=0.5)
+    asum = torch.full((M,), 2.0, device=DEV)
+    ops.gemm_tn(ad[:, :M], bd[:, :N], out=out, accumulate=True, alpha=0.5, asum=asum, asum_scale=0.25)
     close(out, 0.5 * ref + 1, torch.bfloat16, scale=math.sqrt(K))
+    close(asum, 2.0 + 0.25 * a_km[:, :M].float().sum(0), torch.float32, scale=math.sqrt(K))   # fused bias gradient
     # TN, bf16 output
     out2 = ops.gemm_tn(ad[:, :M], bd[:, :N])
     assert out2.dtype == torch.bfloat16

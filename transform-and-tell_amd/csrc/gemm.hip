@@ -31,6 +31,8 @@ struct GemmArgs {
   int accumulate;         // C = C + result  (beta = 1)
   float alpha;            // result = act((acc + bias) * alpha)
   int dbg;                // tuning aid (TELL_GEMM_DEBUG): 1 = skip the epilogue, 2 = one K step only
+  float* asum;            // K-major A only: asum[m] += asum_scale * sum_k A[k][m]  (bias gradient of a wgrad GEMM)
+  float asum_scale;
 };
 
 template <typename T> struct Mma;
@@ -695,10 +697,11 @@ __device__ __forceinline__ bf16x8 tr_frag(const uint16_t* p0, const uint16_t* p1
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <typename OutT, int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB>
+template <typename OutT, int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB, int PF>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tx_kernel(GemmArgs p) {
   using T = uint16_t;
-  constexpr int NT = 64 * WAVES_M * WAVES_N, BK = 64, PF = 2;
+  constexpr int NT = 64 * WAVES_M * WAVES_N, BK = 64;
+  static_assert(PF == 2 || PF == 4, "prefetch depth");
   constexpr int SA = TA ? BM + 32 : 72, SB = TB ? BN + 32 : 72;      // LDS row strides (elements)
   constexpr int ROWS_A = TA ? BK : BM, ROWS_B = TB ? BK : BN;
   constexpr int CPA = TA ? BM / 8 : 8, CPB = TB ? BN / 8 : 8;        // 16-byte chunks per LDS row
@@ -734,6 +737,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tx_kernel(Gemm
 
   u32x4 ra[PF][CHA], rb[PF][CHB];
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  // fused column sums of A (bias gradient): the n-tile-0 workgroup of every m range adds up the chunks it stages
+  const bool want_asum = TA && p.asum != nullptr && tn == 0;          // block-uniform
+  float csum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) csum[e] = 0.f;
   // chunk c of an operand tile: (LDS row, 16-byte chunk in the row).  Normal operand: row = m, chunk = k/8;
   // K-major operand: row = k, chunk = m/8.  Loads are unconditional from clamped in-range addresses, the
   // zero fill for k >= K happens at the LDS store (same pipeline discipline as gemm_nt_kernel).
@@ -765,7 +773,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tx_kernel(Gemm
     _Pragma("unroll") for (int i = 0; i < CHA; ++i) {                                              \
       const int c = tid + i * NT, row = c / CPA, ch = c % CPA;                                     \
       const bool ok = TA ? ((KT) * BK + row) < K : ((m0 + row) < M && ((KT) * BK + ch * 8) < K);   \
-      *reinterpret_cast<u32x4*>(As[BUF] + row * SA + ch * 8) = ok ? ra[S][i] : zero4;              \
+      const u32x4 va = ok ? ra[S][i] : zero4;                                                      \
+      *reinterpret_cast<u32x4*>(As[BUF] + row * SA + ch * 8) = va;                                 \
+      if (want_asum) {                                                                             \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
+          csum[2 * e] += __uint_as_float(va[e] << 16);                                             \
+          csum[2 * e + 1] += __uint_as_float(va[e] & 0xffff0000u);                                 \
+        }                                                                                          \
+      }                                                                                            \
     }                                                                                              \
     _Pragma("unroll") for (int i = 0; i < CHB; ++i) {                                              \
       const int c = tid + i * NT, row = c / CPB, ch = c % CPB;                                     \
@@ -807,15 +822,40 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tx_kernel(Gemm
   const int nk_pad = (nk + PF - 1) / PF * PF;
   TX_GLOAD(0, 0)
   TX_GLOAD(1, 1)
+  if constexpr (PF == 4) {
+    TX_GLOAD(2, 2)
+    TX_GLOAD(3, 3)
+  }
   TX_SSTORE(0, 0, 0)
   __syncthreads();
   for (int kt0 = 0; kt0 < nk_pad; kt0 += PF) {
     TX_STEP(0)
     TX_STEP(1)
+    if constexpr (PF == 4) {
+      TX_STEP(2)
+      TX_STEP(3)
+    }
   }
 #undef TX_STEP
 #undef TX_GLOAD
 #undef TX_SSTORE
+  if constexpr (TA) {
+    if (want_asum) {
+      // every chunk of thread t covers columns (t % CPA) * 8 .. + 7 of the m range (NT % CPA == 0): fold the
+      // NT / CPA threads of a column chunk through LDS (the last loop barrier made the tile buffers free)
+      static_assert(NT % CPA == 0 && NT * 9 * 4 <= (int)sizeof(As), "column-sum scratch");
+      float* red = reinterpret_cast<float*>(&As[0][0]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[tid * 9 + e] = csum[e];
+      __syncthreads();
+      if (tid < BM && m0 + tid < M) {
+        const int ch = tid >> 3, e = tid & 7;
+        float s = 0.f;
+        for (int t = ch; t < NT; t += CPA) s += red[t * 9 + e];
+        p.asum[m0 + tid] += p.asum_scale * s;
+      }
+    }
+  }
   gemm_epilogue<OutT, MI, NI>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, M, N);
 }
 
@@ -823,9 +863,9 @@ template <typename OutT, bool TA, bool TB>
 static int launch_gemm_tx(const GemmArgs& a, hipStream_t stream) {
   auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
   if (tiles(128, 128) >= 256)
-    hipLaunchKernelGGL((gemm_tx_kernel<OutT, 128, 128, 2, 2, TA, TB>), dim3((unsigned)tiles(128, 128)), dim3(256), 0, stream, a);
-  else
-    hipLaunchKernelGGL((gemm_tx_kernel<OutT, 64, 64, 2, 2, TA, TB>), dim3((unsigned)tiles(64, 64)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((gemm_tx_kernel<OutT, 128, 128, 2, 2, TA, TB, 2>), dim3((unsigned)tiles(128, 128)), dim3(256), 0, stream, a);
+  else   // few workgroups, latency bound: 4 K tiles in flight
+    hipLaunchKernelGGL((gemm_tx_kernel<OutT, 64, 64, 2, 2, TA, TB, 4>), dim3((unsigned)tiles(64, 64)), dim3(256), 0, stream, a);
   return tell_check_launch("gemm_tx");
 }
 
@@ -887,7 +927,7 @@ extern "C" int tell_gemm_nt(const void* A, long lda, const void* B, long ldb, vo
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
   a.bias_mode = bias_mode; a.act = act; a.accumulate = accumulate; a.alpha = alpha;
   static const int dbg = getenv("TELL_GEMM_DEBUG") ? atoi(getenv("TELL_GEMM_DEBUG")) : 0;
-  a.dbg = dbg;
+  a.dbg = dbg; a.asum = nullptr; a.asum_scale = 0.f;
   if (in_dtype == TELL_BF16)
     return out_dtype == TELL_BF16 ? launch_gemm<uint16_t, uint16_t>(a, stream)
                                   : launch_gemm<uint16_t, float>(a, stream);
@@ -900,7 +940,8 @@ extern "C" int tell_gemm_nt(const void* A, long lda, const void* B, long ldb, vo
 extern "C" int tell_gemm_bf16(const void* A, long lda, int trans_a, const void* B, long ldb, int trans_b, void* C,
                               long ldc, int M, int N, int K, int out_dtype, const float* bias, int bias_mode,
                               int act, const void* aux, float alpha, int accumulate, const int* m_dev,
-                              hipStream_t stream) {
+                              float* a_colsum, float a_colsum_scale, hipStream_t stream) {
+  TELL_REQUIRE(a_colsum == nullptr || trans_a, "gemm_bf16: a_colsum needs a K-major A");
   if (!trans_a && !trans_b)
     return tell_gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, TELL_BF16, out_dtype, bias, bias_mode, act, aux, alpha,
                         accumulate, m_dev, stream);
@@ -920,6 +961,7 @@ extern "C" int tell_gemm_bf16(const void* A, long lda, int trans_a, const void* 
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux; a.m_dev = m_dev;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
   a.bias_mode = bias_mode; a.act = act; a.accumulate = accumulate; a.alpha = alpha; a.dbg = 0;
+  a.asum = a_colsum; a.asum_scale = a_colsum_scale;
   if (trans_a && trans_b)
     return out_dtype == TELL_BF16 ? launch_gemm_tx<uint16_t, true, true>(a, stream) : launch_gemm_tx<float, true, true>(a, stream);
   if (trans_b)

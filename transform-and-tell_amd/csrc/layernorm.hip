@@ -180,15 +180,119 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, l
     out[c] = sm[c] + sm[2 * C + c] + sm[4 * C + c] + sm[6 * C + c];
 }
 
-__global__ void ln_bwd_finish_kernel(const float* __restrict__ partial, int n_blocks, int C,
-                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                     int accumulate) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * C) return;
+// Fast path (C == 64 * VEC * NCH, 16-byte aligned rows): one wave per row, every operand read once with
+// 16-byte loads and kept in registers; the row's dgamma/dbeta contributions go through LDS once per block.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ dy, long ld_dy,
+                                                         const T* __restrict__ x, long ld_x,
+                                                         const T* __restrict__ res, long ld_r,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd,
+                                                         T* __restrict__ dx, long ld_dx,
+                                                         T* __restrict__ dres, long ld_dres, int dres_acc,
+                                                         float* __restrict__ partial, int rows,
+                                                         uint32_t thr, float inv_keep, uint32_t seed,
+                                                         uint32_t salt) {
+  constexpr int VEC = Elem<T>::VEC, C = 64 * VEC * NCH;
+  __shared__ float sm[4][2][C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * LN_BWD_ROWS + wave;
+  const bool live = row < rows;                                      // wave-uniform
+  float xh[NCH][VEC], g[NCH][VEC], keep[NCH][VEC];
+  float s1 = 0.f, s2 = 0.f, rs = 0.f;
+  if (live) {
+    const float mu = mean[row];
+    rs = rstd[row];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c0 = (lane + 64 * i) * VEC;
+      float d[VEC];
+      unpack16(*reinterpret_cast<const uint4*>(x + (long)row * ld_x + c0), xh[i], (const T*)nullptr);
+      unpack16(*reinterpret_cast<const uint4*>(dy + (long)row * ld_dy + c0), d, (const T*)nullptr);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        keep[i][k] = thr ? tell_keep(seed, salt, (uint64_t)row * C + c0 + k, thr, inv_keep) : 1.f;
+        xh[i][k] *= keep[i][k];
+      }
+      if (res) {
+        float r[VEC];
+        unpack16(*reinterpret_cast<const uint4*>(res + (long)row * ld_r + c0), r, (const T*)nullptr);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) xh[i][k] += r[k];
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        xh[i][k] = (xh[i][k] - mu) * rs;
+        g[i][k] = d[k] * gamma[c0 + k];
+        s1 += g[i][k];
+        s2 += g[i][k] * xh[i][k];
+        sm[wave][0][c0 + k] = d[k] * xh[i][k];
+        sm[wave][1][c0 + k] = d[k];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        sm[wave][0][(lane + 64 * i) * VEC + k] = 0.f;
+        sm[wave][1][(lane + 64 * i) * VEC + k] = 0.f;
+      }
+  }
+  if (live) {
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c0 = (lane + 64 * i) * VEC;
+      float dz[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) dz[k] = rs * (g[i][k] - s1 - xh[i][k] * s2);
+      if (dres) {
+        T* dp = dres + (long)row * ld_dres + c0;
+        float o[VEC];
+        if (dres_acc) {
+          unpack16(*reinterpret_cast<const uint4*>(dp), o, (const T*)nullptr);
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) o[k] += dz[k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) o[k] = dz[k];
+        }
+        *reinterpret_cast<uint4*>(dp) = pack16(o, (const T*)nullptr);
+      }
+      if (dx) {
+        float o[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) o[k] = dz[k] * keep[i][k];
+        *reinterpret_cast<uint4*>(dx + (long)row * ld_dx + c0) = pack16(o, (const T*)nullptr);
+      }
+    }
+  }
+  __syncthreads();
+  float* out = partial + (long)blockIdx.x * 2 * C;
+  const float* s = &sm[0][0][0];
+  for (int c = threadIdx.x; c < 2 * C; c += 256) out[c] = s[c] + s[2 * C + c] + s[4 * C + c] + s[6 * C + c];
+}
+
+// 64 columns x 4 partial-groups per block: coalesced reads, 4 independent chains per column, LDS combine
+__global__ __launch_bounds__(256) void ln_bwd_finish_kernel(const float* __restrict__ partial, int n_blocks, int C,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int accumulate) {
+  __shared__ float sm[4][64];
+  const int cx = threadIdx.x & 63, by = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
   float s = 0.f;
-  for (int b = 0; b < n_blocks; ++b) s += partial[(long)b * 2 * C + c];
-  float* dst = c < C ? dgamma + c : dbeta + (c - C);
-  *dst = accumulate ? *dst + s : s;
+  if (c < 2 * C)
+    for (int b = by; b < n_blocks; b += 4) s += partial[(long)b * 2 * C + c];
+  sm[by][cx] = s;
+  __syncthreads();
+  if (by == 0 && c < 2 * C) {
+    s = sm[0][cx] + sm[1][cx] + sm[2][cx] + sm[3][cx];
+    float* dst = c < C ? dgamma + c : dbeta + (c - C);
+    *dst = accumulate ? *dst + s : s;
+  }
 }
 
 extern "C" int tell_layernorm_bwd_blocks(int rows) { return (rows + LN_BWD_ROWS - 1) / LN_BWD_ROWS; }
@@ -207,12 +311,23 @@ extern "C" int tell_layernorm_bwd(const void* dy, long ld_dy, const void* x, lon
   float ik = 1.f / (1.f - p);
   int nb = tell_layernorm_bwd_blocks(rows);
   size_t smem = (size_t)C * 8 * sizeof(float);
-  if (dtype == TELL_BF16)
+  const int vec = dtype == TELL_BF16 ? 8 : 4;
+  auto al = [&](const void* q, long ld) { return q == nullptr || (ld % vec == 0 && ((uintptr_t)q & 15) == 0); };
+  const bool aligned = al(dy, ld_dy) && al(x, ld_x) && al(res, ld_r) && al(dx, ld_dx) && al(dres, ld_dres);
+  const int nch = C % (64 * vec) == 0 ? C / (64 * vec) : 0;
+#define LNB(T, NCH) hipLaunchKernelGGL((ln_bwd_vec_kernel<T, NCH>), dim3(nb), dim3(256), 0, stream, (const T*)dy, ld_dy, \
+    (const T*)x, ld_x, (const T*)res, ld_r, gamma, mean, rstd, (T*)dx, ld_dx, (T*)dres, ld_dres, dres_accumulate,      \
+    partial, rows, thr, ik, seed, salt)
+  if (aligned && (nch == 1 || nch == 2 || (nch == 4 && dtype == TELL_F32))) {
+    if (dtype == TELL_BF16) { if (nch == 1) LNB(uint16_t, 1); else LNB(uint16_t, 2); }
+    else { if (nch == 1) LNB(float, 1); else if (nch == 2) LNB(float, 2); else LNB(float, 4); }
+  } else if (dtype == TELL_BF16)
     hipLaunchKernelGGL((ln_bwd_kernel<uint16_t>), dim3(nb), dim3(256), smem, stream, (const uint16_t*)dy, ld_dy, (const uint16_t*)x, ld_x, (const uint16_t*)res, ld_r, gamma, mean, rstd, (uint16_t*)dx, ld_dx, (uint16_t*)dres, ld_dres, dres_accumulate, partial, rows, C, thr, ik, seed, salt);
   else
     hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(nb), dim3(256), smem, stream, (const float*)dy, ld_dy, (const float*)x, ld_x, (const float*)res, ld_r, gamma, mean, rstd, (float*)dx, ld_dx, (float*)dres, ld_dres, dres_accumulate, partial, rows, C, thr, ik, seed, salt);
   int rc = tell_check_launch("layernorm_bwd");
   if (rc) return rc;
-  hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, partial, nb, C, dgamma, dbeta, dparam_accumulate);
+#undef LNB
+  hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, stream, partial, nb, C, dgamma, dbeta, dparam_accumulate);
   return tell_check_launch("layernorm_bwd_finish");
 }

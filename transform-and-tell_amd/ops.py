@@ -102,10 +102,12 @@ def _kmajor_ok(t):
             t.data_ptr() % 16 == 0)
 
 
-def gemm_tn(a_km, b_kn, out=None, out_dtype=None, accumulate=False, alpha=1.0, m_dev=None):
+def gemm_tn(a_km, b_kn, out=None, out_dtype=None, accumulate=False, alpha=1.0, m_dev=None, asum=None,
+            asum_scale=1.0):
     """out[M,N] = alpha * sum_k a_km[k,m] * b_kn[k,n] (+ out): both operands K-major, as the forward pass left
     them (wgrad: a_km = dY [T,N_out], b_kn = X [T,K_in]).  bf16 operands go to the LDS-transpose-read kernel;
-    anything else (fp32 parity mode, unaligned strides) takes explicit transposes + the NT kernel."""
+    anything else (fp32 parity mode, unaligned strides) takes explicit transposes + the NT kernel.
+    asum: optional fp32 [M] accumulator, asum += asum_scale * column sums of a_km (the bias gradient)."""
     K, M = a_km.shape
     N = b_kn.shape[1]
     if _kmajor_ok(a_km) and _kmajor_ok(b_kn) and m_dev is None:
@@ -113,8 +115,10 @@ def gemm_tn(a_km, b_kn, out=None, out_dtype=None, accumulate=False, alpha=1.0, m
             out = torch.empty(M, N, dtype=out_dtype or a_km.dtype, device=a_km.device)
         assert out.stride(1) == 1
         call('tell_gemm_bf16', a_km, a_km.stride(0), 1, b_kn, b_kn.stride(0), 1, out, out.stride(0), M, N, K,
-             hip.dt(out), None, 0, 0, None, float(alpha), int(accumulate), None)
+             hip.dt(out), None, 0, 0, None, float(alpha), int(accumulate), None, asum, float(asum_scale))
         return out
+    if asum is not None:
+        colsum_into(a_km, asum, scale=asum_scale)
     at, _ = transpose(a_km)
     bt, _ = transpose(b_kn)
     return gemm(at, bt, out=out, out_dtype=out_dtype, accumulate=accumulate, alpha=alpha, m_dev=m_dev)
@@ -133,7 +137,7 @@ def gemm_nn(a, b_kn, b_t=None, out=None, out_dtype=None, alpha=1.0, act=0, aux=N
         if out is None:
             out = torch.empty(M, N, dtype=out_dtype or a.dtype, device=a.device)
         call('tell_gemm_bf16', a, a.stride(0), 0, b_kn, b_kn.stride(0), 1, out, out.stride(0), M, N, K,
-             hip.dt(out), None, 0, act, aux, float(alpha), 0, m_dev)
+             hip.dt(out), None, 0, act, aux, float(alpha), 0, m_dev, None, 0.0)
         return out
     bt = b_t() if b_t is not None else transpose(b_kn)[0]
     if bt.shape[1] != a.shape[1]:                       # bring both to one (zero padded) K width
@@ -267,16 +271,20 @@ class LinearFn(Function):
             call('tell_relu_bwd', dy2, y, d, dy2.numel(), hip.dt(dy2))
             dy2 = d
         r0, r1 = rows if rows is not None else (0, w_param.shape[0])
+        gb = None
+        if b_param is not None and b_param.requires_grad:
+            gb = grad_buffer(b_param)
+            gb = gb if b_rows is None else gb[b_rows[0]:b_rows[1]]
         if w_param.requires_grad:
             gw = grad_buffer(w_param)
             gw2 = gw.view(gw.shape[0], -1)[r0:r1]
             if x_t is not None:                      # fp32 parity mode: the caller shared one transpose of x
                 gemm(transpose(dy2)[0], x_t, out=gw2, alpha=alpha, accumulate=True)
-            else:
-                gemm_tn(dy2, x2, out=gw2, alpha=alpha, accumulate=True)
-        if b_param is not None and b_param.requires_grad:
-            gb = grad_buffer(b_param)
-            colsum_into(dy2, gb if b_rows is None else gb[b_rows[0]:b_rows[1]], scale=alpha)
+            else:                                    # the bias gradient rides on the wgrad GEMM's A tiles
+                gemm_tn(dy2, x2, out=gw2, alpha=alpha, accumulate=True, asum=gb, asum_scale=alpha)
+                gb = None
+        if gb is not None:
+            colsum_into(dy2, gb, scale=alpha)
         dx = None
         if need_dx:
             dx = gemm_nn(dy2, weight(w_param, rows), b_t=lambda: weight_t(w_param, rows), alpha=alpha)
@@ -312,12 +320,14 @@ class WNLinearFn(Function):
             call('tell_relu_bwd', dy2, y, d, dy2.numel(), hip.dt(dy2))
             dy2 = d
         w, norms = wn_weight(g, v)
+        gb = grad_buffer(b) if (b is not None and b.requires_grad) else None
         if v.requires_grad:
-            dW = gemm_tn(dy2, x2, out_dtype=torch.float32)
+            dW = gemm_tn(dy2, x2, out_dtype=torch.float32, asum=gb)
+            gb = None
             call('tell_wn_backward', dW, g.detach(), v.detach(), norms, v.shape[0], v.shape[1],
                  grad_buffer(g), grad_buffer(v))
-        if b is not None and b.requires_grad:
-            colsum_into(dy2, grad_buffer(b))
+        if gb is not None:
+            colsum_into(dy2, gb)
         dx = None
         if need_dx:
             dx = gemm_nn(dy2, w, b_t=lambda: wn_weight_t(g, v))
