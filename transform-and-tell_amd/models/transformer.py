@@ -7,7 +7,7 @@ from collections import defaultdict
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import graphs, ops
 from ..common.registrable import Registrable
 
 
@@ -66,6 +66,17 @@ class CaptionModel(Model):
         self.n_samples = 0
         self.sample_history = defaultdict(float)
 
+    def _run_resnet(self, image):
+        """The frozen trunk as one hipGraph replay per step (graphs.GraphedCall); eager for the first call."""
+        from .resnet import ResNetFeatureExtractor
+        if not isinstance(self.resnet, ResNetFeatureExtractor):      # a user-supplied trunk: no assumptions
+            return self.resnet(image)
+        g = self.__dict__.get('_resnet_graph')
+        if g is None:
+            g = self.__dict__['_resnet_graph'] = graphs.GraphedCall(self.resnet, 'resnet152')
+        w = self.resnet.conv1.weight                 # a reloaded / moved / re-typed trunk must not replay stale pointers
+        return g(image, key=(self.resnet.training, ops.rt.compute_dtype(), w._version, w.data_ptr()))
+
     # ---- :311-397 -----------------------------------------------------------------
     def _forward(self, context, image, caption, face_embeds=None, obj_embeds=None):
         dtype = ops.rt.compute_dtype()
@@ -90,11 +101,11 @@ class CaptionModel(Model):
             if side is not None:
                 side.wait_event(start)
                 with torch.cuda.stream(side), ops.hip.bound_stream():
-                    x_image = self.resnet(image)                           # [B,49,2048] (NHWC == :335-341)
+                    x_image = self._run_resnet(image)                      # [B,49,2048] (NHWC == :335-341)
                 main.wait_stream(side)
                 x_image.record_stream(main)
             else:
-                x_image = self.resnet(image)
+                x_image = self._run_resnet(image)
             B, P, _ = x_image.shape
         if self.weigh_bert:
             x_article = ops.mix_layers(stack, self.bert_weight)            # :355-364

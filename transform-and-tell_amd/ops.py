@@ -9,6 +9,7 @@ weight gradients *directly* into the parameter's fp32 gradient buffer
 large-model trainers; the Functions therefore return None for parameters.
 """
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -241,6 +242,76 @@ def wn_weight_t(g, v):
 
 
 # --------------------------------------------------------------------------- #
+# weight gradients on a second stream
+# --------------------------------------------------------------------------- #
+# The backward chain of the decoder (M = 512 rows) is a string of small, latency-bound kernels; the weight-
+# gradient GEMMs hang off it as leaves (only the optimizer reads their output).  They are issued on a side
+# stream, fill the idle CUs underneath the dgrad chain, and are joined back when the backward pass ends.
+# All writers of a Linear / GehringLinear gradient buffer go through here, so accumulations into a shared
+# buffer (row slices of in_proj_weight, several uses of one layer) stay ordered on that one stream.
+_WGRAD = {'enabled': os.environ.get('TELL_WGRAD_STREAM', '1') != '0', 'streams': {}, 'main': None, 'queue': [],
+          'hooked': False}
+_WGRAD_FLUSH = 6            # deferred jobs per hand-over (one event + one stream switch per batch, not per GEMM)
+
+
+def _flush_wgrad():
+    q = _WGRAD['queue']
+    if not q:
+        return
+    main = _WGRAD['main']
+    dev = main.device
+    side = _WGRAD['streams'].get(dev)
+    if side is None:
+        side = _WGRAD['streams'][dev] = torch.cuda.Stream(device=dev)
+    side.wait_stream(main)                          # every queued input was produced on `main` before now
+    with torch.cuda.stream(side), hip.bound_stream():
+        for job, keep in q:
+            job()
+            for t in keep:                          # inputs were allocated on `main`: keep them for `side`
+                if t is not None:
+                    t.record_stream(side)
+    _WGRAD['queue'] = []
+    _WGRAD['dirty'] = True
+
+
+def _join_wgrad():
+    _WGRAD['hooked'] = False
+    _flush_wgrad()
+    if _WGRAD.get('dirty'):
+        _WGRAD['dirty'] = False
+        main = _WGRAD['main']
+        main.wait_stream(_WGRAD['streams'][main.device])
+
+
+def wgrad_job(job, *inputs):
+    """Queue `job` (launches that write weight/bias gradient buffers from `inputs`) for the weight-gradient
+    stream; without a GPU side stream it runs in place."""
+    if not _WGRAD['enabled'] or not inputs[0].is_cuda:
+        job()
+        return
+    main = torch.cuda.current_stream(inputs[0].device)
+    if _WGRAD['main'] is not None and _WGRAD['main'] != main and (_WGRAD['queue'] or _WGRAD.get('dirty')):
+        _join_wgrad()                               # the caller switched streams: finish the old hand-over first
+    _WGRAD['main'] = main
+    _WGRAD['queue'].append((job, inputs))
+    if not _WGRAD['hooked']:
+        try:                                        # inside backward(): join when the engine finishes the pass
+            torch.autograd.Variable._execution_engine.queue_callback(_join_wgrad)
+            _WGRAD['hooked'] = True
+        except RuntimeError:                        # called outside a backward pass: run now, the caller joins
+            _flush_wgrad()
+            return
+    if len(_WGRAD['queue']) >= _WGRAD_FLUSH:
+        _flush_wgrad()
+
+
+def join_wgrad_stream():
+    """Make the producing stream wait for outstanding weight-gradient work (no-op if there is none)."""
+    if _WGRAD['main'] is not None:
+        _join_wgrad()
+
+
+# --------------------------------------------------------------------------- #
 # Linear layers
 # --------------------------------------------------------------------------- #
 class LinearFn(Function):
@@ -275,16 +346,19 @@ class LinearFn(Function):
         if b_param is not None and b_param.requires_grad:
             gb = grad_buffer(b_param)
             gb = gb if b_rows is None else gb[b_rows[0]:b_rows[1]]
-        if w_param.requires_grad:
-            gw = grad_buffer(w_param)
-            gw2 = gw.view(gw.shape[0], -1)[r0:r1]
-            if x_t is not None:                      # fp32 parity mode: the caller shared one transpose of x
-                gemm(transpose(dy2)[0], x_t, out=gw2, alpha=alpha, accumulate=True)
-            else:                                    # the bias gradient rides on the wgrad GEMM's A tiles
-                gemm_tn(dy2, x2, out=gw2, alpha=alpha, accumulate=True, asum=gb, asum_scale=alpha)
-                gb = None
-        if gb is not None:
-            colsum_into(dy2, gb, scale=alpha)
+        if w_param.requires_grad or gb is not None:
+            def job(gb=gb):
+                if w_param.requires_grad:
+                    gw = grad_buffer(w_param)
+                    gw2 = gw.view(gw.shape[0], -1)[r0:r1]
+                    if x_t is not None:              # fp32 parity mode: the caller shared one transpose of x
+                        gemm(transpose(dy2)[0], x_t, out=gw2, alpha=alpha, accumulate=True)
+                    else:                            # the bias gradient rides on the wgrad GEMM's A tiles
+                        gemm_tn(dy2, x2, out=gw2, alpha=alpha, accumulate=True, asum=gb, asum_scale=alpha)
+                        gb = None
+                if gb is not None:
+                    colsum_into(dy2, gb, scale=alpha)
+            wgrad_job(job, dy2, x2, x_t)
         dx = None
         if need_dx:
             dx = gemm_nn(dy2, weight(w_param, rows), b_t=lambda: weight_t(w_param, rows), alpha=alpha)
@@ -321,13 +395,16 @@ class WNLinearFn(Function):
             dy2 = d
         w, norms = wn_weight(g, v)
         gb = grad_buffer(b) if (b is not None and b.requires_grad) else None
-        if v.requires_grad:
-            dW = gemm_tn(dy2, x2, out_dtype=torch.float32, asum=gb)
-            gb = None
-            call('tell_wn_backward', dW, g.detach(), v.detach(), norms, v.shape[0], v.shape[1],
-                 grad_buffer(g), grad_buffer(v))
-        if gb is not None:
-            colsum_into(dy2, gb)
+        if v.requires_grad or gb is not None:
+            def job(gb=gb):
+                if v.requires_grad:
+                    dW = gemm_tn(dy2, x2, out_dtype=torch.float32, asum=gb)
+                    gb = None
+                    call('tell_wn_backward', dW, g.detach(), v.detach(), norms, v.shape[0], v.shape[1],
+                         grad_buffer(g), grad_buffer(v))
+                if gb is not None:
+                    colsum_into(dy2, gb)
+            wgrad_job(job, dy2, x2)
         dx = None
         if need_dx:
             dx = gemm_nn(dy2, w, b_t=lambda: wn_weight_t(g, v))

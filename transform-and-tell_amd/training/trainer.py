@@ -12,7 +12,7 @@ backward, then gradients are averaged.  Ranks that see no target of a tail clust
 contribute zeros: the flat buffer is always reduced as a whole."""
 import torch
 
-from .. import hip
+from .. import hip, ops
 from .. import runtime as rt
 from ..common.registrable import Registrable
 from . import dp
@@ -67,6 +67,7 @@ class Trainer:
             if bad.item() > 0:
                 return None
         scaled.backward()                                                # :229-231
+        ops.join_wgrad_stream()                                          # weight-gradient side stream (ops.py)
         if self.world > 1:
             self._all_reduce_grads()
         self.optimizer.step(grad_scale=1.0 / self.world)                 # :238
