@@ -112,6 +112,7 @@ def main():
     loss = None
     for i in range(args.steps):
         loss = trainer.train_one_batch(fresh(batches[i % 2]))
+    issued = time.perf_counter() - t0           # host finished issuing; the rest of `elapsed` is GPU backlog
     sync()
     elapsed = time.perf_counter() - t0
     prof_summary = prof.summary() if not args.no_roofline else {}
@@ -128,6 +129,7 @@ def main():
             'metric': 'training samples/sec (img+article->caption)', 'value': round(value, 2),
             'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'host_issue_ms_per_step': round(1e3 * issued / args.steps, 3),
             'dtype': args.dtype, 'data': 'synthetic (random pixels, random BPE ids; random-init weights)',
             'config': {'workload': 'BASELINE configs[1]: 4-layer DynamicConv decoder (2 contexts: ResNet-152 '
                                    'image regions + RoBERTa-large article), batch %d/GPU, 512-token articles, '

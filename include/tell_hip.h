@@ -180,7 +180,18 @@ int tell_bertadam_step(float* param, const float* grad, float* m, float* v, cons
 int tell_nchw_to_nhwc(const float* x, void* y, int B, int C, int H, int W, int out_dtype, tell_stream_t stream);
 int tell_im2col(const void* x, void* col, int B, int H, int W, int Cin, int KH, int KW, int stride, int pad,
                 int OH, int OW, int Kp, int dtype, tell_stream_t stream);
+/* im2col of y = relu(BatchNorm(x)): the producer's normalisation is applied while gathering (resnet.py Bottleneck:
+ * conv1 -> bn1 -> relu -> conv2); padding taps are zeros of the post-activation tensor. */
+int tell_im2col_bn(const void* x, void* col, int B, int H, int W, int Cin, int KH, int KW, int stride, int pad,
+                   int OH, int OW, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                   int relu, int dtype, tell_stream_t stream);
 long tell_bn_chunks(long M);
+/* conv (as GEMM over NHWC rows) + the batch statistics of the BatchNorm2d that follows it, in one pass: the GEMM
+ * epilogue reduces each output tile's columns, a small second kernel combines the tiles (resnet.py:94-108 with
+ * the trunk in train mode).  bf16 only; workspace: 2 * ceil(M/64) * N floats. */
+int tell_gemm_bn_stats(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                       float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                       float* running_var, float* workspace, tell_stream_t stream);
 int tell_bn_stats(const void* x, long M, int C, float eps, float momentum, float* mean, float* invstd,
                   float* running_mean, float* running_var, float* workspace, int dtype, tell_stream_t stream);
 int tell_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,

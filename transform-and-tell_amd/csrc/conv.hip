@@ -77,6 +77,61 @@ __global__ __launch_bounds__(256) void im2col_vec_kernel(const T* __restrict__ x
   }
 }
 
+// Same gather, but every element first goes through the producer's BatchNorm (+ReLU): the normalised activation
+// of a conv -> BN -> ReLU -> 3x3 conv chain is never written to HBM.  Padding taps stay exact zeros (the padding
+// belongs to the post-activation tensor).
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_bn_vec_kernel(const T* __restrict__ x, T* __restrict__ col, int B, int H,
+                                                            int W, int Cin, int KH, int KW, int stride, int pad,
+                                                            int OH, int OW, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int relu) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cpk = Cin / VEC;
+  const long M = (long)B * OH * OW;
+  const long n = M * KH * KW * cpk;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cpk);
+    long r = i / cpk;
+    const int kw = (int)(r % KW); r /= KW;
+    const int kh = (int)(r % KH); r /= KH;
+    const long m = r;
+    const int ow = (int)(m % OW);
+    const long r2 = m / OW;
+    const int oh = (int)(r2 % OH), b = (int)(r2 / OH);
+    const int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
+    uint4 out = make_uint4(0, 0, 0, 0);
+    if (ih >= 0 && ih < H && iw >= 0 && iw < W) {
+      float v[VEC];
+      unpack16(*reinterpret_cast<const uint4*>(x + (((long)b * H + ih) * W + iw) * Cin + cc * VEC), v, (const T*)nullptr);
+      const int c0 = cc * VEC;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const float o = (v[k] - mean[c0 + k]) * invstd[c0 + k] * gamma[c0 + k] + beta[c0 + k];
+        v[k] = relu ? fmaxf(o, 0.f) : o;
+      }
+      out = pack16(v, (const T*)nullptr);
+    }
+    *reinterpret_cast<uint4*>(col + i * VEC) = out;
+  }
+}
+// requires Cin % (16 bytes / element) == 0 and an unpadded K (every 3x3 conv of the trunk)
+extern "C" int tell_im2col_bn(const void* x, void* col, int B, int H, int W, int Cin, int KH, int KW, int stride,
+                              int pad, int OH, int OW, const float* mean, const float* invstd, const float* gamma,
+                              const float* beta, int relu, int dtype, hipStream_t stream) {
+  const int vec = dtype == TELL_BF16 ? 8 : 4;
+  long n = (long)B * OH * OW * KH * KW * Cin;
+  if (n <= 0) return TELL_OK;
+  TELL_REQUIRE(Cin % vec == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)col & 15) == 0,
+               "im2col_bn: Cin must be a multiple of one 16-byte chunk and the buffers 16-byte aligned");
+  long nv = n / vec;
+  int gv = (int)((nv + 255) / 256 > 16384 ? 16384 : (nv + 255) / 256);
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((im2col_bn_vec_kernel<uint16_t>), dim3(gv), dim3(256), 0, stream, (const uint16_t*)x, (uint16_t*)col, B, H, W, Cin, KH, KW, stride, pad, OH, OW, mean, invstd, gamma, beta, relu);
+  else hipLaunchKernelGGL((im2col_bn_vec_kernel<float>), dim3(gv), dim3(256), 0, stream, (const float*)x, (float*)col, B, H, W, Cin, KH, KW, stride, pad, OH, OW, mean, invstd, gamma, beta, relu);
+  return tell_check_launch("im2col_bn");
+}
+
 extern "C" int tell_im2col(const void* x, void* col, int B, int H, int W, int Cin, int KH, int KW, int stride,
                            int pad, int OH, int OW, int Kp, int dtype, hipStream_t stream) {
   long n = (long)B * OH * OW * Kp;
@@ -205,6 +260,13 @@ __global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict_
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
     }
   }
+}
+int tell_bn_finish_launch(const float* pmean, const float* pm2, long M, int C, int n_chunks, int rows_per_chunk,
+                          float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                          float* running_var, hipStream_t stream) {
+  hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, pmean, pm2, M, C, n_chunks,
+                     rows_per_chunk, eps, momentum, mean, invstd, running_mean, running_var);
+  return tell_check_launch("bn_finish");
 }
 static inline int bn_rows_per_chunk(long M) {
   long r = (M + 255) / 256;                   // ~256 row chunks -> enough workgroups for every layer shape

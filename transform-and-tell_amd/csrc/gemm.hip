@@ -33,6 +33,8 @@ struct GemmArgs {
   int dbg;                // tuning aid (TELL_GEMM_DEBUG): 1 = skip the epilogue, 2 = one K step only
   float* asum;            // K-major A only: asum[m] += asum_scale * sum_k A[k][m]  (bias gradient of a wgrad GEMM)
   float asum_scale;
+  float* stat_mean;       // bf16 NT kernels: per (m-tile, column) mean / M2 of the STORED (bf16-rounded) outputs over
+  float* stat_m2;         //   the tile's valid rows, [tiles_m][N] each - the first stage of train-mode BatchNorm
 };
 
 template <typename T> struct Mma;
@@ -244,6 +246,71 @@ __device__ __forceinline__ bool glds_fast_tile(const GemmArgs& p, int m0, int n0
          (p.bias_mode != 1 || ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0 && (n0 & 3) == 0));
 }
 
+// Epilogue of a convolution GEMM that feeds a train-mode BatchNorm: the bf16 tile is staged in LDS (cs: BM rows
+// of BN+8 elements, then NT floats of scratch), leaves as 16-byte row chunks, and every column's mean / M2 over
+// the tile's valid rows is taken from the staged (already rounded) values - the statistics pass over the
+// activation in HBM disappears.  Handles ragged last tiles (rows >= M, columns >= N are skipped).
+template <int BM, int BN, int WM, int WN, int MI, int NI, int NT>
+__device__ __forceinline__ void staged_store_stats(f32x16 (&acc)[MI][NI], const GemmArgs& p, int m0, int n0, int tm,
+                                                   int wm, int wn, int lane, int tid, uint16_t* cs, int M, int N) {
+  constexpr int CS = BN + 8, CPRW = BN / 8, G = NT / BN;
+  static_assert(NT % BN == 0, "row groups");
+  float* red = reinterpret_cast<float*>(cs + BM * CS);
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int row = wm * WM + i * 32 + (lane & 31);
+    const float bm = (p.bias_mode == 2 && m0 + row < M) ? p.bias[m0 + row] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = wn * WN + j * 32 + 8 * g + 4 * (lane >> 5);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float b = (p.bias_mode == 1 && n0 + col + e < N) ? p.bias[n0 + col + e] : 0.f;
+          v[e] = (acc[i][j][4 * g + e] + b + bm) * p.alpha;
+        }
+        u32x2 w = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(cs + row * CS + col) = w;
+      }
+  }
+  __syncthreads();
+  uint16_t* C = static_cast<uint16_t*>(p.C);
+#pragma unroll
+  for (int i = 0; i < BM * CPRW / NT; ++i) {
+    const int c = tid + i * NT, row = c / CPRW, ch = c % CPRW;
+    if (m0 + row < M && n0 + ch * 8 < N)
+      *reinterpret_cast<u32x4*>(C + (long)(m0 + row) * p.ldc + n0 + ch * 8) =
+          *reinterpret_cast<const u32x4*>(cs + row * CS + ch * 8);
+  }
+  const int c = tid % BN, rg = tid / BN;
+  const int rows = M - m0 < BM ? M - m0 : BM;
+  float s = 0.f;
+  for (int r = rg; r < rows; r += G) s += __uint_as_float((unsigned)cs[r * CS + c] << 16);
+  red[rg * BN + c] = s;
+  __syncthreads();
+  float mean = 0.f;
+#pragma unroll
+  for (int g = 0; g < G; ++g) mean += red[g * BN + c];
+  mean /= (float)rows;
+  __syncthreads();
+  float q = 0.f;
+  for (int r = rg; r < rows; r += G) {
+    const float d = __uint_as_float((unsigned)cs[r * CS + c] << 16) - mean;
+    q += d * d;
+  }
+  red[rg * BN + c] = q;
+  __syncthreads();
+  if (rg == 0 && n0 + c < N) {
+    float m2 = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) m2 += red[g * BN + c];
+    p.stat_mean[(long)tm * N + n0 + c] = mean;
+    p.stat_m2[(long)tm * N + n0 + c] = m2;
+  }
+}
+
 // ------------------------------------------------------------- direct-to-LDS kernel (bf16, K % 64 == 0)
 // global_load_lds_dwordx4: every lane's 16 bytes go straight from L2/HBM into LDS (no VGPR staging, no
 // ds_write), the next K tile streams into the other LDS buffer while the MFMAs run on the current one.
@@ -371,6 +438,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(Ge
     __syncthreads();                                     // everyone's have, and buffer `st` is free again
   }
   // ---- epilogue.  Full interior bf16 tiles go through LDS (the tile buffers are free now).
+  if constexpr (sizeof(OutT) == 2 && BM * (BN + 8) * 2 + 64 * NW * 4 <= 2 * STAGE) {
+    if (p.stat_mean) {                                   // block-uniform: conv + BatchNorm statistics
+      staged_store_stats<BM, BN, WM, WN, MI, NI, 64 * NW>(acc, p, m0, n0, tm, wm, wn, lane, tid,
+                                                          reinterpret_cast<uint16_t*>(smem), M, N);
+      return;
+    }
+  }
   if constexpr (sizeof(OutT) == 2) {
     constexpr int CS = (BM * (BN + 8) * 2 <= 2 * STAGE) ? BN + 8 : BN;   // padded row (elements) when it fits
     static_assert(BM * CS * 2 <= 2 * STAGE, "output tile must fit the freed tile buffers");
@@ -674,6 +748,14 @@ void gemm_nt_kernel(GemmArgs p) {
 #undef GLOAD
 #undef SSTORE
 
+  if constexpr (sizeof(T) == 2 && sizeof(OutT) == 2) {
+    static_assert(BM * (BN + 8) * 2 + NT * 4 <= (int)sizeof(As), "staged epilogue must fit the A tile buffers");
+    if (p.stat_mean) {                                   // block-uniform; the last loop barrier freed As
+      staged_store_stats<BM, BN, WM, WN, MI, NI, NT>(acc, p, m0, n0, tm, wm, wn, lane, tid,
+                                                     reinterpret_cast<uint16_t*>(&As[0][0]), M, N);
+      return;
+    }
+  }
   gemm_epilogue<OutT, MI, NI>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, M, N);
 }
 
@@ -870,7 +952,9 @@ static int launch_gemm_tx(const GemmArgs& a, hipStream_t stream) {
 }
 
 template <typename T, typename OutT>
-static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
+static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nullptr) {
+  int bm_dummy;
+  if (!bm_used) bm_used = &bm_dummy;
   // Tile choice: the kernel is bound by operand re-reads from L2 (flop/byte of a tile =
   // BM*BN/(BM+BN) per 2-byte element), so take the largest tile that still gives every CU work.
   auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
@@ -888,6 +972,13 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL((gemm_nt_glds_kernel<OutT, 256, 256, 2, 4>), dim3((unsigned)tiles(256, 256)), dim3(512), 0, stream, a);
         return tell_check_launch("gemm_nt_glds");
       }
+      // 256x256 (8 waves, 1 workgroup/CU) wins when its tiles fill the chip in whole rounds and K is short
+      // (M8192 N4096 K1024: 889 vs 820 TFLOP/s); partial rounds or few tiles lose to 128x128
+      *bm_used = 128;
+      if (force == 0 && tiles(256, 256) % n_cu == 0 && a.K <= 2048 && !a.accumulate && !a.stat_mean) {
+        hipLaunchKernelGGL((gemm_nt_glds_kernel<OutT, 256, 256, 2, 4>), dim3((unsigned)tiles(256, 256)), dim3(512), 0, stream, a);
+        return tell_check_launch("gemm_nt_glds");
+      }
       if (force == 2)     // 256x128 (8 waves, 1 workgroup/CU) ties 128x128 (2 workgroups/CU) on MI355X: opt-in only
         hipLaunchKernelGGL((gemm_nt_glds_kernel<OutT, 256, 128, 4, 2>), dim3((unsigned)tiles(256, 128)), dim3(512), 0, stream, a);
       else
@@ -897,6 +988,7 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   }
   // (a 256x256 register-staged tile measured slower than 256x128 - 236 VGPRs, one workgroup per CU - and
   //  was removed)
+  *bm_used = (sizeof(T) == 2 && tiles(256, 128) >= 256) ? 256 : tiles(128, 128) >= 256 ? 128 : 64;
   if (sizeof(T) == 2 && tiles(256, 128) >= 256) {
     hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, 256, 128, 4, 2, 2>), dim3((unsigned)tiles(256, 128)), dim3(512), 0, stream, a);
   } else if (tiles(128, 128) >= 256) {
@@ -927,7 +1019,7 @@ extern "C" int tell_gemm_nt(const void* A, long lda, const void* B, long ldb, vo
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
   a.bias_mode = bias_mode; a.act = act; a.accumulate = accumulate; a.alpha = alpha;
   static const int dbg = getenv("TELL_GEMM_DEBUG") ? atoi(getenv("TELL_GEMM_DEBUG")) : 0;
-  a.dbg = dbg; a.asum = nullptr; a.asum_scale = 0.f;
+  a.dbg = dbg; a.asum = nullptr; a.asum_scale = 0.f; a.stat_mean = nullptr; a.stat_m2 = nullptr;
   if (in_dtype == TELL_BF16)
     return out_dtype == TELL_BF16 ? launch_gemm<uint16_t, uint16_t>(a, stream)
                                   : launch_gemm<uint16_t, float>(a, stream);
@@ -961,10 +1053,38 @@ extern "C" int tell_gemm_bf16(const void* A, long lda, int trans_a, const void* 
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux; a.m_dev = m_dev;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
   a.bias_mode = bias_mode; a.act = act; a.accumulate = accumulate; a.alpha = alpha; a.dbg = 0;
-  a.asum = a_colsum; a.asum_scale = a_colsum_scale;
+  a.asum = a_colsum; a.asum_scale = a_colsum_scale; a.stat_mean = nullptr; a.stat_m2 = nullptr;
   if (trans_a && trans_b)
     return out_dtype == TELL_BF16 ? launch_gemm_tx<uint16_t, true, true>(a, stream) : launch_gemm_tx<float, true, true>(a, stream);
   if (trans_b)
     return out_dtype == TELL_BF16 ? launch_gemm_tx<uint16_t, false, true>(a, stream) : launch_gemm_tx<float, false, true>(a, stream);
   return out_dtype == TELL_BF16 ? launch_gemm_tx<uint16_t, true, false>(a, stream) : launch_gemm_tx<float, true, false>(a, stream);
+}
+
+int tell_bn_finish_launch(const float* pmean, const float* pm2, long M, int C, int n_chunks, int rows_per_chunk,
+                          float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                          float* running_var, hipStream_t stream);   // conv.hip
+
+// y[M,N] = A[M,K] . B[N,K]^T (bf16, stored), and the train-mode BatchNorm statistics of y's columns in the same
+// pass: mean[N], invstd[N] (+ running stats update).  workspace: 2 * ceil(M/64) * N floats.
+extern "C" int tell_gemm_bn_stats(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,
+                                  int K, float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                                  float* running_var, float* workspace, hipStream_t stream) {
+  TELL_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_bn_stats: bad dimension");
+  TELL_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && N % 8 == 0 && ldc % 8 == 0,
+               "gemm_bn_stats: K, N and the row strides must be multiples of 8 elements");
+  TELL_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)C & 15) == 0,
+               "gemm_bn_stats: A/B/C must be 16-byte aligned");
+  GemmArgs a;
+  a.A = A; a.B = B; a.C = C; a.bias = nullptr; a.aux = nullptr; a.m_dev = nullptr;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+  a.bias_mode = 0; a.act = 0; a.accumulate = 0; a.alpha = 1.f; a.dbg = 0; a.asum = nullptr; a.asum_scale = 0.f;
+  const long max_tiles = ((long)M + 63) / 64;
+  a.stat_mean = workspace;
+  a.stat_m2 = workspace + max_tiles * N;
+  int bm = 64;
+  int rc = launch_gemm<uint16_t, uint16_t>(a, stream, &bm);
+  if (rc) return rc;
+  return tell_bn_finish_launch(a.stat_mean, a.stat_m2, M, N, (M + bm - 1) / bm, bm, eps, momentum, mean, invstd,
+                               running_mean, running_var, stream);
 }

@@ -54,36 +54,72 @@ class _Conv(nn.Module):
 _BN_WS = {}
 
 
-def conv_bn_act(x, B, H, W, conv, bn, relu, residual, training):
-    """x: [B*H*W, Cin] NHWC rows -> ([B*OH*OW, Cout], OH, OW) with BN (+residual) (+ReLU) applied."""
+def _stat_buffers(device, need_ws, C):
+    """(workspace, [two (mean, invstd) slots]) - stream-ordered reuse across layers; two slots because a
+    BatchNorm whose apply is deferred into the next conv's im2col is still live while that conv's own
+    statistics are produced."""
+    buf = _BN_WS.get(device)
+    if buf is None or buf[0].numel() < need_ws or buf[1].numel() < 4 * C:
+        buf = (torch.empty(max(need_ws, 1 << 20), dtype=torch.float32, device=device),
+               torch.empty(4 * max(C, 4096), dtype=torch.float32, device=device))
+        _BN_WS[device] = buf
+    cap = buf[1].numel() // 4
+    return buf[0], [(buf[1][2 * s * cap:2 * s * cap + C], buf[1][(2 * s + 1) * cap:(2 * s + 1) * cap + C])
+                    for s in range(2)]
+
+
+def conv_stats(x, B, H, W, conv, bn, training, pre=None, slot=0):
+    """The convolution + the statistics of its BatchNorm, NOT yet applied.
+    x: [B*H*W, Cin] NHWC rows.  pre: (mean, invstd, bn_module) of a producer BatchNorm(+ReLU) to apply while
+    gathering (3x3 convs only).  -> (raw y [B*OH*OW, Cout], OH, OW, mean, invstd)."""
     k, s, p = conv.k, conv.stride, conv.padding
     OH = (H + 2 * p - k) // s + 1
     OW = (W + 2 * p - k) // s + 1
     wq = conv.gemm_weight()
     dtype = x.dtype
     if k == 1 and s == 1:
+        assert pre is None
         a = x
     else:
         a = torch.empty(B * OH * OW, wq.shape[1], dtype=dtype, device=x.device)
-        call('tell_im2col', x, a, B, H, W, conv.cin, k, k, s, p, OH, OW, wq.shape[1], hip.dt(dtype))
-    y = ops.gemm(a, wq)
-    M, C = y.shape
+        if pre is not None:
+            pm, pi, pbn = pre
+            call('tell_im2col_bn', x, a, B, H, W, conv.cin, k, k, s, p, OH, OW, pm, pi, pbn.weight.detach(),
+                 pbn.bias.detach(), 1, hip.dt(dtype))
+        else:
+            call('tell_im2col', x, a, B, H, W, conv.cin, k, k, s, p, OH, OW, wq.shape[1], hip.dt(dtype))
+    M, C = a.shape[0], wq.shape[0]
     if training:
-        need = 2 * hip.lib().tell_bn_chunks(M) * C
-        buf = _BN_WS.get(x.device)
-        if buf is None or buf[0].numel() < need or buf[1].numel() < 2 * C:
-            buf = (torch.empty(max(need, 1 << 20), dtype=torch.float32, device=x.device),
-                   torch.empty(2 * max(C, 4096), dtype=torch.float32, device=x.device))
-            _BN_WS[x.device] = buf
-        ws, mean, invstd = buf[0], buf[1][:C], buf[1][C:2 * C]      # stream-ordered reuse across layers
-        call('tell_bn_stats', y, M, C, bn.eps, bn.momentum, mean, invstd, bn.running_mean, bn.running_var, ws,
-             hip.dt(dtype))
+        fused = dtype == torch.bfloat16 and C % 8 == 0        # statistics come out of the GEMM epilogue
+        need = 2 * ((M + 63) // 64) * C if fused else 2 * hip.lib().tell_bn_chunks(M) * C
+        ws, slots = _stat_buffers(x.device, need, C)
+        mean, invstd = slots[slot]
+        if fused:
+            y = torch.empty(M, C, dtype=dtype, device=x.device)
+            call('tell_gemm_bn_stats', a, a.stride(0), wq, wq.stride(0), y, y.stride(0), M, C, a.shape[1], bn.eps,
+                 bn.momentum, mean, invstd, bn.running_mean, bn.running_var, ws)
+        else:
+            y = ops.gemm(a, wq)
+            call('tell_bn_stats', y, M, C, bn.eps, bn.momentum, mean, invstd, bn.running_mean, bn.running_var, ws,
+                 hip.dt(dtype))
     else:
+        y = ops.gemm(a, wq)
         mean = bn.running_mean
         invstd = ops._cached(bn.running_var, ('invstd',), lambda: torch.rsqrt(bn.running_var + bn.eps))
+    return y, OH, OW, mean, invstd
+
+
+def bn_apply(y, mean, invstd, bn, relu, residual=None):
+    M, C = y.shape
     call('tell_bn_apply', y, mean, invstd, bn.weight.detach(), bn.bias.detach(), residual, y, M, C, int(relu),
-         hip.dt(dtype))
-    return y, OH, OW
+         hip.dt(y.dtype))
+    return y
+
+
+def conv_bn_act(x, B, H, W, conv, bn, relu, residual, training):
+    """x: [B*H*W, Cin] NHWC rows -> ([B*OH*OW, Cout], OH, OW) with BN (+residual) (+ReLU) applied."""
+    y, OH, OW, mean, invstd = conv_stats(x, B, H, W, conv, bn, training)
+    return bn_apply(y, mean, invstd, bn, relu, residual), OH, OW
 
 
 class Bottleneck(nn.Module):
@@ -103,8 +139,15 @@ class Bottleneck(nn.Module):
         idt = x
         if self.downsample is not None:
             idt, _, _ = conv_bn_act(x, B, H, W, self.downsample[0], self.downsample[1], False, None, training)
-        y, _, _ = conv_bn_act(x, B, H, W, self.conv1, self.bn1, True, None, training)
-        y, OH, OW = conv_bn_act(y, B, H, W, self.conv2, self.bn2, True, None, training)
+        vec = 8 if x.dtype == torch.bfloat16 else 4
+        if self.conv2.cin % vec == 0:
+            # bn1 + ReLU are applied inside conv2's im2col gather: conv1's raw output is the only copy in HBM
+            y1, _, _, m1, i1 = conv_stats(x, B, H, W, self.conv1, self.bn1, training, slot=0)
+            y, OH, OW, m2, i2 = conv_stats(y1, B, H, W, self.conv2, self.bn2, training, pre=(m1, i1, self.bn1), slot=1)
+            y = bn_apply(y, m2, i2, self.bn2, True)
+        else:
+            y, _, _ = conv_bn_act(x, B, H, W, self.conv1, self.bn1, True, None, training)
+            y, OH, OW = conv_bn_act(y, B, H, W, self.conv2, self.bn2, True, None, training)
         y, _, _ = conv_bn_act(y, B, OH, OW, self.conv3, self.bn3, True, idt, training)
         return y, OH, OW
 

@@ -107,6 +107,7 @@ class CaptionModel(Model):
             else:
                 x_image = self._run_resnet(image)
             B, P, _ = x_image.shape
+        ops.rt.wait_weight_update()      # everything below reads trainable weights (the encoders above do not)
         if self.weigh_bert:
             x_article = ops.mix_layers(stack, self.bert_weight)            # :355-364
         else:

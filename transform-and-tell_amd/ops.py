@@ -82,7 +82,8 @@ def gemm(a, b, out=None, out_dtype=None, bias=None, bias_mode=0, act=0, aux=None
         bf = hip.dt(a) == hip.BF16                                                 # mirrors launch_gemm()
         names = ('f32', 'bf16')[hip.dt(a)], ('f32', 'bf16')[hip.dt(out)]
         if bf and a.shape[1] % 64 == 0 and tiles(128, 128) >= 256:
-            tile = (128, 128)
+            n_cu = torch.cuda.get_device_properties(a.device).multi_processor_count
+            tile = (256, 256) if (tiles(256, 256) % n_cu == 0 and a.shape[1] <= 2048 and not accumulate) else (128, 128)
             kname = 'gemm_nt_glds_kernel<%s,%d,%d>' % (names[1], tile[0], tile[1])
         else:
             tile = ((256, 128) if bf and tiles(256, 128) >= 256 else (128, 128) if tiles(128, 128) >= 256
@@ -195,6 +196,8 @@ def _cached(p, key, maker):
     # trainable masters are rewritten by the optimizer kernel (which bypasses torch's version counter) ->
     # keyed on the weights epoch; frozen tensors (encoders, buffers) only change through torch ops
     epoch = rt.weights_epoch() if p.requires_grad else -1
+    if p.requires_grad:
+        rt.wait_weight_update()          # an optimizer step may still be in flight on the update stream
     stamp = (epoch, rt.compute_dtype(), p._version, p.data_ptr())
     e = _wcache.get(k)
     if e is None or e[0] != stamp:

@@ -43,3 +43,23 @@ def weights_epoch():
 
 def bump_weights_epoch():
     _state['epoch'] += 1
+
+
+# --------------------------------------------------------------------------- #
+# asynchronous weight update
+# --------------------------------------------------------------------------- #
+# The trainer runs gradient all-reduce + optimizer + gradient zeroing on its own stream so that they overlap
+# the NEXT step's frozen encoders (which read no trainable weight).  Whoever is about to read a trainable
+# weight on another stream calls wait_weight_update() first.
+_pending_update = [None]
+
+
+def set_pending_update(event):
+    _pending_update[0] = event
+
+
+def wait_weight_update():
+    ev = _pending_update[0]
+    if ev is not None:
+        _pending_update[0] = None
+        torch.cuda.current_stream().wait_event(ev)

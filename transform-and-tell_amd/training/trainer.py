@@ -10,6 +10,8 @@ DP equivalence with a single-GPU run on the concatenated batch: every rank's los
 re-weighted by n_local*world/n_global (token counts all-reduced on the device) before
 backward, then gradients are averaged.  Ranks that see no target of a tail cluster still
 contribute zeros: the flat buffer is always reduced as a whole."""
+import os
+
 import torch
 
 from .. import hip, ops
@@ -25,7 +27,7 @@ class TrainerBase(Registrable):
 
 class Trainer:
     def __init__(self, model, optimizer_cfg=None, no_grad=(r'^resnet', r'^roberta'), device='cuda',
-                 nan_check=False, bucket_mb=256):
+                 nan_check=False, bucket_mb=256, async_update=None):
         import torch.distributed as dist
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.world = self.dist.get_world_size() if self.dist else 1
@@ -44,6 +46,18 @@ class Trainer:
         if self.world > 1:                    # identical initial weights on every rank
             self.dist.broadcast(self.flat.flat, src=0)
             rt.bump_weights_epoch()
+        # gradient all-reduce + BertAdam + gradient zeroing run on this stream, underneath the next step's
+        # frozen encoders; the model waits for it right before its first trainable weight (rt.wait_weight_update)
+        if async_update is None:
+            async_update = os.environ.get('TELL_ASYNC_UPDATE', '1') != '0'
+        self.async_update = async_update and torch.device(device).type == 'cuda'
+        self.update_stream = torch.cuda.Stream(device=device) if self.async_update else None
+        self.flat.zero_grad()
+        self.model.register_state_dict_pre_hook(lambda *a, **k: self.finish_update())
+
+    def finish_update(self):
+        """Make the current stream wait for an in-flight weight update (checkpointing, evaluation, ...)."""
+        rt.wait_weight_update()
 
     def train_one_batch(self, batch):
         """callback_apex_trainer.py:208-247 for one batch; returns the (detached) loss tensor."""
@@ -51,8 +65,7 @@ class Trainer:
             return self._train_one_batch(batch)
 
     def _train_one_batch(self, batch):
-        self.model.train()
-        self.flat.zero_grad()                                            # :214
+        self.model.train()                       # (:214 zero_grad: done right after the previous update)
         out = self.model(**batch)                                        # :220 / :194
         loss = out['loss']
         if self.world > 1:
@@ -68,11 +81,24 @@ class Trainer:
                 return None
         scaled.backward()                                                # :229-231
         ops.join_wgrad_stream()                                          # weight-gradient side stream (ops.py)
+        if self.async_update:
+            main = torch.cuda.current_stream()
+            self.update_stream.wait_stream(main)
+            with torch.cuda.stream(self.update_stream), hip.bound_stream():
+                self._update()
+                done = torch.cuda.Event()
+                done.record(self.update_stream)
+            rt.set_pending_update(done)
+        else:
+            self._update()
+        self.batch_num_total += 1
+        return loss.detach()
+
+    def _update(self):
         if self.world > 1:
             self._all_reduce_grads()
         self.optimizer.step(grad_scale=1.0 / self.world)                 # :238
-        self.batch_num_total += 1
-        return loss.detach()
+        self.flat.zero_grad()                                            # :214 of the next batch
 
     def _all_reduce_grads(self):
         dp.all_reduce_flat(self.flat.grad, self.dist, self.bucket_elems)
