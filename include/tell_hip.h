@@ -73,6 +73,9 @@ int tell_transpose(const void* src, long ld_src, int src_dtype, void* dst_t, lon
 /* weight norm, tell/modules/linear.py:33 (torch weight_norm dim=0): scale[r] = g[r]/||v[r]||, norms[r] = ||v[r]|| */
 int tell_wn_rowscale(const float* g, const float* v, int rows, int cols, float* scale, float* norms,
                      tell_stream_t stream);
+/* the whole working weight in one pass: w[r,:] = g[r] * v[r,:] / ||v[r,:]|| (bf16 or fp32) and norms[r] */
+int tell_wn_weight(const float* g, const float* v, int rows, int cols, void* w, int out_dtype, float* norms,
+                   tell_stream_t stream);
 int tell_wn_backward(const float* dW, const float* g, const float* v, const float* norms, int rows, int cols,
                      float* dg, float* dv, tell_stream_t stream);
 
@@ -171,10 +174,12 @@ int tell_adaptive_logprob_argmax(const float* head, long ld_head, int c0, int n_
 
 /* ---- BertAdam (config.yaml:126-149), flat fp32 buffers, tensors CHUNK-aligned */
 int tell_opt_chunk(void);
-int tell_bertadam_step(float* param, const float* grad, float* m, float* v, const int* chunk_tensor,
+/* shadow_bf16 (may be NULL): bf16 copy of the updated parameters, same flat layout - the working weights of the
+ * next forward; zero_grad: clear the gradient buffer in the same pass (callback_apex_trainer.py:214). */
+int tell_bertadam_step(float* param, float* grad, float* m, float* v, const int* chunk_tensor,
                        const long* chunk_begin, long n_chunks, int n_tensors, float* partial, float* norms,
                        const float* lr_dev, float b1, float b2, float eps, float wd, float max_norm,
-                       float grad_scale, tell_stream_t stream);
+                       float grad_scale, void* shadow_bf16, int zero_grad, tell_stream_t stream);
 
 /* ---- ResNet-152 trunk helpers, tell/models/resnet.py:92-108 (NHWC) ----------- */
 int tell_nchw_to_nhwc(const float* x, void* y, int B, int C, int H, int W, int out_dtype, tell_stream_t stream);

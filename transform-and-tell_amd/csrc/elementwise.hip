@@ -108,6 +108,55 @@ extern "C" int tell_wn_rowscale(const float* g, const float* v, int rows, int co
   return tell_check_launch("wn_rowscale");
 }
 
+// Working weight of a GehringLinear in ONE pass: w[r,:] = (g[r] / ||v[r,:]||) * v[r,:] in the compute dtype, plus
+// norms[r] = ||v[r,:]|| for the backward.  One wave per row; the second sweep over the row hits L2.
+template <typename OutT>
+__global__ __launch_bounds__(256) void wn_weight_kernel(const float* __restrict__ g, const float* __restrict__ v,
+                                                        int rows, int cols, OutT* __restrict__ w,
+                                                        float* __restrict__ norms) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* vr = v + (long)row * cols;
+  OutT* wr = w + (long)row * cols;
+  float s = 0.f;
+  if ((cols & 3) == 0) {
+    const float4* v4 = reinterpret_cast<const float4*>(vr);
+    for (int c = lane; c < cols / 4; c += 64) { const float4 x = v4[c]; s += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w; }
+  } else {
+    for (int c = lane; c < cols; c += 64) { const float x = vr[c]; s += x * x; }
+  }
+  s = wave_sum(s);
+  const float nrm = sqrtf(s), sc = g[row] / nrm;
+  if (lane == 0) norms[row] = nrm;
+  if ((cols & 3) == 0) {
+    const float4* v4 = reinterpret_cast<const float4*>(vr);
+    for (int c = lane; c < cols / 4; c += 64) {
+      const float4 x = v4[c];
+      if constexpr (sizeof(OutT) == 2) {
+        uint2 o;
+        o.x = (uint32_t)f2bf(x.x * sc) | ((uint32_t)f2bf(x.y * sc) << 16);
+        o.y = (uint32_t)f2bf(x.z * sc) | ((uint32_t)f2bf(x.w * sc) << 16);
+        reinterpret_cast<uint2*>(wr)[c] = o;
+      } else {
+        reinterpret_cast<float4*>(wr)[c] = make_float4(x.x * sc, x.y * sc, x.z * sc, x.w * sc);
+      }
+    }
+  } else {
+    for (int c = lane; c < cols; c += 64) Elem<OutT>::st(wr + c, vr[c] * sc);
+  }
+}
+extern "C" int tell_wn_weight(const float* g, const float* v, int rows, int cols, void* w, int out_dtype,
+                              float* norms, hipStream_t stream) {
+  if (rows <= 0) return TELL_OK;
+  TELL_REQUIRE(((uintptr_t)v & 15) == 0 && ((uintptr_t)w & 15) == 0, "wn_weight: buffers must be 16-byte aligned");
+  if (out_dtype == TELL_BF16)
+    hipLaunchKernelGGL((wn_weight_kernel<uint16_t>), dim3((rows + 3) / 4), dim3(256), 0, stream, g, v, rows, cols, (uint16_t*)w, norms);
+  else
+    hipLaunchKernelGGL((wn_weight_kernel<float>), dim3((rows + 3) / 4), dim3(256), 0, stream, g, v, rows, cols, (float*)w, norms);
+  return tell_check_launch("wn_weight");
+}
+
 // dg[r] += <dW[r], v[r]> / ||v||;  dv[r] += (g/||v||) * (dW[r] - v[r] * <dW[r],v[r]> / ||v||^2)
 __global__ __launch_bounds__(256) void wn_backward_kernel(const float* __restrict__ dW,
                                                           const float* __restrict__ g,
@@ -120,13 +169,30 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const float* __restric
   if (row >= rows) return;
   const float* vr = v + (long)row * cols;
   const float* dr = dW + (long)row * cols;
+  float* o = dv + (long)row * cols;
+  const bool vec = (cols & 3) == 0 && (((uintptr_t)dW | (uintptr_t)v | (uintptr_t)dv) & 15) == 0;
   float dot = 0.f;
-  for (int c = lane; c < cols; c += 64) dot += dr[c] * vr[c];
+  if (vec) {
+    for (int c = lane; c < cols / 4; c += 64) {
+      const float4 d = reinterpret_cast<const float4*>(dr)[c], x = reinterpret_cast<const float4*>(vr)[c];
+      dot += d.x * x.x + d.y * x.y + d.z * x.z + d.w * x.w;
+    }
+  } else {
+    for (int c = lane; c < cols; c += 64) dot += dr[c] * vr[c];
+  }
   dot = wave_sum(dot);
   const float nrm = norms[row], gs = g[row] / nrm, k = dot / (nrm * nrm);
   if (lane == 0) dg[row] += dot / nrm;             // accumulate into the (zeroed) grad buffers
-  float* o = dv + (long)row * cols;
-  for (int c = lane; c < cols; c += 64) o[c] += gs * (dr[c] - vr[c] * k);
+  if (vec) {
+    for (int c = lane; c < cols / 4; c += 64) {
+      const float4 d = reinterpret_cast<const float4*>(dr)[c], x = reinterpret_cast<const float4*>(vr)[c];
+      float4 a = reinterpret_cast<float4*>(o)[c];
+      a.x += gs * (d.x - x.x * k); a.y += gs * (d.y - x.y * k); a.z += gs * (d.z - x.z * k); a.w += gs * (d.w - x.w * k);
+      reinterpret_cast<float4*>(o)[c] = a;
+    }
+  } else {
+    for (int c = lane; c < cols; c += 64) o[c] += gs * (dr[c] - vr[c] * k);
+  }
 }
 
 extern "C" int tell_wn_backward(const float* dW, const float* g, const float* v, const float* norms,

@@ -419,20 +419,35 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(Ge
     if (kt + 1 < nk) issue(kt + 1, st ^ 1);          // streams in under the MFMAs below
     const unsigned char* ta = smem + st * STAGE;
     const unsigned char* tb = ta + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    // Large wave tiles (128x64: 8 MFMAs per k-substep): fragments of substep ks+1 are read into a second
+    // register set BEFORE the MFMAs of substep ks issue, so the LDS latency sits behind this wave's own matrix
+    // work (+5 % at 4096^3).  With 4 MFMAs per substep the compiler's own interleaving is as good (measured).
+    constexpr bool PREFETCH = MI * NI >= 8;
+    bf16x8 a[2][MI], b[2][NI];
+    auto ldfrag = [&](int ks, int buf) __attribute__((always_inline)) {
       const int c = ks * 2 + (lane >> 5);
-      bf16x8 a[MI], b[NI];
 #pragma unroll
       for (int i = 0; i < MI; ++i)
-        a[i] = *reinterpret_cast<const bf16x8*>(ta + a_base[i] + (((a_hi[i] | c) ^ a_x[i]) << 4));
+        a[buf][i] = *reinterpret_cast<const bf16x8*>(ta + a_base[i] + (((a_hi[i] | c) ^ a_x[i]) << 4));
 #pragma unroll
       for (int j = 0; j < NI; ++j)
-        b[j] = *reinterpret_cast<const bf16x8*>(tb + b_base[j] + (((b_hi[j] | c) ^ b_x[j]) << 4));
+        b[buf][j] = *reinterpret_cast<const bf16x8*>(tb + b_base[j] + (((b_hi[j] | c) ^ b_x[j]) << 4));
+    };
+    if constexpr (PREFETCH) ldfrag(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if constexpr (PREFETCH) {
+        if (ks + 1 < 4) ldfrag(ks + 1, (ks + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);             // keep the prefetch ABOVE the MFMAs (the scheduler sinks it)
+      } else {
+        ldfrag(ks, ks & 1);
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ks & 1][j], a[ks & 1][i], acc[i][j], 0, 0, 0);
+      if constexpr (PREFETCH) __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMA pieces of tile kt+1 have landed
     __syncthreads();                                     // everyone's have, and buffer `st` is free again

@@ -36,14 +36,17 @@ __global__ __launch_bounds__(256) void tensor_norms_kernel(const float* __restri
   s = wave_sum(s);
   if (lane == 0) norms[t] = sqrtf(s);
 }
+// One pass over the flat buffers: BertAdam update of the fp32 masters, the bf16 working copy the next forward
+// reads (shadow; no per-tensor cast kernels), and the zeroing of the gradient for the next step.
 __global__ __launch_bounds__(256) void bertadam_update_kernel(float* __restrict__ param,
-                                                              const float* __restrict__ grad,
+                                                              float* __restrict__ grad,
                                                               float* __restrict__ m, float* __restrict__ v,
                                                               const int* __restrict__ chunk_tensor,
                                                               const float* __restrict__ norms, long n_chunks,
                                                               const float* __restrict__ lr_dev, float b1,
                                                               float b2, float eps, float wd, float max_norm,
-                                                              float grad_scale) {
+                                                              float grad_scale, uint16_t* __restrict__ shadow,
+                                                              int zero_grad) {
   const float lr = *lr_dev;
   for (long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     float coef = grad_scale;
@@ -66,17 +69,24 @@ __global__ __launch_bounds__(256) void bertadam_update_kernel(float* __restrict_
     reinterpret_cast<float4*>(param)[o] = p;
     reinterpret_cast<float4*>(m)[o] = mm;
     reinterpret_cast<float4*>(v)[o] = vv;
+    if (shadow) {
+      uint2 s;
+      s.x = (uint32_t)f2bf(p.x) | ((uint32_t)f2bf(p.y) << 16);
+      s.y = (uint32_t)f2bf(p.z) | ((uint32_t)f2bf(p.w) << 16);
+      reinterpret_cast<uint2*>(shadow)[o] = s;
+    }
+    if (zero_grad) reinterpret_cast<float4*>(grad)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
 extern "C" int tell_opt_chunk(void) { return OPT_CHUNK; }
 
 // workspace `partial`: n_chunks floats; `norms`: n_tensors floats
-extern "C" int tell_bertadam_step(float* param, const float* grad, float* m, float* v,
+extern "C" int tell_bertadam_step(float* param, float* grad, float* m, float* v,
                                   const int* chunk_tensor, const long* chunk_begin, long n_chunks,
                                   int n_tensors, float* partial, float* norms, const float* lr_dev,
                                   float b1, float b2, float eps, float wd, float max_norm,
-                                  float grad_scale, hipStream_t stream) {
+                                  float grad_scale, void* shadow_bf16, int zero_grad, hipStream_t stream) {
   if (n_chunks <= 0) return TELL_OK;
   TELL_REQUIRE(((uintptr_t)param & 15) == 0 && ((uintptr_t)grad & 15) == 0, "bertadam: buffers must be 16-byte aligned");
   int g = n_chunks < 4096 ? (int)n_chunks : 4096;
@@ -84,7 +94,7 @@ extern "C" int tell_bertadam_step(float* param, const float* grad, float* m, flo
     hipLaunchKernelGGL(sqsum_chunks_kernel, dim3(g), dim3(256), 0, stream, grad, n_chunks, grad_scale, partial);
     hipLaunchKernelGGL(tensor_norms_kernel, dim3((n_tensors + 3) / 4), dim3(256), 0, stream, partial, chunk_begin, n_tensors, norms);
   }
-  hipLaunchKernelGGL(bertadam_update_kernel, dim3(g), dim3(256), 0, stream, param, grad, m, v, chunk_tensor, norms, n_chunks, lr_dev, b1, b2, eps, wd, max_norm, grad_scale);
+  hipLaunchKernelGGL(bertadam_update_kernel, dim3(g), dim3(256), 0, stream, param, grad, m, v, chunk_tensor, norms, n_chunks, lr_dev, b1, b2, eps, wd, max_norm, grad_scale, (uint16_t*)shadow_bf16, zero_grad);
   return tell_check_launch("bertadam_step");
 }
 

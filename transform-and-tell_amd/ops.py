@@ -212,6 +212,17 @@ def clear_weight_cache():
 
 def weight(p, rows=None):
     """Working copy [N,K] (compute dtype) of fp32 parameter rows p[r0:r1]."""
+    sh = getattr(p, '_tell_shadow', None)
+    if sh is not None and rt.compute_dtype() == torch.bfloat16:
+        # the optimizer kernel maintains a bf16 copy of the flat parameters (training/optimizers.py); anything else
+        # that wrote the parameter (load_state_dict, broadcast) bumped its version -> refresh that slice once
+        rt.wait_weight_update()
+        if p._tell_shadow_version != p._version:
+            call('tell_cast', p.detach().contiguous(), hip.F32, sh, hip.BF16, p.numel())
+            p._tell_shadow_version = p._version
+        src = sh if rows is None else sh[rows[0]:rows[1]]
+        return src.reshape(src.shape[0], -1)
+
     def make():
         src = p.detach() if rows is None else p.detach()[rows[0]:rows[1]]
         src = src.reshape(src.shape[0], -1)
@@ -231,10 +242,9 @@ def wn_weight(g, v):
     """Weight-normalised working weight (tell/modules/linear.py:33): (w [N,K] compute dtype, norms)."""
     def make():
         R, C = v.shape
-        scale = torch.empty(R, dtype=torch.float32, device=v.device)
         norms = torch.empty(R, dtype=torch.float32, device=v.device)
-        call('tell_wn_rowscale', g.detach(), v.detach(), R, C, scale, norms)
-        _, w = transpose(v.detach(), out_dtype=rt.compute_dtype(), row_scale=scale, want_plain=True, want_t=False)
+        w = torch.empty(R, C, dtype=rt.compute_dtype(), device=v.device)
+        call('tell_wn_weight', g.detach(), v.detach(), R, C, w, hip.dt(w), norms)
         return w, norms
     return _cached(v, ('wn', g._version, g.data_ptr()), make)
 

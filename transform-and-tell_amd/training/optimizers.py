@@ -57,6 +57,14 @@ class FlatParams:
         begins.append(self.n_chunks)
         self.chunk_tensor = chunk_tensor.to(device)
         self.chunk_begin = torch.tensor(begins, dtype=torch.int64, device=device)
+        # bf16 working copy of every parameter, rewritten by the optimizer kernel itself (ops.weight reads it)
+        self.shadow = None
+        if torch.device(device).type == 'cuda':
+            self.shadow = torch.empty(total, dtype=torch.bfloat16, device=device)
+            hip.call('tell_cast', self.flat, hip.F32, self.shadow, hip.BF16, total)
+            for p, o in zip(self.params, offs):
+                p._tell_shadow = self.shadow[o:o + p.numel()].view(p.shape)
+                p._tell_shadow_version = p._version
         self.partial = torch.empty(max(self.n_chunks, 1), dtype=torch.float32, device=device)
         self.norms = torch.zeros(len(self.params), dtype=torch.float32, device=device)
         rt.bump_weights_epoch()
@@ -84,12 +92,13 @@ class BertAdam:
             return self.lr * warmup_linear(self.step_count / self.t_total, self.warmup)
         return self.lr
 
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, zero_grad=False):
+        """zero_grad: also clear the gradient buffer (fused into the update pass)."""
         f = self.flat
         self.lr_dev.fill_(self.current_lr())
         hip.call('tell_bertadam_step', f.flat, f.grad, f.m, f.v, f.chunk_tensor, f.chunk_begin, f.n_chunks,
                  len(f.params), f.partial, f.norms, self.lr_dev, self.b1, self.b2, self.e, self.weight_decay,
-                 self.max_grad_norm, float(grad_scale))
+                 self.max_grad_norm, float(grad_scale), f.shadow, int(zero_grad))
         self.step_count += 1
         rt.bump_weights_epoch()
 

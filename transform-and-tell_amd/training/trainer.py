@@ -97,8 +97,7 @@ class Trainer:
     def _update(self):
         if self.world > 1:
             self._all_reduce_grads()
-        self.optimizer.step(grad_scale=1.0 / self.world)                 # :238
-        self.flat.zero_grad()                                            # :214 of the next batch
+        self.optimizer.step(grad_scale=1.0 / self.world, zero_grad=True)  # :238 (+ :214 of the next batch)
 
     def _all_reduce_grads(self):
         dp.all_reduce_flat(self.flat.grad, self.dist, self.bucket_elems)
