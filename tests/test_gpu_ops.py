@@ -325,6 +325,7 @@ def _attn_case(dtype, T, B, E, H, S, kdim, use_mask, p, seed, has_bias=True):
     (70, 2, 1024, 16, 130, True, 0.1),
     (160, 2, 1024, 16, 200, True, 0.1),  # >= 4 query blocks: shared 64-key-tile forward kernel
     (128, 1, 1024, 16, 64, False, 0.0),
+    (130, 2, 1024, 16, 77, True, 0.1),   # odd key count (per-element dropout decisions), ragged query tail
 ])
 def test_attention_core(dtype, T, B, E, H, S, mask, p):
     _attn_case(dtype, T, B, E, H, S, E, mask, p, seed=T * 131 + S)

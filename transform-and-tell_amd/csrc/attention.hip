@@ -486,6 +486,219 @@ __global__ __launch_bounds__(256) void attn_fwd_tile64_kernel(AttnArgs p) {
   if (lane < 32 && p.lse) p.lse[(long)bh * p.Tq + t] = l_run > 0.f ? m_run + __logf(l_run) : INFINITY;
 }
 
+// ------------------------------------------------------------------ long sequences, bf16: probabilities stay in registers
+// Same tiling as attn_fwd_tile64_kernel (4 waves x 32 queries share 64-key K/V tiles) with three changes:
+//  * Q fragments live in registers for the whole kernel (they are the B operand of S^T = K Q^T);
+//  * the S^T accumulator layout already IS the B operand layout of O^T = V^T P^T: lane (q, hh) holds, for every
+//    16-key MFMA step, 8 keys {4hh..4hh+3, 8+4hh..8+4hh+3} - any key order works for a reduction as long as the
+//    A operand uses the same one - so exp(S) is packed to bf16 in place and never visits LDS;
+//  * V is staged row-major exactly as loaded and its transposed fragments come from ds_read_b64_tr_b16 (two
+//    4-key reads per fragment = the same key sets), so the transposing LDS store is gone as well.
+// K/V tiles are double-buffered: one barrier per 64 keys instead of three.
+typedef __attribute__((ext_vector_type(4))) short attn_s16x4;
+typedef __attribute__((address_space(3))) attn_s16x4* attn_lds_s16x4_ptr;
+__device__ __forceinline__ bf16x8 attn_tr_frag(const uint16_t* p0, const uint16_t* p1) {
+  const attn_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((attn_lds_s16x4_ptr)p0);
+  const attn_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((attn_lds_s16x4_ptr)p1);
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(256) void attn_fwd_reg_kernel(AttnArgs p) {
+  using T = uint16_t;
+  constexpr int D = 64, KT = 64, NW = 4;
+  constexpr int KS = 72;                             // K tile row stride (144 B): conflict-free ds_read_b128
+  constexpr int VS = 96;                             // V tile row stride (192 B): 64-byte skew for the tr reads
+  __shared__ __attribute__((aligned(16))) T Ks[2][KT * KS];
+  __shared__ __attribute__((aligned(16))) T Vs[2][KT * VS];
+  __shared__ __attribute__((aligned(16))) float key_bias[2][KT];
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, qi = lane & 31;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+  const int QB = (p.Tq + 31) / 32;
+  const int qb = blockIdx.x * NW + wave;
+  const bool active = qb < QB;
+  const int q0 = qb * 32, t = q0 + qi;
+  const int S_total = p.S + p.has_bias + p.has_zero;
+  const int nkt = (S_total + KT - 1) / KT;
+  const T* qg = static_cast<const T*>(p.q);
+  const T* kg = static_cast<const T*>(p.k);
+  const T* vg = static_cast<const T*>(p.v);
+  const T* bk = static_cast<const T*>(p.bias_k);
+  const T* bv = static_cast<const T*>(p.bias_v);
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  bf16x8 qf[4];                                      // Q[t][16 ks + 8 hh .. + 7]
+  {
+    const bool ok = active && t < p.Tq;
+    const T* qp = ok ? qg + t * p.q_st + b * p.q_sb + (long)h * D : qg;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(qp + (ok ? 16 * ks + 8 * hh : 0));
+      if (!ok) v = zero4;
+      qf[ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+
+  u32x4 rk[2], rv[2];                                // chunk c = tid + 256 i: key c >> 3, 16-byte column c & 7
+#define RLOAD_TILE(KTI)                                                                         \
+  {                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                             \
+      const int c = tid + 256 * i, s = (KTI) * KT + (c >> 3), ch = c & 7;                       \
+      const bool real = s < p.S, isb = (s == p.S) && p.has_bias;                                \
+      const T* kp = real ? kg + s * p.k_ss + b * p.k_sb + (long)h * D : (isb ? bk + (long)h * D : qg); \
+      const T* vp = real ? vg + s * p.v_ss + b * p.v_sb + (long)h * D : (isb ? bv + (long)h * D : qg); \
+      const int off = (real || isb) ? ch * 8 : 0;                                               \
+      rk[i] = *reinterpret_cast<const u32x4*>(kp + off);   /* unconditional; zeroed at the LDS store */ \
+      rv[i] = *reinterpret_cast<const u32x4*>(vp + off);                                        \
+    }                                                                                           \
+  }
+#define RSTORE_TILE(KTI, BUF)                                                                   \
+  {                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                             \
+      const int c = tid + 256 * i, key = c >> 3, ch = c & 7, s = (KTI) * KT + key;              \
+      const bool ok = s < p.S || (s == p.S && p.has_bias);       /* virtual zero row / past the end -> zeros */ \
+      *reinterpret_cast<u32x4*>(&Ks[BUF][key * KS + ch * 8]) = ok ? rk[i] : zero4;              \
+      *reinterpret_cast<u32x4*>(&Vs[BUF][key * VS + ch * 8]) = ok ? rv[i] : zero4;              \
+    }                                                                                           \
+    if (tid < KT) {                                                                             \
+      const int s = (KTI) * KT + tid;                                                           \
+      bool ok = s < S_total;                                                                    \
+      if (ok && s < p.S && p.mask) ok = p.mask[(long)b * p.S + s] == 0;                         \
+      key_bias[BUF][tid] = ok ? 0.f : -INFINITY;                                                \
+    }                                                                                           \
+  }
+  RLOAD_TILE(0)
+  RSTORE_TILE(0, 0)
+  __syncthreads();
+
+  f32x16 o[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[f][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  // per-lane LDS origins: K fragment row (lane&31), k chunk 8 hh; V^T fragment via tr read: key row 4 hh +
+  // ((lane&15)>>2), d column 16 ((lane>>4)&1) + 4 (lane&3)
+  const int k_off = qi * KS + 8 * hh;
+  const int v_off = (4 * hh + ((lane & 15) >> 2)) * VS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1, s0 = kt * KT;
+    if (kt + 1 < nkt) RLOAD_TILE(kt + 1)              // streams in under the MFMAs below
+    if (active) {
+      const T* Kb = &Ks[buf][k_off];
+      const T* Vb = &Vs[buf][v_off];
+      f32x16 st[2];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[f][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kb + f * 32 * KS + 16 * ks);
+          st[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[f], 0, 0, 0);   // S^T[key][q]
+        }
+      }
+      if (p.mask != nullptr || s0 + KT > S_total) {   // block-uniform: some key of this tile may be masked
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 kb4 = *reinterpret_cast<const f32x4*>(&key_bias[buf][f * 32 + 8 * g + 4 * hh]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st[f][4 * g + e] += kb4[e];
+          }
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[f][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;        // all keys masked so far: exp(-inf - 0) = 0
+      const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+      float ls = 0.f;
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __expf(st[f][r] - m_safe);
+          ls += pv;
+          st[f][r] = pv;
+        }
+      if constexpr (DROP) {
+        const uint64_t base = ((uint64_t)bh * p.Tq + t) * S_total + s0 + 4 * hh;
+        if ((S_total & 1) == 0) {
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              float k0, k1;
+              tell_keep2(p.seed, p.salt, base + (f * 32 + (r & 3) + 8 * (r >> 2)), p.thr, p.inv_keep, k0, k1);
+              st[f][r] *= k0;
+              st[f][r + 1] *= k1;
+            }
+        } else {
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              st[f][r] *= tell_keep(p.seed, p.salt, base + (f * 32 + (r & 3) + 8 * (r >> 2)), p.thr, p.inv_keep);
+        }
+      }
+      ls += __shfl_xor(ls, 32, 64);
+      l_run = l_run * alpha + ls;
+      m_run = m_new;
+      if (__any(alpha != 1.f)) {                                       // wave-uniform: the running max moved
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[f][r] *= alpha;
+      }
+      // O^T[d][q] += V^T[d][keys] P^T[keys][q], 16 keys per MFMA: registers 8j..8j+7 of sub-tile f
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          typedef __attribute__((ext_vector_type(4))) unsigned int pk4;
+          const pk4 w = {pack_bf16x2(st[f][8 * j], st[f][8 * j + 1]), pack_bf16x2(st[f][8 * j + 2], st[f][8 * j + 3]),
+                         pack_bf16x2(st[f][8 * j + 4], st[f][8 * j + 5]), pack_bf16x2(st[f][8 * j + 6], st[f][8 * j + 7])};
+          const bf16x8 pf = __builtin_bit_cast(bf16x8, w);
+          const T* vrow = Vb + (f * 32 + j * 16) * VS;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const bf16x8 vf = attn_tr_frag(vrow + dt * 32, vrow + 8 * VS + dt * 32);
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+          }
+        }
+    }
+    if (kt + 1 < nkt) RSTORE_TILE(kt + 1, buf ^ 1)     // buffer buf^1 was last read before the previous barrier
+    __syncthreads();
+  }
+#undef RLOAD_TILE
+#undef RSTORE_TILE
+  if (!active || t >= p.Tq) return;
+  const float inv_l = l_run > 0.f ? 1.f / l_run : 0.f;
+  T* og = static_cast<T*>(p.out) + t * p.o_st + b * p.o_sb + (long)h * D;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {                     // 4 consecutive d per register group -> one 8-byte store
+      const int d0 = dt * 32 + 8 * g + 4 * hh;
+      uint2 w;
+      w.x = pack_bf16x2(o[dt][4 * g] * inv_l, o[dt][4 * g + 1] * inv_l);
+      w.y = pack_bf16x2(o[dt][4 * g + 2] * inv_l, o[dt][4 * g + 3] * inv_l);
+      *reinterpret_cast<uint2*>(og + d0) = w;
+    }
+  if (lane < 32 && p.lse) p.lse[(long)bh * p.Tq + t] = l_run > 0.f ? m_run + __logf(l_run) : INFINITY;
+}
+
 // ------------------------------------------------------------------ backward
 // One workgroup per (b,h); its NW waves split the key tiles.  Query blocks of 32 are
 // the outer loop (Q-side tiles shared by the waves); dQ is reduced across waves in LDS;
@@ -738,7 +951,12 @@ extern "C" int tell_attn_fwd(const void* q, const void* k, const void* v, void* 
   const int QB = (Tq + 31) / 32;
   if (D == 64 && QB >= 4) {            // long sequences: shared 64-key tiles
     dim3 grid((QB + 3) / 4, B * H);
-    if (dtype == TELL_BF16) {
+    static const int old_path = getenv("TELL_ATTN_TILE64") ? atoi(getenv("TELL_ATTN_TILE64")) : 0;   // A/B aid
+    if (dtype == TELL_BF16 && !old_path) {
+      if (a.thr) hipLaunchKernelGGL((attn_fwd_reg_kernel<true>), grid, dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((attn_fwd_reg_kernel<false>), grid, dim3(256), 0, stream, a);
+      return tell_check_launch("attn_fwd_reg");
+    } else if (dtype == TELL_BF16) {
       if (a.thr) hipLaunchKernelGGL((attn_fwd_tile64_kernel<uint16_t, true>), grid, dim3(256), 0, stream, a);
       else hipLaunchKernelGGL((attn_fwd_tile64_kernel<uint16_t, false>), grid, dim3(256), 0, stream, a);
     } else {
