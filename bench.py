@@ -70,6 +70,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=2)
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-pipeline', action='store_true',
+                    help='do not launch the next batch\'s frozen encoders underneath the current decoder step')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -103,15 +105,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # every step trains batch i and launches the frozen encoders of batch i+1 underneath it (what a training loop
+    # with a data loader does); each timed step therefore contains exactly one encoder pass and one decoder pass
+    nxt = lambda i: None if args.no_pipeline else batches[(i + 1) % 2]     # noqa: E731
     for i in range(args.warmup):
-        trainer.train_one_batch(fresh(batches[i % 2]))
+        trainer.train_one_batch(fresh(batches[i % 2]), next_batch=nxt(i))
     sync()
     if not args.no_roofline:
         prof.enable(True)
     t0 = time.perf_counter()
     loss = None
     for i in range(args.steps):
-        loss = trainer.train_one_batch(fresh(batches[i % 2]))
+        loss = trainer.train_one_batch(fresh(batches[(args.warmup + i) % 2]), next_batch=nxt(args.warmup + i))
     issued = time.perf_counter() - t0           # host finished issuing; the rest of `elapsed` is GPU backlog
     sync()
     elapsed = time.perf_counter() - t0

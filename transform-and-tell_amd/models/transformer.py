@@ -15,11 +15,32 @@ _OVERLAP = os.environ.get('TELL_ENCODER_OVERLAP', '1') != '0'
 _side_streams = {}
 
 
-def _side_stream(device):
-    s = _side_streams.get(device)
+def _side_stream(device, name='resnet'):
+    s = _side_streams.get((device, name))
     if s is None:
-        s = _side_streams[device] = torch.cuda.Stream(device=device)
+        s = _side_streams[(device, name)] = torch.cuda.Stream(device=device)
     return s
+
+
+class EncodedBatch:
+    """Outputs of the frozen encoders for one batch (CaptionModel.encode), possibly still in flight on the
+    encoder streams."""
+
+    def __init__(self):
+        self.stack = self.x_image = self.article_mask = None
+        self.events = []
+
+    def wait(self):
+        """Join the producing streams into the current stream (idempotent)."""
+        if self.events:
+            cur = torch.cuda.current_stream()
+            for ev in self.events:
+                cur.wait_event(ev)
+            self.events = []
+            for t in (self.x_image, self.article_mask, self.stack):
+                for u in (t if isinstance(t, (list, tuple)) else (t,)):
+                    if torch.is_tensor(u) and u.is_cuda:
+                        u.record_stream(cur)
 
 
 class Model(nn.Module, Registrable):
@@ -77,36 +98,67 @@ class CaptionModel(Model):
         w = self.resnet.conv1.weight                 # a reloaded / moved / re-typed trunk must not replay stale pointers
         return g(image, key=(self.resnet.training, ops.rt.compute_dtype(), w._version, w.data_ptr()))
 
+    # ---- frozen encoders -------------------------------------------------------------
+    def encode(self, context, image, ahead=False):
+        """ResNet-152 + RoBERTa-large on one batch (transformer_faces_objects.py:335-353) -> EncodedBatch.
+
+        The two encoders are independent and read no trainable weight.  ahead=False: RoBERTa runs on the current
+        stream, ResNet's many small launches on a side stream underneath RoBERTa's chip-filling GEMMs
+        (TELL_ENCODER_OVERLAP=0 serialises them).  ahead=True: both run on their own streams and the call returns
+        at once - the trainer uses it to encode batch N+1 underneath the latency-bound decoder forward /
+        backward / optimizer of batch N; `EncodedBatch.wait()` joins them into the consumer's stream."""
+        with torch.no_grad():
+            main = torch.cuda.current_stream()
+            article_ids = context[self.index]
+            enc = EncodedBatch()
+            if ahead:
+                rs, is_ = _side_stream(image.device, 'roberta'), _side_stream(image.device, 'resnet')
+                start = torch.cuda.Event()
+                start.record(main)
+                rs.wait_event(start)
+                is_.wait_event(start)
+                with torch.cuda.stream(rs), ops.hip.bound_stream():
+                    enc.article_mask = article_ids == self.padding_idx                 # :347
+                    enc.stack = self.roberta.extract_features(article_ids, return_all_hiddens=True)
+                    article_ids.record_stream(rs)
+                    enc.events.append(torch.cuda.Event())
+                    enc.events[-1].record(rs)
+                with torch.cuda.stream(is_), ops.hip.bound_stream():
+                    enc.x_image = self._run_resnet(image)
+                    image.record_stream(is_)
+                    enc.events.append(torch.cuda.Event())
+                    enc.events[-1].record(is_)
+                return enc
+            side = _side_stream(image.device, 'resnet') if _OVERLAP else None
+            enc.article_mask = article_ids == self.padding_idx                         # :347
+            if side is not None:
+                start = torch.cuda.Event()
+                start.record(main)
+            # RoBERTa is issued FIRST: its ~300 launches keep the main stream busy for ~10 ms of GPU time
+            # while the host is still issuing ResNet's small launches onto the side stream.
+            enc.stack = self.roberta.extract_features(article_ids, return_all_hiddens=True)   # [L,B,S,E]
+            if side is not None:
+                side.wait_event(start)
+                with torch.cuda.stream(side), ops.hip.bound_stream():
+                    enc.x_image = self._run_resnet(image)                  # [B,49,2048] (NHWC == :335-341)
+                    enc.events.append(torch.cuda.Event())
+                    enc.events[-1].record(side)
+            else:
+                enc.x_image = self._run_resnet(image)
+            return enc
+
     # ---- :311-397 -----------------------------------------------------------------
-    def _forward(self, context, image, caption, face_embeds=None, obj_embeds=None):
+    def _forward(self, context, image, caption, face_embeds=None, obj_embeds=None, encoded=None):
         dtype = ops.rt.compute_dtype()
         cap = caption[self.index]
         target_ids = cap[:, 1:].contiguous()                               # :321-328
         caption_ids = cap[:, :-1].contiguous()
         caption[self.index] = caption_ids                                  # :329
 
-        with torch.no_grad():                                              # frozen encoders (config :150-152)
-            # The two encoders are independent: ResNet's many small launches run on a side stream
-            # underneath RoBERTa's chip-filling GEMMs (TELL_ENCODER_OVERLAP=0 serialises them).
-            main = torch.cuda.current_stream()
-            side = _side_stream(image.device) if _OVERLAP else None
-            article_ids = context[self.index]
-            article_mask = article_ids == self.padding_idx                 # :347
-            if side is not None:
-                start = torch.cuda.Event()
-                start.record(main)
-            # RoBERTa is issued FIRST: its ~300 launches keep the main stream busy for ~10 ms of GPU time
-            # while the host is still issuing ResNet's ~800 small launches onto the side stream.
-            stack = self.roberta.extract_features(article_ids, return_all_hiddens=True)   # [L,B,S,E]
-            if side is not None:
-                side.wait_event(start)
-                with torch.cuda.stream(side), ops.hip.bound_stream():
-                    x_image = self._run_resnet(image)                      # [B,49,2048] (NHWC == :335-341)
-                main.wait_stream(side)
-                x_image.record_stream(main)
-            else:
-                x_image = self._run_resnet(image)
-            B, P, _ = x_image.shape
+        enc = encoded if encoded is not None else self.encode(context, image)   # frozen encoders (config :150-152)
+        enc.wait()
+        stack, x_image, article_mask = enc.stack, enc.x_image, enc.article_mask
+        B, P, _ = x_image.shape
         ops.rt.wait_weight_update()      # everything below reads trainable weights (the encoders above do not)
         if self.weigh_bert:
             x_article = ops.mix_layers(stack, self.bert_weight)            # :355-364
@@ -134,8 +186,9 @@ class CaptionModel(Model):
 
     # ---- :67-140 ------------------------------------------------------------------
     def forward(self, context, image, caption, face_embeds=None, obj_embeds=None, metadata=None, names=None,
-                attn_idx=None):
-        caption_ids, target_ids, contexts = self._forward(context, image, caption, face_embeds, obj_embeds)
+                attn_idx=None, encoded=None):
+        """encoded: optional EncodedBatch of THIS batch produced earlier by `encode(..., ahead=True)`."""
+        caption_ids, target_ids, contexts = self._forward(context, image, caption, face_embeds, obj_embeds, encoded)
         decoder_out = self.decoder(caption, contexts)
         loss_sum, sample_size = self.criterion(self.decoder.adaptive_softmax, decoder_out, target_ids)
         n = sample_size.to(torch.float32)

@@ -59,14 +59,35 @@ class Trainer:
         """Make the current stream wait for an in-flight weight update (checkpointing, evaluation, ...)."""
         rt.wait_weight_update()
 
-    def train_one_batch(self, batch):
-        """callback_apex_trainer.py:208-247 for one batch; returns the (detached) loss tensor."""
-        with hip.bound_stream():
-            return self._train_one_batch(batch)
+    def train_one_batch(self, batch, next_batch=None):
+        """callback_apex_trainer.py:208-247 for one batch; returns the (detached) loss tensor.
 
-    def _train_one_batch(self, batch):
+        next_batch: the batch that will be trained next, if the caller already has it (a data loader always
+        does).  Its frozen encoders are launched on their own streams BEFORE this batch's decoder work is
+        issued, so ResNet-152 / RoBERTa-large of step N+1 fill the GPU underneath the latency-bound decoder
+        forward, backward and optimizer of step N.  Numerics are unchanged: the encoders read no trainable
+        weight, and BatchNorm running statistics are still updated in batch order on the encoder stream."""
+        with hip.bound_stream():
+            return self._train_one_batch(batch, next_batch)
+
+    def _encoded_for(self, batch):
+        pre, self._prefetched = getattr(self, '_prefetched', None), None
+        if pre is not None and pre[0] is batch.get('image'):
+            return pre[1]
+        return None
+
+    def _train_one_batch(self, batch, next_batch=None):
         self.model.train()                       # (:214 zero_grad: done right after the previous update)
-        out = self.model(**batch)                                        # :220 / :194
+        extra = {}
+        if hasattr(self.model, 'encode') and torch.is_tensor(batch.get('image')) and batch['image'].is_cuda:
+            enc = self._encoded_for(batch)
+            if enc is None:
+                enc = self.model.encode(batch['context'], batch['image'])
+            extra['encoded'] = enc
+            if next_batch is not None:
+                self._prefetched = (next_batch['image'],
+                                    self.model.encode(next_batch['context'], next_batch['image'], ahead=True))
+        out = self.model(**batch, **extra)                               # :220 / :194
         loss = out['loss']
         if self.world > 1:
             scaled = loss * dp.loss_weight(out['sample_size'].to(torch.float32).reshape(1), self.dist,
