@@ -634,7 +634,18 @@ __global__ __launch_bounds__(256) void attn_fwd_reg_kernel(AttnArgs p) {
         }
       if constexpr (DROP) {
         const uint64_t base = ((uint64_t)bh * p.Tq + t) * S_total + s0 + 4 * hh;
-        if ((S_total & 1) == 0) {
+        if ((S_total & 1) == 0 && tell_keep_row_ok(base >> 1, 32)) {
+          const TellKeepRow row = tell_keep_row(p.seed, p.salt, base >> 1);    // base is even here
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              float k0, k1;
+              tell_keep2_row(row, (f * 32 + (r & 3) + 8 * (r >> 2)) >> 1, p.thr, p.inv_keep, k0, k1);
+              st[f][r] *= k0;
+              st[f][r + 1] *= k1;
+            }
+        } else if ((S_total & 1) == 0) {
 #pragma unroll
           for (int f = 0; f < 2; ++f)
 #pragma unroll

@@ -116,6 +116,26 @@ __device__ __forceinline__ float tell_keep(uint32_t seed, uint32_t salt, uint64_
   const uint32_t bits = (idx & 1) ? (h >> 16) : (h & 0xffffu);
   return bits >= thr ? inv_keep : 0.f;
 }
+// Consecutive pairs of one row: the index-dependent part of the hash input is linear in the pair index, so a
+// kernel that walks pair_idx0 + d for small compile-time d pays one add per pair instead of two multiplies.
+// Valid while the low word of the pair index does not wrap (caller checks tell_keep_row_ok).
+struct TellKeepRow { uint32_t x0, y; };
+__device__ __forceinline__ bool tell_keep_row_ok(uint64_t pair_idx0, uint32_t span) {
+  return (uint32_t)pair_idx0 <= 0xFFFFFFFFu - span;
+}
+__device__ __forceinline__ TellKeepRow tell_keep_row(uint32_t seed, uint32_t salt, uint64_t pair_idx0) {
+  TellKeepRow r;
+  r.x0 = (uint32_t)pair_idx0 * 0x9E3779B1u + seed;
+  r.y = (uint32_t)(pair_idx0 >> 32) * 0x85EBCA77u + salt * 0xC2B2AE3Du + 0x27D4EB2Fu;
+  return r;
+}
+__device__ __forceinline__ void tell_keep2_row(const TellKeepRow& r, uint32_t d, uint32_t thr, float inv_keep,
+                                               float& k0, float& k1) {      // == tell_keep2 at pair index pair_idx0 + d
+  uint32_t x = r.x0 + d * 0x9E3779B1u;
+  x ^= r.y; x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  k0 = (x & 0xffffu) >= thr ? inv_keep : 0.f;
+  k1 = (x >> 16) >= thr ? inv_keep : 0.f;
+}
 // both decisions of the aligned pair starting at the EVEN index idx_even
 __device__ __forceinline__ void tell_keep2(uint32_t seed, uint32_t salt, uint64_t idx_even, uint32_t thr,
                                            float inv_keep, float& k0, float& k1) {

@@ -61,13 +61,20 @@ class FlatParams:
         self.shadow = None
         if torch.device(device).type == 'cuda':
             self.shadow = torch.empty(total, dtype=torch.bfloat16, device=device)
-            hip.call('tell_cast', self.flat, hip.F32, self.shadow, hip.BF16, total)
             for p, o in zip(self.params, offs):
                 p._tell_shadow = self.shadow[o:o + p.numel()].view(p.shape)
-                p._tell_shadow_version = p._version
+            self.refresh_shadow()
         self.partial = torch.empty(max(self.n_chunks, 1), dtype=torch.float32, device=device)
         self.norms = torch.zeros(len(self.params), dtype=torch.float32, device=device)
         rt.bump_weights_epoch()
+
+    def refresh_shadow(self):
+        """Re-derive the bf16 working copy from the fp32 masters (after anything but the optimizer kernel wrote the
+        flat buffer: construction, the initial DP broadcast, a checkpoint load into `flat`)."""
+        if self.shadow is not None:
+            hip.call('tell_cast', self.flat, hip.F32, self.shadow, hip.BF16, self.total)
+            for p in self.params:
+                p._tell_shadow_version = p._version
 
     def zero_grad(self):
         hip.call('tell_fill_f32', self.grad, self.total, 0.0)
