@@ -72,6 +72,12 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-pipeline', action='store_true',
                     help='do not launch the next batch\'s frozen encoders underneath the current decoder step')
+    ap.add_argument('--serial', action='store_true',
+                    help='run everything on ONE stream (no encoder prefetch / overlap, no weight-gradient or update '
+                         'stream): per-kernel durations are then well defined - the mode of the roofline leg and of '
+                         'the committed rocprofv3 kernel summaries')
+    ap.add_argument('--roofline-steps', type=int, default=4,
+                    help='extra single-stream steps after the timed region that time the GEMM kernels in isolation')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -105,6 +111,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def set_serial(flag):
+        """One stream for everything (flag) or the overlapped production schedule (not flag)."""
+        import tell_amd.models.transformer as tr_mod
+        from tell_amd import ops
+        torch.cuda.synchronize()
+        tell_amd.runtime.wait_weight_update()
+        tr_mod._OVERLAP = not flag
+        ops._WGRAD['enabled'] = not flag
+        trainer.async_update = (not flag) and trainer.update_stream is not None
+
+    if args.serial:
+        set_serial(True)
+        args.no_pipeline = True
+
     # every step trains batch i and launches the frozen encoders of batch i+1 underneath it (what a training loop
     # with a data loader does); each timed step therefore contains exactly one encoder pass and one decoder pass
     nxt = lambda i: None if args.no_pipeline else batches[(i + 1) % 2]     # noqa: E731
@@ -112,6 +132,7 @@ def main():
         trainer.train_one_batch(fresh(batches[i % 2]), next_batch=nxt(i))
     sync()
     if not args.no_roofline:
+        prof.calibrate()
         prof.enable(True)
     t0 = time.perf_counter()
     loss = None
@@ -120,8 +141,22 @@ def main():
     issued = time.perf_counter() - t0           # host finished issuing; the rest of `elapsed` is GPU backlog
     sync()
     elapsed = time.perf_counter() - t0
-    prof_summary = prof.summary() if not args.no_roofline else {}
+    prof_concurrent = prof.summary() if not args.no_roofline else {}
     prof.enable(False)
+    # ---- roofline leg: the same steps on ONE stream, so that a kernel's event-bracketed duration is its own
+    # (in the overlapped schedule above several streams share the CUs and every duration is inflated)
+    prof_summary = prof_concurrent
+    if not args.no_roofline and not args.serial and args.roofline_steps > 0:
+        set_serial(True)
+        trainer.train_one_batch(fresh(batches[0]))
+        sync()
+        prof.enable(True)
+        for i in range(args.roofline_steps):
+            trainer.train_one_batch(fresh(batches[i % 2]))
+        sync()
+        prof_summary = prof.summary()
+        prof.enable(False)
+        set_serial(False)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -160,12 +195,20 @@ def main():
                 'frac': round(achieved / peak, 4), 'traffic': traffic,
                 'traffic_note': 'bytes/launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE on this '
                                 'command, profiles/r01_pmc_gemm_traffic.json',
-                'launches_per_step': d['launches'] // args.steps,
+                'mode': ('single stream (--serial run)' if args.serial else
+                         '%d extra single-stream steps after the timed region' % args.roofline_steps),
+                'launches_per_step': d['launches'] // (args.steps if args.serial else args.roofline_steps),
                 'avg_launch_us': round(d['avg_us'], 2),
-                'timed_launches': d['timed'], 'timing': 'HIP events around every 3rd launch of each GEMM kernel '
-                                                        '(>= 2 GFLOP) inside the timed region',
-                'step_share': round(d['avg_us'] * d['launches'] * 1e-6 / elapsed, 4),
-                'all_gemm_kernels': {k: {'avg_us': round(v['avg_us'], 2), 'launches_per_step': v['launches'] // args.steps,
+                'timed_launches': d['timed'],
+                'timing': 'HIP events around every 3rd launch of each GEMM kernel (>= 2 GFLOP), on the launch stream; '
+                          'the duration of an empty bracket (event_overhead_us) is subtracted',
+                'event_overhead_us': round(prof.overhead_us(), 2),
+                'concurrent': ({k: {'avg_us': round(v['avg_us'], 2),
+                                    'tflops': round(v['work'] / (v['total_ms'] * 1e-3) / 1e12, 2)}
+                                for k, v in prof_concurrent.items()} if not args.serial else None),
+                'concurrent_note': 'the same kernels timed inside the timed region, where 4-5 streams share the CUs',
+                'all_gemm_kernels': {k: {'avg_us': round(v['avg_us'], 2),
+                                         'launches_per_step': v['launches'] // (args.steps if args.serial else args.roofline_steps),
                                          'tflops': round(v['work'] / (v['total_ms'] * 1e-3) / 1e12, 2)}
                                      for k, v in prof_summary.items()}}
         if world == 1 and not args.no_cpu_baseline:

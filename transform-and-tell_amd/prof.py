@@ -41,13 +41,36 @@ def end(rec):
     _records.append(rec)
 
 
+_overhead_ms = [0.0]
+
+
+def calibrate(n=40):
+    """Duration of an EMPTY event bracket on the current stream (the two timing packets themselves): subtracted
+    from every measured bracket so that avg_us is the kernel's own time, as rocprofv3 reports it."""
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    x = torch.zeros(1, device='cuda')
+    for e0, e1 in evs:
+        x.add_(1)                  # something in front, as in a real stream
+        e0.record()
+        e1.record()
+    torch.cuda.synchronize()
+    d = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    _overhead_ms[0] = d[len(d) // 2]
+    return _overhead_ms[0] * 1e3
+
+
+def overhead_us():
+    return _overhead_ms[0] * 1e3
+
+
 def summary():
     """-> {kernel: dict(launches, timed, total_ms, avg_us, work)}; call after torch.cuda.synchronize()."""
     out = {}
     for name, work, e0, e1 in _records:
         d = out.setdefault(name, dict(timed=0, total_ms=0.0, work=0.0))
         d['timed'] += 1
-        d['total_ms'] += e0.elapsed_time(e1)
+        d['total_ms'] += max(e0.elapsed_time(e1) - _overhead_ms[0], 1e-4)
         d['work'] += work                                   # work of the TIMED launches only
     for name, d in out.items():
         d['launches'] = _seen.get(name, d['timed'])         # all qualifying launches, timed or not
