@@ -133,3 +133,47 @@ def test_bf16_training_reduces_loss_with_dropout():
         losses.append(float(trainer.train_one_batch(b)))
     assert all(l == l for l in losses)                   # no NaN
     assert sum(losses[-5:]) / 5 < 0.6 * sum(losses[:3]) / 3, losses
+
+
+@pytest.mark.parametrize('kind', ['flattened', 'faces_objects'])
+def test_beam_search_matches_oracle_definition_fp32(kind):
+    """beam search on the cached generator (replicated K/V, reordered DynamicConv buffers) against
+    the plain prefix-re-decoding definition in oracle/beam.py; beam 1 through the beam code == greedy ids."""
+    import tell_amd
+    from oracle.beam import beam_search
+    from oracle.build import build_model as obuild
+    from tell_amd.build import build_model
+    from tell_amd.data import synthetic_batch
+    tell_amd.set_compute_dtype(torch.float32)
+    torch.manual_seed(5)
+    adim = 64 if kind == 'flattened' else 1024
+    gpu = build_model(kind, _Res(True), _Rob(adim), n_bert_layers=3, article_dim=adim, **KW)
+    cpu = obuild(kind, _Res(False), _Rob(adim), n_bert_layers=3, article_dim=adim, **KW).eval()
+    sd = gpu.state_dict()
+    # sharpen the output distribution a little so that hypotheses finish at different lengths
+    for k in sd:
+        if k.endswith('adaptive_softmax.head.word_proj.weight') or k.endswith('embed_tokens.embeddings.0.weight'):
+            sd[k][2] *= 1.6                                              # EOS row
+    gpu.load_state_dict(sd)
+    cpu.load_state_dict({k: v for k, v in sd.items() if k in cpu.state_dict()}, strict=False)
+    gpu.eval().to(DEV)
+    batch = synthetic_batch(B=3, article_len=20, caption_len=9, faces_objects=(kind == 'faces_objects'), vocab=600,
+                            cutoffs=(100, 300), seed=77, variable=True)
+    dev_batch = {k: ({kk: vv.to(DEV) for kk, vv in v.items()} if isinstance(v, dict) else v.to(DEV))
+                 for k, v in batch.items()}
+    clone = lambda b: {k: (dict(v) if isinstance(v, dict) else v.clone()) for k, v in b.items()}   # noqa: E731
+    with torch.no_grad():
+        cap_ids, _, ctx = cpu._forward(**{k: v for k, v in clone(batch).items()})
+        cids, _, gctx = gpu._forward(**clone(dev_batch))
+        for K in (4, 2):
+            ref_ids, ref_score = beam_search(cpu, cap_ids, ctx, K, gen_len=24)
+            lp, got, _ = gpu._generate(cids, gctx, beam_size=K, gen_len=24)
+            got = got.cpu()
+            n = min(got.shape[1], ref_ids.shape[1])
+            assert torch.equal(got[:, :n], ref_ids[:, :n]), (K, got, ref_ids)
+            assert (got[:, n:] == 1).all() and (ref_ids[:, n:] == 1).all()
+            assert torch.allclose(lp.sum(1).cpu(), ref_score, rtol=1e-4, atol=2e-4)
+        _, greedy, _ = gpu._generate(cids, gctx, gen_len=24)
+        _, one, _ = gpu._generate_beam(cids, gctx, 1, gen_len=24)
+        n = min(greedy.shape[1], one.shape[1])
+        assert torch.equal(greedy.cpu()[:, :n], one.cpu()[:, :n])

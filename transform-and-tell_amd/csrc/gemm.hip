@@ -30,7 +30,6 @@ struct GemmArgs {
   int act;                // 0 none, 1 relu, 2 gelu(erf), 3 multiply by (aux > 0)
   int accumulate;         // C = C + result  (beta = 1)
   float alpha;            // result = act((acc + bias) * alpha)
-  int dbg;                // tuning aid (TELL_GEMM_DEBUG): 1 = skip the epilogue, 2 = one K step only
   float* asum;            // K-major A only: asum[m] += asum_scale * sum_k A[k][m]  (bias gradient of a wgrad GEMM)
   float asum_scale;
   float* stat_mean;       // bf16 NT kernels: per (m-tile, column) mean / M2 of the STORED (bf16-rounded) outputs over
@@ -472,162 +471,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(Ge
   gemm_epilogue<OutT, MI, NI>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, M, N);
 }
 
-// ------------------------------------------------------------- direct-to-LDS, persistent workgroups
-// Short-K GEMMs (K = 1024: 16 K steps per 128x128 tile) spend a quarter of a one-tile workgroup's life
-// in launch, the exposed first-tile load and the epilogue.  Here 2 workgroups per CU stay resident and
-// walk their XCD's tile range with a stride; the first K step of the NEXT tile is issued into the free
-// LDS stage during the last K step of the current one, so it lands under that step's MFMAs and the
-// epilogue (which stages C through the stage just consumed).
-template <typename OutT, int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_nt_glds_persist_kernel(GemmArgs p) {
-  constexpr int NW = WAVES_M * WAVES_N, BK = 64;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int IA = BM / 8 / NW, IB = BN / 8 / NW;
-  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 32, NI = WN / 32;
-  static_assert(BM * BN * 2 <= STAGE, "C tile is staged through ONE consumed stage");
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  int M = p.M;
-  if (p.m_dev) { int md = *p.m_dev; M = md < M ? md : M; }
-  const int N = p.N, K = p.K;
-  const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
-  const int ntiles = tiles_m * tiles_n;
-  // XCD x (= blockIdx & 7) owns a contiguous range of the grouped tile order; its gridDim/8 resident
-  // workgroups sweep that range together, so they share A/B panels in the XCD's L2.
-  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, stride = gridDim.x >> 3;
-  const int q = ntiles >> 3, r = ntiles & 7;
-  const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  const int count = xcd < r ? q + 1 : q;
-  if (local >= count) return;
-
-  const uint16_t* A = static_cast<const uint16_t*>(p.A);
-  const uint16_t* B = static_cast<const uint16_t*>(p.B);
-  int a_row[IA], b_row[IB];                            // tile-relative source row of each of this lane's pieces
-  int a_col, b_col;                                    // k offset (elements) - identical for all pieces of a lane?
-  const uint16_t* asrc[IA];
-  const uint16_t* bsrc[IB];
-  int a_k[IA], b_k[IB];
-#pragma unroll
-  for (int j = 0; j < IA; ++j) {
-    const int s = (wave * IA + j) * 64 + lane, pr = s >> 4, l16 = (s & 15) ^ (pr & 15);
-    a_row[j] = 2 * pr + (l16 >> 3); a_k[j] = (l16 & 7) * 8;
-  }
-#pragma unroll
-  for (int j = 0; j < IB; ++j) {
-    const int s = (wave * IB + j) * 64 + lane, pr = s >> 4, l16 = (s & 15) ^ (pr & 15);
-    b_row[j] = 2 * pr + (l16 >> 3); b_k[j] = (l16 & 7) * 8;
-  }
-  (void)a_col; (void)b_col;
-  int m0, n0;
-  auto locate = [&](int t) __attribute__((always_inline)) {      // grouped (GROUP_M m-tiles per n sweep) order
-    constexpr int GROUP_M = 8;
-    const int per_group = GROUP_M * tiles_n;
-    const int g = t / per_group, first_m = g * GROUP_M;
-    const int gm = tiles_m - first_m < GROUP_M ? tiles_m - first_m : GROUP_M;
-    const int in_g = t - g * per_group;
-    m0 = (first_m + in_g % gm) * BM;
-    n0 = (in_g / gm) * BN;
-#pragma unroll
-    for (int j = 0; j < IA; ++j) {
-      int row = m0 + a_row[j];
-      row = row < M ? row : M - 1;
-      asrc[j] = A + (long)row * p.lda + a_k[j];
-    }
-#pragma unroll
-    for (int j = 0; j < IB; ++j) {
-      int row = n0 + b_row[j];
-      row = row < N ? row : N - 1;
-      bsrc[j] = B + (long)row * p.ldb + b_k[j];
-    }
-  };
-  auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
-    unsigned char* sa = smem + stage * STAGE + (wave * IA) * 1024;
-    unsigned char* sb = smem + stage * STAGE + A_BYTES + (wave * IB) * 1024;
-#pragma unroll
-    for (int j = 0; j < IA; ++j)
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[j] + kt * BK), (lds_ptr_t)(sa + j * 1024), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < IB; ++j)
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(bsrc[j] + kt * BK), (lds_ptr_t)(sb + j * 1024), 16, 0, 0);
-  };
-
-  int a_base[MI], a_x[MI], a_hi[MI], b_base[NI], b_x[NI], b_hi[NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int rr = wm * WM + i * 32 + (lane & 31);
-    a_base[i] = (rr >> 1) * 256; a_x[i] = (rr >> 1) & 15; a_hi[i] = (rr & 1) << 3;
-  }
-#pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int rr = wn * WN + j * 32 + (lane & 31);
-    b_base[j] = (rr >> 1) * 256; b_x[j] = (rr >> 1) & 15; b_hi[j] = (rr & 1) << 3;
-  }
-
-  const int nk = (p.dbg & 2) ? 1 : K / BK;
-  int st = 0;                                          // stage holding the K step about to be used
-  locate(first + local);
-  issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int t = local; t < count; t += stride) {
-    const int cm0 = m0, cn0 = n0;                      // this tile's origin (m0/n0 move on at the prefetch)
-    const bool has_next = t + stride < count;
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) acc[i][j][rr] = 0.f;
-
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) {
-        issue(kt + 1, st ^ 1);                             // streams in under the MFMAs below
-      } else if (has_next) {
-        locate(first + t + stride);
-        issue(0, st ^ 1);                                  // next tile's first K step, under this step's MFMAs
-      }
-      const unsigned char* ta = smem + st * STAGE;
-      const unsigned char* tb = ta + A_BYTES;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int c = ks * 2 + (lane >> 5);
-        bf16x8 av[MI], bv[NI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-          av[i] = *reinterpret_cast<const bf16x8*>(ta + a_base[i] + (((a_hi[i] | c) ^ a_x[i]) << 4));
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-          bv[j] = *reinterpret_cast<const bf16x8*>(tb + b_base[j] + (((b_hi[j] | c) ^ b_x[j]) << 4));
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j], av[i], acc[i][j], 0, 0, 0);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMA pieces of the next K step have landed
-      __syncthreads();                                     // everyone's have, and stage `st` is free again
-      st ^= 1;
-    }
-    // stage st^1 was consumed last (all waves are past its reads); stage st holds the next tile's first K step.
-    bool fast = false;
-    if (p.dbg & 1) {
-      if (acc[0][0][0] == 12345.678f) static_cast<float*>(p.C)[0] = 1.f;
-      continue;
-    }
-    if constexpr (sizeof(OutT) == 2) {
-      fast = glds_fast_tile(p, cm0, cn0, BM, BN, M, N);
-      if (fast) {                                          // block-uniform
-        glds_store_tile<BM, BN, WM, WN, MI, NI, BN, 64 * NW>(acc, p, cm0, cn0, wm, wn, lane, tid,
-                                                             reinterpret_cast<uint16_t*>(smem + (st ^ 1) * STAGE));
-        if (has_next) __syncthreads();                     // copy-out reads done before the next DMA into this stage
-      }
-    }
-    if (!fast) gemm_epilogue<OutT, MI, NI>(acc, p, cm0 + wm * WM, cn0 + wn * WN, lane, M, N);
-  }
-}
-
+// ------------------------------------------------------------- register-staged kernel (any dtype, any K)
 template <typename T, typename OutT, int BM, int BN, int WAVES_M, int WAVES_N, int PF>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 4 * (BM * BN >= 256 * 128 ? 1 : 2))
 void gemm_nt_kernel(GemmArgs p) {
@@ -977,12 +821,6 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
     if (a.K % 64 == 0 && tiles(128, 128) >= 256) {       // direct-to-LDS path
       static const int force = getenv("TELL_GEMM_TILE") ? atoi(getenv("TELL_GEMM_TILE")) : 0;   // tuning aid
       static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); (void)hipGetDeviceProperties(&pr, d); return pr.multiProcessorCount; }();
-      if (force == 6) {   // persistent 128x128, 2 workgroups/CU, cross-tile prefetch
-        long g = tiles(128, 128) < 2L * n_cu ? tiles(128, 128) : 2L * n_cu;
-        g = (g + 7) / 8 * 8;
-        hipLaunchKernelGGL((gemm_nt_glds_persist_kernel<OutT, 128, 128, 2, 2>), dim3((unsigned)g), dim3(256), 0, stream, a);
-        return tell_check_launch("gemm_nt_glds_persist");
-      }
       if (force == 5) {   // 256x256, 8 waves (128x64 per wave), 2-stage
         hipLaunchKernelGGL((gemm_nt_glds_kernel<OutT, 256, 256, 2, 4>), dim3((unsigned)tiles(256, 256)), dim3(512), 0, stream, a);
         return tell_check_launch("gemm_nt_glds");
@@ -1033,8 +871,7 @@ extern "C" int tell_gemm_nt(const void* A, long lda, const void* B, long ldb, vo
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux; a.m_dev = m_dev;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
   a.bias_mode = bias_mode; a.act = act; a.accumulate = accumulate; a.alpha = alpha;
-  static const int dbg = getenv("TELL_GEMM_DEBUG") ? atoi(getenv("TELL_GEMM_DEBUG")) : 0;
-  a.dbg = dbg; a.asum = nullptr; a.asum_scale = 0.f; a.stat_mean = nullptr; a.stat_m2 = nullptr;
+  a.asum = nullptr; a.asum_scale = 0.f; a.stat_mean = nullptr; a.stat_m2 = nullptr;
   if (in_dtype == TELL_BF16)
     return out_dtype == TELL_BF16 ? launch_gemm<uint16_t, uint16_t>(a, stream)
                                   : launch_gemm<uint16_t, float>(a, stream);
@@ -1067,7 +904,7 @@ extern "C" int tell_gemm_bf16(const void* A, long lda, int trans_a, const void* 
   GemmArgs a;
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux; a.m_dev = m_dev;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
-  a.bias_mode = bias_mode; a.act = act; a.accumulate = accumulate; a.alpha = alpha; a.dbg = 0;
+  a.bias_mode = bias_mode; a.act = act; a.accumulate = accumulate; a.alpha = alpha;
   a.asum = a_colsum; a.asum_scale = a_colsum_scale; a.stat_mean = nullptr; a.stat_m2 = nullptr;
   if (trans_a && trans_b)
     return out_dtype == TELL_BF16 ? launch_gemm_tx<uint16_t, true, true>(a, stream) : launch_gemm_tx<float, true, true>(a, stream);
@@ -1093,7 +930,7 @@ extern "C" int tell_gemm_bn_stats(const void* A, long lda, const void* B, long l
   GemmArgs a;
   a.A = A; a.B = B; a.C = C; a.bias = nullptr; a.aux = nullptr; a.m_dev = nullptr;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
-  a.bias_mode = 0; a.act = 0; a.accumulate = 0; a.alpha = 1.f; a.dbg = 0; a.asum = nullptr; a.asum_scale = 0.f;
+  a.bias_mode = 0; a.act = 0; a.accumulate = 0; a.alpha = 1.f; a.asum = nullptr; a.asum_scale = 0.f;
   const long max_tiles = ((long)M + 63) / 64;
   a.stat_mean = workspace;
   a.stat_m2 = workspace + max_tiles * N;

@@ -180,6 +180,14 @@ class _DynamicConvDecoderBase(Decoder):
         out = self.adaptive_softmax.get_log_prob(net_output[0])
         return out if log_probs else out.exp()
 
+    def reorder_incremental_state(self, incremental_state, new_order):
+        """Beam search: row r of the new state is row new_order[r] of the old one (dynamic.py:338-342)."""
+        if incremental_state is None:
+            return
+        for key in incremental_state:
+            if 'DynamicConv1dTBC' in key:
+                incremental_state[key] = incremental_state[key].index_select(1, new_order)
+
     def filter_incremental_state(self, incremental_state, active_idx):             # :175-180
         if incremental_state is None:
             return

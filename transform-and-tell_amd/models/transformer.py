@@ -206,15 +206,17 @@ class CaptionModel(Model):
         return output_dict
 
     def generate(self, context, image, caption, face_embeds=None, obj_embeds=None, metadata=None, names=None,
-                 attn_idx=None):
+                 attn_idx=None, beam_size=1):
         caption_ids, _, contexts = self._forward(context, image, caption, face_embeds, obj_embeds)
-        log_probs, gen_ids, attns = self._generate(caption_ids, contexts, attn_idx)
+        log_probs, gen_ids, attns = self._generate(caption_ids, contexts, attn_idx, beam_size=beam_size)
         return {'gen_ids': gen_ids, 'log_probs': log_probs, 'attns': attns}
 
     # ---- :399-494 -----------------------------------------------------------------
     fast_generation = True      # projected-K/V cache + static batch; False = the reference's control flow
 
-    def _generate(self, caption_ids, contexts, attn_idx=None, gen_len=100, eos=2):
+    def _generate(self, caption_ids, contexts, attn_idx=None, gen_len=100, eos=2, beam_size=1):
+        if beam_size > 1:
+            return self._generate_beam(caption_ids, contexts, beam_size, gen_len, eos)
         if self.fast_generation:
             return self._generate_cached(caption_ids, contexts, gen_len, eos)
         return self._generate_reference_flow(caption_ids, contexts, attn_idx, gen_len, eos)
@@ -256,6 +258,63 @@ class CaptionModel(Model):
         steps = int(done_step.max())                                          # one sync at the end
         steps = max(steps, 1)
         return lps[:, :steps], ids[:, :steps + 1], []
+
+    @torch.no_grad()
+    def _generate_beam(self, caption_ids, contexts, beam_size, gen_len=100, eos=2, check_every=8):
+        """Beam search on the cached static-shape generator (SURVEY 8-f1 / BASELINE config 5; the reference itself
+        only samples top-1, transformer_faces_objects.py:443-464).  B*K rows (row = b*K + j) stay resident; the
+        projected K/V of the static contexts are computed once per caption and replicated per beam; the DynamicConv
+        input buffers are reordered by parent with the reference's `reorder_incremental_state` contract
+        (dynamic.py:338-342).  Score = sum of token log-probs (no length penalty); a finished hypothesis keeps its
+        score and is extended with pad only.  -> (log_probs [B,steps], ids [B,steps+1] of the best hypothesis, [])."""
+        dec = self.decoder
+        B, K = caption_ids.shape[0], int(beam_size)
+        dev = caption_ids.device
+        pad = self.padding_idx
+        rep = lambda t, dim: t.repeat_interleave(K, dim=dim).contiguous()           # noqa: E731
+        ctx = {}
+        for name, val in contexts.items():
+            if not torch.is_tensor(val):
+                continue
+            ctx[name] = rep(val, 0) if name.endswith('_mask') else rep(val, 1)
+        kv = [{name: tuple(rep(t, 1) for t in pair) for name, pair in layer_kv.items()}
+              for layer_kv in dec.project_contexts(contexts)]
+        state = {}
+        cur = rep(caption_ids[:, 0:1], 0)
+        cum = torch.full((B, K), float('-inf'), dtype=torch.float32, device=dev)
+        cum[:, 0] = 0.0                                     # all K rows start identical: only hypothesis 0 counts
+        finished = (cur[:, 0] == eos).view(B, K)
+        seqs = torch.full((B, K, gen_len + 1), pad, dtype=torch.long, device=dev)
+        seqs[:, :, 0] = cur.view(B, K)
+        lps = torch.zeros(B, K, gen_len, dtype=torch.float32, device=dev)
+        base = (torch.arange(B, device=dev) * K).view(B, 1)
+        n_steps = gen_len
+        for i in range(gen_len):
+            out = dec({self.index: cur}, ctx, incremental_state=state, kv_cache=kv)
+            lp = dec.adaptive_softmax.get_log_prob(out[0][:, -1:]).view(B, K, -1) / self.sampling_temp
+            V = lp.shape[-1]
+            lp = lp.masked_fill(finished.unsqueeze(-1), float('-inf'))
+            lp[..., pad] = torch.where(finished, torch.zeros_like(cum), lp[..., pad])
+            top, idx = (cum.unsqueeze(-1) + lp).view(B, K * V).topk(K, dim=1)        # sorted, best first
+            parent, tok = idx // V, idx % V
+            rows = (base + parent).view(-1)
+            was_finished = finished.gather(1, parent)
+            tok = torch.where(was_finished, torch.full_like(tok, pad), tok)
+            seqs = seqs.view(B * K, -1).index_select(0, rows).view(B, K, -1)
+            lps = lps.view(B * K, -1).index_select(0, rows).view(B, K, -1)
+            seqs[:, :, i + 1] = tok
+            lps[:, :, i] = torch.where(was_finished, torch.zeros_like(top), top - cum.gather(1, parent))
+            finished = was_finished | (tok == eos)
+            cum = top
+            dec.reorder_incremental_state(state, rows)
+            cur = tok.view(B * K, 1)
+            if (i + 1) % check_every == 0 and bool(finished.all()):
+                n_steps = i + 1
+                break
+        best = seqs[:, 0]                                    # topk keeps hypotheses sorted by score
+        steps = int((best[:, 1:] != pad).sum(1).max())       # one sync: length of the longest best caption
+        steps = max(min(steps, n_steps), 1)
+        return lps[:, 0, :steps], best[:, :steps + 1], []
 
     @torch.no_grad()
     def _generate_reference_flow(self, caption_ids, contexts, attn_idx=None, gen_len=100, eos=2):
