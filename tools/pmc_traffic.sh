@@ -2,7 +2,7 @@
 # usage (GPU box, repo root): tools/pmc_traffic.sh <kernel-substring> <out.json>
 # HBM traffic per launch of one kernel: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over a short
 # single-stream bench run, averaged over that kernel's dispatches; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md).
-kern=$1; out=$2
+kern=$1; out=$2   # add a "kernel" key with bench.py's short name by hand if bench should pick it up
 root=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
