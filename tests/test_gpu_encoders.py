@@ -91,3 +91,29 @@ def test_roberta_matches_oracle(dtype):
         r = rel(out[l].cpu()[keep], ref[l][keep])
         assert r < (2e-4 if dtype == torch.float32 else 4e-2), (l, r)
     assert (out[0].cpu()[~keep] == 0).all()            # fairseq zeroes padded positions after the embedding LN
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_resnet_graph_replay_equals_eager(dtype):
+    """graphs.GraphedCall: eager (1st call), capture + replay (2nd), replay (3rd...) give the eager results,
+    including the BatchNorm running statistics that the captured kernels keep updating."""
+    import copy
+    import tell_amd
+    from tell_amd import graphs
+    from tell_amd.models.resnet import ResNetFeatureExtractor as HRes
+    tell_amd.set_compute_dtype(dtype)
+    torch.manual_seed(1)
+    eager = HRes((2, 1, 1, 1), width=16).to(DEV).train()
+    graphed = copy.deepcopy(eager)
+    g = graphs.GraphedCall(graphed, 'test-resnet')
+    gen = torch.Generator().manual_seed(3)
+    for it in range(4):
+        img = torch.randn(2, 3, 64, 64, generator=gen).to(DEV)
+        want = eager(img)
+        got = g(img, key=(True, dtype))
+        assert torch.equal(got, want), it                       # same kernels, same order -> bit-identical
+    e = g.entries[next(iter(g.entries))]
+    assert e['state'] == 'ready', e.get('error')                # the graph path really ran
+    for (n1, b1), (n2, b2) in zip(eager.named_buffers(), graphed.named_buffers()):
+        if 'running' in n1:
+            assert torch.equal(b1, b2), n1

@@ -177,3 +177,35 @@ def test_beam_search_matches_oracle_definition_fp32(kind):
         _, one, _ = gpu._generate_beam(cids, gctx, 1, gen_len=24)
         n = min(greedy.shape[1], one.shape[1])
         assert torch.equal(greedy.cpu()[:, :n], one.cpu()[:, :n])
+
+
+def test_pipelined_steps_equal_plain_steps_fp32():
+    """Trainer.train_one_batch(batch, next_batch=...) launches the next batch's encoders underneath the current
+    step; losses and parameters must equal the plain schedule exactly (same kernels, no dropout)."""
+    import copy
+    import tell_amd
+    from tell_amd.build import build_model
+    from tell_amd.data import synthetic_batch
+    from tell_amd.training import Trainer
+    tell_amd.set_compute_dtype(torch.float32)
+    torch.manual_seed(2)
+    a = build_model('faces_objects', _Res(True), _Rob(1024), n_bert_layers=3, **KW)
+    _no_dropout(a)
+    b = copy.deepcopy(a)
+    ocfg = dict(lr=5e-3, warmup=0.5, t_total=6, b1=0.9, b2=0.98, e=1e-6, weight_decay=1e-5, max_grad_norm=0.1)
+    ta, tb = Trainer(a, dict(ocfg), device=DEV), Trainer(b, dict(ocfg), device=DEV)
+    batches = []
+    for s in range(4):
+        bt = synthetic_batch(B=3, article_len=20, caption_len=9, faces_objects=True, vocab=600, cutoffs=(100, 300),
+                             seed=90 + s, variable=True)
+        batches.append({k: ({kk: vv.to(DEV) for kk, vv in v.items()} if isinstance(v, dict) else v.to(DEV))
+                        for k, v in bt.items()})
+    clone = lambda x: {k: (dict(v) if isinstance(v, dict) else v) for k, v in x.items()}   # noqa: E731
+    for s in range(4):
+        la = ta.train_one_batch(clone(batches[s]))
+        lb = tb.train_one_batch(clone(batches[s]), next_batch=batches[s + 1] if s + 1 < 4 else None)
+        assert float(la) == float(lb), (s, float(la), float(lb))
+    tb.finish_update()
+    torch.cuda.synchronize()
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(p, q), n
