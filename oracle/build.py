@@ -2,7 +2,8 @@
 
 TEST INFRASTRUCTURE - see oracle/__init__.py.
 """
-from .decoders import CONTEXTS_FACES_OBJECTS, CONTEXTS_FLATTENED, DynamicConvDecoder
+from .decoders import (CONTEXTS_FACES_OBJECTS, CONTEXTS_FACES_PARALLEL, CONTEXTS_FLATTENED, CONTEXTS_NO_IMAGE,
+                       DynamicConvDecoder)
 from .models import CaptionModel
 from .modules import (AdaptiveEmbedding, AdaptiveLoss, SinusoidalPositionalEmbedding,
                       SumTextFieldEmbedder)
@@ -23,6 +24,10 @@ def build_decoder(kind='faces_objects', vocab_size=50265, dim=1024, heads=16, ff
     expt/nytimes/5_transformer_roberta (`dynamic_conv_decoder_flattened`)."""
     if kind == 'faces_objects':
         contexts = CONTEXTS_FACES_OBJECTS
+    elif kind == 'faces_parallel':                       # expt/*/8_transformer_faces
+        contexts = CONTEXTS_FACES_PARALLEL
+    elif kind == 'flattened_no_image':                   # expt/*/4_no_image
+        contexts = (('article', article_dim),)
     else:
         contexts = (CONTEXTS_FLATTENED[0], ('article', article_dim))
     kw = dict(decoder_conv_dim=dim, decoder_attention_heads=heads, decoder_ffn_embed_dim=ffn,
@@ -35,5 +40,5 @@ def build_decoder(kind='faces_objects', vocab_size=50265, dim=1024, heads=16, ff
 def build_model(kind, resnet, roberta, n_bert_layers=25, **decoder_kw):
     dec = build_decoder(kind, **decoder_kw)
     return CaptionModel(dec, AdaptiveLoss(padding_idx=1), resnet, roberta,
-                        use_faces_objects=(kind == 'faces_objects'), weigh_bert=True,
+                        use_faces_objects=(kind in ('faces_objects', 'faces_parallel')), weigh_bert=True,
                         n_bert_layers=n_bert_layers)

@@ -16,6 +16,8 @@ from .modules import (AdaptiveSoftmax, DynamicConv1dTBC, GehringLinear, MultiHea
 
 CONTEXTS_FLATTENED = (('image', 2048), ('article', 1024))
 CONTEXTS_FACES_OBJECTS = (('image', 2048), ('article', 1024), ('faces', 512), ('obj', 2048))
+CONTEXTS_FACES_PARALLEL = (('image', 2048), ('article', 1024), ('faces', 512))    # decoder_faces_parallel.py:22
+CONTEXTS_NO_IMAGE = (('article', 1024),)                                         # decoder_flattened_no_image.py:22
 
 
 class DynamicConvDecoderLayer(nn.Module):

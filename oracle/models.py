@@ -62,10 +62,11 @@ class CaptionModel(nn.Module):
         if self.use_faces_objects:                                        # :373-379, :390-393
             fm = torch.isnan(face_embeds).any(dim=-1)
             face_embeds[fm] = 0
-            om = torch.isnan(obj_embeds).any(dim=-1)
-            obj_embeds[om] = 0
-            contexts.update(faces=face_embeds.transpose(0, 1), faces_mask=fm,
-                            obj=obj_embeds.transpose(0, 1), obj_mask=om)
+            contexts.update(faces=face_embeds.transpose(0, 1), faces_mask=fm)
+            if obj_embeds is not None:                                    # transformer_faces.py has no objects
+                om = torch.isnan(obj_embeds).any(dim=-1)
+                obj_embeds[om] = 0
+                contexts.update(obj=obj_embeds.transpose(0, 1), obj_mask=om)
         return caption_ids, target_ids, contexts
 
     # ---- transformer_faces_objects.py:67-140 -------------------------------

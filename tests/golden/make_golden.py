@@ -21,6 +21,7 @@ import ref_import  # noqa: E402
 import seeded  # noqa: E402
 
 dfo, dfl, tfo, tfl, _ = ref_import.import_models()
+dfp, dni = ref_import.import_decoder_variants()
 from tell.modules.attention.multi_head import MultiHeadAttention  # noqa: E402
 from tell.modules.convolutions.dynamic import DynamicConv1dTBC  # noqa: E402
 from tell.modules.criteria.adaptive_loss import AdaptiveLoss  # noqa: E402
@@ -210,7 +211,7 @@ def adaptive_softmax():
                         gx=x.grad, **grads)})
 
 
-ART_DIM = {'flattened': 64, 'faces_objects': 1024}   # flattened: kdim == embed_dim -> in_proj_weight path
+ART_DIM = {'flattened': 64, 'faces_objects': 1024, 'faces_parallel': 1024, 'flattened_no_image': 64}   # flattened: kdim == embed_dim -> in_proj_weight path
 
 
 def _mk_contexts(B, S, kind, seed):
@@ -219,10 +220,13 @@ def _mk_contexts(B, S, kind, seed):
            'article': torch.randn(S, B, ART_DIM[kind], generator=g),
            'article_mask': torch.zeros(B, S, dtype=torch.bool)}
     ctx['article_mask'][0, S - 3:] = True
-    if kind == 'faces_objects':
+    if kind == 'flattened_no_image':
+        del ctx['image'], ctx['image_mask']
+    if kind in ('faces_objects', 'faces_parallel'):
         ctx['faces'] = torch.randn(3, B, 512, generator=g)
         ctx['faces_mask'] = torch.zeros(B, 3, dtype=torch.bool)
         ctx['faces_mask'][1, 1:] = True
+    if kind == 'faces_objects':
         ctx['obj'] = torch.randn(6, B, 2048, generator=g).abs()
         ctx['obj_mask'] = torch.zeros(B, 6, dtype=torch.bool)
         ctx['obj_mask'][0, 4:] = True
@@ -243,11 +247,15 @@ def _ref_decoder(kind):
     emb = _ref_embedder(600, 64, (100, 300), init_size=512)
     if kind == 'faces_objects':
         return dfo.DynamicConvFacesObjectsDecoder(None, emb, **DEC_KW)
+    if kind == 'faces_parallel':
+        return dfp.DynamicConvFacesParallelDecoder(None, emb, **DEC_KW)
+    if kind == 'flattened_no_image':
+        return dni.DynamicConvDecoderNoImage(None, emb, article_embed_size=ART_DIM[kind], **DEC_KW)
     return dfl.DynamicConvDecoder(None, emb, article_embed_size=ART_DIM[kind], **DEC_KW)
 
 
-def decoders():
-    for kind in ('flattened', 'faces_objects'):
+def decoders(kinds=('flattened', 'faces_objects', 'faces_parallel', 'flattened_no_image')):
+    for kind in kinds:
         torch.manual_seed(50)
         dec = _ref_decoder(kind).eval()
         for p in dec.parameters():          # make biases / LN params non-trivial
@@ -269,9 +277,10 @@ def decoders():
         loss, n = crit(dec.adaptive_softmax, out, tgt)
         (loss / n).backward()
         names = ['layers.0.linear1.weight_v', 'layers.0.linear1.weight_g', 'layers.3.conv.weight_linear.weight',
-                 'layers.1.context_attns.article.' + ('in_proj_weight' if kind == 'flattened' else 'v_proj_weight'),
-                 'layers.1.context_attns.image.k_proj_weight',
-                 'layers.2.context_attns.image.bias_k', 'layers.2.context_attn_lns.article.weight',
+                 'layers.1.context_attns.article.' + ('in_proj_weight' if kind.startswith('flattened') else 'v_proj_weight'),
+                 'layers.1.context_attns.' + ('article.in_proj_bias' if kind == 'flattened_no_image' else 'image.k_proj_weight'),
+                 'layers.2.context_attns.' + ('article' if kind == 'flattened_no_image' else 'image') + '.bias_k',
+                 'layers.2.context_attn_lns.article.weight',
                  'layers.3.fc2.bias', 'layers.0.context_fc.weight_v',
                  'embedder.token_embedder_adaptive.embeddings.0.0.weight',
                  'embedder.token_embedder_adaptive.embeddings.2.1.weight',
@@ -353,6 +362,10 @@ def models():
                                                            gen_ids=gen_ids, gen_log_probs=lp)})
         print('   gen lengths:', [(r != 1).sum().item() for r in gen_ids], 'gen shape', tuple(gen_ids.shape))
 
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'decoder_variants':
+    decoders(('faces_parallel', 'flattened_no_image'))       # only the fixtures added later
+    sys.exit(0)
 
 if __name__ == '__main__':
     gehring()

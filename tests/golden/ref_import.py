@@ -206,3 +206,11 @@ def import_models():
     finally:
         pass
     return dfo, dfl, tfo, tfl, _orig_hub
+
+
+def import_decoder_variants():
+    """The context-table siblings of the two decoders: 3-context `faces_parallel`
+    (expt/*/8_transformer_faces, a1-a3) and article-only `flattened_no_image` (expt/*/4_no_image)."""
+    import_models()
+    return (importlib.import_module('tell.models.decoder_faces_parallel'),
+            importlib.import_module('tell.models.decoder_flattened_no_image'))

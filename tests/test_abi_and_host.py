@@ -126,6 +126,22 @@ def test_reference_expt_configs_instantiate_unmodified():
     m2, _ = config.from_config(REF_CFG.replace('9_transformer_objects', '5_transformer_roberta'),
                                resnet=object(), roberta=object())
     assert m2.decoder.layers[0].context_names == ['image', 'article']
+    # the context-table siblings and every other config of the transformer family
+    m3, _ = config.from_config(REF_CFG.replace('9_transformer_objects', '8_transformer_faces'),
+                               resnet=object(), roberta=object())
+    assert type(m3).__name__ == 'TransformerFacesModel'
+    assert m3.decoder.layers[0].context_names == ['image', 'article', 'faces']
+    m4, _ = config.from_config(REF_CFG.replace('9_transformer_objects', '4_no_image'),
+                               resnet=object(), roberta=object())
+    assert m4.decoder.layers[0].context_names == ['article']
+    for name in ('6_transformer_weighted_roberta', '7_transformer_location_aware'):
+        mm, _ = config.from_config(REF_CFG.replace('9_transformer_objects', name), resnet=object(), roberta=object())
+        assert mm.decoder.layers[0].context_names == ['image', 'article'], name
+    for ds in ('goodnews',):
+        for name in ('4_no_image', '5_transformer_roberta', '6_transformer_weighted_roberta', '8_transformer_faces',
+                     '9_transformer_objects'):
+            config.from_config(REF_CFG.replace('nytimes', ds).replace('9_transformer_objects', name),
+                               resnet=object(), roberta=object())
     from tell_amd.common.registrable import Registrable
     from tell_amd.training.trainer import TrainerBase
     assert TrainerBase.by_name(params['trainer']['type']).__name__ == 'CallbackApexTrainer'

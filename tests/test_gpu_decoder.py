@@ -43,14 +43,14 @@ def _ctx_to_dev(ins, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('kind', ['flattened', 'faces_objects'])
+@pytest.mark.parametrize('kind', ['flattened', 'faces_objects', 'faces_parallel', 'flattened_no_image'])
 def test_decoder_golden(golden, dtype, kind):
     import tell_amd
     from tell_amd.build import build_decoder
     from tell_amd.modules import AdaptiveLoss
     tell_amd.set_compute_dtype(dtype)
     fx = golden('decoder_' + kind)
-    dec = build_decoder(kind, article_dim=64 if kind == 'flattened' else 1024, **DEC_KW).eval()
+    dec = build_decoder(kind, article_dim=64 if kind.startswith('flattened') else 1024, **DEC_KW).eval()
     dec.load_state_dict(fx['sd'], strict=False)
     dec.to(DEV)
     ins = fx['in']

@@ -209,3 +209,44 @@ def test_pipelined_steps_equal_plain_steps_fp32():
     torch.cuda.synchronize()
     for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
         assert torch.equal(p, q), n
+
+
+@pytest.mark.parametrize('kind', ['faces_parallel', 'flattened_no_image'])
+def test_model_variants_train_step_matches_oracle_fp32(kind):
+    """`transformer_faces` + `dynamic_conv_decoder_faces_parallel` (expt/*/8_transformer_faces) and
+    `transformer_flattened` + `dynamic_conv_decoder_flattened_no_image` (expt/*/4_no_image) - one full step."""
+    import tell_amd
+    from oracle.build import build_model as obuild
+    from tell_amd.build import build_model
+    from tell_amd.data import synthetic_batch
+    tell_amd.set_compute_dtype(torch.float32)
+    torch.manual_seed(3)
+    adim = 1024 if kind == 'faces_parallel' else 64
+    gpu = build_model(kind, _Res(True), _Rob(adim), n_bert_layers=3, article_dim=adim, **KW)
+    cpu = obuild(kind, _Res(False), _Rob(adim), n_bert_layers=3, article_dim=adim, **KW).train()
+    cpu.load_state_dict({k: v for k, v in gpu.state_dict().items() if k in cpu.state_dict()}, strict=False)
+    _no_dropout(gpu)
+    _no_dropout(cpu)
+    gpu.to(DEV).train()
+    batch = synthetic_batch(B=3, article_len=20, caption_len=9, faces_objects=(kind == 'faces_parallel'), vocab=600,
+                            cutoffs=(100, 300), seed=31, variable=True)
+    if kind == 'faces_parallel':
+        batch.pop('obj_embeds')
+    ref = cpu(**{k: (dict(v) if isinstance(v, dict) else v.clone()) for k, v in batch.items()})
+    ref['loss'].backward()
+    dev_batch = {k: ({kk: vv.to(DEV) for kk, vv in v.items()} if isinstance(v, dict) else v.to(DEV))
+                 for k, v in batch.items()}
+    out = gpu(**dev_batch)
+    out['loss'].backward()
+    tell_amd.ops.join_wgrad_stream()
+    torch.cuda.synchronize()
+    assert abs(float(out['loss']) - float(ref['loss'])) <= 1e-3 * abs(float(ref['loss']))
+    cp = dict(cpu.named_parameters())
+    checked = 0
+    for n, p in gpu.named_parameters():
+        if n.startswith(('resnet', 'roberta')) or p.grad is None or cp[n].grad is None:
+            continue
+        g, r = p.grad.detach().cpu(), cp[n].grad
+        assert (g - r).norm() <= 2e-3 * (r.norm() + 1e-6), n
+        checked += 1
+    assert checked > 40

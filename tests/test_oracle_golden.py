@@ -134,10 +134,10 @@ def test_adaptive_softmax_and_loss(golden):
 DEC_KW = dict(vocab_size=600, dim=64, heads=4, ffn=128, cutoff=(100, 300))
 
 
-@pytest.mark.parametrize('kind', ['flattened', 'faces_objects'])
+@pytest.mark.parametrize('kind', ['flattened', 'faces_objects', 'faces_parallel', 'flattened_no_image'])
 def test_decoder(golden, kind):
     fx = golden('decoder_' + kind)
-    dec = build_decoder(kind, article_dim=64 if kind == 'flattened' else 1024, **DEC_KW).eval()
+    dec = build_decoder(kind, article_dim=64 if kind.startswith('flattened') else 1024, **DEC_KW).eval()
     load_sd(dec, fx['sd'])
     ins = fx['in']
     ctx = {k: v for k, v in ins.items() if k not in ('ids', 'target')}

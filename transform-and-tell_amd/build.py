@@ -1,7 +1,8 @@
 """Programmatic constructors equivalent to the `model:` section of the expt/ configs
 (used by tests, bench.py and smoke(); `config.py` builds the same objects from YAML)."""
-from .models.decoders import DynamicConvDecoder, DynamicConvFacesObjectsDecoder
-from .models.transformer import TransformerFacesObjectModel, TransformerFlattenedModel
+from .models.decoders import (DynamicConvDecoder, DynamicConvDecoderNoImage, DynamicConvFacesObjectsDecoder,
+                              DynamicConvFacesParallelDecoder)
+from .models.transformer import TransformerFacesModel, TransformerFacesObjectModel, TransformerFlattenedModel
 from .modules import AdaptiveEmbedding, AdaptiveLoss, SinusoidalPositionalEmbedding, SumTextFieldEmbedder
 
 
@@ -31,11 +32,16 @@ def build_decoder(kind='faces_objects', vocab_size=50265, dim=1024, heads=16, ff
     kw = decoder_kwargs(vocab_size, dim, heads, ffn, kernels, cutoff)
     if kind == 'faces_objects':
         return DynamicConvFacesObjectsDecoder(None, emb, **kw)
+    if kind in ('faces_parallel', 'faces'):                  # expt/*/8_transformer_faces
+        return DynamicConvFacesParallelDecoder(None, emb, **kw)
+    if kind == 'flattened_no_image':                         # expt/*/4_no_image
+        return DynamicConvDecoderNoImage(None, emb, article_embed_size=article_dim, **kw)
     return DynamicConvDecoder(None, emb, article_embed_size=article_dim, **kw)
 
 
 def build_model(kind, resnet=None, roberta=None, weigh_bert=True, n_bert_layers=25, **decoder_kw):
     dec = build_decoder(kind, **decoder_kw)
-    cls = TransformerFacesObjectModel if kind == 'faces_objects' else TransformerFlattenedModel
+    cls = {'faces_objects': TransformerFacesObjectModel, 'faces': TransformerFacesModel,
+           'faces_parallel': TransformerFacesModel}.get(kind, TransformerFlattenedModel)
     return cls(None, dec, AdaptiveLoss(padding_idx=1), weigh_bert=weigh_bert, vocab_size=decoder_kw.get('vocab_size', 50265),
                resnet=resnet, roberta=roberta, n_bert_layers=n_bert_layers)

@@ -208,3 +208,18 @@ class DynamicConvDecoder(_DynamicConvDecoderBase):
     """tell/models/decoder_flattened.py:23 (`contexts['image'|'article']`)."""
     CONTEXTS = (('image', 2048), ('article', 1024))
     ARTICLE_DIM_FROM_ARG = True
+
+
+@Decoder.register('dynamic_conv_decoder_faces_parallel')
+class DynamicConvFacesParallelDecoder(_DynamicConvDecoderBase):
+    """tell/models/decoder_faces_parallel.py:22 (`contexts['image'|'article'|'faces']`; expt/*/8_transformer_faces
+    and the copying ablations): the faces+objects layer without the object attention (context_size 3E, :240)."""
+    CONTEXTS = (('image', 2048), ('article', 1024), ('faces', 512))
+    ARTICLE_DIM_FROM_ARG = False
+
+
+@Decoder.register('dynamic_conv_decoder_flattened_no_image')
+class DynamicConvDecoderNoImage(_DynamicConvDecoderBase):
+    """tell/models/decoder_flattened_no_image.py:22 (`contexts['article']` only; expt/*/4_no_image)."""
+    CONTEXTS = (('article', 1024),)
+    ARTICLE_DIM_FROM_ARG = True

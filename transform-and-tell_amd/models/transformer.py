@@ -59,6 +59,7 @@ class Model(nn.Module, Registrable):
 
 class CaptionModel(Model):
     USE_FACES_OBJECTS = False
+    EXTRA_CONTEXTS = ()          # which of ('faces', 'obj') the model feeds to its decoder
 
     def __init__(self, vocab, decoder, criterion, evaluate_mode=False, attention_dim=1024, hidden_size=1024,
                  dropout=0.1, vocab_size=50264, model_name='roberta-base', namespace='bpe', index='roberta',
@@ -170,8 +171,10 @@ class CaptionModel(Model):
             'article': x_article.transpose(0, 1),
             'article_mask': article_mask,
         }
-        if self.USE_FACES_OBJECTS:                                         # :373-379
+        if self.EXTRA_CONTEXTS:                                            # :373-379
             for key, emb in (('faces', face_embeds), ('obj', obj_embeds)):
+                if key not in self.EXTRA_CONTEXTS:
+                    continue
                 Bf, n, dim = emb.shape
                 if n == 0 or dim == 0:
                     contexts[key] = emb.new_zeros(n, Bf, dim).to(dtype)
@@ -370,9 +373,19 @@ class CaptionModel(Model):
 class TransformerFacesObjectModel(CaptionModel):
     """tell/models/transformer_faces_objects.py:22-23"""
     USE_FACES_OBJECTS = True
+    EXTRA_CONTEXTS = ('faces', 'obj')
+
+
+@Model.register('transformer_faces')
+class TransformerFacesModel(CaptionModel):
+    """tell/models/transformer_faces.py:21-22 (expt/*/8_transformer_faces): image + article + faces, driven by
+    `dynamic_conv_decoder_faces_parallel`; the faces+objects forward without `obj_embeds`."""
+    USE_FACES_OBJECTS = True
+    EXTRA_CONTEXTS = ('faces',)
 
 
 @Model.register('transformer_flattened')
 class TransformerFlattenedModel(CaptionModel):
-    """tell/models/transformer_flattened.py:23-24"""
+    """tell/models/transformer_flattened.py:23-24 (also drives `dynamic_conv_decoder_flattened_no_image`)"""
     USE_FACES_OBJECTS = False
+    EXTRA_CONTEXTS = ()
