@@ -96,7 +96,8 @@ def test_gemm_kmajor_forms(M, N, K):
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('M,N,K', [(64, 64, 64), (130, 70, 96), (512, 1024, 1024), (37, 5002, 128),
                                    (1000, 48, 1024), (300, 300, 2048), (2048, 2048, 512),
-                                   (4096, 4096, 256), (5000, 6200, 128), (8192, 4096, 320)])   # 256x128 / 256x256 tiles, ragged
+                                   (4096, 4096, 256), (5000, 6200, 128), (8192, 4096, 320),
+                                   (8192, 3072, 128)])   # 128x128 / 256x256 / 256x192 direct-to-LDS tiles, ragged
 def test_gemm_nt(dtype, M, N, K):
     from tell_amd import ops
     g = torch.Generator().manual_seed(M * 7 + N)

@@ -5,7 +5,7 @@ import sys, torch
 sys.path.insert(0, '.')
 import tell_amd
 from tell_amd import ops
-shapes = [(8192, 8192, 8192), (8192, 4096, 1024), (8192, 1024, 4096), (8192, 3072, 1024), (8192, 1024, 1024), (4096, 4096, 4096)]
+shapes = [(8192, 3072, 1024), (8192, 4096, 1024), (8192, 1024, 4096), (8192, 3072, 1024), (8192, 1024, 1024), (4096, 4096, 4096)]
 for M, N, K in shapes:
     a = torch.randn(M, K, device='cuda').bfloat16(); b = torch.randn(N, K, device='cuda').bfloat16()
     out = torch.zeros(M, N, device='cuda', dtype=torch.bfloat16)

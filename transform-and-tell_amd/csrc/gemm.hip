@@ -452,7 +452,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(Ge
     __syncthreads();                                     // everyone's have, and buffer `st` is free again
   }
   // ---- epilogue.  Full interior bf16 tiles go through LDS (the tile buffers are free now).
-  if constexpr (sizeof(OutT) == 2 && BM * (BN + 8) * 2 + 64 * NW * 4 <= 2 * STAGE) {
+  if constexpr (sizeof(OutT) == 2 && BM * (BN + 8) * 2 + 64 * NW * 4 <= 2 * STAGE && (64 * NW) % BN == 0) {
     if (p.stat_mean) {                                   // block-uniform: conv + BatchNorm statistics
       staged_store_stats<BM, BN, WM, WN, MI, NI, 64 * NW>(acc, p, m0, n0, tm, wm, wn, lane, tid,
                                                           reinterpret_cast<uint16_t*>(smem), M, N);
@@ -821,6 +821,12 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
     if (a.K % 64 == 0 && tiles(128, 128) >= 256) {       // direct-to-LDS path
       static const int force = getenv("TELL_GEMM_TILE") ? atoi(getenv("TELL_GEMM_TILE")) : 0;   // tuning aid
       static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); (void)hipGetDeviceProperties(&pr, d); return pr.multiProcessorCount; }();
+      // 256x192 (8 waves as 4x2, 64x96 per wave): the QKV projection (N = 3072) quantises to whole rounds with it
+      if ((force == 0 || force == 9) && a.N % 192 == 0 && tiles(256, 192) % n_cu == 0 && a.K <= 2048 && !a.accumulate &&
+          !a.stat_mean && tiles(256, 256) % n_cu != 0) {
+        hipLaunchKernelGGL((gemm_nt_glds_kernel<OutT, 256, 192, 4, 2>), dim3((unsigned)tiles(256, 192)), dim3(512), 0, stream, a);
+        return tell_check_launch("gemm_nt_glds");
+      }
       if (force == 5) {   // 256x256, 8 waves (128x64 per wave), 2-stage
         hipLaunchKernelGGL((gemm_nt_glds_kernel<OutT, 256, 256, 2, 4>), dim3((unsigned)tiles(256, 256)), dim3(512), 0, stream, a);
         return tell_check_launch("gemm_nt_glds");

@@ -83,7 +83,9 @@ def gemm(a, b, out=None, out_dtype=None, bias=None, bias_mode=0, act=0, aux=None
         names = ('f32', 'bf16')[hip.dt(a)], ('f32', 'bf16')[hip.dt(out)]
         if bf and a.shape[1] % 64 == 0 and tiles(128, 128) >= 256:
             n_cu = torch.cuda.get_device_properties(a.device).multi_processor_count
-            tile = (256, 256) if (tiles(256, 256) % n_cu == 0 and a.shape[1] <= 2048 and not accumulate) else (128, 128)
+            small_k = a.shape[1] <= 2048 and not accumulate
+            tile = ((256, 256) if (small_k and tiles(256, 256) % n_cu == 0) else
+                    (256, 192) if (small_k and N % 192 == 0 and tiles(256, 192) % n_cu == 0) else (128, 128))
             kname = 'gemm_nt_glds_kernel<%s,%d,%d>' % (names[1], tile[0], tile[1])
         else:
             tile = ((256, 128) if bf and tiles(256, 128) >= 256 else (128, 128) if tiles(128, 128) >= 256
