@@ -45,8 +45,6 @@ def cpu_baseline(sample_b=2, threads=None):
 
     def step():
         opt.zero_grad()
-        with torch.no_grad():
-            pass
         out = model(context={'roberta': batch['context']['roberta'].clone()}, image=batch['image'],
                     caption={'roberta': batch['caption']['roberta'].clone()})
         out['loss'].backward()
@@ -54,7 +52,14 @@ def cpu_baseline(sample_b=2, threads=None):
     t0 = time.time()
     step()
     dt = time.time() - t0
+    cpu = 'unknown'
+    try:
+        with open('/proc/cpuinfo') as f:
+            cpu = next((ln.split(':', 1)[1].strip() for ln in f if ln.startswith('model name')), cpu)
+    except OSError:
+        pass
     return {'value': round(sample_b / dt, 4), 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'cpu_model': cpu,
             'sample': '1 full optimisation step (ResNet-152 + RoBERTa-large fwd, 2-ctx decoder fwd+loss+bwd, '
                       'BertAdam) of the fp32 CPU oracle on %d samples, %.1f s' % (sample_b, dt)}
 
@@ -82,12 +87,22 @@ def main():
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
+    if world > 1 or os.environ.get('TELL_DP_SELFTEST') in ('1', '2'):
+        # Must precede the first HIP call.  The step schedule keeps 4 hardware queues busy (GPU_MAX_HW_QUEUES
+        # default); an RCCL communicator adds its own, and with MORE than 4 active queues per process the command
+        # processor time-slices them (measured on MI355X, 1 rank: 1125 -> 940 samples/s; 8 queues: 780).  Three
+        # queues for our streams + RCCL's keeps the total at 4 (1085 samples/s with the communicator alive).
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', '3')
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
-    if world > 1:
-        dist.init_process_group('nccl', device_id=dev)       # RCCL on ROCm
+    import tell_amd
+    tell_amd.streams.warm(dev)         # before RCCL creates its streams: keeps ours on distinct hardware queues
+    if world > 1 or os.environ.get('TELL_DP_SELFTEST') in ('1', '2'):   # '2': group only, no DP collectives
+        dist.init_process_group(os.environ.get('TELL_DP_BACKEND', 'nccl'),      # RCCL on ROCm
+                                **({'device_id': dev} if os.environ.get('TELL_DP_BACKEND', 'nccl') == 'nccl' and
+                                   os.environ.get('TELL_DP_LAZY') != '1' else {}))
     import tell_amd
     from tell_amd import prof
     from tell_amd.build import build_model
@@ -214,7 +229,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.cpu_sample)
         print(json.dumps(result))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -6,7 +6,7 @@ ABI of include/tell_hip.h; this package is the Python host side that mirrors the
 reference's plugin surface (`tell.models`, `tell.modules`, registrable names,
 constructor arguments, state_dict keys).
 """
-from . import hip, runtime  # noqa: F401
+from . import hip, runtime, streams  # noqa: F401
 from .runtime import (compute_dtype, manual_seed, set_compute_dtype,  # noqa: F401
                       bump_weights_epoch)
 

@@ -7,19 +7,13 @@ from collections import defaultdict
 import torch
 import torch.nn as nn
 
-from .. import graphs, ops
+from .. import graphs, ops, streams
 from ..common.registrable import Registrable
 
 
 _OVERLAP = os.environ.get('TELL_ENCODER_OVERLAP', '1') != '0'
-_side_streams = {}
-
-
 def _side_stream(device, name='resnet'):
-    s = _side_streams.get((device, name))
-    if s is None:
-        s = _side_streams[(device, name)] = torch.cuda.Stream(device=device)
-    return s
+    return streams.get(name, device)
 
 
 class EncodedBatch:

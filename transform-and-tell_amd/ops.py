@@ -14,7 +14,7 @@ import os
 import torch
 from torch.autograd import Function
 
-from . import hip, prof
+from . import hip, prof, streams
 from . import runtime as rt
 
 call = hip.call
@@ -277,7 +277,7 @@ def _flush_wgrad():
     dev = main.device
     side = _WGRAD['streams'].get(dev)
     if side is None:
-        side = _WGRAD['streams'][dev] = torch.cuda.Stream(device=dev)
+        side = _WGRAD['streams'][dev] = streams.get('wgrad', dev)
     side.wait_stream(main)                          # every queued input was produced on `main` before now
     with torch.cuda.stream(side), hip.bound_stream():
         for job, keep in q:

@@ -14,7 +14,7 @@ import os
 
 import torch
 
-from .. import hip, ops
+from .. import hip, ops, streams
 from .. import runtime as rt
 from ..common.registrable import Registrable
 from . import dp
@@ -31,6 +31,9 @@ class Trainer:
         import torch.distributed as dist
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.world = self.dist.get_world_size() if self.dist else 1
+        # TELL_DP_SELFTEST=1: run every collective of the data-parallel path even in a 1-rank group (single-GPU check
+        # of the RCCL calls, the streams they are issued on and their ordering)
+        self.dp = self.world > 1 or (self.dist is not None and os.environ.get('TELL_DP_SELFTEST') == '1')
         self.rank = self.dist.get_rank() if self.dist else 0
         self.model = model.to(device)
         apply_no_grad(model, no_grad)
@@ -43,7 +46,7 @@ class Trainer:
         self.nan_check = nan_check
         self.bucket_elems = bucket_mb * (1 << 20) // 4
         self.batch_num_total = 0
-        if self.world > 1:                    # identical initial weights on every rank
+        if self.dp:                           # identical initial weights on every rank
             self.dist.broadcast(self.flat.flat, src=0)
             self.flat.refresh_shadow()
             rt.bump_weights_epoch()
@@ -52,7 +55,7 @@ class Trainer:
         if async_update is None:
             async_update = os.environ.get('TELL_ASYNC_UPDATE', '1') != '0'
         self.async_update = async_update and torch.device(device).type == 'cuda'
-        self.update_stream = torch.cuda.Stream(device=device) if self.async_update else None
+        self.update_stream = streams.get('update', device) if self.async_update else None
         self.flat.zero_grad()
         self.model.register_state_dict_pre_hook(lambda *a, **k: self.finish_update())
 
@@ -91,14 +94,14 @@ class Trainer:
                                     self.model.encode(next_batch['context'], next_batch['image'], ahead=True))
         out = self.model(**batch, **extra)                               # :220 / :194
         loss = out['loss']
-        if self.world > 1:
+        if self.dp:
             scaled = loss * dp.loss_weight(out['sample_size'].to(torch.float32).reshape(1), self.dist,
                                            self.world).reshape(())
         else:
             scaled = loss
         if self.nan_check:                                               # :225-227 (host sync, collective)
             bad = torch.isnan(loss.detach()).to(torch.float32)
-            if self.world > 1:
+            if self.dp:
                 self.dist.all_reduce(bad)
             if bad.item() > 0:
                 return None
@@ -118,7 +121,7 @@ class Trainer:
         return loss.detach()
 
     def _update(self):
-        if self.world > 1:
+        if self.dp:
             self._all_reduce_grads()
         self.optimizer.step(grad_scale=1.0 / self.world, zero_grad=True)  # :238 (+ :214 of the next batch)
 
