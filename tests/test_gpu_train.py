@@ -181,7 +181,7 @@ def test_beam_search_matches_oracle_definition_fp32(kind):
 
 def test_pipelined_steps_equal_plain_steps_fp32():
     """Trainer.train_one_batch(batch, next_batch=...) launches the next batch's encoders underneath the current
-    step; losses and parameters must equal the plain schedule exactly (same kernels, no dropout)."""
+    step; losses and parameters must equal the plain schedule (same kernels, no dropout)."""
     import copy
     import tell_amd
     from tell_amd.build import build_model
@@ -204,11 +204,12 @@ def test_pipelined_steps_equal_plain_steps_fp32():
     for s in range(4):
         la = ta.train_one_batch(clone(batches[s]))
         lb = tb.train_one_batch(clone(batches[s]), next_batch=batches[s + 1] if s + 1 < 4 else None)
-        assert float(la) == float(lb), (s, float(la), float(lb))
+        # not bit-exact: the embedding-table gradient accumulates duplicate tokens with fp32 atomics
+        assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(la)), (s, float(la), float(lb))
     tb.finish_update()
     torch.cuda.synchronize()
     for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
-        assert torch.equal(p, q), n
+        assert (p - q).norm() <= 1e-4 * (p.norm() + 1e-6), n
 
 
 @pytest.mark.parametrize('kind', ['faces_parallel', 'flattened_no_image'])
@@ -250,3 +251,47 @@ def test_model_variants_train_step_matches_oracle_fp32(kind):
         assert (g - r).norm() <= 2e-3 * (r.norm() + 1e-6), n
         checked += 1
     assert checked > 40
+
+
+def test_dp_code_path_one_rank_rccl(monkeypatch):
+    """Every collective of the data-parallel step (token-count all-reduce, NaN flag, bf16-on-the-wire gradient
+    all-reduce on the update stream) through a real 1-rank RCCL group; result == the non-DP trainer up to the
+    bf16 rounding of the exchanged gradients."""
+    import copy
+    import torch.distributed as dist
+    import tell_amd
+    from tell_amd.build import build_model
+    from tell_amd.data import synthetic_batch
+    from tell_amd.training import Trainer
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    tell_amd.manual_seed(4)
+    torch.manual_seed(4)
+    a = build_model('flattened', _Res(True), _Rob(64), n_bert_layers=3, article_dim=64, **KW)
+    _no_dropout(a)
+    b = copy.deepcopy(a)
+    ocfg = dict(lr=2e-3, warmup=0.5, t_total=6, max_grad_norm=0.1, weight_decay=0.0)
+    plain = Trainer(a, dict(ocfg), device=DEV)
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    monkeypatch.setenv('MASTER_PORT', '29581')
+    monkeypatch.setenv('TELL_DP_SELFTEST', '1')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        dpt = Trainer(b, dict(ocfg), device=DEV, nan_check=True)
+        assert dpt.dp and dpt.allreduce_dtype == torch.bfloat16
+        for s in range(3):
+            bt = synthetic_batch(B=3, article_len=20, caption_len=9, vocab=600, cutoffs=(100, 300), seed=40 + s)
+            dev = {k: ({kk: vv.to(DEV) for kk, vv in v.items()} if isinstance(v, dict) else v.to(DEV))
+                   for k, v in bt.items()}
+            clone = lambda x: {k: (dict(v) if isinstance(v, dict) else v) for k, v in x.items()}   # noqa: E731
+            l0, l1 = plain.train_one_batch(clone(dev)), dpt.train_one_batch(clone(dev))
+            assert abs(float(l0) - float(l1)) <= 2e-2 * abs(float(l0)), (s, float(l0), float(l1))
+        dpt.finish_update()
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    # BertAdam normalises every update by sqrt(v): elements whose gradient is ~0 can move by +-lr in either
+    # direction after the bf16 rounding, so compare in the large (whole-model norm), not per tensor
+    num = sum(float((p - q).norm() ** 2) for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters())
+              if p.requires_grad)
+    den = sum(float(p.norm() ** 2) for n, p in a.named_parameters() if p.requires_grad)
+    assert (num / den) ** 0.5 < 1e-2, (num / den) ** 0.5

@@ -27,7 +27,7 @@ class TrainerBase(Registrable):
 
 class Trainer:
     def __init__(self, model, optimizer_cfg=None, no_grad=(r'^resnet', r'^roberta'), device='cuda',
-                 nan_check=False, bucket_mb=256, async_update=None):
+                 nan_check=False, bucket_mb=256, async_update=None, allreduce_dtype=None):
         import torch.distributed as dist
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.world = self.dist.get_world_size() if self.dist else 1
@@ -46,6 +46,12 @@ class Trainer:
         self.nan_check = nan_check
         self.bucket_elems = bucket_mb * (1 << 20) // 4
         self.batch_num_total = 0
+        # gradients travel in bf16 when the model computes in bf16 (dp.all_reduce_flat_bf16), in fp32 in parity mode
+        if allreduce_dtype is None:
+            allreduce_dtype = torch.bfloat16 if (rt.compute_dtype() == torch.bfloat16 and
+                                                 torch.device(device).type == 'cuda' and
+                                                 os.environ.get('TELL_ALLREDUCE_FP32') != '1') else torch.float32
+        self.allreduce_dtype, self._wire = allreduce_dtype, None
         if self.dp:                           # identical initial weights on every rank
             self.dist.broadcast(self.flat.flat, src=0)
             self.flat.refresh_shadow()
@@ -126,7 +132,14 @@ class Trainer:
         self.optimizer.step(grad_scale=1.0 / self.world, zero_grad=True)  # :238 (+ :214 of the next batch)
 
     def _all_reduce_grads(self):
-        dp.all_reduce_flat(self.flat.grad, self.dist, self.bucket_elems)
+        if self.allreduce_dtype == torch.bfloat16:
+            if self._wire is None:
+                self._wire = torch.empty(self.flat.total, dtype=torch.bfloat16, device=self.flat.grad.device)
+            dp.all_reduce_flat_bf16(
+                self.flat.grad, self._wire, self.dist, 2 * self.bucket_elems,
+                lambda s, d: hip.call('tell_cast', s, hip.dt(s), d, hip.dt(d), s.numel()))
+        else:
+            dp.all_reduce_flat(self.flat.grad, self.dist, self.bucket_elems)
 
 
 @TrainerBase.register('callback_apex')
