@@ -133,6 +133,7 @@ def main():
         torch.cuda.synchronize()
         tell_amd.runtime.wait_weight_update()
         tr_mod._OVERLAP = not flag
+        tell_amd.graphs.ENABLED = not flag         # eager encoders: every GEMM launch passes the timing hook
         ops._WGRAD['enabled'] = not flag
         trainer.async_update = (not flag) and trainer.update_stream is not None
 
@@ -192,7 +193,10 @@ def main():
                                    '+ BertAdam' % args.batch if args.model == 'flattened' else
                                    'BASELINE configs[2] shape: faces+objects model, batch %d/GPU' % args.batch,
                        'global_batch': world * args.batch, 'article_len': 512, 'caption_len': 33,
-                       'parallelism': 'dp%d' % world, 'final_loss_bits': round(float(loss), 4)},
+                       'parallelism': 'dp%d' % world, 'final_loss_bits': round(float(loss), 4),
+                       'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+                       'resnet_hipgraph': sorted({e['state'] for e in getattr(model.__dict__.get('_resnet_graph'),
+                                                                              'entries', {}).values()})},
         }
         if prof_summary:
             # dominant kernel = largest estimated total time (avg of the timed samples x all its launches)

@@ -41,6 +41,10 @@ const char* tell_last_error(void);
 void tell_set_error(const char* msg);
 /* host evaluation of the dropout hash / threshold used by every kernel (csrc/common.h) */
 uint32_t tell_hash32_host(uint32_t seed, uint32_t salt, uint64_t idx);
+/* hipGraph capture of kernels with dropout: while `counter` (device uint32) is registered, every RNG kernel adds
+ * counter * odd-constant to its salt, so a captured graph draws fresh masks after the owner increments it;
+ * NULL (default) = eager behaviour.  The stream argument is ignored (uniform binding signature). */
+int tell_set_rng_step_ptr(const void* counter, tell_stream_t stream);
 uint32_t tell_drop_threshold_host(float p);
 
 /* ---- GEMM (every nn.Linear / F.linear / 1x1 conv on the path) --------------

@@ -117,3 +117,35 @@ def test_resnet_graph_replay_equals_eager(dtype):
     for (n1, b1), (n2, b2) in zip(eager.named_buffers(), graphed.named_buffers()):
         if 'running' in n1:
             assert torch.equal(b1, b2), n1
+
+
+def test_roberta_graph_replay_dropout_step_counter():
+    """graphs.GraphedCall(rng=True): eval-mode replay == eager bit for bit; train-mode replays draw FRESH dropout
+    masks through the device step counter (frozen seed/salt kernel arguments + tell_step_salt), with the same
+    statistics as eager dropout."""
+    import tell_amd
+    from tell_amd import graphs
+    from tell_amd.models.roberta import RobertaEncoder as HRob
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    tell_amd.manual_seed(9)
+    torch.manual_seed(2)
+    m = HRob(vocab=300, dim=128, ffn=256, layers=2, heads=2, max_positions=160).to(DEV).eval()
+    ids = torch.randint(3, 300, (2, 150), device=DEV)
+    ids[:, 0] = 0
+    fn = lambda x: m.extract_features(x, return_all_hiddens=True)       # noqa: E731
+    g = graphs.GraphedCall(fn, 'test-roberta', rng=True)
+    for it in range(3):
+        assert torch.equal(g(ids, key='eval'), fn(ids)), it
+    assert g.entries[(tuple(ids.shape), ids.dtype, ids.device.index, 'eval')]['state'] == 'ready'
+    m.train()
+    eager = fn(ids).float()
+    outs = [g(ids, key='train').float().clone() for _ in range(4)]       # call 0 eager, 1 capture + replay, 2, 3 replay
+    e = g.entries[(tuple(ids.shape), ids.dtype, ids.device.index, 'train')]
+    assert e['state'] == 'ready', e.get('error')
+    assert int(e['counter']) == 3
+    for a, b in ((1, 2), (2, 3), (1, 3)):
+        d = (outs[a] - outs[b]).norm() / outs[a].norm()
+        assert d > 1e-2, (a, b, float(d))                                # different masks every replay
+    for o in outs:
+        assert torch.isfinite(o).all()
+        assert abs(float(o[-1].std()) - float(eager[-1].std())) < 0.1 * float(eager[-1].std())

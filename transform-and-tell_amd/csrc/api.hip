@@ -20,5 +20,10 @@ extern "C" int tell_device_count(void) {
 
 // host-side evaluation of the dropout hash (same function the kernels use) - lets CPU tests pin
 // the numpy restatement in tell_amd/rng.py without a GPU
+const uint32_t* g_tell_rng_step = nullptr;
+extern "C" int tell_set_rng_step_ptr(const void* counter, hipStream_t) {
+  g_tell_rng_step = static_cast<const uint32_t*>(counter);
+  return TELL_OK;
+}
 extern "C" uint32_t tell_hash32_host(uint32_t seed, uint32_t salt, uint64_t idx) { return tell_hash32(seed, salt, idx); }
 extern "C" uint32_t tell_drop_threshold_host(float p) { return tell_drop_threshold(p); }

@@ -92,6 +92,7 @@ struct AttnArgs {
   int B, H, Tq, S;
   int has_bias, has_zero;
   uint32_t thr; float inv_keep; uint32_t seed, salt;
+  const uint32_t* step;      // replayable dropout (common.h tell_step_salt); NULL in eager mode
   // backward only
   const void *dout, *o;           // same layout as out
   void *dq, *dk, *dv;             // same layouts as q, k, v
@@ -101,6 +102,7 @@ struct AttnArgs {
 // ------------------------------------------------------------------ forward
 template <typename T, int D, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
+  const uint32_t salt_eff = tell_step_salt(p.salt, p.step);   // hoisted: one scalar load per kernel
   using C_ = ACfg<T, D>;
   constexpr int DS = C_::DS, SS = C_::SS, DP = C_::DP, DF = C_::DF;
   constexpr int WAVE_ELEMS = 2 * 32 * DS + DP * SS + 32 * SS;   // Qs, Ks, Vt, Ps
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
         const int kk = acc_row(r, lane);
         float v = pr[r];
         if (p.thr)
-          v *= tell_keep(p.seed, p.salt, ((uint64_t)bh * p.Tq + t) * S_total + (s0 + kk), p.thr, p.inv_keep);
+          v *= tell_keep(p.seed, salt_eff, ((uint64_t)bh * p.Tq + t) * S_total + (s0 + kk), p.thr, p.inv_keep);
         Elem<T>::st(Ps + qi * SS + kk, v);                    // P[q][key], key contiguous
       }
     }
@@ -284,6 +286,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {   // -> v_
 
 template <typename T, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_tile64_kernel(AttnArgs p) {
+  const uint32_t salt_eff = tell_step_salt(p.salt, p.step);   // hoisted: one scalar load per kernel
   constexpr int D = 64, KT = 64, NW = 4;
   constexpr int VEC = Elem<T>::VEC;
   constexpr int PAD = sizeof(T) == 2 ? 8 : 1;
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(256) void attn_fwd_tile64_kernel(AttnArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
               float k0, k1;
-              tell_keep2(p.seed, p.salt, base + (f * 32 + (r & 3) + 8 * (r >> 2)), p.thr, p.inv_keep, k0, k1);
+              tell_keep2(p.seed, salt_eff, base + (f * 32 + (r & 3) + 8 * (r >> 2)), p.thr, p.inv_keep, k0, k1);
               st[f][r] *= k0;
               st[f][r + 1] *= k1;
             }
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(256) void attn_fwd_tile64_kernel(AttnArgs p) {
           for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-              st[f][r] *= tell_keep(p.seed, p.salt, base + (f * 32 + (r & 3) + 8 * (r >> 2)), p.thr, p.inv_keep);
+              st[f][r] *= tell_keep(p.seed, salt_eff, base + (f * 32 + (r & 3) + 8 * (r >> 2)), p.thr, p.inv_keep);
         }
       }
       ls += __shfl_xor(ls, 32, 64);
@@ -507,6 +510,7 @@ __device__ __forceinline__ bf16x8 attn_tr_frag(const uint16_t* p0, const uint16_
 
 template <bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_reg_kernel(AttnArgs p) {
+  const uint32_t salt_eff = tell_step_salt(p.salt, p.step);   // hoisted: one scalar load per kernel
   using T = uint16_t;
   constexpr int D = 64, KT = 64, NW = 4;
   constexpr int KS = 72;                             // K tile row stride (144 B): conflict-free ds_read_b128
@@ -635,7 +639,7 @@ __global__ __launch_bounds__(256) void attn_fwd_reg_kernel(AttnArgs p) {
       if constexpr (DROP) {
         const uint64_t base = ((uint64_t)bh * p.Tq + t) * S_total + s0 + 4 * hh;
         if ((S_total & 1) == 0 && tell_keep_row_ok(base >> 1, 32)) {
-          const TellKeepRow row = tell_keep_row(p.seed, p.salt, base >> 1);    // base is even here
+          const TellKeepRow row = tell_keep_row(p.seed, salt_eff, base >> 1);    // base is even here
 #pragma unroll
           for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -651,7 +655,7 @@ __global__ __launch_bounds__(256) void attn_fwd_reg_kernel(AttnArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
               float k0, k1;
-              tell_keep2(p.seed, p.salt, base + (f * 32 + (r & 3) + 8 * (r >> 2)), p.thr, p.inv_keep, k0, k1);
+              tell_keep2(p.seed, salt_eff, base + (f * 32 + (r & 3) + 8 * (r >> 2)), p.thr, p.inv_keep, k0, k1);
               st[f][r] *= k0;
               st[f][r + 1] *= k1;
             }
@@ -660,7 +664,7 @@ __global__ __launch_bounds__(256) void attn_fwd_reg_kernel(AttnArgs p) {
           for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-              st[f][r] *= tell_keep(p.seed, p.salt, base + (f * 32 + (r & 3) + 8 * (r >> 2)), p.thr, p.inv_keep);
+              st[f][r] *= tell_keep(p.seed, salt_eff, base + (f * 32 + (r & 3) + 8 * (r >> 2)), p.thr, p.inv_keep);
         }
       }
       ls += __shfl_xor(ls, 32, 64);
@@ -716,6 +720,7 @@ __global__ __launch_bounds__(256) void attn_fwd_reg_kernel(AttnArgs p) {
 // each key tile is owned by exactly one wave, so dK/dV need no atomics.
 template <typename T, int D, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(AttnArgs p) {
+  const uint32_t salt_eff = tell_step_salt(p.salt, p.step);   // hoisted: one scalar load per kernel
   using C_ = ACfg<T, D>;
   constexpr int DS = C_::DS, SS = C_::SS, DP = C_::DP, DF = C_::DF;
   constexpr int SHARED_ELEMS = 2 * 32 * DS + 2 * DP * SS;       // Qs, dOs, Qt, dOt
@@ -827,7 +832,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(AttnArgs p) {
           const float pv = ok ? __expf(st[r] - lse) : 0.f;
           float keep = 1.f;
           if (p.thr)
-            keep = tell_keep(p.seed, p.salt, ((uint64_t)bh * p.Tq + t) * S_total + s, p.thr, p.inv_keep);
+            keep = tell_keep(p.seed, salt_eff, ((uint64_t)bh * p.Tq + t) * S_total + s, p.thr, p.inv_keep);
           const float ds = pv * (dp[r] * keep - delta);
           Elem<T>::st(PdT + kk * SS + qi, pv * keep);         // Pd^T[key][q]
           Elem<T>::st(dST + kk * SS + qi, ds);                // dS^T[key][q]
@@ -945,7 +950,7 @@ static int fill_args(AttnArgs& a, const void* q, const void* k, const void* v, v
   a.q_st = q_st; a.q_sb = q_sb; a.k_ss = k_ss; a.k_sb = k_sb; a.v_ss = v_ss; a.v_sb = v_sb;
   a.o_st = o_st; a.o_sb = o_sb; a.B = B; a.H = H; a.Tq = Tq; a.S = S;
   a.has_bias = bias_k ? 1 : 0; a.has_zero = has_zero;
-  a.thr = p > 0.f ? tell_drop_threshold(p) : 0u; a.inv_keep = 1.f / (1.f - p); a.seed = seed; a.salt = salt;
+  a.thr = p > 0.f ? tell_drop_threshold(p) : 0u; a.inv_keep = 1.f / (1.f - p); a.seed = seed; a.salt = salt; a.step = g_tell_rng_step;
   a.dout = nullptr; a.o = nullptr; a.dq = a.dk = a.dv = nullptr; a.dbias_k = a.dbias_v = nullptr;
   return TELL_OK;
 }

@@ -92,6 +92,16 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---------------------------------------------------------------- replayable dropout (hipGraph capture)
+// A captured kernel's seed/salt arguments are frozen.  While `g_tell_rng_step` points at a device counter
+// (tell_set_rng_step_ptr), every launcher passes that pointer along and the kernel adds counter * odd constant to
+// its salt, so a graph replays with fresh masks once the owner bumps the counter; NULL (the default, eager mode)
+// leaves the salt untouched.
+extern const uint32_t* g_tell_rng_step;
+__device__ __forceinline__ uint32_t tell_step_salt(uint32_t salt, const uint32_t* step) {
+  return step ? salt + *step * 0x632BE5ABu : salt;
+}
+
 // ---------------------------------------------------------------- counter-based RNG for dropout
 // Stateless.  One 32-bit hash serves an aligned PAIR of element indices (2i, 2i+1): element idx keeps iff
 // the 16-bit half (idx & 1) of hash(seed, salt, idx >> 1) is >= floor(p * 2^16).  Kernels whose lanes own

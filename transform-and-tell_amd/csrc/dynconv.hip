@@ -13,8 +13,9 @@ __global__ __launch_bounds__(256) void dynconv_fwd_kernel(const T* __restrict__ 
                                                           const T* __restrict__ logits,
                                                           T* __restrict__ y, float* __restrict__ taps,
                                                           int Tn, int B, int H, int K, int R,
-                                                          uint32_t thr, float inv_keep, uint32_t seed,
-                                                          uint32_t salt) {
+                                                          uint32_t thr, float inv_keep, uint32_t seed, uint32_t salt,
+    const uint32_t* __restrict__ step) {
+  salt = tell_step_salt(salt, step);
   const int lane = threadIdx.x & 63;
   const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // (t*B + b)*H + h
   if (wid >= (long)Tn * B * H) return;
@@ -53,8 +54,9 @@ __global__ __launch_bounds__(256) void dynconv_bwd_taps_kernel(const T* __restri
                                                                const float* __restrict__ taps,
                                                                T* __restrict__ dlogits, int Tn, int B,
                                                                int H, int K, int R, uint32_t thr,
-                                                               float inv_keep, uint32_t seed,
-                                                               uint32_t salt) {
+                                                               float inv_keep, uint32_t seed, uint32_t salt,
+    const uint32_t* __restrict__ step) {
+  salt = tell_step_salt(salt, step);
   const int lane = threadIdx.x & 63;
   const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wid >= (long)Tn * B * H) return;
@@ -86,8 +88,9 @@ __global__ __launch_bounds__(256) void dynconv_bwd_x_kernel(const T* __restrict_
                                                             const float* __restrict__ taps,
                                                             T* __restrict__ dx, int accumulate, int Tn,
                                                             int B, int H, int K, int R, uint32_t thr,
-                                                            float inv_keep, uint32_t seed,
-                                                            uint32_t salt) {
+                                                            float inv_keep, uint32_t seed, uint32_t salt,
+    const uint32_t* __restrict__ step) {
+  salt = tell_step_salt(salt, step);
   const int lane = threadIdx.x & 63;
   const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wid >= (long)Tn * B * H) return;
@@ -121,9 +124,9 @@ extern "C" int tell_dynconv_fwd(const void* x, const void* logits, void* y, floa
   long waves = (long)T * B * H;
   dim3 grid((unsigned)((waves + 3) / 4));
   if (dtype == TELL_BF16)
-    hipLaunchKernelGGL((dynconv_fwd_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)x, (const uint16_t*)logits, (uint16_t*)y, taps, T, B, H, K, R, thr, ik, seed, salt);
+    hipLaunchKernelGGL((dynconv_fwd_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)x, (const uint16_t*)logits, (uint16_t*)y, taps, T, B, H, K, R, thr, ik, seed, salt, g_tell_rng_step);
   else
-    hipLaunchKernelGGL((dynconv_fwd_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, (const float*)logits, (float*)y, taps, T, B, H, K, R, thr, ik, seed, salt);
+    hipLaunchKernelGGL((dynconv_fwd_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, (const float*)logits, (float*)y, taps, T, B, H, K, R, thr, ik, seed, salt, g_tell_rng_step);
   return tell_check_launch("dynconv_fwd");
 }
 
@@ -138,11 +141,11 @@ extern "C" int tell_dynconv_bwd(const void* x, const void* dy, const float* taps
   long waves = (long)T * B * H;
   dim3 grid((unsigned)((waves + 3) / 4));
   if (dtype == TELL_BF16) {
-    hipLaunchKernelGGL((dynconv_bwd_taps_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)x, (const uint16_t*)dy, taps, (uint16_t*)dlogits, T, B, H, K, R, thr, ik, seed, salt);
-    hipLaunchKernelGGL((dynconv_bwd_x_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)dy, taps, (uint16_t*)dx, dx_accumulate, T, B, H, K, R, thr, ik, seed, salt);
+    hipLaunchKernelGGL((dynconv_bwd_taps_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)x, (const uint16_t*)dy, taps, (uint16_t*)dlogits, T, B, H, K, R, thr, ik, seed, salt, g_tell_rng_step);
+    hipLaunchKernelGGL((dynconv_bwd_x_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)dy, taps, (uint16_t*)dx, dx_accumulate, T, B, H, K, R, thr, ik, seed, salt, g_tell_rng_step);
   } else {
-    hipLaunchKernelGGL((dynconv_bwd_taps_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, (const float*)dy, taps, (float*)dlogits, T, B, H, K, R, thr, ik, seed, salt);
-    hipLaunchKernelGGL((dynconv_bwd_x_kernel<float>), grid, dim3(256), 0, stream, (const float*)dy, taps, (float*)dx, dx_accumulate, T, B, H, K, R, thr, ik, seed, salt);
+    hipLaunchKernelGGL((dynconv_bwd_taps_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, (const float*)dy, taps, (float*)dlogits, T, B, H, K, R, thr, ik, seed, salt, g_tell_rng_step);
+    hipLaunchKernelGGL((dynconv_bwd_x_kernel<float>), grid, dim3(256), 0, stream, (const float*)dy, taps, (float*)dx, dx_accumulate, T, B, H, K, R, thr, ik, seed, salt, g_tell_rng_step);
   }
   return tell_check_launch("dynconv_bwd");
 }

@@ -245,7 +245,9 @@ extern "C" int tell_glu_bwd(const void* h, const void* dy, void* dh, long rows, 
 // ---------------------------------------------------------------- dropout  y = x * keep(idx)
 template <typename T>
 __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long n, uint32_t thr,
-                               float inv_keep, uint32_t seed, uint32_t salt) {
+                               float inv_keep, uint32_t seed, uint32_t salt,
+                               const uint32_t* __restrict__ step) {
+  salt = tell_step_salt(salt, step);
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long stride = (long)gridDim.x * blockDim.x;
   for (; i < n; i += stride)
@@ -258,8 +260,8 @@ extern "C" int tell_dropout(const void* x, void* y, long n, float p, uint32_t se
   int g = grid_for(n, 256 * 4);
   uint32_t thr = tell_drop_threshold(p);
   float ik = 1.f / (1.f - p);
-  if (dtype == TELL_BF16) hipLaunchKernelGGL((dropout_kernel<uint16_t>), dim3(g), dim3(256), 0, stream, (const uint16_t*)x, (uint16_t*)y, n, thr, ik, seed, salt);
-  else hipLaunchKernelGGL((dropout_kernel<float>), dim3(g), dim3(256), 0, stream, (const float*)x, (float*)y, n, thr, ik, seed, salt);
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((dropout_kernel<uint16_t>), dim3(g), dim3(256), 0, stream, (const uint16_t*)x, (uint16_t*)y, n, thr, ik, seed, salt, g_tell_rng_step);
+  else hipLaunchKernelGGL((dropout_kernel<float>), dim3(g), dim3(256), 0, stream, (const float*)x, (float*)y, n, thr, ik, seed, salt, g_tell_rng_step);
   return tell_check_launch("dropout");
 }
 

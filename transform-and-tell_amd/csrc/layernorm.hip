@@ -12,7 +12,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, lo
                                                      long ld_y, float* __restrict__ mean,
                                                      float* __restrict__ rstd, int rows, int C,
                                                      float eps, uint32_t thr, float inv_keep,
-                                                     uint32_t seed, uint32_t salt) {
+                                                     uint32_t seed, uint32_t salt,
+    const uint32_t* __restrict__ step) {
+  salt = tell_step_salt(salt, step);
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -44,8 +46,9 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x
                                                          const float* __restrict__ beta, T* __restrict__ y,
                                                          long ld_y, float* __restrict__ mean,
                                                          float* __restrict__ rstd, int rows, float eps,
-                                                         uint32_t thr, float inv_keep, uint32_t seed,
-                                                         uint32_t salt) {
+                                                         uint32_t thr, float inv_keep, uint32_t seed, uint32_t salt,
+    const uint32_t* __restrict__ step) {
+  salt = tell_step_salt(salt, step);
   constexpr int VEC = Elem<T>::VEC, C = 64 * VEC * NCH;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -100,7 +103,7 @@ extern "C" int tell_layernorm_fwd(const void* x, long ld_x, const void* res, lon
   const bool aligned = ld_x % vec == 0 && ld_y % vec == 0 && (res == nullptr || ld_r % vec == 0) &&
                        ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)res & 15) == 0;
 #define LNV(T, NCH) hipLaunchKernelGGL((ln_fwd_vec_kernel<T, NCH>), grid, dim3(256), 0, stream, (const T*)x, ld_x, \
-    (const T*)res, ld_r, gamma, beta, (T*)y, ld_y, mean, rstd, rows, eps, thr, ik, seed, salt)
+    (const T*)res, ld_r, gamma, beta, (T*)y, ld_y, mean, rstd, rows, eps, thr, ik, seed, salt, g_tell_rng_step)
   if (aligned && C % (64 * vec) == 0 && C / (64 * vec) <= 4 && C / (64 * vec) != 3) {
     const int nch = C / (64 * vec);
     if (dtype == TELL_BF16) { if (nch == 1) LNV(uint16_t, 1); else if (nch == 2) LNV(uint16_t, 2); else LNV(uint16_t, 4); }
@@ -109,9 +112,9 @@ extern "C" int tell_layernorm_fwd(const void* x, long ld_x, const void* res, lon
   }
 #undef LNV
   if (dtype == TELL_BF16)
-    hipLaunchKernelGGL((ln_fwd_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)x, ld_x, (const uint16_t*)res, ld_r, gamma, beta, (uint16_t*)y, ld_y, mean, rstd, rows, C, eps, thr, ik, seed, salt);
+    hipLaunchKernelGGL((ln_fwd_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)x, ld_x, (const uint16_t*)res, ld_r, gamma, beta, (uint16_t*)y, ld_y, mean, rstd, rows, C, eps, thr, ik, seed, salt, g_tell_rng_step);
   else
-    hipLaunchKernelGGL((ln_fwd_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, ld_x, (const float*)res, ld_r, gamma, beta, (float*)y, ld_y, mean, rstd, rows, C, eps, thr, ik, seed, salt);
+    hipLaunchKernelGGL((ln_fwd_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, ld_x, (const float*)res, ld_r, gamma, beta, (float*)y, ld_y, mean, rstd, rows, C, eps, thr, ik, seed, salt, g_tell_rng_step);
   return tell_check_launch("layernorm_fwd");
 }
 
@@ -131,8 +134,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, l
                                                      T* __restrict__ dx, long ld_dx,
                                                      T* __restrict__ dres, long ld_dres, int dres_acc,
                                                      float* __restrict__ partial, int rows, int C,
-                                                     uint32_t thr, float inv_keep, uint32_t seed,
-                                                     uint32_t salt) {
+                                                     uint32_t thr, float inv_keep, uint32_t seed, uint32_t salt,
+    const uint32_t* __restrict__ step) {
+  salt = tell_step_salt(salt, step);
   extern __shared__ float sm[];                 // [4 waves][2][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* my_g = sm + (long)wave * 2 * C;
@@ -192,8 +196,9 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
                                                          T* __restrict__ dx, long ld_dx,
                                                          T* __restrict__ dres, long ld_dres, int dres_acc,
                                                          float* __restrict__ partial, int rows,
-                                                         uint32_t thr, float inv_keep, uint32_t seed,
-                                                         uint32_t salt) {
+                                                         uint32_t thr, float inv_keep, uint32_t seed, uint32_t salt,
+    const uint32_t* __restrict__ step) {
+  salt = tell_step_salt(salt, step);
   constexpr int VEC = Elem<T>::VEC, C = 64 * VEC * NCH;
   __shared__ float sm[4][2][C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -317,14 +322,14 @@ extern "C" int tell_layernorm_bwd(const void* dy, long ld_dy, const void* x, lon
   const int nch = C % (64 * vec) == 0 ? C / (64 * vec) : 0;
 #define LNB(T, NCH) hipLaunchKernelGGL((ln_bwd_vec_kernel<T, NCH>), dim3(nb), dim3(256), 0, stream, (const T*)dy, ld_dy, \
     (const T*)x, ld_x, (const T*)res, ld_r, gamma, mean, rstd, (T*)dx, ld_dx, (T*)dres, ld_dres, dres_accumulate,      \
-    partial, rows, thr, ik, seed, salt)
+    partial, rows, thr, ik, seed, salt, g_tell_rng_step)
   if (aligned && (nch == 1 || nch == 2 || (nch == 4 && dtype == TELL_F32))) {
     if (dtype == TELL_BF16) { if (nch == 1) LNB(uint16_t, 1); else LNB(uint16_t, 2); }
     else { if (nch == 1) LNB(float, 1); else if (nch == 2) LNB(float, 2); else LNB(float, 4); }
   } else if (dtype == TELL_BF16)
-    hipLaunchKernelGGL((ln_bwd_kernel<uint16_t>), dim3(nb), dim3(256), smem, stream, (const uint16_t*)dy, ld_dy, (const uint16_t*)x, ld_x, (const uint16_t*)res, ld_r, gamma, mean, rstd, (uint16_t*)dx, ld_dx, (uint16_t*)dres, ld_dres, dres_accumulate, partial, rows, C, thr, ik, seed, salt);
+    hipLaunchKernelGGL((ln_bwd_kernel<uint16_t>), dim3(nb), dim3(256), smem, stream, (const uint16_t*)dy, ld_dy, (const uint16_t*)x, ld_x, (const uint16_t*)res, ld_r, gamma, mean, rstd, (uint16_t*)dx, ld_dx, (uint16_t*)dres, ld_dres, dres_accumulate, partial, rows, C, thr, ik, seed, salt, g_tell_rng_step);
   else
-    hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(nb), dim3(256), smem, stream, (const float*)dy, ld_dy, (const float*)x, ld_x, (const float*)res, ld_r, gamma, mean, rstd, (float*)dx, ld_dx, (float*)dres, ld_dres, dres_accumulate, partial, rows, C, thr, ik, seed, salt);
+    hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(nb), dim3(256), smem, stream, (const float*)dy, ld_dy, (const float*)x, ld_x, (const float*)res, ld_r, gamma, mean, rstd, (float*)dx, ld_dx, (float*)dres, ld_dres, dres_accumulate, partial, rows, C, thr, ik, seed, salt, g_tell_rng_step);
   int rc = tell_check_launch("layernorm_bwd");
   if (rc) return rc;
 #undef LNB

@@ -16,11 +16,18 @@ from . import hip
 ENABLED = os.environ.get('TELL_GRAPHS', '1') != '0'
 
 
+MAX_SIGNATURES = 4      # every captured signature keeps its activations in a private pool; further ones run eagerly
+
+
 class GraphedCall:
-    def __init__(self, fn, name='graph'):
+    def __init__(self, fn, name='graph', rng=False):
+        """rng: the function contains dropout.  Its kernels are captured with a device step counter registered
+        (tell_set_rng_step_ptr) and the counter is bumped before every replay, so the frozen seed/salt arguments
+        still give fresh masks (csrc/common.h tell_step_salt)."""
         self.fn = fn
         self.name = name
-        self.entries = {}          # signature -> dict(state=..., graph, static_in, static_out)
+        self.rng = rng
+        self.entries = {}          # signature -> dict(state=..., graph, static_in, static_out[, counter])
 
     def reset(self):
         self.entries.clear()
@@ -32,22 +39,32 @@ class GraphedCall:
         sig = (tuple(x.shape), x.dtype, x.device.index, key)
         e = self.entries.get(sig)
         if e is None:
-            self.entries[sig] = {'state': 'warm'}
+            ready = sum(1 for v in self.entries.values() if v['state'] in ('warm', 'ready'))
+            self.entries[sig] = {'state': 'warm' if ready < MAX_SIGNATURES else 'eager'}
             return self.fn(x)
         if e['state'] == 'eager':
             return self.fn(x)
         if e['state'] == 'warm':
             try:
                 static_in = x.clone()
+                counter = torch.zeros(1, dtype=torch.int32, device=x.device) if self.rng else None
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    with hip.bound_stream():            # launches must go to the CAPTURING stream
-                        static_out = self.fn(static_in)
-                e.update(state='ready', graph=g, static_in=static_in, static_out=static_out)
+                try:
+                    if counter is not None:
+                        hip.call('tell_set_rng_step_ptr', counter)
+                    with torch.cuda.graph(g):
+                        with hip.bound_stream():        # launches must go to the CAPTURING stream
+                            static_out = self.fn(static_in)
+                finally:
+                    if counter is not None:
+                        hip.call('tell_set_rng_step_ptr', None)
+                e.update(state='ready', graph=g, static_in=static_in, static_out=static_out, counter=counter)
             except Exception as exc:                    # noqa: BLE001 - any capture problem -> eager for good
                 e['state'] = 'eager'
                 e['error'] = repr(exc)
                 return self.fn(x)
         e['static_in'].copy_(x)
+        if e.get('counter') is not None:
+            e['counter'].add_(1)                        # same stream as the replay: ordered before it
         e['graph'].replay()
         return e['static_out']

@@ -93,6 +93,18 @@ class CaptionModel(Model):
         w = self.resnet.conv1.weight                 # a reloaded / moved / re-typed trunk must not replay stale pointers
         return g(image, key=(self.resnet.training, ops.rt.compute_dtype(), w._version, w.data_ptr()))
 
+    def _run_roberta(self, article_ids):
+        """RoBERTa-large (~170 launches, dropout active in train mode) as one hipGraph replay per step."""
+        from .roberta import RobertaEncoder
+        if not isinstance(self.roberta, RobertaEncoder):
+            return self.roberta.extract_features(article_ids, return_all_hiddens=True)
+        g = self.__dict__.get('_roberta_graph')
+        if g is None:
+            g = self.__dict__['_roberta_graph'] = graphs.GraphedCall(
+                lambda ids: self.roberta.extract_features(ids, return_all_hiddens=True), 'roberta-large', rng=True)
+        w = self.roberta.model.decoder.sentence_encoder.layers[0].fc1.weight
+        return g(article_ids, key=(self.roberta.training, ops.rt.compute_dtype(), w._version, w.data_ptr()))
+
     # ---- frozen encoders -------------------------------------------------------------
     def encode(self, context, image, ahead=False):
         """ResNet-152 + RoBERTa-large on one batch (transformer_faces_objects.py:335-353) -> EncodedBatch.
@@ -114,7 +126,7 @@ class CaptionModel(Model):
                 is_.wait_event(start)
                 with torch.cuda.stream(rs), ops.hip.bound_stream():
                     enc.article_mask = article_ids == self.padding_idx                 # :347
-                    enc.stack = self.roberta.extract_features(article_ids, return_all_hiddens=True)
+                    enc.stack = self._run_roberta(article_ids)
                     article_ids.record_stream(rs)
                     enc.events.append(torch.cuda.Event())
                     enc.events[-1].record(rs)
@@ -131,7 +143,7 @@ class CaptionModel(Model):
                 start.record(main)
             # RoBERTa is issued FIRST: its ~300 launches keep the main stream busy for ~10 ms of GPU time
             # while the host is still issuing ResNet's small launches onto the side stream.
-            enc.stack = self.roberta.extract_features(article_ids, return_all_hiddens=True)   # [L,B,S,E]
+            enc.stack = self._run_roberta(article_ids)                                        # [L,B,S,E]
             if side is not None:
                 side.wait_event(start)
                 with torch.cuda.stream(side), ops.hip.bound_stream():
