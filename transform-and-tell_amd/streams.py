@@ -9,7 +9,9 @@ registry in a fixed order, and multi-GPU launchers set GPU_MAX_HW_QUEUES=3 befor
 (bench.py does)."""
 import torch
 
-ROLES = ('resnet', 'roberta', 'wgrad', 'update')
+import os
+
+ROLES = tuple(os.environ.get('TELL_STREAM_ORDER', 'resnet,roberta,wgrad,update').split(','))
 _streams = {}
 
 
