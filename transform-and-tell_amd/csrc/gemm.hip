@@ -1,18 +1,20 @@
-// NT GEMM on the CDNA4 matrix cores:  C[M,N] = epilogue(A[M,K] . B[N,K]^T)
+// GEMMs on the CDNA4 matrix cores:  C[M,N] = epilogue(op(A) . op(B))
 //
-// Both operands are row-major with the contraction index contiguous, which is
-// what every linear layer of the decoder / RoBERTa / ResNet(1x1, im2col) needs
-// (x.W^T).  Backward products (dY.W, dY^T.X) are brought into the same form by
-// the transpose kernel in elementwise.hip.
+//   gemm_nt_glds_kernel  bf16, K % 64 == 0, >= 256 tiles: operands stream global -> LDS directly
+//                        (global_load_lds_dwordx4), tiles 128x128 / 256x192 / 256x256.
+//   gemm_nt_kernel       any dtype / K / size: register-staged 2-4 deep prefetch, tiles 64x64 .. 256x128.
+//   gemm_tx_kernel       bf16 with K-major operands (A stored [K][M] and/or B stored [K][N]): the backward
+//                        products dY^T.X and dY.W read activations and weights as the forward pass left them;
+//                        fragments come from the LDS transpose read ds_read_b64_tr_b16.
 //
 //   bf16 : v_mfma_f32_32x32x16_bf16  (lane l supplies row l&31, k-chunk 8*(l>>5)..+8)
 //   f32  : v_mfma_f32_32x32x2_f32    (exact-f32 parity mode; lane l: row l&31, k = l>>5)
-// C/D layout of both:  col = l&31 (B row = n),  row = (r&3) + 8*(r>>2) + 4*(l>>5) (A row = m).
+// Every MFMA is issued with the operands SWAPPED (B fragment first), so the accumulator tile is C^T:
+// lane l owns output row (l&31) and 4 consecutive output columns per register quad - see the epilogue.
 //
-// Tiling: workgroup = 256 threads = 4 waves in 2x2; tile BMxBN in {128x128, 64x64};
-// K-step = 128 bytes of K per row (64 bf16 / 32 f32); register-prefetched,
-// double-buffered LDS; LDS rows padded (bf16: 144 B stride -> conflict-free
-// ds_read_b128 per 16-lane service group; f32: 33-dword stride).
+// LDS rows are padded (bf16: 144 B stride -> conflict-free ds_read_b128 per 16-lane service group; f32:
+// 33-dword stride; K-major tiles: +64 B skew for the transpose reads) or, for the lane-linear direct-to-LDS
+// image, swizzled on the source address.
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
