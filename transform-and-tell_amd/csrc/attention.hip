@@ -628,11 +628,13 @@ __global__ __launch_bounds__(256) void attn_fwd_reg_kernel(AttnArgs p) {
       const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;        // all keys masked so far: exp(-inf - 0) = 0
       const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
       float ls = 0.f;
+      constexpr float LOG2E = 1.4426950408889634f;
+      const float neg_m = -m_safe * LOG2E;
 #pragma unroll
       for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float pv = __expf(st[f][r] - m_safe);
+          const float pv = __builtin_amdgcn_exp2f(fmaf(st[f][r], LOG2E, neg_m));   // exp(s - m): one fma + v_exp_f32
           ls += pv;
           st[f][r] = pv;
         }

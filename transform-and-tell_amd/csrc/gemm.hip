@@ -89,7 +89,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, branch-free: one rcp + one exp + 6 fma)
 __device__ __forceinline__ float erf_as(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));   // v_rcp_f32 (1 ulp); __frcp_rn expands to a 10-instruction IEEE division
   float y = fmaf(1.061405429f, t, -1.453152027f);
   y = fmaf(y, t, 1.421413741f);
   y = fmaf(y, t, -0.284496736f);
