@@ -133,6 +133,13 @@ def test_bf16_training_reduces_loss_with_dropout():
         losses.append(float(trainer.train_one_batch(b)))
     assert all(l == l for l in losses)                   # no NaN
     assert sum(losses[-5:]) / 5 < 0.6 * sum(losses[:3]) / 3, losses
+    # the optimizer kernel keeps the bf16 working copy of every parameter and leaves the gradient buffer zeroed
+    trainer.finish_update()
+    torch.cuda.synchronize()
+    assert float(trainer.flat.grad.abs().max()) == 0.0
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            assert torch.equal(p._tell_shadow, p.detach().to(torch.bfloat16)), n
 
 
 @pytest.mark.parametrize('kind', ['flattened', 'faces_objects'])
