@@ -150,12 +150,17 @@ def test_model_loss_and_greedy_generation_golden(golden, dtype, kind):
     assert int(out['sample_size']) == fx['out']['sample_size']
     close(out['loss'].reshape(1), fx['out']['loss'], dtype, rtol=1e-3 if dtype == torch.float32 else 3e-2)
     ref_ids = fx['out']['gen_ids']
-    for fast in (True, False):          # K/V-cached static-batch generator and the reference's control flow
+    # K/V-cached static-batch generator (1st call: eager step 0 + capture at step 1; 2nd call: every step is a
+    # replay of the captured decode step, position offset from the device counter) and the reference's control flow
+    for fast in (True, True, False):
         model.fast_generation = fast
         gen = model.generate(**batch())
         got = gen['gen_ids'].cpu()
         if dtype == torch.float32:
             assert got.shape == ref_ids.shape and torch.equal(got, ref_ids), fast    # bit-exact greedy token ids
+            if fast:
+                hs = list(model.__dict__.get('_decode_graphs', {}).values())
+                assert hs and all(h['graph'] not in (None, False) for h in hs), [h.get('error') for h in hs]
             close(gen['log_probs'], fx['out']['gen_log_probs'], dtype, atol=2e-4)
         else:
             n = min(got.shape[1], ref_ids.shape[1])

@@ -90,7 +90,10 @@ __global__ __launch_bounds__(256) void embed_finalize_kernel(const T* __restrict
                                                              const float* __restrict__ pos_table,
                                                              int pos_rows, T* __restrict__ out, int Bn,
                                                              int Tn, int E, float scale, int pos_pad,
-                                                             int start_pos, int tbc) {
+                                                             int start_pos, int tbc,
+                                                             const uint32_t* __restrict__ step) {
+  // inside a captured decode step the position offset advances with the graph's device counter (common.h)
+  if (step) start_pos += (int)*step;
   const int n = blockIdx.x;
   const int b = n / Tn, t = n % Tn;
   const long id = ids[n];
@@ -106,8 +109,8 @@ extern "C" int tell_embed_finalize(const void* band_out, const int* slot, const 
                                    float scale, int pos_pad, int start_pos, int tbc, int dtype,
                                    hipStream_t stream) {
   if (B * T <= 0) return TELL_OK;
-  if (dtype == TELL_BF16) hipLaunchKernelGGL((embed_finalize_kernel<uint16_t>), dim3(B * T), dim3(256), 0, stream, (const uint16_t*)band_out, slot, ids, pos_table, pos_rows, (uint16_t*)out, B, T, E, scale, pos_pad, start_pos, tbc);
-  else hipLaunchKernelGGL((embed_finalize_kernel<float>), dim3(B * T), dim3(256), 0, stream, (const float*)band_out, slot, ids, pos_table, pos_rows, (float*)out, B, T, E, scale, pos_pad, start_pos, tbc);
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((embed_finalize_kernel<uint16_t>), dim3(B * T), dim3(256), 0, stream, (const uint16_t*)band_out, slot, ids, pos_table, pos_rows, (uint16_t*)out, B, T, E, scale, pos_pad, start_pos, tbc, g_tell_rng_step);
+  else hipLaunchKernelGGL((embed_finalize_kernel<float>), dim3(B * T), dim3(256), 0, stream, (const float*)band_out, slot, ids, pos_table, pos_rows, (float*)out, B, T, E, scale, pos_pad, start_pos, tbc, g_tell_rng_step);
   return tell_check_launch("embed_finalize");
 }
 

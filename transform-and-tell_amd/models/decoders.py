@@ -180,6 +180,14 @@ class _DynamicConvDecoderBase(Decoder):
         out = self.adaptive_softmax.get_log_prob(net_output[0])
         return out if log_probs else out.exp()
 
+    def static_incremental_state(self, batch, device, dtype):
+        """Incremental state of fixed shape (every DynamicConv buffer K-1 zero rows) for the captured decode step."""
+        st = {'_static': True}
+        for layer in self.layers:
+            conv = layer.conv
+            st[conv._state_key] = torch.zeros(conv.kernel_size - 1, batch, conv.input_size, dtype=dtype, device=device)
+        return st
+
     def reorder_incremental_state(self, incremental_state, new_order):
         """Beam search: row r of the new state is row new_order[r] of the old one (dynamic.py:338-342)."""
         if incremental_state is None:

@@ -242,7 +242,7 @@ class CaptionModel(Model):
         B = caption_ids.shape[0]
         dev = caption_ids.device
         kv = dec.project_contexts(contexts)
-        state = {}
+        step = self._decode_stepper(B, kv, contexts, gen_len)
         cur = caption_ids[:, 0:1].contiguous()
         finished = cur[:, 0] == eos
         ids = torch.full((B, gen_len + 1), self.padding_idx, dtype=torch.long, device=dev)
@@ -252,8 +252,7 @@ class CaptionModel(Model):
         done_step[finished] = 0
         steps = gen_len
         for i in range(gen_len):
-            out = dec({self.index: cur}, contexts, incremental_state=state, kv_cache=kv)
-            tok, lp = dec.adaptive_softmax.greedy(out[0][:, -1:])
+            tok, lp = step(i, cur)
             tok = tok.long().view(B)
             lp = lp.view(B) / self.sampling_temp
             ids[:, i + 1] = torch.where(finished, ids[:, i + 1], tok)
@@ -267,6 +266,93 @@ class CaptionModel(Model):
         steps = int(done_step.max())                                          # one sync at the end
         steps = max(steps, 1)
         return lps[:, :steps], ids[:, :steps + 1], []
+
+    def _decode_stepper(self, B, kv, contexts, gen_len, full=False):
+        """-> step(i, cur [B,1]) -> (token [B,1], log-prob [B,1]) - or, with full=True, the log-probabilities over
+        the whole vocabulary [B,1,V] - for the cached greedy / beam generators; step.reorder(rows) permutes the
+        rows of the incremental state (beam search).
+
+        With graphs enabled the decode step (about 150 launches of a few microseconds each, host-bound when issued
+        one by one) is captured ONCE per (batch, context shapes) signature and replayed: every tensor it touches is
+        static - the DynamicConv input buffers have their final K-1 rows from the start (zero history), the
+        projected K/V and masks are copied into fixed buffers per caption batch, and the position offset comes from
+        the graph's device step counter (embed_finalize reads it, like the dropout kernels)."""
+        dec = self.decoder
+        names = [n for layer_kv in kv[:1] for n in layer_kv]
+        if not graphs.ENABLED or self.training or not torch.is_tensor(kv[0][names[0]][0]) or \
+                not kv[0][names[0]][0].is_cuda:
+            state = {}
+            head = dec.adaptive_softmax.get_log_prob if full else dec.adaptive_softmax.greedy
+
+            def eager_step(i, cur):
+                return head(dec({self.index: cur}, contexts, incremental_state=state, kv_cache=kv)[0][:, -1:])
+            eager_step.reorder = lambda rows: dec.reorder_incremental_state(state, rows)
+            return eager_step
+        dev, dtype = kv[0][names[0]][0].device, kv[0][names[0]][0].dtype
+        sig = (B, dtype, full, tuple((n, tuple(kv[0][n][0].shape), tuple(kv[0][n][1].shape)) for n in names),
+               dec.embedder.token_embedder_position.weights.data_ptr())
+        cache = self.__dict__.setdefault('_decode_graphs', {})
+        h = cache.get(sig)
+        if h is None:
+            if len(cache) >= graphs.MAX_SIGNATURES:
+                cache.pop(next(iter(cache)))
+            h = cache[sig] = {
+                'graph': None, 'counter': torch.zeros(1, dtype=torch.int32, device=dev),
+                'cur': torch.zeros(B, 1, dtype=torch.long, device=dev),
+                'kv': [{n: tuple(torch.empty_like(t) for t in pair) for n, pair in lk.items()} for lk in kv],
+                'ctx': {k: torch.empty_like(v) for k, v in contexts.items() if torch.is_tensor(v)},
+                'state': dec.static_incremental_state(B, dev, dtype),
+            }
+            po = dec.embedder.token_embedder_position            # the table must already cover the longest caption
+            po.next_start(gen_len + 2, None)
+        for lk, ls in zip(kv, h['kv']):
+            for n, pair in lk.items():
+                for t, s in zip(pair, ls[n]):
+                    s.copy_(t)
+        for k, s in h['ctx'].items():
+            s.copy_(contexts[k])
+        for k, s in h['state'].items():
+            if torch.is_tensor(s):
+                s.zero_()
+        pos_key = dec.embedder.token_embedder_position._state_key
+        h['state'].pop(pos_key, None)
+
+        head = dec.adaptive_softmax.get_log_prob if full else dec.adaptive_softmax.greedy
+
+        def run():
+            out = dec({self.index: h['cur']}, h['ctx'], incremental_state=h['state'], kv_cache=h['kv'])
+            return head(out[0][:, -1:])
+
+        def step(i, cur):
+            h['cur'].copy_(cur)
+            if h['graph'] is None and i != 1:
+                return run()                                      # warm step(s) before the capture, or fallback
+            if h['graph'] is None:                                # i == 1: the host position state is 1 now
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    try:
+                        ops.call('tell_set_rng_step_ptr', h['counter'])
+                        with torch.cuda.graph(g):
+                            with ops.hip.bound_stream():
+                                h['out'] = run()
+                    finally:
+                        ops.call('tell_set_rng_step_ptr', None)
+                    h['graph'], h['base'] = g, 1
+                except Exception as exc:                          # noqa: BLE001 - stay eager for this signature
+                    h['graph'], h['error'] = False, repr(exc)
+                    return run()
+            if h['graph'] is False:
+                return run()
+            h['counter'].fill_(i - h['base'])                     # position offset of this step (may be -1)
+            h['graph'].replay()
+            return h['out']
+
+        def reorder(rows):                                        # in place: the buffers are part of the graph
+            for k, s in h['state'].items():
+                if torch.is_tensor(s):
+                    s.copy_(s.index_select(1, rows))
+        step.reorder = reorder
+        return step
 
     @torch.no_grad()
     def _generate_beam(self, caption_ids, contexts, beam_size, gen_len=100, eos=2, check_every=8):
@@ -288,7 +374,7 @@ class CaptionModel(Model):
             ctx[name] = rep(val, 0) if name.endswith('_mask') else rep(val, 1)
         kv = [{name: tuple(rep(t, 1) for t in pair) for name, pair in layer_kv.items()}
               for layer_kv in dec.project_contexts(contexts)]
-        state = {}
+        step = self._decode_stepper(B * K, kv, ctx, gen_len, full=True)
         cur = rep(caption_ids[:, 0:1], 0)
         cum = torch.full((B, K), float('-inf'), dtype=torch.float32, device=dev)
         cum[:, 0] = 0.0                                     # all K rows start identical: only hypothesis 0 counts
@@ -299,8 +385,7 @@ class CaptionModel(Model):
         base = (torch.arange(B, device=dev) * K).view(B, 1)
         n_steps = gen_len
         for i in range(gen_len):
-            out = dec({self.index: cur}, ctx, incremental_state=state, kv_cache=kv)
-            lp = dec.adaptive_softmax.get_log_prob(out[0][:, -1:]).view(B, K, -1) / self.sampling_temp
+            lp = step(i, cur).view(B, K, -1) / self.sampling_temp
             V = lp.shape[-1]
             lp = lp.masked_fill(finished.unsqueeze(-1), float('-inf'))
             lp[..., pad] = torch.where(finished, torch.zeros_like(cum), lp[..., pad])
@@ -315,7 +400,7 @@ class CaptionModel(Model):
             lps[:, :, i] = torch.where(was_finished, torch.zeros_like(top), top - cum.gather(1, parent))
             finished = was_finished | (tok == eos)
             cum = top
-            dec.reorder_incremental_state(state, rows)
+            step.reorder(rows)
             cur = tok.view(B * K, 1)
             if (i + 1) % check_every == 0 and bool(finished.all()):
                 n_steps = i + 1

@@ -30,7 +30,16 @@ class DynamicConv1dTBC(nn.Module):
     def forward(self, X, incremental_state=None, query=None, unfold=None):
         assert query is None
         n_hist = 0
-        if incremental_state is not None:                            # dynamic.py:94-99
+        if incremental_state is not None and incremental_state.get('_static'):
+            # fixed-shape variant for the captured decode step: the buffer always holds K-1 rows, zero before the
+            # caption starts.  Identical results: the tap softmax runs over all K taps and taps that reach before
+            # the start multiply zero rows, which is what the reference's narrowing does (dynamic.py:306-311).
+            prev = incremental_state[self._state_key]
+            n_hist = prev.shape[0]
+            X = torch.cat([prev, X], dim=0)
+            if n_hist:
+                prev.copy_(X[-n_hist:])
+        elif incremental_state is not None:                          # dynamic.py:94-99
             prev = incremental_state.get(self._state_key)
             if prev is not None:
                 n_hist = prev.shape[0]
