@@ -171,6 +171,11 @@ int tell_ce_bwd(const float* logits, long ld, int M, int V, const int* targets, 
                 const int* m_dev, int ignore_index, const float* lse, const float* gscale_dev, void* dlogits,
                 long ld_d, int dtype, tell_stream_t stream);
 /* get_log_prob + topk(1), softmax.py:193-222, transformer_faces_objects.py:443-464 */
+/* the k (<= 8) best (token, log-prob) pairs per row, best first - what a beam of k needs from each hypothesis;
+ * `tokens`, `lps`: [rows, k] */
+int tell_adaptive_logprob_topk(const float* head, long ld_head, int c0, int n_tails, const float* tail0, long ld0,
+                               int n0, const float* tail1, long ld1, int n1, const float* tail2, long ld2, int n2,
+                               int rows, int k, int* tokens, float* lps, tell_stream_t stream);
 int tell_adaptive_logprob_argmax(const float* head, long ld_head, int c0, int n_tails, const float* tail0,
                                  long ld0, int n0, const float* tail1, long ld1, int n1, const float* tail2,
                                  long ld2, int n2, int rows, float* log_probs, long ld_lp, int* token,

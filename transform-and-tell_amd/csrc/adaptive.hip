@@ -330,6 +330,97 @@ __global__ __launch_bounds__(256) void logprob_argmax_kernel(LogProbArgs p) {
     if (p.token_lp) p.token_lp[i] = bv;
   }
 }
+// Top-k variant for beam search: per row the k best (log-prob, token) pairs of the adaptive softmax, sorted best
+// first, without materialising [rows, vocab] (a beam of k only ever needs each hypothesis' own k best tokens).
+// Every thread keeps its k best in registers while streaming the row; the block then pops the global best k times.
+template <int K>
+__global__ __launch_bounds__(256) void logprob_topk_kernel(LogProbArgs p, int k, int* __restrict__ tokens,
+                                                           float* __restrict__ lps) {
+  __shared__ float red[4];
+  __shared__ float best_v[4];
+  __shared__ int best_i[4];
+  __shared__ int win_i;
+  const int i = blockIdx.x;
+  const float* hrow = p.head + (long)i * p.ld_head;
+  float tv[K]; int ti[K];
+#pragma unroll
+  for (int q = 0; q < K; ++q) { tv[q] = -INFINITY; ti[q] = 0x7fffffff; }
+  auto better = [](float v, int j, float w, int m) { return v > w || (v == w && j < m); };
+  auto push = [&](float v, int j) {
+    if (!better(v, j, tv[K - 1], ti[K - 1])) return;
+    tv[K - 1] = v; ti[K - 1] = j;
+#pragma unroll
+    for (int q = K - 1; q > 0; --q)
+      if (better(tv[q], ti[q], tv[q - 1], ti[q - 1])) {
+        const float fv = tv[q]; tv[q] = tv[q - 1]; tv[q - 1] = fv;
+        const int fi = ti[q]; ti[q] = ti[q - 1]; ti[q - 1] = fi;
+      }
+  };
+  float mx = -INFINITY;
+  for (int j = threadIdx.x; j < p.head_n; j += 256) mx = fmaxf(mx, hrow[j]);
+  mx = block_max(mx, red);
+  float s = 0.f;
+  for (int j = threadIdx.x; j < p.head_n; j += 256) s += __expf(hrow[j] - mx);
+  s = block_sum(s, red);
+  const float lse_h = mx + __logf(s);
+  for (int j = threadIdx.x; j < p.c0; j += 256) push(hrow[j] - lse_h, j);
+  int base = p.c0;
+  for (int c = 0; c < p.n_tails; ++c) {
+    const float* trow = p.tail[c] + (long)i * p.ld_tail[c];
+    const int n = p.tail_n[c];
+    float m2 = -INFINITY;
+    for (int j = threadIdx.x; j < n; j += 256) m2 = fmaxf(m2, trow[j]);
+    m2 = block_max(m2, red);
+    float s2 = 0.f;
+    for (int j = threadIdx.x; j < n; j += 256) s2 += __expf(trow[j] - m2);
+    s2 = block_sum(s2, red);
+    const float off = (hrow[p.c0 + c] - lse_h) - (m2 + __logf(s2));
+    for (int j = threadIdx.x; j < n; j += 256) push(trow[j] + off, base + j);
+    base += n;
+  }
+  for (int r = 0; r < k; ++r) {                       // pop the block-wide best k times
+    float bv = tv[0]; int bi = ti[0];
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    __syncthreads();                                   // previous round's win_i / best_* consumed
+    if ((threadIdx.x & 63) == 0) { best_v[threadIdx.x >> 6] = bv; best_i[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (better(best_v[w], best_i[w], bv, bi)) { bv = best_v[w]; bi = best_i[w]; }
+      tokens[(long)i * k + r] = bi;
+      lps[(long)i * k + r] = bv;
+      win_i = bi;
+    }
+    __syncthreads();
+    if (ti[0] == win_i) {                              // the owner of the winner advances its list
+#pragma unroll
+      for (int q = 0; q < K - 1; ++q) { tv[q] = tv[q + 1]; ti[q] = ti[q + 1]; }
+      tv[K - 1] = -INFINITY; ti[K - 1] = 0x7fffffff;
+    }
+  }
+}
+extern "C" int tell_adaptive_logprob_topk(const float* head, long ld_head, int c0, int n_tails,
+                                          const float* tail0, long ld0, int n0, const float* tail1, long ld1,
+                                          int n1, const float* tail2, long ld2, int n2, int rows, int k,
+                                          int* tokens, float* lps, hipStream_t stream) {
+  TELL_REQUIRE(n_tails >= 0 && n_tails <= 3, "logprob_topk: up to 3 tails");
+  TELL_REQUIRE(k >= 1 && k <= 8, "logprob_topk: 1 <= k <= 8");
+  if (rows <= 0) return TELL_OK;
+  LogProbArgs p;
+  p.head = head; p.ld_head = ld_head; p.head_n = c0 + n_tails; p.c0 = c0; p.n_tails = n_tails; p.rows = rows;
+  p.tail[0] = tail0; p.ld_tail[0] = ld0; p.tail_n[0] = n0;
+  p.tail[1] = tail1; p.ld_tail[1] = ld1; p.tail_n[1] = n1;
+  p.tail[2] = tail2; p.ld_tail[2] = ld2; p.tail_n[2] = n2;
+  p.log_probs = nullptr; p.ld_lp = 0; p.token = nullptr; p.token_lp = nullptr;
+  if (k <= 4) hipLaunchKernelGGL((logprob_topk_kernel<4>), dim3(rows), dim3(256), 0, stream, p, k, tokens, lps);
+  else hipLaunchKernelGGL((logprob_topk_kernel<8>), dim3(rows), dim3(256), 0, stream, p, k, tokens, lps);
+  return tell_check_launch("logprob_topk");
+}
+
 extern "C" int tell_adaptive_logprob_argmax(const float* head, long ld_head, int c0, int n_tails,
                                             const float* tail0, long ld0, int n0, const float* tail1,
                                             long ld1, int n1, const float* tail2, long ld2, int n2,

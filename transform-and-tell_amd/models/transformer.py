@@ -267,9 +267,9 @@ class CaptionModel(Model):
         steps = max(steps, 1)
         return lps[:, :steps], ids[:, :steps + 1], []
 
-    def _decode_stepper(self, B, kv, contexts, gen_len, full=False):
-        """-> step(i, cur [B,1]) -> (token [B,1], log-prob [B,1]) - or, with full=True, the log-probabilities over
-        the whole vocabulary [B,1,V] - for the cached greedy / beam generators; step.reorder(rows) permutes the
+    def _decode_stepper(self, B, kv, contexts, gen_len, topk=0):
+        """-> step(i, cur [B,1]) -> (token [B,1], log-prob [B,1]) - or, with topk=k, the k best (tokens [B,1,k],
+        log-probs [B,1,k]) of every row - for the cached greedy / beam generators; step.reorder(rows) permutes the
         rows of the incremental state (beam search).
 
         With graphs enabled the decode step (about 150 launches of a few microseconds each, host-bound when issued
@@ -282,14 +282,14 @@ class CaptionModel(Model):
         if not graphs.ENABLED or self.training or not torch.is_tensor(kv[0][names[0]][0]) or \
                 not kv[0][names[0]][0].is_cuda:
             state = {}
-            head = dec.adaptive_softmax.get_log_prob if full else dec.adaptive_softmax.greedy
+            head = (lambda x: dec.adaptive_softmax.topk(x, topk)) if topk else dec.adaptive_softmax.greedy
 
             def eager_step(i, cur):
                 return head(dec({self.index: cur}, contexts, incremental_state=state, kv_cache=kv)[0][:, -1:])
             eager_step.reorder = lambda rows: dec.reorder_incremental_state(state, rows)
             return eager_step
         dev, dtype = kv[0][names[0]][0].device, kv[0][names[0]][0].dtype
-        sig = (B, dtype, full, tuple((n, tuple(kv[0][n][0].shape), tuple(kv[0][n][1].shape)) for n in names),
+        sig = (B, dtype, topk, tuple((n, tuple(kv[0][n][0].shape), tuple(kv[0][n][1].shape)) for n in names),
                dec.embedder.token_embedder_position.weights.data_ptr())
         cache = self.__dict__.setdefault('_decode_graphs', {})
         h = cache.get(sig)
@@ -317,7 +317,7 @@ class CaptionModel(Model):
         pos_key = dec.embedder.token_embedder_position._state_key
         h['state'].pop(pos_key, None)
 
-        head = dec.adaptive_softmax.get_log_prob if full else dec.adaptive_softmax.greedy
+        head = (lambda x: dec.adaptive_softmax.topk(x, topk)) if topk else dec.adaptive_softmax.greedy
 
         def run():
             out = dec({self.index: h['cur']}, h['ctx'], incremental_state=h['state'], kv_cache=h['kv'])
@@ -367,14 +367,11 @@ class CaptionModel(Model):
         dev = caption_ids.device
         pad = self.padding_idx
         rep = lambda t, dim: t.repeat_interleave(K, dim=dim).contiguous()           # noqa: E731
-        ctx = {}
-        for name, val in contexts.items():
-            if not torch.is_tensor(val):
-                continue
-            ctx[name] = rep(val, 0) if name.endswith('_mask') else rep(val, 1)
-        kv = [{name: tuple(rep(t, 1) for t in pair) for name, pair in layer_kv.items()}
-              for layer_kv in dec.project_contexts(contexts)]
-        step = self._decode_stepper(B * K, kv, ctx, gen_len, full=True)
+        # contexts, masks and projected K/V stay at batch B: the attention modules present the K hypotheses of a
+        # sample as K query positions of that sample (modules/attention.py), nothing is replicated per beam
+        ctx = {k_: v_ for k_, v_ in contexts.items() if torch.is_tensor(v_)}
+        kv = dec.project_contexts(contexts)
+        step = self._decode_stepper(B * K, kv, ctx, gen_len, topk=K)
         cur = rep(caption_ids[:, 0:1], 0)
         cum = torch.full((B, K), float('-inf'), dtype=torch.float32, device=dev)
         cum[:, 0] = 0.0                                     # all K rows start identical: only hypothesis 0 counts
@@ -385,12 +382,18 @@ class CaptionModel(Model):
         base = (torch.arange(B, device=dev) * K).view(B, 1)
         n_steps = gen_len
         for i in range(gen_len):
-            lp = step(i, cur).view(B, K, -1) / self.sampling_temp
-            V = lp.shape[-1]
-            lp = lp.masked_fill(finished.unsqueeze(-1), float('-inf'))
-            lp[..., pad] = torch.where(finished, torch.zeros_like(cum), lp[..., pad])
-            top, idx = (cum.unsqueeze(-1) + lp).view(B, K * V).topk(K, dim=1)        # sorted, best first
-            parent, tok = idx // V, idx % V
+            # each hypothesis contributes its own K best tokens (the best K of K x V always lie among them)
+            tk, lp = step(i, cur)
+            tk, lp = tk.view(B, K, K).long(), lp.view(B, K, K) / self.sampling_temp
+            # a finished hypothesis has ONE continuation: pad, at no cost
+            fin = finished.unsqueeze(-1)
+            first = torch.zeros(K, dtype=torch.bool, device=dev)
+            first[0] = True
+            lp = torch.where(fin, torch.where(first, torch.zeros_like(lp), torch.full_like(lp, float('-inf'))), lp)
+            tk = torch.where(fin, torch.full_like(tk, pad), tk)
+            top, idx = (cum.unsqueeze(-1) + lp).view(B, K * K).topk(K, dim=1)       # sorted, best first
+            parent = idx // K
+            tok = tk.view(B, K * K).gather(1, idx)
             rows = (base + parent).view(-1)
             was_finished = finished.gather(1, parent)
             tok = torch.where(was_finished, torch.full_like(tok, pad), tok)

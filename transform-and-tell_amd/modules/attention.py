@@ -80,8 +80,18 @@ class MultiHeadAttention(nn.Module):
         mask = None
         if key_padding_mask is not None and k.shape[0] > 0:
             mask = key_padding_mask.to(torch.uint8).contiguous()
+        beams = 1
+        if kv is not None and T == 1 and k.shape[0] > 0 and B != k.shape[1] and B % k.shape[1] == 0:
+            # beam search: the n hypotheses of a sample (rows b*n + j) attend to the SAME static context, so they are
+            # presented to the kernel as n query positions of batch element b - K/V are read once per sample, not
+            # once per hypothesis (cross-attention has no causal mask, so query positions are independent)
+            beams = B // k.shape[1]
+            q = q.view(k.shape[1], beams, E).transpose(0, 1)                      # [n, B/n, E] strided view
         attn, lse = ops.attention(q, k, v, mask, self.bias_k, self.bias_v, self.num_heads, self.add_zero_attn,
                                   self.dropout, self.training, return_lse=True)
+        if beams > 1:
+            assert not need_weights
+            attn = attn.transpose(0, 1).reshape(1, B, E)
         out = self.out_proj(attn)
         weights = None
         if need_weights:

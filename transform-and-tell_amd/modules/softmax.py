@@ -70,6 +70,13 @@ class AdaptiveSoftmax(nn.Module):
                                             self.head.class_proj.weight, self._tails(), want_full=True)
         return full.view(B, T, self.vocab_size)
 
+    def topk(self, X, k):
+        """The k best (token, log-prob) of every position, best first, fused like `greedy` (beam search)."""
+        B, T, E = X.shape
+        tok, lp, _ = ops.adaptive_log_probs(ops.as2dc(X), self.cutoff, self.head.word_proj.weight,
+                                            self.head.class_proj.weight, self._tails(), topk=k)
+        return tok.view(B, T, k), lp.view(B, T, k)
+
     def greedy(self, X):
         """Fused arg-max over the full vocabulary (get_log_prob + topk(1),
         transformer_faces_objects.py:443-464) without materialising [N, vocab]."""

@@ -10,6 +10,7 @@ large-model trainers; the Functions therefore return None for parameters.
 """
 import math
 import os
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -202,8 +203,10 @@ def _cached(p, key, maker):
         rt.wait_weight_update()          # an optimizer step may still be in flight on the update stream
     stamp = (epoch, rt.compute_dtype(), p._version, p.data_ptr())
     e = _wcache.get(k)
-    if e is None or e[0] != stamp:
-        e = (stamp, maker())
+    # id() is only unique among LIVE objects: the entry remembers its tensor weakly, so a new tensor that
+    # inherited a dead one's id (and possibly its storage address) never sees the old working copy
+    if e is None or e[0] != stamp or e[2]() is not p:
+        e = (stamp, maker(), weakref.ref(p))
         _wcache[k] = e
     return e[1]
 
@@ -571,6 +574,16 @@ def _kv_strides(t, S, B):
     return t.stride(0), t.stride(1)
 
 
+def _bias_row(p, dtype):
+    """bias_k / bias_v [1,1,E] as a flat row in `dtype`: the cached / optimizer-maintained working copy when the
+    tensor runs in the global compute dtype, an explicit cast otherwise (unit tests drive the kernels directly)."""
+    if p is None:
+        return None
+    if dtype == rt.compute_dtype():
+        return weight(p).reshape(-1)
+    return cast(p.detach().reshape(-1), dtype)
+
+
 class AttnFn(Function):
     """softmax(q k^T + mask) v with the virtual bias_k/bias_v row and zero row.
     q: [T,B,E] (already scaled); k, v: [S,B,E] views; mask: [B,S] uint8 or None."""
@@ -584,8 +597,8 @@ class AttnFn(Function):
             q = q.contiguous()
         out = torch.empty(T, B, E, dtype=q.dtype, device=q.device)
         lse = torch.empty(B * H, T, dtype=torch.float32, device=q.device)
-        bk = cast(bias_k.detach().reshape(-1), q.dtype) if bias_k is not None else None
-        bv = cast(bias_v.detach().reshape(-1), q.dtype) if bias_v is not None else None
+        bk = _bias_row(bias_k, q.dtype)
+        bv = _bias_row(bias_v, q.dtype)
         if S == 0:      # empty context (multi_head.py:349-374): only the virtual rows remain
             k = v = q.new_zeros(1, B, E)
         call('tell_attn_fwd', q, k, v, out, lse, mask, bk, bv, B, H, T, S, D, q.stride(0), q.stride(1),
@@ -632,7 +645,7 @@ def attention_avg_weights(q, k, mask, bias_k, lse, H, has_zero=True):
     S = k.shape[0]
     S_total = S + (1 if bias_k is not None else 0) + int(has_zero)
     w = torch.empty(B, T, S_total, dtype=torch.float32, device=q.device)
-    bk = cast(bias_k.detach().reshape(-1), q.dtype) if bias_k is not None else None
+    bk = _bias_row(bias_k, q.dtype)
     call('tell_attn_avg_weights', q, k, lse, mask, bk, w, B, H, T, S, E // H, q.stride(0), q.stride(1),
          k.stride(0), k.stride(1), int(has_zero), hip.dt(q))
     return w
@@ -876,8 +889,9 @@ def adaptive_loss(x, target, cutoffs, pad_idx, emb0, class_proj, tails):
     return AdaptiveLossFn.apply(x, target, tuple(cutoffs), pad_idx, emb0, class_proj, *tails)
 
 
-def adaptive_log_probs(x2, cutoffs, emb0, class_proj, tails, want_full=False):
-    """Generation head (softmax.py:193-222 + topk(1)): -> (token int32 [N], logprob fp32 [N], full or None)."""
+def adaptive_log_probs(x2, cutoffs, emb0, class_proj, tails, want_full=False, topk=0):
+    """Generation head (softmax.py:193-222 + topk(1)): -> (token int32 [N], logprob fp32 [N], full or None);
+    topk = k > 0: -> (tokens int32 [N,k], logprobs fp32 [N,k], None), best first (beam search)."""
     N, E = x2.shape
     dev = x2.device
     c0 = cutoffs[0]
@@ -892,6 +906,12 @@ def adaptive_log_probs(x2, cutoffs, emb0, class_proj, tails, want_full=False):
         tl[i] = gemm(h, weight(emb), out_dtype=torch.float32)
         ld[i], nn_[i] = tl[i].stride(0), tl[i].shape[1]
     vocab = c0 + sum(nn_)
+    if topk:
+        tokens = torch.empty(N, topk, dtype=torch.int32, device=dev)
+        lps = torch.empty(N, topk, dtype=torch.float32, device=dev)
+        call('tell_adaptive_logprob_topk', head, head.stride(0), c0, n_tails, tl[0], ld[0], nn_[0], tl[1], ld[1],
+             nn_[1], tl[2], ld[2], nn_[2], N, int(topk), tokens, lps)
+        return tokens, lps, None
     full = torch.empty(N, vocab, dtype=torch.float32, device=dev) if want_full else None
     token = torch.empty(N, dtype=torch.int32, device=dev)
     token_lp = torch.empty(N, dtype=torch.float32, device=dev)
