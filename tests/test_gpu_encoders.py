@@ -139,7 +139,7 @@ def test_roberta_graph_replay_dropout_step_counter():
     assert g.entries[(tuple(ids.shape), ids.dtype, ids.device.index, 'eval')]['state'] == 'ready'
     m.train()
     eager = fn(ids).float()
-    outs = [g(ids, key='train').float().clone() for _ in range(4)]       # call 0 eager, 1 capture + replay, 2, 3 replay
+    outs = [g(ids, key='train').float().clone() for _ in range(4)]       # call 0 eager (+ capture), 1-3 replay
     e = g.entries[(tuple(ids.shape), ids.dtype, ids.device.index, 'train')]
     assert e['state'] == 'ready', e.get('error')
     assert int(e['counter']) == 3

