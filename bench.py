@@ -230,6 +230,14 @@ def main():
                                          'launches_per_step': v['launches'] // (args.steps if args.serial else args.roofline_steps),
                                          'tflops': round(v['work'] / (v['total_ms'] * 1e-3) / 1e12, 2)}
                                      for k, v in prof_summary.items()}}
+        if args.model == 'flattened' and args.dtype == 'bf16':
+            # whole-step MFMA utilisation (BASELINE.json metric): algorithmic GEMM-class work per sample from the module
+            # shapes: RoBERTa-large fwd 335 GF, ResNet-152 fwd 23 GF, 2-context decoder training step
+            # (4.92 per-token + 0.90 head) x 3 (fwd + dgrad + wgrad) + 10.23 K/V projections x 2 (no dX) = 37.9 GF
+            gf = 335.0 + 23.0 + 37.9
+            tf = gf * 1e-3 * world * args.batch / (ms * 1e-3)
+            result['step_mfma'] = {'gflop_per_sample': gf, 'achieved': round(tf, 1), 'peak': 2500.0 * world,
+                                   'unit': 'TFLOP/s', 'frac': round(tf / (2500.0 * world), 4)}
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.cpu_sample)
         print(json.dumps(result))
