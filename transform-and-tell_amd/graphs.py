@@ -20,14 +20,20 @@ MAX_SIGNATURES = 4      # every captured signature keeps its activations in a pr
 
 
 class GraphedCall:
-    def __init__(self, fn, name='graph', rng=False):
+    def __init__(self, fn, name='graph', rng=False, buffers=2):
         """rng: the function contains dropout.  Its kernels are captured with a device step counter registered
         (tell_set_rng_step_ptr) and the counter is bumped before every replay, so the frozen seed/salt arguments
-        still give fresh masks (csrc/common.h tell_step_salt)."""
+        still give fresh masks (csrc/common.h tell_step_salt).
+
+        buffers: a replay writes its result into buffers owned by the graph, so every signature is captured
+        `buffers` times and the captures are used round-robin: the tensor returned by a call stays intact until
+        `buffers` further calls - the step pipeline needs 2 (the encoders of batch N+1 are replayed while the
+        decoder step of batch N is still reading the outputs for batch N)."""
         self.fn = fn
         self.name = name
         self.rng = rng
-        self.entries = {}          # signature -> dict(state=..., graph, static_in, static_out[, counter])
+        self.buffers = max(1, int(os.environ.get('TELL_GRAPH_BUFFERS', buffers)))   # env: test aid
+        self.entries = {}          # signature -> dict(state=..., slots=[dict(graph, static_in, static_out, counter)], turn)
 
     def reset(self):
         self.entries.clear()
@@ -40,34 +46,40 @@ class GraphedCall:
         e = self.entries.get(sig)
         if e is None:
             ready = sum(1 for v in self.entries.values() if v['state'] == 'ready')
-            e = self.entries[sig] = {'state': 'eager'}
+            e = self.entries[sig] = {'state': 'eager', 'slots': [], 'turn': 0}
             out = self.fn(x)                            # eager: also builds the weight caches the capture relies on
             if ready < MAX_SIGNATURES:
                 self._capture(e, x)                     # records, does not execute: the first call pays for it,
             return out                                  # not a later (timed) one
         if e['state'] != 'ready':
             return self.fn(x)
-        e['static_in'].copy_(x)
-        if e.get('counter') is not None:
-            e['counter'].add_(1)                        # same stream as the replay: ordered before it
-        e['graph'].replay()
-        return e['static_out']
+        s = e['slots'][e['turn']]
+        e['turn'] = (e['turn'] + 1) % len(e['slots'])
+        s['static_in'].copy_(x)
+        if s['counter'] is not None:
+            s['counter'].fill_(e['replays'])            # same stream as the replay: ordered before it
+        e['replays'] += 1
+        s['graph'].replay()
+        return s['static_out']
 
     def _capture(self, e, x):
         try:
-            static_in = x.clone()
-            counter = torch.zeros(1, dtype=torch.int32, device=x.device) if self.rng else None
-            g = torch.cuda.CUDAGraph()
-            try:
-                if counter is not None:
-                    hip.call('tell_set_rng_step_ptr', counter)
-                with torch.cuda.graph(g):
-                    with hip.bound_stream():            # launches must go to the CAPTURING stream
-                        static_out = self.fn(static_in)
-            finally:
-                if counter is not None:
-                    hip.call('tell_set_rng_step_ptr', None)
-            e.update(state='ready', graph=g, static_in=static_in, static_out=static_out, counter=counter)
+            slots = []
+            for _ in range(self.buffers):
+                static_in = x.clone()
+                counter = torch.zeros(1, dtype=torch.int32, device=x.device) if self.rng else None
+                g = torch.cuda.CUDAGraph()
+                try:
+                    if counter is not None:
+                        hip.call('tell_set_rng_step_ptr', counter)
+                    with torch.cuda.graph(g):
+                        with hip.bound_stream():        # launches must go to the CAPTURING stream
+                            static_out = self.fn(static_in)
+                finally:
+                    if counter is not None:
+                        hip.call('tell_set_rng_step_ptr', None)
+                slots.append({'graph': g, 'static_in': static_in, 'static_out': static_out, 'counter': counter})
+            e.update(state='ready', slots=slots, turn=0, replays=1)
         except Exception as exc:                        # noqa: BLE001 - any capture problem -> eager for good
             e['state'] = 'eager'
             e['error'] = repr(exc)
