@@ -518,6 +518,7 @@ __global__ __launch_bounds__(256) void attn_fwd_reg_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) T Ks[2][KT * KS];
   __shared__ __attribute__((aligned(16))) T Vs[2][KT * VS];
   __shared__ __attribute__((aligned(16))) float key_bias[2][KT];
+  __shared__ int tile_masked[2];                     // any key of the staged tile masked / past the end?
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
   typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -574,6 +575,8 @@ __global__ __launch_bounds__(256) void attn_fwd_reg_kernel(AttnArgs p) {
       bool ok = s < S_total;                                                                    \
       if (ok && s < p.S && p.mask) ok = p.mask[(long)b * p.S + s] == 0;                         \
       key_bias[BUF][tid] = ok ? 0.f : -INFINITY;                                                \
+      const bool any_masked = __ballot(!ok) != 0;             /* tid < 64 is exactly wave 0 */   \
+      if (tid == 0) tile_masked[BUF] = any_masked;                                              \
     }                                                                                           \
   }
   RLOAD_TILE(0)
@@ -608,7 +611,8 @@ __global__ __launch_bounds__(256) void attn_fwd_reg_kernel(AttnArgs p) {
           st[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[f], 0, 0, 0);   // S^T[key][q]
         }
       }
-      if (p.mask != nullptr || s0 + KT > S_total) {   // block-uniform: some key of this tile may be masked
+      // block-uniform: padding sits at the end of a sequence, so most tiles of a padded batch have nothing to add
+      if (__builtin_amdgcn_readfirstlane(tile_masked[buf])) {
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -627,29 +631,38 @@ __global__ __launch_bounds__(256) void attn_fwd_reg_kernel(AttnArgs p) {
       const float m_new = fmaxf(m_run, mx);
       const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;        // all keys masked so far: exp(-inf - 0) = 0
       const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
-      float ls = 0.f;
+      typedef __attribute__((ext_vector_type(2))) float f32x2;
       constexpr float LOG2E = 1.4426950408889634f;
       const float neg_m = -m_safe * LOG2E;
+      f32x2 ls2 = {0.f, 0.f};                          // pairs: the scale/shift and the row sum are packed fp32 ops
 #pragma unroll
       for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(fmaf(st[f][r], LOG2E, neg_m));   // exp(s - m): one fma + v_exp_f32
-          ls += pv;
-          st[f][r] = pv;
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 s2 = {st[f][r], st[f][r + 1]};
+          const f32x2 e2 = s2 * LOG2E + neg_m;         // exp(s - m) = exp2(s log2e - m log2e)
+          const f32x2 pv = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
+          ls2 += pv;
+          st[f][r] = pv[0];
+          st[f][r + 1] = pv[1];
         }
+      float ls = ls2[0] + ls2[1];
+      // Dropout only SELECTS here (kept probability or 0); the 1/(1-p) factor is applied once to the output row.
       if constexpr (DROP) {
         const uint64_t base = ((uint64_t)bh * p.Tq + t) * S_total + s0 + 4 * hh;
         if ((S_total & 1) == 0 && tell_keep_row_ok(base >> 1, 32)) {
+          // pair offsets visited: d = 0 1 4 5 8 9 12 13 16 17 ... 29 -> one running hash input, += stride or 3 strides
           const TellKeepRow row = tell_keep_row(p.seed, salt_eff, base >> 1);    // base is even here
+          uint32_t x = row.x0;
 #pragma unroll
           for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-              float k0, k1;
-              tell_keep2_row(row, (f * 32 + (r & 3) + 8 * (r >> 2)) >> 1, p.thr, p.inv_keep, k0, k1);
-              st[f][r] *= k0;
-              st[f][r + 1] *= k1;
+              bool k0, k1;
+              tell_keep2_bits(x, row.y, p.thr, k0, k1);     // == tell_keep2_row(row, (f*32 + (r&3) + 8*(r>>2)) >> 1, ...)
+              st[f][r] = k0 ? st[f][r] : 0.f;
+              st[f][r + 1] = k1 ? st[f][r + 1] : 0.f;
+              x += (r & 2) ? 3u * TELL_PAIR_STRIDE : TELL_PAIR_STRIDE;
             }
         } else if ((S_total & 1) == 0) {
 #pragma unroll
@@ -658,15 +671,16 @@ __global__ __launch_bounds__(256) void attn_fwd_reg_kernel(AttnArgs p) {
             for (int r = 0; r < 16; r += 2) {
               float k0, k1;
               tell_keep2(p.seed, salt_eff, base + (f * 32 + (r & 3) + 8 * (r >> 2)), p.thr, p.inv_keep, k0, k1);
-              st[f][r] *= k0;
-              st[f][r + 1] *= k1;
+              st[f][r] = k0 != 0.f ? st[f][r] : 0.f;
+              st[f][r + 1] = k1 != 0.f ? st[f][r + 1] : 0.f;
             }
         } else {
 #pragma unroll
           for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-              st[f][r] *= tell_keep(p.seed, salt_eff, base + (f * 32 + (r & 3) + 8 * (r >> 2)), p.thr, p.inv_keep);
+              st[f][r] = tell_keep(p.seed, salt_eff, base + (f * 32 + (r & 3) + 8 * (r >> 2)), p.thr, p.inv_keep) != 0.f
+                             ? st[f][r] : 0.f;
         }
       }
       ls += __shfl_xor(ls, 32, 64);
@@ -701,7 +715,7 @@ __global__ __launch_bounds__(256) void attn_fwd_reg_kernel(AttnArgs p) {
 #undef RLOAD_TILE
 #undef RSTORE_TILE
   if (!active || t >= p.Tq) return;
-  const float inv_l = l_run > 0.f ? 1.f / l_run : 0.f;
+  const float inv_l = (l_run > 0.f ? 1.f / l_run : 0.f) * (DROP ? p.inv_keep : 1.f);
   T* og = static_cast<T*>(p.out) + t * p.o_st + b * p.o_sb + (long)h * D;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)

@@ -146,6 +146,15 @@ __device__ __forceinline__ void tell_keep2_row(const TellKeepRow& r, uint32_t d,
   k0 = (x & 0xffffu) >= thr ? inv_keep : 0.f;
   k1 = (x >> 16) >= thr ? inv_keep : 0.f;
 }
+// The same two decisions as booleans, with the caller maintaining x = r.x0 + d * 0x9E3779B1 itself (a kernel that
+// walks a fixed pattern of d keeps ONE running value and adds one of two constants per pair instead of holding a
+// constant per pair in SGPRs).  keep <=> tell_keep2_row's factor != 0.
+#define TELL_PAIR_STRIDE 0x9E3779B1u
+__device__ __forceinline__ void tell_keep2_bits(uint32_t x, uint32_t y, uint32_t thr, bool& k0, bool& k1) {
+  x ^= y; x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  k0 = (x & 0xffffu) >= thr;
+  k1 = (x >> 16) >= thr;
+}
 // both decisions of the aligned pair starting at the EVEN index idx_even
 __device__ __forceinline__ void tell_keep2(uint32_t seed, uint32_t salt, uint64_t idx_even, uint32_t thr,
                                            float inv_keep, float& k0, float& k1) {

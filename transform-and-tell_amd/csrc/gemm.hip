@@ -2,6 +2,8 @@
 //
 //   gemm_nt_glds_kernel  bf16, K % 64 == 0, >= 256 tiles: operands stream global -> LDS directly
 //                        (global_load_lds_dwordx4), tiles 128x128 / 256x192 / 256x256.
+//   gemm_nt_pp_kernel    bf16, whole rounds of full 256x256 tiles: the same DMA image consumed by two wave groups
+//                        that alternate between LDS/DMA issue and MFMA segments (ping-pong), counted vmcnt.
 //   gemm_nt_kernel       any dtype / K / size: register-staged 2-4 deep prefetch, tiles 64x64 .. 256x128.
 //   gemm_tx_kernel       bf16 with K-major operands (A stored [K][M] and/or B stored [K][N]): the backward
 //                        products dY^T.X and dY.W read activations and weights as the forward pass left them;
@@ -196,20 +198,22 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmA
 // Full interior bf16 tile of a direct-to-LDS kernel: staged through free LDS (`cs`, BM rows of CS elements;
 // CS == BN means unpadded with the 16-byte chunk index XOR-swizzled by the row), so every output row
 // leaves as whole 128-byte lines.  Needs a block barrier BEFORE (cs no longer read as a tile) by the caller.
-template <int BM, int BN, int WM, int WN, int MI, int NI, int CS, int NT, int ACT>
+// LAY 0: a wave owns one contiguous WM x WN block.  LAY 1 (ping-pong kernel): a wave owns 64 rows in each half of
+// the tile's rows and 32 columns in each half of its columns (block i: half i>>1, 32-row group i&1; block j: half j).
+template <int BM, int BN, int WM, int WN, int MI, int NI, int CS, int NT, int ACT, int LAY = 0>
 __device__ __forceinline__ void glds_store_tile_act(f32x16 (&acc)[MI][NI], const GemmArgs& p, int m0, int n0, int wm,
                                                     int wn, int lane, int tid, uint16_t* cs) {
   constexpr bool SWZ = CS == BN;
   constexpr int CPRW = BN / 8;                                     // 16-byte chunks per tile row
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const int row = wm * WM + i * 32 + (lane & 31);
+    const int row = LAY ? (i >> 1) * (BM / 2) + wm * 64 + (i & 1) * 32 + (lane & 31) : wm * WM + i * 32 + (lane & 31);
     const float bm = p.bias_mode == 2 ? p.bias[m0 + row] : 0.f;
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int col = wn * WN + j * 32 + 8 * g + 4 * (lane >> 5);
+        const int col = (LAY ? j * (BN / 2) + wn * 32 : wn * WN + j * 32) + 8 * g + 4 * (lane >> 5);
         f32x4_t b4 = {0.f, 0.f, 0.f, 0.f};
         if (p.bias_mode == 1) b4 = *reinterpret_cast<const f32x4_t*>(p.bias + n0 + col);
         f32x4_t v;
@@ -232,13 +236,13 @@ __device__ __forceinline__ void glds_store_tile_act(f32x16 (&acc)[MI][NI], const
         *reinterpret_cast<const u32x4*>(cs + row * CS + sch * 8);
   }
 }
-template <int BM, int BN, int WM, int WN, int MI, int NI, int CS, int NT>
+template <int BM, int BN, int WM, int WN, int MI, int NI, int CS, int NT, int LAY = 0>
 __device__ __forceinline__ void glds_store_tile(f32x16 (&acc)[MI][NI], const GemmArgs& p, int m0, int n0, int wm,
                                                 int wn, int lane, int tid, uint16_t* cs) {
   switch (p.act) {
-    case 1: glds_store_tile_act<BM, BN, WM, WN, MI, NI, CS, NT, 1>(acc, p, m0, n0, wm, wn, lane, tid, cs); break;
-    case 2: glds_store_tile_act<BM, BN, WM, WN, MI, NI, CS, NT, 2>(acc, p, m0, n0, wm, wn, lane, tid, cs); break;
-    default: glds_store_tile_act<BM, BN, WM, WN, MI, NI, CS, NT, 0>(acc, p, m0, n0, wm, wn, lane, tid, cs); break;
+    case 1: glds_store_tile_act<BM, BN, WM, WN, MI, NI, CS, NT, 1, LAY>(acc, p, m0, n0, wm, wn, lane, tid, cs); break;
+    case 2: glds_store_tile_act<BM, BN, WM, WN, MI, NI, CS, NT, 2, LAY>(acc, p, m0, n0, wm, wn, lane, tid, cs); break;
+    default: glds_store_tile_act<BM, BN, WM, WN, MI, NI, CS, NT, 0, LAY>(acc, p, m0, n0, wm, wn, lane, tid, cs); break;
   }
 }
 __device__ __forceinline__ bool glds_fast_tile(const GemmArgs& p, int m0, int n0, int BM, int BN, int M, int N) {
@@ -379,15 +383,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(Ge
     row = row < N ? row : N - 1;
     bsrc[j] = B + (long)row * p.ldb + (l16 & 7) * 8;
   }
-  auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+  // quarter q (0..3) of tile kt's DMA instructions, or all of them (q < 0)
+  auto issue = [&](int kt, int stage, int q) __attribute__((always_inline)) {
     unsigned char* sa = smem + stage * STAGE + (wave * IA) * 1024;
     unsigned char* sb = smem + stage * STAGE + A_BYTES + (wave * IB) * 1024;
 #pragma unroll
     for (int j = 0; j < IA; ++j)
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[j] + kt * BK), (lds_ptr_t)(sa + j * 1024), 16, 0, 0);
+      if (q < 0 || j * 4 / IA == q)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[j] + kt * BK), (lds_ptr_t)(sa + j * 1024), 16, 0, 0);
 #pragma unroll
     for (int j = 0; j < IB; ++j)
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(bsrc[j] + kt * BK), (lds_ptr_t)(sb + j * 1024), 16, 0, 0);
+      if (q < 0 || j * 4 / IB == q)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(bsrc[j] + kt * BK), (lds_ptr_t)(sb + j * 1024), 16, 0, 0);
   };
 
   // fragment addressing: row r of a tile, 16-byte k-chunk c (0..7): byte = (r>>1)*256 + ((((r&1)<<3)|c) ^ ((r>>1)&15))*16
@@ -412,12 +419,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(Ge
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = K / BK;
-  issue(0, 0);
+  issue(0, 0, -1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int st = kt & 1;
-    if (kt + 1 < nk) issue(kt + 1, st ^ 1);          // streams in under the MFMAs below
+    // tile kt+1 streams in under the MFMAs below, a quarter of its DMA instructions per k-substep: the LDS port
+    // is shared by these writes and the fragment reads, and a burst of 8 at the top of the iteration stalls both
+    // (probe: tools/probes/gemm_ablate.hip, +3..9 %)
+    const bool more = kt + 1 < nk;
     const unsigned char* ta = smem + st * STAGE;
     const unsigned char* tb = ta + A_BYTES;
     // Large wave tiles (128x64: 8 MFMAs per k-substep): fragments of substep ks+1 are read into a second
@@ -443,6 +453,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(Ge
       } else {
         ldfrag(ks, ks & 1);
       }
+      if (more) issue(kt + 1, st ^ 1, ks);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -471,6 +482,162 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(Ge
     }
   }
   gemm_epilogue<OutT, MI, NI>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, M, N);
+}
+
+// ------------------------------------------------------------- 256x256 ping-pong kernel (bf16, full tiles only)
+// 8 waves as 2 groups x 4 (one wave of each group per SIMD).  The K tile (64) is staged as four half-tile images
+// (A rows 0-127 / 128-255, B rows 0-127 / 128-255; 16 KB each = 2 DMA instructions per wave), two K tiles in LDS.
+// A K tile is consumed in 4 phases, one 64x32 output quadrant per wave and phase (8 MFMAs):
+//     phase 1: read A0, B0 -> C(0,0)   2: read B1 -> C(0,1)   3: read A1 -> C(1,1)   4: (B0 still held) -> C(1,0)
+// Every phase is  { ds_reads + one half-tile of DMA prefetch | s_barrier | MFMAs | s_barrier }  and group 1 runs
+// one barrier behind group 0, so on each SIMD one wave is in its MFMA segment while the other does its LDS reads
+// and DMA issue - LDS port and matrix core are busy at the same time instead of taking turns (the lockstep 2-barrier
+// kernels above lose ~40 % to that, tools/probes/gemm_ablate.hip).  Loads are never drained inside the loop:
+// half-tile n (n = 4*tile + {A0,B0,B1,A1}) is issued in phase n-6 and retired by the counted vmcnt(4) of phase 4 of
+// the PREVIOUS K tile, i.e. at least one barrier before its first read (RAW) and it overwrites a slot whose last
+// read was >= 2 phases earlier (WAR).
+template <typename OutT>
+__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
+  constexpr int BM = 256, BN = 256, BK = 64;
+  constexpr int HALF = 128 * 128, TILE = 4 * HALF;        // bytes: one half-tile image, one K tile (A0 A1 B0 B1)
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * TILE];
+  const int tid = threadIdx.x, lane = tid & 63, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int M = p.M, N = p.N, K = p.K;
+  const int tiles_n = N / BN, tiles_m = M / BM;
+  int tile_id;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  int tm, tn;
+  {
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * tiles_n;
+    const int g = tile_id / per_group, first_m = g * GROUP_M;
+    const int gm = tiles_m - first_m < GROUP_M ? tiles_m - first_m : GROUP_M;
+    const int in_g = tile_id - g * per_group;
+    tm = first_m + in_g % gm;
+    tn = in_g / gm;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const uint16_t* A = static_cast<const uint16_t*>(p.A);
+  const uint16_t* B = static_cast<const uint16_t*>(p.B);
+  // DMA sources (same swizzled lane-linear image as gemm_nt_glds_kernel, per half-tile of 128 rows)
+  const uint16_t* asrc[2];
+  const uint16_t* bsrc[2];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int s = (wave * 2 + jj) * 64 + lane, pr = s >> 4, l16 = (s & 15) ^ (pr & 15);
+    const int row = 2 * pr + (l16 >> 3);
+    asrc[jj] = A + (long)(m0 + row) * p.lda + (l16 & 7) * 8;
+    bsrc[jj] = B + (long)(n0 + row) * p.ldb + (l16 & 7) * 8;
+  }
+  const long a_half = 128 * p.lda, b_half = 128 * p.ldb;
+  // half-tile KIND of K tile tt: 0 = A0, 1 = B0, 2 = B1, 3 = A1 (the order the phases need them)
+  auto stage = [&](int tt, auto kind_c) __attribute__((always_inline)) {
+    constexpr int KIND = decltype(kind_c)::value;
+    constexpr int H = KIND == 0 ? 0 : KIND == 3 ? 1 : KIND == 1 ? 2 : 3;      // LDS order A0 A1 B0 B1
+    unsigned char* dst = smem + (tt & 1) * TILE + H * HALF + wave * 2048;
+    const long off = (long)tt * BK + (KIND == 3 ? a_half : KIND == 2 ? b_half : 0);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(((KIND == 0 || KIND == 3) ? asrc[jj] : bsrc[jj]) + off),
+                                       (lds_ptr_t)(dst + jj * 1024), 16, 0, 0);
+  };
+  // fragment addresses inside a half-tile image
+  int a_off[2][4], b_off[4];
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii) {
+    const int r = wr * 64 + ii * 32 + (lane & 31);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      a_off[ii][ks] = (r >> 1) * 256 + (((((r & 1) << 3) | (ks * 2 + lh)) ^ ((r >> 1) & 15)) << 4);
+  }
+  {
+    const int r = wc * 32 + (lane & 31);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      b_off[ks] = (r >> 1) * 256 + (((((r & 1) << 3) | (ks * 2 + lh)) ^ ((r >> 1) & 15)) << 4);
+  }
+  bf16x8 af[2][4], bfr[2][4];
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  auto read_a = [&](int tt, int a) __attribute__((always_inline)) {
+    const unsigned char* t = smem + (tt & 1) * TILE + a * HALF;
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) af[ii][ks] = *reinterpret_cast<const bf16x8*>(t + a_off[ii][ks]);
+  };
+  auto read_b = [&](int tt, int bb) __attribute__((always_inline)) {
+    const unsigned char* t = smem + (tt & 1) * TILE + (2 + bb) * HALF;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) bfr[bb][ks] = *reinterpret_cast<const bf16x8*>(t + b_off[ks]);
+  };
+  auto mma = [&](int a, int bb) __attribute__((always_inline)) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+        acc[a * 2 + ii][bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[bb][ks], af[ii][ks], acc[a * 2 + ii][bb], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+  using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+
+  const int nk = K / BK;
+  stage(0, K0{}); stage(0, K1{}); stage(0, K2{}); stage(0, K3{});
+  if (nk >= 2) {
+    stage(1, K0{}); stage(1, K1{});
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();            // group 1 runs one barrier behind
+  for (int t = 0; t < nk; ++t) {
+    // phase 1
+    read_a(t, 0); read_b(t, 0);
+    if (t + 1 < nk) stage(t + 1, K2{});
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0, 0);
+    // phase 2
+    read_b(t, 1);
+    if (t + 1 < nk) stage(t + 1, K3{});
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0, 1);
+    // phase 3
+    read_a(t, 1);
+    if (t + 2 < nk) stage(t + 2, K0{});
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1, 1);
+    // phase 4: K tile t+1 must have landed before anyone reads it in the next phase 1
+    if (t + 2 < nk) {
+      stage(t + 2, K1{});
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1, 0);
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  // every wave has passed its last phase: the tile buffers are free for the staged store
+  glds_store_tile<BM, BN, 128, 64, 4, 2, BN, 512, 1>(acc, p, m0, n0, wr, wc, lane, tid,
+                                                     reinterpret_cast<uint16_t*>(smem));
 }
 
 // ------------------------------------------------------------- register-staged kernel (any dtype, any K)
@@ -821,7 +988,9 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
   auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
   if constexpr (sizeof(T) == 2) {
     if (a.K % 64 == 0 && tiles(128, 128) >= 256) {       // direct-to-LDS path
-      static const int force = getenv("TELL_GEMM_TILE") ? atoi(getenv("TELL_GEMM_TILE")) : 0;   // tuning aid
+      static const int force_env = getenv("TELL_GEMM_TILE") ? atoi(getenv("TELL_GEMM_TILE")) : 0;   // tuning aid
+      const bool no_pp = force_env == 7;                  // 7: the default choice without the ping-pong kernel (A/B)
+      const int force = no_pp ? 0 : force_env;
       static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); (void)hipGetDeviceProperties(&pr, d); return pr.multiProcessorCount; }();
       // 256x192 (8 waves as 4x2, 64x96 per wave): the QKV projection (N = 3072) quantises to whole rounds with it
       if ((force == 0 || force == 9) && a.N % 192 == 0 && tiles(256, 192) % n_cu == 0 && a.K <= 2048 && !a.accumulate &&
@@ -829,12 +998,22 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
         hipLaunchKernelGGL((gemm_nt_glds_kernel<OutT, 256, 192, 4, 2>), dim3((unsigned)tiles(256, 192)), dim3(512), 0, stream, a);
         return tell_check_launch("gemm_nt_glds");
       }
+      if constexpr (std::is_same<OutT, uint16_t>::value) {
+        const bool full = a.M % 256 == 0 && a.N % 256 == 0 && !a.accumulate && a.act != 3 && !a.m_dev && !a.stat_mean &&
+                          (a.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0 &&
+                          (a.bias_mode != 1 || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
+        // ping-pong 256x256: whole rounds of full tiles (fc1 of RoBERTa: 878 vs 838 TFLOP/s, 4096^3: 1171 vs 1022,
+        // 8192^3: 1333 vs 1164); partial rounds lose to the smaller tiles below.  TELL_GEMM_TILE=8 forces it.
+        if (full && !no_pp && ((force == 0 && tiles(256, 256) % n_cu == 0) || (force == 8 && tiles(256, 256) >= n_cu))) {
+          hipLaunchKernelGGL((gemm_nt_pp_kernel<OutT>), dim3((unsigned)tiles(256, 256)), dim3(512), 0, stream, a);
+          return tell_check_launch("gemm_nt_pp");
+        }
+      }
       if (force == 5) {   // 256x256, 8 waves (128x64 per wave), 2-stage
         hipLaunchKernelGGL((gemm_nt_glds_kernel<OutT, 256, 256, 2, 4>), dim3((unsigned)tiles(256, 256)), dim3(512), 0, stream, a);
         return tell_check_launch("gemm_nt_glds");
       }
-      // 256x256 (8 waves, 1 workgroup/CU) wins when its tiles fill the chip in whole rounds and K is short
-      // (M8192 N4096 K1024: 889 vs 820 TFLOP/s); partial rounds or few tiles lose to 128x128
+      // lockstep 256x256 (8 waves, 1 workgroup/CU) for whole rounds with ragged edges / fp32 output, short K
       *bm_used = 128;
       if (force == 0 && tiles(256, 256) % n_cu == 0 && a.K <= 2048 && !a.accumulate && !a.stat_mean) {
         hipLaunchKernelGGL((gemm_nt_glds_kernel<OutT, 256, 256, 2, 4>), dim3((unsigned)tiles(256, 256)), dim3(512), 0, stream, a);

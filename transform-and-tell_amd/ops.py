@@ -86,9 +86,14 @@ def gemm(a, b, out=None, out_dtype=None, bias=None, bias_mode=0, act=0, aux=None
         if bf and a.shape[1] % 64 == 0 and tiles(128, 128) >= 256:
             n_cu = torch.cuda.get_device_properties(a.device).multi_processor_count
             small_k = a.shape[1] <= 2048 and not accumulate
+            full = (M % 256 == 0 and N % 256 == 0 and not accumulate and act != 3 and out.dtype == torch.bfloat16 and
+                    out.stride(0) % 8 == 0 and out.data_ptr() % 16 == 0 and
+                    (bias_mode != 1 or bias.data_ptr() % 16 == 0))
             tile = ((256, 256) if (small_k and tiles(256, 256) % n_cu == 0) else
                     (256, 192) if (small_k and N % 192 == 0 and tiles(256, 192) % n_cu == 0) else (128, 128))
             kname = 'gemm_nt_glds_kernel<%s,%d,%d>' % (names[1], tile[0], tile[1])
+            if full and tiles(256, 256) % n_cu == 0:
+                kname = 'gemm_nt_pp_kernel<bf16,256,256>'
         else:
             tile = ((256, 128) if bf and tiles(256, 128) >= 256 else (128, 128) if tiles(128, 128) >= 256
                     else (64, 64))
