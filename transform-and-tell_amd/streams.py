@@ -6,7 +6,10 @@ time-slices them.  Measured on MI355X with this schedule (samples/s, 1 GPU): GPU
 2: 835, 3: 1073, 4: 1125, 8: 779, 16: 760 - and 940 at the default 4 once an RCCL communicator exists (its
 queue is a 5th), back to 1085-1093 with GPU_MAX_HW_QUEUES=3.  Hence: every role gets its stream from this one
 registry in a fixed order, and multi-GPU launchers set GPU_MAX_HW_QUEUES=3 before the first HIP call
-(bench.py does)."""
+(bench.py does).
+Stream priorities are not an option for the same reason: hipStreamCreateWithPriority streams get hardware queues of
+their own (low-priority encoder streams: 1060 -> 640 samples/s, high-priority wgrad/update streams: -> 640).  Folding
+roles together loses too: update on the wgrad stream -1 %, both encoders on one stream -11 %."""
 import torch
 
 import os
