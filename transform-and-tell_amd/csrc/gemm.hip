@@ -496,6 +496,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(Ge
 // half-tile n (n = 4*tile + {A0,B0,B1,A1}) is issued in phase n-6 and retired by the counted vmcnt(4) of phase 4 of
 // the PREVIOUS K tile, i.e. at least one barrier before its first read (RAW) and it overwrites a slot whose last
 // read was >= 2 phases earlier (WAR).
+// (A 256x128 variant of this schedule - 64x64 wave tiles, one uniform 32-k phase, ring of 6 LDS slots - was built and
+//  measured: 923 TFLOP/s at 8192^3, the same as the lockstep 128x128 kernel.  With 64x64 wave tiles the LDS port
+//  (fragment reads + DMA writes = 1.34x the MFMA time) is the wall whatever the schedule; only the 128x64 wave tile
+//  of the 256x256 block gets under it.  N = 1024 outputs therefore stay on the 128x128 kernel.)
 template <typename OutT>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
   constexpr int BM = 256, BN = 256, BK = 64;
