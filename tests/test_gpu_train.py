@@ -296,12 +296,64 @@ def test_dp_code_path_one_rank_rccl(monkeypatch):
         torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
+        from tell_amd import runtime as rt_
+        rt_.set_grad_ready_callback(None)
     # BertAdam normalises every update by sqrt(v): elements whose gradient is ~0 can move by +-lr in either
     # direction after the bf16 rounding, so compare in the large (whole-model norm), not per tensor
     num = sum(float((p - q).norm() ** 2) for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters())
               if p.requires_grad)
     den = sum(float(p.norm() ** 2) for n, p in a.named_parameters() if p.requires_grad)
     assert (num / den) ** 0.5 < 1e-2, (num / den) ** 0.5
+
+
+def test_dp_bucketed_allreduce_during_backward_one_rank_rccl(monkeypatch):
+    """The gradient slices of the decoder layers are all-reduced while backward is still running.  A slice exchanged
+    before its last contribution would be wrong on N > 1 ranks only, so the test emulates two identical ranks: every
+    all-reduce is followed by x2 on the range it covered.  The bucketed schedule must then give the same weights as
+    the single exchange after backward (any gradient added after its slice was reduced would count once, not twice)."""
+    import copy
+    import torch.distributed as dist
+    import tell_amd
+    from tell_amd.build import build_model
+    from tell_amd.data import synthetic_batch
+    from tell_amd.training import Trainer
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    tell_amd.manual_seed(5)
+    torch.manual_seed(5)
+    a = build_model('flattened', _Res(True), _Rob(64), n_bert_layers=3, article_dim=64, **KW)
+    _no_dropout(a)
+    b = copy.deepcopy(a)
+    ocfg = dict(lr=2e-3, warmup=0.5, t_total=6, max_grad_norm=0.1, weight_decay=0.0)
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    monkeypatch.setenv('MASTER_PORT', '29582')
+    monkeypatch.setenv('TELL_DP_SELFTEST', '1')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        monkeypatch.setenv('TELL_DP_BUCKETED', '0')
+        single = Trainer(a, dict(ocfg), device=DEV)
+        monkeypatch.setenv('TELL_DP_BUCKETED', '1')
+        bucketed = Trainer(b, dict(ocfg), device=DEV)
+        assert not single._ranges and len(bucketed._ranges) == len(b.decoder.layers)
+        single._test_reduce_scale = bucketed._test_reduce_scale = 2.0
+        for s in range(3):
+            bt = synthetic_batch(B=3, article_len=20, caption_len=9, vocab=600, cutoffs=(100, 300), seed=50 + s)
+            dev = {k: ({kk: vv.to(DEV) for kk, vv in v.items()} if isinstance(v, dict) else v.to(DEV))
+                   for k, v in bt.items()}
+            clone = lambda x: {k: (dict(v) if isinstance(v, dict) else v) for k, v in x.items()}   # noqa: E731
+            l0, l1 = single.train_one_batch(clone(dev)), bucketed.train_one_batch(clone(dev))
+            assert abs(float(l0) - float(l1)) <= 1e-3 * abs(float(l0)), (s, float(l0), float(l1))
+        assert bucketed.bucketed_reduces == 3 * len(b.decoder.layers) and single.bucketed_reduces == 0
+        single.finish_update()
+        bucketed.finish_update()
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+        from tell_amd import runtime as rt
+        rt.set_grad_ready_callback(None)
+    num = sum(float((p - q).norm() ** 2) for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters())
+              if p.requires_grad)
+    den = sum(float(p.norm() ** 2) for n, p in a.named_parameters() if p.requires_grad)
+    assert (num / den) ** 0.5 < 1e-4, (num / den) ** 0.5
 
 
 def test_pipelined_steps_with_graphed_encoders_equal_eager_fp32():

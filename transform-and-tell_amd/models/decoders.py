@@ -159,6 +159,7 @@ class _DynamicConvDecoderBase(Decoder):
         attns, inner_states = [], [X]
         for i, layer in enumerate(self.layers):
             if not use_layers or i in use_layers:
+                X = ops.grad_ready_marker(X, 'decoder.layers.%d.' % i)    # DP: layer i's gradients are final here
                 X, attn = layer(X, contexts, incremental_state, contexts_t,
                                 None if kv_cache is None else kv_cache[i])
                 inner_states.append(X)

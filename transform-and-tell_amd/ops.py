@@ -329,6 +329,37 @@ def wgrad_job(job, *inputs):
         _flush_wgrad()
 
 
+class _GradReadyFn(Function):
+    """Identity whose backward reports that everything downstream of it has finished its backward."""
+
+    @staticmethod
+    def forward(ctx, x, tag):
+        ctx.tag = tag
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        cb = rt.grad_ready_callback()
+        if cb is not None:
+            cb(ctx.tag)
+        return g, None
+
+
+def grad_ready_marker(x, tag):
+    """Put in front of a block of layers: when its backward runs, the gradients of that block's parameters are final
+    (data-parallel bucketed all-reduce, training/trainer.py).  A no-op unless a callback is registered."""
+    if rt.grad_ready_callback() is None or not (torch.is_grad_enabled() and x.requires_grad):
+        return x
+    return _GradReadyFn.apply(x, tag)
+
+
+def flush_wgrad_stream():
+    """Hand every queued weight-gradient job to the side stream now; -> that stream (None if unused)."""
+    _flush_wgrad()
+    main = _WGRAD['main']
+    return None if main is None else _WGRAD['streams'].get(main.device)
+
+
 def join_wgrad_stream():
     """Make the producing stream wait for outstanding weight-gradient work (no-op if there is none)."""
     if _WGRAD['main'] is not None:

@@ -54,6 +54,19 @@ def bump_weights_epoch():
 _pending_update = [None]
 
 
+_grad_ready = [None]
+
+
+def set_grad_ready_callback(fn):
+    """Data-parallel trainer: fn(tag) is called from the backward pass when every gradient of the parameters behind
+    `ops.grad_ready_marker(x, tag)` has been issued (they can be all-reduced while the rest of backward runs)."""
+    _grad_ready[0] = fn
+
+
+def grad_ready_callback():
+    return _grad_ready[0]
+
+
 def set_pending_update(event):
     _pending_update[0] = event
 

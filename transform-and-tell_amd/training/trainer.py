@@ -64,6 +64,45 @@ class Trainer:
         self.update_stream = streams.get('update', device) if self.async_update else None
         self.flat.zero_grad()
         self.model.register_state_dict_pre_hook(lambda *a, **k: self.finish_update())
+        # DP: the gradients of a decoder layer are final when backward leaves the layer (ops.grad_ready_marker); their
+        # slice of the flat buffer is all-reduced on the update stream right then, underneath the rest of backward.
+        # Only what is left (embedder / tied adaptive tables, 35 % of the bytes) is exchanged after backward.
+        self._ranges, self._reduced, self._in_backward = {}, [], False
+        self.bucketed_reduces = 0
+        self._test_reduce_scale = None              # tests: emulate world_size 2 with identical ranks (x2 after a reduce)
+        if self.dp and self.async_update and os.environ.get('TELL_DP_BUCKETED', '1') != '0':
+            self._ranges = self._layer_ranges()
+            if self._ranges:
+                rt.set_grad_ready_callback(self._grad_ready)
+
+    def _layer_ranges(self):
+        """{prefix: (lo, hi)} - the contiguous slice of the flat buffers that holds exactly the parameters whose name
+        starts with 'decoder.layers.<i>.'."""
+        fl, out = self.flat, {}
+        ends = fl.offsets[1:] + [fl.total]
+        for i in range(len(getattr(getattr(self.model, 'decoder', None), 'layers', []))):
+            pre = 'decoder.layers.%d.' % i
+            idx = [k for k, n in enumerate(fl.names) if n.startswith(pre)]
+            if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+                return {}                            # not contiguous (tied across layers): keep the single exchange
+            out[pre] = (fl.offsets[idx[0]], ends[idx[-1]])
+        return out
+
+    def _grad_ready(self, tag):
+        """Called from the autograd thread (current stream = the stream backward runs on)."""
+        rng_ = self._ranges.get(tag)
+        if rng_ is None or not self._in_backward:
+            return
+        main = torch.cuda.current_stream()
+        side = ops.flush_wgrad_stream()              # this layer's weight-gradient GEMMs are on the side stream now
+        us = self.update_stream
+        us.wait_stream(main)
+        if side is not None:
+            us.wait_stream(side)
+        with torch.cuda.stream(us), hip.bound_stream():
+            self._all_reduce_grads(*rng_)
+        self._reduced.append(rng_)
+        self.bucketed_reduces += 1
 
     def finish_update(self):
         """Make the current stream wait for an in-flight weight update (checkpointing, evaluation, ...)."""
@@ -111,7 +150,11 @@ class Trainer:
                 self.dist.all_reduce(bad)
             if bad.item() > 0:
                 return None
-        scaled.backward()                                                # :229-231
+        self._in_backward = True
+        try:
+            scaled.backward()                                            # :229-231
+        finally:
+            self._in_backward = False
         ops.join_wgrad_stream()                                          # weight-gradient side stream (ops.py)
         if self.async_update:
             main = torch.cuda.current_stream()
@@ -128,18 +171,27 @@ class Trainer:
 
     def _update(self):
         if self.dp:
-            self._all_reduce_grads()
+            done, self._reduced = sorted(self._reduced), []
+            lo = 0
+            for a, b in done + [(self.flat.total, self.flat.total)]:     # everything not exchanged during backward
+                if a > lo:
+                    self._all_reduce_grads(lo, a)
+                lo = max(lo, b)
         self.optimizer.step(grad_scale=1.0 / self.world, zero_grad=True)  # :238 (+ :214 of the next batch)
 
-    def _all_reduce_grads(self):
+    def _all_reduce_grads(self, lo=0, hi=None):
+        hi = self.flat.total if hi is None else hi
+        grad = self.flat.grad[lo:hi]
         if self.allreduce_dtype == torch.bfloat16:
             if self._wire is None:
                 self._wire = torch.empty(self.flat.total, dtype=torch.bfloat16, device=self.flat.grad.device)
             dp.all_reduce_flat_bf16(
-                self.flat.grad, self._wire, self.dist, 2 * self.bucket_elems,
+                grad, self._wire[lo:hi], self.dist, 2 * self.bucket_elems,
                 lambda s, d: hip.call('tell_cast', s, hip.dt(s), d, hip.dt(d), s.numel()))
         else:
-            dp.all_reduce_flat(self.flat.grad, self.dist, self.bucket_elems)
+            dp.all_reduce_flat(grad, self.dist, self.bucket_elems)
+        if self._test_reduce_scale is not None:
+            grad.mul_(self._test_reduce_scale)
 
 
 @TrainerBase.register('callback_apex')
