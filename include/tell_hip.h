@@ -59,6 +59,12 @@ int tell_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, long
                  int in_dtype, int out_dtype, const float* bias, int bias_mode, int act, const void* aux,
                  float alpha, int accumulate, const int* m_dev, tell_stream_t stream);
 
+/* The kernel tell_gemm_nt would launch for exactly these arguments, as a readable label ("gemm_nt_pp_kernel<bf16,256,256>",
+ * "gemm_nt_glds_kernel<bf16,128,128>", ...); nothing is launched.  Measurement aid (bench.py's roofline block). */
+const char* tell_gemm_nt_plan(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                 int in_dtype, int out_dtype, const float* bias, int bias_mode, int act, const void* aux,
+                 float alpha, int accumulate, const int* m_dev, tell_stream_t stream);
+
 /* bf16 GEMM with K-major operands (no transposed copies in HBM): trans_a -> A stored [K][M] (lda >= M),
  * trans_b -> B stored [K][N].  The backward forms of the same reference lines: autograd of F.linear gives
  * grad_weight = grad_out^T . x (trans_a = trans_b = 1) and grad_in = grad_out . W (trans_b = 1).

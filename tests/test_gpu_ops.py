@@ -153,6 +153,14 @@ def test_gemm_pingpong_kernel(M, N, K):
     for _ in range(4):
         assert torch.equal(ops.gemm(ad, bd), out)
         assert torch.equal(ops.gemm(ad, bd, bias=bias_n.to(DEV), bias_mode=1, act=2, alpha=0.5), out2)
+    # the library itself says which kernel these calls ran on (and that the ragged one did not)
+    from tell_amd import hip
+
+    def plan(x, y, o):
+        return hip.query('tell_gemm_nt_plan', x, x.stride(0), y, y.stride(0), o, o.stride(0), x.shape[0], y.shape[0],
+                         x.shape[1], hip.BF16, hip.BF16, None, 0, 0, None, 1.0, 0, None)
+    assert plan(ad, bd, out) == 'gemm_nt_pp_kernel<bf16,256,256>'
+    assert plan(ad[:M - 8], bd, out_small).startswith('gemm_nt_glds_kernel<bf16,')
 
 
 @pytest.mark.parametrize('dtype', DTYPES)

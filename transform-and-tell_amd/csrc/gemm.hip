@@ -20,6 +20,7 @@
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <stdio.h>
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // 16-byte staging chunk (native vector: stays in VGPRs)
 
@@ -983,6 +984,19 @@ static int launch_gemm_tx(const GemmArgs& a, hipStream_t stream) {
   return tell_check_launch("gemm_tx");
 }
 
+// Which kernel a call runs is decided here and only here: every launch goes through TELL_GEMM_LAUNCH, which records a
+// readable label; tell_gemm_nt_plan() runs the same decision with the launch suppressed (bench.py's roofline block
+// names kernels by asking, not by mirroring the heuristics).
+static thread_local char g_gemm_label[96] = "";
+static thread_local bool g_gemm_plan = false;
+static const char* gemm_label(const char* base, int in_bf16, int out_bf16, int bm, int bn) {
+  if (in_bf16 < 0) snprintf(g_gemm_label, sizeof(g_gemm_label), "%s<%s,%d,%d>", base, out_bf16 ? "bf16" : "f32", bm, bn);
+  else snprintf(g_gemm_label, sizeof(g_gemm_label), "%s<%s,%s,%d,%d>", base, in_bf16 ? "bf16" : "f32", out_bf16 ? "bf16" : "f32", bm, bn);
+  return g_gemm_label;
+}
+#define TELL_GEMM_LAUNCH(label, kern, grid, block) \
+  do { if (g_gemm_plan) (void)(label); else hipLaunchKernelGGL(kern, grid, block, 0, stream, a); } while (0)
+
 template <typename T, typename OutT>
 static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nullptr) {
   int bm_dummy;
@@ -999,8 +1013,8 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
       // 256x192 (8 waves as 4x2, 64x96 per wave): the QKV projection (N = 3072) quantises to whole rounds with it
       if ((force == 0 || force == 9) && a.N % 192 == 0 && tiles(256, 192) % n_cu == 0 && a.K <= 2048 && !a.accumulate &&
           !a.stat_mean && tiles(256, 256) % n_cu != 0) {
-        hipLaunchKernelGGL((gemm_nt_glds_kernel<OutT, 256, 192, 4, 2>), dim3((unsigned)tiles(256, 192)), dim3(512), 0, stream, a);
-        return tell_check_launch("gemm_nt_glds");
+        TELL_GEMM_LAUNCH(gemm_label("gemm_nt_glds_kernel", -1, sizeof(OutT) == 2, 256, 192), (gemm_nt_glds_kernel<OutT, 256, 192, 4, 2>), dim3((unsigned)tiles(256, 192)), dim3(512));
+        return g_gemm_plan ? TELL_OK : tell_check_launch("gemm_nt_glds");
       }
       if constexpr (std::is_same<OutT, uint16_t>::value) {
         const bool full = a.M % 256 == 0 && a.N % 256 == 0 && !a.accumulate && a.act != 3 && !a.m_dev && !a.stat_mean &&
@@ -1009,38 +1023,38 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
         // ping-pong 256x256: whole rounds of full tiles (fc1 of RoBERTa: 878 vs 838 TFLOP/s, 4096^3: 1171 vs 1022,
         // 8192^3: 1333 vs 1164); partial rounds lose to the smaller tiles below.  TELL_GEMM_TILE=8 forces it.
         if (full && !no_pp && ((force == 0 && tiles(256, 256) % n_cu == 0) || (force == 8 && tiles(256, 256) >= n_cu))) {
-          hipLaunchKernelGGL((gemm_nt_pp_kernel<OutT>), dim3((unsigned)tiles(256, 256)), dim3(512), 0, stream, a);
-          return tell_check_launch("gemm_nt_pp");
+          TELL_GEMM_LAUNCH(gemm_label("gemm_nt_pp_kernel", -1, sizeof(OutT) == 2, 256, 256), (gemm_nt_pp_kernel<OutT>), dim3((unsigned)tiles(256, 256)), dim3(512));
+          return g_gemm_plan ? TELL_OK : tell_check_launch("gemm_nt_pp");
         }
       }
       if (force == 5) {   // 256x256, 8 waves (128x64 per wave), 2-stage
-        hipLaunchKernelGGL((gemm_nt_glds_kernel<OutT, 256, 256, 2, 4>), dim3((unsigned)tiles(256, 256)), dim3(512), 0, stream, a);
-        return tell_check_launch("gemm_nt_glds");
+        TELL_GEMM_LAUNCH(gemm_label("gemm_nt_glds_kernel", -1, sizeof(OutT) == 2, 256, 256), (gemm_nt_glds_kernel<OutT, 256, 256, 2, 4>), dim3((unsigned)tiles(256, 256)), dim3(512));
+        return g_gemm_plan ? TELL_OK : tell_check_launch("gemm_nt_glds");
       }
       // lockstep 256x256 (8 waves, 1 workgroup/CU) for whole rounds with ragged edges / fp32 output, short K
       *bm_used = 128;
       if (force == 0 && tiles(256, 256) % n_cu == 0 && a.K <= 2048 && !a.accumulate && !a.stat_mean) {
-        hipLaunchKernelGGL((gemm_nt_glds_kernel<OutT, 256, 256, 2, 4>), dim3((unsigned)tiles(256, 256)), dim3(512), 0, stream, a);
-        return tell_check_launch("gemm_nt_glds");
+        TELL_GEMM_LAUNCH(gemm_label("gemm_nt_glds_kernel", -1, sizeof(OutT) == 2, 256, 256), (gemm_nt_glds_kernel<OutT, 256, 256, 2, 4>), dim3((unsigned)tiles(256, 256)), dim3(512));
+        return g_gemm_plan ? TELL_OK : tell_check_launch("gemm_nt_glds");
       }
       if (force == 2)     // 256x128 (8 waves, 1 workgroup/CU) ties 128x128 (2 workgroups/CU) on MI355X: opt-in only
-        hipLaunchKernelGGL((gemm_nt_glds_kernel<OutT, 256, 128, 4, 2>), dim3((unsigned)tiles(256, 128)), dim3(512), 0, stream, a);
+        TELL_GEMM_LAUNCH(gemm_label("gemm_nt_glds_kernel", -1, sizeof(OutT) == 2, 256, 128), (gemm_nt_glds_kernel<OutT, 256, 128, 4, 2>), dim3((unsigned)tiles(256, 128)), dim3(512));
       else
-        hipLaunchKernelGGL((gemm_nt_glds_kernel<OutT, 128, 128, 2, 2>), dim3((unsigned)tiles(128, 128)), dim3(256), 0, stream, a);
-      return tell_check_launch("gemm_nt_glds");
+        TELL_GEMM_LAUNCH(gemm_label("gemm_nt_glds_kernel", -1, sizeof(OutT) == 2, 128, 128), (gemm_nt_glds_kernel<OutT, 128, 128, 2, 2>), dim3((unsigned)tiles(128, 128)), dim3(256));
+      return g_gemm_plan ? TELL_OK : tell_check_launch("gemm_nt_glds");
     }
   }
   // (a 256x256 register-staged tile measured slower than 256x128 - 236 VGPRs, one workgroup per CU - and
   //  was removed)
   *bm_used = (sizeof(T) == 2 && tiles(256, 128) >= 256) ? 256 : tiles(128, 128) >= 256 ? 128 : 64;
   if (sizeof(T) == 2 && tiles(256, 128) >= 256) {
-    hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, 256, 128, 4, 2, 2>), dim3((unsigned)tiles(256, 128)), dim3(512), 0, stream, a);
+    TELL_GEMM_LAUNCH(gemm_label("gemm_nt_kernel", sizeof(T) == 2, sizeof(OutT) == 2, 256, 128), (gemm_nt_kernel<T, OutT, 256, 128, 4, 2, 2>), dim3((unsigned)tiles(256, 128)), dim3(512));
   } else if (tiles(128, 128) >= 256) {
-    hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, 128, 128, 2, 2, 2>), dim3((unsigned)tiles(128, 128)), dim3(256), 0, stream, a);
+    TELL_GEMM_LAUNCH(gemm_label("gemm_nt_kernel", sizeof(T) == 2, sizeof(OutT) == 2, 128, 128), (gemm_nt_kernel<T, OutT, 128, 128, 2, 2, 2>), dim3((unsigned)tiles(128, 128)), dim3(256));
   } else {
-    hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, 64, 64, 2, 2, 4>), dim3((unsigned)tiles(64, 64)), dim3(256), 0, stream, a);
+    TELL_GEMM_LAUNCH(gemm_label("gemm_nt_kernel", sizeof(T) == 2, sizeof(OutT) == 2, 64, 64), (gemm_nt_kernel<T, OutT, 64, 64, 2, 2, 4>), dim3((unsigned)tiles(64, 64)), dim3(256));
   }
-  return tell_check_launch("gemm_nt");
+  return g_gemm_plan ? TELL_OK : tell_check_launch("gemm_nt");
 }
 
 extern "C" int tell_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc,
@@ -1068,6 +1082,18 @@ extern "C" int tell_gemm_nt(const void* A, long lda, const void* B, long ldb, vo
                                   : launch_gemm<uint16_t, float>(a, stream);
   return out_dtype == TELL_BF16 ? launch_gemm<float, uint16_t>(a, stream)
                                 : launch_gemm<float, float>(a, stream);
+}
+
+extern "C" const char* tell_gemm_nt_plan(const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                                         int M, int N, int K, int in_dtype, int out_dtype, const float* bias,
+                                         int bias_mode, int act, const void* aux, float alpha, int accumulate,
+                                         const int* m_dev, hipStream_t stream) {
+  g_gemm_label[0] = 0;
+  g_gemm_plan = true;
+  (void)tell_gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, in_dtype, out_dtype, bias, bias_mode, act, aux, alpha, accumulate,
+                     m_dev, stream);
+  g_gemm_plan = false;
+  return g_gemm_label;
 }
 
 // C[M,N] = act((op(A) . op(B) + bias) * alpha) (+ C), bf16 operands.  trans_a: A is stored [K][M] (K-major,

@@ -113,6 +113,13 @@ class bound_stream:
         return False
 
 
+def query(name, *args):
+    """Call an entry point that returns a string (tell_*_plan): tensors -> device pointers, stream = NULL."""
+    fn = getattr(lib(), name)
+    res = fn(*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args], None)
+    return res.decode() if res is not None else ''
+
+
 def call(name, *args):
     """Call a C-ABI entry point; tensors -> device pointers; last arg (stream) added here."""
     fn = _fns.get(name)

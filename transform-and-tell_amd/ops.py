@@ -76,32 +76,15 @@ def gemm(a, b, out=None, out_dtype=None, bias=None, bias_mode=0, act=0, aux=None
     if out is None:
         out = torch.empty(M, N, dtype=out_dtype or a.dtype, device=a.device)
     assert out.stride(1) == 1
+    args = (a, a.stride(0), b, b.stride(0), out, out.stride(0), M, N, a.shape[1], hip.dt(a), hip.dt(out), bias, bias_mode,
+            act, aux, float(alpha), int(accumulate), m_dev)
     rec = None
     if prof.enabled() and m_dev is None and 2.0 * M * N * a.shape[1] >= prof.MIN_WORK and \
             not torch.cuda.is_current_stream_capturing():      # timing events cannot live inside a captured graph
-        def tiles(bm, bn):
-            return ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
-        bf = hip.dt(a) == hip.BF16                                                 # mirrors launch_gemm()
-        names = ('f32', 'bf16')[hip.dt(a)], ('f32', 'bf16')[hip.dt(out)]
-        if bf and a.shape[1] % 64 == 0 and tiles(128, 128) >= 256:
-            n_cu = torch.cuda.get_device_properties(a.device).multi_processor_count
-            small_k = a.shape[1] <= 2048 and not accumulate
-            full = (M % 256 == 0 and N % 256 == 0 and not accumulate and act != 3 and out.dtype == torch.bfloat16 and
-                    out.stride(0) % 8 == 0 and out.data_ptr() % 16 == 0 and
-                    (bias_mode != 1 or bias.data_ptr() % 16 == 0))
-            tile = ((256, 256) if (small_k and tiles(256, 256) % n_cu == 0) else
-                    (256, 192) if (small_k and N % 192 == 0 and tiles(256, 192) % n_cu == 0) else (128, 128))
-            kname = 'gemm_nt_glds_kernel<%s,%d,%d>' % (names[1], tile[0], tile[1])
-            if full and tiles(256, 256) % n_cu == 0:
-                kname = 'gemm_nt_pp_kernel<bf16,256,256>'
-        else:
-            tile = ((256, 128) if bf and tiles(256, 128) >= 256 else (128, 128) if tiles(128, 128) >= 256
-                    else (64, 64))
-            kname = 'gemm_nt_kernel<%s,%s,%d,%d>' % (names[0], names[1], tile[0], tile[1])
+        kname = hip.query('tell_gemm_nt_plan', *args)          # the library names the kernel it is about to launch
         if prof.sampled(kname):
             rec = prof.begin(kname, 2.0 * M * N * a.shape[1])
-    call('tell_gemm_nt', a, a.stride(0), b, b.stride(0), out, out.stride(0), M, N, a.shape[1], hip.dt(a),
-         hip.dt(out), bias, bias_mode, act, aux, float(alpha), int(accumulate), m_dev)
+    call('tell_gemm_nt', *args)
     if rec is not None:
         prof.end(rec)
     return out
