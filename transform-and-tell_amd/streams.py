@@ -9,7 +9,9 @@ registry in a fixed order, and multi-GPU launchers set GPU_MAX_HW_QUEUES=3 befor
 (bench.py does).
 Stream priorities are not an option for the same reason: hipStreamCreateWithPriority streams get hardware queues of
 their own (low-priority encoder streams: 1060 -> 640 samples/s, high-priority wgrad/update streams: -> 640).  Folding
-roles together loses too: update on the wgrad stream -1 %, both encoders on one stream -11 %."""
+roles together loses too: update on the wgrad stream -1 %, both encoders on one stream -11 %.  The creation order of the
+streams does not change which of them share a hardware queue (four orders: 1065-1069 samples/s), and GPU_MAX_HW_QUEUES = 5 / 6
+are as bad as 8 (780-830)."""
 import torch
 
 import os
