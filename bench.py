@@ -87,12 +87,8 @@ def main():
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    if world > 1 or os.environ.get('TELL_DP_SELFTEST') in ('1', '2'):
-        # Must precede the first HIP call.  The step schedule keeps 4 hardware queues busy (GPU_MAX_HW_QUEUES
-        # default); an RCCL communicator adds its own, and with MORE than 4 active queues per process the command
-        # processor time-slices them (measured on MI355X, 1 rank: 1125 -> 940 samples/s; 8 queues: 780).  Three
-        # queues for our streams + RCCL's keeps the total at 4 (1085 samples/s with the communicator alive).
-        os.environ.setdefault('GPU_MAX_HW_QUEUES', '3')
+    # (GPU_MAX_HW_QUEUES stays at its default of 4: the schedule uses three streams - backward/decoder, RoBERTa, ResNet -
+    #  and an RCCL communicator brings the fourth; see tell_amd/streams.py for the measurements)
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -126,6 +122,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    wgrad_default = tell_amd.ops._WGRAD['enabled']
+
     def set_serial(flag):
         """One stream for everything (flag) or the overlapped production schedule (not flag)."""
         import tell_amd.models.transformer as tr_mod
@@ -134,7 +132,7 @@ def main():
         tell_amd.runtime.wait_weight_update()
         tr_mod._OVERLAP = not flag
         tell_amd.graphs.ENABLED = not flag         # eager encoders: every GEMM launch passes the timing hook
-        ops._WGRAD['enabled'] = not flag
+        ops._WGRAD['enabled'] = (not flag) and wgrad_default
         trainer.async_update = (not flag) and trainer.update_stream is not None
 
     if args.serial:
@@ -225,7 +223,7 @@ def main():
                 'concurrent': ({k: {'avg_us': round(v['avg_us'], 2),
                                     'tflops': round(v['work'] / (v['total_ms'] * 1e-3) / 1e12, 2)}
                                 for k, v in prof_concurrent.items()} if not args.serial else None),
-                'concurrent_note': 'the same kernels timed inside the timed region, where 4-5 streams share the CUs',
+                'concurrent_note': 'the same kernels timed inside the timed region, where three streams share the CUs',
                 'all_gemm_kernels': {k: {'avg_us': round(v['avg_us'], 2),
                                          'launches_per_step': v['launches'] // (args.steps if args.serial else args.roofline_steps),
                                          'tflops': round(v['work'] / (v['total_ms'] * 1e-3) / 1e12, 2)}

@@ -186,11 +186,14 @@ def test_beam_search_matches_oracle_definition_fp32(kind):
         assert torch.equal(greedy.cpu()[:, :n], one.cpu()[:, :n])
 
 
-def test_pipelined_steps_equal_plain_steps_fp32():
+@pytest.mark.parametrize('side_streams', [False, True])
+def test_pipelined_steps_equal_plain_steps_fp32(side_streams):
     """Trainer.train_one_batch(batch, next_batch=...) launches the next batch's encoders underneath the current
-    step; losses and parameters must equal the plain schedule (same kernels, no dropout)."""
+    step; losses and parameters must equal the plain schedule (same kernels, no dropout).  side_streams: also with the
+    opt-in weight-gradient stream (TELL_WGRAD_STREAM=1) and asynchronous update stream (TELL_ASYNC_UPDATE=1)."""
     import copy
     import tell_amd
+    from tell_amd import ops
     from tell_amd.build import build_model
     from tell_amd.data import synthetic_batch
     from tell_amd.training import Trainer
@@ -200,7 +203,20 @@ def test_pipelined_steps_equal_plain_steps_fp32():
     _no_dropout(a)
     b = copy.deepcopy(a)
     ocfg = dict(lr=5e-3, warmup=0.5, t_total=6, b1=0.9, b2=0.98, e=1e-6, weight_decay=1e-5, max_grad_norm=0.1)
-    ta, tb = Trainer(a, dict(ocfg), device=DEV), Trainer(b, dict(ocfg), device=DEV)
+    ta = Trainer(a, dict(ocfg), device=DEV, async_update=False)
+    tb = Trainer(b, dict(ocfg), device=DEV, async_update=side_streams)
+    assert tb.async_update == side_streams
+    wg0 = ops._WGRAD['enabled']
+    try:
+        _pipelined_vs_plain(ta, tb, a, b, side_streams)
+    finally:
+        ops.join_wgrad_stream()
+        ops._WGRAD['enabled'] = wg0
+
+
+def _pipelined_vs_plain(ta, tb, a, b, side_streams):
+    from tell_amd import ops
+    from tell_amd.data import synthetic_batch
     batches = []
     for s in range(4):
         bt = synthetic_batch(B=3, article_len=20, caption_len=9, faces_objects=True, vocab=600, cutoffs=(100, 300),
@@ -209,7 +225,10 @@ def test_pipelined_steps_equal_plain_steps_fp32():
                         for k, v in bt.items()})
     clone = lambda x: {k: (dict(v) if isinstance(v, dict) else v) for k, v in x.items()}   # noqa: E731
     for s in range(4):
+        ops._WGRAD['enabled'] = False
         la = ta.train_one_batch(clone(batches[s]))
+        ops.join_wgrad_stream()
+        ops._WGRAD['enabled'] = side_streams
         lb = tb.train_one_batch(clone(batches[s]), next_batch=batches[s + 1] if s + 1 < 4 else None)
         # not bit-exact: the embedding-table gradient accumulates duplicate tokens with fp32 atomics
         assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(la)), (s, float(la), float(lb))

@@ -256,9 +256,9 @@ def wn_weight_t(g, v):
 # stream, fill the idle CUs underneath the dgrad chain, and are joined back when the backward pass ends.
 # All writers of a Linear / GehringLinear gradient buffer go through here, so accumulations into a shared
 # buffer (row slices of in_proj_weight, several uses of one layer) stay ordered on that one stream.
-_WGRAD = {'enabled': os.environ.get('TELL_WGRAD_STREAM', '1') != '0', 'streams': {}, 'main': None, 'queue': [],
+_WGRAD = {'enabled': os.environ.get('TELL_WGRAD_STREAM', '0') == '1', 'streams': {}, 'main': None, 'queue': [],
           'hooked': False}
-_WGRAD_FLUSH = 6            # deferred jobs per hand-over (one event + one stream switch per batch, not per GEMM)
+_WGRAD_FLUSH = int(os.environ.get('TELL_WGRAD_FLUSH', '6'))            # deferred jobs per hand-over (one event + one stream switch per batch, not per GEMM)
 
 
 def _flush_wgrad():

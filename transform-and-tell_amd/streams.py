@@ -1,22 +1,26 @@
-"""The side streams of the step schedule, created in ONE canonical order.
+"""The side streams of the step schedule.
 
-ROCm multiplexes HIP streams onto a small number of hardware queues (GPU_MAX_HW_QUEUES, 4 by default) in
-creation order, and the command processor runs up to 4 active queues per process concurrently; beyond that it
-time-slices them.  Measured on MI355X with this schedule (samples/s, 1 GPU): GPU_MAX_HW_QUEUES = 1: 778,
-2: 835, 3: 1073, 4: 1125, 8: 779, 16: 760 - and 940 at the default 4 once an RCCL communicator exists (its
-queue is a 5th), back to 1085-1093 with GPU_MAX_HW_QUEUES=3.  Hence: every role gets its stream from this one
-registry in a fixed order, and multi-GPU launchers set GPU_MAX_HW_QUEUES=3 before the first HIP call
-(bench.py does).
-Stream priorities are not an option for the same reason: hipStreamCreateWithPriority streams get hardware queues of
-their own (low-priority encoder streams: 1060 -> 640 samples/s, high-priority wgrad/update streams: -> 640).  Folding
-roles together loses too: update on the wgrad stream -1 %, both encoders on one stream -11 %.  The creation order of the
-streams does not change which of them share a hardware queue (four orders: 1065-1069 samples/s), and GPU_MAX_HW_QUEUES = 5 / 6
-are as bad as 8 (780-830)."""
+ROCm multiplexes HIP streams onto a small number of hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and streams that
+share a queue run FIFO.  The production schedule therefore uses THREE streams - the default stream (decoder forward /
+backward, weight gradients, optimizer), `roberta` and `resnet` (the frozen encoders of the next batch, replayed as
+hipGraphs) - which leaves the fourth queue to an RCCL communicator.  Measured on MI355X (samples/s, 1 GPU, same box):
+
+  3 streams (default)                              1149
+  + `update` stream  (TELL_ASYNC_UPDATE=1)         1134
+  + `wgrad` stream   (TELL_WGRAD_STREAM=1) too     1061   <- the weight-gradient GEMMs share RoBERTa's hardware queue
+  1-rank RCCL group, GPU_MAX_HW_QUEUES=4 / 3       1120 / 885
+  GPU_MAX_HW_QUEUES = 3 / 5 / 6 / 8 (no RCCL)       933 / 660 / ~800 / ~780
+  low-priority encoder streams / high-priority update stream (hipStreamCreateWithPriority)   640 / 640
+  both encoders on one stream                      -11 %
+
+(Before the encoders were prefetched and graph-replayed, the two extra streams were a gain - they are kept as opt-in
+paths and covered by tests/test_gpu_train.py.)  The creation order of the streams does not change which of them share a
+queue (four orders: 1065-1069 with five streams).  Roles outside ROLES are created on demand."""
 import torch
 
 import os
 
-ROLES = tuple(os.environ.get('TELL_STREAM_ORDER', 'resnet,roberta,wgrad,update').split(','))
+ROLES = tuple(os.environ.get('TELL_STREAM_ORDER', 'resnet,roberta').split(','))   # wgrad / update: created on demand (opt-in)
 _streams = {}
 
 

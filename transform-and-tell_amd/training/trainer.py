@@ -56,21 +56,25 @@ class Trainer:
             self.dist.broadcast(self.flat.flat, src=0)
             self.flat.refresh_shadow()
             rt.bump_weights_epoch()
-        # gradient all-reduce + BertAdam + gradient zeroing run on this stream, underneath the next step's
-        # frozen encoders; the model waits for it right before its first trainable weight (rt.wait_weight_update)
+        # TELL_ASYNC_UPDATE=1: gradient all-reduce + BertAdam + gradient zeroing run on their own stream and the model
+        # waits for it right before its first trainable weight (rt.wait_weight_update).  Off by default: with the
+        # encoders of the next batch already running on their two streams, a fourth / fifth stream of ours costs more
+        # in hardware-queue sharing than the overlap returns (streams.py: 1149 vs 1134 vs 1061 samples/s for
+        # 3 / 4 / 5 streams)
         if async_update is None:
-            async_update = os.environ.get('TELL_ASYNC_UPDATE', '1') != '0'
+            async_update = os.environ.get('TELL_ASYNC_UPDATE', '0') == '1'
         self.async_update = async_update and torch.device(device).type == 'cuda'
         self.update_stream = streams.get('update', device) if self.async_update else None
         self.flat.zero_grad()
         self.model.register_state_dict_pre_hook(lambda *a, **k: self.finish_update())
         # DP: the gradients of a decoder layer are final when backward leaves the layer (ops.grad_ready_marker); their
-        # slice of the flat buffer is all-reduced on the update stream right then, underneath the rest of backward.
-        # Only what is left (embedder / tied adaptive tables, 35 % of the bytes) is exchanged after backward.
-        self._ranges, self._reduced, self._in_backward = {}, [], False
+        # slice of the flat buffer is handed to RCCL right then (cast to the wire dtype on the backward stream, the
+        # collective itself runs on RCCL's stream underneath the rest of backward).  Only what is left (embedder / tied
+        # adaptive tables, 35 % of the bytes) is exchanged after backward.
+        self._ranges, self._reduced, self._pending, self._in_backward = {}, [], [], False
         self.bucketed_reduces = 0
         self._test_reduce_scale = None              # tests: emulate world_size 2 with identical ranks (x2 after a reduce)
-        if self.dp and self.async_update and os.environ.get('TELL_DP_BUCKETED', '1') != '0':
+        if self.dp and torch.device(device).type == 'cuda' and os.environ.get('TELL_DP_BUCKETED', '1') != '0':
             self._ranges = self._layer_ranges()
             if self._ranges:
                 rt.set_grad_ready_callback(self._grad_ready)
@@ -93,14 +97,11 @@ class Trainer:
         rng_ = self._ranges.get(tag)
         if rng_ is None or not self._in_backward:
             return
-        main = torch.cuda.current_stream()
-        side = ops.flush_wgrad_stream()              # this layer's weight-gradient GEMMs are on the side stream now
-        us = self.update_stream
-        us.wait_stream(main)
+        side = ops.flush_wgrad_stream()              # only with the opt-in weight-gradient stream
         if side is not None:
-            us.wait_stream(side)
-        with torch.cuda.stream(us), hip.bound_stream():
-            self._all_reduce_grads(*rng_)
+            torch.cuda.current_stream().wait_stream(side)
+        with hip.bound_stream():
+            self._start_reduce(*rng_)
         self._reduced.append(rng_)
         self.bucketed_reduces += 1
 
@@ -175,23 +176,38 @@ class Trainer:
             lo = 0
             for a, b in done + [(self.flat.total, self.flat.total)]:     # everything not exchanged during backward
                 if a > lo:
-                    self._all_reduce_grads(lo, a)
+                    self._start_reduce(lo, a)
                 lo = max(lo, b)
+            self._finish_reduces()
         self.optimizer.step(grad_scale=1.0 / self.world, zero_grad=True)  # :238 (+ :214 of the next batch)
 
-    def _all_reduce_grads(self, lo=0, hi=None):
-        hi = self.flat.total if hi is None else hi
+    def _cast(self, src, dst):
+        hip.call('tell_cast', src, hip.dt(src), dst, hip.dt(dst), src.numel())
+
+    def _start_reduce(self, lo, hi):
+        """Hand flat.grad[lo:hi] to RCCL (asynchronously; bf16 on the wire in bf16 mode, see dp.all_reduce_flat_bf16)."""
         grad = self.flat.grad[lo:hi]
         if self.allreduce_dtype == torch.bfloat16:
             if self._wire is None:
                 self._wire = torch.empty(self.flat.total, dtype=torch.bfloat16, device=self.flat.grad.device)
-            dp.all_reduce_flat_bf16(
-                grad, self._wire[lo:hi], self.dist, 2 * self.bucket_elems,
-                lambda s, d: hip.call('tell_cast', s, hip.dt(s), d, hip.dt(d), s.numel()))
+            buf, step = self._wire[lo:hi], 2 * self.bucket_elems
+            self._cast(grad, buf)
         else:
-            dp.all_reduce_flat(grad, self.dist, self.bucket_elems)
-        if self._test_reduce_scale is not None:
-            grad.mul_(self._test_reduce_scale)
+            buf, step = grad, self.bucket_elems
+        handles = [self.dist.all_reduce(buf[s:s + step], async_op=True) for s in range(0, buf.numel(), step)]
+        self._pending.append((lo, hi, handles))
+
+    def _finish_reduces(self):
+        """The current stream waits for every exchange in flight; bf16 results are widened back into flat.grad."""
+        pending, self._pending = self._pending, []
+        for lo, hi, handles in pending:
+            for h in handles:
+                h.wait()
+            grad = self.flat.grad[lo:hi]
+            if self.allreduce_dtype == torch.bfloat16:
+                self._cast(self._wire[lo:hi], grad)
+            if self._test_reduce_scale is not None:
+                grad.mul_(self._test_reduce_scale)
 
 
 @TrainerBase.register('callback_apex')
