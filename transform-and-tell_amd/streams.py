@@ -11,7 +11,7 @@ hipGraphs) - which leaves the fourth queue to an RCCL communicator.  Measured on
   1-rank RCCL group, GPU_MAX_HW_QUEUES=4 / 3       1120 / 885
   GPU_MAX_HW_QUEUES = 3 / 5 / 6 / 8 (no RCCL)       933 / 660 / ~800 / ~780
   low-priority encoder streams / high-priority update stream (hipStreamCreateWithPriority)   640 / 640
-  both encoders on one stream                      -11 %
+  ResNet replay on the main / on RoBERTa's stream  943 / 957 (own stream: 1170)
 
 (Before the encoders were prefetched and graph-replayed, the two extra streams were a gain - they are kept as opt-in
 paths and covered by tests/test_gpu_train.py.)  The creation order of the streams does not change which of them share a
