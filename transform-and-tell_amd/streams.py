@@ -10,7 +10,8 @@ hipGraphs) - which leaves the fourth queue to an RCCL communicator.  Measured on
   + `wgrad` stream   (TELL_WGRAD_STREAM=1) too     1061   <- the weight-gradient GEMMs share RoBERTa's hardware queue
   1-rank RCCL group, GPU_MAX_HW_QUEUES=4 / 3       1120 / 885
   GPU_MAX_HW_QUEUES = 3 / 5 / 6 / 8 (no RCCL)       933 / 660 / ~800 / ~780
-  low-priority encoder streams / high-priority update stream (hipStreamCreateWithPriority)   640 / 640
+  low-priority encoder streams / high-priority update stream (hipStreamCreateWithPriority)   640 / 640  (five streams)
+  high-priority RoBERTa stream / low-priority ResNet stream with three streams              -2 % / 0 %
   ResNet replay on the main / on RoBERTa's stream  943 / 957 (own stream: 1170)
 
 (Before the encoders were prefetched and graph-replayed, the two extra streams were a gain - they are kept as opt-in
