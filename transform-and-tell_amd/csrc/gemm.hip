@@ -89,24 +89,43 @@ __device__ __forceinline__ void static_for(F&& f) {
 // bf16 conversion a packed v_cvt_pk_bf16_f32.  The activation is a template parameter (one block-uniform
 // switch per tile instead of branches per element).
 
-// erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, branch-free: one rcp + one exp + 6 fma)
-__device__ __forceinline__ float erf_as(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));   // v_rcp_f32 (1 ulp); __frcp_rn expands to a 10-instruction IEEE division
-  float y = fmaf(1.061405429f, t, -1.453152027f);
-  y = fmaf(y, t, 1.421413741f);
-  y = fmaf(y, t, -0.284496736f);
-  y = fmaf(y, t, 0.254829592f);
-  y = 1.f - y * t * __expf(-ax * ax);
-  return copysignf(y, x);
+// exact-erf GELU without exp: Abramowitz-Stegun 7.1.28,  erfc(x) = 1 / (1 + a1 x + ... + a6 x^6)^16  for x >= 0
+// (|error| <= 3e-7), and  gelu(v) = v Phi(v) = max(v, 0) - |v| erfc(|v| / sqrt 2) / 2.  One v_rcp_f32 and fourteen
+// multiply-adds per element (the compiler packs pairs into v_pk_fma_f32 / v_pk_mul_f32) instead of rcp + exp + two
+// more multiplies for the 7.1.26 form: the epilogue of the fc1 GEMM is pure VALU work with nothing to overlap it
+// (one workgroup per CU), so every instruction there is wall time.  A large argument overflows the power to +inf and
+// v_rcp_f32 returns 0, which is the right limit.
+typedef __attribute__((ext_vector_type(2))) float f32x2e_t;
+__device__ __forceinline__ f32x2e_t gelu_erf2(f32x2e_t v) {          // two elements per instruction (packed fp32 VALU)
+  const f32x2e_t av = {fabsf(v[0]), fabsf(v[1])};
+  const f32x2e_t x = av * 0.70710678118654752f;
+  f32x2e_t q = x * 0.0000430638f + 0.0002765672f;
+  q = q * x + 0.0001520143f;
+  q = q * x + 0.0092705272f;
+  q = q * x + 0.0422820123f;
+  q = q * x + 0.0705230784f;
+  q = q * x + 1.f;
+  q *= q; q *= q; q *= q; q *= q;                                   // ^16
+  const f32x2e_t erfc_x = {__builtin_amdgcn_rcpf(q[0]), __builtin_amdgcn_rcpf(q[1])};
+  const f32x2e_t relu = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
+  return (av * -0.5f) * erfc_x + relu;
 }
 template <int ACT> __device__ __forceinline__ float epi_act(float v) {
   if constexpr (ACT == 1) return fmaxf(v, 0.f);
-  else if constexpr (ACT == 2) return 0.5f * v * (1.f + erf_as(v * 0.70710678118654752f));
+  else if constexpr (ACT == 2) { const f32x2e_t r = gelu_erf2(f32x2e_t{v, v}); return r[0]; }
   else return v;
 }
+// four consecutive outputs at once (what every epilogue holds per register quad)
+template <int ACT> __device__ __forceinline__ void epi_act4(__attribute__((ext_vector_type(4))) float& v) {
+  if constexpr (ACT == 2) {
+    const f32x2e_t lo = gelu_erf2(f32x2e_t{v[0], v[1]}), hi = gelu_erf2(f32x2e_t{v[2], v[3]});
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = epi_act<ACT>(v[e]);
+  }
+}
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-typedef __attribute__((ext_vector_type(2))) float f32x2e_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2e_t;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {      // v_cvt_pk_bf16_f32 (RNE)
@@ -162,7 +181,8 @@ __device__ __forceinline__ void gemm_epilogue_act(f32x16 (&acc)[MI][NI], const G
         if (n >= N) continue;
         f32x4_t v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = epi_act<ACT>((acc[i][j][4 * g + e] + bn[j][g][e] + bm) * p.alpha);
+        for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][4 * g + e] + bn[j][g][e] + bm) * p.alpha;
+        epi_act4<ACT == 3 ? 0 : ACT>(v);
         OutT* dst = C + (long)m * p.ldc + n;
         if (vec_ok && n + 3 < N) {
           if constexpr (ACT == 3) {
@@ -219,7 +239,8 @@ __device__ __forceinline__ void glds_store_tile_act(f32x16 (&acc)[MI][NI], const
         if (p.bias_mode == 1) b4 = *reinterpret_cast<const f32x4_t*>(p.bias + n0 + col);
         f32x4_t v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = epi_act<ACT>((acc[i][j][4 * g + e] + b4[e] + bm) * p.alpha);
+        for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][4 * g + e] + b4[e] + bm) * p.alpha;
+        epi_act4<ACT>(v);
         int ch = col >> 3;
         if constexpr (SWZ) ch ^= row & (CPRW - 1) & 15;
         u32x2 w = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
