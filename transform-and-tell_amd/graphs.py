@@ -72,7 +72,9 @@ class GraphedCall:
                 try:
                     if counter is not None:
                         hip.call('tell_set_rng_step_ptr', counter)
-                    with torch.cuda.graph(g):
+                    # thread_local: calls made by OTHER threads while we capture (the RCCL watchdog of a data-parallel
+                    # run polls events) must not invalidate the capture; everything captured is issued from this thread
+                    with torch.cuda.graph(g, capture_error_mode='thread_local'):
                         with hip.bound_stream():        # launches must go to the CAPTURING stream
                             static_out = self.fn(static_in)
                 finally:
