@@ -28,8 +28,10 @@ def build_decoder(kind='faces_objects', vocab_size=50265, dim=1024, heads=16, ff
         contexts = CONTEXTS_FACES_PARALLEL
     elif kind == 'flattened_no_image':                   # expt/*/4_no_image
         contexts = (('article', article_dim),)
-    else:
+    else:                                                # 'flattened', 'flattened_lightweight'
         contexts = (CONTEXTS_FLATTENED[0], ('article', article_dim))
+    if kind.endswith('_lightweight'):                    # `decoder_conv_type: lightweight` (decoder_flattened.py:199-203)
+        overrides.setdefault('decoder_conv_type', 'lightweight')
     kw = dict(decoder_conv_dim=dim, decoder_attention_heads=heads, decoder_ffn_embed_dim=ffn,
               decoder_kernel_size_list=tuple(kernels), adaptive_softmax_cutoff=tuple(cutoff),
               decoder_layers=len(kernels), vocab_size=vocab_size)

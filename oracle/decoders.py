@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .modules import (AdaptiveSoftmax, DynamicConv1dTBC, GehringLinear, MultiHeadAttention,
+from .modules import (AdaptiveSoftmax, DynamicConv1dTBC, GehringLinear, LightweightConv1dTBC, MultiHeadAttention,
                       _maybe_dropout)
 
 CONTEXTS_FLATTENED = (('image', 2048), ('article', 1024))
@@ -24,11 +24,13 @@ class DynamicConvDecoderLayer(nn.Module):
     """decoder_faces_objects.py:184-372 / decoder_flattened.py:185-326."""
 
     def __init__(self, embed_dim, conv_dim, glu, heads, weight_dropout, dropout, relu_dropout,
-                 input_dropout, normalize_before, attention_dropout, ffn_dim, kernel_size, contexts):
+                 input_dropout, normalize_before, attention_dropout, ffn_dim, kernel_size, contexts,
+                 conv_type='dynamic'):
         super().__init__()
         self.linear1 = GehringLinear(embed_dim, 2 * conv_dim if glu else conv_dim)
         self.glu = glu
-        self.conv = DynamicConv1dTBC(conv_dim, kernel_size, heads, weight_dropout)
+        conv_cls = {'dynamic': DynamicConv1dTBC, 'lightweight': LightweightConv1dTBC}[conv_type]   # :199-211
+        self.conv = conv_cls(conv_dim, kernel_size, heads, weight_dropout)
         self.linear2 = GehringLinear(conv_dim, embed_dim)
         self.dropout, self.relu_dropout, self.input_dropout = dropout, relu_dropout, input_dropout
         self.normalize_before = normalize_before
@@ -92,7 +94,7 @@ class DynamicConvDecoder(nn.Module):
                  input_dropout=0.1, decoder_normalize_before=False, attention_dropout=0.1,
                  decoder_ffn_embed_dim=4096, decoder_kernel_size_list=(3, 7, 15, 31),
                  adaptive_softmax_cutoff=(5000, 20000), decoder_layers=4, final_norm=False,
-                 vocab_size=50265, max_target_positions=512):
+                 vocab_size=50265, max_target_positions=512, decoder_conv_type='dynamic'):
         super().__init__()
         self.embedder = embedder
         E = embedder.get_output_dim()
@@ -102,7 +104,8 @@ class DynamicConvDecoder(nn.Module):
             DynamicConvDecoderLayer(E, decoder_conv_dim, decoder_glu, decoder_attention_heads,
                                     weight_dropout, dropout, relu_dropout, input_dropout,
                                     decoder_normalize_before, attention_dropout,
-                                    decoder_ffn_embed_dim, decoder_kernel_size_list[i], contexts)
+                                    decoder_ffn_embed_dim, decoder_kernel_size_list[i], contexts,
+                                    conv_type=decoder_conv_type)
             for i in range(decoder_layers)])
         self.adaptive_softmax = AdaptiveSoftmax(vocab_size, E, list(adaptive_softmax_cutoff),
                                                 embedder.token_embedder_adaptive)

@@ -79,6 +79,42 @@ class DynamicConv1dTBC(nn.Module):
         return out[n_hist:]                                              # dynamic.py:115-116
 
 
+class LightweightConv1dTBC(nn.Module):
+    """tell/modules/convolutions/lightweight.py:83-240 as `decoder_conv_type: lightweight` builds it
+    (decoder_faces_objects.py:199-203: weight_softmax, padding_l = K-1, no bias): one learned tap vector per head,
+    softmax over ALL K taps (:163-164 / :186-187), DropConnect on the taps (:174 / :204-205), then the same causal
+    K-tap sum as the dynamic convolution - a window shorter than K simply drops the taps that reach before the
+    start (:166-168 incremental, :193-195 K > T)."""
+
+    _instances = 0
+
+    def __init__(self, input_size, kernel_size, num_heads, weight_dropout=0.0):
+        super().__init__()
+        self.input_size, self.kernel_size, self.num_heads = input_size, kernel_size, num_heads
+        self.weight_dropout = weight_dropout
+        self.weight = nn.Parameter(torch.empty(num_heads, 1, kernel_size))
+        nn.init.xavier_uniform_(self.weight)                                # lightweight.py:127
+        LightweightConv1dTBC._instances += 1
+        self._state_key = 'LightweightConv1dTBC.%d.input_buffer' % LightweightConv1dTBC._instances
+
+    def forward(self, x, incremental_state=None, drop_mask=None):
+        n_hist = 0
+        if incremental_state is not None:                               # lightweight.py:152-160
+            prev = incremental_state.get(self._state_key)
+            if prev is not None:
+                n_hist = prev.shape[0]
+                x = torch.cat([prev, x], dim=0)
+            incremental_state[self._state_key] = x[-self.kernel_size + 1:] if self.kernel_size > 1 \
+                else x[:0]
+        T, B, _ = x.shape
+        logits = self.weight.view(1, 1, -1).expand(T, B, self.num_heads * self.kernel_size)
+        p = self.weight_dropout if self.training else 0.0
+        if drop_mask is None and p > 0:
+            drop_mask = (torch.rand(T, B, self.num_heads, self.kernel_size) >= p).float()
+        taps = OF.dynamic_conv_taps(logits, self.num_heads, self.kernel_size, drop_mask if p > 0 else None, p)
+        return OF.dynamic_conv_apply(x, taps)[n_hist:]
+
+
 class MultiHeadAttention(nn.Module):
     """tell/modules/attention/multi_head.py:207-552 (add_bias_kv, add_zero_attn)."""
 

@@ -24,6 +24,7 @@ dfo, dfl, tfo, tfl, _ = ref_import.import_models()
 dfp, dni = ref_import.import_decoder_variants()
 from tell.modules.attention.multi_head import MultiHeadAttention  # noqa: E402
 from tell.modules.convolutions.dynamic import DynamicConv1dTBC  # noqa: E402
+from tell.modules.convolutions.lightweight import LightweightConv1dTBC  # noqa: E402
 from tell.modules.criteria.adaptive_loss import AdaptiveLoss  # noqa: E402
 from tell.modules.linear import GehringLinear  # noqa: E402
 from tell.modules.softmax import AdaptiveSoftmax  # noqa: E402
@@ -116,6 +117,23 @@ def dynconv():
              **{'in': {'x': x, 'gy': gy},
                 'out': {'y': y, 'gx': x.grad, 'g_weight': m.weight_linear.weight.grad,
                         'y_incremental': inc, 'y_incremental2': inc2}})
+
+
+def lightconv():
+    """LightweightConv1dTBC (static taps per head, lightweight.py:83-240) as `decoder_conv_type: lightweight` builds it."""
+    for K, T in ((3, 6), (31, 12)):
+        torch.manual_seed(20 + K)
+        m = LightweightConv1dTBC(64, K, padding_l=K - 1, num_heads=4, weight_softmax=True,
+                                 weight_dropout=0.1).eval()
+        x = torch.randn(T, 2, 64, requires_grad=True)
+        y = m(x)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        st = {}
+        inc = torch.cat([m(x[t:t + 1].detach(), incremental_state=st) for t in range(T)], dim=0)
+        save('lightconv_K%d_T%d' % (K, T), m.state_dict(),
+             **{'in': {'x': x, 'gy': gy},
+                'out': {'y': y, 'gx': x.grad, 'g_weight': m.weight.grad, 'y_incremental': inc}})
 
 
 def mha():
@@ -211,7 +229,8 @@ def adaptive_softmax():
                         gx=x.grad, **grads)})
 
 
-ART_DIM = {'flattened': 64, 'faces_objects': 1024, 'faces_parallel': 1024, 'flattened_no_image': 64}   # flattened: kdim == embed_dim -> in_proj_weight path
+ART_DIM = {'flattened': 64, 'faces_objects': 1024, 'faces_parallel': 1024, 'flattened_no_image': 64,
+           'flattened_lightweight': 64}   # flattened: kdim == embed_dim -> in_proj_weight path
 
 
 def _mk_contexts(B, S, kind, seed):
@@ -245,6 +264,9 @@ DEC_KW = dict(max_target_positions=512, dropout=0.1, share_decoder_input_output_
 
 def _ref_decoder(kind):
     emb = _ref_embedder(600, 64, (100, 300), init_size=512)
+    if kind == 'flattened_lightweight':       # the 2-context decoder with `decoder_conv_type: lightweight`
+        return dfl.DynamicConvDecoder(None, emb, article_embed_size=ART_DIM['flattened'],
+                                      **dict(DEC_KW, decoder_conv_type='lightweight'))
     if kind == 'faces_objects':
         return dfo.DynamicConvFacesObjectsDecoder(None, emb, **DEC_KW)
     if kind == 'faces_parallel':
@@ -276,7 +298,8 @@ def decoders(kinds=('flattened', 'faces_objects', 'faces_parallel', 'flattened_n
         out = dec({'roberta': ids}, ctx)
         loss, n = crit(dec.adaptive_softmax, out, tgt)
         (loss / n).backward()
-        names = ['layers.0.linear1.weight_v', 'layers.0.linear1.weight_g', 'layers.3.conv.weight_linear.weight',
+        names = ['layers.0.linear1.weight_v', 'layers.0.linear1.weight_g',
+                 'layers.3.conv.weight' if kind == 'flattened_lightweight' else 'layers.3.conv.weight_linear.weight',
                  'layers.1.context_attns.article.' + ('in_proj_weight' if kind.startswith('flattened') else 'v_proj_weight'),
                  'layers.1.context_attns.' + ('article.in_proj_bias' if kind == 'flattened_no_image' else 'image.k_proj_weight'),
                  'layers.2.context_attns.' + ('article' if kind == 'flattened_no_image' else 'image') + '.bias_k',
@@ -363,6 +386,11 @@ def models():
         print('   gen lengths:', [(r != 1).sum().item() for r in gen_ids], 'gen shape', tuple(gen_ids.shape))
 
 
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'lightweight':
+    lightconv()                                              # only the fixtures added later
+    decoders(('flattened_lightweight',))
+    sys.exit(0)
+
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'decoder_variants':
     decoders(('faces_parallel', 'flattened_no_image'))       # only the fixtures added later
     sys.exit(0)
@@ -370,8 +398,10 @@ if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'decoder_vari
 if __name__ == '__main__':
     gehring()
     dynconv()
+    lightconv()
     mha()
     embed_and_positions()
     adaptive_softmax()
     decoders()
+    decoders(('flattened_lightweight',))
     models()

@@ -272,6 +272,31 @@ def test_dynamic_conv_golden(golden, dtype, K, T):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('K,T', [(3, 6), (31, 12)])
+def test_lightweight_conv_golden(golden, dtype, K, T):
+    """`decoder_conv_type: lightweight` (static taps per head) on the DynamicConv kernels vs what the REFERENCE's
+    LightweightConv1dTBC produced, incl. K > T and the incremental (generation) path."""
+    import tell_amd
+    from tell_amd.modules import LightweightConv1dTBC
+    tell_amd.set_compute_dtype(dtype)
+    fx = golden('lightconv_K%d_T%d' % (K, T))
+    m = LightweightConv1dTBC(64, K, padding_l=K - 1, num_heads=4, weight_softmax=True, weight_dropout=0.1).eval()
+    m.load_state_dict(fx['sd'])
+    m.to(DEV)
+    x = fx['in']['x'].to(DEV, dtype).requires_grad_(True)
+    m.weight.grad = torch.zeros_like(m.weight)             # gradient buffer the kernels accumulate into
+    y = m(x)
+    y.backward(fx['in']['gy'].to(DEV, dtype))
+    check_fx(fx, 'y', y, dtype)
+    check_fx(fx, 'gx', x.grad, dtype, scale=4)
+    check_fx(fx, 'g_weight', m.weight.grad, dtype, scale=8)
+    with torch.no_grad():
+        st = {}
+        inc = torch.cat([m(x[t:t + 1].detach(), incremental_state=st) for t in range(T)], dim=0)
+    check_fx(fx, 'y_incremental', inc, dtype)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_dynamic_conv_full_size_dropconnect(dtype):
     """decoder shapes (T=32,B=16,C=1024,H=16,K=31) with DropConnect, vs the oracle with the same mask."""
     import tell_amd

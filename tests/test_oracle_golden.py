@@ -65,6 +65,20 @@ def test_dynamic_conv(golden, K, T):
                            y_incremental2=inc2))
 
 
+@pytest.mark.parametrize('K,T', [(3, 6), (31, 12)])
+def test_lightweight_conv(golden, K, T):
+    from oracle.modules import LightweightConv1dTBC
+    fx = golden('lightconv_K%d_T%d' % (K, T))
+    m = LightweightConv1dTBC(64, K, 4, weight_dropout=0.1).eval()
+    load_sd(m, fx['sd'])
+    x = fx['in']['x'].clone().requires_grad_(True)
+    y = m(x)
+    y.backward(fx['in']['gy'])
+    st = {}
+    inc = torch.cat([m(x[t:t + 1].detach(), incremental_state=st) for t in range(T)], dim=0)
+    check_outputs(fx, dict(y=y, gx=x.grad, g_weight=m.weight.grad, y_incremental=inc))
+
+
 @pytest.mark.parametrize('tag', ['sep', 'same', 'nomask', 'empty'])
 def test_multi_head_attention(golden, tag):
     fx = golden('mha_' + tag)
@@ -134,7 +148,8 @@ def test_adaptive_softmax_and_loss(golden):
 DEC_KW = dict(vocab_size=600, dim=64, heads=4, ffn=128, cutoff=(100, 300))
 
 
-@pytest.mark.parametrize('kind', ['flattened', 'faces_objects', 'faces_parallel', 'flattened_no_image'])
+@pytest.mark.parametrize('kind', ['flattened', 'faces_objects', 'faces_parallel', 'flattened_no_image',
+                                  'flattened_lightweight'])
 def test_decoder(golden, kind):
     fx = golden('decoder_' + kind)
     dec = build_decoder(kind, article_dim=64 if kind.startswith('flattened') else 1024, **DEC_KW).eval()

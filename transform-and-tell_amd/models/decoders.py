@@ -7,7 +7,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..common.registrable import Registrable
-from ..modules import AdaptiveSoftmax, DynamicConv1dTBC, GehringLinear, MultiHeadAttention
+from ..modules import AdaptiveSoftmax, DynamicConv1dTBC, GehringLinear, LightweightConv1dTBC, MultiHeadAttention
 from ..modules.token_embedders import AdaptiveEmbedding
 
 
@@ -39,15 +39,15 @@ class DynamicConvDecoderLayer(DecoderLayer):
                  decoder_attention_heads, weight_dropout, dropout, relu_dropout, input_dropout,
                  decoder_normalize_before, attention_dropout, decoder_ffn_embed_dim, contexts, kernel_size=0):
         super().__init__()
-        if decoder_conv_type != 'dynamic' or not decoder_glu or decoder_normalize_before:
-            raise NotImplementedError('HIP path implements decoder_conv_type=dynamic, decoder_glu=true, '
+        if decoder_conv_type not in ('dynamic', 'lightweight') or not decoder_glu or decoder_normalize_before:
+            raise NotImplementedError('HIP path implements decoder_conv_type=dynamic|lightweight, decoder_glu=true, '
                                       'decoder_normalize_before=false (all 19 dynamic-conv configs)')
         E = self.embed_dim = decoder_embed_dim
         self.conv_dim = decoder_conv_dim
         self.linear1 = GehringLinear(E, 2 * self.conv_dim)
-        self.conv = DynamicConv1dTBC(self.conv_dim, kernel_size, padding_l=kernel_size - 1,
-                                     weight_softmax=weight_softmax, num_heads=decoder_attention_heads,
-                                     weight_dropout=weight_dropout)
+        conv_cls = DynamicConv1dTBC if decoder_conv_type == 'dynamic' else LightweightConv1dTBC      # :199-211
+        self.conv = conv_cls(self.conv_dim, kernel_size, padding_l=kernel_size - 1, weight_softmax=weight_softmax,
+                             num_heads=decoder_attention_heads, weight_dropout=weight_dropout)
         self.linear2 = GehringLinear(self.conv_dim, E)
         self.dropout, self.relu_dropout, self.input_dropout = dropout, relu_dropout, input_dropout
         self.normalize_before = decoder_normalize_before
@@ -194,14 +194,14 @@ class _DynamicConvDecoderBase(Decoder):
         if incremental_state is None:
             return
         for key in incremental_state:
-            if 'DynamicConv1dTBC' in key:
+            if 'Conv1dTBC' in key:
                 incremental_state[key] = incremental_state[key].index_select(1, new_order)
 
     def filter_incremental_state(self, incremental_state, active_idx):             # :175-180
         if incremental_state is None:
             return
         for key in incremental_state:
-            if 'DynamicConv1dTBC' in key:
+            if 'Conv1dTBC' in key:          # (the reference names DynamicConv1dTBC only)
                 incremental_state[key] = incremental_state[key][:, active_idx]
 
 

@@ -1,4 +1,4 @@
-"""tell/modules/convolutions/dynamic.py:25-361 on the MI355X path."""
+"""tell/modules/convolutions/dynamic.py:25-361 and lightweight.py:83-240 on the MI355X path."""
 import torch
 import torch.nn as nn
 
@@ -45,11 +45,36 @@ class DynamicConv1dTBC(nn.Module):
                 n_hist = prev.shape[0]
                 X = torch.cat([prev, X], dim=0)
             incremental_state[self._state_key] = X[-self.kernel_size + 1:] if self.kernel_size > 1 else X[:0]
-        logits = self.weight_linear(X)
+        logits = self._logits(X)
         out = ops.dynamic_conv(X, logits, self.num_heads, self.kernel_size, self.weight_dropout, self.training)
         return out[n_hist:] if n_hist else out                       # dynamic.py:115-116
+
+    def _logits(self, X):
+        return self.weight_linear(X)
 
     def reorder_incremental_state(self, incremental_state, new_order):
         buf = incremental_state.get(self._state_key)
         if buf is not None:
             incremental_state[self._state_key] = buf.index_select(1, new_order)
+
+
+class LightweightConv1dTBC(DynamicConv1dTBC):
+    """tell/modules/convolutions/lightweight.py:83-240 as `decoder_conv_type: lightweight` builds it
+    (decoder_faces_objects.py:199-203): one learned tap vector per head instead of taps predicted from the input.
+    Same causal K-tap kernels; only the source of the tap logits differs (`ops.static_taps`)."""
+
+    def __init__(self, input_size, kernel_size=1, padding_l=None, num_heads=1, weight_dropout=0.,
+                 weight_softmax=True, bias=False):
+        nn.Module.__init__(self)
+        if not weight_softmax or bias or (padding_l is not None and padding_l != kernel_size - 1):
+            raise NotImplementedError('only the causal weight_softmax configuration the decoders build is implemented')
+        self.input_size, self.kernel_size, self.num_heads = input_size, kernel_size, num_heads
+        self.padding_l = kernel_size - 1
+        self.weight_dropout = weight_dropout
+        self.weight = nn.Parameter(torch.empty(num_heads, 1, kernel_size))
+        nn.init.xavier_uniform_(self.weight)                                      # lightweight.py:127
+        _INSTANCES[0] += 1
+        self._state_key = 'LightweightConv1dTBC.%d.input_buffer' % _INSTANCES[0]
+
+    def _logits(self, X):
+        return ops.static_taps(self.weight, X.shape[0], X.shape[1])

@@ -580,6 +580,29 @@ class DynConvFn(Function):
         return dx, dlogits, None, None, None, None
 
 
+class StaticTapsFn(Function):
+    """LightweightConv1dTBC (lightweight.py:186-188): the learned [H,1,K] tap parameter seen as per-position tap
+    logits [T,B,H*K], so that the DynamicConv kernels serve `decoder_conv_type: lightweight` unchanged; backward sums
+    the logit gradients over (t, b) straight into the parameter's gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, w_param, T, B):
+        w = weight(w_param).reshape(1, 1, -1)                     # [1,1,H*K] compute dtype
+        ctx.w_param = w_param
+        return w.expand(T, B, w.shape[2]).contiguous()
+
+    @staticmethod
+    def backward(ctx, dl):
+        p = ctx.w_param
+        if p.requires_grad:
+            colsum_into(as2dc(dl), grad_buffer(p).view(-1))
+        return None, None, None
+
+
+def static_taps(w_param, T, B):
+    return StaticTapsFn.apply(w_param, T, B)
+
+
 def dynamic_conv(x, logits, H, K, p=0.0, training=False):
     p = p if training else 0.0
     return DynConvFn.apply(x, logits, H, K, p, rt.next_salt() if p > 0 else 0)
