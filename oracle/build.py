@@ -30,6 +30,10 @@ def build_decoder(kind='faces_objects', vocab_size=50265, dim=1024, heads=16, ff
         contexts = (('article', article_dim),)
     else:                                                # 'flattened', 'flattened_lightweight'
         contexts = (CONTEXTS_FLATTENED[0], ('article', article_dim))
+    if kind.endswith('_prenorm'):                        # decoder_normalize_before + final_norm, decoder_glu: false
+        overrides.setdefault('decoder_normalize_before', True)
+        overrides.setdefault('final_norm', True)
+        overrides.setdefault('decoder_glu', False)
     if kind.endswith('_lightweight'):                    # `decoder_conv_type: lightweight` (decoder_flattened.py:199-203)
         overrides.setdefault('decoder_conv_type', 'lightweight')
     kw = dict(decoder_conv_dim=dim, decoder_attention_heads=heads, decoder_ffn_embed_dim=ffn,

@@ -230,7 +230,7 @@ def adaptive_softmax():
 
 
 ART_DIM = {'flattened': 64, 'faces_objects': 1024, 'faces_parallel': 1024, 'flattened_no_image': 64,
-           'flattened_lightweight': 64}   # flattened: kdim == embed_dim -> in_proj_weight path
+           'flattened_lightweight': 64, 'flattened_prenorm': 64}   # flattened: kdim == embed_dim -> in_proj_weight path
 
 
 def _mk_contexts(B, S, kind, seed):
@@ -264,6 +264,9 @@ DEC_KW = dict(max_target_positions=512, dropout=0.1, share_decoder_input_output_
 
 def _ref_decoder(kind):
     emb = _ref_embedder(600, 64, (100, 300), init_size=512)
+    if kind == 'flattened_prenorm':           # pre-LN blocks + final LayerNorm, no GLU (the remaining layer switches)
+        return dfl.DynamicConvDecoder(None, emb, article_embed_size=ART_DIM['flattened'],
+                                      **dict(DEC_KW, decoder_normalize_before=True, final_norm=True, decoder_glu=False))
     if kind == 'flattened_lightweight':       # the 2-context decoder with `decoder_conv_type: lightweight`
         return dfl.DynamicConvDecoder(None, emb, article_embed_size=ART_DIM['flattened'],
                                       **dict(DEC_KW, decoder_conv_type='lightweight'))
@@ -386,6 +389,10 @@ def models():
         print('   gen lengths:', [(r != 1).sum().item() for r in gen_ids], 'gen shape', tuple(gen_ids.shape))
 
 
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'prenorm':
+    decoders(('flattened_prenorm',))
+    sys.exit(0)
+
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'lightweight':
     lightconv()                                              # only the fixtures added later
     decoders(('flattened_lightweight',))
@@ -403,5 +410,5 @@ if __name__ == '__main__':
     embed_and_positions()
     adaptive_softmax()
     decoders()
-    decoders(('flattened_lightweight',))
+    decoders(('flattened_lightweight', 'flattened_prenorm'))
     models()

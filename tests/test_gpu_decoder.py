@@ -44,7 +44,7 @@ def _ctx_to_dev(ins, dtype):
 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('kind', ['flattened', 'faces_objects', 'faces_parallel', 'flattened_no_image',
-                                  'flattened_lightweight'])
+                                  'flattened_lightweight', 'flattened_prenorm'])
 def test_decoder_golden(golden, dtype, kind):
     import tell_amd
     from tell_amd.build import build_decoder

@@ -149,7 +149,7 @@ DEC_KW = dict(vocab_size=600, dim=64, heads=4, ffn=128, cutoff=(100, 300))
 
 
 @pytest.mark.parametrize('kind', ['flattened', 'faces_objects', 'faces_parallel', 'flattened_no_image',
-                                  'flattened_lightweight'])
+                                  'flattened_lightweight', 'flattened_prenorm'])
 def test_decoder(golden, kind):
     fx = golden('decoder_' + kind)
     dec = build_decoder(kind, article_dim=64 if kind.startswith('flattened') else 1024, **DEC_KW).eval()

@@ -30,6 +30,8 @@ def build_decoder(kind='faces_objects', vocab_size=50265, dim=1024, heads=16, ff
                   cutoff=(5000, 20000), article_dim=1024, init_size=512):
     emb = build_embedder(vocab_size, dim, cutoff, init_size)
     kw = decoder_kwargs(vocab_size, dim, heads, ffn, kernels, cutoff)
+    if kind.endswith('_prenorm'):                            # pre-LN blocks + final LayerNorm, no GLU
+        kw.update(decoder_normalize_before=True, final_norm=True, decoder_glu=False)
     if kind.endswith('_lightweight'):                        # `decoder_conv_type: lightweight` (decoder_flattened.py:199-203)
         kw['decoder_conv_type'] = 'lightweight'
     if kind == 'faces_objects':

@@ -39,12 +39,12 @@ class DynamicConvDecoderLayer(DecoderLayer):
                  decoder_attention_heads, weight_dropout, dropout, relu_dropout, input_dropout,
                  decoder_normalize_before, attention_dropout, decoder_ffn_embed_dim, contexts, kernel_size=0):
         super().__init__()
-        if decoder_conv_type not in ('dynamic', 'lightweight') or not decoder_glu or decoder_normalize_before:
-            raise NotImplementedError('HIP path implements decoder_conv_type=dynamic|lightweight, decoder_glu=true, '
-                                      'decoder_normalize_before=false (all 19 dynamic-conv configs)')
+        if decoder_conv_type not in ('dynamic', 'lightweight'):
+            raise NotImplementedError('decoder_conv_type must be dynamic or lightweight (decoder_faces_objects.py:199-211)')
         E = self.embed_dim = decoder_embed_dim
         self.conv_dim = decoder_conv_dim
-        self.linear1 = GehringLinear(E, 2 * self.conv_dim)
+        self.glu = bool(decoder_glu)                                                      # :190-197
+        self.linear1 = GehringLinear(E, 2 * self.conv_dim if self.glu else self.conv_dim)
         conv_cls = DynamicConv1dTBC if decoder_conv_type == 'dynamic' else LightweightConv1dTBC      # :199-211
         self.conv = conv_cls(self.conv_dim, kernel_size, padding_l=kernel_size - 1, weight_softmax=weight_softmax,
                              num_heads=decoder_attention_heads, weight_dropout=weight_dropout)
@@ -69,32 +69,45 @@ class DynamicConvDecoderLayer(DecoderLayer):
     def _ln(ln, x, res, p, training):
         return ops.layer_norm(x, res, ln.weight, ln.bias, ln.eps, p, training)
 
+    def _pre(self, ln, x):
+        """maybe_layer_norm(before=True), :367-372: LayerNorm in front of the block for pre-LN layers."""
+        return ops.layer_norm(x, None, ln.weight, ln.bias, ln.eps, 0.0, False) if self.normalize_before else x
+
+    def _post(self, ln, h, res):
+        """res + dropout(h), then maybe_layer_norm(after=True): post-LN layers (every expt/ config) take the fused
+        LN(res + dropout(h)) kernel."""
+        if self.normalize_before:
+            return res + ops.dropout(h, self.dropout, self.training)
+        return self._ln(ln, h, res, self.dropout, self.training)
+
     def forward(self, X, contexts, incremental_state, contexts_t=None, kv=None):
         tr = self.training
         res = X                                                            # :256-266
-        h = ops.dropout(X, self.input_dropout, tr)
-        h = ops.glu(self.linear1(h))
+        h = ops.dropout(self._pre(self.conv_layer_norm, X), self.input_dropout, tr)
+        h = self.linear1(h)
+        if self.glu:
+            h = ops.glu(h)
         h = self.conv(h, incremental_state=incremental_state)
         h = self.linear2(h)
-        X = self._ln(self.conv_layer_norm, h, res, self.dropout, tr)      # LN(res + dropout(h))
+        X = self._post(self.conv_layer_norm, h, res)
 
         attns, outs = {}, []
         for name in self.context_names:                                   # :271-352
             a, w = self.context_attns[name](
-                X, contexts[name], contexts[name], key_padding_mask=contexts[name + '_mask'],
-                need_weights=(not tr and self.need_attn),
+                self._pre(self.context_attn_lns[name], X), contexts[name], contexts[name],
+                key_padding_mask=contexts[name + '_mask'], need_weights=(not tr and self.need_attn),
                 key_t=None if contexts_t is None else contexts_t.get(name),
                 kv=None if kv is None else kv[name])
-            outs.append(self._ln(self.context_attn_lns[name], a, X, self.dropout, tr))
+            outs.append(self._post(self.context_attn_lns[name], a, X))
             if w is not None:
                 attns[name] = w.cpu().numpy()
         X = self.context_fc(torch.cat(outs, dim=-1))                       # :354-355
 
         res = X                                                            # :357-364
-        h = self.fc1(X, act=1)
+        h = self.fc1(self._pre(self.final_layer_norm, X), act=1)
         h = ops.dropout(h, self.relu_dropout, tr)
         h = self.fc2(h)
-        return self._ln(self.final_layer_norm, h, res, self.dropout, tr), attns
+        return self._post(self.final_layer_norm, h, res), attns
 
     def make_generation_fast_(self, need_attn=False, **kwargs):
         self.need_attn = need_attn
@@ -137,6 +150,8 @@ class _DynamicConvDecoderBase(Decoder):
                                                 factor=adaptive_softmax_factor, tie_proj=tie_adaptive_proj)
         self.register_buffer('version', torch.Tensor([2]))
         self.normalize = decoder_normalize_before and final_norm
+        if self.normalize:                                                         # :88-90
+            self.layer_norm = nn.LayerNorm(E)
 
     def forward(self, prev_target, contexts, incremental_state=None, use_layers=None, kv_cache=None, **kwargs):
         X = self.embedder(prev_target, incremental_state=incremental_state)      # :98  [B,T,E] view
@@ -164,6 +179,8 @@ class _DynamicConvDecoderBase(Decoder):
                                 None if kv_cache is None else kv_cache[i])
                 inner_states.append(X)
             attns.append(attn)
+        if self.normalize:                                                         # :125-126
+            X = ops.layer_norm(X, None, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, 0.0, False)
         X = X.transpose(0, 1)                                                      # :129 B x T x C
         return X, {'attn': attns, 'inner_states': inner_states}
 
