@@ -375,6 +375,26 @@ def test_dp_bucketed_allreduce_during_backward_one_rank_rccl(monkeypatch):
     assert (num / den) ** 0.5 < 1e-4, (num / den) ** 0.5
 
 
+def test_dp_two_real_ranks_share_one_gpu():
+    """Two data-parallel ranks (gloo carries the gradients through the host, both ranks compute on cuda:0) with different,
+    ragged batches: the per-layer exchange started during backward must leave both ranks with bit-identical weights
+    after every step (tools/dp_two_ranks.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TELL_DP_BUCKETED='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nproc-per-node', '2', '--master-addr',
+                        '127.0.0.1', '--master-port', '29653', os.path.join(root, 'tools', 'dp_two_ranks.py')],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-3000:]
+    assert 'RESULT ranks consistent' in out, out[-3000:]
+    assert 'bucketed reduces so far: 16' in out, out[-3000:]
+
+
 def test_pipelined_steps_with_graphed_encoders_equal_eager_fp32():
     """Real (small) ResNet + RoBERTa encoders replayed as hipGraphs AND prefetched one batch ahead: the decoder step
     of batch N must see batch N's features although the graphs for batch N+1 are already running (the captures are
