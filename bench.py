@@ -90,6 +90,8 @@ def main():
     # (GPU_MAX_HW_QUEUES stays at its default of 4: the schedule uses three streams - backward/decoder, RoBERTa, ResNet -
     #  and an RCCL communicator brings the fourth; see tell_amd/streams.py for the measurements)
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('TELL_BENCH_ONE_GPU') == '1':      # rehearsal of the multi-rank control flow on a 1-GPU box:
+        local_rank = 0                                   # every rank computes on cuda:0 (use TELL_DP_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
