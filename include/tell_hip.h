@@ -128,6 +128,26 @@ int tell_layernorm_bwd(const void* dy, long ld_dy, const void* x, long ld_x, con
                        int dparam_accumulate, float* partial, int rows, int C, float p, uint32_t seed,
                        uint32_t salt, int dtype, tell_stream_t stream);
 
+/* ---- LSTM decoder of the GloVe/LSTM baseline (tell/models/decoder_flattened_lstm.py) ----
+ * nn.LSTMCell (:20-26, :160-161): g1 = x W_ih^T + b_ih and g2 = h W_hh^T + b_hh come from tell_gemm_nt ([B,4H], chunk
+ * order i f g o); this applies the gate non-linearities and the state update.  gates: [B,4H] fp32, activated (saved). */
+int tell_lstm_cell_fwd(const void* g1, const void* g2, const void* c_prev, void* h, void* c, float* gates, int B, int H,
+                       int dtype, tell_stream_t stream);
+/* dh / dc may be NULL; dgates ([B,4H], the gradient of both g1 and g2) and dc_prev are written */
+int tell_lstm_cell_bwd(const void* dh, const void* dc, const float* gates, const void* c, const void* c_prev,
+                       void* dgates, void* dc_prev, int B, int H, int dtype, tell_stream_t stream);
+/* AttentionLayer.forward (:40-60) between its two projections: scores[l,b] = <src[l,b,:], x[b,:]>, key-padding mask
+ * ([B,L] uint8, may be NULL), softmax over l, ctx[b,:] = sum_l probs[l,b] src[l,b,:].  src element (l,b,d) at
+ * l*src_stride_l + b*src_stride_b + d; probs: [L,B] fp32 (the returned attention scores, saved); L <= 1024. */
+int tell_dot_attn_fwd(const void* src, long src_stride_l, long src_stride_b, const void* x, const unsigned char* mask,
+                      void* ctx, float* probs, int L, int B, int D, int dtype, tell_stream_t stream);
+/* gradient w.r.t. the projected query x (source_hids are encoder outputs without gradient on this path) */
+int tell_dot_attn_bwd(const void* src, long src_stride_l, long src_stride_b, const float* probs, const void* dctx,
+                      void* dx, int L, int B, int D, int dtype, tell_stream_t stream);
+/* torch.tanh around output_proj (:62) */
+int tell_tanh_fwd(const void* x, void* y, long n, int dtype, tell_stream_t stream);
+int tell_tanh_bwd(const void* dy, const void* y, void* dx, long n, int dtype, tell_stream_t stream);
+
 /* ---- DynamicConv1dTBC core, tell/modules/convolutions/dynamic.py:285-336 (T x B x C)
  * taps = softmax_K(logits) (:302-304), DropConnect (:305), causal K-tap weighted sum;
  * replaces the band-matrix build + bmm (:318-335).  taps: [T*B*H, K] fp32 (saved for backward). */

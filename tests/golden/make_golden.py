@@ -233,6 +233,47 @@ ART_DIM = {'flattened': 64, 'faces_objects': 1024, 'faces_parallel': 1024, 'flat
            'flattened_lightweight': 64, 'flattened_prenorm': 64}   # flattened: kdim == embed_dim -> in_proj_weight path
 
 
+def lstm_decoder():
+    """LSTMDecoder (`lstm_decoder_flattened`, decoder_flattened_lstm.py:68-208): the decoder of the GloVe/LSTM baseline."""
+    import importlib
+    dl = importlib.import_module('tell.models.decoder_flattened_lstm')
+    torch.manual_seed(60)
+    emb = _ref_embedder(600, 64, (100, 300), init_size=512)
+    dec = dl.LSTMDecoder(None, emb, num_layers=3, hidden_size=48, dropout=0.1, share_decoder_input_output_embed=True,
+                         vocab_size=600, adaptive_softmax_cutoff=[100, 300], tie_adaptive_weights=True,
+                         adaptive_softmax_dropout=0, tie_adaptive_proj=False, adaptive_softmax_factor=1,
+                         article_embed_size=300, image_embed_size=2048).eval()
+    for p in dec.parameters():
+        if p.dim() == 1 or p.shape[0] == 1:          # biases, learned initial states
+            p.data.add_(0.1 * torch.randn_like(p))
+    seed_big('decoder_lstm', {'sd/' + k: v for k, v in dec.state_dict().items() if 'token_embedder_position' not in k})
+    B, T, S = 2, 7, 11
+    g = torch.Generator().manual_seed(61)
+    ctx = {'image': torch.randn(5, B, 2048, generator=g), 'image_mask': torch.zeros(B, 5, dtype=torch.bool),
+           'article': torch.randn(S, B, 300, generator=g), 'article_mask': torch.zeros(B, S, dtype=torch.bool)}
+    ctx['article_mask'][0, S - 3:] = True
+    seed_big('decoder_lstm', {'in/' + k: v for k, v in ctx.items()})
+    ids = torch.randint(2, 600, (B, T))
+    ids[:, 0] = 0
+    ids[1, 5:] = 1
+    tgt = torch.randint(2, 600, (B, T))
+    tgt[1, 4:] = 1
+    tgt[0, :3] = torch.tensor([101, 301, 99])
+    out = dec({'roberta': ids}, ctx)
+    loss, n = AdaptiveLoss(padding_idx=1)(dec.adaptive_softmax, out, tgt)
+    (loss / n).backward()
+    pd = dict(dec.named_parameters())
+    names = ['layers.0.weight_ih', 'layers.0.bias_hh', 'layers.2.weight_hh', 'h.0', 'c.1',
+             'image_attention.input_proj.weight_v', 'image_attention.input_proj.bias',
+             'article_attention.output_proj.weight_g', 'article_attention.output_proj.bias', 'attn_proj.weight_v',
+             'project_out_dim.weight_v', 'embedder.token_embedder_adaptive.embeddings.0.0.weight',
+             'adaptive_softmax.tail.1.0.weight']
+    grads = {'g_' + k: pd[k].grad for k in names}
+    sd = {k: v for k, v in dec.state_dict().items() if 'token_embedder_position' not in k}
+    save('decoder_lstm', sd, **{'in': dict(ids=ids, target=tgt, **ctx),
+                                'out': dict(x=out[0], loss=loss, sample_size=n, **grads)})
+
+
 def _mk_contexts(B, S, kind, seed):
     g = torch.Generator().manual_seed(seed)
     ctx = {'image': torch.randn(5, B, 2048, generator=g), 'image_mask': torch.zeros(B, 5, dtype=torch.bool),
@@ -389,6 +430,10 @@ def models():
         print('   gen lengths:', [(r != 1).sum().item() for r in gen_ids], 'gen shape', tuple(gen_ids.shape))
 
 
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'lstm':
+    lstm_decoder()
+    sys.exit(0)
+
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'prenorm':
     decoders(('flattened_prenorm',))
     sys.exit(0)
@@ -411,4 +456,5 @@ if __name__ == '__main__':
     adaptive_softmax()
     decoders()
     decoders(('flattened_lightweight', 'flattened_prenorm'))
+    lstm_decoder()
     models()

@@ -167,3 +167,41 @@ def test_model_loss_and_greedy_generation_golden(golden, dtype, kind):
             n = min(got.shape[1], ref_ids.shape[1])
             agree = (got[:, :n] == ref_ids[:, :n]).float().mean().item()
             assert agree > 0.5, agree
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_lstm_decoder_golden(golden, dtype):
+    """`lstm_decoder_flattened` (the decoder of the GloVe/LSTM baseline): loss, outputs and gradients vs
+    what the REFERENCE's LSTMDecoder produced."""
+    import tell_amd
+    from tell_amd.build import build_embedder
+    from tell_amd.models import LSTMDecoder
+    from tell_amd.modules import AdaptiveLoss
+    tell_amd.set_compute_dtype(dtype)
+    fx = golden('decoder_lstm')
+    dec = LSTMDecoder(None, build_embedder(600, 64, (100, 300), 512), num_layers=3, hidden_size=48, dropout=0.1,
+                      share_decoder_input_output_embed=True, vocab_size=600, adaptive_softmax_cutoff=[100, 300],
+                      tie_adaptive_weights=True, adaptive_softmax_dropout=0, tie_adaptive_proj=False,
+                      adaptive_softmax_factor=1, article_embed_size=300, image_embed_size=2048)
+    dec.load_state_dict(fx['sd'], strict=False)
+    dec.to(DEV)
+    ins = fx['in']
+    ctx = _ctx_to_dev(ins, dtype)
+    torch.set_grad_enabled(True)
+    dec.train()
+    dec.dropout = 0.0                                   # training graph, dropout off (the reference ran eval())
+    out = dec({'roberta': ins['ids'].to(DEV)}, ctx)
+    loss, n = AdaptiveLoss(1)(dec.adaptive_softmax, out, ins['target'].to(DEV))
+    (loss / n.float()).sum().backward()
+    assert int(n) == fx['out']['sample_size']
+    close(out[0], fx['out']['x'], dtype, scale=20)
+    close(loss.reshape(1), fx['out']['loss'], dtype, rtol=1e-3 if dtype == torch.float32 else 3e-2)
+    pd = dict(dec.named_parameters())
+    gtol = dict(rtol=0.15) if dtype == torch.bfloat16 else {}
+    for k, v in fx['out'].items():
+        if k.startswith('g_'):
+            close(pd[k[2:]].grad, v, dtype, scale=10, **gtol)
+    for k, v in fx.get('sub', {}).items():
+        if k.startswith('g_'):
+            close(torch.from_numpy(seeded.subsample(pd[k[2:]].grad.float().cpu().numpy())), v, dtype, scale=10,
+                  **gtol)

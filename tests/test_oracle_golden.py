@@ -174,6 +174,28 @@ def test_decoder(golden, kind):
     check_outputs(fx, got)
 
 
+def test_lstm_decoder(golden):
+    """LSTMDecoder of the GloVe/LSTM baseline (decoder_flattened_lstm.py:68-208) vs the reference's outputs."""
+    from oracle.build import build_embedder
+    from oracle.lstm import LSTMDecoder
+    fx = golden('decoder_lstm')
+    dec = LSTMDecoder(build_embedder(600, 64, (100, 300)), num_layers=3, hidden_size=48, dropout=0.1, vocab_size=600,
+                      adaptive_softmax_cutoff=(100, 300), article_embed_size=300, image_embed_size=2048).eval()
+    load_sd(dec, fx['sd'])
+    ins = fx['in']
+    ctx = {k: v for k, v in ins.items() if k not in ('ids', 'target')}
+    out = dec({'roberta': ins['ids']}, ctx)
+    loss, n = AdaptiveLoss(1)(dec.adaptive_softmax, out, ins['target'])
+    (loss / n).backward()
+    assert n == fx['out']['sample_size']
+    got = dict(x=out[0], loss=loss.reshape(1))
+    pd = dict(dec.named_parameters())
+    for k in list(fx['out']) + list(fx.get('sub', {})):
+        if k.startswith('g_'):
+            got[k] = pd[k[2:]].grad
+    check_outputs(fx, got)
+
+
 class _TableRoberta:
     """the fixture generator's stand-in article encoder (ref_import.StandInEncoders.Roberta)"""
 

@@ -3,3 +3,4 @@ from .decoders import (Decoder, DecoderLayer, DynamicConvDecoder,  # noqa: F401
                        DynamicConvFacesObjectsDecoder, DynamicConvDecoderLayer)
 from .transformer import (TransformerFacesObjectModel, TransformerFlattenedModel,  # noqa: F401
                           CaptionModel)
+from .decoder_lstm import LSTMDecoder  # noqa: F401

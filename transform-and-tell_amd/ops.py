@@ -580,6 +580,87 @@ class DynConvFn(Function):
         return dx, dlogits, None, None, None, None
 
 
+# --------------------------------------------------------------------------- #
+# LSTM decoder pieces (tell/models/decoder_flattened_lstm.py, the GloVe/LSTM baseline)
+# --------------------------------------------------------------------------- #
+class LSTMCellFn(Function):
+    """Gate non-linearities + state update of nn.LSTMCell from the two gate pre-activations ([B,4H] each)."""
+
+    @staticmethod
+    def forward(ctx, g1, g2, c_prev):
+        g1, g2, c_prev = g1.contiguous(), g2.contiguous(), c_prev.contiguous()
+        B, H = c_prev.shape
+        h, c = torch.empty_like(c_prev), torch.empty_like(c_prev)
+        gates = torch.empty(B, 4 * H, dtype=torch.float32, device=g1.device)
+        call('tell_lstm_cell_fwd', g1, g2, c_prev, h, c, gates, B, H, hip.dt(g1))
+        ctx.save_for_backward(gates, c, c_prev)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        gates, c, c_prev = ctx.saved_tensors
+        B, H = c.shape
+        dg = torch.empty(B, 4 * H, dtype=c.dtype, device=c.device)
+        dcp = torch.empty_like(c)
+        call('tell_lstm_cell_bwd', dh.contiguous() if dh is not None else None,
+             dc.contiguous() if dc is not None else None, gates, c, c_prev, dg, dcp, B, H, hip.dt(c))
+        return dg, dg, dcp
+
+
+def lstm_cell(g1, g2, c_prev):
+    return LSTMCellFn.apply(g1, g2, c_prev)
+
+
+class DotAttnFn(Function):
+    """AttentionLayer core (decoder_flattened_lstm.py:46-60): dot-product scores of one query per batch element against
+    source_hids [L,B,D], key-padding mask [B,L], softmax over L, weighted sum.  -> (ctx [B,D], probs [L,B] fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, src, mask):
+        assert src.stride(2) == 1 and not src.requires_grad
+        x = x.contiguous()
+        L, B, D = src.shape
+        out = torch.empty(B, D, dtype=x.dtype, device=x.device)
+        probs = torch.empty(L, B, dtype=torch.float32, device=x.device)
+        call('tell_dot_attn_fwd', src, src.stride(0), src.stride(1), x, mask, out, probs, L, B, D, hip.dt(x))
+        ctx.save_for_backward(src, probs)
+        ctx.mark_non_differentiable(probs)
+        return out, probs
+
+    @staticmethod
+    def backward(ctx, dctx, _dprobs):
+        src, probs = ctx.saved_tensors
+        L, B, D = src.shape
+        dx = torch.empty(B, D, dtype=src.dtype, device=src.device)
+        call('tell_dot_attn_bwd', src, src.stride(0), src.stride(1), probs, dctx.contiguous(), dx, L, B, D, hip.dt(src))
+        return dx, None, None
+
+
+def dot_attention(x, src, mask):
+    return DotAttnFn.apply(x, src, mask)
+
+
+class TanhFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        call('tell_tanh_fwd', x, y, x.numel(), hip.dt(x))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        call('tell_tanh_bwd', dy.contiguous(), y, dx, y.numel(), hip.dt(y))
+        return dx
+
+
+def tanh(x):
+    return TanhFn.apply(x)
+
+
 class StaticTapsFn(Function):
     """LightweightConv1dTBC (lightweight.py:186-188): the learned [H,1,K] tap parameter seen as per-position tap
     logits [T,B,H*K], so that the DynamicConv kernels serve `decoder_conv_type: lightweight` unchanged; backward sums
