@@ -75,3 +75,66 @@ class LSTMDecoder(nn.Module):
         if self.project_out_dim is not None:
             y = self.project_out_dim(y)
         return y, {'attn': None, 'inner_states': None}
+
+
+class BaselineGloveModel(nn.Module):
+    """tell/models/baseline_glove.py:22-320 from the point where the article is a NaN-padded tensor of GloVe vectors
+    (`context_vectors` [B,L,300], what :207-220 builds with spaCy): caption shift + truncation (:168-183), ResNet regions
+    (:186-198), NaN rows -> padding mask and zeros (:222-226), LSTM decoder, adaptive loss in bits per token (:80-90),
+    greedy generation by re-decoding the prefix of the still-active rows (:247-320)."""
+
+    def __init__(self, decoder, criterion, resnet, padding_value=1, max_caption_len=50, sampling_temp=1.0):
+        super().__init__()
+        self.decoder, self.criterion, self.resnet = decoder, criterion, resnet
+        self.padding_idx, self.max_caption_len, self.sampling_temp = padding_value, max_caption_len, sampling_temp
+
+    def _forward(self, context_vectors, image, caption_ids_full):
+        import math  # noqa: F401
+        cap = caption_ids_full
+        target = torch.zeros_like(cap)
+        target[:, :-1] = cap[:, 1:]
+        cap, target = cap[:, :-1][:, :self.max_caption_len], target[:, :-1][:, :self.max_caption_len]
+        x = self.resnet(image).permute(0, 2, 3, 1)
+        B, H, W, C = x.shape
+        x = x.reshape(B, H * W, C)
+        cv = context_vectors.clone()
+        mask = torch.isnan(cv).any(dim=-1)
+        cv[mask] = 0
+        ctx = {'image': x.transpose(0, 1), 'image_mask': torch.zeros(B, H * W, dtype=torch.bool),
+               'article': cv.transpose(0, 1), 'article_mask': mask}
+        return cap, target, ctx
+
+    def forward(self, image, caption_ids, context_vectors):
+        import math
+        cap, target, ctx = self._forward(context_vectors, image, caption_ids)
+        out = self.decoder({'roberta': cap}, ctx)
+        loss, n = self.criterion(self.decoder.adaptive_softmax, out, target)
+        return {'loss': loss / math.log(2) / n, 'sample_size': n}
+
+    @torch.no_grad()
+    def generate(self, image, caption_ids, context_vectors, gen_len=100, eos=2):
+        cap, _, ctx = self._forward(context_vectors, image, caption_ids)
+        B = cap.shape[0]
+        seed = cap[:, 0:1]
+        active = seed[:, -1] != eos                       # rows still decoding (indices into the full batch)
+        paths, lps = [seed], []
+        for _ in range(gen_len):
+            sub = {k: (v[:, active] if k in ('image', 'article') else v[active]) for k, v in ctx.items()}
+            out = self.decoder({'roberta': seed}, sub)
+            lp = self.decoder.adaptive_softmax.get_log_prob(out[0][:, -1:]).squeeze(1)
+            top_lp, top = lp.max(dim=-1)
+            path = torch.full((B, 1), self.padding_idx, dtype=torch.long)
+            path[active] = top.unsqueeze(1)
+            lpf = torch.zeros(B, 1)
+            lpf[active] = (top_lp / self.sampling_temp).unsqueeze(1)
+            paths.append(path)
+            lps.append(lpf)
+            seed = torch.cat([seed, top.unsqueeze(1)], dim=-1)
+            still = top != eos
+            idx = active.nonzero().squeeze(1)
+            active = active.clone()
+            active[idx[~still]] = False
+            seed = seed[still]
+            if not bool(active.any()):
+                break
+        return torch.cat(lps, dim=-1), torch.cat(paths, dim=-1)

@@ -274,6 +274,73 @@ def lstm_decoder():
                                 'out': dict(x=out[0], loss=loss, sample_size=n, **grads)})
 
 
+def baseline_model():
+    """BaselineGloveModel + LSTMDecoder (`baseline_glove`, expt/*/1_lstm_glove): loss and greedy generation.  spaCy is
+    absent; the stand-in below supplies a token list with `.has_vector` / `.vector` per article (deterministic vectors
+    per token id), and the NaN-padded tensor the reference builds from it (:207-220) is stored as the model INPUT."""
+    import importlib
+    import types
+    import numpy as np
+
+    class _Tok:
+        def __init__(self, w):
+            i = int(w[1:])
+            self.has_vector = i % 5 != 0
+            self.vector = np.random.RandomState(1000 + i).randn(300).astype('float32')
+
+    class _NLP:
+        def pipe(self, texts):
+            for t in texts:
+                yield [_Tok(w) for w in t.split()]
+    sp = types.ModuleType('spacy')
+    sp.load = lambda *a, **k: _NLP()
+    sys.modules['spacy'] = sp
+    bg = importlib.import_module('tell.models.baseline_glove')
+    dl = importlib.import_module('tell.models.decoder_flattened_lstm')
+    torch.manual_seed(70)
+    emb = _ref_embedder(600, 64, (100, 300), init_size=512)
+    dec = dl.LSTMDecoder(None, emb, num_layers=2, hidden_size=48, dropout=0.1, share_decoder_input_output_embed=True,
+                         vocab_size=600, adaptive_softmax_cutoff=[100, 300], tie_adaptive_weights=True,
+                         adaptive_softmax_dropout=0, tie_adaptive_proj=False, adaptive_softmax_factor=1,
+                         article_embed_size=300, image_embed_size=2048)
+    model = bg.BaselineGloveModel(None, dec, AdaptiveLoss(padding_idx=1)).eval()
+    for p in dec.parameters():
+        if p.dim() == 1 or p.shape[0] == 1:
+            p.data.add_(0.1 * torch.randn_like(p))
+    w0 = dec.embedder.token_embedder_adaptive.embeddings[0][0].weight
+    w0.data[2] *= 1.3                       # <eos> row: greedy decoding ends at different steps per row
+    seed_big('model_baseline_glove', {'sd/' + k: v for k, v in model.state_dict().items()
+                                      if not k.startswith(('resnet.', 'roberta.')) and 'token_embedder_position' not in k
+                                      and 'embeddings.0.0' not in k and 'head.word_proj' not in k})
+    B = 3
+    g = torch.Generator().manual_seed(71)
+    image = torch.randn(B, 3, 224, 224, generator=g)
+    seed_big('model_baseline_glove', {'in/image': image})
+    lens = [9, 14, 6]
+    texts = [' '.join('W%d' % int(t) for t in torch.randint(1, 400, (n,), generator=g)) for n in lens]
+    cap = torch.randint(4, 600, (B, 8), generator=g)
+    cap[:, 0] = 0
+    cap[1, 6:] = 1
+    cap[1, 5] = 2
+    # the tensor :207-220 builds (lower-cased text -> our stand-in parses 'w<i>')
+    vs = [[_Tok(w).vector for w in t.lower().split() if _Tok(w).has_vector] for t in texts]
+    L = max(len(v) for v in vs)
+    cv = torch.full((B, L, 300), float('nan'))
+    for i, v in enumerate(vs):
+        cv[i, :len(v)] = torch.from_numpy(np.array(v))
+    meta = [{'context': t} for t in texts]
+    out = model(image.clone(), {'roberta': cap.clone()}, meta)
+    cid, tid, ctx = model._forward(texts, image.clone(), {'roberta': cap.clone()})
+    assert torch.equal(torch.nan_to_num(cv), ctx['article'].transpose(0, 1)), 'stand-in tensor != what the reference built'
+    lp, gen_ids = model._generate(cid, ctx)
+    sd = {k: v for k, v in model.state_dict().items() if not k.startswith(('resnet.', 'roberta.'))
+          and 'token_embedder_position' not in k}
+    save('model_baseline_glove', sd, **{'in': dict(image=image, caption=cap, context_vectors=cv),
+                                        'out': dict(loss=out['loss'], sample_size=out['sample_size'], gen_ids=gen_ids,
+                                                    gen_log_probs=lp)})
+    print('   gen lengths:', [(r != 1).sum().item() for r in gen_ids], 'gen shape', tuple(gen_ids.shape))
+
+
 def _mk_contexts(B, S, kind, seed):
     g = torch.Generator().manual_seed(seed)
     ctx = {'image': torch.randn(5, B, 2048, generator=g), 'image_mask': torch.zeros(B, 5, dtype=torch.bool),
@@ -432,6 +499,7 @@ def models():
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'lstm':
     lstm_decoder()
+    baseline_model()
     sys.exit(0)
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'prenorm':
@@ -457,4 +525,5 @@ if __name__ == '__main__':
     decoders()
     decoders(('flattened_lightweight', 'flattened_prenorm'))
     lstm_decoder()
+    baseline_model()
     models()

@@ -205,3 +205,38 @@ def test_lstm_decoder_golden(golden, dtype):
         if k.startswith('g_'):
             close(torch.from_numpy(seeded.subsample(pd[k[2:]].grad.float().cpu().numpy())), v, dtype, scale=10,
                   **gtol)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_baseline_glove_model_golden(golden, dtype):
+    """`baseline_glove` (ResNet regions + GloVe article vectors -> LSTM decoder): loss and greedy token
+    ids vs the REFERENCE; generation carries the LSTM state instead of re-decoding the prefix."""
+    import tell_amd
+    from tell_amd.build import build_embedder
+    from tell_amd.models import BaselineGloveModel, LSTMDecoder
+    from tell_amd.modules import AdaptiveLoss
+    tell_amd.set_compute_dtype(dtype)
+    fx = golden('model_baseline_glove')
+    dec = LSTMDecoder(None, build_embedder(600, 64, (100, 300), 512), num_layers=2, hidden_size=48, dropout=0.1,
+                      share_decoder_input_output_embed=True, vocab_size=600, adaptive_softmax_cutoff=[100, 300],
+                      tie_adaptive_weights=True, adaptive_softmax_dropout=0, tie_adaptive_proj=False,
+                      adaptive_softmax_factor=1, article_embed_size=300, image_embed_size=2048)
+    model = BaselineGloveModel(None, dec, AdaptiveLoss(1), resnet=_PoolResnet()).eval()
+    own = model.state_dict()
+    model.load_state_dict({k: v for k, v in fx['sd'].items() if k in own}, strict=False)
+    model.to(DEV)
+    ins = fx['in']
+    batch = lambda: dict(image=ins['image'].to(DEV), caption={'roberta': ins['caption'].to(DEV)},   # noqa: E731
+                         context_vectors=ins['context_vectors'].to(DEV))
+    with torch.no_grad():
+        out = model(**batch())
+    assert int(out['sample_size']) == fx['out']['sample_size']
+    close(out['loss'].reshape(1), fx['out']['loss'], dtype, rtol=1e-3 if dtype == torch.float32 else 3e-2)
+    gen = model.generate(**batch())
+    got, ref_ids = gen['gen_ids'].cpu(), fx['out']['gen_ids']
+    if dtype == torch.float32:
+        assert got.shape == ref_ids.shape and torch.equal(got, ref_ids)                  # bit-exact greedy token ids
+        close(gen['log_probs'], fx['out']['gen_log_probs'], dtype, atol=2e-4)
+    else:
+        n = min(got.shape[1], ref_ids.shape[1])
+        assert (got[:, :n] == ref_ids[:, :n]).float().mean().item() > 0.5

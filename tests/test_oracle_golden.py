@@ -246,3 +246,22 @@ def test_model_loss_and_greedy_generation(golden, kind):
     gen = model.generate(**batch())
     assert torch.equal(gen['gen_ids'], fx['out']['gen_ids'])          # bit-exact token ids
     close(gen['log_probs'], fx['out']['gen_log_probs'], atol=1e-4)
+
+
+def test_baseline_glove_model(golden):
+    """BaselineGloveModel + LSTMDecoder (expt/*/1_lstm_glove): loss and bit-exact greedy ids vs the reference."""
+    from oracle.build import build_embedder
+    from oracle.lstm import BaselineGloveModel, LSTMDecoder
+    fx = golden('model_baseline_glove')
+    dec = LSTMDecoder(build_embedder(600, 64, (100, 300)), num_layers=2, hidden_size=48, dropout=0.1, vocab_size=600,
+                      adaptive_softmax_cutoff=(100, 300), article_embed_size=300, image_embed_size=2048)
+    model = BaselineGloveModel(dec, AdaptiveLoss(1), _PoolResnet()).eval()
+    own = model.state_dict()
+    model.load_state_dict({k: v for k, v in fx['sd'].items() if k in own}, strict=False)
+    ins = fx['in']
+    out = model(ins['image'].clone(), ins['caption'].clone(), ins['context_vectors'].clone())
+    assert out['sample_size'] == fx['out']['sample_size']
+    close(out['loss'].reshape(1), fx['out']['loss'])
+    lp, ids = model.generate(ins['image'].clone(), ins['caption'].clone(), ins['context_vectors'].clone())
+    assert torch.equal(ids, fx['out']['gen_ids'])
+    close(lp, fx['out']['gen_log_probs'], atol=1e-4)

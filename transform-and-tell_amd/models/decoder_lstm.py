@@ -40,13 +40,20 @@ class LSTMDecoder(Decoder):
                                                 factor=adaptive_softmax_factor, tie_proj=tie_adaptive_proj)
 
     def forward(self, prev_target, contexts, incremental_state=None, use_layers=None, **kwargs):
+        """incremental_state (generation): besides the embedder's position it carries the recurrent state
+        (`LSTMDecoder.state`), so a call with the NEXT token continues where the previous call stopped - the same
+        arithmetic as re-decoding the whole prefix (baseline_glove.py:252-275 does that), without the O(T^2)."""
         tr = self.training
         X = self.embedder(prev_target, incremental_state=incremental_state)
         X = ops.dropout(X, self.dropout, tr).transpose(0, 1)                  # T x B x C (:137-141)
         T, B, _ = X.shape
-        hs = [h.to(X.dtype).expand(B, -1).contiguous() for h in self.h]      # :148-149 learned initial states
-        cs = [c.to(X.dtype).expand(B, -1).contiguous() for c in self.c]
-        feed = X.new_zeros(B, self.hidden_size)
+        carried = incremental_state.get('LSTMDecoder.state') if incremental_state is not None else None
+        if carried is not None:
+            hs, cs, feed = list(carried[0]), list(carried[1]), carried[2]
+        else:
+            hs = [h.to(X.dtype).expand(B, -1).contiguous() for h in self.h]  # :148-149 learned initial states
+            cs = [c.to(X.dtype).expand(B, -1).contiguous() for c in self.c]
+            feed = X.new_zeros(B, self.hidden_size)
         outs = []
         for t in range(T):                                                    # :155-186
             inp = torch.cat((X[t], feed), dim=1)                              # input feeding
@@ -57,6 +64,8 @@ class LSTMDecoder(Decoder):
             art, _ = self.article_attention(hs[-1], contexts['article'], contexts['article_mask'])
             feed = self.attn_proj(ops.dropout(torch.cat([img, art], dim=1), self.dropout, tr))
             outs.append(feed)
+        if incremental_state is not None:
+            incremental_state['LSTMDecoder.state'] = (hs, cs, feed)
         Y = torch.stack(outs, dim=0).transpose(0, 1)                          # B x T x hidden
         if self.project_out_dim is not None:
             Y = self.project_out_dim(Y)
