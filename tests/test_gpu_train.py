@@ -279,6 +279,62 @@ def test_model_variants_train_step_matches_oracle_fp32(kind):
     assert checked > 40
 
 
+def test_baseline_glove_training_steps_match_oracle_fp32():
+    """`baseline_glove` (LSTM decoder) through the Trainer - forward, loss, backward of every LSTM /
+    attention kernel, BertAdam - twice; loss and every gradient of the first step against the CPU oracle, finite
+    decreasing loss afterwards."""
+    import tell_amd
+    from oracle.build import build_embedder as obuild_embedder
+    from oracle.lstm import BaselineGloveModel as OModel, LSTMDecoder as ODecoder
+    from oracle.modules import AdaptiveLoss as OLoss
+    from tell_amd.build import build_embedder
+    from tell_amd.models import BaselineGloveModel, LSTMDecoder
+    from tell_amd.modules import AdaptiveLoss
+    from tell_amd.training import Trainer
+    tell_amd.set_compute_dtype(torch.float32)
+    torch.manual_seed(8)
+    dec = LSTMDecoder(None, build_embedder(600, 64, (100, 300), 512), num_layers=2, hidden_size=48, dropout=0.0,
+                      share_decoder_input_output_embed=True, vocab_size=600, adaptive_softmax_cutoff=[100, 300],
+                      tie_adaptive_weights=True, adaptive_softmax_dropout=0, tie_adaptive_proj=False,
+                      adaptive_softmax_factor=1, article_embed_size=300, image_embed_size=2048)
+    gpu = BaselineGloveModel(None, dec, AdaptiveLoss(1), resnet=_Res(True))
+    odec = ODecoder(obuild_embedder(600, 64, (100, 300)), num_layers=2, hidden_size=48, dropout=0.0, vocab_size=600,
+                    adaptive_softmax_cutoff=(100, 300), article_embed_size=300, image_embed_size=2048)
+    cpu = OModel(odec, OLoss(1), _Res(False)).train()
+    cpu.load_state_dict({k: v for k, v in gpu.state_dict().items() if k in cpu.state_dict()}, strict=False)
+    g = torch.Generator().manual_seed(9)
+    B = 3
+    image = torch.randn(B, 3, 224, 224, generator=g)
+    cap = torch.randint(4, 600, (B, 9), generator=g)
+    cap[:, 0] = 0
+    cap[2, 6:] = 1
+    cv = torch.randn(B, 12, 300, generator=g)
+    cv[0, 9:] = float('nan')
+    cv[2, 5:] = float('nan')
+    ref = cpu(image.clone(), cap.clone(), cv.clone())
+    ref['loss'].backward()
+    trainer = Trainer(gpu, dict(lr=2e-3, warmup=0.5, t_total=6, max_grad_norm=0.1, weight_decay=0.0), device=DEV,
+                      no_grad=(r'^resnet',))
+    batch = lambda: dict(image=image.to(DEV), caption={'roberta': cap.to(DEV)}, context_vectors=cv.to(DEV))  # noqa: E731
+    gpu.train()
+    out = gpu(**batch())
+    out['loss'].backward()
+    torch.cuda.synchronize()
+    assert abs(float(out['loss']) - float(ref['loss'])) <= 1e-3 * abs(float(ref['loss']))
+    cp = dict(cpu.named_parameters())
+    checked = 0
+    for n, p in gpu.named_parameters():
+        if n.startswith('resnet') or p.grad is None or cp[n].grad is None:
+            continue
+        gg, r = p.grad.detach().cpu(), cp[n].grad
+        assert (gg - r).norm() <= 2e-3 * (r.norm() + 1e-6), n
+        checked += 1
+    assert checked >= 30, checked
+    trainer.flat.zero_grad()
+    losses = [float(trainer.train_one_batch(batch())) for _ in range(4)]
+    assert all(l == l and abs(l) < 1e4 for l in losses) and losses[-1] < losses[0], losses
+
+
 def test_dp_code_path_one_rank_rccl(monkeypatch):
     """Every collective of the data-parallel step (token-count all-reduce, NaN flag, bf16-on-the-wire gradient
     all-reduce on the update stream) through a real 1-rank RCCL group; result == the non-DP trainer up to the
