@@ -141,9 +141,10 @@ int tell_lstm_cell_bwd(const void* dh, const void* dc, const float* gates, const
  * l*src_stride_l + b*src_stride_b + d; probs: [L,B] fp32 (the returned attention scores, saved); L <= 1024. */
 int tell_dot_attn_fwd(const void* src, long src_stride_l, long src_stride_b, const void* x, const unsigned char* mask,
                       void* ctx, float* probs, int L, int B, int D, int dtype, tell_stream_t stream);
-/* gradient w.r.t. the projected query x (source_hids are encoder outputs without gradient on this path) */
+/* gradient w.r.t. the projected query x and - dsrc != NULL, contiguous [L,B,D] - w.r.t. the source states (needed when
+ * they are the trainable `weigh_bert` mix of the RoBERTa layers, expt/3_lstm_roberta) */
 int tell_dot_attn_bwd(const void* src, long src_stride_l, long src_stride_b, const float* probs, const void* dctx,
-                      void* dx, int L, int B, int D, int dtype, tell_stream_t stream);
+                      const void* x, void* dx, void* dsrc, int L, int B, int D, int dtype, tell_stream_t stream);
 /* torch.tanh around output_proj (:62) */
 int tell_tanh_fwd(const void* x, void* y, long n, int dtype, tell_stream_t stream);
 int tell_tanh_bwd(const void* dy, const void* y, void* dx, long n, int dtype, tell_stream_t stream);

@@ -138,3 +138,20 @@ class BaselineGloveModel(nn.Module):
             if not bool(active.any()):
                 break
         return torch.cat(lps, dim=-1), torch.cat(paths, dim=-1)
+
+
+class TransformerGloveModel(BaselineGloveModel):
+    """tell/models/transformer_glove.py (`transformer_glove`): the baseline's `_forward` without the caption truncation
+    (:161-230) in front of the 2-context DynamicConv decoder; generation is transformer_flattened's incremental greedy
+    decode (`oracle.models.CaptionModel._generate`)."""
+
+    def __init__(self, decoder, criterion, resnet, padding_value=1, sampling_temp=1.0):
+        super().__init__(decoder, criterion, resnet, padding_value, max_caption_len=1 << 30, sampling_temp=sampling_temp)
+        self.index, self.sampling_topk = 'roberta', 1
+
+    @torch.no_grad()
+    def generate(self, image, caption_ids, context_vectors):
+        from .models import CaptionModel
+        cap, _, ctx = self._forward(context_vectors, image, caption_ids)
+        lp, ids, _ = CaptionModel._generate(self, cap, ctx)
+        return lp, ids

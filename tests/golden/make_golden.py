@@ -341,6 +341,65 @@ def baseline_model():
     print('   gen lengths:', [(r != 1).sum().item() for r in gen_ids], 'gen shape', tuple(gen_ids.shape))
 
 
+def transformer_glove_model():
+    """TransformerGloveModel (`transformer_glove`, expt/*/2_transformer_glove): the flattened decoder over GloVe vectors."""
+    import importlib
+    import types
+    import numpy as np
+
+    class _Tok:
+        def __init__(self, w):
+            i = int(w[1:])
+            self.has_vector = i % 5 != 0
+            self.vector = np.random.RandomState(1000 + i).randn(300).astype('float32')
+
+    class _NLP:
+        def pipe(self, texts):
+            for t in texts:
+                yield [_Tok(w) for w in t.split()]
+    sp = types.ModuleType('spacy')
+    sp.load = lambda *a, **k: _NLP()
+    sys.modules['spacy'] = sp
+    tg = importlib.import_module('tell.models.transformer_glove')
+    torch.manual_seed(80)
+    emb = _ref_embedder(600, 64, (100, 300), init_size=512)
+    dec = dfl.DynamicConvDecoder(None, emb, article_embed_size=300, **DEC_KW)
+    model = tg.TransformerGloveModel(None, dec, AdaptiveLoss(padding_idx=1), vocab_size=600).eval()
+    for p in dec.parameters():
+        if p.dim() == 1:
+            p.data.add_(0.1 * torch.randn_like(p))
+    w0 = dec.embedder.token_embedder_adaptive.embeddings[0][0].weight
+    w0.data[2] *= 1.6
+    seed_big('model_transformer_glove', {'sd/' + k: v for k, v in model.state_dict().items()
+                                         if not k.startswith(('resnet.', 'roberta.')) and 'token_embedder_position' not in k
+                                         and 'embeddings.0.0' not in k and 'head.word_proj' not in k})
+    B = 3
+    g = torch.Generator().manual_seed(81)
+    image = torch.randn(B, 3, 224, 224, generator=g)
+    seed_big('model_transformer_glove', {'in/image': image})
+    lens = [9, 14, 6]
+    texts = [' '.join('W%d' % int(t) for t in torch.randint(1, 400, (n,), generator=g)) for n in lens]
+    cap = torch.randint(4, 600, (B, 8), generator=g)
+    cap[:, 0] = 0
+    cap[1, 6:] = 1
+    cap[1, 5] = 2
+    vs = [[_Tok(w).vector for w in t.lower().split() if _Tok(w).has_vector] for t in texts]
+    L = max(len(v) for v in vs)
+    cv = torch.full((B, L, 300), float('nan'))
+    for i, v in enumerate(vs):
+        cv[i, :len(v)] = torch.from_numpy(np.array(v))
+    out = model(image.clone(), {'roberta': cap.clone()}, [{'context': t} for t in texts])
+    cid, tid, ctx = model._forward(texts, image.clone(), {'roberta': cap.clone()})
+    assert torch.equal(torch.nan_to_num(cv), ctx['article'].transpose(0, 1))
+    lp, gen_ids = model._generate(cid, ctx)[:2]
+    sd = {k: v for k, v in model.state_dict().items() if not k.startswith(('resnet.', 'roberta.'))
+          and 'token_embedder_position' not in k}
+    save('model_transformer_glove', sd, **{'in': dict(image=image, caption=cap, context_vectors=cv),
+                                           'out': dict(loss=out['loss'], sample_size=out['sample_size'], gen_ids=gen_ids,
+                                                       gen_log_probs=lp)})
+    print('   gen lengths:', [(r != 1).sum().item() for r in gen_ids], 'gen shape', tuple(gen_ids.shape))
+
+
 def _mk_contexts(B, S, kind, seed):
     g = torch.Generator().manual_seed(seed)
     ctx = {'image': torch.randn(5, B, 2048, generator=g), 'image_mask': torch.zeros(B, 5, dtype=torch.bool),
@@ -497,6 +556,10 @@ def models():
         print('   gen lengths:', [(r != 1).sum().item() for r in gen_ids], 'gen shape', tuple(gen_ids.shape))
 
 
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'transformer_glove':
+    transformer_glove_model()
+    sys.exit(0)
+
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'lstm':
     lstm_decoder()
     baseline_model()
@@ -526,4 +589,5 @@ if __name__ == '__main__':
     decoders(('flattened_lightweight', 'flattened_prenorm'))
     lstm_decoder()
     baseline_model()
+    transformer_glove_model()
     models()

@@ -149,6 +149,15 @@ def test_reference_expt_configs_instantiate_unmodified():
         assert type(mb).__name__ == 'BaselineGloveModel' and type(mb.decoder).__name__ == 'LSTMDecoder'
         assert len(mb.decoder.layers) == 4 and mb.decoder.hidden_size == 1536 and mb.max_caption_len == 50
         assert mb.decoder.article_attention.input_proj.weight_v.shape == (300, 1536)
+        # 2_transformer_glove: the flattened decoder over GloVe vectors; 3_lstm_roberta: the LSTM decoder behind the
+        # RoBERTa model class
+        mg, _ = config.from_config(REF_CFG.replace('nytimes', ds).replace('9_transformer_objects', '2_transformer_glove'),
+                                   resnet=object())
+        assert type(mg).__name__ == 'TransformerGloveModel'
+        assert mg.decoder.layers[0].context_attns['article'].kdim == 300
+        ml, _ = config.from_config(REF_CFG.replace('nytimes', ds).replace('9_transformer_objects', '3_lstm_roberta'),
+                                   resnet=object(), roberta=object())
+        assert type(ml).__name__ == 'TransformerFlattenedModel' and type(ml.decoder).__name__ == 'LSTMDecoder'
     from tell_amd.common.registrable import Registrable
     from tell_amd.training.trainer import TrainerBase
     assert TrainerBase.by_name(params['trainer']['type']).__name__ == 'CallbackApexTrainer'

@@ -240,3 +240,38 @@ def test_baseline_glove_model_golden(golden, dtype):
     else:
         n = min(got.shape[1], ref_ids.shape[1])
         assert (got[:, :n] == ref_ids[:, :n]).float().mean().item() > 0.5
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_transformer_glove_model_golden(golden, dtype):
+    """`transformer_glove` (expt/*/2_transformer_glove): the flattened DynamicConv decoder over ResNet regions + GloVe
+    vectors; loss and greedy ids (cached static-batch generator) vs the REFERENCE."""
+    import tell_amd
+    from tell_amd.build import build_decoder
+    from tell_amd.models import TransformerGloveModel
+    from tell_amd.modules import AdaptiveLoss
+    tell_amd.set_compute_dtype(dtype)
+    fx = golden('model_transformer_glove')
+    dec = build_decoder('flattened', article_dim=300, **DEC_KW)
+    model = TransformerGloveModel(None, dec, AdaptiveLoss(1), vocab_size=600, resnet=_PoolResnet()).eval()
+    own = model.state_dict()
+    model.load_state_dict({k: v for k, v in fx['sd'].items() if k in own}, strict=False)
+    model.to(DEV)
+    ins = fx['in']
+    batch = lambda: dict(image=ins['image'].to(DEV), caption={'roberta': ins['caption'].to(DEV)},   # noqa: E731
+                         context_vectors=ins['context_vectors'].to(DEV))
+    with torch.no_grad():
+        out = model(**batch())
+    assert int(out['sample_size']) == fx['out']['sample_size']
+    close(out['loss'].reshape(1), fx['out']['loss'], dtype, rtol=1e-3 if dtype == torch.float32 else 3e-2)
+    ref_ids = fx['out']['gen_ids']
+    for fast in (True, False):
+        model.fast_generation = fast
+        gen = model.generate(**batch())
+        got = gen['gen_ids'].cpu()
+        if dtype == torch.float32:
+            assert got.shape == ref_ids.shape and torch.equal(got, ref_ids), fast
+            close(gen['log_probs'], fx['out']['gen_log_probs'], dtype, atol=2e-4)
+        else:
+            n = min(got.shape[1], ref_ids.shape[1])
+            assert (got[:, :n] == ref_ids[:, :n]).float().mean().item() > 0.5

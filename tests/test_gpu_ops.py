@@ -164,6 +164,49 @@ def test_gemm_pingpong_kernel(M, N, K):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+def test_lstm_cell_and_dot_attention_vs_torch(dtype):
+    """csrc/lstm.hip against torch on CPU: nn.LSTMCell semantics from the two gate pre-activations, and the
+    AttentionLayer core (masked softmax over the source, weighted sum) incl. the gradient w.r.t. the source states."""
+    from tell_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, H, L, D = 5, 48, 23, 72
+    g1, g2, c0 = torch.randn(B, 4 * H, generator=g), torch.randn(B, 4 * H, generator=g), torch.randn(B, H, generator=g)
+    gh, gc = torch.randn(B, H, generator=g), torch.randn(B, H, generator=g)
+    a, b, c = [t.clone().to(dtype).float().requires_grad_(True) for t in (g1, g2, c0)]
+    i, f, gg, o = (a + b).chunk(4, dim=1)
+    cn = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+    hn = torch.sigmoid(o) * torch.tanh(cn)
+    (hn * gh + cn * gc).sum().backward()
+    ad, bd, cd = [t.clone().to(DEV, dtype).requires_grad_(True) for t in (g1, g2, c0)]
+    h2, c2 = ops.lstm_cell(ad, bd, cd)
+    (h2.float() * gh.to(DEV) + c2.float() * gc.to(DEV)).sum().backward()
+    close(h2, hn, dtype)
+    close(c2, cn, dtype)
+    close(ad.grad, a.grad, dtype, scale=2)
+    close(bd.grad, a.grad, dtype, scale=2)
+    close(cd.grad, c.grad, dtype, scale=2)
+    src, x = torch.randn(L, B, D, generator=g), torch.randn(B, D, generator=g) * 0.3
+    mask = torch.zeros(B, L, dtype=torch.bool)
+    mask[1, 17:] = True
+    mask[3, 5:] = True
+    gctx = torch.randn(B, D, generator=g)
+    sr, xr = src.clone().to(dtype).float().requires_grad_(True), x.clone().to(dtype).float().requires_grad_(True)
+    sc = (sr * xr.unsqueeze(0)).sum(2).masked_fill(mask.t(), float('-inf'))
+    pr = torch.softmax(sc, dim=0)
+    ctx = (pr.unsqueeze(2) * sr).sum(0)
+    (ctx * gctx).sum().backward()
+    sd, xd = src.clone().to(DEV, dtype).requires_grad_(True), x.clone().to(DEV, dtype).requires_grad_(True)
+    ctx2, pr2 = ops.dot_attention(xd, sd, mask.to(DEV).to(torch.uint8))
+    (ctx2.float() * gctx.to(DEV)).sum().backward()
+    close(ctx2, ctx, dtype)
+    close(pr2, pr, torch.float32 if dtype == torch.float32 else dtype)
+    close(xd.grad, xr.grad, dtype, scale=4)
+    close(sd.grad, sr.grad, dtype, scale=4)
+    y = ops.tanh(xd.detach().requires_grad_(True))
+    close(y, torch.tanh(x.to(dtype).float()), dtype)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_transpose_and_weight_norm(dtype):
     from tell_amd import ops
     x = torch.randn(70, 130)

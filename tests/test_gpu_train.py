@@ -335,6 +335,35 @@ def test_baseline_glove_training_steps_match_oracle_fp32():
     assert all(l == l and abs(l) < 1e4 for l in losses) and losses[-1] < losses[0], losses
 
 
+@pytest.mark.parametrize('weigh_bert', [False, True])
+def test_lstm_decoder_behind_roberta_model_trains_and_generates(weigh_bert):
+    """expt/*/3_lstm_roberta: `transformer_flattened` with `lstm_decoder_flattened` (article_embed_size 1024): a training
+    step through the Trainer and a greedy decode (state-carrying generator) run end to end."""
+    import tell_amd
+    from tell_amd.build import build_embedder
+    from tell_amd.data import synthetic_batch
+    from tell_amd.models import LSTMDecoder, TransformerFlattenedModel
+    from tell_amd.modules import AdaptiveLoss
+    from tell_amd.training import Trainer
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(11)
+    dec = LSTMDecoder(None, build_embedder(600, 64, (100, 300), 512), num_layers=2, hidden_size=48, dropout=0.1,
+                      share_decoder_input_output_embed=True, vocab_size=600, adaptive_softmax_cutoff=[100, 300],
+                      tie_adaptive_weights=True, adaptive_softmax_dropout=0, tie_adaptive_proj=False,
+                      adaptive_softmax_factor=1, article_embed_size=64, image_embed_size=2048)
+    model = TransformerFlattenedModel(None, dec, AdaptiveLoss(1), weigh_bert=weigh_bert, vocab_size=600, resnet=_Res(True),
+                                      roberta=_Rob(64), n_bert_layers=3)   # weigh_bert: the article states carry a gradient
+    tr = Trainer(model, dict(lr=2e-3, warmup=0.5, t_total=8, max_grad_norm=0.1, weight_decay=0.0), device=DEV)
+    bt = synthetic_batch(B=3, article_len=20, caption_len=9, vocab=600, cutoffs=(100, 300), seed=70)
+    dev = {k: ({kk: vv.to(DEV) for kk, vv in v.items()} if isinstance(v, dict) else v.to(DEV)) for k, v in bt.items()}
+    clone = lambda x: {k: (dict(v) if isinstance(v, dict) else v) for k, v in x.items()}   # noqa: E731
+    losses = [float(tr.train_one_batch(clone(dev))) for _ in range(5)]
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+    model.eval()
+    gen = model.generate(**clone(dev))
+    assert gen['gen_ids'].shape[0] == 3 and 2 <= gen['gen_ids'].shape[1] <= 101
+
+
 def test_dp_code_path_one_rank_rccl(monkeypatch):
     """Every collective of the data-parallel step (token-count all-reduce, NaN flag, bf16-on-the-wire gradient
     all-reduce on the update stream) through a real 1-rank RCCL group; result == the non-DP trainer up to the

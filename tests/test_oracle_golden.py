@@ -265,3 +265,20 @@ def test_baseline_glove_model(golden):
     lp, ids = model.generate(ins['image'].clone(), ins['caption'].clone(), ins['context_vectors'].clone())
     assert torch.equal(ids, fx['out']['gen_ids'])
     close(lp, fx['out']['gen_log_probs'], atol=1e-4)
+
+
+def test_transformer_glove_model(golden):
+    """TransformerGloveModel (expt/*/2_transformer_glove): loss and bit-exact greedy ids vs the reference."""
+    from oracle.lstm import TransformerGloveModel
+    fx = golden('model_transformer_glove')
+    dec = build_decoder('flattened', article_dim=300, **DEC_KW)
+    model = TransformerGloveModel(dec, AdaptiveLoss(1), _PoolResnet()).eval()
+    own = model.state_dict()
+    model.load_state_dict({k: v for k, v in fx['sd'].items() if k in own}, strict=False)
+    ins = fx['in']
+    out = model(ins['image'].clone(), ins['caption'].clone(), ins['context_vectors'].clone())
+    assert out['sample_size'] == fx['out']['sample_size']
+    close(out['loss'].reshape(1), fx['out']['loss'])
+    lp, ids = model.generate(ins['image'].clone(), ins['caption'].clone(), ins['context_vectors'].clone())
+    assert torch.equal(ids, fx['out']['gen_ids'])
+    close(lp, fx['out']['gen_log_probs'], atol=1e-4)

@@ -90,10 +90,12 @@ __global__ __launch_bounds__(256) void dot_attn_fwd_kernel(const T* src, long s_
   }
 }
 
-// gradient w.r.t. the projected query x only (source_hids are encoder outputs without gradient on this path)
+// gradient w.r.t. the projected query x and, when dsrc != null (weigh_bert: the article states are a trainable mix of
+// the RoBERTa layers), w.r.t. the source states: dsrc[l,b,:] = probs[l,b] dctx[b,:] + dscore[l] x[b,:], contiguous [L,B,D]
 template <typename T>
 __global__ __launch_bounds__(256) void dot_attn_bwd_kernel(const T* src, long s_sl, long s_sb, const float* probs,
-                                                           const T* dctx, T* dx, int L, int B, int D) {
+                                                           const T* dctx, const T* x, T* dx, T* dsrc, int L, int B,
+                                                           int D) {
   __shared__ float ds[DA_MAXL];
   __shared__ float red[4];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -118,6 +120,14 @@ __global__ __launch_bounds__(256) void dot_attn_bwd_kernel(const T* src, long s_
     float acc = 0.f;
     for (int l = 0; l < L; ++l) acc += ds[l] * Elem<T>::ld(src + l * s_sl + b * s_sb + d);
     Elem<T>::st(dx + (long)b * D + d, acc);
+  }
+  if (dsrc) {
+    const T* xb = x + (long)b * D;
+    for (int d = tid; d < D; d += 256) {
+      const float g = Elem<T>::ld(gb + d), xv = Elem<T>::ld(xb + d);
+      for (int l = 0; l < L; ++l)
+        Elem<T>::st(dsrc + ((long)l * B + b) * D + d, probs[(long)l * B + b] * g + ds[l] * xv);
+    }
   }
 }
 
@@ -165,12 +175,13 @@ extern "C" int tell_dot_attn_fwd(const void* src, long src_stride_l, long src_st
 }
 
 extern "C" int tell_dot_attn_bwd(const void* src, long src_stride_l, long src_stride_b, const float* probs,
-                                 const void* dctx, void* dx, int L, int B, int D, int dtype, hipStream_t stream) {
+                                 const void* dctx, const void* x, void* dx, void* dsrc, int L, int B, int D, int dtype,
+                                 hipStream_t stream) {
   if (B <= 0) return TELL_OK;
   TELL_REQUIRE(L >= 1 && L <= DA_MAXL, "dot_attn_bwd: source length must be in 1..1024");
   TELL_REQUIRE(dtype == TELL_BF16 || dtype == TELL_F32, "dot_attn_bwd: bad dtype");
   DISPATCH(dtype, hipLaunchKernelGGL((dot_attn_bwd_kernel<T>), dim3(B), dim3(256), 0, stream, (const T*)src, src_stride_l,
-                                     src_stride_b, probs, (const T*)dctx, (T*)dx, L, B, D));
+                                     src_stride_b, probs, (const T*)dctx, (const T*)x, (T*)dx, (T*)dsrc, L, B, D));
   return tell_check_launch("dot_attn_bwd");
 }
 

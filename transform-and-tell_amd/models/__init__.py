@@ -4,4 +4,4 @@ from .decoders import (Decoder, DecoderLayer, DynamicConvDecoder,  # noqa: F401
 from .transformer import (TransformerFacesObjectModel, TransformerFlattenedModel,  # noqa: F401
                           CaptionModel)
 from .decoder_lstm import LSTMDecoder  # noqa: F401
-from .baseline_glove import BaselineGloveModel  # noqa: F401
+from .baseline_glove import BaselineGloveModel, TransformerGloveModel  # noqa: F401

@@ -108,3 +108,53 @@ class BaselineGloveModel(Model):
                 steps = i + 1
                 break
         return lps[:, :steps], ids[:, :steps + 1]
+
+
+@Model.register('transformer_glove')
+class TransformerGloveModel(CaptionModel):
+    """tell/models/transformer_glove.py (`transformer_glove`, expt/*/2_transformer_glove): the 2-context DynamicConv decoder
+    over ResNet regions and GloVe article vectors.  `_forward` is the baseline's (:161-230, no caption truncation);
+    generation is the transformer models' (projected-K/V cache, static batch, captured decode step)."""
+
+    def __init__(self, vocab, decoder, criterion, evaluate_mode=False, attention_dim=1024, hidden_size=1024, dropout=0.1,
+                 vocab_size=50264, model_name='roberta-base', namespace='bpe', index='roberta', padding_value=1,
+                 use_context=True, sampling_topk=1, sampling_temp=1.0, initializer=None, resnet=None):
+        Model.__init__(self, vocab)
+        self.decoder, self.criterion = decoder, criterion
+        self.index, self.namespace = index, namespace
+        if resnet is None:
+            from .resnet import resnet152
+            resnet = resnet152()
+        self.resnet = resnet
+        self.use_context, self.padding_idx, self.evaluate_mode = use_context, padding_value, evaluate_mode
+        if sampling_topk != 1:
+            raise NotImplementedError('generation is greedy (sampling_topk: 1 in every config)')
+        self.sampling_topk, self.sampling_temp = sampling_topk, sampling_temp
+        self.weigh_bert = False
+        self.max_caption_len = 1 << 30
+        self.n_batches = self.n_samples = 0
+
+    _vectors = staticmethod(BaselineGloveModel._vectors)
+    _glove_forward = BaselineGloveModel._forward
+
+    def forward(self, image, caption, metadata=None, context_vectors=None):
+        ops.hip.require_gpu()
+        caption_ids, target_ids, contexts = self._glove_forward(self._vectors(context_vectors, metadata), image, caption)
+        contexts = {k: v for k, v in contexts.items() if v is not None}
+        ops.rt.wait_weight_update()
+        decoder_out = self.decoder(caption, contexts)
+        loss_sum, sample_size = self.criterion(self.decoder.adaptive_softmax, decoder_out, target_ids)
+        loss = (loss_sum / math.log(2) / sample_size.to(torch.float32)).reshape(())
+        out = {'loss': loss, 'sample_size': sample_size.reshape(())}
+        if not self.training and self.evaluate_mode:
+            _, gen_ids, _ = self._generate(caption_ids, contexts)
+            out['gen_ids'] = gen_ids.cpu().numpy()
+        self.n_samples += caption_ids.shape[0]
+        self.n_batches += 1
+        return out
+
+    def generate(self, image, caption, metadata=None, context_vectors=None, beam_size=1):
+        caption_ids, _, contexts = self._glove_forward(self._vectors(context_vectors, metadata), image, caption)
+        contexts = {k: v for k, v in contexts.items() if v is not None}
+        log_probs, gen_ids, attns = self._generate(caption_ids, contexts, beam_size=beam_size)
+        return {'gen_ids': gen_ids, 'log_probs': log_probs, 'attns': attns}

@@ -224,6 +224,14 @@ class CaptionModel(Model):
     fast_generation = True      # projected-K/V cache + static batch; False = the reference's control flow
 
     def _generate(self, caption_ids, contexts, attn_idx=None, gen_len=100, eos=2, beam_size=1):
+        if not hasattr(self.decoder, 'project_contexts'):
+            # a recurrent decoder behind this model class (expt/*/3_lstm_roberta: `lstm_decoder_flattened`): greedy
+            # decode that carries the LSTM state.  (The reference's loop feeds such a decoder only the last token with
+            # an incremental_state its LSTMDecoder ignores, i.e. every step restarts from the initial state -
+            # transformer_flattened.py:_generate with decoder_flattened_lstm.py:131-152; not reproduced.)
+            from .baseline_glove import BaselineGloveModel
+            lps, ids = BaselineGloveModel._generate(self, caption_ids, contexts, gen_len, eos)
+            return lps, ids, []
         if beam_size > 1:
             return self._generate_beam(caption_ids, contexts, beam_size, gen_len, eos)
         if self.fast_generation:

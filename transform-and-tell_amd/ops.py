@@ -617,23 +617,27 @@ class DotAttnFn(Function):
 
     @staticmethod
     def forward(ctx, x, src, mask):
-        assert src.stride(2) == 1 and not src.requires_grad
+        if src.stride(2) != 1:
+            src = src.contiguous()
         x = x.contiguous()
         L, B, D = src.shape
         out = torch.empty(B, D, dtype=x.dtype, device=x.device)
         probs = torch.empty(L, B, dtype=torch.float32, device=x.device)
         call('tell_dot_attn_fwd', src, src.stride(0), src.stride(1), x, mask, out, probs, L, B, D, hip.dt(x))
-        ctx.save_for_backward(src, probs)
+        ctx.save_for_backward(src, probs, x)
+        ctx.need_dsrc = src.requires_grad
         ctx.mark_non_differentiable(probs)
         return out, probs
 
     @staticmethod
     def backward(ctx, dctx, _dprobs):
-        src, probs = ctx.saved_tensors
+        src, probs, x = ctx.saved_tensors
         L, B, D = src.shape
         dx = torch.empty(B, D, dtype=src.dtype, device=src.device)
-        call('tell_dot_attn_bwd', src, src.stride(0), src.stride(1), probs, dctx.contiguous(), dx, L, B, D, hip.dt(src))
-        return dx, None, None
+        dsrc = torch.empty(L, B, D, dtype=src.dtype, device=src.device) if ctx.need_dsrc else None
+        call('tell_dot_attn_bwd', src, src.stride(0), src.stride(1), probs, dctx.contiguous(), x, dx, dsrc, L, B, D,
+             hip.dt(src))
+        return dx, dsrc, None
 
 
 def dot_attention(x, src, mask):
