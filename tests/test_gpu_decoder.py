@@ -159,7 +159,7 @@ def test_model_loss_and_greedy_generation_golden(golden, dtype, kind):
         got = gen['gen_ids'].cpu()
         if dtype == torch.float32:
             assert got.shape == ref_ids.shape and torch.equal(got, ref_ids), fast    # bit-exact greedy token ids
-            if fast:
+            if fast and tell_amd.graphs.ENABLED:             # (TELL_GRAPHS=0 runs the same steps eagerly)
                 hs = list(model.__dict__.get('_decode_graphs', {}).values())
                 assert hs and all(h['graph'] not in (None, False) for h in hs), [h.get('error') for h in hs]
             close(gen['log_probs'], fx['out']['gen_log_probs'], dtype, atol=2e-4)
