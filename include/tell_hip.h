@@ -45,6 +45,9 @@ uint32_t tell_hash32_host(uint32_t seed, uint32_t salt, uint64_t idx);
  * counter * odd-constant to its salt, so a captured graph draws fresh masks after the owner increments it;
  * NULL (default) = eager behaviour.  The stream argument is ignored (uniform binding signature). */
 int tell_set_rng_step_ptr(const void* counter, tell_stream_t stream);
+/* the same mechanism for the position offset of the embedder (positional.py:170-173 keeps it in incremental_state):
+ * while registered, tell_embed_finalize adds *counter to start_pos - one captured decode step serves every position */
+int tell_set_pos_step_ptr(const void* counter, tell_stream_t stream);
 uint32_t tell_drop_threshold_host(float p);
 
 /* ---- GEMM (every nn.Linear / F.linear / 1x1 conv on the path) --------------
@@ -77,6 +80,10 @@ int tell_gemm_bf16(const void* A, long lda, int trans_a, const void* B, long ldb
 
 /* ---- casts / transposes / weight norm -------------------------------------- */
 int tell_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, tell_stream_t stream);
+/* dst = (dst_dtype)(src * *scale_dev) (scale_dev NULL = 1; dst may alias src for fp32): the fp32 flat gradient on its way
+ * to the data-parallel exchange, weighted by the rank's share of the global token count - what scaling the loss
+ * before backward() does in the eager schedule (new functionality; ref loop callback_apex_trainer.py:208-247) */
+int tell_scale_cast(const float* src, void* dst, int dst_dtype, long n, const float* scale_dev, tell_stream_t stream);
 /* dst_t[c][r] = src[r][c] * row_scale[r]; optional dst_plain[r][c] = same value (either may be NULL) */
 int tell_transpose(const void* src, long ld_src, int src_dtype, void* dst_t, long ld_t, void* dst_plain,
                    long ld_p, int dst_dtype, const float* row_scale, int rows, int cols, tell_stream_t stream);
@@ -215,7 +222,12 @@ int tell_opt_chunk(void);
 int tell_bertadam_step(float* param, float* grad, float* m, float* v, const int* chunk_tensor,
                        const long* chunk_begin, long n_chunks, int n_tensors, float* partial, float* norms,
                        const float* lr_dev, float b1, float b2, float eps, float wd, float max_norm,
-                       float grad_scale, void* shadow_bf16, int zero_grad, tell_stream_t stream);
+                       float grad_scale, void* shadow_bf16, int zero_grad, int* skip, tell_stream_t stream);
+/* skip (int[2], may be NULL): skip[0] != 0 -> the step leaves parameters / moments untouched (gradient still cleared)
+ * and skip[1] counts such steps; tell_loss_flag sets skip[0] = !isfinite(loss) (the NaN-loss skip of
+ * callback_apex_trainer.py:225-227 without a host sync), the norm pass ORs in 2 for a non-finite gradient (what apex
+ * amp O2's overflow check does). */
+int tell_loss_flag(const float* loss, int* skip, tell_stream_t stream);
 
 /* ---- ResNet-152 trunk helpers, tell/models/resnet.py:92-108 (NHWC) ----------- */
 int tell_nchw_to_nhwc(const float* x, void* y, int B, int C, int H, int W, int out_dtype, tell_stream_t stream);

@@ -1,0 +1,189 @@
+"""GPU: the decoder half of the optimisation step replayed as one hipGraph (training/step_graph.py) against the eager
+schedule; the device-side NaN / Inf skip; data-parallel equivalence with one process on the concatenated batch."""
+import copy
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from test_gpu_train import DEV, KW, _no_dropout, _Res, _Rob
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _gpu(monkeypatch):
+    import tell_amd
+    tell_amd.hip.require_gpu()
+    monkeypatch.setenv('TELL_STEP_GRAPH_STRICT', '1')       # a failed capture fails the test instead of going eager
+    yield
+    torch.cuda.synchronize()
+
+
+def _dev(b):
+    return {k: ({kk: vv.to(DEV) for kk, vv in v.items()} if isinstance(v, dict) else v.to(DEV)) for k, v in b.items()}
+
+
+def _clone(x):
+    return {k: (dict(v) if isinstance(v, dict) else v.clone()) for k, v in x.items()}
+
+
+@pytest.mark.parametrize('kind,dtype', [('faces_objects', torch.float32), ('flattened', torch.float32),
+                                        ('faces_objects', torch.bfloat16)])
+def test_step_graph_equals_eager(kind, dtype):
+    """Same model, same batches: trainer A issues every kernel from Python, trainer B replays the captured step.
+    Without dropout the two run the same kernels on the same numbers: losses and weights must agree to rounding of
+    the few atomically accumulated gradients (embedding rows)."""
+    import tell_amd
+    from tell_amd.build import build_model
+    from tell_amd.data import synthetic_batch
+    from tell_amd.training import Trainer
+    tell_amd.set_compute_dtype(dtype)
+    torch.manual_seed(0)
+    adim = 64 if kind == 'flattened' else 1024
+    a = build_model(kind, _Res(True), _Rob(adim), n_bert_layers=3, article_dim=adim, **KW)
+    _no_dropout(a)
+    for m in a.modules():
+        if isinstance(getattr(m, 'dropout', None), float):
+            m.dropout = 0.0
+    b = copy.deepcopy(a)
+    ocfg = dict(lr=5e-3, warmup=0.5, t_total=12, b1=0.9, b2=0.98, e=1e-6, weight_decay=1e-5, max_grad_norm=0.1)
+    ta, tb = Trainer(a, dict(ocfg), device=DEV), Trainer(b, dict(ocfg), device=DEV)
+    ta.step_graph = None
+    batches = [_dev(synthetic_batch(B=3, article_len=20, caption_len=9, faces_objects=(kind == 'faces_objects'),
+                                    vocab=600, cutoffs=(100, 300), seed=60 + s, variable=True)) for s in range(2)]
+    for s in range(7):
+        la = ta.train_one_batch(_clone(batches[s % 2]))
+        lb = tb.train_one_batch(_clone(batches[s % 2]))
+        tol = 1e-6 if dtype == torch.float32 else 1e-3
+        assert abs(float(la) - float(lb)) <= tol * abs(float(la)), (s, float(la), float(lb))
+    assert tb.step_graph.replays == 6 and [e['state'] for e in tb.step_graph.entries.values()] == ['ready']
+    assert tb.optimizer.step_count == ta.optimizer.step_count == 7
+    num = float((ta.flat.flat - tb.flat.flat).norm())
+    assert num <= (1e-6 if dtype == torch.float32 else 2e-3) * float(ta.flat.flat.norm()), num
+    assert float(tb.flat.grad.abs().max()) == 0.0
+    assert b.n_batches == a.n_batches == 7
+
+
+def test_step_graph_draws_fresh_dropout_masks():
+    """lr = 0 keeps the weights fixed: replaying the same batch must still give different losses, because every replay
+    adds the graph's device step counter to the dropout salts."""
+    import tell_amd
+    from tell_amd.build import build_model
+    from tell_amd.data import synthetic_batch
+    from tell_amd.training import Trainer
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    tell_amd.manual_seed(3)
+    torch.manual_seed(3)
+    m = build_model('faces_objects', _Res(True), _Rob(1024), n_bert_layers=3, **KW)
+    tr = Trainer(m, dict(lr=0.0, warmup=-1, t_total=-1, weight_decay=0.0), device=DEV)
+    batch = _dev(synthetic_batch(B=4, article_len=24, caption_len=12, faces_objects=True, vocab=600,
+                                 cutoffs=(100, 300), seed=7))
+    losses = [float(tr.train_one_batch(_clone(batch))) for _ in range(6)]
+    assert tr.step_graph.replays == 5
+    assert len({round(x, 5) for x in losses[1:]}) >= 4, losses
+    assert max(losses) - min(losses) < 0.2 * abs(losses[0]), losses        # same weights: only the masks differ
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_non_finite_step_is_skipped_on_device(graph):
+    """An Inf in the inputs makes loss and gradients non-finite: the optimizer kernel must leave parameters and
+    moments untouched, clear the gradient and count the skip - callback_apex_trainer.py:225-227 without its host
+    sync - and the next finite batch must train normally."""
+    import tell_amd
+    from tell_amd.build import build_model
+    from tell_amd.data import synthetic_batch
+    from tell_amd.training import Trainer
+    tell_amd.set_compute_dtype(torch.float32)
+    torch.manual_seed(1)
+    m = build_model('faces_objects', _Res(True), _Rob(1024), n_bert_layers=3, **KW)
+    _no_dropout(m)
+    tr = Trainer(m, dict(lr=5e-3, warmup=0.5, t_total=12, max_grad_norm=0.1), device=DEV)
+    if not graph:
+        tr.step_graph = None
+    good = _dev(synthetic_batch(B=3, article_len=20, caption_len=9, faces_objects=True, vocab=600, cutoffs=(100, 300),
+                                seed=5))
+    bad = _clone(good)
+    bad['obj_embeds'] = good['obj_embeds'].clone()
+    bad['obj_embeds'][0, 0, :8] = float('inf')
+    for _ in range(2):
+        tr.train_one_batch(_clone(good))
+    w0, m0 = tr.flat.flat.clone(), tr.flat.m.clone()
+    loss = tr.train_one_batch(_clone(bad))
+    assert not torch.isfinite(loss)
+    assert torch.equal(tr.flat.flat, w0) and torch.equal(tr.flat.m, m0)
+    assert float(tr.flat.grad.abs().max()) == 0.0 and tr.skipped_steps() == 1
+    loss = tr.train_one_batch(_clone(good))
+    assert torch.isfinite(loss) and not torch.equal(tr.flat.flat, w0) and tr.skipped_steps() == 1
+    assert bool(torch.isfinite(tr.flat.flat).all())
+
+
+def test_generate_after_training_step_does_not_replay_stale_decode_graph():
+    """The captured decode step bakes in the addresses of weight-derived buffers; after an optimizer step (or a
+    load_state_dict) the next generate() at the same shapes must agree with the eager generator, not with the old
+    weights (round-1 advisor finding)."""
+    import tell_amd
+    from tell_amd import graphs
+    from tell_amd.build import build_model
+    from tell_amd.data import synthetic_batch
+    from tell_amd.training import Trainer
+    tell_amd.set_compute_dtype(torch.float32)
+    torch.manual_seed(2)
+    m = build_model('faces_objects', _Res(True), _Rob(1024), n_bert_layers=3, **KW)
+    _no_dropout(m)
+    tr = Trainer(m, dict(lr=5e-2, warmup=-1, t_total=-1, max_grad_norm=1.0), device=DEV)
+    batch = _dev(synthetic_batch(B=3, article_len=20, caption_len=9, faces_objects=True, vocab=600, cutoffs=(100, 300),
+                                 seed=9))
+
+    def gen(enabled):
+        was = graphs.ENABLED
+        graphs.ENABLED = enabled
+        try:
+            m.eval()
+            out = m.generate(**_clone(batch))
+            m.train()
+            return out['gen_ids'].clone(), out['log_probs'].clone()
+        finally:
+            graphs.ENABLED = was
+    ids0, _ = gen(True)
+    for _ in range(3):
+        tr.train_one_batch(_clone(batch))
+    ids_g, lp_g = gen(True)
+    ids_e, lp_e = gen(False)
+    assert torch.equal(ids_g, ids_e)
+    torch.testing.assert_close(lp_g, lp_e, rtol=1e-5, atol=1e-6)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    for k in sd:
+        if 'decoder.layers.0.fc1.weight_v' in k:
+            sd[k] = sd[k] * 1.5 + 0.01
+    m.load_state_dict(sd)
+    ids_g, lp_g = gen(True)
+    ids_e, lp_e = gen(False)
+    assert torch.equal(ids_g, ids_e)
+    torch.testing.assert_close(lp_g, lp_e, rtol=1e-5, atol=1e-6)
+
+
+def _run_two_ranks(script, env_extra, port):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'TELL_STEP_GRAPH_STRICT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nproc-per-node', '2', '--master-addr',
+                        '127.0.0.1', '--master-port', str(port), os.path.join(root, 'tools', script)],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    return r.returncode, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize('graph', ['0', '1'])
+def test_two_dp_ranks_equal_one_process_on_concatenated_batch(graph):
+    """SURVEY 8e parity target with the HIP Trainer itself (fp32): weights of 2 data-parallel ranks == weights of one
+    process on the concatenated batch after every step, for the eager (bucketed, loss weighted before backward) and
+    the step-graph (gradient weighted on the way to the wire) schedules - tools/dp_equivalence.py."""
+    rc, out = _run_two_ranks('dp_equivalence.py', {'TELL_STEP_GRAPH': graph, 'TELL_ALLREDUCE_FP32': '1'},
+                             29660 + int(graph))
+    assert rc == 0, out[-3000:]
+    assert 'RESULT dp == single' in out, out[-3000:]
+    if graph == '1':
+        assert 'graph replays 4' in out, out[-3000:]

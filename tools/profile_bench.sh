@@ -11,4 +11,4 @@ timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -o $name -- pyth
 cd $root
 grep '^{"metric"' /tmp/prof_$name.log > gpurun_out/${name}_bench.json
 db=$(find /tmp/prof_$name -name '*.db' | head -1)
-python tools/rocprof_summary.py "$db" gpurun_out/${name}_bench_kernel_stats.txt "round 1: python bench.py $args (+ one-time init), 1x MI355X bf16 configs[1], under rocprofv3"
+python tools/rocprof_summary.py "$db" gpurun_out/${name}_bench_kernel_stats.txt "python bench.py $args (+ one-time init), 1x MI355X, under rocprofv3"

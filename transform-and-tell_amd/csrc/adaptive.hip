@@ -109,8 +109,8 @@ extern "C" int tell_embed_finalize(const void* band_out, const int* slot, const 
                                    float scale, int pos_pad, int start_pos, int tbc, int dtype,
                                    hipStream_t stream) {
   if (B * T <= 0) return TELL_OK;
-  if (dtype == TELL_BF16) hipLaunchKernelGGL((embed_finalize_kernel<uint16_t>), dim3(B * T), dim3(256), 0, stream, (const uint16_t*)band_out, slot, ids, pos_table, pos_rows, (uint16_t*)out, B, T, E, scale, pos_pad, start_pos, tbc, g_tell_rng_step);
-  else hipLaunchKernelGGL((embed_finalize_kernel<float>), dim3(B * T), dim3(256), 0, stream, (const float*)band_out, slot, ids, pos_table, pos_rows, (float*)out, B, T, E, scale, pos_pad, start_pos, tbc, g_tell_rng_step);
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((embed_finalize_kernel<uint16_t>), dim3(B * T), dim3(256), 0, stream, (const uint16_t*)band_out, slot, ids, pos_table, pos_rows, (uint16_t*)out, B, T, E, scale, pos_pad, start_pos, tbc, g_tell_pos_step);
+  else hipLaunchKernelGGL((embed_finalize_kernel<float>), dim3(B * T), dim3(256), 0, stream, (const float*)band_out, slot, ids, pos_table, pos_rows, (float*)out, B, T, E, scale, pos_pad, start_pos, tbc, g_tell_pos_step);
   return tell_check_launch("embed_finalize");
 }
 

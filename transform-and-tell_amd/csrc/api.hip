@@ -25,5 +25,13 @@ extern "C" int tell_set_rng_step_ptr(const void* counter, hipStream_t) {
   g_tell_rng_step = static_cast<const uint32_t*>(counter);
   return TELL_OK;
 }
+// position offset of a captured decode step (adaptive.hip embed_finalize): separate from the dropout counter, so that
+// a captured TRAINING step (fresh masks per replay, positions fixed) and a captured DECODE step (position advances per
+// replay) can both exist
+const uint32_t* g_tell_pos_step = nullptr;
+extern "C" int tell_set_pos_step_ptr(const void* counter, hipStream_t) {
+  g_tell_pos_step = static_cast<const uint32_t*>(counter);
+  return TELL_OK;
+}
 extern "C" uint32_t tell_hash32_host(uint32_t seed, uint32_t salt, uint64_t idx) { return tell_hash32(seed, salt, idx); }
 extern "C" uint32_t tell_drop_threshold_host(float p) { return tell_drop_threshold(p); }

@@ -35,6 +35,30 @@ extern "C" int tell_cast(const void* src, int src_dtype, void* dst, int dst_dtyp
   return tell_check_launch("cast");
 }
 
+// dst[i] = (D)(src[i] * *scale): data-parallel gradient exchange - the fp32 gradient goes on the wire (bf16 or fp32,
+// dst may alias src for fp32) weighted by this rank's share of the global token count (training/trainer.py)
+template <typename D>
+__global__ __launch_bounds__(256) void scale_cast_kernel(const float* __restrict__ src, D* __restrict__ dst, long n,
+                                                         const float* __restrict__ scale) {
+  const float sc = scale ? *scale : 1.f;
+  const long nv = n / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(src)[i];
+    Elem<D>::st(dst + 4 * i, v.x * sc); Elem<D>::st(dst + 4 * i + 1, v.y * sc);
+    Elem<D>::st(dst + 4 * i + 2, v.z * sc); Elem<D>::st(dst + 4 * i + 3, v.w * sc);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) Elem<D>::st(dst + nv * 4 + threadIdx.x, src[nv * 4 + threadIdx.x] * sc);
+}
+extern "C" int tell_scale_cast(const float* src, void* dst, int dst_dtype, long n, const float* scale_dev,
+                               hipStream_t stream) {
+  if (n <= 0) return TELL_OK;
+  TELL_REQUIRE(((uintptr_t)src & 15) == 0, "scale_cast: src must be 16-byte aligned");
+  int g = grid_for(n / 4 + 1, 256 * 2);
+  if (dst_dtype == TELL_BF16) hipLaunchKernelGGL((scale_cast_kernel<uint16_t>), dim3(g), dim3(256), 0, stream, src, (uint16_t*)dst, n, scale_dev);
+  else hipLaunchKernelGGL((scale_cast_kernel<float>), dim3(g), dim3(256), 0, stream, src, (float*)dst, n, scale_dev);
+  return tell_check_launch("scale_cast");
+}
+
 // ---------------------------------------------------------------- transpose (+cast, +row scale)
 // dst_t[c][r] = src[r][c] * row_scale[r];  optional dst_plain[r][c] = same value.
 template <typename S, typename D>
@@ -418,9 +442,79 @@ __global__ __launch_bounds__(256) void mix_bwd_kernel(const T* __restrict__ H, c
     partial[(long)blockIdx.x * L + threadIdx.x] =
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
+// 16-byte-chunk variants (L <= 32): every thread owns one chunk position and walks the L layers, so the stack is
+// streamed exactly once with 16 B per lane (HBM-bound: L*n elements read, n written / L*n + n read).
+template <typename T>
+__global__ __launch_bounds__(256) void mix_fwd_vec_kernel(const T* __restrict__ H, const float* __restrict__ w,
+                                                          int L, long n, T* __restrict__ out) {
+  constexpr int VEC = Elem<T>::VEC;
+  __shared__ float sw[64];
+  if (threadIdx.x < 64) {
+    float v = threadIdx.x < L ? w[threadIdx.x] : -INFINITY;
+    float m = wave_max(v);
+    float e = threadIdx.x < L ? __expf(v - m) : 0.f;
+    float s = wave_sum(e);
+    sw[threadIdx.x] = e / s;
+  }
+  __syncthreads();
+  const long nv = n / VEC;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+#pragma unroll 5
+    for (int l = 0; l < L; ++l) {
+      float v[VEC];
+      unpack16(*reinterpret_cast<const uint4*>(H + (long)l * n + i * VEC), v, (const T*)nullptr);
+      const float wl = sw[l];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] += wl * v[k];
+    }
+    *reinterpret_cast<uint4*>(out + i * VEC) = pack16(acc, (const T*)nullptr);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void mix_bwd_vec_kernel(const T* __restrict__ H, const T* __restrict__ dOut,
+                                                          int L, long n, float* __restrict__ partial) {
+  constexpr int VEC = Elem<T>::VEC;
+  __shared__ float red[4][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc[32];
+#pragma unroll
+  for (int l = 0; l < 32; ++l) acc[l] = 0.f;
+  const long nv = n / VEC;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    float d[VEC];
+    unpack16(*reinterpret_cast<const uint4*>(dOut + i * VEC), d, (const T*)nullptr);
+#pragma unroll
+    for (int l = 0; l < 32; ++l) {
+      if (l < L) {
+        float v[VEC];
+        unpack16(*reinterpret_cast<const uint4*>(H + (long)l * n + i * VEC), v, (const T*)nullptr);
+        float a = acc[l];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) a += d[k] * v[k];
+        acc[l] = a;
+      }
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < 32; ++l) {
+    const float a = wave_sum(acc[l]);
+    if (lane == 0) red[wave][l] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < L)
+    partial[(long)blockIdx.x * L + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
 extern "C" int tell_mix_fwd(const void* H, const float* w, int L, long n, void* out, int dtype,
                             hipStream_t stream) {
   TELL_REQUIRE(L >= 1 && L <= 64, "mix_fwd: L must be in [1,64]");
+  if (L <= 32 && n % 8 == 0 && (((uintptr_t)H | (uintptr_t)out) & 15) == 0 && dtype == TELL_BF16) {
+    hipLaunchKernelGGL((mix_fwd_vec_kernel<uint16_t>), dim3(grid_for(n / 8, 256)), dim3(256), 0, stream, (const uint16_t*)H, w, L, n, (uint16_t*)out);
+    return tell_check_launch("mix_fwd_vec");
+  }
   int g = grid_for(n, 256 * 4);
   if (dtype == TELL_BF16) hipLaunchKernelGGL((mix_fwd_kernel<uint16_t>), dim3(g), dim3(256), 0, stream, (const uint16_t*)H, w, L, n, (uint16_t*)out);
   else hipLaunchKernelGGL((mix_fwd_kernel<float>), dim3(g), dim3(256), 0, stream, (const float*)H, w, L, n, (float*)out);
@@ -431,6 +525,10 @@ extern "C" int tell_mix_bwd(const void* H, const void* dOut, int L, long n, floa
                             int n_blocks, int dtype, hipStream_t stream) {
   TELL_REQUIRE(L >= 1 && L <= 64, "mix_bwd: L must be in [1,64]");
   TELL_REQUIRE(n_blocks >= 1, "mix_bwd: n_blocks");
+  if (L <= 32 && n % 8 == 0 && (((uintptr_t)H | (uintptr_t)dOut) & 15) == 0 && dtype == TELL_BF16) {
+    hipLaunchKernelGGL((mix_bwd_vec_kernel<uint16_t>), dim3(n_blocks), dim3(256), 0, stream, (const uint16_t*)H, (const uint16_t*)dOut, L, n, partial);
+    return tell_check_launch("mix_bwd_vec");
+  }
   if (dtype == TELL_BF16) hipLaunchKernelGGL((mix_bwd_kernel<uint16_t>), dim3(n_blocks), dim3(256), 0, stream, (const uint16_t*)H, (const uint16_t*)dOut, L, n, partial);
   else hipLaunchKernelGGL((mix_bwd_kernel<float>), dim3(n_blocks), dim3(256), 0, stream, (const float*)H, (const float*)dOut, L, n, partial);
   return tell_check_launch("mix_bwd");

@@ -28,13 +28,25 @@ __global__ __launch_bounds__(256) void sqsum_chunks_kernel(const float* __restri
 // norms[t] = sqrt(sum of the tensor's chunk partials); one wave per tensor (fixed order -> deterministic)
 __global__ __launch_bounds__(256) void tensor_norms_kernel(const float* __restrict__ partial,
                                                            const long* __restrict__ chunk_begin,
-                                                           int n_tensors, float* __restrict__ norms) {
+                                                           int n_tensors, float* __restrict__ norms,
+                                                           int* __restrict__ skip) {
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (t >= n_tensors) return;
   float s = 0.f;
   for (long c = chunk_begin[t] + lane; c < chunk_begin[t + 1]; c += 64) s += partial[c];
   s = wave_sum(s);
-  if (lane == 0) norms[t] = sqrtf(s);
+  if (lane == 0) {
+    norms[t] = sqrtf(s);
+    if (skip && !(fabsf(s) <= 3.4e38f)) atomicOr(skip, 2);      // NaN / Inf gradient (apex O2 skips such steps)
+  }
+}
+// skip[0] = 1 if the loss is NaN / Inf (callback_apex_trainer.py:225-227 skips the batch), else 0
+__global__ void loss_flag_kernel(const float* __restrict__ loss, int* __restrict__ skip) {
+  skip[0] = (fabsf(loss[0]) <= 3.4e38f) ? 0 : 1;
+}
+extern "C" int tell_loss_flag(const float* loss, int* skip, hipStream_t stream) {
+  hipLaunchKernelGGL(loss_flag_kernel, dim3(1), dim3(1), 0, stream, loss, skip);
+  return tell_check_launch("loss_flag");
 }
 // One pass over the flat buffers: BertAdam update of the fp32 masters, the bf16 working copy the next forward
 // reads (shadow; no per-tensor cast kernels), and the zeroing of the gradient for the next step.
@@ -46,8 +58,15 @@ __global__ __launch_bounds__(256) void bertadam_update_kernel(float* __restrict_
                                                               const float* __restrict__ lr_dev, float b1,
                                                               float b2, float eps, float wd, float max_norm,
                                                               float grad_scale, uint16_t* __restrict__ shadow,
-                                                              int zero_grad) {
+                                                              int zero_grad, int* __restrict__ skip) {
   const float lr = *lr_dev;
+  if (skip && skip[0] != 0) {      // non-finite loss or gradient: leave p, m, v and the shadow alone, only clear the gradient
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skip + 1, 1);          // running count of skipped steps
+    if (zero_grad)
+      for (long c = blockIdx.x; c < n_chunks; c += gridDim.x)
+        reinterpret_cast<float4*>(grad)[c * OPT_CHUNK / 4 + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   for (long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     float coef = grad_scale;
     if (max_norm > 0.f) {
@@ -86,15 +105,16 @@ extern "C" int tell_bertadam_step(float* param, float* grad, float* m, float* v,
                                   const int* chunk_tensor, const long* chunk_begin, long n_chunks,
                                   int n_tensors, float* partial, float* norms, const float* lr_dev,
                                   float b1, float b2, float eps, float wd, float max_norm,
-                                  float grad_scale, void* shadow_bf16, int zero_grad, hipStream_t stream) {
+                                  float grad_scale, void* shadow_bf16, int zero_grad, int* skip,
+                                  hipStream_t stream) {
   if (n_chunks <= 0) return TELL_OK;
   TELL_REQUIRE(((uintptr_t)param & 15) == 0 && ((uintptr_t)grad & 15) == 0, "bertadam: buffers must be 16-byte aligned");
   int g = n_chunks < 4096 ? (int)n_chunks : 4096;
   if (max_norm > 0.f) {
     hipLaunchKernelGGL(sqsum_chunks_kernel, dim3(g), dim3(256), 0, stream, grad, n_chunks, grad_scale, partial);
-    hipLaunchKernelGGL(tensor_norms_kernel, dim3((n_tensors + 3) / 4), dim3(256), 0, stream, partial, chunk_begin, n_tensors, norms);
+    hipLaunchKernelGGL(tensor_norms_kernel, dim3((n_tensors + 3) / 4), dim3(256), 0, stream, partial, chunk_begin, n_tensors, norms, skip);
   }
-  hipLaunchKernelGGL(bertadam_update_kernel, dim3(g), dim3(256), 0, stream, param, grad, m, v, chunk_tensor, norms, n_chunks, lr_dev, b1, b2, eps, wd, max_norm, grad_scale, (uint16_t*)shadow_bf16, zero_grad);
+  hipLaunchKernelGGL(bertadam_update_kernel, dim3(g), dim3(256), 0, stream, param, grad, m, v, chunk_tensor, norms, n_chunks, lr_dev, b1, b2, eps, wd, max_norm, grad_scale, (uint16_t*)shadow_bf16, zero_grad, skip);
   return tell_check_launch("bertadam_step");
 }
 

@@ -40,6 +40,7 @@ class GraphedCall:
 
     def __call__(self, x, key=()):
         """x: the single tensor input; key: extra hashable state the kernel sequence depends on."""
+        self.last_replayed = False          # True: the result just returned lives in a graph-owned static buffer
         if not ENABLED or not x.is_cuda:
             return self.fn(x)
         sig = (tuple(x.shape), x.dtype, x.device.index, key)
@@ -60,6 +61,7 @@ class GraphedCall:
             s['counter'].fill_(e['replays'])            # same stream as the replay: ordered before it
         e['replays'] += 1
         s['graph'].replay()
+        self.last_replayed = True
         return s['static_out']
 
     def _capture(self, e, x):

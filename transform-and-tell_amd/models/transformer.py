@@ -23,6 +23,7 @@ class EncodedBatch:
     def __init__(self):
         self.stack = self.x_image = self.article_mask = None
         self.events = []
+        self.static = False      # stack / x_image are graph-owned static buffers (stable addresses across steps)
 
     def wait(self):
         """Join the producing streams into the current stream (idempotent)."""
@@ -135,6 +136,7 @@ class CaptionModel(Model):
                     image.record_stream(is_)
                     enc.events.append(torch.cuda.Event())
                     enc.events[-1].record(is_)
+                enc.static = self._encoders_replayed()
                 return enc
             side = _side_stream(image.device, 'resnet') if _OVERLAP else None
             enc.article_mask = article_ids == self.padding_idx                         # :347
@@ -152,7 +154,11 @@ class CaptionModel(Model):
                     enc.events[-1].record(side)
             else:
                 enc.x_image = self._run_resnet(image)
+            enc.static = self._encoders_replayed()
             return enc
+
+    def _encoders_replayed(self):
+        return all(getattr(self.__dict__.get(k), 'last_replayed', False) for k in ('_resnet_graph', '_roberta_graph'))
 
     # ---- :311-397 -----------------------------------------------------------------
     def _forward(self, context, image, caption, face_embeds=None, obj_embeds=None, encoded=None):
@@ -300,6 +306,13 @@ class CaptionModel(Model):
         sig = (B, dtype, topk, tuple((n, tuple(kv[0][n][0].shape), tuple(kv[0][n][1].shape)) for n in names),
                dec.embedder.token_embedder_position.weights.data_ptr())
         cache = self.__dict__.setdefault('_decode_graphs', {})
+        # A captured step bakes in the addresses of the working weights (weight-normalised copies, the concatenated
+        # softmax head) that ops._cached rebuilds - at NEW addresses - whenever the weights change (optimizer step,
+        # load_state_dict): every capture belongs to one state of the weights and is dropped with it
+        stamp = (ops.rt.weights_epoch(), sum(p._version for p in dec.parameters()))
+        if self.__dict__.get('_decode_graphs_stamp') != stamp:
+            cache.clear()
+            self.__dict__['_decode_graphs_stamp'] = stamp
         h = cache.get(sig)
         if h is None:
             if len(cache) >= graphs.MAX_SIGNATURES:
@@ -340,11 +353,13 @@ class CaptionModel(Model):
                     g = torch.cuda.CUDAGraph()
                     try:
                         ops.call('tell_set_rng_step_ptr', h['counter'])
+                        ops.call('tell_set_pos_step_ptr', h['counter'])
                         with torch.cuda.graph(g):
                             with ops.hip.bound_stream():
                                 h['out'] = run()
                     finally:
                         ops.call('tell_set_rng_step_ptr', None)
+                        ops.call('tell_set_pos_step_ptr', None)
                     h['graph'], h['base'] = g, 1
                 except Exception as exc:                          # noqa: BLE001 - stay eager for this signature
                     h['graph'], h['error'] = False, repr(exc)

@@ -204,6 +204,13 @@ def clear_weight_cache():
     _wcache.clear()
 
 
+def drop_trainable_cache():
+    """Forget the working copies derived from TRAINABLE parameters (weight-normalised weights, the concatenated
+    softmax head).  The copies of frozen tensors stay: captured encoder graphs hold their addresses."""
+    for k in [k for k, e in _wcache.items() if e[2]() is None or e[2]().requires_grad]:
+        del _wcache[k]
+
+
 def weight(p, rows=None):
     """Working copy [N,K] (compute dtype) of fp32 parameter rows p[r0:r1]."""
     sh = getattr(p, '_tell_shadow', None)

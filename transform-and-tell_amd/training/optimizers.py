@@ -99,13 +99,28 @@ class BertAdam:
             return self.lr * warmup_linear(self.step_count / self.t_total, self.warmup)
         return self.lr
 
-    def step(self, grad_scale=1.0, zero_grad=False):
-        """zero_grad: also clear the gradient buffer (fused into the update pass)."""
-        f = self.flat
+    def step(self, grad_scale=1.0, zero_grad=False, skip=None):
+        """zero_grad: also clear the gradient buffer (fused into the update pass).  skip: device int32[2] flag -
+        a non-zero skip[0] (non-finite loss / gradient) turns the step into gradient zeroing only."""
+        self.prepare()
+        self.launch(grad_scale, zero_grad, skip)
+        self.advance()
+
+    # the three parts of step(), separable so that the kernel launches can live in a captured graph
+    def prepare(self):
+        """Host part before the kernels: this step's learning rate into the device scalar the kernel reads."""
         self.lr_dev.fill_(self.current_lr())
+
+    def launch(self, grad_scale=1.0, zero_grad=False, skip=None):
+        f = self.flat
         hip.call('tell_bertadam_step', f.flat, f.grad, f.m, f.v, f.chunk_tensor, f.chunk_begin, f.n_chunks,
                  len(f.params), f.partial, f.norms, self.lr_dev, self.b1, self.b2, self.e, self.weight_decay,
-                 self.max_grad_norm, float(grad_scale), f.shadow, int(zero_grad))
+                 self.max_grad_norm, float(grad_scale), f.shadow, int(zero_grad), skip)
+
+    def advance(self):
+        """Host part after the kernels.  (A skipped step still advances the schedule by one: the host does not read
+        the device flag; the reference's skipped batches do not reach optimizer.step() - a difference of one
+        warmup/decay tick per non-finite batch out of 437 600.)"""
         self.step_count += 1
         rt.bump_weights_epoch()
 

@@ -1,0 +1,154 @@
+"""The decoder half of the optimisation step - decoder forward, adaptive-softmax loss, backward and (single process)
+BertAdam, callback_apex_trainer.py:208-247 minus the frozen encoders - as ONE hipGraph per shape signature.
+
+Issued kernel by kernel this half is ~900 dependent launches of 5-30 us each (M = T*B = 1024 rows): 22 ms of Python
+per step at BASELINE configs[2] against 27 ms of GPU time, so the host is the bound.  Captured, a step costs the host
+a handful of small copies and one graph launch.
+
+What makes the capture legal:
+  * no host synchronisation anywhere in the step (device-side band compaction, device row counts, the NaN/Inf skip is
+    a device flag read by the optimizer kernel, ops / csrc/optim.hip);
+  * dropout draws fresh masks from the graph's device step counter (tell_set_rng_step_ptr, csrc/common.h);
+  * weight gradients accumulate into the flat fp32 gradient buffer, parameters / moments / the bf16 shadow live in
+    flat static buffers (training/optimizers.py) - every pointer a kernel sees is stable;
+  * the weight-normalised working weights are rebuilt INSIDE the graph (ops._cached runs its makers while capturing);
+  * the learning rate is a device scalar filled before each replay.
+
+Inputs: the outputs of the frozen encoders are consumed in place when they are graph-owned static buffers (the
+encoder GraphedCalls; one capture per buffer slot), copied into static buffers otherwise (stand-in encoders of the
+tests); token ids and the face / object arrays are always copied (small).
+
+Data parallel: the graph ends after backward; the token-count and gradient exchanges and the optimizer stay outside
+(trainer._update).  The per-rank loss weight n_r * world / sum(n) is applied to the gradient on its way to the wire
+(tell_scale_cast) instead of to the loss before backward - the same numbers, gradients are linear in that factor."""
+import os
+
+import torch
+
+from .. import graphs, hip, ops
+from .. import runtime as rt
+
+ENABLED = os.environ.get('TELL_STEP_GRAPH', '1') != '0'
+COPY_LIMIT = 256 << 20          # encoder outputs that are not graph-owned are copied in when smaller than this
+
+
+class StepGraph:
+    def __init__(self, trainer):
+        self.tr = trainer
+        self.entries = {}
+        self.replays = 0
+
+    def reset(self):
+        self.entries.clear()
+
+    # ------------------------------------------------------------------ signature
+    def _plan(self, batch, enc):
+        tr = self.tr
+        model = tr.model
+        idx = model.index
+        if not (ENABLED and graphs.ENABLED) or not hasattr(model, 'encode') or not model.training:
+            return None
+        if tr.async_update or ops._WGRAD['enabled']:       # the opt-in side streams belong to the eager schedule
+            return None
+        cap = batch['caption'][idx]
+        ctx = batch['context'][idx]
+        if not (torch.is_tensor(cap) and cap.is_cuda):
+            return None
+        by_ptr = bool(getattr(enc, 'static', False))
+        big = [enc.stack, enc.x_image]
+        if not all(torch.is_tensor(t) for t in big):
+            return None                                   # a user encoder returned a list: stay eager
+        if not by_ptr and sum(t.numel() * t.element_size() for t in big) > COPY_LIMIT:
+            return None
+        small = {'ctx': ctx, 'cap': cap}
+        for k in ('face_embeds', 'obj_embeds'):
+            if batch.get(k) is not None:
+                small[k] = batch[k]
+        sig = (tuple((k, tuple(v.shape), v.dtype) for k, v in small.items()),
+               tuple((tuple(t.shape), t.dtype, t.data_ptr() if by_ptr else 0) for t in big),
+               by_ptr, rt.compute_dtype(), tr.dp)
+        return sig, small, big, by_ptr
+
+    # ------------------------------------------------------------------ one step
+    def run(self, batch, enc, eager_step):
+        """-> detached loss, or None when this batch cannot go through a graph (caller runs the eager step).
+        eager_step(batch, enc) is the uncaptured step; it runs once per signature (that call also builds every cache
+        the capture relies on), the graph is recorded right after it and replayed from the next call on."""
+        plan = self._plan(batch, enc)
+        if plan is None:
+            return None
+        sig, small, big, by_ptr = plan
+        e = self.entries.get(sig)
+        if e is None:
+            ready = sum(1 for v in self.entries.values() if v['state'] == 'ready')
+            e = self.entries[sig] = {'state': 'eager'}
+            loss = eager_step(batch, enc)
+            if ready < 2 * graphs.MAX_SIGNATURES:
+                self._capture(e, batch, small, big, by_ptr, enc)
+            return loss
+        if e['state'] != 'ready':
+            return None
+        tr = self.tr
+        enc.wait()                                         # the encoder streams join the current stream here
+        for k, v in small.items():
+            e['small'][k].copy_(v)
+        if not by_ptr:
+            for s, t in zip(e['big'], big):
+                s.copy_(t)
+        e['counter'].fill_(e['replays'])
+        e['replays'] += 1
+        self.replays += 1
+        if not tr.dp:
+            tr.optimizer.prepare()
+        e['graph'].replay()
+        model = tr.model
+        model.n_samples += small['cap'].shape[0]
+        model.n_batches += 1
+        if tr.dp:
+            tr._update(n_local=e['sample_size'])
+        else:
+            tr.optimizer.advance()
+        return e['loss'].clone()
+
+    # ------------------------------------------------------------------ capture
+    def _capture(self, e, batch, small, big, by_ptr, enc):
+        from ..models.transformer import EncodedBatch
+        tr = self.tr
+        model = tr.model
+        idx = model.index
+        dev = small['cap'].device
+        st_small = {k: v.clone() for k, v in small.items()}
+        st_big = big if by_ptr else [t.clone() for t in big]
+        counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        saved = (model.n_samples, model.n_batches, tr.optimizer.step_count)
+        g = torch.cuda.CUDAGraph()
+        tr._capturing = True
+        try:
+            ops.drop_trainable_cache()          # working weights of trainable parameters are rebuilt inside the graph
+            hip.call('tell_set_rng_step_ptr', counter)
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                with hip.bound_stream():
+                    encs = EncodedBatch()
+                    encs.stack, encs.x_image = st_big
+                    encs.article_mask = st_small['ctx'] == model.padding_idx
+                    kw = {k: st_small[k] for k in ('face_embeds', 'obj_embeds') if k in st_small}
+                    out = model(context={idx: st_small['ctx']}, image=batch['image'], caption={idx: st_small['cap']},
+                                encoded=encs, **kw)
+                    loss = out['loss']
+                    tr._flag_loss(loss)
+                    tr._backward(loss)
+                    if not tr.dp:
+                        tr.optimizer.launch(grad_scale=1.0, zero_grad=True, skip=tr.skip)
+            e.update(state='ready', graph=g, small=st_small, big=st_big, counter=counter, replays=1,
+                     loss=loss.detach(), sample_size=out['sample_size'])
+        except Exception as exc:                # noqa: BLE001 - any capture problem -> this signature stays eager
+            e['state'] = 'failed'
+            e['error'] = repr(exc)
+            if os.environ.get('TELL_STEP_GRAPH_STRICT') == '1':
+                raise
+        finally:
+            tr._capturing = False
+            hip.call('tell_set_rng_step_ptr', None)
+            model.n_samples, model.n_batches, tr.optimizer.step_count = saved
+            ops.drop_trainable_cache()          # entries made while capturing point into the graph's pool
+            rt.bump_weights_epoch()

@@ -27,9 +27,12 @@ class TrainerBase(Registrable):
 
 class Trainer:
     def __init__(self, model, optimizer_cfg=None, no_grad=(r'^resnet', r'^roberta'), device='cuda',
-                 nan_check=False, bucket_mb=256, async_update=None, allreduce_dtype=None):
+                 nan_check=False, bucket_mb=256, async_update=None, allreduce_dtype=None, data_parallel=None):
+        """nan_check=True: the reference's host-synchronous NaN test (returns None for a skipped batch, no step graph);
+        the default skips non-finite steps on the device instead (self.skip, skipped_steps())."""
         import torch.distributed as dist
-        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        # data_parallel=False: a single-process trainer even though a process group exists (equivalence tests)
+        self.dist = dist if (dist.is_available() and dist.is_initialized() and data_parallel is not False) else None
         self.world = self.dist.get_world_size() if self.dist else 1
         # TELL_DP_SELFTEST=1: run every collective of the data-parallel path even in a 1-rank group (single-GPU check
         # of the RCCL calls, the streams they are issued on and their ordering)
@@ -72,12 +75,24 @@ class Trainer:
         # collective itself runs on RCCL's stream underneath the rest of backward).  Only what is left (embedder / tied
         # adaptive tables, 35 % of the bytes) is exchanged after backward.
         self._ranges, self._reduced, self._pending, self._in_backward = {}, [], [], False
+        self._capturing = False
+        on_gpu = torch.device(device).type == 'cuda'
+        # device-side NaN / Inf skip: [flag, count] read by the optimizer kernel (csrc/optim.hip) - the reference's
+        # skip of a NaN batch (:225-227) and apex O2's overflow skip without a host synchronisation
+        self.skip = torch.zeros(2, dtype=torch.int32, device=device) if on_gpu else None
+        from .step_graph import StepGraph
+        self.step_graph = StepGraph(self) if on_gpu else None
         self.bucketed_reduces = 0
         self._test_reduce_scale = None              # tests: emulate world_size 2 with identical ranks (x2 after a reduce)
-        if self.dp and torch.device(device).type == 'cuda' and os.environ.get('TELL_DP_BUCKETED', '1') != '0':
+        # The bucketed exchange needs Python inside backward, i.e. the eager schedule: it is used when the step graph is
+        # off (TELL_STEP_GRAPH=0); with the graph the exchange follows backward and hides under the next batch's encoders
+        from . import step_graph as _sg
+        bucketed_default = '0' if (_sg.ENABLED and on_gpu) else '1'
+        if self.dp and on_gpu and os.environ.get('TELL_DP_BUCKETED', bucketed_default) != '0':
             self._ranges = self._layer_ranges()
             if self._ranges:
                 rt.set_grad_ready_callback(self._grad_ready)
+                self.step_graph = None                   # the exchange is driven from Python inside backward
 
     def _layer_ranges(self):
         """{prefix: (lo, hi)} - the contiguous slice of the flat buffers that holds exactly the parameters whose name
@@ -95,7 +110,7 @@ class Trainer:
     def _grad_ready(self, tag):
         """Called from the autograd thread (current stream = the stream backward runs on)."""
         rng_ = self._ranges.get(tag)
-        if rng_ is None or not self._in_backward:
+        if rng_ is None or not self._in_backward or self._capturing:
             return
         side = ops.flush_wgrad_stream()              # only with the opt-in weight-gradient stream
         if side is not None:
@@ -129,71 +144,112 @@ class Trainer:
     def _train_one_batch(self, batch, next_batch=None):
         if not self.model.training:              # (recursing through ~650 modules costs 2.5 ms of host time)
             self.model.train()                   # (:214 zero_grad: done right after the previous update)
-        extra = {}
+        enc = None
         if hasattr(self.model, 'encode') and torch.is_tensor(batch.get('image')) and batch['image'].is_cuda:
             enc = self._encoded_for(batch)
             if enc is None:
                 enc = self.model.encode(batch['context'], batch['image'])
-            extra['encoded'] = enc
             if next_batch is not None:
                 self._prefetched = (next_batch['image'],
                                     self.model.encode(next_batch['context'], next_batch['image'], ahead=True))
-        out = self.model(**batch, **extra)                               # :220 / :194
-        loss = out['loss']
-        if self.dp:
-            scaled = loss * dp.loss_weight(out['sample_size'].to(torch.float32).reshape(1), self.dist,
-                                           self.world).reshape(())
-        else:
-            scaled = loss
-        if self.nan_check:                                               # :225-227 (host sync, collective)
-            bad = torch.isnan(loss.detach()).to(torch.float32)
-            if self.dp:
-                self.dist.all_reduce(bad)
-            if bad.item() > 0:
-                return None
+        loss = None
+        if enc is not None and self.step_graph is not None and not self.nan_check:
+            loss = self.step_graph.run(batch, enc, self._eager_step)      # decoder fwd + loss + bwd (+ update) replayed
+        if loss is None:
+            loss = self._eager_step(batch, enc)
+        if loss is not None:
+            self.batch_num_total += 1
+        return loss
+
+    def _flag_loss(self, loss):
+        """skip[0] = the loss is NaN / Inf (:225-227 skips such a batch; here the optimizer kernel does, no host sync)."""
+        if loss.is_cuda:
+            hip.call('tell_loss_flag', loss.detach().reshape(1).float(), self.skip)
+
+    def _backward(self, scaled):
         self._in_backward = True
         try:
             scaled.backward()                                            # :229-231
         finally:
             self._in_backward = False
         ops.join_wgrad_stream()                                          # weight-gradient side stream (ops.py)
+
+    def skipped_steps(self):
+        """Number of optimisation steps the device-side NaN / Inf check turned into no-ops so far (one host sync)."""
+        return int(self.skip[1].item()) if self.skip is not None else 0
+
+    def _eager_step(self, batch, enc=None):
+        extra = {'encoded': enc} if enc is not None else {}
+        out = self.model(**batch, **extra)                               # :220 / :194
+        loss = out['loss']
+        self._flag_loss(loss)
+        n_local = None
+        if self.dp and self._ranges:
+            # bucketed exchange during backward: the per-rank weight has to be in the gradients before the first
+            # bucket leaves, i.e. on the loss
+            scaled = loss * dp.loss_weight(out['sample_size'].to(torch.float32).reshape(1), self.dist,
+                                           self.world).reshape(())
+        else:
+            scaled = loss
+            n_local = out['sample_size'] if self.dp else None
+        if self.nan_check:                                               # :225-227 with the reference's host sync
+            bad = (~torch.isfinite(loss.detach())).to(torch.float32)
+            if self.dp:
+                self.dist.all_reduce(bad)
+            if bad.item() > 0:
+                self.flat.zero_grad()
+                return None
+        self._backward(scaled)
         if self.async_update:
             main = torch.cuda.current_stream()
             self.update_stream.wait_stream(main)
             with torch.cuda.stream(self.update_stream), hip.bound_stream():
-                self._update()
+                self._update(n_local)
                 done = torch.cuda.Event()
                 done.record(self.update_stream)
             rt.set_pending_update(done)
         else:
-            self._update()
-        self.batch_num_total += 1
+            self._update(n_local)
         return loss.detach()
 
-    def _update(self):
+    def _update(self, n_local=None):
+        """Gradient exchange (data parallel) + BertAdam + gradient zeroing.  n_local: this rank's token count when
+        the loss was NOT weighted before backward (graph replay, unbucketed eager): the weight n_local * world /
+        n_global is then applied to the gradient on its way to the wire."""
         if self.dp:
+            scale = None
+            if n_local is not None:
+                scale = dp.loss_weight(n_local.to(torch.float32).reshape(1), self.dist, self.world)
+            if self.skip is not None and self.skip.is_cuda:
+                self.dist.all_reduce(self.skip[:1], op=self.dist.ReduceOp.MAX)        # collective NaN skip (SURVEY 5)
             done, self._reduced = sorted(self._reduced), []
             lo = 0
             for a, b in done + [(self.flat.total, self.flat.total)]:     # everything not exchanged during backward
                 if a > lo:
-                    self._start_reduce(lo, a)
+                    self._start_reduce(lo, a, scale)
                 lo = max(lo, b)
             self._finish_reduces()
-        self.optimizer.step(grad_scale=1.0 / self.world, zero_grad=True)  # :238 (+ :214 of the next batch)
+        self.optimizer.step(grad_scale=1.0 / self.world, zero_grad=True, skip=self.skip)  # :238 (+ :214 of the next batch)
 
     def _cast(self, src, dst):
         hip.call('tell_cast', src, hip.dt(src), dst, hip.dt(dst), src.numel())
 
-    def _start_reduce(self, lo, hi):
-        """Hand flat.grad[lo:hi] to RCCL (asynchronously; bf16 on the wire in bf16 mode, see dp.all_reduce_flat_bf16)."""
+    def _start_reduce(self, lo, hi, scale=None):
+        """Hand flat.grad[lo:hi] to RCCL (asynchronously; bf16 on the wire in bf16 mode, see dp.all_reduce_flat_bf16).
+        scale: optional device scalar multiplied in on the way (the rank's loss weight)."""
         grad = self.flat.grad[lo:hi]
         if self.allreduce_dtype == torch.bfloat16:
             if self._wire is None:
                 self._wire = torch.empty(self.flat.total, dtype=torch.bfloat16, device=self.flat.grad.device)
             buf, step = self._wire[lo:hi], 2 * self.bucket_elems
-            self._cast(grad, buf)
+            hip.call('tell_scale_cast', grad, buf, hip.BF16, grad.numel(), scale)
         else:
             buf, step = grad, self.bucket_elems
+            if scale is not None:
+                if grad.is_cuda:
+                    hip.call('tell_scale_cast', grad, grad, hip.F32, grad.numel(), scale)
+                else:
+                    grad.mul_(scale)
         handles = [self.dist.all_reduce(buf[s:s + step], async_op=True) for s in range(0, buf.numel(), step)]
         self._pending.append((lo, hi, handles))
 
