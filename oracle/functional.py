@@ -115,7 +115,7 @@ def adaptive_embed(ids, cutoffs, emb_weights, proj_weights, scale):
     for i, hi in enumerate(cutoffs):
         m = (ids >= lo) & (ids < hi)
         if m.any():
-            out[m] = F.linear(emb_weights[i][ids[m] - lo], proj_weights[i])
+            out[m] = F.linear(emb_weights[i][ids[m] - lo], proj_weights[i]).to(out.dtype)   # (.to: autocast runs)
         lo = hi
     return out * scale
 
