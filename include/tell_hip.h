@@ -110,6 +110,10 @@ int tell_colsum(const void* x, long ld, int rows, int C, int dtype, float* out, 
 /* F.relu backward (decoder_faces_objects.py:360): dx = dy * (y > 0) */
 int tell_relu_bwd(const void* dy, const void* y, void* dx, long n, int dtype, tell_stream_t stream);
 int tell_axpy(const void* x, void* y, long n, float alpha, int dtype, tell_stream_t stream);
+/* out = x0 + ... + x[n_in-1] (dense, same shape; unused pointers NULL): the gradient fan-in autograd performs with
+ * n-1 pairwise adds where one activation feeds several branches (decoder_faces_objects.py:271-352) */
+int tell_sum_n(const void* x0, const void* x1, const void* x2, const void* x3, const void* x4, const void* x5,
+               const void* x6, const void* x7, int n_in, void* out, long n, int dtype, tell_stream_t stream);
 int tell_fill_f32(float* x, long n, float value, tell_stream_t stream);
 int tell_sum_f32(const float* x, int n, const int* m_dev, float* out, int accumulate, tell_stream_t stream);
 /* X.index_select(0, idx) / inverse, softmax.py:184-189 */

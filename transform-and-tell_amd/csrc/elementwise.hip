@@ -549,6 +549,44 @@ extern "C" int tell_axpy(const void* x, void* y, long n, float alpha, int dtype,
   return tell_check_launch("axpy");
 }
 
+// ---------------------------------------------------------------- out = x0 + x1 + ... (up to 8 dense tensors): gradient fan-in
+// of an activation that feeds several branches (the 4 context attentions + their residuals read the same X,
+// decoder_faces_objects.py:271-352) in ONE pass instead of n-1 pairwise adds
+struct SumNArgs { const void* x[8]; };
+template <typename T>
+__global__ __launch_bounds__(256) void sum_n_kernel(SumNArgs a, int n_in, T* __restrict__ out, long n) {
+  constexpr int VEC = Elem<T>::VEC;
+  const long nv = n / VEC;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < n_in) {
+        float v[VEC];
+        unpack16(*reinterpret_cast<const uint4*>(static_cast<const T*>(a.x[j]) + i * VEC), v, (const T*)nullptr);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] += v[k];
+      }
+    }
+    *reinterpret_cast<uint4*>(out + i * VEC) = pack16(acc, (const T*)nullptr);
+  }
+}
+extern "C" int tell_sum_n(const void* x0, const void* x1, const void* x2, const void* x3, const void* x4,
+                          const void* x5, const void* x6, const void* x7, int n_in, void* out, long n, int dtype,
+                          hipStream_t stream) {
+  if (n <= 0) return TELL_OK;
+  const int vec = dtype == TELL_BF16 ? 8 : 4;
+  TELL_REQUIRE(n_in >= 1 && n_in <= 8 && n % vec == 0, "sum_n: 1..8 inputs, n a multiple of one 16-byte chunk");
+  SumNArgs a = {{x0, x1, x2, x3, x4, x5, x6, x7}};
+  for (int j = 0; j < n_in; ++j) TELL_REQUIRE(a.x[j] && ((uintptr_t)a.x[j] & 15) == 0, "sum_n: inputs must be 16-byte aligned");
+  int g = grid_for(n / vec, 256);
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((sum_n_kernel<uint16_t>), dim3(g), dim3(256), 0, stream, a, n_in, (uint16_t*)out, n);
+  else hipLaunchKernelGGL((sum_n_kernel<float>), dim3(g), dim3(256), 0, stream, a, n_in, (float*)out, n);
+  return tell_check_launch("sum_n");
+}
+
 // ---------------------------------------------------------------- relu backward: dx = dy * (y > 0)
 template <typename T>
 __global__ void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, long n) {

@@ -37,6 +37,7 @@ struct GemmArgs {
   float alpha;            // result = act((acc + bias) * alpha)
   float* asum;            // K-major A only: asum[m] += asum_scale * sum_k A[k][m]  (bias gradient of a wgrad GEMM)
   float asum_scale;
+  int atomic_out;         // fp32 output shared by several workgroups (split K): accumulate with hardware float atomics
   float* stat_mean;       // bf16 NT kernels: per (m-tile, column) mean / M2 of the STORED (bf16-rounded) outputs over
   float* stat_m2;         //   the tile's valid rows, [tiles_m][N] each - the first stage of train-mode BatchNorm
 };
@@ -190,6 +191,13 @@ __device__ __forceinline__ void gemm_epilogue_act(f32x16 (&acc)[MI][NI], const G
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
           }
+          if constexpr (std::is_same<OutT, float>::value) {
+            if (p.atomic_out) {                                     // block-uniform
+#pragma unroll
+              for (int e = 0; e < 4; ++e) unsafeAtomicAdd(reinterpret_cast<float*>(dst) + e, v[e]);
+              continue;
+            }
+          }
           if (p.accumulate) v += Vec4<OutT>::ld(dst);
           Vec4<OutT>::st(dst, v);
         } else {
@@ -198,6 +206,9 @@ __device__ __forceinline__ void gemm_epilogue_act(f32x16 (&acc)[MI][NI], const G
             if (n + e < N) {
               float x = v[e];
               if constexpr (ACT == 3) x = Elem<OutT>::ld(aux + (long)m * p.ldc + n + e) > 0.f ? x : 0.f;
+              if constexpr (std::is_same<OutT, float>::value) {
+                if (p.atomic_out) { unsafeAtomicAdd(reinterpret_cast<float*>(dst) + e, x); continue; }
+              }
               if (p.accumulate) x += Elem<OutT>::ld(dst + e);
               Elem<OutT>::st(dst + e, x);
             }
@@ -850,7 +861,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tx_kernel(Gemm
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   int M = p.M;
   if (p.m_dev) { int md = *p.m_dev; M = md < M ? md : M; }
-  const int N = p.N, K = p.K;
+  const int N = p.N;
+  // split K (gridDim.y > 1): this workgroup reduces rows [kb, K) of its slice only and adds its partial tile to the
+  // fp32 output with float atomics (p.atomic_out)
+  const int kper = ((p.K + BK - 1) / BK + gridDim.y - 1) / gridDim.y * BK;
+  const int kb = blockIdx.y * kper;
+  const int K = p.K < kb + kper ? p.K : kb + kper;
+  if (kb >= K) return;
   const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
   int tile_id;
   {
@@ -886,20 +903,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tx_kernel(Gemm
     _Pragma("unroll") for (int i = 0; i < CHA; ++i) {                                              \
       const int c = tid + i * NT, row = c / CPA, ch = c % CPA;                                     \
       if constexpr (TA) {                                                                          \
-        const int gk = (KT) * BK + row, gm = m0 + ch * 8;                                          \
+        const int gk = kb + (KT) * BK + row, gm = m0 + ch * 8;                                          \
         ra[S][i] = *reinterpret_cast<const u32x4*>(A + (long)(gk < K ? gk : 0) * p.lda + (gm < M ? gm : 0)); \
       } else {                                                                                     \
-        const int gm = m0 + row, gk = (KT) * BK + ch * 8;                                          \
+        const int gm = m0 + row, gk = kb + (KT) * BK + ch * 8;                                          \
         ra[S][i] = *reinterpret_cast<const u32x4*>(A + (long)(gm < M ? gm : M - 1) * p.lda + (gk < K ? gk : 0)); \
       }                                                                                            \
     }                                                                                              \
     _Pragma("unroll") for (int i = 0; i < CHB; ++i) {                                              \
       const int c = tid + i * NT, row = c / CPB, ch = c % CPB;                                     \
       if constexpr (TB) {                                                                          \
-        const int gk = (KT) * BK + row, gn = n0 + ch * 8;                                          \
+        const int gk = kb + (KT) * BK + row, gn = n0 + ch * 8;                                          \
         rb[S][i] = *reinterpret_cast<const u32x4*>(B + (long)(gk < K ? gk : 0) * p.ldb + (gn < N ? gn : 0)); \
       } else {                                                                                     \
-        const int gn = n0 + row, gk = (KT) * BK + ch * 8;                                          \
+        const int gn = n0 + row, gk = kb + (KT) * BK + ch * 8;                                          \
         rb[S][i] = *reinterpret_cast<const u32x4*>(B + (long)(gn < N ? gn : N - 1) * p.ldb + (gk < K ? gk : 0)); \
       }                                                                                            \
     }                                                                                              \
@@ -908,7 +925,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tx_kernel(Gemm
   {                                                                                                \
     _Pragma("unroll") for (int i = 0; i < CHA; ++i) {                                              \
       const int c = tid + i * NT, row = c / CPA, ch = c % CPA;                                     \
-      const bool ok = TA ? ((KT) * BK + row) < K : ((m0 + row) < M && ((KT) * BK + ch * 8) < K);   \
+      const bool ok = TA ? (kb + (KT) * BK + row) < K : ((m0 + row) < M && (kb + (KT) * BK + ch * 8) < K);   \
       const u32x4 va = ok ? ra[S][i] : zero4;                                                      \
       *reinterpret_cast<u32x4*>(As[BUF] + row * SA + ch * 8) = va;                                 \
       if (want_asum) {                                                                             \
@@ -920,7 +937,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tx_kernel(Gemm
     }                                                                                              \
     _Pragma("unroll") for (int i = 0; i < CHB; ++i) {                                              \
       const int c = tid + i * NT, row = c / CPB, ch = c % CPB;                                     \
-      const bool ok = TB ? ((KT) * BK + row) < K : ((n0 + row) < N && ((KT) * BK + ch * 8) < K);   \
+      const bool ok = TB ? (kb + (KT) * BK + row) < K : ((n0 + row) < N && (kb + (KT) * BK + ch * 8) < K);   \
       *reinterpret_cast<u32x4*>(Bs[BUF] + row * SB + ch * 8) = ok ? rb[S][i] : zero4;              \
     }                                                                                              \
   }
@@ -954,7 +971,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tx_kernel(Gemm
     TX_SSTORE(((S) + 1) % PF, ((S) + 1) & 1, kt + 1)                                               \
     __syncthreads();                                                                               \
   }
-  const int nk = (K + BK - 1) / BK;
+  const int nk = (K - kb + BK - 1) / BK;
   const int nk_pad = (nk + PF - 1) / PF * PF;
   TX_GLOAD(0, 0)
   TX_GLOAD(1, 1)
@@ -988,7 +1005,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tx_kernel(Gemm
         const int ch = tid >> 3, e = tid & 7;
         float s = 0.f;
         for (int t = ch; t < NT; t += CPA) s += red[t * 9 + e];
-        p.asum[m0 + tid] += p.asum_scale * s;
+        if (gridDim.y > 1) unsafeAtomicAdd(p.asum + m0 + tid, p.asum_scale * s);
+        else p.asum[m0 + tid] += p.asum_scale * s;
       }
     }
   }
@@ -996,8 +1014,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tx_kernel(Gemm
 }
 
 template <typename OutT, bool TA, bool TB>
-static int launch_gemm_tx(const GemmArgs& a, hipStream_t stream) {
+static int launch_gemm_tx(const GemmArgs& a_in, hipStream_t stream) {
+  GemmArgs a = a_in;
   auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+  static const int split_env = getenv("TELL_GEMM_SPLITK") ? atoi(getenv("TELL_GEMM_SPLITK")) : -1;   // tuning aid: 0 = off
+  if constexpr (std::is_same<OutT, float>::value) {
+    // Opt-in (TELL_GEMM_SPLITK=n): long reductions into a small fp32 output that is accumulated anyway (weight gradients
+    // of the context K/V projections: K = S*B = 16384 rows into [2048, 1024]) split over gridDim.y, partial tiles added
+    // with float atomics.  Measured on MI355X it LOSES: 216 us against 139 us for the plain 64x64-tile launch of that
+    // shape (6.3 M L2 atomics), so it stays off by default.
+    const long t128 = tiles(128, 128);
+    if (a.accumulate && !a.m_dev && a.act == 0 && a.bias_mode == 0 && t128 < 256 && a.K >= 2048 && split_env > 0) {
+      int splits = (int)((384 + t128 - 1) / t128);
+      while (splits > 1 && a.K / splits < 1024) --splits;
+      if (split_env > 0) splits = split_env;
+      if (splits > 1) {
+        a.atomic_out = 1;
+        hipLaunchKernelGGL((gemm_tx_kernel<OutT, 128, 128, 2, 2, TA, TB, 2>), dim3((unsigned)t128, (unsigned)splits), dim3(256), 0, stream, a);
+        return tell_check_launch("gemm_tx_splitk");
+      }
+    }
+  }
   if (tiles(128, 128) >= 256)
     hipLaunchKernelGGL((gemm_tx_kernel<OutT, 128, 128, 2, 2, TA, TB, 2>), dim3((unsigned)tiles(128, 128)), dim3(256), 0, stream, a);
   else   // few workgroups, latency bound: 4 K tiles in flight
@@ -1097,7 +1134,7 @@ extern "C" int tell_gemm_nt(const void* A, long lda, const void* B, long ldb, vo
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux; a.m_dev = m_dev;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
   a.bias_mode = bias_mode; a.act = act; a.accumulate = accumulate; a.alpha = alpha;
-  a.asum = nullptr; a.asum_scale = 0.f; a.stat_mean = nullptr; a.stat_m2 = nullptr;
+  a.asum = nullptr; a.asum_scale = 0.f; a.stat_mean = nullptr; a.stat_m2 = nullptr; a.atomic_out = 0;
   if (in_dtype == TELL_BF16)
     return out_dtype == TELL_BF16 ? launch_gemm<uint16_t, uint16_t>(a, stream)
                                   : launch_gemm<uint16_t, float>(a, stream);
@@ -1143,7 +1180,7 @@ extern "C" int tell_gemm_bf16(const void* A, long lda, int trans_a, const void* 
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux; a.m_dev = m_dev;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
   a.bias_mode = bias_mode; a.act = act; a.accumulate = accumulate; a.alpha = alpha;
-  a.asum = a_colsum; a.asum_scale = a_colsum_scale; a.stat_mean = nullptr; a.stat_m2 = nullptr;
+  a.asum = a_colsum; a.asum_scale = a_colsum_scale; a.stat_mean = nullptr; a.stat_m2 = nullptr; a.atomic_out = 0;
   if (trans_a && trans_b)
     return out_dtype == TELL_BF16 ? launch_gemm_tx<uint16_t, true, true>(a, stream) : launch_gemm_tx<float, true, true>(a, stream);
   if (trans_b)
@@ -1168,7 +1205,7 @@ extern "C" int tell_gemm_bn_stats(const void* A, long lda, const void* B, long l
   GemmArgs a;
   a.A = A; a.B = B; a.C = C; a.bias = nullptr; a.aux = nullptr; a.m_dev = nullptr;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
-  a.bias_mode = 0; a.act = 0; a.accumulate = 0; a.alpha = 1.f; a.asum = nullptr; a.asum_scale = 0.f;
+  a.bias_mode = 0; a.act = 0; a.accumulate = 0; a.alpha = 1.f; a.asum = nullptr; a.asum_scale = 0.f; a.atomic_out = 0;
   const long max_tiles = ((long)M + 63) / 64;
   a.stat_mean = workspace;
   a.stat_m2 = workspace + max_tiles * N;

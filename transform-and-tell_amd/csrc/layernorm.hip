@@ -281,20 +281,32 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
   for (int c = threadIdx.x; c < 2 * C; c += 256) out[c] = s[c] + s[2 * C + c] + s[4 * C + c] + s[6 * C + c];
 }
 
-// 64 columns x 4 partial-groups per block: coalesced reads, 4 independent chains per column, LDS combine
-__global__ __launch_bounds__(256) void ln_bwd_finish_kernel(const float* __restrict__ partial, int n_blocks, int C,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int accumulate) {
-  __shared__ float sm[4][64];
+// 64 columns x 16 partial-groups per block (1024 threads): coalesced reads, every thread keeps 4 independent loads in
+// flight, LDS combine.  (4 groups of serial dependent loads cost 20 us per LayerNorm at 256 partial rows.)
+__global__ __launch_bounds__(1024) void ln_bwd_finish_kernel(const float* __restrict__ partial, int n_blocks, int C,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             int accumulate) {
+  __shared__ float sm[16][64];
   const int cx = threadIdx.x & 63, by = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cx;
-  float s = 0.f;
-  if (c < 2 * C)
-    for (int b = by; b < n_blocks; b += 4) s += partial[(long)b * 2 * C + c];
-  sm[by][cx] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < 2 * C) {
+    const long ld = 2L * C;
+    int b = by;
+    for (; b + 48 < n_blocks; b += 64) {
+      s0 += partial[(long)b * ld + c];
+      s1 += partial[(long)(b + 16) * ld + c];
+      s2 += partial[(long)(b + 32) * ld + c];
+      s3 += partial[(long)(b + 48) * ld + c];
+    }
+    for (; b < n_blocks; b += 16) s0 += partial[(long)b * ld + c];
+  }
+  sm[by][cx] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (by == 0 && c < 2 * C) {
-    s = sm[0][cx] + sm[1][cx] + sm[2][cx] + sm[3][cx];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += sm[k][cx];
     float* dst = c < C ? dgamma + c : dbeta + (c - C);
     *dst = accumulate ? *dst + s : s;
   }
@@ -333,6 +345,6 @@ extern "C" int tell_layernorm_bwd(const void* dy, long ld_dy, const void* x, lon
   int rc = tell_check_launch("layernorm_bwd");
   if (rc) return rc;
 #undef LNB
-  hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, stream, partial, nb, C, dgamma, dbeta, dparam_accumulate);
+  hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, stream, partial, nb, C, dgamma, dbeta, dparam_accumulate);
   return tell_check_launch("layernorm_bwd_finish");
 }

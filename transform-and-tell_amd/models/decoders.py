@@ -92,16 +92,28 @@ class DynamicConvDecoderLayer(DecoderLayer):
         X = self._post(self.conv_layer_norm, h, res)
 
         attns, outs = {}, []
-        for name in self.context_names:                                   # :271-352
+        fused = not self.normalize_before and X.is_cuda     # post-LN layers (every expt/ config): LN_c writes its slice
+        nctx = len(self.context_names)
+        if fused and torch.is_grad_enabled() and X.requires_grad:
+            # X feeds the n query projections and (once) the residuals of the n LayerNorms: one fan-in kernel in backward
+            handles = ops.fan_out(X, nctx + 1)
+        else:
+            handles = (X,) * (nctx + 1)
+        for i, name in enumerate(self.context_names):                     # :271-352
             a, w = self.context_attns[name](
-                self._pre(self.context_attn_lns[name], X), contexts[name], contexts[name],
+                self._pre(self.context_attn_lns[name], handles[i]), contexts[name], contexts[name],
                 key_padding_mask=contexts[name + '_mask'], need_weights=(not tr and self.need_attn),
                 key_t=None if contexts_t is None else contexts_t.get(name),
                 kv=None if kv is None else kv[name])
-            outs.append(self._post(self.context_attn_lns[name], a, X))
+            outs.append(a if fused else self._post(self.context_attn_lns[name], a, X))
             if w is not None:
                 attns[name] = w.cpu().numpy()
-        X = self.context_fc(torch.cat(outs, dim=-1))                       # :354-355
+        if fused:
+            cat = ops.layer_norm_cat(outs, handles[nctx], [self.context_attn_lns[n] for n in self.context_names],
+                                     self.dropout, tr)
+        else:
+            cat = torch.cat(outs, dim=-1)
+        X = self.context_fc(cat)                                          # :354-355
 
         res = X                                                            # :357-364
         h = self.fc1(self._pre(self.final_layer_norm, X), act=1)
@@ -172,6 +184,12 @@ class _DynamicConvDecoderBase(Decoder):
                         contexts_t[name] = ops.transpose(ops.as2d(src))[0]
                 contexts['_transposed'] = contexts_t
         attns, inner_states = [], [X]
+        if X.is_cuda:                        # key-padding masks as the uint8 the attention kernels read: once, not per layer
+            contexts = dict(contexts)
+            for name, _ in self.CONTEXTS:
+                m = contexts.get(name + '_mask')
+                if torch.is_tensor(m) and m.dtype == torch.bool:
+                    contexts[name + '_mask'] = m.to(torch.uint8).contiguous()
         for i, layer in enumerate(self.layers):
             if not use_layers or i in use_layers:
                 X = ops.grad_ready_marker(X, 'decoder.layers.%d.' % i)    # DP: layer i's gradients are final here

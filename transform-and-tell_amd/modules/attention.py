@@ -67,6 +67,17 @@ class MultiHeadAttention(nn.Module):
             k, v = k.transpose(0, 1), v.transpose(0, 1)
         return k, v
 
+    def project_kv_packed(self, key):
+        """K and V of a (non-empty) context as ONE projection [S,B,2E] (ops.kv_linear): half the launches, twice the
+        N of the GEMMs forward and backward; the attention kernels read the halves through their strides."""
+        E = self.embed_dim
+        bm = key.transpose(0, 1)
+        src = bm if (bm.is_contiguous() and not key.is_contiguous()) else key.contiguous()
+        wk, rk = self._wrows(1)
+        wv, rv = self._wrows(2)
+        kv = ops.kv_linear(src, wk, rk, wv, rv, self.in_proj_bias, E)
+        return kv.transpose(0, 1) if src is bm else kv
+
     def forward(self, query, key, value=None, key_padding_mask=None, incremental_state=None,
                 need_weights=True, static_kv=True, attn_mask=None, key_t=None, kv=None):
         """kv: optional (k, v) already projected by `project_kv` - the contexts are static during
@@ -76,10 +87,18 @@ class MultiHeadAttention(nn.Module):
         assert E == self.embed_dim
         wq, rq = self._wrows(0)
         q = ops.linear(query, wq, self.in_proj_bias, rows=rq, b_rows=(0, E), alpha=self.scaling)  # :348-353
-        k, v = kv if kv is not None else self.project_kv(key, key_t)
+        packed = None
+        if kv is None and ops.rt.compute_dtype() == torch.bfloat16 and key.shape[0] > 0 and key.shape[2] > 0 \
+                and torch.is_grad_enabled():
+            packed = self.project_kv_packed(key)          # training: K and V as one [S,B,2E] projection
+            k = v = packed
+        else:
+            k, v = kv if kv is not None else self.project_kv(key, key_t)
         mask = None
         if key_padding_mask is not None and k.shape[0] > 0:
-            mask = key_padding_mask.to(torch.uint8).contiguous()
+            # (the decoder converts every context mask once per step - 4 layers share it)
+            mask = key_padding_mask if key_padding_mask.dtype == torch.uint8 else \
+                key_padding_mask.to(torch.uint8).contiguous()
         beams = 1
         if kv is not None and T == 1 and k.shape[0] > 0 and B != k.shape[1] and B % k.shape[1] == 0:
             # beam search: the n hypotheses of a sample (rows b*n + j) attend to the SAME static context, so they are
@@ -87,8 +106,10 @@ class MultiHeadAttention(nn.Module):
             # once per hypothesis (cross-attention has no causal mask, so query positions are independent)
             beams = B // k.shape[1]
             q = q.view(k.shape[1], beams, E).transpose(0, 1)                      # [n, B/n, E] strided view
-        attn, lse = ops.attention(q, k, v, mask, self.bias_k, self.bias_v, self.num_heads, self.add_zero_attn,
-                                  self.dropout, self.training, return_lse=True)
+        attn, lse = ops.attention(q, k, None if packed is not None else v, mask, self.bias_k, self.bias_v,
+                                  self.num_heads, self.add_zero_attn, self.dropout, self.training, return_lse=True)
+        if packed is not None:
+            k = packed[..., :E]
         if beams > 1:
             assert not need_weights
             attn = attn.transpose(0, 1).reshape(1, B, E)

@@ -416,6 +416,70 @@ def linear(x, w_param, b_param=None, rows=None, act=0, alpha=1.0, x_t=None, b_ro
     return LinearFn.apply(x, w_param, b_param, rows, act, alpha, x.requires_grad, x_t, b_rows)
 
 
+
+def _adjacent(a, b):
+    """b starts where a ends (same dtype, both dense): the two live back to back in one flat buffer."""
+    return (a is not None and b is not None and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous() and
+            a.data_ptr() + a.numel() * a.element_size() == b.data_ptr() and
+            a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr())
+
+
+def _stacked(a, b):
+    """[rows_a + rows_b, C] view over two adjacent [rows, C] tensors (no copy)."""
+    C = a.shape[-1]
+    return torch.as_strided(a, (a.numel() // C + b.numel() // C, C), (C, 1))
+
+
+class KVLinearFn(Function):
+    """K and V projections of one context (multi_head.py:500-518) as ONE GEMM with N = 2E:
+    kv[rows, 0:E] = x Wk^T + b_k, kv[rows, E:2E] = x Wv^T + b_v.  The two weights (slices E:3E of in_proj_weight, or
+    k_proj_weight / v_proj_weight, which the flat parameter buffer stores back to back) are used as one [2E, kdim]
+    operand; so are their gradients.  bf16 path (the fp32 parity mode keeps the two plain projections)."""
+
+    @staticmethod
+    def forward(ctx, x, wk, rk, wv, rv, b_param, E, need_dx):
+        x2 = as2d(x)
+        a, b = weight(wk, rk), weight(wv, rv)
+        w = _stacked(a, b) if _adjacent(a, b) else _cached(wk, ('kv', rk, id(wv), wv._version), lambda: torch.cat([a, b], 0))
+        bias = b_param.detach()[E:3 * E]
+        y = gemm(x2, w, bias=bias, bias_mode=1)
+        ctx.save_for_backward(x2)
+        ctx.meta = (wk, rk, wv, rv, b_param, E, need_dx, x.shape, w)
+        return y.view(*x.shape[:-1], 2 * E)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, = ctx.saved_tensors
+        wk, rk, wv, rv, b_param, E, need_dx, xshape, w = ctx.meta
+        dy2 = as2d(dy)
+        gb = grad_buffer(b_param)[E:3 * E] if b_param.requires_grad else None
+        if wk.requires_grad:
+            def rows_of(p, r):
+                g = grad_buffer(p)
+                g = g.view(g.shape[0], -1)
+                return g if r is None else g[r[0]:r[1]]
+            gk, gv = rows_of(wk, rk), rows_of(wv, rv)
+
+            def job(gb=gb):
+                if _adjacent(gk, gv):
+                    gemm_tn(dy2, x2, out=_stacked(gk, gv), accumulate=True, asum=gb)
+                else:
+                    gemm_tn(dy2[:, :E], x2, out=gk, accumulate=True, asum=None if gb is None else gb[:E])
+                    gemm_tn(dy2[:, E:], x2, out=gv, accumulate=True, asum=None if gb is None else gb[E:])
+            wgrad_job(job, dy2, x2)
+        elif gb is not None:
+            colsum_into(dy2, gb)
+        dx = None
+        if need_dx:
+            dx = gemm_nn(dy2, w)
+            dx = dx.reshape(xshape) if dx.is_contiguous() else dx.contiguous().view(xshape)
+        return dx, None, None, None, None, None, None, None
+
+
+def kv_linear(x, wk, rk, wv, rv, b_param, E):
+    return KVLinearFn.apply(x, wk, rk, wv, rv, b_param, E, x.requires_grad)
+
+
 class WNLinearFn(Function):
     """GehringLinear (tell/modules/linear.py:8-33): y = act(x (g v/||v||)^T + b)."""
 
@@ -464,6 +528,39 @@ def wn_linear(x, g, v, b=None, act=0):
 # --------------------------------------------------------------------------- #
 # elementwise
 # --------------------------------------------------------------------------- #
+class FanOutFn(Function):
+    """x -> n aliases of x; backward adds the n incoming gradients in one kernel (autograd would issue n-1 adds)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g for g in grads if g is not None]
+        if len(gs) == 1:
+            return gs[0], None
+        gs = [g if g.is_contiguous() else g.contiguous() for g in gs]
+        vec = _vec(gs[0].dtype)
+        if len(gs) > 8 or gs[0].numel() % vec or any(g.data_ptr() % 16 for g in gs) or not gs[0].is_cuda:
+            out = gs[0]
+            for g in gs[1:]:
+                out = out + g
+            return out, None
+        out = torch.empty_like(gs[0])
+        ptrs = gs + [None] * (8 - len(gs))
+        call('tell_sum_n', *ptrs, len(gs), out, out.numel(), hip.dt(out))
+        return out, None
+
+
+def fan_out(x, n):
+    """n handles on x for n consumers (see FanOutFn); plain aliases when no gradient is needed."""
+    if n <= 1 or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * n
+    return FanOutFn.apply(x, n)
+
+
 class GLUFn(Function):
     @staticmethod
     def forward(ctx, h):
@@ -556,6 +653,60 @@ class LayerNormFn(Function):
 def layer_norm(x, res, gamma, beta, eps=1e-5, p=0.0, training=False):
     p = p if training else 0.0
     return LayerNormFn.apply(x, res, gamma, beta, eps, p, rt.next_salt() if p > 0 else 0)
+
+
+class LNCatFn(Function):
+    """cat_i LayerNorm_i(res + dropout(x_i)) along the feature axis: the n context branches of a decoder layer
+    (decoder_faces_objects.py:283-352) write their normalised outputs straight into the [rows, n*C] input of
+    context_fc (:354, no torch.cat), and in backward the n residual gradients are accumulated into ONE buffer by the
+    LayerNorm kernels themselves (no pairwise adds)."""
+
+    @staticmethod
+    def forward(ctx, res, eps, p, salts, n, *args):
+        xs, gammas, betas = args[:n], args[n:2 * n], args[2 * n:3 * n]
+        r2 = as2d(res)
+        rows, C = r2.shape
+        cat = torch.empty(rows, n * C, dtype=res.dtype, device=res.device)
+        mean = torch.empty(n, rows, dtype=torch.float32, device=res.device)
+        rstd = torch.empty(n, rows, dtype=torch.float32, device=res.device)
+        x2s = [as2d(x) for x in xs]
+        for i in range(n):
+            y = cat[:, i * C:(i + 1) * C]
+            call('tell_layernorm_fwd', x2s[i], x2s[i].stride(0), r2, r2.stride(0), gammas[i].detach(), betas[i].detach(),
+                 y, y.stride(0), mean[i], rstd[i], rows, C, float(eps), float(p), rt.seed(), salts[i], hip.dt(r2))
+        ctx.save_for_backward(r2, mean, rstd, *x2s)
+        ctx.meta = (gammas, betas, p, salts, n, res.shape, res.requires_grad, [x.requires_grad for x in xs])
+        return cat.view(*res.shape[:-1], n * C)
+
+    @staticmethod
+    def backward(ctx, dcat):
+        r2, mean, rstd = ctx.saved_tensors[:3]
+        x2s = ctx.saved_tensors[3:]
+        gammas, betas, p, salts, n, shape, need_dres, need_dx = ctx.meta
+        rows, C = r2.shape
+        d2 = as2d(dcat)
+        nb = hip.lib().tell_layernorm_bwd_blocks(rows)
+        dres = torch.empty_like(r2) if need_dres else None
+        dxs = []
+        for i in range(n):
+            dy = d2[:, i * C:(i + 1) * C]
+            partial = torch.empty(nb * 2 * C, dtype=torch.float32, device=r2.device)
+            dx = torch.empty_like(x2s[i]) if need_dx[i] else None
+            call('tell_layernorm_bwd', dy, dy.stride(0), x2s[i], x2s[i].stride(0), r2, r2.stride(0),
+                 gammas[i].detach(), mean[i], rstd[i], dx, dx.stride(0) if dx is not None else 0,
+                 dres, dres.stride(0) if dres is not None else 0, int(i > 0),
+                 grad_buffer(gammas[i]), grad_buffer(betas[i]), 1, partial, rows, C, float(p), rt.seed(), salts[i],
+                 hip.dt(r2))
+            dxs.append(dx.view(shape) if dx is not None else None)
+        return (dres.view(shape) if dres is not None else None, None, None, None, None, *dxs) + (None,) * (2 * n)
+
+
+def layer_norm_cat(xs, res, lns, p=0.0, training=False):
+    """[LN_i(res + dropout(x_i))]_i concatenated on the last axis; lns: the nn.LayerNorm modules."""
+    p = p if training else 0.0
+    n = len(xs)
+    salts = tuple(rt.next_salt() if p > 0 else 0 for _ in range(n))
+    return LNCatFn.apply(res, lns[0].eps, p, salts, n, *xs, *[ln.weight for ln in lns], *[ln.bias for ln in lns])
 
 
 # --------------------------------------------------------------------------- #
@@ -721,13 +872,21 @@ def _bias_row(p, dtype):
 
 class AttnFn(Function):
     """softmax(q k^T + mask) v with the virtual bias_k/bias_v row and zero row.
-    q: [T,B,E] (already scaled); k, v: [S,B,E] views; mask: [B,S] uint8 or None."""
+    q: [T,B,E] (already scaled); k, v: [S,B,E] views; mask: [B,S] uint8 or None.
+    v is None: `k` is the packed projection [S,B,2E] of kv_linear (K in columns 0:E, V in E:2E); the gradient comes
+    back as one [S,B,2E] tensor too (no slice / concatenate nodes in the autograd graph)."""
 
     @staticmethod
     def forward(ctx, q, k, v, mask, bias_k, bias_v, H, has_zero, p, salt):
         T, B, E = q.shape
         S = k.shape[0]
         D = E // H
+        packed = v is None
+        if packed:
+            kv = k
+            assert kv.stride(2) == 1 and kv.shape[2] == 2 * E
+            ctx.kv_layout = (tuple(kv.shape), tuple(kv.stride()))
+            k, v = kv[..., :E], kv[..., E:]
         if q.stride(2) != 1:
             q = q.contiguous()
         out = torch.empty(T, B, E, dtype=q.dtype, device=q.device)
@@ -740,36 +899,53 @@ class AttnFn(Function):
              k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1),
              int(has_zero), float(p), rt.seed(), salt, hip.dt(q))
         ctx.save_for_backward(q, k, v, out, lse, mask, bk, bv)
-        ctx.meta = (bias_k, bias_v, H, has_zero, p, salt, S)
+        ctx.meta = (bias_k, bias_v, H, has_zero, p, salt, S, packed)
         ctx.mark_non_differentiable(lse)
         return out, lse
 
     @staticmethod
     def backward(ctx, dout, _dlse):
         q, k, v, out, lse, mask, bk, bv = ctx.saved_tensors
-        bias_k, bias_v, H, has_zero, p, salt, S = ctx.meta
+        bias_k, bias_v, H, has_zero, p, salt, S, packed = ctx.meta
         T, B, E = q.shape
         D = E // H
         dout = dout.contiguous()
         dq = torch.empty_like(q)
-        dbk = torch.zeros(B, E, dtype=torch.float32, device=q.device) if bk is not None else None
-        dbv = torch.zeros(B, E, dtype=torch.float32, device=q.device) if bk is not None else None
+        # (every element is ASSIGNED by the workgroup of its (b, h) while it handles q block 0: no zero fill)
+        dbk = torch.empty(B, E, dtype=torch.float32, device=q.device) if bk is not None else None
+        dbv = torch.empty(B, E, dtype=torch.float32, device=q.device) if bk is not None else None
         # dk/dv share k's / v's strides (the kernel uses one stride set for K and dK);
         # empty_like keeps the strides of dense permuted views ([B,S,E] storage seen as [S,B,E])
         kc, vc = k, v
-        dk, dv = torch.empty_like(kc), torch.empty_like(vc)
-        if dk.stride() != kc.stride():
-            kc = k.contiguous()
-            dk = torch.empty_like(kc)
-        if dv.stride() != vc.stride():
-            vc = v.contiguous()
-            dv = torch.empty_like(vc)
+        dkv = None
+        if packed and S > 0:
+            # one [S,B,2E] gradient buffer laid out like the packed projection; the K / V halves are views of it
+            kshape, kstride = ctx.kv_layout
+            dkv = torch.empty_strided(kshape, kstride, dtype=k.dtype, device=k.device)
+        if dkv is not None:
+            dk, dv = dkv[..., :E], dkv[..., E:]
+        else:
+            dk, dv = torch.empty_like(kc), torch.empty_like(vc)
+            if dk.stride() != kc.stride():
+                kc = k.contiguous()
+                dk = torch.empty_like(kc)
+            if dv.stride() != vc.stride():
+                vc = v.contiguous()
+                dv = torch.empty_like(vc)
         call('tell_attn_bwd', q, kc, vc, out, dout, lse, mask, bk, bv, dq, dk, dv, dbk, dbv, B, H, T, S, D,
              q.stride(0), q.stride(1), kc.stride(0), kc.stride(1), vc.stride(0), vc.stride(1),
              out.stride(0), out.stride(1), int(has_zero), float(p), rt.seed(), salt, hip.dt(q))
         if bias_k is not None and bias_k.requires_grad:
             colsum_into(dbk, grad_buffer(bias_k).view(-1))
             colsum_into(dbv, grad_buffer(bias_v).view(-1))
+        if packed:
+            if S == 0:
+                gk = None
+            elif dkv is not None:
+                gk = dkv
+            else:
+                gk = torch.cat([dk, dv], dim=-1)
+            return dq, gk, None, None, None, None, None, None, None, None
         return dq, dk if S > 0 else None, dv if S > 0 else None, None, None, None, None, None, None, None
 
 
