@@ -235,6 +235,16 @@ int tell_loss_flag(const float* loss, int* skip, tell_stream_t stream);
 
 /* ---- ResNet-152 trunk helpers, tell/models/resnet.py:92-108 (NHWC) ----------- */
 int tell_nchw_to_nhwc(const float* x, void* y, int B, int C, int H, int W, int out_dtype, tell_stream_t stream);
+/* conv (1x1 / 3x3, stride 1 / 2, Cin = 64 * 2^n) as an IMPLICIT GEMM on the matrix cores + the statistics of the
+ * train-mode BatchNorm behind it (resnet.py:92-108: torchvision Bottleneck conv -> bn; BN in batch-stat mode per
+ * callback_apex_trainer.py:259): no im2col matrix, no statistics pass over the activation.  x [B,H,W,Cin] bf16,
+ * w [Cout, KH*KW*Cin] bf16, y [B*OH*OW, Cout] bf16 raw conv output; mean / invstd [Cout] (+ running stats update), or
+ * mean == NULL for the convolution alone.  workspace: 2 * ceil(B*OH*OW / 64) * Cout floats; zero_page: >= 16 zero
+ * bytes, 16-byte aligned (source of the padding ring). */
+int tell_conv_bn_stats(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int KH, int KW, int stride,
+                       int pad, int OH, int OW, int Cout, float eps, float momentum, float* mean, float* invstd,
+                       float* running_mean, float* running_var, float* workspace, const void* zero_page,
+                       tell_stream_t stream);
 int tell_im2col(const void* x, void* col, int B, int H, int W, int Cin, int KH, int KW, int stride, int pad,
                 int OH, int OW, int Kp, int dtype, tell_stream_t stream);
 /* im2col of y = relu(BatchNorm(x)): the producer's normalisation is applied while gathering (resnet.py Bottleneck:

@@ -9,9 +9,12 @@ from tell_amd.build import build_model
 tell_amd.set_compute_dtype(torch.bfloat16)
 tell_amd.manual_seed(1234)
 torch.manual_seed(0)
-model = build_model('flattened', weigh_bert=False)
+kind = sys.argv[1] if len(sys.argv) > 1 else 'faces_objects'
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+fo = kind == 'faces_objects'
+model = build_model(kind, weigh_bert=fo)
 tr = Trainer(model, device='cuda')
-batches = [synthetic_batch(16, 512, 33, False, seed=1234 + i, device='cuda') for i in range(2)]
+batches = [synthetic_batch(B, 512, 33, fo, seed=1234 + i, device='cuda') for i in range(2)]
 fresh = lambda b: {k: (dict(v) if isinstance(v, dict) else v) for k, v in b.items()}
 run_res, run_rob = model._run_resnet, model._run_roberta
 cache = {}

@@ -1,0 +1,52 @@
+"""Device time of tell_conv_bn_stats on the ResNet-152 bottleneck shapes at B = 32, each captured as 10 launches in one
+hipGraph: with / without the BatchNorm statistics + in-kernel finish, per tile shape (TELL_CONV_TILE)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tell_amd
+from tell_amd import hip
+REP = 10
+ws = torch.empty(1 << 24, dtype=torch.float32, device='cuda')
+zero = torch.zeros(256, dtype=torch.uint8, device='cuda')
+
+
+def timed(fn):
+    fn(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g), hip.bound_stream():
+        for _ in range(REP):
+            fn()
+    g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        g.replay()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (5 * REP)
+
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+shapes = [('l1 conv1', 56, 256, 1, 1, 64), ('l1 conv2', 56, 64, 3, 1, 64), ('l1 conv3', 56, 64, 1, 1, 256),
+          ('l2 conv1', 28, 512, 1, 1, 128), ('l2 conv2', 28, 128, 3, 1, 128), ('l2 conv3', 28, 128, 1, 1, 512),
+          ('l3 conv1', 14, 1024, 1, 1, 256), ('l3 conv2', 14, 256, 3, 1, 256), ('l3 conv3', 14, 256, 1, 1, 1024),
+          ('l4 conv1', 7, 2048, 1, 1, 512), ('l4 conv2', 7, 512, 3, 1, 512), ('l4 conv3', 7, 512, 1, 1, 2048),
+          ('l3 ds', 28, 512, 1, 2, 1024), ('l3 conv2 s2', 28, 256, 3, 2, 256)]
+print('%-12s %7s %5s %5s | per tile 128x128 | 128x64 | 64x64: us conv + statistics + finish / conv only, TFLOP/s | BN apply' % ('shape', 'M', 'N', 'K'))
+for name, H, Cin, k, s, Cout in shapes:
+    p = k // 2
+    OH = (H + 2 * p - k) // s + 1
+    M, K = B * OH * OH, k * k * Cin
+    x = torch.randn(B, H, H, Cin, device='cuda').bfloat16()
+    w = (torch.randn(Cout, K, device='cuda') * 0.05).bfloat16()
+    y = torch.empty(M, Cout, dtype=torch.bfloat16, device='cuda')
+    mean = torch.empty(Cout, device='cuda'); invstd = torch.empty(Cout, device='cuda')
+    rm = torch.zeros(Cout, device='cuda'); rv = torch.ones(Cout, device='cuda')
+    out = []
+    for tile in ('1', '2', '3'):
+        os.environ['TELL_CONV_TILE'] = tile
+        t1 = timed(lambda: hip.call('tell_conv_bn_stats', x, w, y, B, H, H, Cin, k, k, s, p, OH, OH, Cout, 1e-5, 0.1, mean,
+                                    invstd, rm, rv, ws, zero))
+        t0 = timed(lambda: hip.call('tell_conv_bn_stats', x, w, y, B, H, H, Cin, k, k, s, p, OH, OH, Cout, 1e-5, 0.1, None,
+                                    None, None, None, None, zero))
+        out.append('%5.1f/%5.1f %4.0f' % (t1, t0, 2.0 * M * Cout * K * 1e-6 / t1))
+    ta = timed(lambda: hip.call('tell_bn_apply', y, mean, invstd, rm, rv, None, y, M, Cout, 1, 1))
+    print('%-12s %7d %5d %5d | %s | apply %5.1f' % (name, M, Cout, K, ' | '.join(out), ta), flush=True)

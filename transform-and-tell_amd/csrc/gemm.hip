@@ -38,6 +38,11 @@ struct GemmArgs {
   float* asum;            // K-major A only: asum[m] += asum_scale * sum_k A[k][m]  (bias gradient of a wgrad GEMM)
   float asum_scale;
   int atomic_out;         // fp32 output shared by several workgroups (split K): accumulate with hardware float atomics
+  // implicit convolution (direct-to-LDS kernel): A is not a matrix but the NHWC activation [B,H,W,Cin]; row m is output
+  // pixel (b, oh, ow), K = KH*KW*Cin in (kh, kw, c) order - each 64-wide K tile lies inside one tap (Cin % 64 == 0), and
+  // every lane's DMA source is the shifted input pixel (a 128-byte zero page for the padding ring): no im2col matrix
+  const void* conv_zero;  // != NULL selects the mode
+  int conv_H, conv_W, conv_OH, conv_OW, conv_KW, conv_stride, conv_pad, conv_cshift;   // Cin = 64 << conv_cshift
   float* stat_mean;       // bf16 NT kernels: per (m-tile, column) mean / M2 of the STORED (bf16-rounded) outputs over
   float* stat_m2;         //   the tile's valid rows, [tiles_m][N] each - the first stage of train-mode BatchNorm
 };
@@ -359,7 +364,7 @@ __device__ __forceinline__ void staged_store_stats(f32x16 (&acc)[MI][NI], const 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-template <typename OutT, int BM, int BN, int WAVES_M, int WAVES_N>
+template <typename OutT, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(GemmArgs p) {
   constexpr int NW = WAVES_M * WAVES_N, BK = 64;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -402,13 +407,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(Ge
   // per-lane source pointers (row clamped: rows past M/N only feed outputs that are never stored)
   const uint16_t* asrc[IA];
   const uint16_t* bsrc[IB];
+  constexpr bool conv = CONV;                               // implicit-convolution gather (tell_conv_bn_stats)
+  int cv_ih[IA], cv_iw[IA];                                 // conv mode: top-left input pixel of the row's window
 #pragma unroll
   for (int j = 0; j < IA; ++j) {
     const int s = (wave * IA + j) * 64 + lane, pr = s >> 4, l16 = (s & 15) ^ (pr & 15);
     int row = m0 + 2 * pr + (l16 >> 3);
     row = row < M ? row : M - 1;
-    asrc[j] = A + (long)row * p.lda + (l16 & 7) * 8;
+    if (conv) {
+      const int ow = row % p.conv_OW, t = row / p.conv_OW, oh = t % p.conv_OH, b = t / p.conv_OH;
+      cv_ih[j] = oh * p.conv_stride - p.conv_pad;
+      cv_iw[j] = ow * p.conv_stride - p.conv_pad;
+      asrc[j] = A + ((long)b * p.conv_H * p.conv_W << (6 + p.conv_cshift)) + (l16 & 7) * 8;   // image base + chunk
+    } else {
+      cv_ih[j] = cv_iw[j] = 0;
+      asrc[j] = A + (long)row * p.lda + (l16 & 7) * 8;
+    }
   }
+  const uint16_t* zero_src = static_cast<const uint16_t*>(p.conv_zero);     // 16 zero bytes for a padding pixel
 #pragma unroll
   for (int j = 0; j < IB; ++j) {
     const int s = (wave * IB + j) * 64 + lane, pr = s >> 4, l16 = (s & 15) ^ (pr & 15);
@@ -420,10 +436,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(Ge
   auto issue = [&](int kt, int stage, int q) __attribute__((always_inline)) {
     unsigned char* sa = smem + stage * STAGE + (wave * IA) * 1024;
     unsigned char* sb = smem + stage * STAGE + A_BYTES + (wave * IB) * 1024;
+    if (conv) {
+      // K tile kt = channels [c0, c0 + 64) of tap (kh, kw): scalar
+      const int tap = kt >> p.conv_cshift, c0 = (kt & ((1 << p.conv_cshift) - 1)) << 6;
+      const int kh = tap / p.conv_KW, kw = tap - kh * p.conv_KW;
 #pragma unroll
-    for (int j = 0; j < IA; ++j)
-      if (q < 0 || j * 4 / IA == q)
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[j] + kt * BK), (lds_ptr_t)(sa + j * 1024), 16, 0, 0);
+      for (int j = 0; j < IA; ++j)
+        if (q < 0 || j * 4 / IA == q) {
+          const int ih = cv_ih[j] + kh, iw = cv_iw[j] + kw;
+          const bool in = (unsigned)ih < (unsigned)p.conv_H && (unsigned)iw < (unsigned)p.conv_W;
+          const uint16_t* src = in ? asrc[j] + ((long)(ih * p.conv_W + iw) << (6 + p.conv_cshift)) + c0 : zero_src;
+          __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(sa + j * 1024), 16, 0, 0);
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < IA; ++j)
+        if (q < 0 || j * 4 / IA == q)
+          __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[j] + kt * BK), (lds_ptr_t)(sa + j * 1024), 16, 0, 0);
+    }
 #pragma unroll
     for (int j = 0; j < IB; ++j)
       if (q < 0 || j * 4 / IB == q)
@@ -1134,7 +1164,7 @@ extern "C" int tell_gemm_nt(const void* A, long lda, const void* B, long ldb, vo
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux; a.m_dev = m_dev;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
   a.bias_mode = bias_mode; a.act = act; a.accumulate = accumulate; a.alpha = alpha;
-  a.asum = nullptr; a.asum_scale = 0.f; a.stat_mean = nullptr; a.stat_m2 = nullptr; a.atomic_out = 0;
+  a.asum = nullptr; a.asum_scale = 0.f; a.stat_mean = nullptr; a.stat_m2 = nullptr; a.atomic_out = 0; a.conv_zero = nullptr;
   if (in_dtype == TELL_BF16)
     return out_dtype == TELL_BF16 ? launch_gemm<uint16_t, uint16_t>(a, stream)
                                   : launch_gemm<uint16_t, float>(a, stream);
@@ -1180,7 +1210,7 @@ extern "C" int tell_gemm_bf16(const void* A, long lda, int trans_a, const void* 
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux; a.m_dev = m_dev;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
   a.bias_mode = bias_mode; a.act = act; a.accumulate = accumulate; a.alpha = alpha;
-  a.asum = a_colsum; a.asum_scale = a_colsum_scale; a.stat_mean = nullptr; a.stat_m2 = nullptr; a.atomic_out = 0;
+  a.asum = a_colsum; a.asum_scale = a_colsum_scale; a.stat_mean = nullptr; a.stat_m2 = nullptr; a.atomic_out = 0; a.conv_zero = nullptr;
   if (trans_a && trans_b)
     return out_dtype == TELL_BF16 ? launch_gemm_tx<uint16_t, true, true>(a, stream) : launch_gemm_tx<float, true, true>(a, stream);
   if (trans_b)
@@ -1205,13 +1235,77 @@ extern "C" int tell_gemm_bn_stats(const void* A, long lda, const void* B, long l
   GemmArgs a;
   a.A = A; a.B = B; a.C = C; a.bias = nullptr; a.aux = nullptr; a.m_dev = nullptr;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
-  a.bias_mode = 0; a.act = 0; a.accumulate = 0; a.alpha = 1.f; a.asum = nullptr; a.asum_scale = 0.f; a.atomic_out = 0;
+  a.bias_mode = 0; a.act = 0; a.accumulate = 0; a.alpha = 1.f; a.asum = nullptr; a.asum_scale = 0.f; a.atomic_out = 0; a.conv_zero = nullptr;
   const long max_tiles = ((long)M + 63) / 64;
   a.stat_mean = workspace;
   a.stat_m2 = workspace + max_tiles * N;
   int bm = 64;
   int rc = launch_gemm<uint16_t, uint16_t>(a, stream, &bm);
   if (rc) return rc;
+  return tell_bn_finish_launch(a.stat_mean, a.stat_m2, M, N, (M + bm - 1) / bm, bm, eps, momentum, mean, invstd,
+                               running_mean, running_var, stream);
+}
+
+
+// Convolution (1x1 or 3x3, stride 1 or 2, NHWC, Cin a power-of-two multiple of 64) as an IMPLICIT GEMM on the
+// direct-to-LDS kernel - the im2col matrix never exists: every lane's DMA source is the shifted input pixel, the
+// padding ring reads a zero page - with the statistics of the train-mode BatchNorm that follows
+// (resnet.py:92-108 via torchvision's Bottleneck; callback_apex_trainer.py:259 keeps the frozen trunk in train mode):
+// per-m-tile column mean / M2 from the stored bf16 tile (GEMM epilogue), merged by one small finish launch.
+// mean == NULL: plain convolution (eval mode, running statistics).
+//   X [B,H,W,Cin] bf16, Wt [Cout, KH*KW*Cin] bf16 ((kh,kw,c) order), Y [B*OH*OW, Cout] bf16 (raw, BN not applied)
+//   workspace: 2 * ceil(M / 64) * Cout floats; zero_page: >= 16 zero bytes, 16-byte aligned
+// Measured alternatives for the statistics (tools/bench_conv.py, B = 32, layer3 conv1 9.5 us alone, 15 us this way):
+//   * merging the partials INSIDE the GEMM launch by the last workgroup to arrive (agent-scope ticket): 22-26 us for
+//     that shape, 85 us for layer1 - one workgroup's dependent loads become the critical path;
+//   * column sums / sums of squares from the accumulator registers (lane shuffles) added to [2, Cout] with float
+//     atomics: 31-49 us, 320-620 us for layer1 - thousands of same-address atomics serialise in L2.
+extern "C" int tell_conv_bn_stats(const void* X, const void* Wt, void* Y, int B, int H, int W, int Cin, int KH, int KW,
+                                  int stride, int pad, int OH, int OW, int Cout, float eps, float momentum, float* mean,
+                                  float* invstd, float* running_mean, float* running_var, float* workspace,
+                                  const void* zero_page, hipStream_t stream) {
+  const long Ml = (long)B * OH * OW;
+  TELL_REQUIRE(Ml > 0 && Ml < (1L << 31) && Cout > 0, "conv_bn_stats: bad dimension");
+  int cshift = 0;
+  while ((64 << cshift) < Cin) ++cshift;
+  TELL_REQUIRE((64 << cshift) == Cin, "conv_bn_stats: Cin must be 64 * 2^n");
+  TELL_REQUIRE(KH == KW && (KH == 1 || KH == 3) && (stride == 1 || stride == 2), "conv_bn_stats: 1x1 / 3x3, stride 1 / 2");
+  TELL_REQUIRE(Cout % 8 == 0, "conv_bn_stats: Cout must be a multiple of 8");
+  TELL_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)Wt & 15) == 0 && ((uintptr_t)Y & 15) == 0 &&
+               ((uintptr_t)zero_page & 15) == 0 && zero_page != nullptr, "conv_bn_stats: 16-byte alignment");
+  const int M = (int)Ml, N = Cout, K = KH * KW * Cin;
+  GemmArgs a;
+  a.A = X; a.B = Wt; a.C = Y; a.bias = nullptr; a.aux = nullptr; a.m_dev = nullptr;
+  a.lda = Cin; a.ldb = K; a.ldc = N; a.M = M; a.N = N; a.K = K;
+  a.bias_mode = 0; a.act = 0; a.accumulate = 0; a.alpha = 1.f; a.asum = nullptr; a.asum_scale = 0.f; a.atomic_out = 0;
+  a.conv_zero = (KH == 1 && stride == 1) ? nullptr : zero_page;          // 1x1 / stride 1: A is the activation matrix
+  a.conv_H = H; a.conv_W = W; a.conv_OH = OH; a.conv_OW = OW; a.conv_KW = KW; a.conv_stride = stride; a.conv_pad = pad;
+  a.conv_cshift = cshift;
+  a.stat_mean = a.stat_m2 = nullptr;
+  if (mean) {
+    TELL_REQUIRE(invstd && workspace, "conv_bn_stats: statistics need invstd and workspace");
+    a.stat_mean = workspace;
+    a.stat_m2 = workspace + (((long)M + 63) / 64) * N;
+  }
+  auto tiles = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+  const char* fe = getenv("TELL_CONV_TILE");                       // tuning / test aid: 1 / 2 / 3 forces a tile shape
+  const int force = fe ? atoi(fe) : 0;
+  // 64x64 tiles (4 waves, 32 KB of LDS, 5 workgroups per CU) win on every bottleneck shape of the trunk at B = 32
+  // (tools/bench_conv.py: layer3 conv1 15.1 us against 20.4 / 22.3 with 128x64 / 128x128 - these GEMMs are only
+  // 50-800 tiles of 128x128, the small tile fills the chip and hides the short K loops behind its neighbours); 128x64
+  // ties once there are thousands of tiles
+  int pick = (tiles(64, 64) >= 6000 && N % 64 == 0) ? 2 : 3;
+  if (force) pick = force;
+#define CONV_LAUNCH(BM_, BN_, CV)                                                                                   \
+  hipLaunchKernelGGL((gemm_nt_glds_kernel<uint16_t, BM_, BN_, 2, 2, CV>), dim3((unsigned)tiles(BM_, BN_)), dim3(256), 0, stream, a)
+  const bool cv = a.conv_zero != nullptr;
+  if (pick == 1) { if (cv) CONV_LAUNCH(128, 128, true); else CONV_LAUNCH(128, 128, false); }
+  else if (pick == 2) { if (cv) CONV_LAUNCH(128, 64, true); else CONV_LAUNCH(128, 64, false); }
+  else { if (cv) CONV_LAUNCH(64, 64, true); else CONV_LAUNCH(64, 64, false); }
+#undef CONV_LAUNCH
+  int rc = tell_check_launch("conv_bn_stats");
+  if (rc || !mean) return rc;
+  const int bm = pick == 3 ? 64 : 128;
   return tell_bn_finish_launch(a.stat_mean, a.stat_m2, M, N, (M + bm - 1) / bm, bm, eps, momentum, mean, invstd,
                                running_mean, running_var, stream);
 }

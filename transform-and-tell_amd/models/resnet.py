@@ -122,6 +122,46 @@ def conv_bn_act(x, B, H, W, conv, bn, relu, residual, training):
     return bn_apply(y, mean, invstd, bn, relu, residual), OH, OW
 
 
+# ---- bf16 path: implicit-GEMM convolution (no im2col matrix in HBM) with the BatchNorm statistics in its epilogue
+_ZERO_PAGE = {}
+
+
+def _zero_page(device):
+    z = _ZERO_PAGE.get(device)
+    if z is None:
+        z = _ZERO_PAGE[device] = torch.zeros(256, dtype=torch.uint8, device=device)   # padding ring of the gather
+    return z
+
+
+def implicit_ok(conv, dtype):
+    c = conv.cin // 64
+    return (dtype == torch.bfloat16 and conv.k in (1, 3) and conv.cin % 64 == 0 and c & (c - 1) == 0 and
+            conv.cout % 8 == 0 and conv.padding == conv.k // 2)
+
+
+def conv_bn_implicit(x, B, H, W, conv, bn, relu, residual, training, slot=0):
+    """conv -> BatchNorm (-> + residual) (-> ReLU): implicit-GEMM convolution whose epilogue leaves the per-tile
+    statistics (+ one small finish launch in train mode), then one elementwise pass.  x: [B*H*W, Cin] NHWC rows
+    (post-activation).  -> ([B*OH*OW, Cout], OH, OW)."""
+    k, s, p = conv.k, conv.stride, conv.padding
+    OH = (H + 2 * p - k) // s + 1
+    OW = (W + 2 * p - k) // s + 1
+    M, C = B * OH * OW, conv.cout
+    wq = conv.gemm_weight()
+    y = torch.empty(M, C, dtype=x.dtype, device=x.device)
+    if training:
+        ws, slots = _stat_buffers(x.device, 2 * ((M + 63) // 64) * C, C)
+        mean, invstd = slots[slot]
+        call('tell_conv_bn_stats', x, wq, y, B, H, W, conv.cin, k, k, s, p, OH, OW, C, bn.eps, bn.momentum, mean,
+             invstd, bn.running_mean, bn.running_var, ws, _zero_page(x.device))
+    else:
+        call('tell_conv_bn_stats', x, wq, y, B, H, W, conv.cin, k, k, s, p, OH, OW, C, bn.eps, bn.momentum, None,
+             None, None, None, None, _zero_page(x.device))
+        mean = bn.running_mean
+        invstd = ops._cached(bn.running_var, ('invstd',), lambda: torch.rsqrt(bn.running_var + bn.eps))
+    return bn_apply(y, mean, invstd, bn, relu, residual), OH, OW
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -137,6 +177,16 @@ class Bottleneck(nn.Module):
 
     def run(self, x, B, H, W, training):
         idt = x
+        if all(implicit_ok(c, x.dtype) for c in (self.conv1, self.conv2, self.conv3)) and \
+                (self.downsample is None or implicit_ok(self.downsample[0], x.dtype)):
+            # bf16: every conv is an implicit GEMM (+ statistics epilogue, + finish in train mode), every BatchNorm
+            # (+ReLU, + residual) one elementwise pass; the BatchNorms of conv1 / conv2 run on the block's two SMALL
+            # tensors ([rows, planes]) instead of inside a 9x larger im2col matrix
+            if self.downsample is not None:
+                idt, _, _ = conv_bn_implicit(x, B, H, W, self.downsample[0], self.downsample[1], False, None, training, 0)
+            y, _, _ = conv_bn_implicit(x, B, H, W, self.conv1, self.bn1, True, None, training, 1)
+            y, OH, OW = conv_bn_implicit(y, B, H, W, self.conv2, self.bn2, True, None, training, 0)
+            return conv_bn_implicit(y, B, OH, OW, self.conv3, self.bn3, True, idt, training, 1)
         if self.downsample is not None:
             idt, _, _ = conv_bn_act(x, B, H, W, self.downsample[0], self.downsample[1], False, None, training)
         vec = 8 if x.dtype == torch.bfloat16 else 4

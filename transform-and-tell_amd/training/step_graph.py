@@ -48,7 +48,7 @@ class StepGraph:
         idx = model.index
         if not (ENABLED and graphs.ENABLED) or not hasattr(model, 'encode') or not model.training:
             return None
-        if tr.async_update or ops._WGRAD['enabled']:       # the opt-in side streams belong to the eager schedule
+        if tr.async_update:                                # the opt-in update stream belongs to the eager schedule
             return None
         cap = batch['caption'][idx]
         ctx = batch['context'][idx]
@@ -66,7 +66,7 @@ class StepGraph:
                 small[k] = batch[k]
         sig = (tuple((k, tuple(v.shape), v.dtype) for k, v in small.items()),
                tuple((tuple(t.shape), t.dtype, t.data_ptr() if by_ptr else 0) for t in big),
-               by_ptr, rt.compute_dtype(), tr.dp)
+               by_ptr, rt.compute_dtype(), tr.dp, ops._WGRAD['enabled'])
         return sig, small, big, by_ptr
 
     # ------------------------------------------------------------------ one step
