@@ -324,6 +324,83 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
     return res, trainer
 
 
+
+def generate_bench(args, dev, world, rank, dist):
+    """BASELINE configs[4]: caption generation throughput of the full faces+objects model (beam 4; the reference itself
+    only decodes greedily, `--beam 1`), one replica per GPU, every rank decoding its own shard of synthetic images (no
+    collective on the data path: replicas only).  A "step" is one batch of `--batch` captions: frozen encoders
+    + K/V projection of the contexts + up to 100 decode steps (random-init weights never emit </s>: every caption runs
+    the full 100 steps)."""
+    import tell_amd
+    from tell_amd.build import build_model
+    from tell_amd.data import synthetic_batch
+    torch.manual_seed(0)
+    model = build_model('faces_objects').to(dev).eval()
+    B, beam = args.batch, args.beam
+    batches = [synthetic_batch(B, 512, 33, True, seed=4321 + rank + 97 * i, device=dev) for i in range(2)]
+
+    def clone(b):
+        return {k: (dict(v) if isinstance(v, dict) else v.clone()) for k, v in b.items()}
+    out = None
+    with tell_amd.hip.bound_stream():
+        for i in range(args.warmup):
+            out = model.generate(**clone(batches[i % 2]), beam_size=beam)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = model.generate(**clone(batches[i % 2]), beam_size=beam)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        # decode loop alone (contexts already encoded): HIP events on its stream -> time per decode step
+        with torch.no_grad():
+            cap_ids, _, contexts = model._forward(**{k: v for k, v in clone(batches[0]).items() if k != 'metadata'})
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _, ids, _ = model._generate(cap_ids, contexts, beam_size=beam)
+            e1.record()
+            torch.cuda.synchronize()
+            dec_ms, n_steps = e0.elapsed_time(e1), ids.shape[1] - 1
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank != 0:
+        return None
+    # algorithmic HBM bytes of ONE decode step (bf16): the decoder's per-token weights + the tied softmax tables are
+    # read once, the projected K/V of the four contexts once per SAMPLE (the beam's hypotheses are query positions)
+    E, FF, H, V = 1024, 4096, 16, 50265
+    per_layer = lambda K: (2 * E * E + H * K * E + E * E + 4 * 2 * E * E + 4 * E * E + 2 * FF * E)     # noqa: E731
+    w_bytes = 2 * (sum(per_layer(K) for K in (3, 7, 15, 31)) + V * E + 2 * E * E + 2 * E)
+    kv_bytes = 2 * 4 * B * (512 + 49 + 64 + 4 + 8) * 2 * E
+    step_us = 1e3 * dec_ms / max(n_steps, 1)
+    tbs = (w_bytes + kv_bytes) / (step_us * 1e-6) / 1e12
+    return {
+        'metric': 'caption generation throughput (img+article->caption), beam %d' % beam if beam > 1 else
+                  'caption generation throughput (img+article->caption), greedy',
+        'value': round(world * B * args.steps / elapsed, 2), 'unit': 'captions/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 2),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
+        'data': 'synthetic (random pixels, random BPE ids; random-init weights)',
+        'config': {'workload': 'BASELINE configs[4]: caption generation, full faces+objects model '
+                               '(expt/nytimes/9_transformer_objects), %s, %d captions per batch per GPU, up to 100 '
+                               'steps, encoders included; replicas only (each rank decodes its own images)'
+                               % ('beam %d' % beam if beam > 1 else 'greedy (sampling_topk 1, as the reference)', B),
+                   'global_batch': world * B, 'article_len': 512, 'decode_steps': int(n_steps),
+                   'parallelism': 'replicas x%d' % world},
+        'roofline': {'bound': 'hbm', 'kernel': 'captured decode step (one hipGraph replay per generated token)',
+                     'achieved': round(tbs, 3), 'peak': 8.0, 'unit': 'TB/s', 'frac': round(tbs / 8.0, 4),
+                     'traffic': None, 'avg_step_us': round(step_us, 1),
+                     'algorithmic_bytes_per_step': int(w_bytes + kv_bytes),
+                     'note': 'decoder per-token weights + tied softmax tables (%.0f MB) + projected K/V of the 4 '
+                             'contexts read once per sample (%.0f MB), per decode step; duration = HIP events around '
+                             'the decode loop / steps' % (w_bytes / 1e6, kv_bytes / 1e6)},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -342,6 +419,8 @@ def main():
                     help='run everything on ONE stream, eagerly (no encoder prefetch / overlap, no graphs): per-kernel '
                          'durations are then well defined - the mode of the roofline leg and of the committed '
                          'rocprofv3 kernel summaries')
+    ap.add_argument('--generate', action='store_true', help='BASELINE configs[4]: caption generation throughput')
+    ap.add_argument('--beam', type=int, default=4, help='beam size of --generate (1 = greedy, what the reference does)')
     ap.add_argument('--roofline-steps', type=int, default=3,
                     help='extra single-stream steps after the timed region that time the GEMM kernels in isolation')
     args = ap.parse_args()
@@ -370,6 +449,15 @@ def main():
     tell_amd.hip.require_gpu()
     tell_amd.set_compute_dtype(torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
 
+    if args.generate:
+        if args.steps == 20 and args.warmup == 5:          # defaults are sized for training steps; a batch of captions
+            args.steps, args.warmup = 4, 1                 # is ~0.2 s
+        result = generate_bench(args, dev, world, rank, dist)
+        if rank == 0:
+            print(json.dumps(result))
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
     res, trainer = measure(args, args.model, args.batch, dev, world, rank, dist)
     if rank == 0:
         result = {

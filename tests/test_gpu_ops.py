@@ -340,12 +340,14 @@ def test_lightweight_conv_golden(golden, dtype, K, T):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-def test_dynamic_conv_full_size_dropconnect(dtype):
-    """decoder shapes (T=32,B=16,C=1024,H=16,K=31) with DropConnect, vs the oracle with the same mask."""
+@pytest.mark.parametrize('T,K', [(32, 31), (32, 3), (32, 7), (32, 15), (5, 31), (100, 15)])
+def test_dynamic_conv_full_size_dropconnect(dtype, T, K):
+    """decoder shapes (B=16, C=1024, H=16, head width 64: the LDS-tiled kernels; T=100 takes the tiled forward and the
+    wave-per-row backward, T < K the tap narrowing) with DropConnect, vs the oracle with the same mask."""
     import tell_amd
     from tell_amd import ops, rng
     from oracle import functional as OF
-    T, B, C, H, K, p = 32, 16, 1024, 16, 31, 0.1
+    B, C, H, p = 16, 1024, 16, 0.1
     g = torch.Generator().manual_seed(3)
     x = torch.randn(T, B, C, generator=g)
     lg = torch.randn(T, B, H * K, generator=g)
