@@ -234,6 +234,10 @@ int tell_bertadam_step(float* param, float* grad, float* m, float* v, const int*
 int tell_loss_flag(const float* loss, int* skip, tell_stream_t stream);
 
 /* ---- ResNet-152 trunk helpers, tell/models/resnet.py:92-108 (NHWC) ----------- */
+/* ToTensor + Normalize(mean, std) of the dataset readers (nytimes_faces_ner_matched.py:67-69) on the device:
+ * uint8 [B,H,W,3] -> float32 [B,3,H,W] */
+int tell_image_normalize(const uint8_t* x, float* y, int B, int H, int W, float m0, float m1, float m2, float s0,
+                         float s1, float s2, tell_stream_t stream);
 int tell_nchw_to_nhwc(const float* x, void* y, int B, int C, int H, int W, int out_dtype, tell_stream_t stream);
 /* conv (1x1 / 3x3, stride 1 / 2, Cin = 64 * 2^n) as an IMPLICIT GEMM on the matrix cores + the statistics of the
  * train-mode BatchNorm behind it (resnet.py:92-108: torchvision Bottleneck conv -> bn; BN in batch-stat mode per

@@ -1,0 +1,208 @@
+"""CPU: the data plane - RoBERTa byte-level BPE + indexer, shard format, readers under the
+reference's registration names, bucket iterator and the batch tensor contract of Model.forward."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def _write_vocab(d):
+    """A small synthetic RoBERTa vocabulary: all 256 byte symbols + a handful of merges, fairseq dict.txt on top."""
+    from tell_amd.data.bpe import bytes_to_unicode
+    chars = list(bytes_to_unicode().values())
+    merges = [('Ġ', 't'), ('Ġt', 'h'), ('Ġth', 'e'), ('h', 'e'), ('l', 'l'), ('he', 'll'), ('hell', 'o'),
+              ('Ġ', 'M'), ('ĠM', 'i'), ('l', 'a'), ('ĠMi', 'la'), ('ĠMila', 'n')]
+    tokens = chars + [a + b for a, b in merges]
+    enc = {t: i for i, t in enumerate(tokens)}
+    with open(os.path.join(d, 'encoder.json'), 'w') as f:
+        json.dump(enc, f)
+    with open(os.path.join(d, 'vocab.bpe'), 'w', encoding='utf-8') as f:
+        f.write('#version: 0.2\n' + '\n'.join('%s %s' % m for m in merges) + '\n')
+    order = list(reversed(range(len(tokens))))                 # fairseq orders by frequency: any permutation
+    with open(os.path.join(d, 'dict.txt'), 'w') as f:
+        f.write('\n'.join('%d %d' % (i, 1000 - k) for k, i in enumerate(order)) + '\n')
+    return enc, order
+
+
+def test_byte_bpe_known_answers_and_round_trip(tmp_path):
+    from tell_amd.data.bpe import RobertaBPE
+    enc, order = _write_vocab(str(tmp_path))
+    rb = RobertaBPE(str(tmp_path))
+    # 'hello' merges h+e, l+l, he+ll, hell+o -> one token; ' the' -> 'Gthe'; ' them' -> 'Gthe' + 'm'
+    assert rb.bpe.encode('hello') == [enc['hello']]
+    assert rb.bpe.encode('hello the them') == [enc['hello'], enc['Ġthe'], enc['Ġthe'], enc['m']]
+    assert rb.bpe.pretokenize("Tomas Maier, autumn/winter 2014,\n in Milan.") == \
+        ['Tomas', ' Maier', ',', ' autumn', '/', 'winter', ' 2014', ',', '\n', ' in', ' Milan', '.']
+    for text in ['hello the  world\n\nnew para', 'café — naïve 中文 \U0001f600', " it's 12,345.67 "]:
+        assert rb.bpe.decode(rb.bpe.encode(text)) == text
+    # fairseq ids: <s>=0 ... </s>=2, symbol i of dict.txt -> 4 + its line
+    ids = rb.encode_ids('hello the')
+    assert ids[0] == 0 and ids[-1] == 2
+    assert ids[1] == 4 + order.index(enc['hello']) and ids[2] == 4 + order.index(enc['Ġthe'])
+    assert rb.decode(ids[1:]) == 'hello the'                   # stops at </s>
+    assert len(rb.encode_ids('x ' * 600, max_len=512)) == 512
+
+
+def test_roberta_indexer_contract(tmp_path):
+    """roberta_indexer.py:89-109,185-200: <s> ... </s>, truncation to max_len, entity copy masks, padding 1 / -1."""
+    from tell_amd.data import RobertaTokenIndexer, TokenIndexer
+    from tell_amd.data.bpe import RobertaBPE
+    _write_vocab(str(tmp_path))
+    assert TokenIndexer.by_name('roberta') is RobertaTokenIndexer
+    idx = RobertaTokenIndexer(model_name='roberta-base', namespace='bpe', padding_on_right=True, padding_value=1,
+                              max_len=16, bpe=RobertaBPE(str(tmp_path)))
+
+    class Ent:
+        def __init__(self, s, e):
+            self.start_char, self.end_char = s, e
+
+    class Doc:
+        ents = [Ent(10, 15)]                                   # "Milan" in "hello the Milan x"
+    text = 'hello the Milan x'
+    ids, copy = idx.encode(text, Doc())
+    assert ids[0] == 0 and ids[-1] == 2 and len(ids) == len(copy)
+    assert copy == [0, 0, 0, 1, 0, 0, 0]                       # <s> hello Gthe GMilan G x </s>: only ' Milan' is inside
+    out = idx.tokens_to_indices(text.split(' '), None, 'roberta')
+    assert out['roberta'] == idx.encode(text)[0] and set(out) == {'roberta', 'roberta_copy_masks'}
+    long_ids, long_copy = idx.encode('x ' * 100)
+    assert len(long_ids) == 16 and long_ids[-1] == 2 and len(long_copy) == 16
+    padded = idx.as_padded_tensor({'roberta': ids, 'roberta_copy_masks': copy}, {'roberta': 10, 'roberta_copy_masks': 10})
+    assert padded['roberta'].dtype == torch.long and padded['roberta'].tolist()[-3:] == [1, 1, 1]
+    assert padded['roberta_copy_masks'].tolist()[-3:] == [-1, -1, -1]
+    with pytest.raises(FileNotFoundError):                    # no silent fallback when the BPE files are missing
+        RobertaBPE(str(tmp_path / 'nowhere'))
+
+
+def _samples(n, seed=0, with_obj=True):
+    g = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        L, T, F, O = g.randint(20, 200), g.randint(5, 30), g.randint(0, 5), g.randint(0, 9)
+        s = {'context_ids': np.r_[0, g.randint(4, 50265, L - 2), 2], 'caption_ids': np.r_[0, g.randint(4, 50265, T - 2), 2],
+             'image': g.randint(0, 256, (224, 224, 3)).astype(np.uint8), 'face_embeds': g.randn(F, 512).astype(np.float32),
+             'metadata': {'caption': 'c%d' % i, 'context': 'x', 'web_url': 'u', 'image_path': 'p%d.jpg' % i, 'image_pos': 0}}
+        if with_obj:
+            s['obj_embeds'] = np.abs(g.randn(O, 2048)).astype(np.float32)
+        out.append(s)
+    return out
+
+
+def test_shards_reader_and_batch_contract(tmp_path):
+    """write -> read round trip, reader under the reference's name and constructor keys, the tensors Model.forward gets
+    (ids right-padded with 1, <s>=0 first, </s>=2 last real token, copy masks -1, faces <= 4 rows and
+    objects NaN-padded, the empty [1,0] field, normalised image)."""
+    from tell_amd.data import BucketIterator, DatasetReader, collate, read_shard, write_shard
+    samples = _samples(11)
+    samples[3]['face_embeds'] = np.zeros((0, 512), np.float32)
+    write_shard(str(tmp_path / 'train-00000.npz'), samples[:6])
+    write_shard(str(tmp_path / 'train-00001.npz'), samples[6:])
+    back = read_shard(str(tmp_path / 'train-00000.npz'))
+    assert len(back) == 6
+    for a, b in zip(samples[:6], back):
+        assert np.array_equal(a['context_ids'], b['context_ids']) and np.array_equal(a['image'], b['image'])
+        assert np.array_equal(a['face_embeds'], b['face_embeds']) and a['metadata'] == b['metadata']
+    reader = DatasetReader.by_name('nytimes_faces_ner_matched')(
+        tokenizer={'type': 'word'}, token_indexers={'roberta': {'type': 'roberta', 'model_name': 'roberta-base',
+                                                                'namespace': 'bpe', 'padding_on_right': True,
+                                                                'padding_value': 1, 'max_len': 512}},
+        image_dir='unused', lazy=True, use_caption_names=False, use_objects=True, shard_dir=str(tmp_path))
+    inst = list(reader._read('train'))
+    assert len(inst) == 11 and set(inst[0]) == {'context', 'caption', 'image', 'face_embeds', 'obj_embeds', 'metadata'}
+    empties = [i for i in inst if i['face_embeds'].shape == (1, 0)]
+    assert len(empties) >= 1                                               # `np.array([[]])`, reader :166
+    with pytest.raises(ValueError):
+        list(reader._read('dev'))
+    batch = collate(inst[:5])
+    ctx, cap = batch['context']['roberta'], batch['caption']['roberta']
+    assert ctx.dtype == torch.long and (ctx[:, 0] == 0).all()
+    for row, i in zip(ctx, inst[:5]):
+        n = len(i['context']['roberta'])
+        assert row[n - 1] == 2 and (row[n:] == 1).all()
+    assert (batch['caption']['roberta_copy_masks'][cap == 1] == -1).all()
+    assert batch['image'].shape == (5, 3, 224, 224) and batch['image'].dtype == torch.float32
+    want = (torch.from_numpy(inst[0]['image']).permute(2, 0, 1).float() / 255 -
+            torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)) / torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+    torch.testing.assert_close(batch['image'][0], want)
+    fe, oe = batch['face_embeds'], batch['obj_embeds']
+    assert fe.shape[0] == 5 and fe.shape[1] <= 4 and fe.shape[2] == 512 and oe.shape[2] == 2048
+    for j, i in enumerate(inst[:5]):
+        f = i['face_embeds']
+        nf = 0 if f.shape == (1, 0) else f.shape[0]
+        assert torch.isnan(fe[j, nf:]).all() and not torch.isnan(fe[j, :nf]).any()
+    all_empty = collate([e for e in empties for _ in range(2)][:2])
+    assert all_empty['face_embeds'].shape == (2, 1, 0)                      # the kdim == 0 branch of the attention
+    # the whole pipeline, iterator of config.yaml:99-110
+    it = BucketIterator(sorting_keys=[['context', 'num_tokens'], ['caption', 'num_tokens']], batch_size=4,
+                        max_instances_in_memory=8192, biggest_batch_first=False, instances_per_epoch=8,
+                        maximum_samples_per_batch=['num_tokens', 16384])
+    b1 = list(it(inst, num_epochs=1, shuffle=True))
+    assert sum(b['context']['roberta'].shape[0] for b in b1) == 8          # one epoch = 8 instances
+    b2 = list(it(inst, num_epochs=1, shuffle=True))
+    assert sum(b['context']['roberta'].shape[0] for b in b2) == 8          # the cursor continues (3 left + 5 new)
+
+
+def test_bucket_iterator_semantics():
+    from tell_amd.data import BucketIterator, NYTimesFacesNERMatchedReader
+    reader = NYTimesFacesNERMatchedReader(use_objects=True, synthetic_samples=40)
+    inst = list(reader._read('valid'))
+    it = BucketIterator(sorting_keys=[['context', 'num_tokens']], batch_size=16, padding_noise=0.0,
+                        maximum_samples_per_batch=['num_tokens', 2048])
+    batches = list(it._batches(inst, shuffle=False))
+    assert sum(len(b) for b in batches) == 40
+    lens = [len(i['context']['roberta']) for b in batches for i in b]
+    assert lens == sorted(lens)                                            # bucketed by article length
+    for b in batches:
+        longest = max(max(len(i['context']['roberta']), len(i['caption']['roberta'])) for i in b)
+        assert len(b) <= 16 and longest * len(b) <= 2048
+    big = BucketIterator(sorting_keys=[['context', 'num_tokens']], batch_size=16, padding_noise=0.0, biggest_batch_first=True)
+    bb = list(big._batches(inst, shuffle=False))
+    assert max(len(i['context']['roberta']) for i in bb[0]) == max(lens)   # the longest batch is run first
+
+
+REF_CFG = '/root/reference/expt/nytimes/9_transformer_objects/config.yaml'
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CFG), reason='reference tree only exists in the authoring container')
+def test_reference_config_data_sections_instantiate_unmodified():
+    from tell_amd import config
+    from tell_amd.data import BucketIterator, NYTimesFacesNERMatchedReader, RobertaVocabulary
+    for name in ('9_transformer_objects', '5_transformer_roberta', '8_transformer_faces'):
+        p = config.yaml_to_params(REF_CFG.replace('9_transformer_objects', name))
+        reader = config.reader_from_params(p['dataset_reader'])
+        assert isinstance(reader, NYTimesFacesNERMatchedReader) or type(reader).__name__.startswith('NYTimes')
+        assert isinstance(config.iterator_from_params(p['iterator']), BucketIterator)
+        assert isinstance(config.iterator_from_params(p['validation_iterator']), BucketIterator)
+        assert isinstance(config.vocabulary_from_params(p['vocabulary']), RobertaVocabulary)
+    r9 = config.reader_from_params(config.yaml_to_params(REF_CFG)['dataset_reader'])
+    assert r9.use_objects is True and next(iter(r9._token_indexers.values()))._max_len == 512
+    gp = config.yaml_to_params(REF_CFG.replace('nytimes', 'goodnews').replace('9_transformer_objects', '1_lstm_glove'))
+    assert type(config.reader_from_params(gp['dataset_reader'])).__name__ == 'FlattenedGloveGoodNewsReader'
+
+
+def test_bleu_scorer_known_answers():
+    """Hand-computed BLEU of the restated scorer (pycocoevalcap's algorithm, transformer_faces_objects.py:109-116)."""
+    from tell_amd.metrics import BleuScorer
+    s = BleuScorer(n=4)
+    s += ('the cat sat on the mat', ['the cat sat on the mat'])
+    score, per = s.compute_score(option='closest')
+    assert all(abs(x - 1.0) < 1e-6 for x in score)
+    # hypothesis 'the the cat' vs reference 'the cat': unigrams clipped 2/3 (the:1 of 2, cat:1), bigrams 1/2 ('the cat'),
+    # trigrams 0/1, 4-grams 0/0 -> tiny/small smoothing; longer than the reference: no brevity penalty
+    s = BleuScorer(n=4)
+    s += ('the the cat', ['the cat'])
+    score, _ = s.compute_score(option='closest')
+    assert abs(score[0] - 2 / 3) < 1e-6
+    assert abs(score[1] - ((2 / 3) * (1 / 2)) ** 0.5) < 1e-6
+    assert score[2] < 1e-4 and score[3] < 1e-2
+    # brevity penalty: 2 of 4 words -> exp(1 - 4/2)
+    s = BleuScorer(n=4)
+    s += ('the cat', ['the cat sat down'])
+    score, _ = s.compute_score(option='closest')
+    import math
+    assert abs(score[0] - math.exp(1 - 2.0)) < 1e-6
+    # 'closest' reference length with two references
+    s = BleuScorer(n=4)
+    s += ('a b c', ['a b c d e f', 'a b'])
+    assert s.ctest[0]['reflen'] == [6, 2] and s._single_reflen([6, 2], 'closest', 3) == 2

@@ -1,0 +1,82 @@
+"""GPU: the data plane feeding the model (shards -> reader -> bucket iterator -> device batches -> training steps) and
+the evaluation tail (evaluate loop -> generations.jsonl + BLEU bookkeeping, tell/commands/evaluate.py:89-223)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_train import DEV, KW, _Res, _Rob, _no_dropout
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _gpu():
+    import tell_amd
+    tell_amd.hip.require_gpu()
+    yield
+    torch.cuda.synchronize()
+
+
+def _shards(tmp_path, n=24, vocab=600, seed=0):
+    from tell_amd.data import write_shard
+    g = np.random.RandomState(seed)
+    for split in ('train', 'test'):
+        samples = []
+        for i in range(n):
+            L, T, F, O = g.randint(8, 24), g.randint(5, 12), g.randint(0, 5), g.randint(0, 7)
+            samples.append({
+                'context_ids': np.r_[0, g.randint(4, vocab, L - 2), 2], 'caption_ids': np.r_[0, g.randint(4, vocab, T - 2), 2],
+                'image': g.randint(0, 256, (224, 224, 3)).astype(np.uint8),
+                'face_embeds': g.randn(F, 512).astype(np.float32), 'obj_embeds': np.abs(g.randn(O, 2048)).astype(np.float32),
+                'metadata': {'caption': 'word%d word%d again' % (i, i + 1), 'context': 'ctx', 'web_url': 'u%d' % i,
+                             'image_path': '%d.jpg' % i, 'image_pos': 0}})
+        write_shard(str(tmp_path / ('%s-00000.npz' % split)), samples)
+
+
+def test_image_normalize_kernel_matches_host_path():
+    from tell_amd.data.iterators import normalize_images
+    img = np.random.RandomState(1).randint(0, 256, (3, 224, 224, 3)).astype(np.uint8)
+    torch.testing.assert_close(normalize_images(img, DEV).cpu(), normalize_images(img, 'cpu'), rtol=1e-6, atol=1e-6)
+
+
+def test_shards_to_training_steps_and_evaluation_tail(tmp_path):
+    import tell_amd
+    from tell_amd.build import build_model
+    from tell_amd.commands import evaluate
+    from tell_amd.data import BucketIterator, DatasetReader
+    from tell_amd.training import Trainer
+    _shards(tmp_path)
+    tell_amd.set_compute_dtype(torch.float32)
+    torch.manual_seed(0)
+    model = build_model('faces_objects', _Res(True), _Rob(1024), n_bert_layers=3, **KW)
+    _no_dropout(model)
+    reader = DatasetReader.by_name('nytimes_faces_ner_matched')(use_objects=True, shard_dir=str(tmp_path))
+    it = BucketIterator(sorting_keys=[['context', 'num_tokens'], ['caption', 'num_tokens']], batch_size=8,
+                        maximum_samples_per_batch=['num_tokens', 16384])
+    tr = Trainer(model, dict(lr=5e-3, warmup=-1, t_total=-1, max_grad_norm=1.0), device=DEV)
+    losses = []
+    for epoch in range(3):
+        for batch in it(reader._read('train'), shuffle=True, device=DEV):
+            n = batch['context']['roberta'].shape[0]
+            assert batch['image'].is_cuda and batch['face_embeds'].shape[0] == n and len(batch['metadata']) == n
+            losses.append(float(tr.train_one_batch(batch)))
+    assert all(l == l for l in losses) and sum(losses[-3:]) < sum(losses[:3])
+    # ---- evaluation tail
+    model.get_metrics(reset=True)                 # (the trainer resets the running counters at every epoch end)
+    out_dir = str(tmp_path / 'serialization')
+    metrics = evaluate(model, reader._read('test'), BucketIterator(sorting_keys=[['context', 'num_tokens']], batch_size=8),
+                       DEV, out_dir, eval_suffix='_t')
+    assert metrics['_n_samples'] == 24 and metrics['loss'] == metrics['loss']
+    assert all(('bleu-%d' % k) in metrics for k in (1, 2, 3, 4))
+    lines = [json.loads(ln) for ln in open(os.path.join(out_dir, 'generations_t.jsonl'))]
+    assert len(lines) == 24
+    for rec in lines:
+        assert {'caption', 'raw_caption', 'generation', 'copied_texts', 'web_url', 'image_path', 'context',
+                'caption_np', 'gen_np'} <= set(rec)
+        assert rec['raw_caption'].startswith('word') and isinstance(rec['generation'], str)
+    assert model.evaluate_mode is True
+    with pytest.raises(AssertionError):            # the reference refuses to append to an existing generations file
+        evaluate(model, reader._read('test'), it, DEV, out_dir, eval_suffix='_t')

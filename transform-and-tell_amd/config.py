@@ -10,7 +10,9 @@ import json
 
 import yaml
 
-from .data.synthetic import DatasetReader
+from .data.readers import DatasetReader
+from .data.indexers import Vocabulary
+from .data.iterators import DataIterator
 from .models.decoders import Decoder
 from .models.transformer import Model
 from .modules.criteria import Criterion
@@ -72,6 +74,18 @@ def reader_from_params(p, **extra):
     cls = DatasetReader.by_name(p.pop('type'))
     p.update(extra)
     return cls(**p)
+
+
+def vocabulary_from_params(p):
+    """`vocabulary:` section (config.yaml:22-24: `type: roberta`, directory_path)."""
+    p = dict(p)
+    return Vocabulary.by_name(p.pop('type'))(**p)
+
+
+def iterator_from_params(p):
+    """`iterator:` / `validation_iterator:` sections (config.yaml:99-114: `type: bucket`)."""
+    p = dict(p)
+    return DataIterator.by_name(p.pop('type'))(**p)
 
 
 def trainer_from_params(p, model):

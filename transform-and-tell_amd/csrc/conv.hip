@@ -358,6 +358,30 @@ extern "C" int tell_bn_apply(const void* x, const float* mean, const float* invs
   return tell_check_launch("bn_apply");
 }
 
+// ToTensor + Normalize of the readers (nytimes_faces_ner_matched.py:67-69) on the device: uint8 [B,H,W,3] (decoded
+// pixels as the shards store them) -> float32 [B,3,H,W] = (x / 255 - mean[c]) / std[c], the model's `image` input
+__global__ __launch_bounds__(256) void image_normalize_kernel(const uint8_t* __restrict__ x, float* __restrict__ y,
+                                                              long npix, long hw, float m0, float m1, float m2,
+                                                              float s0, float s1, float s2) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / hw, r = i - b * hw;
+    const uint8_t* p = x + i * 3;
+    float* o = y + b * 3 * hw + r;
+    o[0] = ((float)p[0] * (1.f / 255.f) - m0) / s0;
+    o[hw] = ((float)p[1] * (1.f / 255.f) - m1) / s1;
+    o[2 * hw] = ((float)p[2] * (1.f / 255.f) - m2) / s2;
+  }
+}
+extern "C" int tell_image_normalize(const uint8_t* x, float* y, int B, int H, int W, float m0, float m1, float m2,
+                                    float s0, float s1, float s2, hipStream_t stream) {
+  const long hw = (long)H * W, npix = hw * B;
+  if (npix <= 0) return TELL_OK;
+  TELL_REQUIRE(s0 > 0.f && s1 > 0.f && s2 > 0.f, "image_normalize: std must be positive");
+  int g = (int)((npix + 255) / 256 > 8192 ? 8192 : (npix + 255) / 256);
+  hipLaunchKernelGGL(image_normalize_kernel, dim3(g), dim3(256), 0, stream, x, y, npix, hw, m0, m1, m2, s0, s1, s2);
+  return tell_check_launch("image_normalize");
+}
+
 // 3x3 / stride 2 / pad 1 max pooling, NHWC
 template <typename T>
 __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int OH,

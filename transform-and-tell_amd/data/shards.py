@@ -1,0 +1,72 @@
+"""On-disk shard format of the data plane: the MongoDB documents + JPEG directory of the reference's
+readers (nytimes_faces_ner_matched.py:81-227) replaced by self-contained `.npz` shards, one file per few thousand
+samples, already tokenised (RoBERTa BPE ids) and decoded (uint8 pixels of the 224 x 224 crop that
+scripts/process_images.py:37-39 produces).  Ragged fields are stored concatenated with an offset vector.
+
+    <dir>/<split>-00000.npz
+        context_ids  int32 [sum L]      context_off  int64 [N+1]     (ids incl. <s> ... </s>, <= 512 each)
+        caption_ids  int32 [sum T]      caption_off  int64 [N+1]
+        context_copy int8  [sum L]      caption_copy int8 [sum T]    (entity copy masks of the indexer; optional)
+        image        uint8 [N,224,224,3]
+        face_embeds  float32 [sum F,512]   face_off int64 [N+1]      (F <= 4; 0 rows = the reference's empty [1,0] field)
+        obj_embeds   float32 [sum O,2048]  obj_off  int64 [N+1]      (O <= 64; absent when use_objects is false)
+        metadata     str [N]                                          (JSON: caption, context, web_url, image_path, ...)
+"""
+import glob
+import json
+import os
+
+import numpy as np
+
+
+def write_shard(path, samples):
+    """samples: list of dicts with keys context_ids, caption_ids, image (uint8 HWC), face_embeds [F,512] (F may be 0),
+    optional obj_embeds [O,2048], context_copy / caption_copy, metadata (dict)."""
+    def ragged(key, dtype, width=None):
+        parts = [np.asarray(s[key], dtype=dtype).reshape(-1, width) if width else np.asarray(s[key], dtype=dtype)
+                 for s in samples]
+        off = np.zeros(len(samples) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(p) for p in parts])
+        cat = np.concatenate(parts) if parts else np.zeros((0, width) if width else (0,), dtype=dtype)
+        return cat, off
+    out = {}
+    out['context_ids'], out['context_off'] = ragged('context_ids', np.int32)
+    out['caption_ids'], out['caption_off'] = ragged('caption_ids', np.int32)
+    if all('context_copy' in s for s in samples):
+        out['context_copy'], _ = ragged('context_copy', np.int8)
+        out['caption_copy'], _ = ragged('caption_copy', np.int8)
+    out['image'] = np.stack([np.asarray(s['image'], dtype=np.uint8) for s in samples])
+    out['face_embeds'], out['face_off'] = ragged('face_embeds', np.float32, 512)
+    if all(s.get('obj_embeds') is not None for s in samples):
+        out['obj_embeds'], out['obj_off'] = ragged('obj_embeds', np.float32, 2048)
+    out['metadata'] = np.array([json.dumps(s.get('metadata', {})) for s in samples])
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    np.savez(path, **out)
+
+
+def shard_paths(directory, split):
+    return sorted(glob.glob(os.path.join(directory, '%s-*.npz' % split)))
+
+
+def read_shard(path):
+    """-> list of sample dicts (numpy views into the loaded arrays)."""
+    z = np.load(path, allow_pickle=False)
+    n = len(z['context_off']) - 1
+    has_obj, has_copy = 'obj_embeds' in z.files, 'context_copy' in z.files
+    arrays = {k: z[k] for k in z.files}
+    out = []
+    for i in range(n):
+        c0, c1 = arrays['context_off'][i:i + 2]
+        t0, t1 = arrays['caption_off'][i:i + 2]
+        f0, f1 = arrays['face_off'][i:i + 2]
+        s = {'context_ids': arrays['context_ids'][c0:c1], 'caption_ids': arrays['caption_ids'][t0:t1],
+             'image': arrays['image'][i], 'face_embeds': arrays['face_embeds'][f0:f1],
+             'metadata': json.loads(str(arrays['metadata'][i]))}
+        if has_copy:
+            s['context_copy'] = arrays['context_copy'][c0:c1]
+            s['caption_copy'] = arrays['caption_copy'][t0:t1]
+        if has_obj:
+            o0, o1 = arrays['obj_off'][i:i + 2]
+            s['obj_embeds'] = arrays['obj_embeds'][o0:o1]
+        out.append(s)
+    return out

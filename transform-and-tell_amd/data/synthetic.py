@@ -61,11 +61,9 @@ class DatasetReader(Registrable):
 
 
 @DatasetReader.register('synthetic')
-@DatasetReader.register('nytimes_faces_ner_matched')
-@DatasetReader.register('nytimes')
 class SyntheticReader(DatasetReader):
-    """Answers to the reference readers' registration names but yields synthetic batches
-    (the Mongo/JPEG data plane is a `next` row of SURVEY.md section 8f)."""
+    """Whole synthetic batches of the input contract (bench.py / tests); the readers under the reference's own
+    registration names live in data/readers.py."""
 
     def __init__(self, use_objects=False, batch_size=16, article_len=512, caption_len=33, seed=1234,
                  device='cuda', **unused):

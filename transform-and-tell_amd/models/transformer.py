@@ -209,16 +209,53 @@ class CaptionModel(Model):
         n = sample_size.to(torch.float32)
         loss = (loss_sum / math.log(2) / n).reshape(())                    # :85-88, bits per token
         output_dict = {'loss': loss, 'sample_size': sample_size.reshape(())}
-        if not self.training and self.evaluate_mode:
-            _, gen_ids, attns = self._generate(caption_ids, contexts)
-            output_dict['gen_ids'] = gen_ids.cpu().numpy()
+        if not self.training and self.evaluate_mode:                       # :92-116
+            _, gen_ids, attns = self._generate(caption_ids, contexts, beam_size=getattr(self, 'eval_beam_size', 1))
+            ids_cpu = gen_ids.cpu()
+            output_dict['gen_ids'] = ids_cpu.numpy()
             output_dict['attns'] = attns
+            gen_texts = [self.detokenize(x[x > 1]) for x in ids_cpu]        # :96 "we ignore <s> and <pad>"
+            output_dict['generations'] = gen_texts
             if metadata is not None:
-                output_dict['captions'] = [m.get('caption') for m in metadata]
+                captions = [m.get('caption') or '' for m in metadata]
+                output_dict['captions'] = captions
                 output_dict['metadata'] = metadata
+                import re
+                from ..metrics import BleuScorer
+                gens = [re.sub(r'[^\w\s]', '', t) for t in gen_texts]       # :105-106 remove punctuation
+                refs = [re.sub(r'[^\w\s]', '', t) for t in captions]
+                for gen, ref in zip(gens, refs):                            # :108-116
+                    scorer = BleuScorer(n=4)
+                    scorer += (gen, [ref])
+                    score, _ = scorer.compute_score(option='closest')
+                    for k in range(4):
+                        self.sample_history['bleu-%d' % (k + 1)] += score[k] * 100
         self.n_samples += caption_ids.shape[0]
         self.n_batches += 1
         return output_dict
+
+    def detokenize(self, ids):
+        """`self.roberta.decode(ids)` of the reference (:96): BPE ids -> text.  Uses the encoder's own `decode` when it
+        has one (a fairseq hub model), else the byte-level BPE of the data plane when its files are installed
+        (data/indexers.bpe_directory), else the ids themselves as space-separated words (synthetic data has no text)."""
+        dec = getattr(self.roberta, 'decode', None)
+        if callable(dec):
+            try:
+                return dec(ids)
+            except Exception:                                   # noqa: BLE001 - fall through to the local tokenizer
+                pass
+        bpe = self.__dict__.get('_bpe')
+        if bpe is None:
+            from ..data.bpe import RobertaBPE
+            from ..data.indexers import bpe_directory
+            try:
+                bpe = RobertaBPE(bpe_directory())
+            except FileNotFoundError:
+                bpe = False
+            self.__dict__['_bpe'] = bpe
+        if bpe:
+            return bpe.decode(ids)
+        return ' '.join(str(int(i)) for i in ids if int(i) != 2)
 
     def generate(self, context, image, caption, face_embeds=None, obj_embeds=None, metadata=None, names=None,
                  attn_idx=None, beam_size=1):
