@@ -199,13 +199,17 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
     # every step trains batch i and launches the frozen encoders of batch i+1 underneath it (what a training loop
     # with a data loader does); each timed step therefore contains exactly one encoder pass and one decoder pass
     nxt = lambda i: None if no_pipeline else batches[(i + 1) % 2]     # noqa: E731
+    want_prof = roofline and not args.no_roofline
+    if want_prof:
+        # enabled BEFORE the warm-up: the encoder / decoder hipGraphs are recorded there, and a launch inside a captured
+        # graph can only be timed by what is captured with it (device timestamps around every 4th large GEMM, prof.py)
+        prof.calibrate()
+        prof.enable(True)
     for i in range(args.warmup):
         trainer.train_one_batch(fresh(batches[i % 2]), next_batch=nxt(i))
     sync()
-    want_prof = roofline and not args.no_roofline
     if want_prof:
-        prof.calibrate()
-        prof.enable(True)
+        prof.reset_records()
     dec_ev = []
     t0 = time.perf_counter()
     loss = None
@@ -224,6 +228,8 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
     elapsed = time.perf_counter() - t0
     graph_replays = trainer.step_graph.replays if trainer.step_graph is not None else 0
     prof_concurrent = prof.summary() if want_prof else {}
+    if want_prof and not args.serial:
+        prof_concurrent.update(prof.graph_summary())       # launches replayed from graphs: the last replay of each graph
     prof.enable(False)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -302,19 +308,28 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
                             'command, profiles/' + fn
                     break
         conc = prof_concurrent.get(name) if not args.serial else None
+        iso = {'achieved': round(achieved, 2), 'frac': round(achieved / peak, 4), 'avg_launch_us': round(d['avg_us'], 2),
+               'timed_launches': d['timed']}
+        if conc:        # headline = the kernel INSIDE the timed region (three streams share the CUs there)
+            c_tf = conc['work'] / (conc['total_ms'] * 1e-3) / 1e12
+            head = {'achieved': round(c_tf, 2), 'frac': round(c_tf / peak, 4), 'avg_launch_us': round(conc['avg_us'], 2),
+                    'timed_launches': conc['timed']}
+        else:
+            head = iso
         res['roofline'] = {
-            'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-            'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_note': tnote,
-            'mode': ('single stream (--serial run)' if args.serial else
-                     '%d extra single-stream eager steps after the timed region (a kernel\'s own duration); '
-                     '`in_timed_region` is the same kernel inside the timed region, where three streams share the CUs'
-                     % args.roofline_steps),
-            'launches_per_step': d['launches'] // nsteps, 'avg_launch_us': round(d['avg_us'], 2),
-            'timed_launches': d['timed'],
-            'in_timed_region': ({'avg_launch_us': round(conc['avg_us'], 2),
-                                 'achieved': round(conc['work'] / (conc['total_ms'] * 1e-3) / 1e12, 2),
-                                 'frac': round(conc['work'] / (conc['total_ms'] * 1e-3) / 1e12 / peak, 4)}
-                                if conc else None),
+            'bound': 'mfma', 'kernel': name, 'achieved': head['achieved'], 'peak': peak, 'unit': 'TFLOP/s',
+            'frac': head['frac'], 'traffic': traffic, 'traffic_note': tnote,
+            'mode': ('single stream (--serial run): HIP events' if args.serial else
+                     'in the timed region: this kernel as replayed from the encoder / decoder hipGraphs while three '
+                     'streams share the CUs - every 4th launch records its own execution span (first workgroup in -> '
+                     'last workgroup out, device wall clock at 100 MHz, csrc/gemm.hip gemm_ts_*; HIP events cannot be '
+                     'recorded inside a captured graph on ROCm), last replay of each graph; `isolated` = the same '
+                     'kernel in %d extra single-stream eager steps after the timed region (HIP events)'
+                     % args.roofline_steps) if conc else
+                    ('%d extra single-stream eager steps after the timed region (HIP events)' % args.roofline_steps),
+            'launches_per_step': d['launches'] // nsteps, 'avg_launch_us': head['avg_launch_us'],
+            'timed_launches': head['timed_launches'],
+            'isolated': iso if conc else None,
             'timing': 'HIP events around every 3rd launch of each GEMM kernel (>= 2 GFLOP), on the launch stream; '
                       'event_overhead_us (bracket around a 1-element kernel minus its 1.5 us) is subtracted',
             'event_overhead_us': round(prof.overhead_us(), 2),

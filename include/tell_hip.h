@@ -49,6 +49,12 @@ int tell_set_rng_step_ptr(const void* counter, tell_stream_t stream);
  * while registered, tell_embed_finalize adds *counter to start_pos - one captured decode step serves every position */
 int tell_set_pos_step_ptr(const void* counter, tell_stream_t stream);
 uint32_t tell_drop_threshold_host(float p);
+/* measurement aid (bench.py roofline): rate of the device wall clock in kHz (100 000 on MI355X) */
+int tell_wall_clock_khz(void);
+/* arm the NEXT tell_gemm_nt launch of this thread: its direct-to-LDS / ping-pong kernel records its execution span
+ * into ts[0] (first workgroup in) / ts[1] (last workgroup out), device wall-clock ticks (uint64[2]) */
+int tell_gemm_ts_next(void* ts, tell_stream_t stream);
+int tell_wall_clock_khz(void);
 
 /* ---- GEMM (every nn.Linear / F.linear / 1x1 conv on the path) --------------
  * C[M,N] = act((A[M,K] . B[N,K]^T + bias) * alpha) (+ C if accumulate)

@@ -2,7 +2,7 @@
 # usage (GPU box, repo root): tools/pmc_traffic.sh <kernel-substring> <out.json>
 # HBM traffic per launch of one kernel: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over a short
 # single-stream bench run, averaged over that kernel's dispatches; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md).
-kern=$1; out=$2   # add a "kernel" key with bench.py's short name by hand if bench should pick it up
+kern=$1; out=$2; short=$3; model=${4:-faces_objects}   # short: bench.py's name of the kernel (roofline.kernel)
 root=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -11,9 +11,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
     python $root/bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/pmc_$c.log 2>&1
 done
 cd $root
-python - "$kern" "$out" <<'PY'
+python - "$kern" "$out" "$short" "$model" <<'PY'
 import csv, glob, json, sys
-kern, out = sys.argv[1], sys.argv[2]
+kern, out, short, model = sys.argv[1:5]
 res = {}
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     f = glob.glob('/tmp/pmc_%s/**/*counter_collection.csv' % c, recursive=True)[0]
@@ -27,7 +27,7 @@ fetch_kb, n, name = res['FETCH_SIZE']
 write_kb = res['WRITE_SIZE'][0]
 j = {'command': 'rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --serial --steps 2 --warmup 1 '
                 '--no-cpu-baseline --no-roofline (separate passes)',
-     'kernel_symbol': name, 'dispatches': n, 'FETCH_SIZE_KB_per_launch_raw': round(fetch_kb, 1),
+     'kernel': short, 'model': model, 'kernel_symbol': name, 'dispatches': n, 'FETCH_SIZE_KB_per_launch_raw': round(fetch_kb, 1),
      'WRITE_SIZE_KB_per_launch': round(write_kb, 1),
      'gfx950_correction': 'FETCH_SIZE counts 64 B per 128 B request for wide coalesced reads -> x2 '
                           '(MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncorrected',

@@ -35,3 +35,11 @@ extern "C" int tell_set_pos_step_ptr(const void* counter, hipStream_t) {
 }
 extern "C" uint32_t tell_hash32_host(uint32_t seed, uint32_t salt, uint64_t idx) { return tell_hash32(seed, salt, idx); }
 extern "C" uint32_t tell_drop_threshold_host(float p) { return tell_drop_threshold(p); }
+
+// rate of the device wall clock (wall_clock64) that the GEMM kernels' execution-span stamps use (bench.py roofline)
+extern "C" int tell_wall_clock_khz(void) {
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return khz;
+}

@@ -37,6 +37,7 @@ struct GemmArgs {
   float alpha;            // result = act((acc + bias) * alpha)
   float* asum;            // K-major A only: asum[m] += asum_scale * sum_k A[k][m]  (bias gradient of a wgrad GEMM)
   float asum_scale;
+  unsigned long long* ts; // measurement aid: ts[0] = min over workgroups of the wall clock at entry, ts[1] = max at exit
   int atomic_out;         // fp32 output shared by several workgroups (split K): accumulate with hardware float atomics
   // implicit convolution (direct-to-LDS kernel): A is not a matrix but the NHWC activation [B,H,W,Cin]; row m is output
   // pixel (b, oh, ow), K = KH*KW*Cin in (kh, kw, c) order - each 64-wide K tile lies inside one tap (Cin % 64 == 0), and
@@ -46,6 +47,13 @@ struct GemmArgs {
   float* stat_mean;       // bf16 NT kernels: per (m-tile, column) mean / M2 of the STORED (bf16-rounded) outputs over
   float* stat_m2;         //   the tile's valid rows, [tiles_m][N] each - the first stage of train-mode BatchNorm
 };
+
+// In-kernel execution span (bench.py roofline for launches replayed from hipGraphs, where neither HIP events nor an
+// external profiler can bracket a kernel): every workgroup folds the device wall clock into ts[0] (min at entry) and
+// ts[1] (max at exit) - the interval rocprofv3 reports as the kernel's duration.  tell_gemm_ts_next arms it for the next
+// tell_gemm_nt launch only (the launcher first resets the two words).
+__device__ __forceinline__ void gemm_ts_enter(const GemmArgs& p);
+__device__ __forceinline__ void gemm_ts_exit(const GemmArgs& p);
 
 template <typename T> struct Mma;
 template <> struct Mma<uint16_t> {
@@ -156,6 +164,17 @@ template <> struct Vec4<uint16_t> {
     *reinterpret_cast<u32x2*>(p) = w;
   }
 };
+
+__device__ __forceinline__ void gemm_ts_enter(const GemmArgs& p) {
+  if (p.ts && threadIdx.x == 0) atomicMin(p.ts, (unsigned long long)wall_clock64());
+}
+__device__ __forceinline__ void gemm_ts_exit(const GemmArgs& p) {
+  if (p.ts && threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's stores have left
+    atomicMax(p.ts + 1, (unsigned long long)wall_clock64());
+  }
+}
+__global__ void gemm_ts_reset_kernel(unsigned long long* ts) { ts[0] = ~0ull; ts[1] = 0ull; }
 
 template <typename OutT, int MI, int NI, int ACT>
 __device__ __forceinline__ void gemm_epilogue_act(f32x16 (&acc)[MI][NI], const GemmArgs& p, int mw, int nw, int lane,
@@ -373,6 +392,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(Ge
   static_assert(IA >= 1 && IB >= 1, "tile too small for the wave count");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
 
+  gemm_ts_enter(p);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   int M = p.M;
@@ -541,10 +561,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(Ge
     if (glds_fast_tile(p, m0, n0, BM, BN, M, N)) {       // block-uniform
       glds_store_tile<BM, BN, WM, WN, MI, NI, CS, 64 * NW>(acc, p, m0, n0, wm, wn, lane, tid,
                                                            reinterpret_cast<uint16_t*>(smem));
+      gemm_ts_exit(p);
       return;
     }
   }
   gemm_epilogue<OutT, MI, NI>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, M, N);
+  gemm_ts_exit(p);
 }
 
 // ------------------------------------------------------------- 256x256 ping-pong kernel (bf16, full tiles only)
@@ -568,6 +590,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
   constexpr int BM = 256, BN = 256, BK = 64;
   constexpr int HALF = 128 * 128, TILE = 4 * HALF;        // bytes: one half-tile image, one K tile (A0 A1 B0 B1)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * TILE];
+  gemm_ts_enter(p);
   const int tid = threadIdx.x, lane = tid & 63, lh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -705,6 +728,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
   // every wave has passed its last phase: the tile buffers are free for the staged store
   glds_store_tile<BM, BN, 128, 64, 4, 2, BN, 512, 1>(acc, p, m0, n0, wr, wc, lane, tid,
                                                      reinterpret_cast<uint16_t*>(smem));
+  gemm_ts_exit(p);
 }
 
 // ------------------------------------------------------------- register-staged kernel (any dtype, any K)
@@ -1132,6 +1156,21 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
       return g_gemm_plan ? TELL_OK : tell_check_launch("gemm_nt_glds");
     }
   }
+  // Small bf16 GEMMs (fewer than 256 tiles of 128x128: the decoder's M = T*B = 1024-row chain): the direct-to-LDS kernel
+  // with 64x64 tiles.  Its 32 KB of LDS (the register-staged 64x64 kernel below takes 36.9 KB) lets a workgroup share a
+  // CU with a 256x256 ping-pong workgroup of the RoBERTa stream (128 KB of the CU's 160 KB): the decoder chain then runs
+  // UNDER the encoder GEMMs instead of taking turns with them at CU granularity (+0.5 % samples/s at configs[2]).  Not
+  // for the decode step's M <= 128 rows: with a handful of workgroups the 4-deep register prefetch of the kernel below
+  // wins (11.8 us against 20 us per launch).  TELL_GEMM_SMALL=0 restores the register-staged kernel everywhere (A/B).
+  if constexpr (sizeof(T) == 2) {
+    static const bool small_glds = !(getenv("TELL_GEMM_SMALL") && atoi(getenv("TELL_GEMM_SMALL")) == 0);
+    if (small_glds && a.M >= 512 && a.K <= 2048 && a.K % 64 == 0 && !a.stat_mean &&   // (K = 4096: 35.6 us against 23.7 us) (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(a.B) & 15) == 0 && (a.lda & 7) == 0 && (a.ldb & 7) == 0) {
+      *bm_used = 64;
+      TELL_GEMM_LAUNCH(gemm_label("gemm_nt_glds_kernel", -1, sizeof(OutT) == 2, 64, 64), (gemm_nt_glds_kernel<OutT, 64, 64, 2, 2>), dim3((unsigned)tiles(64, 64)), dim3(256));
+      return g_gemm_plan ? TELL_OK : tell_check_launch("gemm_nt_glds");
+    }
+  }
   // (a 256x256 register-staged tile measured slower than 256x128 - 236 VGPRs, one workgroup per CU - and
   //  was removed)
   *bm_used = (sizeof(T) == 2 && tiles(256, 128) >= 256) ? 256 : tiles(128, 128) >= 256 ? 128 : 64;
@@ -1143,6 +1182,12 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
     TELL_GEMM_LAUNCH(gemm_label("gemm_nt_kernel", sizeof(T) == 2, sizeof(OutT) == 2, 64, 64), (gemm_nt_kernel<T, OutT, 64, 64, 2, 2, 4>), dim3((unsigned)tiles(64, 64)), dim3(256));
   }
   return g_gemm_plan ? TELL_OK : tell_check_launch("gemm_nt");
+}
+
+static thread_local unsigned long long* g_gemm_ts_next = nullptr;
+extern "C" int tell_gemm_ts_next(void* ts, hipStream_t) {
+  g_gemm_ts_next = static_cast<unsigned long long*>(ts);
+  return TELL_OK;
 }
 
 extern "C" int tell_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc,
@@ -1164,7 +1209,12 @@ extern "C" int tell_gemm_nt(const void* A, long lda, const void* B, long ldb, vo
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux; a.m_dev = m_dev;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
   a.bias_mode = bias_mode; a.act = act; a.accumulate = accumulate; a.alpha = alpha;
-  a.asum = nullptr; a.asum_scale = 0.f; a.stat_mean = nullptr; a.stat_m2 = nullptr; a.atomic_out = 0; a.conv_zero = nullptr;
+  a.asum = nullptr; a.asum_scale = 0.f; a.stat_mean = nullptr; a.stat_m2 = nullptr; a.atomic_out = 0; a.ts = nullptr; a.conv_zero = nullptr;
+  if (g_gemm_ts_next && !g_gemm_plan) {
+    a.ts = g_gemm_ts_next;
+    g_gemm_ts_next = nullptr;
+    hipLaunchKernelGGL(gemm_ts_reset_kernel, dim3(1), dim3(1), 0, stream, a.ts);
+  }
   if (in_dtype == TELL_BF16)
     return out_dtype == TELL_BF16 ? launch_gemm<uint16_t, uint16_t>(a, stream)
                                   : launch_gemm<uint16_t, float>(a, stream);
@@ -1210,7 +1260,7 @@ extern "C" int tell_gemm_bf16(const void* A, long lda, int trans_a, const void* 
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux; a.m_dev = m_dev;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
   a.bias_mode = bias_mode; a.act = act; a.accumulate = accumulate; a.alpha = alpha;
-  a.asum = a_colsum; a.asum_scale = a_colsum_scale; a.stat_mean = nullptr; a.stat_m2 = nullptr; a.atomic_out = 0; a.conv_zero = nullptr;
+  a.asum = a_colsum; a.asum_scale = a_colsum_scale; a.stat_mean = nullptr; a.stat_m2 = nullptr; a.atomic_out = 0; a.ts = nullptr; a.conv_zero = nullptr;
   if (trans_a && trans_b)
     return out_dtype == TELL_BF16 ? launch_gemm_tx<uint16_t, true, true>(a, stream) : launch_gemm_tx<float, true, true>(a, stream);
   if (trans_b)
@@ -1235,7 +1285,7 @@ extern "C" int tell_gemm_bn_stats(const void* A, long lda, const void* B, long l
   GemmArgs a;
   a.A = A; a.B = B; a.C = C; a.bias = nullptr; a.aux = nullptr; a.m_dev = nullptr;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
-  a.bias_mode = 0; a.act = 0; a.accumulate = 0; a.alpha = 1.f; a.asum = nullptr; a.asum_scale = 0.f; a.atomic_out = 0; a.conv_zero = nullptr;
+  a.bias_mode = 0; a.act = 0; a.accumulate = 0; a.alpha = 1.f; a.asum = nullptr; a.asum_scale = 0.f; a.atomic_out = 0; a.ts = nullptr; a.conv_zero = nullptr;
   const long max_tiles = ((long)M + 63) / 64;
   a.stat_mean = workspace;
   a.stat_m2 = workspace + max_tiles * N;
@@ -1278,6 +1328,7 @@ extern "C" int tell_conv_bn_stats(const void* X, const void* Wt, void* Y, int B,
   a.A = X; a.B = Wt; a.C = Y; a.bias = nullptr; a.aux = nullptr; a.m_dev = nullptr;
   a.lda = Cin; a.ldb = K; a.ldc = N; a.M = M; a.N = N; a.K = K;
   a.bias_mode = 0; a.act = 0; a.accumulate = 0; a.alpha = 1.f; a.asum = nullptr; a.asum_scale = 0.f; a.atomic_out = 0;
+  a.ts = nullptr;
   a.conv_zero = (KH == 1 && stride == 1) ? nullptr : zero_page;          // 1x1 / stride 1: A is the activation matrix
   a.conv_H = H; a.conv_W = W; a.conv_OH = OH; a.conv_OW = OW; a.conv_KW = KW; a.conv_stride = stride; a.conv_pad = pad;
   a.conv_cshift = cshift;

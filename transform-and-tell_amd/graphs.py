@@ -56,6 +56,8 @@ class GraphedCall:
             return self.fn(x)
         s = e['slots'][e['turn']]
         e['turn'] = (e['turn'] + 1) % len(e['slots'])
+        s['generation'] = s.get('generation', 0) + 1       # consumers holding this slot's output can detect reuse
+        self.last_slot = s
         s['static_in'].copy_(x)
         if s['counter'] is not None:
             s['counter'].fill_(e['replays'])            # same stream as the replay: ordered before it

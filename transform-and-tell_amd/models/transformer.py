@@ -24,6 +24,11 @@ class EncodedBatch:
         self.stack = self.x_image = self.article_mask = None
         self.events = []
         self.static = False      # stack / x_image are graph-owned static buffers (stable addresses across steps)
+        self.slots = []          # (graph slot, generation at production): a later replay of the slot overwrites the data
+
+    def stale(self):
+        """True when a graph replay issued after this batch was encoded has reused one of its output buffers."""
+        return any(s.get('generation') != g for s, g in self.slots)
 
     def wait(self):
         """Join the producing streams into the current stream (idempotent)."""
@@ -82,6 +87,18 @@ class CaptionModel(Model):
         self.n_batches = 0
         self.n_samples = 0
         self.sample_history = defaultdict(float)
+        # captured encoder / decode graphs bake in the addresses of working copies of the weights: anything that can
+        # re-home those copies (a checkpoint load, a trainer re-flagging requires_grad) drops the captures
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.reset_graphs())
+
+    def reset_graphs(self):
+        """Forget every captured hipGraph of this model (encoders, decode steps); they are re-recorded on next use."""
+        for k in ('_resnet_graph', '_roberta_graph'):
+            g = self.__dict__.get(k)
+            if g is not None:
+                g.reset()
+        self.__dict__.pop('_decode_graphs', None)
+        self.__dict__.pop('_decode_graphs_stamp', None)
 
     def _run_resnet(self, image):
         """The frozen trunk as one hipGraph replay per step (graphs.GraphedCall); eager for the first call."""
@@ -137,6 +154,7 @@ class CaptionModel(Model):
                     enc.events.append(torch.cuda.Event())
                     enc.events[-1].record(is_)
                 enc.static = self._encoders_replayed()
+                self._note_slots(enc)
                 return enc
             side = _side_stream(image.device, 'resnet') if _OVERLAP else None
             enc.article_mask = article_ids == self.padding_idx                         # :347
@@ -155,10 +173,17 @@ class CaptionModel(Model):
             else:
                 enc.x_image = self._run_resnet(image)
             enc.static = self._encoders_replayed()
+            self._note_slots(enc)
             return enc
 
     def _encoders_replayed(self):
         return all(getattr(self.__dict__.get(k), 'last_replayed', False) for k in ('_resnet_graph', '_roberta_graph'))
+
+    def _note_slots(self, enc):
+        for k in ('_resnet_graph', '_roberta_graph'):
+            g = self.__dict__.get(k)
+            if g is not None and getattr(g, 'last_replayed', False):
+                enc.slots.append((g.last_slot, g.last_slot['generation']))
 
     # ---- :311-397 -----------------------------------------------------------------
     def _forward(self, context, image, caption, face_embeds=None, obj_embeds=None, encoded=None):

@@ -78,15 +78,18 @@ def gemm(a, b, out=None, out_dtype=None, bias=None, bias_mode=0, act=0, aux=None
     assert out.stride(1) == 1
     args = (a, a.stride(0), b, b.stride(0), out, out.stride(0), M, N, a.shape[1], hip.dt(a), hip.dt(out), bias, bias_mode,
             act, aux, float(alpha), int(accumulate), m_dev)
-    rec = None
-    if prof.enabled() and m_dev is None and 2.0 * M * N * a.shape[1] >= prof.MIN_WORK and \
-            not torch.cuda.is_current_stream_capturing():      # timing events cannot live inside a captured graph
+    rec = slot = None
+    if prof.enabled() and m_dev is None and 2.0 * M * N * a.shape[1] >= prof.MIN_WORK:
         kname = hip.query('tell_gemm_nt_plan', *args)          # the library names the kernel it is about to launch
-        if prof.sampled(kname):
+        if torch.cuda.is_current_stream_capturing():           # no events inside a captured graph: device timestamps
+            slot = prof.graph_begin(kname, 2.0 * M * N * a.shape[1])
+        elif prof.sampled(kname):
             rec = prof.begin(kname, 2.0 * M * N * a.shape[1])
     call('tell_gemm_nt', *args)
     if rec is not None:
         prof.end(rec)
+    if slot is not None:
+        prof.graph_end(slot)
     return out
 
 

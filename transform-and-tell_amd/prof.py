@@ -18,6 +18,67 @@ def enable(flag=True):
         _seen.clear()
 
 
+def reset_records():
+    """Forget the event-bracketed samples so far (the stamps inside captured graphs stay: they are part of the graphs)."""
+    _records.clear()
+    _seen.clear()
+
+
+# ---- launches inside captured hipGraphs: the kernel records its own execution span (csrc/gemm.hip gemm_ts_*) --------
+GRAPH_SAMPLE = 4          # every 4th qualifying launch records its execution span
+_g = {'buf': None, 'n': 0, 'slots': [], 'seen': {}, 'khz': 0}
+
+
+def graph_begin(name, work):
+    """Called while a stream is capturing: -> slot index if this launch is sampled (the caller launches the kernel and
+    then calls graph_end(slot)), else None."""
+    from . import hip
+    n = _g['seen'].get(name, 0)
+    _g['seen'][name] = n + 1
+    if n % GRAPH_SAMPLE:
+        return None
+    if _g['buf'] is None:
+        _g['buf'] = torch.zeros(2 * 4096, dtype=torch.int64, device='cuda')
+        _g['khz'] = hip.lib().tell_wall_clock_khz()
+    i = _g['n']
+    if i >= 4096:
+        return None
+    _g['n'] = i + 1
+    _g['slots'].append((name, work))
+    # the kernel itself records [first workgroup in, last workgroup out] (csrc/gemm.hip gemm_ts_enter / gemm_ts_exit):
+    # the interval an external profiler reports as the kernel's duration, without the dispatch waits a bracket of
+    # neighbouring launches would add when other streams keep the CUs busy
+    hip.call('tell_gemm_ts_next', _g['buf'][2 * i:])
+    return i
+
+
+def graph_end(i):
+    pass
+
+
+def graph_summary():
+    """-> {kernel: dict(timed, total_ms, avg_us, work)} from the stamps of the LAST replay of every captured graph;
+    call after torch.cuda.synchronize()."""
+    out = {}
+    if _g['buf'] is None or not _g['khz']:
+        return out
+    v = _g['buf'][:2 * _g['n']].tolist()
+    for i, (name, work) in enumerate(_g['slots']):
+        t0, t1 = v[2 * i], v[2 * i + 1]
+        if t0 == 0 or t1 <= t0:
+            continue                                   # a graph that was captured but not replayed since
+        if t0 < 0 or t1 < 0:
+            continue                                   # (~0 as int64): armed but the kernel had no timestamp hooks
+        ms = max(t1 - t0, 1.0) / _g['khz']
+        d = out.setdefault(name, dict(timed=0, total_ms=0.0, work=0.0))
+        d['timed'] += 1
+        d['total_ms'] += ms
+        d['work'] += work
+    for d in out.values():
+        d['avg_us'] = 1e3 * d['total_ms'] / max(d['timed'], 1)
+    return out
+
+
 def enabled():
     return _enabled
 

@@ -40,6 +40,8 @@ class Trainer:
         self.rank = self.dist.get_rank() if self.dist else 0
         self.model = model.to(device)
         apply_no_grad(model, no_grad)
+        if hasattr(model, 'reset_graphs'):           # requires_grad flags decide where the working weight copies live
+            model.reset_graphs()
         self.flat = FlatParams(model.named_parameters(), device)
         cfg = dict(lr=1e-4, warmup=0.05, t_total=437600, schedule='warmup_linear', b1=0.9, b2=0.98, e=1e-6,
                    weight_decay=1e-5, max_grad_norm=0.1)                 # config.yaml:126-136
@@ -55,6 +57,10 @@ class Trainer:
                                                  torch.device(device).type == 'cuda' and
                                                  os.environ.get('TELL_ALLREDUCE_FP32') != '1') else torch.float32
         self.allreduce_dtype, self._wire = allreduce_dtype, None
+        if self.dp and self.rank:
+            # every rank draws its own dropout masks: the counter-hash seed is process-global with the same default on
+            # all ranks (runtime.py); offset it once here instead of relying on every caller to do so
+            rt.manual_seed(rt.seed() + 0x9E3779B1 * self.rank, rt._state['salt'])
         if self.dp:                           # identical initial weights on every rank
             self.dist.broadcast(self.flat.flat, src=0)
             self.flat.refresh_shadow()
@@ -137,8 +143,8 @@ class Trainer:
 
     def _encoded_for(self, batch):
         pre, self._prefetched = getattr(self, '_prefetched', None), None
-        if pre is not None and pre[0] is batch.get('image'):
-            return pre[1]
+        if pre is not None and pre[0] is batch.get('image') and not pre[1].stale():
+            return pre[1]           # (stale: other encode() / generate() calls in between reused the graph's buffers)
         return None
 
     def _train_one_batch(self, batch, next_batch=None):
