@@ -39,8 +39,9 @@ int tell_abi_version(void);
 int tell_device_count(void);
 const char* tell_last_error(void);
 void tell_set_error(const char* msg);
-/* host evaluation of the dropout hash / threshold used by every kernel (csrc/common.h) */
-uint32_t tell_hash32_host(uint32_t seed, uint32_t salt, uint64_t idx);
+/* host evaluation of the dropout RNG / threshold used by every kernel (csrc/common.h): the 16-bit field element idx
+ * is judged by (kept iff field >= threshold) */
+uint32_t tell_keep_field_host(uint32_t seed, uint32_t salt, uint64_t idx);
 /* hipGraph capture of kernels with dropout: while `counter` (device uint32) is registered, every RNG kernel adds
  * counter * odd-constant to its salt, so a captured graph draws fresh masks after the owner increments it;
  * NULL (default) = eager behaviour.  The stream argument is ignored (uniform binding signature). */
@@ -101,6 +102,14 @@ int tell_wn_weight(const float* g, const float* v, int rows, int cols, void* w, 
                    tell_stream_t stream);
 int tell_wn_backward(const float* dW, const float* g, const float* v, const float* norms, int rows, int cols,
                      float* dg, float* dv, tell_stream_t stream);
+/* The same two passes over n GehringLinears in ONE launch (per 32 tensors).  Every array argument is a HOST array of
+   n entries: device pointers (g [rows], v [rows, cols], w [rows, cols], norms [rows], dW / dv [rows, cols],
+   dg [rows]) or sizes. */
+int tell_wn_weight_multi(int n, const void* const* g, const void* const* v, void* const* w, void* const* norms,
+                         const int* rows, const int* cols, int out_dtype, tell_stream_t stream);
+int tell_wn_backward_multi(int n, const void* const* dW, const void* const* g, const void* const* v,
+                           const void* const* norms, const int* rows, const int* cols, void* const* dg,
+                           void* const* dv, tell_stream_t stream);
 
 /* ---- elementwise ------------------------------------------------------------ */
 /* nn.GLU, decoder_faces_objects.py:194-195,259-261: h = [a | gate] */
@@ -183,6 +192,8 @@ int tell_attn_fwd(const void* q, const void* k, const void* v, void* out, float*
                   const void* bias_k, const void* bias_v, int B, int H, int Tq, int S, int D, long q_st,
                   long q_sb, long k_ss, long k_sb, long v_ss, long v_sb, long o_st, long o_sb, int has_zero,
                   float p, uint32_t seed, uint32_t salt, int dtype, tell_stream_t stream);
+/* dbias_k / dbias_v: fp32 [B, H*D] per-sample partials of the bias_k / bias_v gradients (the caller sums over B), each
+   with row stride H*D - or, when dbias_v == dbias_k + H*D, the two column halves of one [B, 2*H*D] buffer. */
 int tell_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                   const float* lse, const uint8_t* mask, const void* bias_k, const void* bias_v, void* dq,
                   void* dk, void* dv, float* dbias_k, float* dbias_v, int B, int H, int Tq, int S, int D,

@@ -43,15 +43,38 @@ def test_rng_restatement_matches_c():
     import tell_amd
     from tell_amd import rng
     lib = tell_amd.hip.lib()
-    idx = np.array([0, 1, 2, 63, 64, 1000, 2 ** 31 - 1, 2 ** 32 + 5, 2 ** 40 + 123, 2 ** 63 - 1], dtype=np.uint64)
+    idx = np.array([0, 1, 2, 3, 4, 5, 6, 7, 63, 64, 1001, 1002, 2 ** 31 - 1, 2 ** 32 + 5, 2 ** 34 + 6, 2 ** 40 + 123,
+                    2 ** 63 - 1], dtype=np.uint64)
     for seed, salt in [(0, 0), (0x5EED, 1), (123456789, 4000000000), (0xFFFFFFFF, 0xFFFFFFFF)]:
-        want = np.array([lib.tell_hash32_host(seed, salt, int(i)) for i in idx], dtype=np.uint64)
-        got = rng.hash32(seed, salt, idx)
+        want = np.array([lib.tell_keep_field_host(seed, salt, int(i)) for i in idx], dtype=np.uint64)
+        got = rng.keep_field(seed, salt, idx)
         assert (got == want).all(), (seed, salt)
     for p in (0.0, 0.1, 0.25, 0.5, 0.999):
         assert int(rng.threshold(p)) == lib.tell_drop_threshold_host(p)
-    m = rng.keep_mask(7, 9, 200000, 0.1)
-    assert abs(m.mean() - 0.9) < 5e-3
+
+
+def test_rng_statistics():
+    """The quad hash shares one mix between four decisions: keep rate, the joint distribution of a quad's four
+    decisions, correlations along the index and across salts / seeds / graph steps have to look independent."""
+    from tell_amd import rng
+    n = 1 << 22
+    sd = 1.0 / np.sqrt(n)
+    for seed, salt in ((1, 2), (12345, 999), (0, 0)):
+        for p in (0.1, 0.5):
+            k = rng.keep_mask(seed, salt, n, p)
+            kp = 1.0 - float(rng.threshold(p)) / 65536.0
+            assert abs(k.mean() - kp) < 5 * np.sqrt(kp * (1 - kp)) * sd
+            q = k.reshape(-1, 4).astype(np.int64)
+            cnt = np.bincount(q[:, 0] + 2 * q[:, 1] + 4 * q[:, 2] + 8 * q[:, 3], minlength=16).astype(float)
+            exp = np.array([np.prod([kp if (i >> j) & 1 else 1 - kp for j in range(4)]) for i in range(16)]) * len(q)
+            assert ((cnt - exp) ** 2 / exp).sum() < 45.0           # chi2, 15 dof: p ~ 1e-4
+            kc = k - k.mean()
+            for lag in (1, 2, 3, 4, 8, 512, 513):
+                assert abs(float((kc[:-lag] * kc[lag:]).mean() / kc.var())) < 6 * sd
+    base = rng.keep_mask(5, 100, n, 0.1)
+    step_salt = (100 + 1 * 0x632BE5AB) & 0xFFFFFFFF                # tell_step_salt: the next replay of a captured graph
+    for other in (rng.keep_mask(5, 101, n, 0.1), rng.keep_mask(6, 100, n, 0.1), rng.keep_mask(5, step_salt, n, 0.1)):
+        assert abs(np.corrcoef(base, other)[0, 1]) < 6 * sd
 
 
 def test_warmup_linear_and_flat_layout():

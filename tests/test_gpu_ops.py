@@ -248,6 +248,45 @@ def test_gehring_linear_golden(golden, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+def test_weight_norm_many_tensors_one_launch(dtype):
+    """wn_prepare + deferred chain rule (one launch each over all GehringLinears) == the per-layer kernels, bit for bit,
+    across more tensors than one launch carries (32) and ragged shapes."""
+    import tell_amd
+    from tell_amd import ops
+    tell_amd.set_compute_dtype(dtype)
+    torch.manual_seed(3)
+    shapes = [(40, 24), (7, 130), (64, 64), (128, 1024)] * 9                     # 36 tensors
+    gs = [torch.nn.Parameter((torch.rand(r, 1) + 0.5).to(DEV)) for r, _ in shapes]
+    vs = [torch.nn.Parameter(torch.randn(r, c).to(DEV)) for r, c in shapes]
+    xs = [torch.randn(16, c, device=DEV, dtype=dtype) for _, c in shapes]
+
+    def run(batched):
+        ops.clear_weight_cache()
+        for p in gs + vs:
+            p.grad = None
+        if batched:
+            ops.wn_prepare(list(zip(gs, vs)))
+            ops.wn_defer(True)
+        ws, outs = [], []
+        for g, v, x in zip(gs, vs, xs):
+            ws.append(ops.wn_weight(g, v))
+            xr = x.clone().requires_grad_(True)
+            y = ops.wn_linear(xr, g, v)
+            y.backward(torch.ones_like(y))
+            outs.append(xr.grad)
+        ops.wn_defer(False)
+        ops.wn_flush()
+        return ws, outs, [p.grad.clone() for p in gs + vs]
+
+    w0, dx0, g0 = run(False)
+    w1, dx1, g1 = run(True)
+    for (wa, na), (wb, nb) in zip(w0, w1):
+        assert torch.equal(wa, wb) and torch.equal(na, nb)
+    for a, b in zip(dx0 + g0, dx1 + g1):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_glu_dropout_layernorm(dtype):
     import tell_amd
     from tell_amd import ops, rng

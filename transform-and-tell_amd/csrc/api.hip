@@ -33,7 +33,7 @@ extern "C" int tell_set_pos_step_ptr(const void* counter, hipStream_t) {
   g_tell_pos_step = static_cast<const uint32_t*>(counter);
   return TELL_OK;
 }
-extern "C" uint32_t tell_hash32_host(uint32_t seed, uint32_t salt, uint64_t idx) { return tell_hash32(seed, salt, idx); }
+extern "C" uint32_t tell_keep_field_host(uint32_t seed, uint32_t salt, uint64_t idx) { return tell_keep_field(seed, salt, idx); }
 extern "C" uint32_t tell_drop_threshold_host(float p) { return tell_drop_threshold(p); }
 
 // rate of the device wall clock (wall_clock64) that the GEMM kernels' execution-span stamps use (bench.py roofline)

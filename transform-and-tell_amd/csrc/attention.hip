@@ -96,7 +96,8 @@ struct AttnArgs {
   // backward only
   const void *dout, *o;           // same layout as out
   void *dq, *dk, *dv;             // same layouts as q, k, v
-  float *dbias_k, *dbias_v;       // [B, H*D] fp32 partials (summed over b by the caller)
+  float *dbias_k, *dbias_v;       // [B, H*D] fp32 partials (summed over b by the caller), row stride dbias_ld
+  long dbias_ld;
 };
 
 // ------------------------------------------------------------------ forward
@@ -650,19 +651,22 @@ __global__ __launch_bounds__(256) void attn_fwd_reg_kernel(AttnArgs p) {
       // Dropout only SELECTS here (kept probability or 0); the 1/(1-p) factor is applied once to the output row.
       if constexpr (DROP) {
         const uint64_t base = ((uint64_t)bh * p.Tq + t) * S_total + s0 + 4 * hh;
-        if ((S_total & 1) == 0 && tell_keep_row_ok(base >> 1, 32)) {
-          // pair offsets visited: d = 0 1 4 5 8 9 12 13 16 17 ... 29 -> one running hash input, += stride or 3 strides
-          const TellKeepRow row = tell_keep_row(p.seed, salt_eff, base >> 1);    // base is even here
+        if ((S_total & 3) == 0 && tell_keep_row_ok(base >> 2, 16)) {
+          // the lane's keys come in aligned quads: 4 hh + 8 m + {0..3}, m = 0..7 -> quad offsets 0, 2, 4, ... 14:
+          // one running hash input, += two quad strides per step, four decisions per hash
+          const TellKeepRow row = tell_keep_row(p.seed, salt_eff, base >> 2);    // base is a multiple of 4 here
           uint32_t x = row.x0;
 #pragma unroll
           for (int f = 0; f < 2; ++f)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-              bool k0, k1;
-              tell_keep2_bits(x, row.y, p.thr, k0, k1);     // == tell_keep2_row(row, (f*32 + (r&3) + 8*(r>>2)) >> 1, ...)
+            for (int r = 0; r < 16; r += 4) {
+              bool k0, k1, k2, k3;
+              tell_keep4_bits(x, row.y, p.thr, k0, k1, k2, k3);   // elements base + f*32 + 8*(r>>2) + {0,1,2,3}
               st[f][r] = k0 ? st[f][r] : 0.f;
               st[f][r + 1] = k1 ? st[f][r + 1] : 0.f;
-              x += (r & 2) ? 3u * TELL_PAIR_STRIDE : TELL_PAIR_STRIDE;
+              st[f][r + 2] = k2 ? st[f][r + 2] : 0.f;
+              st[f][r + 3] = k3 ? st[f][r + 3] : 0.f;
+              x += 2u * TELL_QUAD_STRIDE;
             }
         } else if ((S_total & 1) == 0) {
 #pragma unroll
@@ -876,8 +880,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(AttnArgs p) {
                 if (qb == 0) { Elem<T>::st(pk, dk[r]); Elem<T>::st(pv_, dv[r]); }
                 else { Elem<T>::st(pk, Elem<T>::ld(pk) + dk[r]); Elem<T>::st(pv_, Elem<T>::ld(pv_) + dv[r]); }
               } else if (s == p.S && p.has_bias) {
-                float* gk = p.dbias_k + (long)b * p.H * D + (long)h * D + d;
-                float* gv = p.dbias_v + (long)b * p.H * D + (long)h * D + d;
+                float* gk = p.dbias_k + (long)b * p.dbias_ld + (long)h * D + d;
+                float* gv = p.dbias_v + (long)b * p.dbias_ld + (long)h * D + d;
                 if (qb == 0) { *gk = dk[r]; *gv = dv[r]; }
                 else { *gk += dk[r]; *gv += dv[r]; }
               }
@@ -967,7 +971,7 @@ static int fill_args(AttnArgs& a, const void* q, const void* k, const void* v, v
   a.o_st = o_st; a.o_sb = o_sb; a.B = B; a.H = H; a.Tq = Tq; a.S = S;
   a.has_bias = bias_k ? 1 : 0; a.has_zero = has_zero;
   a.thr = p > 0.f ? tell_drop_threshold(p) : 0u; a.inv_keep = 1.f / (1.f - p); a.seed = seed; a.salt = salt; a.step = g_tell_rng_step;
-  a.dout = nullptr; a.o = nullptr; a.dq = a.dk = a.dv = nullptr; a.dbias_k = a.dbias_v = nullptr;
+  a.dout = nullptr; a.o = nullptr; a.dq = a.dk = a.dv = nullptr; a.dbias_k = a.dbias_v = nullptr; a.dbias_ld = 0;
   return TELL_OK;
 }
 
@@ -1025,6 +1029,9 @@ extern "C" int tell_attn_bwd(const void* q, const void* k, const void* v, const 
   if (rc) return rc;
   TELL_REQUIRE(!bias_k || (dbias_k && dbias_v), "attention bwd: dbias buffers required with bias rows");
   a.dout = dout; a.o = out; a.dq = dq; a.dk = dk; a.dv = dv; a.dbias_k = dbias_k; a.dbias_v = dbias_v;
+  // the two partial buffers may be the halves of ONE [B, 2 H D] buffer (dbias_v == dbias_k + H D): one column-sum
+  // launch then folds both bias gradients
+  a.dbias_ld = (dbias_k && dbias_v == dbias_k + (long)H * D) ? 2L * H * D : (long)H * D;
   dim3 grid(B * H);
   if (dtype == TELL_BF16) {
     if (D == 64) hipLaunchKernelGGL((attn_bwd_kernel<uint16_t, 64, 4>), grid, dim3(256), 0, stream, a);

@@ -104,15 +104,39 @@ __device__ __forceinline__ uint32_t tell_step_salt(uint32_t salt, const uint32_t
 }
 
 // ---------------------------------------------------------------- counter-based RNG for dropout
-// Stateless.  One 32-bit hash serves an aligned PAIR of element indices (2i, 2i+1): element idx keeps iff
-// the 16-bit half (idx & 1) of hash(seed, salt, idx >> 1) is >= floor(p * 2^16).  Kernels whose lanes own
-// consecutive elements (attention probabilities, vectorised rows) so pay one hash per two decisions.  The
-// same functions are restated in numpy (tell_amd/rng.py) so tests can rebuild masks.
-__device__ __host__ __forceinline__ uint32_t tell_hash32(uint32_t seed, uint32_t salt, uint64_t idx) {
-  uint32_t x = (uint32_t)idx * 0x9E3779B1u + seed;
-  const uint32_t y = (uint32_t)(idx >> 32) * 0x85EBCA77u + salt * 0xC2B2AE3Du + 0x27D4EB2Fu;
-  x ^= y; x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+// Stateless.  One hash serves an aligned QUAD of element indices (4i .. 4i+3): a shared 32-bit mix of
+// (seed, salt, i) - one full-rate-unfriendly 32-bit multiply - followed by two cheap finalisers, each a 24-bit
+// multiply (v_mul_u32_u24, full rate) of one 24-bit window of the mix and a xor-shift.  Finaliser a carries the
+// 16-bit fields of elements 0 (low half) and 1 (high half), finaliser b those of elements 2 and 3; element idx is
+// kept iff its field is >= floor(p * 2^16).  Kernels whose lanes own consecutive elements (attention probabilities,
+// vectorised rows) pay one mix per four decisions; the RoBERTa self-attention kernel, where the hash is the larger
+// half of the VALU work, is what this shape is for (56 issue cycles per two decisions against 96 for a full
+// two-multiply hash per pair).  The same functions are restated in numpy (tell_amd/rng.py) so tests can rebuild
+// masks; tests/test_abi_and_host.py checks keep rate, joint quad patterns and lag correlations.
+__device__ __host__ __forceinline__ uint32_t tell_quad_x(uint32_t seed, uint64_t quad) {
+  return (uint32_t)quad * 0x9E3779B1u + seed * 0x85EBCA6Bu;
+}
+__device__ __host__ __forceinline__ uint32_t tell_quad_y(uint32_t salt, uint64_t quad) {
+  return (uint32_t)(quad >> 32) * 0x85EBCA77u + salt * 0xC2B2AE3Du + 0x27D4EB2Fu;
+}
+__device__ __host__ __forceinline__ uint32_t tell_quad_mix(uint32_t x, uint32_t y) {
+  x ^= y; x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15;
   return x;
+}
+__device__ __host__ __forceinline__ uint32_t tell_quad_a(uint32_t h) {       // elements 0, 1
+  const uint32_t a = (h & 0xffffffu) * 0xD1B54Bu;
+  return a ^ (a >> 15);
+}
+__device__ __host__ __forceinline__ uint32_t tell_quad_b(uint32_t h) {       // elements 2, 3
+  const uint32_t b = (h >> 8) * 0xA54FF5u;
+  return b ^ (b >> 15);
+}
+// the 16-bit field element idx is judged by
+__device__ __host__ __forceinline__ uint32_t tell_keep_field(uint32_t seed, uint32_t salt, uint64_t idx) {
+  const uint64_t quad = idx >> 2;
+  const uint32_t h = tell_quad_mix(tell_quad_x(seed, quad), tell_quad_y(salt, quad));
+  const uint32_t w = (idx & 2) ? tell_quad_b(h) : tell_quad_a(h);
+  return (idx & 1) ? (w >> 16) : (w & 0xffffu);
 }
 __device__ __host__ __forceinline__ uint32_t tell_drop_threshold(float p) {   // 16-bit: 0 = no dropout
   double t = (double)p * 65536.0;
@@ -123,43 +147,38 @@ __device__ __host__ __forceinline__ uint32_t tell_drop_threshold(float p) {   //
 // returns the multiplicative keep factor: 0 or 1/(1-p)
 __device__ __forceinline__ float tell_keep(uint32_t seed, uint32_t salt, uint64_t idx, uint32_t thr,
                                            float inv_keep) {
-  const uint32_t h = tell_hash32(seed, salt, idx >> 1);
-  const uint32_t bits = (idx & 1) ? (h >> 16) : (h & 0xffffu);
-  return bits >= thr ? inv_keep : 0.f;
-}
-// Consecutive pairs of one row: the index-dependent part of the hash input is linear in the pair index, so a
-// kernel that walks pair_idx0 + d for small compile-time d pays one add per pair instead of two multiplies.
-// Valid while the low word of the pair index does not wrap (caller checks tell_keep_row_ok).
-struct TellKeepRow { uint32_t x0, y; };
-__device__ __forceinline__ bool tell_keep_row_ok(uint64_t pair_idx0, uint32_t span) {
-  return (uint32_t)pair_idx0 <= 0xFFFFFFFFu - span;
-}
-__device__ __forceinline__ TellKeepRow tell_keep_row(uint32_t seed, uint32_t salt, uint64_t pair_idx0) {
-  TellKeepRow r;
-  r.x0 = (uint32_t)pair_idx0 * 0x9E3779B1u + seed;
-  r.y = (uint32_t)(pair_idx0 >> 32) * 0x85EBCA77u + salt * 0xC2B2AE3Du + 0x27D4EB2Fu;
-  return r;
-}
-__device__ __forceinline__ void tell_keep2_row(const TellKeepRow& r, uint32_t d, uint32_t thr, float inv_keep,
-                                               float& k0, float& k1) {      // == tell_keep2 at pair index pair_idx0 + d
-  uint32_t x = r.x0 + d * 0x9E3779B1u;
-  x ^= r.y; x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-  k0 = (x & 0xffffu) >= thr ? inv_keep : 0.f;
-  k1 = (x >> 16) >= thr ? inv_keep : 0.f;
-}
-// The same two decisions as booleans, with the caller maintaining x = r.x0 + d * 0x9E3779B1 itself (a kernel that
-// walks a fixed pattern of d keeps ONE running value and adds one of two constants per pair instead of holding a
-// constant per pair in SGPRs).  keep <=> tell_keep2_row's factor != 0.
-#define TELL_PAIR_STRIDE 0x9E3779B1u
-__device__ __forceinline__ void tell_keep2_bits(uint32_t x, uint32_t y, uint32_t thr, bool& k0, bool& k1) {
-  x ^= y; x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-  k0 = (x & 0xffffu) >= thr;
-  k1 = (x >> 16) >= thr;
+  return tell_keep_field(seed, salt, idx) >= thr ? inv_keep : 0.f;
 }
 // both decisions of the aligned pair starting at the EVEN index idx_even
 __device__ __forceinline__ void tell_keep2(uint32_t seed, uint32_t salt, uint64_t idx_even, uint32_t thr,
                                            float inv_keep, float& k0, float& k1) {
-  const uint32_t h = tell_hash32(seed, salt, idx_even >> 1);
-  k0 = (h & 0xffffu) >= thr ? inv_keep : 0.f;
-  k1 = (h >> 16) >= thr ? inv_keep : 0.f;
+  const uint64_t quad = idx_even >> 2;
+  const uint32_t h = tell_quad_mix(tell_quad_x(seed, quad), tell_quad_y(salt, quad));
+  const uint32_t w = (idx_even & 2) ? tell_quad_b(h) : tell_quad_a(h);
+  k0 = (w & 0xffffu) >= thr ? inv_keep : 0.f;
+  k1 = (w >> 16) >= thr ? inv_keep : 0.f;
+}
+// Consecutive quads of one row: the index-dependent part of the hash input is linear in the quad index, so a kernel
+// that walks quad0 + d keeps ONE running value x and adds a multiple of TELL_QUAD_STRIDE per quad instead of
+// redoing the index multiply.  Valid while the low word of the quad index does not wrap (tell_keep_row_ok).
+struct TellKeepRow { uint32_t x0, y; };
+#define TELL_QUAD_STRIDE 0x9E3779B1u
+__device__ __forceinline__ bool tell_keep_row_ok(uint64_t quad0, uint32_t span) {
+  return (uint32_t)quad0 <= 0xFFFFFFFFu - span;
+}
+__device__ __forceinline__ TellKeepRow tell_keep_row(uint32_t seed, uint32_t salt, uint64_t quad0) {
+  TellKeepRow r;
+  r.x0 = tell_quad_x(seed, quad0);
+  r.y = tell_quad_y(salt, quad0);
+  return r;
+}
+// the four decisions of the quad whose running value is x (= row.x0 + d * TELL_QUAD_STRIDE)
+__device__ __forceinline__ void tell_keep4_bits(uint32_t x, uint32_t y, uint32_t thr, bool& k0, bool& k1, bool& k2,
+                                                bool& k3) {
+  const uint32_t h = tell_quad_mix(x, y);
+  const uint32_t a = tell_quad_a(h), b = tell_quad_b(h);
+  k0 = (a & 0xffffu) >= thr;
+  k1 = (a >> 16) >= thr;
+  k2 = (b & 0xffffu) >= thr;
+  k3 = (b >> 16) >= thr;
 }

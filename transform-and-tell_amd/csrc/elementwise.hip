@@ -135,12 +135,8 @@ extern "C" int tell_wn_rowscale(const float* g, const float* v, int rows, int co
 // Working weight of a GehringLinear in ONE pass: w[r,:] = (g[r] / ||v[r,:]||) * v[r,:] in the compute dtype, plus
 // norms[r] = ||v[r,:]|| for the backward.  One wave per row; the second sweep over the row hits L2.
 template <typename OutT>
-__global__ __launch_bounds__(256) void wn_weight_kernel(const float* __restrict__ g, const float* __restrict__ v,
-                                                        int rows, int cols, OutT* __restrict__ w,
-                                                        float* __restrict__ norms) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+__device__ __forceinline__ void wn_weight_row(const float* __restrict__ g, const float* __restrict__ v, int row,
+                                              int cols, OutT* __restrict__ w, float* __restrict__ norms, int lane) {
   const float* vr = v + (long)row * cols;
   OutT* wr = w + (long)row * cols;
   float s = 0.f;
@@ -170,6 +166,13 @@ __global__ __launch_bounds__(256) void wn_weight_kernel(const float* __restrict_
     for (int c = lane; c < cols; c += 64) Elem<OutT>::st(wr + c, vr[c] * sc);
   }
 }
+template <typename OutT>
+__global__ __launch_bounds__(256) void wn_weight_kernel(const float* __restrict__ g, const float* __restrict__ v,
+                                                        int rows, int cols, OutT* __restrict__ w,
+                                                        float* __restrict__ norms) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row < rows) wn_weight_row<OutT>(g, v, row, cols, w, norms, threadIdx.x & 63);
+}
 extern "C" int tell_wn_weight(const float* g, const float* v, int rows, int cols, void* w, int out_dtype,
                               float* norms, hipStream_t stream) {
   if (rows <= 0) return TELL_OK;
@@ -182,15 +185,10 @@ extern "C" int tell_wn_weight(const float* g, const float* v, int rows, int cols
 }
 
 // dg[r] += <dW[r], v[r]> / ||v||;  dv[r] += (g/||v||) * (dW[r] - v[r] * <dW[r],v[r]> / ||v||^2)
-__global__ __launch_bounds__(256) void wn_backward_kernel(const float* __restrict__ dW,
-                                                          const float* __restrict__ g,
-                                                          const float* __restrict__ v,
-                                                          const float* __restrict__ norms, int rows,
-                                                          int cols, float* __restrict__ dg,
-                                                          float* __restrict__ dv) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+__device__ __forceinline__ void wn_backward_row(const float* __restrict__ dW, const float* __restrict__ g,
+                                                const float* __restrict__ v, const float* __restrict__ norms,
+                                                int row, int cols, float* __restrict__ dg, float* __restrict__ dv,
+                                                int lane) {
   const float* vr = v + (long)row * cols;
   const float* dr = dW + (long)row * cols;
   float* o = dv + (long)row * cols;
@@ -218,12 +216,89 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const float* __restric
     for (int c = lane; c < cols; c += 64) o[c] += gs * (dr[c] - vr[c] * k);
   }
 }
+__global__ __launch_bounds__(256) void wn_backward_kernel(const float* __restrict__ dW,
+                                                          const float* __restrict__ g,
+                                                          const float* __restrict__ v,
+                                                          const float* __restrict__ norms, int rows,
+                                                          int cols, float* __restrict__ dg,
+                                                          float* __restrict__ dv) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row < rows) wn_backward_row(dW, g, v, norms, row, cols, dg, dv, threadIdx.x & 63);
+}
 
 extern "C" int tell_wn_backward(const float* dW, const float* g, const float* v, const float* norms,
                                 int rows, int cols, float* dg, float* dv, hipStream_t stream) {
   if (rows <= 0) return TELL_OK;
   hipLaunchKernelGGL(wn_backward_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, dW, g, v, norms, rows, cols, dg, dv);
   return tell_check_launch("wn_backward");
+}
+
+// The same two row kernels over MANY GehringLinears in one launch (the decoder has 20: at 10-15 us a launch for 1-4 M
+// elements each they are latency, not bandwidth).  The per-tensor pointers travel BY VALUE in the kernel arguments
+// (no device table to keep alive, and a captured graph bakes them in); a wave finds its tensor by walking the row
+// prefix sums, which sit in scalar registers.
+#define WN_MULTI_MAX 32
+struct WNMulti {
+  const float* a[WN_MULTI_MAX];        // forward: unused          backward: dW
+  const float* g[WN_MULTI_MAX];
+  const float* v[WN_MULTI_MAX];
+  void* w[WN_MULTI_MAX];               // forward: working weight  backward: dv
+  float* norms[WN_MULTI_MAX];
+  float* dg[WN_MULTI_MAX];
+  int cols[WN_MULTI_MAX];
+  int row_start[WN_MULTI_MAX + 1];
+  int n;
+};
+template <typename OutT, bool BWD>
+__global__ __launch_bounds__(256) void wn_multi_kernel(WNMulti m) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= m.row_start[m.n]) return;
+  int i = 0;
+  while (i + 1 < m.n && row >= m.row_start[i + 1]) ++i;       // wave-uniform
+  const int r = row - m.row_start[i];
+  if constexpr (BWD) wn_backward_row(m.a[i], m.g[i], m.v[i], m.norms[i], r, m.cols[i], m.dg[i], static_cast<float*>(m.w[i]), lane);
+  else wn_weight_row<OutT>(m.g[i], m.v[i], r, m.cols[i], static_cast<OutT*>(m.w[i]), m.norms[i], lane);
+}
+template <bool BWD>
+static int wn_multi_launch(int n, const void* const* a, const void* const* g, const void* const* v, void* const* w,
+                           void* const* norms, void* const* dg, const int* rows, const int* cols, int out_dtype,
+                           hipStream_t stream) {
+  for (int base = 0; base < n; base += WN_MULTI_MAX) {
+    WNMulti m;
+    m.n = n - base < WN_MULTI_MAX ? n - base : WN_MULTI_MAX;
+    m.row_start[0] = 0;
+    for (int i = 0; i < m.n; ++i) {
+      const int j = base + i;
+      TELL_REQUIRE(rows[j] > 0 && cols[j] > 0, "wn_multi: empty tensor");
+      TELL_REQUIRE(BWD || (((uintptr_t)v[j] | (uintptr_t)w[j]) & 15) == 0, "wn_weight_multi: buffers must be 16-byte aligned");
+      m.a[i] = BWD ? static_cast<const float*>(a[j]) : nullptr;
+      m.g[i] = static_cast<const float*>(g[j]);
+      m.v[i] = static_cast<const float*>(v[j]);
+      m.w[i] = w[j];
+      m.norms[i] = static_cast<float*>(norms[j]);
+      m.dg[i] = BWD ? static_cast<float*>(dg[j]) : nullptr;
+      m.cols[i] = cols[j];
+      m.row_start[i + 1] = m.row_start[i] + rows[j];
+    }
+    const dim3 grid((m.row_start[m.n] + 3) / 4);
+    if (BWD) hipLaunchKernelGGL((wn_multi_kernel<float, true>), grid, dim3(256), 0, stream, m);
+    else if (out_dtype == TELL_BF16) hipLaunchKernelGGL((wn_multi_kernel<uint16_t, false>), grid, dim3(256), 0, stream, m);
+    else hipLaunchKernelGGL((wn_multi_kernel<float, false>), grid, dim3(256), 0, stream, m);
+  }
+  return tell_check_launch(BWD ? "wn_backward_multi" : "wn_weight_multi");
+}
+// host arrays of n device pointers / sizes
+extern "C" int tell_wn_weight_multi(int n, const void* const* g, const void* const* v, void* const* w,
+                                    void* const* norms, const int* rows, const int* cols, int out_dtype,
+                                    hipStream_t stream) {
+  if (n <= 0) return TELL_OK;
+  return wn_multi_launch<false>(n, nullptr, g, v, w, norms, nullptr, rows, cols, out_dtype, stream);
+}
+extern "C" int tell_wn_backward_multi(int n, const void* const* dW, const void* const* g, const void* const* v,
+                                      const void* const* norms, const int* rows, const int* cols, void* const* dg,
+                                      void* const* dv, hipStream_t stream) {
+  if (n <= 0) return TELL_OK;
+  return wn_multi_launch<true>(n, dW, g, v, dv, const_cast<void* const*>(norms), dg, rows, cols, TELL_F32, stream);
 }
 
 // ---------------------------------------------------------------- GLU  (h = [a | gate], y = a * sigmoid(gate))
@@ -295,7 +370,8 @@ extern "C" int tell_dropout(const void* x, void* y, long n, float p, uint32_t se
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, long ld, int rows, int C,
                                                              int rows_per_chunk, float* __restrict__ partial,
-                                                             const int* __restrict__ m_dev) {
+                                                             const int* __restrict__ m_dev, float* __restrict__ direct,
+                                                             int accumulate, float scale) {
   __shared__ float part[4][65];
   if (m_dev) { int md = *m_dev; rows = md < rows ? md : rows; }
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
@@ -307,7 +383,11 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     for (int r = r0 + ry; r < r1; r += 4) s += Elem<T>::ld(x + (long)r * ld + c);
   part[ry][cx] = s;
   __syncthreads();
-  if (ry == 0 && c < C) partial[(long)blockIdx.y * C + c] = part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx];
+  if (ry == 0 && c < C) {
+    const float t = part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx];
+    if (direct) direct[c] = (accumulate ? direct[c] : 0.f) + scale * t;      // single chunk: no second pass
+    else partial[(long)blockIdx.y * C + c] = t;
+  }
 }
 __global__ void colsum_finish_kernel(const float* __restrict__ partial, int n_chunks, int C, float* __restrict__ out,
                                      int accumulate, float scale) {
@@ -326,9 +406,10 @@ extern "C" int tell_colsum(const void* x, long ld, int rows, int C, int dtype, f
   const int nch = tell_colsum_chunks(rows);
   const int rpc = (rows + nch - 1) / nch;
   dim3 grid((C + 63) / 64, nch);
-  if (dtype == TELL_BF16) hipLaunchKernelGGL((colsum_partial_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)x, ld, rows, C, rpc, workspace, m_dev);
-  else hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, ld, rows, C, rpc, workspace, m_dev);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, workspace, nch, C, out, accumulate, scale);
+  float* direct = nch == 1 ? out : nullptr;
+  if (dtype == TELL_BF16) hipLaunchKernelGGL((colsum_partial_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)x, ld, rows, C, rpc, workspace, m_dev, direct, accumulate, scale);
+  else hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, ld, rows, C, rpc, workspace, m_dev, direct, accumulate, scale);
+  if (!direct) hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, workspace, nch, C, out, accumulate, scale);
   return tell_check_launch("colsum");
 }
 

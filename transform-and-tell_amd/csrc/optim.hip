@@ -25,17 +25,27 @@ __global__ __launch_bounds__(256) void sqsum_chunks_kernel(const float* __restri
     __syncthreads();
   }
 }
-// norms[t] = sqrt(sum of the tensor's chunk partials); one wave per tensor (fixed order -> deterministic)
+// norms[t] = sqrt(sum of the tensor's chunk partials); one 256-thread block per tensor, four loads in flight per thread,
+// partial sums folded in a fixed order (deterministic).  (One wave per tensor walked the 50 k chunks of the embedding
+// table one dependent load at a time: 145 us.)
 __global__ __launch_bounds__(256) void tensor_norms_kernel(const float* __restrict__ partial,
                                                            const long* __restrict__ chunk_begin,
                                                            int n_tensors, float* __restrict__ norms,
                                                            int* __restrict__ skip) {
-  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (t >= n_tensors) return;
-  float s = 0.f;
-  for (long c = chunk_begin[t] + lane; c < chunk_begin[t + 1]; c += 64) s += partial[c];
-  s = wave_sum(s);
-  if (lane == 0) {
+  __shared__ float red[4];
+  const int t = blockIdx.x, lane = threadIdx.x & 63;
+  const long c0 = chunk_begin[t], c1 = chunk_begin[t + 1];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  long c = c0 + threadIdx.x;
+  for (; c + 768 < c1; c += 1024) {
+    s0 += partial[c]; s1 += partial[c + 256]; s2 += partial[c + 512]; s3 += partial[c + 768];
+  }
+  for (; c < c1; c += 256) s0 += partial[c];
+  float s = wave_sum((s0 + s1) + (s2 + s3));
+  if (lane == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s = (red[0] + red[1]) + (red[2] + red[3]);
     norms[t] = sqrtf(s);
     if (skip && !(fabsf(s) <= 3.4e38f)) atomicOr(skip, 2);      // NaN / Inf gradient (apex O2 skips such steps)
   }
@@ -112,7 +122,7 @@ extern "C" int tell_bertadam_step(float* param, float* grad, float* m, float* v,
   int g = n_chunks < 4096 ? (int)n_chunks : 4096;
   if (max_norm > 0.f) {
     hipLaunchKernelGGL(sqsum_chunks_kernel, dim3(g), dim3(256), 0, stream, grad, n_chunks, grad_scale, partial);
-    hipLaunchKernelGGL(tensor_norms_kernel, dim3((n_tensors + 3) / 4), dim3(256), 0, stream, partial, chunk_begin, n_tensors, norms, skip);
+    hipLaunchKernelGGL(tensor_norms_kernel, dim3(n_tensors), dim3(256), 0, stream, partial, chunk_begin, n_tensors, norms, skip);
   }
   hipLaunchKernelGGL(bertadam_update_kernel, dim3(g), dim3(256), 0, stream, param, grad, m, v, chunk_tensor, norms, n_chunks, lr_dev, b1, b2, eps, wd, max_norm, grad_scale, (uint16_t*)shadow_bf16, zero_grad, skip);
   return tell_check_launch("bertadam_step");

@@ -165,7 +165,16 @@ class _DynamicConvDecoderBase(Decoder):
         if self.normalize:                                                         # :88-90
             self.layer_norm = nn.LayerNorm(E)
 
+    def _wn_pairs(self):
+        pairs = getattr(self, '_wn_pair_list', None)
+        if pairs is None:
+            pairs = [(m.weight_g, m.weight_v) for m in self.modules() if isinstance(m, GehringLinear)]
+            object.__setattr__(self, '_wn_pair_list', pairs)
+        return pairs
+
     def forward(self, prev_target, contexts, incremental_state=None, use_layers=None, kv_cache=None, **kwargs):
+        if self.training and torch.is_grad_enabled():
+            ops.wn_prepare(self._wn_pairs())          # every weight-normalised working weight of the step in one launch
         X = self.embedder(prev_target, incremental_state=incremental_state)      # :98  [B,T,E] view
         X = X.transpose(0, 1)                                                      # :109 T x B x C (contiguous)
         X = ops.dropout(X, self.dropout, self.training)                            # :106

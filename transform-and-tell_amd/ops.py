@@ -8,6 +8,7 @@ weight gradients *directly* into the parameter's fp32 gradient buffer
 (`grad_buffer(p)`, which is `p.grad`), the way fused wgrad accumulation works in
 large-model trainers; the Functions therefore return None for parameters.
 """
+import ctypes
 import math
 import os
 import weakref
@@ -186,20 +187,30 @@ def colsum_into(x2, out, scale=1.0, m_dev=None):
 _wcache = {}
 
 
-def _cached(p, key, maker):
-    k = (id(p), key)
+def _stamp(p):
     # trainable masters are rewritten by the optimizer kernel (which bypasses torch's version counter) ->
     # keyed on the weights epoch; frozen tensors (encoders, buffers) only change through torch ops
     epoch = rt.weights_epoch() if p.requires_grad else -1
     if p.requires_grad:
         rt.wait_weight_update()          # an optimizer step may still be in flight on the update stream
-    stamp = (epoch, rt.compute_dtype(), p._version, p.data_ptr())
-    e = _wcache.get(k)
+    return (epoch, rt.compute_dtype(), p._version, p.data_ptr())
+
+
+def _fresh(p, key):
+    """The cached working copy of p under `key`, or None when there is none / it is stale."""
+    e = _wcache.get((id(p), key))
     # id() is only unique among LIVE objects: the entry remembers its tensor weakly, so a new tensor that
     # inherited a dead one's id (and possibly its storage address) never sees the old working copy
-    if e is None or e[0] != stamp or e[2]() is not p:
-        e = (stamp, maker(), weakref.ref(p))
-        _wcache[k] = e
+    if e is None or e[0] != _stamp(p) or e[2]() is not p:
+        return None
+    return e
+
+
+def _cached(p, key, maker):
+    e = _fresh(p, key)
+    if e is None:
+        e = (_stamp(p), maker(), weakref.ref(p))
+        _wcache[(id(p), key)] = e
     return e[1]
 
 
@@ -251,6 +262,63 @@ def wn_weight(g, v):
         call('tell_wn_weight', g.detach(), v.detach(), R, C, w, hip.dt(w), norms)
         return w, norms
     return _cached(v, ('wn', g._version, g.data_ptr()), make)
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _int_array(values):
+    return (ctypes.c_int * len(values))(*values)
+
+
+def wn_prepare(pairs):
+    """Working weights of MANY GehringLinears [(weight_g, weight_v), ...] in one launch: whatever is stale in the cache
+    is rebuilt together (tell_wn_weight_multi), so the layers' own wn_weight() calls all hit.  The decoder calls this
+    once per forward: 20 launches of ~10 us become one."""
+    stale = []
+    for g, v in pairs:
+        if v.is_cuda and _fresh(v, ('wn', g._version, g.data_ptr())) is None:
+            stale.append((g, v))
+    if len(stale) < 2:
+        return
+    dtype = rt.compute_dtype()
+    ws = [torch.empty(v.shape[0], v.shape[1], dtype=dtype, device=v.device) for _, v in stale]
+    norms = [torch.empty(v.shape[0], dtype=torch.float32, device=v.device) for _, v in stale]
+    call('tell_wn_weight_multi', len(stale), _ptr_array([g.detach() for g, _ in stale]),
+         _ptr_array([v.detach() for _, v in stale]), _ptr_array(ws), _ptr_array(norms),
+         _int_array([v.shape[0] for _, v in stale]), _int_array([v.shape[1] for _, v in stale]), hip.dt(dtype))
+    for (g, v), w, n in zip(stale, ws, norms):
+        _wcache[(id(v), ('wn', g._version, g.data_ptr()))] = (_stamp(v), (w, n), weakref.ref(v))
+
+
+_WN_PENDING = {'defer': False, 'items': []}
+
+
+def wn_defer(on):
+    """While on, the weight-norm chain rule of every GehringLinear (dW -> dg, dv) is queued instead of launched; the
+    caller flushes the queue with wn_flush() once the backward pass is over (trainer._backward)."""
+    _WN_PENDING['defer'] = bool(on)
+
+
+def wn_drop():
+    _WN_PENDING['items'] = []
+
+
+def wn_flush():
+    items, _WN_PENDING['items'] = _WN_PENDING['items'], []
+    if not items:
+        return
+    if len(items) == 1:
+        dW, g, v, norms = items[0]
+        call('tell_wn_backward', dW, g.detach(), v.detach(), norms, v.shape[0], v.shape[1], grad_buffer(g),
+             grad_buffer(v))
+        return
+    call('tell_wn_backward_multi', len(items), _ptr_array([i[0] for i in items]),
+         _ptr_array([i[1].detach() for i in items]), _ptr_array([i[2].detach() for i in items]),
+         _ptr_array([i[3] for i in items]), _int_array([i[2].shape[0] for i in items]),
+         _int_array([i[2].shape[1] for i in items]), _ptr_array([grad_buffer(i[1]) for i in items]),
+         _ptr_array([grad_buffer(i[2]) for i in items]))
 
 
 def wn_weight_t(g, v):
@@ -512,8 +580,11 @@ class WNLinearFn(Function):
                 if v.requires_grad:
                     dW = gemm_tn(dy2, x2, out_dtype=torch.float32, asum=gb)
                     gb = None
-                    call('tell_wn_backward', dW, g.detach(), v.detach(), norms, v.shape[0], v.shape[1],
-                         grad_buffer(g), grad_buffer(v))
+                    if _WN_PENDING['defer']:
+                        _WN_PENDING['items'].append((dW, g, v, norms))
+                    else:
+                        call('tell_wn_backward', dW, g.detach(), v.detach(), norms, v.shape[0], v.shape[1],
+                             grad_buffer(g), grad_buffer(v))
                 if gb is not None:
                     colsum_into(dy2, gb)
             wgrad_job(job, dy2, x2)
@@ -915,8 +986,15 @@ class AttnFn(Function):
         dout = dout.contiguous()
         dq = torch.empty_like(q)
         # (every element is ASSIGNED by the workgroup of its (b, h) while it handles q block 0: no zero fill)
-        dbk = torch.empty(B, E, dtype=torch.float32, device=q.device) if bk is not None else None
-        dbv = torch.empty(B, E, dtype=torch.float32, device=q.device) if bk is not None else None
+        dbk = dbv = dbkv = None
+        if bk is not None:
+            gbk, gbv = (grad_buffer(t).view(-1) if t.requires_grad else None for t in (bias_k, bias_v))
+            if gbk is not None and gbv is not None and _adjacent(gbk, gbv):
+                dbkv = torch.empty(B, 2 * E, dtype=torch.float32, device=q.device)     # one column sum for both
+                dbk, dbv = dbkv[:, :E], dbkv[:, E:]
+            else:
+                dbk = torch.empty(B, E, dtype=torch.float32, device=q.device)
+                dbv = torch.empty(B, E, dtype=torch.float32, device=q.device)
         # dk/dv share k's / v's strides (the kernel uses one stride set for K and dK);
         # empty_like keeps the strides of dense permuted views ([B,S,E] storage seen as [S,B,E])
         kc, vc = k, v
@@ -938,7 +1016,9 @@ class AttnFn(Function):
         call('tell_attn_bwd', q, kc, vc, out, dout, lse, mask, bk, bv, dq, dk, dv, dbk, dbv, B, H, T, S, D,
              q.stride(0), q.stride(1), kc.stride(0), kc.stride(1), vc.stride(0), vc.stride(1),
              out.stride(0), out.stride(1), int(has_zero), float(p), rt.seed(), salt, hip.dt(q))
-        if bias_k is not None and bias_k.requires_grad:
+        if dbkv is not None:
+            colsum_into(dbkv, torch.as_strided(gbk, (2 * E,), (1,)))
+        elif bias_k is not None and bias_k.requires_grad:
             colsum_into(dbk, grad_buffer(bias_k).view(-1))
             colsum_into(dbv, grad_buffer(bias_v).view(-1))
         if packed:

@@ -22,7 +22,7 @@ def set_compute_dtype(dtype):
 
 
 def manual_seed(seed, salt=0):
-    """Seed of the counter-based dropout RNG (csrc/common.h tell_hash32)."""
+    """Seed of the counter-based dropout RNG (csrc/common.h tell_keep_field)."""
     _state['seed'] = int(seed) & 0xFFFFFFFF
     _state['salt'] = int(salt) & 0xFFFFFFFF
 

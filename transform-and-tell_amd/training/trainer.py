@@ -174,11 +174,19 @@ class Trainer:
 
     def _backward(self, scaled):
         self._in_backward = True
+        # the weight-norm chain rule of all GehringLinears runs as ONE launch after the pass - unless gradient buckets
+        # leave during backward (a layer's gradients have to be final at its marker then)
+        ops.wn_defer(not self._ranges)
         try:
             scaled.backward()                                            # :229-231
+        except BaseException:
+            ops.wn_drop()
+            raise
         finally:
             self._in_backward = False
+            ops.wn_defer(False)
         ops.join_wgrad_stream()                                          # weight-gradient side stream (ops.py)
+        ops.wn_flush()
 
     def skipped_steps(self):
         """Number of optimisation steps the device-side NaN / Inf check turned into no-ops so far (one host sync)."""
