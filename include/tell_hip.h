@@ -85,6 +85,24 @@ int tell_gemm_bf16(const void* A, long lda, int trans_a, const void* B, long ldb
                    float alpha, int accumulate, const int* m_dev, float* a_colsum, float a_colsum_scale,
                    tell_stream_t stream);
 
+/* n independent K-major products in a few launches (the weight gradients of a backward pass, queued until its end):
+   C_i[M,N] (+)= alpha_i * A_i^T B_i with A_i bf16 [K, M] (row stride lda) and B_i bf16 [K, N] - dW = dY^T X exactly as
+   the forward pass left dY and X - and, optionally, asum_i[m] += asum_scale_i * sum_k A_i[k][m] (the bias gradient).
+   `problems` is a HOST array. */
+typedef struct tell_gemm_tn_problem {
+  const void* A; long lda;
+  const void* B; long ldb;
+  void* C; long ldc;
+  int M, N, K;
+  int out_dtype;          /* of C: TELL_F32 / TELL_BF16 */
+  int accumulate;         /* C += */
+  float alpha;
+  float* asum;            /* fp32 [M] or NULL */
+  float asum_scale;
+  int reserved;
+} tell_gemm_tn_problem;
+int tell_gemm_tn_grouped(int n, const tell_gemm_tn_problem* problems, tell_stream_t stream);
+
 /* ---- casts / transposes / weight norm -------------------------------------- */
 int tell_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, tell_stream_t stream);
 /* dst = (dst_dtype)(src * *scale_dev) (scale_dev NULL = 1; dst may alias src for fp32): the fp32 flat gradient on its way

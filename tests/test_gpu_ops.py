@@ -591,3 +591,46 @@ def test_adaptive_softmax_golden(golden, dtype):
     if dtype == torch.float32:
         assert torch.equal(tok.cpu().long().view(-1), ref.argmax(dim=1))
     close(tlp.view(-1), ref.max(dim=1).values, dtype, scale=4)
+
+
+def test_grouped_wgrad_gemms_match_single_launches():
+    """gemm_tn queued + flushed as grouped launches == the same products launched one by one, bit for bit (the K
+    reduction order does not depend on the tile shape), over both output types, both tile shapes, ragged sizes, fused bias column sums and
+    two products accumulating into ONE buffer (tied weights: must not share a launch)."""
+    import tell_amd
+    from tell_amd import ops
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(5)
+    shapes = [(1024, 1024, 1024), (1024, 2048, 1024), (128, 2048, 512), (1568, 2048, 2048), (96, 200, 72),
+              (1024, 496, 1024), (64, 64, 64), (2048, 1024, 4096)] * 4                    # (K rows, M, N) x 32
+    probs = []
+    for i, (K, M, N) in enumerate(shapes):
+        a = torch.randn(K, M, device=DEV).bfloat16()
+        b = torch.randn(K, N, device=DEV).bfloat16()
+        probs.append((a, b, torch.float32 if i % 3 else torch.bfloat16, i % 2 == 0, i % 4 == 1))
+    tied = torch.zeros(1024, 1024, device=DEV)
+
+    def run(grouped):
+        outs = []
+        ops.wgrad_group_defer(grouped)
+        try:
+            for a, b, dt, acc, with_sum in probs:
+                out = torch.full((a.shape[1], b.shape[1]), 0.5, device=DEV, dtype=dt) if acc else None
+                asum = torch.full((a.shape[1],), 0.25, device=DEV) if with_sum else None
+                o = ops.gemm_tn(a, b, out=out, out_dtype=dt, accumulate=acc, alpha=0.5, asum=asum, asum_scale=0.5)
+                outs.append((o, asum))
+            t = tied.clone()
+            for a, b, *_ in probs[:9:8]:                       # two 1024 x 1024 products into the same buffer
+                ops.gemm_tn(a, b, out=t, accumulate=True)
+            outs.append((t, None))
+        finally:
+            ops.wgrad_group_defer(False)
+        ops.wgrad_group_flush()
+        return outs
+
+    ref = run(False)
+    got = run(True)
+    for (o0, s0), (o1, s1) in zip(ref, got):
+        assert torch.equal(o0, o1)
+        if s0 is not None:            # the fused column sums fold in tile order: 64- and 128-row tiles differ in the last bits
+            assert torch.allclose(s0, s1, rtol=1e-5, atol=1e-3)

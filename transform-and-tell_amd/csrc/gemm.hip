@@ -18,8 +18,10 @@
 // 33-dword stride; K-major tiles: +64 B skew for the transpose reads) or, for the lane-linear direct-to-LDS
 // image, swizzled on the source address.
 #include "common.h"
+#include "../../include/tell_hip.h"    // tell_gemm_tn_problem (and every prototype: a drifted definition fails to compile)
 #include <type_traits>
 #include <stdlib.h>
+#include <alloca.h>
 #include <stdio.h>
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // 16-byte staging chunk (native vector: stays in VGPRs)
@@ -898,8 +900,11 @@ __device__ __forceinline__ bf16x8 tr_frag(const uint16_t* p0, const uint16_t* p1
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// The body takes its workgroup coordinates as arguments: (block, n_blocks) along the tile axis and (split, n_splits)
+// along K - the plain kernel passes blockIdx / gridDim, the grouped kernel the position inside one problem's range.
 template <typename OutT, int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB, int PF>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tx_kernel(GemmArgs p) {
+__device__ __forceinline__ void gemm_tx_body(const GemmArgs& p, const int block, const int n_blocks, const int split,
+                                             const int n_splits) {
   using T = uint16_t;
   constexpr int NT = 64 * WAVES_M * WAVES_N, BK = 64;
   static_assert(PF == 2 || PF == 4, "prefetch depth");
@@ -918,14 +923,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tx_kernel(Gemm
   const int N = p.N;
   // split K (gridDim.y > 1): this workgroup reduces rows [kb, K) of its slice only and adds its partial tile to the
   // fp32 output with float atomics (p.atomic_out)
-  const int kper = ((p.K + BK - 1) / BK + gridDim.y - 1) / gridDim.y * BK;
-  const int kb = blockIdx.y * kper;
+  const int kper = ((p.K + BK - 1) / BK + n_splits - 1) / n_splits * BK;
+  const int kb = split * kper;
   const int K = p.K < kb + kper ? p.K : kb + kper;
   if (kb >= K) return;
   const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
   int tile_id;
   {
-    const int orig = blockIdx.x, xcd = orig & 7, q = gridDim.x >> 3, r = gridDim.x & 7;
+    const int orig = block, xcd = orig & 7, q = n_blocks >> 3, r = n_blocks & 7;
     tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
   if (tile_id >= tiles_m * tiles_n) return;
@@ -1059,12 +1064,50 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tx_kernel(Gemm
         const int ch = tid >> 3, e = tid & 7;
         float s = 0.f;
         for (int t = ch; t < NT; t += CPA) s += red[t * 9 + e];
-        if (gridDim.y > 1) unsafeAtomicAdd(p.asum + m0 + tid, p.asum_scale * s);
+        if (n_splits > 1) unsafeAtomicAdd(p.asum + m0 + tid, p.asum_scale * s);
         else p.asum[m0 + tid] += p.asum_scale * s;
       }
     }
   }
   gemm_epilogue<OutT, MI, NI>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, M, N);
+}
+template <typename OutT, int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB, int PF>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tx_kernel(GemmArgs p) {
+  gemm_tx_body<OutT, BM, BN, WAVES_M, WAVES_N, TA, TB, PF>(p, blockIdx.x, gridDim.x, blockIdx.y, gridDim.y);
+}
+
+// ------------------------------------------------------------- grouped weight-gradient GEMMs
+// The decoder's backward pass ends in ~80 independent dW = dY^T X products, most of them 256-512 tiles of 64x64 with
+// a 1024-row reduction: one workgroup per CU, 16 dependent K steps each - latency, not throughput (200-250 TFLOP/s).
+// Queued until the pass is over (ops.py) they run as a few launches of thousands of tiles: several workgroups per CU
+// hide each other's load latency and the ~80 launch gaps are gone.  Problems travel by value in the kernel arguments;
+// a workgroup finds its problem by walking the (8-aligned, so the XCD phase of a block is its problem-local one)
+// block prefix sums, which live in scalar registers.
+#define TX_GROUP_MAX 24
+struct TxProblem {
+  const void* A; const void* B; void* C; float* asum;
+  long lda, ldb, ldc;
+  int M, N, K, accumulate;
+  float alpha, asum_scale;
+};
+struct TxGroup {
+  TxProblem pr[TX_GROUP_MAX];
+  int start[TX_GROUP_MAX + 1];
+  int n;
+};
+template <typename OutT, int BM, int BN, int PF>
+__global__ __launch_bounds__(256, 2) void gemm_tx_group_kernel(TxGroup g) {
+  const int b = blockIdx.x;
+  int i = 0;
+  while (i + 1 < g.n && b >= g.start[i + 1]) ++i;            // block-uniform
+  const TxProblem& q = g.pr[i];
+  GemmArgs p;
+  p.A = q.A; p.B = q.B; p.C = q.C; p.bias = nullptr; p.aux = nullptr; p.m_dev = nullptr;
+  p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc; p.M = q.M; p.N = q.N; p.K = q.K;
+  p.bias_mode = 0; p.act = 0; p.accumulate = q.accumulate; p.alpha = q.alpha;
+  p.asum = q.asum; p.asum_scale = q.asum_scale; p.ts = nullptr; p.atomic_out = 0; p.conv_zero = nullptr;
+  p.stat_mean = nullptr; p.stat_m2 = nullptr;
+  gemm_tx_body<OutT, BM, BN, 2, 2, true, true, PF>(p, b - g.start[i], g.start[i + 1] - g.start[i], 0, 1);
 }
 
 template <typename OutT, bool TA, bool TB>
@@ -1266,6 +1309,59 @@ extern "C" int tell_gemm_bf16(const void* A, long lda, int trans_a, const void* 
   if (trans_b)
     return out_dtype == TELL_BF16 ? launch_gemm_tx<uint16_t, false, true>(a, stream) : launch_gemm_tx<float, false, true>(a, stream);
   return out_dtype == TELL_BF16 ? launch_gemm_tx<uint16_t, true, false>(a, stream) : launch_gemm_tx<float, true, false>(a, stream);
+}
+
+// n independent K-major products C_i[M,N] (+)= alpha_i * A_i^T B_i (A_i bf16 [K,M], B_i bf16 [K,N]: dW = dY^T X as the
+// forward pass left the operands), each with the optional fused column sums of A_i (the bias gradient).  Problems are
+// bucketed by output type and tile shape and each bucket runs as one launch per TX_GROUP_MAX problems.
+template <typename OutT, int BM, int BN, int PF>
+static int launch_tx_group(const tell_gemm_tn_problem* pr, const int* ids, int n, hipStream_t stream) {
+  for (int base = 0; base < n; base += TX_GROUP_MAX) {
+    TxGroup g;
+    g.n = n - base < TX_GROUP_MAX ? n - base : TX_GROUP_MAX;
+    g.start[0] = 0;
+    for (int i = 0; i < g.n; ++i) {
+      const tell_gemm_tn_problem& q = pr[ids[base + i]];
+      TxProblem& t = g.pr[i];
+      t.A = q.A; t.B = q.B; t.C = q.C; t.asum = q.asum; t.lda = q.lda; t.ldb = q.ldb; t.ldc = q.ldc;
+      t.M = q.M; t.N = q.N; t.K = q.K; t.accumulate = q.accumulate; t.alpha = q.alpha; t.asum_scale = q.asum_scale;
+      const long tiles = (long)((q.M + BM - 1) / BM) * ((q.N + BN - 1) / BN);
+      g.start[i + 1] = g.start[i] + (int)((tiles + 7) / 8 * 8);
+    }
+    hipLaunchKernelGGL((gemm_tx_group_kernel<OutT, BM, BN, PF>), dim3((unsigned)g.start[g.n]), dim3(256), 0, stream, g);
+  }
+  return tell_check_launch("gemm_tn_grouped");
+}
+extern "C" int tell_gemm_tn_grouped(int n, const tell_gemm_tn_problem* pr, hipStream_t stream) {
+  if (n <= 0) return TELL_OK;
+  static const int tile_env = getenv("TELL_GROUP_TILE") ? atoi(getenv("TELL_GROUP_TILE")) : 0;   // A/B aid: 64 / 128
+  int* ids = (int*)alloca(sizeof(int) * 4 * n);
+  int cnt[4] = {0, 0, 0, 0};                         // buckets: (bf16, f32) x (64, 128)
+  long big_tiles[2] = {0, 0};
+  for (int i = 0; i < n; ++i) {
+    const tell_gemm_tn_problem& q = pr[i];
+    TELL_REQUIRE(q.M > 0 && q.N > 0 && q.K > 0, "gemm_tn_grouped: bad dimension");
+    TELL_REQUIRE(q.out_dtype == TELL_F32 || q.out_dtype == TELL_BF16, "gemm_tn_grouped: bad output dtype");
+    TELL_REQUIRE(q.lda % 8 == 0 && q.ldb % 8 == 0 && (((uintptr_t)q.A | (uintptr_t)q.B) & 15) == 0,
+                 "gemm_tn_grouped: K-major operands need 16-byte aligned rows");
+    if (q.M >= 128 && q.N >= 128) big_tiles[q.out_dtype == TELL_F32] += (long)((q.M + 127) / 128) * ((q.N + 127) / 128);
+  }
+  for (int i = 0; i < n; ++i) {
+    const tell_gemm_tn_problem& q = pr[i];
+    const int f32 = q.out_dtype == TELL_F32;
+    // 128x128 tiles halve the LDS and L2 traffic per flop; they need enough tiles in flight to fill the chip twice over
+    bool big = q.M >= 128 && q.N >= 128 && big_tiles[f32] >= 512;
+    if (tile_env == 64) big = false;
+    if (tile_env == 128) big = q.M >= 128 && q.N >= 128;
+    const int b = f32 * 2 + (big ? 1 : 0);
+    ids[b * n + cnt[b]++] = i;
+  }
+  int rc = TELL_OK;
+  if (cnt[0] && !rc) rc = launch_tx_group<uint16_t, 64, 64, 4>(pr, ids + 0 * n, cnt[0], stream);
+  if (cnt[1] && !rc) rc = launch_tx_group<uint16_t, 128, 128, 2>(pr, ids + 1 * n, cnt[1], stream);
+  if (cnt[2] && !rc) rc = launch_tx_group<float, 64, 64, 4>(pr, ids + 2 * n, cnt[2], stream);
+  if (cnt[3] && !rc) rc = launch_tx_group<float, 128, 128, 2>(pr, ids + 3 * n, cnt[3], stream);
+  return rc;
 }
 
 int tell_bn_finish_launch(const float* pmean, const float* pm2, long M, int C, int n_chunks, int rows_per_chunk,

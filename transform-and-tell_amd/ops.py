@@ -112,6 +112,10 @@ def gemm_tn(a_km, b_kn, out=None, out_dtype=None, accumulate=False, alpha=1.0, m
         if out is None:
             out = torch.empty(M, N, dtype=out_dtype or a_km.dtype, device=a_km.device)
         assert out.stride(1) == 1
+        if _WGRAD_GROUP['defer'] and K > 0:
+            # queued: the pass's weight-gradient GEMMs run together once it is over (wgrad_group_flush)
+            _WGRAD_GROUP['items'].append((a_km, b_kn, out, float(alpha), int(accumulate), asum, float(asum_scale)))
+            return out
         call('tell_gemm_bf16', a_km, a_km.stride(0), 1, b_kn, b_kn.stride(0), 1, out, out.stride(0), M, N, K,
              hip.dt(out), None, 0, 0, None, float(alpha), int(accumulate), None, asum, float(asum_scale))
         return out
@@ -120,6 +124,60 @@ def gemm_tn(a_km, b_kn, out=None, out_dtype=None, accumulate=False, alpha=1.0, m
     at, _ = transpose(a_km)
     bt, _ = transpose(b_kn)
     return gemm(at, bt, out=out, out_dtype=out_dtype, accumulate=accumulate, alpha=alpha, m_dev=m_dev)
+
+
+class _TnProblem(ctypes.Structure):
+    """tell_gemm_tn_problem (include/tell_hip.h)."""
+    _fields_ = [('A', ctypes.c_void_p), ('lda', ctypes.c_long), ('B', ctypes.c_void_p), ('ldb', ctypes.c_long),
+                ('C', ctypes.c_void_p), ('ldc', ctypes.c_long), ('M', ctypes.c_int), ('N', ctypes.c_int),
+                ('K', ctypes.c_int), ('out_dtype', ctypes.c_int), ('accumulate', ctypes.c_int),
+                ('alpha', ctypes.c_float), ('asum', ctypes.c_void_p), ('asum_scale', ctypes.c_float),
+                ('reserved', ctypes.c_int)]
+
+
+_WGRAD_GROUP = {'defer': False, 'items': [], 'enabled': os.environ.get('TELL_WGRAD_GROUP', '1') != '0'}
+
+
+def wgrad_group_defer(on):
+    """While on, K-major weight-gradient GEMMs (gemm_tn) are queued instead of launched; wgrad_group_flush() runs the
+    queue as a few grouped launches (tell_gemm_tn_grouped).  The trainer turns it on around backward when no gradient
+    bucket has to leave before the pass is over."""
+    _WGRAD_GROUP['defer'] = bool(on) and _WGRAD_GROUP['enabled']
+
+
+def wgrad_group_drop():
+    _WGRAD_GROUP['items'] = []
+
+
+def wgrad_group_flush():
+    items, _WGRAD_GROUP['items'] = _WGRAD_GROUP['items'], []
+    # two products into overlapping outputs (tied projections accumulate into one gradient buffer) must not share a
+    # launch: the later one waits for the next round
+    while items:
+        now, later, spans = [], [], []
+        for it in items:
+            out = it[2]
+            lo = out.data_ptr()
+            hi = lo + ((out.shape[0] - 1) * out.stride(0) + out.shape[1]) * out.element_size()
+            if any(lo < h and l < hi for l, h in spans):
+                later.append(it)
+            else:
+                spans.append((lo, hi))
+                now.append(it)
+        _launch_wgrad_group(now)
+        items = later
+
+
+def _launch_wgrad_group(items):
+    arr = (_TnProblem * len(items))()
+    for q, (a, b, out, alpha, acc, asum, asum_scale) in zip(arr, items):
+        q.A, q.lda, q.B, q.ldb = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0)
+        q.C, q.ldc = out.data_ptr(), out.stride(0)
+        q.M, q.N, q.K = a.shape[1], b.shape[1], a.shape[0]
+        q.out_dtype, q.accumulate, q.alpha = hip.dt(out), acc, alpha
+        q.asum = asum.data_ptr() if asum is not None else None
+        q.asum_scale = asum_scale
+    call('tell_gemm_tn_grouped', len(items), arr)
 
 
 def gemm_nn(a, b_kn, b_t=None, out=None, out_dtype=None, alpha=1.0, act=0, aux=None, m_dev=None):

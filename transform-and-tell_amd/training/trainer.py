@@ -177,15 +177,19 @@ class Trainer:
         # the weight-norm chain rule of all GehringLinears runs as ONE launch after the pass - unless gradient buckets
         # leave during backward (a layer's gradients have to be final at its marker then)
         ops.wn_defer(not self._ranges)
+        ops.wgrad_group_defer(not self._ranges)                          # ... and so do the weight-gradient GEMMs
         try:
             scaled.backward()                                            # :229-231
         except BaseException:
             ops.wn_drop()
+            ops.wgrad_group_drop()
             raise
         finally:
             self._in_backward = False
             ops.wn_defer(False)
+            ops.wgrad_group_defer(False)
         ops.join_wgrad_stream()                                          # weight-gradient side stream (ops.py)
+        ops.wgrad_group_flush()
         ops.wn_flush()
 
     def skipped_steps(self):
