@@ -85,23 +85,29 @@ int tell_gemm_bf16(const void* A, long lda, int trans_a, const void* B, long ldb
                    float alpha, int accumulate, const int* m_dev, float* a_colsum, float a_colsum_scale,
                    tell_stream_t stream);
 
-/* n independent K-major products in a few launches (the weight gradients of a backward pass, queued until its end):
-   C_i[M,N] (+)= alpha_i * A_i^T B_i with A_i bf16 [K, M] (row stride lda) and B_i bf16 [K, N] - dW = dY^T X exactly as
-   the forward pass left dY and X - and, optionally, asum_i[m] += asum_scale_i * sum_k A_i[k][m] (the bias gradient).
-   `problems` is a HOST array. */
-typedef struct tell_gemm_tn_problem {
+/* n independent bf16 products in a few launches (the weight gradients of a backward pass queued until its end, the
+   query / output projections of a decoder layer's context attentions, their input gradients):
+       C_i[M,N] (+)= act((op(A_i) op(B_i)^T + bias_i) * alpha_i)
+   trans_a / trans_b as in tell_gemm_bf16: 0/0 the NT form (A [M,K], B [N,K]); 0/1 B stored [K,N] (dX = dY W);
+   1/1 A stored [K,M] as well (dW = dY^T X), which may carry asum_i[m] += asum_scale_i * sum_k A_i[k][m] (the bias
+   gradient).  bias: fp32 per column (bias_mode 1), NT form only; act: 0 none, 1 relu.  `problems` is a HOST array. */
+typedef struct tell_gemm_problem {
   const void* A; long lda;
   const void* B; long ldb;
   void* C; long ldc;
   int M, N, K;
+  int trans_a, trans_b;
   int out_dtype;          /* of C: TELL_F32 / TELL_BF16 */
   int accumulate;         /* C += */
   float alpha;
+  const float* bias;      /* fp32 [N] or NULL */
+  int bias_mode;          /* 0 none, 1 per column */
+  int act;
   float* asum;            /* fp32 [M] or NULL */
   float asum_scale;
   int reserved;
-} tell_gemm_tn_problem;
-int tell_gemm_tn_grouped(int n, const tell_gemm_tn_problem* problems, tell_stream_t stream);
+} tell_gemm_problem;
+int tell_gemm_grouped(int n, const tell_gemm_problem* problems, tell_stream_t stream);
 
 /* ---- casts / transposes / weight norm -------------------------------------- */
 int tell_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, tell_stream_t stream);

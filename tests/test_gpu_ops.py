@@ -634,3 +634,46 @@ def test_grouped_wgrad_gemms_match_single_launches():
         assert torch.equal(o0, o1)
         if s0 is not None:            # the fused column sums fold in tile order: 64- and 128-row tiles differ in the last bits
             assert torch.allclose(s0, s1, rtol=1e-5, atol=1e-3)
+
+
+def test_grouped_linear_matches_single_linears():
+    """ops.grouped_linear (one launch forward, one for the input gradients) == one ops.linear per item: outputs and
+    input gradients bit for bit, parameter gradients to fp32 rounding; row slices of a packed in_proj weight, scaling,
+    missing bias, ragged row counts."""
+    import tell_amd
+    from tell_amd import ops
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(11)
+    E = 1024
+    packed_w = torch.nn.Parameter(torch.randn(3 * E, E, device=DEV) * 0.03)
+    packed_b = torch.nn.Parameter(torch.randn(3 * E, device=DEV) * 0.1)
+    ws = [torch.nn.Parameter(torch.randn(n, k, device=DEV) * 0.03) for n, k in ((E, E), (512, E), (E, 2048), (200, 72 * 8))]
+    bs = [torch.nn.Parameter(torch.randn(w.shape[0], device=DEV) * 0.1) for w in ws]
+    specs = [(packed_w, (0, E), packed_b, (0, E), 0.125), (ws[0], None, bs[0], None, 1.0), (ws[1], None, None, None, 1.0),
+             (ws[2], None, bs[2], None, 0.5), (ws[3], None, bs[3], None, 1.0)]
+    xs0 = [torch.randn(32, 32, E, device=DEV).bfloat16(), torch.randn(32, 32, E, device=DEV).bfloat16(),
+           torch.randn(1024, E, device=DEV).bfloat16(), torch.randn(96, 2048, device=DEV).bfloat16(),
+           torch.randn(7, 3, 576, device=DEV).bfloat16()]
+    gys = None
+
+    def run(grouped):
+        nonlocal gys
+        for p in [packed_w, packed_b] + ws + bs:
+            p.grad = None
+        xs = [x.clone().requires_grad_(True) for x in xs0]
+        if grouped:
+            ys = ops.grouped_linear(xs, specs)
+        else:
+            ys = [ops.linear(x, w, b, rows=r, alpha=a, b_rows=br) for x, (w, r, b, br, a) in zip(xs, specs)]
+        if gys is None:
+            gys = [torch.randn_like(y) for y in ys]
+        torch.autograd.backward(ys, gys)
+        grads = [p.grad.clone() for p in [packed_w, packed_b] + ws + [b for b in bs if b.grad is not None]]
+        return [y.detach() for y in ys], [x.grad for x in xs], grads
+
+    y0, dx0, g0 = run(False)
+    y1, dx1, g1 = run(True)
+    for a, b in zip(y0 + dx0, y1 + dx1):
+        assert torch.equal(a, b)
+    for a, b in zip(g0, g1):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-4)

@@ -11,3 +11,4 @@ cd $root
 grep -v "^W2026\|^I2026\|^E2026" /tmp/prof_$name.log | tail -5 > gpurun_out/${name}_stdout.txt
 db=$(find /tmp/prof_$name -name '*.db' | head -1)
 python tools/rocprof_summary.py "$db" gpurun_out/${name}_kernel_stats.txt "$note"
+if [ -n "$SEQ_ANCHOR" ]; then python tools/rocprof_sequence.py "$db" gpurun_out/${name}_sequence.txt "$SEQ_ANCHOR"; fi

@@ -386,7 +386,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 template <typename OutT, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(GemmArgs p) {
+__device__ __forceinline__ void gemm_nt_glds_body(const GemmArgs& p, const int block, const int n_blocks) {
   constexpr int NW = WAVES_M * WAVES_N, BK = 64;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int IA = BM / 8 / NW, IB = BN / 8 / NW;   // wave-instructions (1 KiB each) per wave per tile
@@ -401,10 +401,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(Ge
   if (p.m_dev) { int md = *p.m_dev; M = md < M ? md : M; }
   const int N = p.N, K = p.K;
   const int tiles_n = (N + BN - 1) / BN;
-  const int nwg = gridDim.x;
+  const int nwg = n_blocks;
   int tile_id;
   {
-    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int orig = block, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
   // grouped traversal inside the XCD's contiguous range: GROUP_M m-tiles share one sweep over n, so the
@@ -569,6 +569,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(Ge
   }
   gemm_epilogue<OutT, MI, NI>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, M, N);
   gemm_ts_exit(p);
+}
+template <typename OutT, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV = false>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(GemmArgs p) {
+  gemm_nt_glds_body<OutT, BM, BN, WAVES_M, WAVES_N, CONV>(p, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------- 256x256 ping-pong kernel (bf16, full tiles only)
@@ -1076,38 +1080,51 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tx_kernel(Gemm
   gemm_tx_body<OutT, BM, BN, WAVES_M, WAVES_N, TA, TB, PF>(p, blockIdx.x, gridDim.x, blockIdx.y, gridDim.y);
 }
 
-// ------------------------------------------------------------- grouped weight-gradient GEMMs
-// The decoder's backward pass ends in ~80 independent dW = dY^T X products, most of them 256-512 tiles of 64x64 with
-// a 1024-row reduction: one workgroup per CU, 16 dependent K steps each - latency, not throughput (200-250 TFLOP/s).
-// Queued until the pass is over (ops.py) they run as a few launches of thousands of tiles: several workgroups per CU
-// hide each other's load latency and the ~80 launch gaps are gone.  Problems travel by value in the kernel arguments;
-// a workgroup finds its problem by walking the (8-aligned, so the XCD phase of a block is its problem-local one)
-// block prefix sums, which live in scalar registers.
-#define TX_GROUP_MAX 24
-struct TxProblem {
-  const void* A; const void* B; void* C; float* asum;
+// ------------------------------------------------------------- grouped GEMMs
+// The decoder works on M = T*B = 1024 rows: its GEMMs are 256-512 tiles of 64x64 with 16 dependent K steps - one
+// workgroup per CU, latency rather than throughput (200-250 TFLOP/s) - and every launch costs ~4.5 us of dispatch on
+// top.  Independent products therefore travel together: the ~80 weight gradients of a backward pass (queued until it
+// is over, ops.py), the query / output projections of a layer's four context attentions, their input gradients.  One
+// launch carries up to GROUP_MAX problems BY VALUE in its kernel arguments; a workgroup finds its problem by walking the
+// (8-aligned, so a block's XCD phase is its problem-local one) block prefix sums, which live in scalar registers.
+// Several workgroups per CU then hide each other's load latency.
+#define GROUP_MAX 24
+struct GroupProblem {
+  const void* A; const void* B; void* C; float* asum; const float* bias;
   long lda, ldb, ldc;
-  int M, N, K, accumulate;
+  int M, N, K, accumulate, bias_mode, act;
   float alpha, asum_scale;
 };
-struct TxGroup {
-  TxProblem pr[TX_GROUP_MAX];
-  int start[TX_GROUP_MAX + 1];
+struct GemmGroup {
+  GroupProblem pr[GROUP_MAX];
+  int start[GROUP_MAX + 1];
   int n;
 };
-template <typename OutT, int BM, int BN, int PF>
-__global__ __launch_bounds__(256, 2) void gemm_tx_group_kernel(TxGroup g) {
-  const int b = blockIdx.x;
+__device__ __forceinline__ int group_find(const GemmGroup& g, int b) {
   int i = 0;
   while (i + 1 < g.n && b >= g.start[i + 1]) ++i;            // block-uniform
-  const TxProblem& q = g.pr[i];
+  return i;
+}
+__device__ __forceinline__ GemmArgs group_args(const GroupProblem& q) {
   GemmArgs p;
-  p.A = q.A; p.B = q.B; p.C = q.C; p.bias = nullptr; p.aux = nullptr; p.m_dev = nullptr;
+  p.A = q.A; p.B = q.B; p.C = q.C; p.bias = q.bias; p.aux = nullptr; p.m_dev = nullptr;
   p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc; p.M = q.M; p.N = q.N; p.K = q.K;
-  p.bias_mode = 0; p.act = 0; p.accumulate = q.accumulate; p.alpha = q.alpha;
+  p.bias_mode = q.bias_mode; p.act = q.act; p.accumulate = q.accumulate; p.alpha = q.alpha;
   p.asum = q.asum; p.asum_scale = q.asum_scale; p.ts = nullptr; p.atomic_out = 0; p.conv_zero = nullptr;
   p.stat_mean = nullptr; p.stat_m2 = nullptr;
-  gemm_tx_body<OutT, BM, BN, 2, 2, true, true, PF>(p, b - g.start[i], g.start[i + 1] - g.start[i], 0, 1);
+  return p;
+}
+template <typename OutT, int BM, int BN, bool TA, bool TB, int PF>
+__global__ __launch_bounds__(256, 2) void gemm_tx_group_kernel(GemmGroup g) {
+  const int i = group_find(g, blockIdx.x);
+  const GemmArgs p = group_args(g.pr[i]);
+  gemm_tx_body<OutT, BM, BN, 2, 2, TA, TB, PF>(p, blockIdx.x - g.start[i], g.start[i + 1] - g.start[i], 0, 1);
+}
+template <typename OutT, int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_group_kernel(GemmGroup g) {
+  const int i = group_find(g, blockIdx.x);
+  const GemmArgs p = group_args(g.pr[i]);
+  gemm_nt_glds_body<OutT, BM, BN, 2, 2, false>(p, blockIdx.x - g.start[i], g.start[i + 1] - g.start[i]);
 }
 
 template <typename OutT, bool TA, bool TB>
@@ -1311,56 +1328,85 @@ extern "C" int tell_gemm_bf16(const void* A, long lda, int trans_a, const void* 
   return out_dtype == TELL_BF16 ? launch_gemm_tx<uint16_t, true, false>(a, stream) : launch_gemm_tx<float, true, false>(a, stream);
 }
 
-// n independent K-major products C_i[M,N] (+)= alpha_i * A_i^T B_i (A_i bf16 [K,M], B_i bf16 [K,N]: dW = dY^T X as the
-// forward pass left the operands), each with the optional fused column sums of A_i (the bias gradient).  Problems are
-// bucketed by output type and tile shape and each bucket runs as one launch per TX_GROUP_MAX problems.
-template <typename OutT, int BM, int BN, int PF>
-static int launch_tx_group(const tell_gemm_tn_problem* pr, const int* ids, int n, hipStream_t stream) {
-  for (int base = 0; base < n; base += TX_GROUP_MAX) {
-    TxGroup g;
-    g.n = n - base < TX_GROUP_MAX ? n - base : TX_GROUP_MAX;
+// n independent bf16 products in a few launches.  Problems are bucketed by form (NT / B K-major / both K-major), output
+// type and tile shape; each bucket runs as one launch per GROUP_MAX problems.  A problem the grouped kernels cannot take
+// (NT form with K % 64 != 0 or unaligned operands) is launched on its own through the ordinary dispatcher.
+template <typename Kern>
+static int launch_group(Kern kern, int bm, int bn, const tell_gemm_problem* pr, const int* ids, int n, hipStream_t stream) {
+  for (int base = 0; base < n; base += GROUP_MAX) {
+    GemmGroup g;
+    g.n = n - base < GROUP_MAX ? n - base : GROUP_MAX;
     g.start[0] = 0;
     for (int i = 0; i < g.n; ++i) {
-      const tell_gemm_tn_problem& q = pr[ids[base + i]];
-      TxProblem& t = g.pr[i];
-      t.A = q.A; t.B = q.B; t.C = q.C; t.asum = q.asum; t.lda = q.lda; t.ldb = q.ldb; t.ldc = q.ldc;
-      t.M = q.M; t.N = q.N; t.K = q.K; t.accumulate = q.accumulate; t.alpha = q.alpha; t.asum_scale = q.asum_scale;
-      const long tiles = (long)((q.M + BM - 1) / BM) * ((q.N + BN - 1) / BN);
+      const tell_gemm_problem& q = pr[ids[base + i]];
+      GroupProblem& t = g.pr[i];
+      t.A = q.A; t.B = q.B; t.C = q.C; t.asum = q.asum; t.bias = q.bias; t.lda = q.lda; t.ldb = q.ldb; t.ldc = q.ldc;
+      t.M = q.M; t.N = q.N; t.K = q.K; t.accumulate = q.accumulate; t.bias_mode = q.bias_mode; t.act = q.act;
+      t.alpha = q.alpha; t.asum_scale = q.asum_scale;
+      const long tiles = (long)((q.M + bm - 1) / bm) * ((q.N + bn - 1) / bn);
       g.start[i + 1] = g.start[i] + (int)((tiles + 7) / 8 * 8);
     }
-    hipLaunchKernelGGL((gemm_tx_group_kernel<OutT, BM, BN, PF>), dim3((unsigned)g.start[g.n]), dim3(256), 0, stream, g);
+    hipLaunchKernelGGL(kern, dim3((unsigned)g.start[g.n]), dim3(256), 0, stream, g);
   }
-  return tell_check_launch("gemm_tn_grouped");
+  return tell_check_launch("gemm_grouped");
 }
-extern "C" int tell_gemm_tn_grouped(int n, const tell_gemm_tn_problem* pr, hipStream_t stream) {
+extern "C" int tell_gemm_bf16(const void* A, long lda, int trans_a, const void* B, long ldb, int trans_b, void* C,
+                              long ldc, int M, int N, int K, int out_dtype, const float* bias, int bias_mode, int act,
+                              const void* aux, float alpha, int accumulate, const int* m_dev, float* a_colsum,
+                              float a_colsum_scale, hipStream_t stream);
+extern "C" int tell_gemm_grouped(int n, const tell_gemm_problem* pr, hipStream_t stream) {
   if (n <= 0) return TELL_OK;
   static const int tile_env = getenv("TELL_GROUP_TILE") ? atoi(getenv("TELL_GROUP_TILE")) : 0;   // A/B aid: 64 / 128
-  int* ids = (int*)alloca(sizeof(int) * 4 * n);
-  int cnt[4] = {0, 0, 0, 0};                         // buckets: (bf16, f32) x (64, 128)
-  long big_tiles[2] = {0, 0};
+  enum { FORMS = 3, BUCKETS = FORMS * 2 * 2 };       // form x (bf16, f32) x (64, 128)
+  int* ids = (int*)alloca(sizeof(int) * BUCKETS * n);
+  int* form_of = (int*)alloca(sizeof(int) * n);
+  int cnt[BUCKETS] = {0};
+  long big_tiles[FORMS][2] = {{0, 0}, {0, 0}, {0, 0}};
   for (int i = 0; i < n; ++i) {
-    const tell_gemm_tn_problem& q = pr[i];
-    TELL_REQUIRE(q.M > 0 && q.N > 0 && q.K > 0, "gemm_tn_grouped: bad dimension");
-    TELL_REQUIRE(q.out_dtype == TELL_F32 || q.out_dtype == TELL_BF16, "gemm_tn_grouped: bad output dtype");
-    TELL_REQUIRE(q.lda % 8 == 0 && q.ldb % 8 == 0 && (((uintptr_t)q.A | (uintptr_t)q.B) & 15) == 0,
-                 "gemm_tn_grouped: K-major operands need 16-byte aligned rows");
-    if (q.M >= 128 && q.N >= 128) big_tiles[q.out_dtype == TELL_F32] += (long)((q.M + 127) / 128) * ((q.N + 127) / 128);
-  }
-  for (int i = 0; i < n; ++i) {
-    const tell_gemm_tn_problem& q = pr[i];
-    const int f32 = q.out_dtype == TELL_F32;
-    // 128x128 tiles halve the LDS and L2 traffic per flop; they need enough tiles in flight to fill the chip twice over
-    bool big = q.M >= 128 && q.N >= 128 && big_tiles[f32] >= 512;
-    if (tile_env == 64) big = false;
-    if (tile_env == 128) big = q.M >= 128 && q.N >= 128;
-    const int b = f32 * 2 + (big ? 1 : 0);
-    ids[b * n + cnt[b]++] = i;
+    const tell_gemm_problem& q = pr[i];
+    TELL_REQUIRE(q.M > 0 && q.N > 0 && q.K > 0, "gemm_grouped: bad dimension");
+    TELL_REQUIRE(q.out_dtype == TELL_F32 || q.out_dtype == TELL_BF16, "gemm_grouped: bad output dtype");
+    TELL_REQUIRE(!(q.trans_a && !q.trans_b), "gemm_grouped: A K-major with B row-major is not a form of the step");
+    TELL_REQUIRE(q.act == 0 || q.act == 1, "gemm_grouped: act must be 0 (none) or 1 (relu)");
+    TELL_REQUIRE(q.asum == nullptr || q.trans_a, "gemm_grouped: fused column sums need a K-major A");
+    const bool aligned = q.lda % 8 == 0 && q.ldb % 8 == 0 && (((uintptr_t)q.A | (uintptr_t)q.B) & 15) == 0;
+    int form = q.trans_a ? 2 : q.trans_b ? 1 : 0;
+    if (form > 0) TELL_REQUIRE(aligned, "gemm_grouped: K-major operands need 16-byte aligned rows");
+    if (form == 0 && !(aligned && q.K % 64 == 0)) form = -1;                         // on its own
+    form_of[i] = form;
+    if (form >= 0 && q.M >= 128 && q.N >= 128)
+      big_tiles[form][q.out_dtype == TELL_F32] += (long)((q.M + 127) / 128) * ((q.N + 127) / 128);
   }
   int rc = TELL_OK;
-  if (cnt[0] && !rc) rc = launch_tx_group<uint16_t, 64, 64, 4>(pr, ids + 0 * n, cnt[0], stream);
-  if (cnt[1] && !rc) rc = launch_tx_group<uint16_t, 128, 128, 2>(pr, ids + 1 * n, cnt[1], stream);
-  if (cnt[2] && !rc) rc = launch_tx_group<float, 64, 64, 4>(pr, ids + 2 * n, cnt[2], stream);
-  if (cnt[3] && !rc) rc = launch_tx_group<float, 128, 128, 2>(pr, ids + 3 * n, cnt[3], stream);
+  for (int i = 0; i < n && !rc; ++i) {
+    const tell_gemm_problem& q = pr[i];
+    if (form_of[i] < 0) {
+      rc = tell_gemm_bf16(q.A, q.lda, 0, q.B, q.ldb, 0, q.C, q.ldc, q.M, q.N, q.K, q.out_dtype, q.bias, q.bias_mode, q.act,
+                          nullptr, q.alpha, q.accumulate, nullptr, nullptr, 0.f, stream);
+      continue;
+    }
+    const int f32 = q.out_dtype == TELL_F32;
+    // 128x128 tiles halve the LDS and L2 traffic per flop; they need enough tiles in flight to fill the chip twice over
+    bool big = q.M >= 128 && q.N >= 128 && big_tiles[form_of[i]][f32] >= 512;
+    if (tile_env == 64) big = false;
+    if (tile_env == 128) big = q.M >= 128 && q.N >= 128;
+    const int b = (form_of[i] * 2 + f32) * 2 + (big ? 1 : 0);
+    ids[b * n + cnt[b]++] = i;
+  }
+#define GROUP_RUN(B, KERN, BM, BN) if (cnt[B] && !rc) rc = launch_group(KERN, BM, BN, pr, ids + (B) * n, cnt[B], stream);
+  GROUP_RUN(0, (gemm_nt_group_kernel<uint16_t, 64, 64>), 64, 64)
+  GROUP_RUN(1, (gemm_nt_group_kernel<uint16_t, 128, 128>), 128, 128)
+  GROUP_RUN(2, (gemm_nt_group_kernel<float, 64, 64>), 64, 64)
+  GROUP_RUN(3, (gemm_nt_group_kernel<float, 128, 128>), 128, 128)
+  GROUP_RUN(4, (gemm_tx_group_kernel<uint16_t, 64, 64, false, true, 4>), 64, 64)
+  GROUP_RUN(5, (gemm_tx_group_kernel<uint16_t, 128, 128, false, true, 2>), 128, 128)
+  GROUP_RUN(6, (gemm_tx_group_kernel<float, 64, 64, false, true, 4>), 64, 64)
+  GROUP_RUN(7, (gemm_tx_group_kernel<float, 128, 128, false, true, 2>), 128, 128)
+  GROUP_RUN(8, (gemm_tx_group_kernel<uint16_t, 64, 64, true, true, 4>), 64, 64)
+  GROUP_RUN(9, (gemm_tx_group_kernel<uint16_t, 128, 128, true, true, 2>), 128, 128)
+  GROUP_RUN(10, (gemm_tx_group_kernel<float, 64, 64, true, true, 4>), 64, 64)
+  GROUP_RUN(11, (gemm_tx_group_kernel<float, 128, 128, true, true, 2>), 128, 128)
+#undef GROUP_RUN
   return rc;
 }
 

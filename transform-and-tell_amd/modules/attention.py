@@ -78,6 +78,28 @@ class MultiHeadAttention(nn.Module):
         kv = ops.kv_linear(src, wk, rk, wv, rv, self.in_proj_bias, E)
         return kv.transpose(0, 1) if src is bm else kv
 
+    # The three stages of forward() for a caller that runs SEVERAL attentions side by side (the decoder's context
+    # block): the query and output projections of all of them go out as one grouped launch each (ops.grouped_linear).
+    def q_spec(self):
+        wq, rq = self._wrows(0)
+        return (wq, rq, self.in_proj_bias, (0, self.embed_dim), self.scaling)                      # :348-353
+
+    def out_spec(self):
+        return (self.out_proj.weight, None, self.out_proj.bias, None, 1.0)
+
+    def core(self, q, key, key_padding_mask=None):
+        """softmax(q K^T) V of a training step: q already projected and scaled, K / V projected here."""
+        if key.shape[0] > 0 and key.shape[2] > 0:
+            k, v = self.project_kv_packed(key), None       # K and V as one [S,B,2E] projection
+        else:
+            k, v = self.project_kv(key)
+        mask = None
+        if key_padding_mask is not None and k.shape[0] > 0:
+            mask = key_padding_mask if key_padding_mask.dtype == torch.uint8 else \
+                key_padding_mask.to(torch.uint8).contiguous()
+        return ops.attention(q, k, v, mask, self.bias_k, self.bias_v, self.num_heads, self.add_zero_attn, self.dropout,
+                             self.training)
+
     def forward(self, query, key, value=None, key_padding_mask=None, incremental_state=None,
                 need_weights=True, static_kv=True, attn_mask=None, key_t=None, kv=None):
         """kv: optional (k, v) already projected by `project_kv` - the contexts are static during

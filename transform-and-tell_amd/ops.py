@@ -126,13 +126,40 @@ def gemm_tn(a_km, b_kn, out=None, out_dtype=None, accumulate=False, alpha=1.0, m
     return gemm(at, bt, out=out, out_dtype=out_dtype, accumulate=accumulate, alpha=alpha, m_dev=m_dev)
 
 
-class _TnProblem(ctypes.Structure):
-    """tell_gemm_tn_problem (include/tell_hip.h)."""
+class _GemmProblem(ctypes.Structure):
+    """tell_gemm_problem (include/tell_hip.h)."""
     _fields_ = [('A', ctypes.c_void_p), ('lda', ctypes.c_long), ('B', ctypes.c_void_p), ('ldb', ctypes.c_long),
                 ('C', ctypes.c_void_p), ('ldc', ctypes.c_long), ('M', ctypes.c_int), ('N', ctypes.c_int),
-                ('K', ctypes.c_int), ('out_dtype', ctypes.c_int), ('accumulate', ctypes.c_int),
-                ('alpha', ctypes.c_float), ('asum', ctypes.c_void_p), ('asum_scale', ctypes.c_float),
-                ('reserved', ctypes.c_int)]
+                ('K', ctypes.c_int), ('trans_a', ctypes.c_int), ('trans_b', ctypes.c_int),
+                ('out_dtype', ctypes.c_int), ('accumulate', ctypes.c_int), ('alpha', ctypes.c_float),
+                ('bias', ctypes.c_void_p), ('bias_mode', ctypes.c_int), ('act', ctypes.c_int),
+                ('asum', ctypes.c_void_p), ('asum_scale', ctypes.c_float), ('reserved', ctypes.c_int)]
+
+
+def gemm_grouped(problems):
+    """Independent bf16 products in a few launches (tell_gemm_grouped).  problems: dicts with a, b, out (tensors),
+    form ('nt': a [M,K], b [N,K]; 'nn': b stored [K,N]; 'tn': a stored [K,M] as well) and optionally alpha,
+    accumulate, bias (fp32 [N], 'nt' only), act, asum, asum_scale."""
+    if not problems:
+        return
+    arr = (_GemmProblem * len(problems))()
+    for q, pr in zip(arr, problems):
+        a, b, out, form = pr['a'], pr['b'], pr['out'], pr['form']
+        assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.stride(1) == 1 and b.stride(1) == 1 and \
+            out.stride(1) == 1
+        q.A, q.lda, q.B, q.ldb, q.C, q.ldc = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), \
+            out.stride(0)
+        q.trans_a, q.trans_b = int(form == 'tn'), int(form in ('tn', 'nn'))
+        q.M = a.shape[1] if form == 'tn' else a.shape[0]
+        q.N = b.shape[0] if form == 'nt' else b.shape[1]
+        q.K = b.shape[1] if form == 'nt' else b.shape[0]            # ('nn': dY may carry zero padding beyond K)
+        q.out_dtype, q.accumulate, q.alpha = hip.dt(out), int(pr.get('accumulate', False)), float(pr.get('alpha', 1.0))
+        bias = pr.get('bias')
+        q.bias, q.bias_mode, q.act = (bias.data_ptr() if bias is not None else None), int(bias is not None), \
+            int(pr.get('act', 0))
+        asum = pr.get('asum')
+        q.asum, q.asum_scale = (asum.data_ptr() if asum is not None else None), float(pr.get('asum_scale', 1.0))
+    call('tell_gemm_grouped', len(problems), arr)
 
 
 _WGRAD_GROUP = {'defer': False, 'items': [], 'enabled': os.environ.get('TELL_WGRAD_GROUP', '1') != '0'}
@@ -169,15 +196,8 @@ def wgrad_group_flush():
 
 
 def _launch_wgrad_group(items):
-    arr = (_TnProblem * len(items))()
-    for q, (a, b, out, alpha, acc, asum, asum_scale) in zip(arr, items):
-        q.A, q.lda, q.B, q.ldb = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0)
-        q.C, q.ldc = out.data_ptr(), out.stride(0)
-        q.M, q.N, q.K = a.shape[1], b.shape[1], a.shape[0]
-        q.out_dtype, q.accumulate, q.alpha = hip.dt(out), acc, alpha
-        q.asum = asum.data_ptr() if asum is not None else None
-        q.asum_scale = asum_scale
-    call('tell_gemm_tn_grouped', len(items), arr)
+    gemm_grouped([dict(a=a, b=b, out=out, form='tn', alpha=alpha, accumulate=acc, asum=asum, asum_scale=asum_scale)
+                  for a, b, out, alpha, acc, asum, asum_scale in items])
 
 
 def gemm_nn(a, b_kn, b_t=None, out=None, out_dtype=None, alpha=1.0, act=0, aux=None, m_dev=None):
@@ -538,6 +558,78 @@ class LinearFn(Function):
             dx = gemm_nn(dy2, weight(w_param, rows), b_t=lambda: weight_t(w_param, rows), alpha=alpha)
             dx = dx.reshape(xshape) if dx.is_contiguous() else dx.contiguous().view(xshape)
         return dx, None, None, None, None, None, None, None, None
+
+
+class GroupedLinearFn(Function):
+    """n independent plain linears y_i = (x_i W_i[rows_i]^T + b_i[b_rows_i]) * alpha_i as ONE launch forward
+    (tell_gemm_grouped, NT form) and one launch for the input gradients (B K-major form); the weight gradients go
+    through gemm_tn - queued with everything else while the trainer defers them.  The decoder's context block uses it
+    for the query projections and the output projections of its attentions (multi_head.py:488-526, 4 per layer each).
+    bf16 path only; specs: [(w_param, rows, b_param, b_rows, alpha)]."""
+
+    @staticmethod
+    def forward(ctx, specs, *xs):
+        x2s, ys, probs = [], [], []
+        for x, (w_param, rows, b_param, b_rows, alpha) in zip(xs, specs):
+            x2 = as2d(x)
+            w = weight(w_param, rows)
+            b = None
+            if b_param is not None:
+                b = b_param.detach() if b_rows is None else b_param.detach()[b_rows[0]:b_rows[1]]
+            y = torch.empty(x2.shape[0], w.shape[0], dtype=x2.dtype, device=x2.device)
+            probs.append(dict(a=x2, b=w, out=y, form='nt', bias=b, alpha=alpha))
+            x2s.append(x2)
+            ys.append(y.view(*x.shape[:-1], y.shape[1]))
+        gemm_grouped(probs)
+        ctx.save_for_backward(*x2s)
+        ctx.specs = specs
+        ctx.shapes = [x.shape for x in xs]
+        ctx.need_dx = [x.requires_grad for x in xs]
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x2s = ctx.saved_tensors
+        dxs, probs = [], []
+        for x2, dy, shape, need_dx, (w_param, rows, b_param, b_rows, alpha) in zip(x2s, dys, ctx.shapes, ctx.need_dx,
+                                                                                  ctx.specs):
+            if dy is None:
+                dxs.append(None)
+                continue
+            dy2 = as2d(dy)
+            if not _kmajor_ok(dy2):
+                dy2 = dy2.contiguous()
+            r0, r1 = rows if rows is not None else (0, w_param.shape[0])
+            gb = None
+            if b_param is not None and b_param.requires_grad:
+                gb = grad_buffer(b_param)
+                gb = gb if b_rows is None else gb[b_rows[0]:b_rows[1]]
+            if w_param.requires_grad:
+                gw = grad_buffer(w_param)
+                gemm_tn(dy2, x2, out=gw.view(gw.shape[0], -1)[r0:r1], alpha=alpha, accumulate=True, asum=gb,
+                        asum_scale=alpha)
+            elif gb is not None:
+                colsum_into(dy2, gb, scale=alpha)
+            if need_dx:
+                w = weight(w_param, rows)
+                dx = torch.empty(dy2.shape[0], w.shape[1], dtype=dy2.dtype, device=dy2.device)
+                probs.append(dict(a=dy2, b=w, out=dx, form='nn', alpha=alpha))
+                dxs.append(dx.view(shape))
+            else:
+                dxs.append(None)
+        gemm_grouped(probs)
+        return (None,) + tuple(dxs)
+
+
+def grouped_linear(xs, specs):
+    """[y_i] for [x_i] and specs [(w_param, rows, b_param, b_rows, alpha)]: one launch (bf16 CUDA tensors with rows of
+    whole 16-byte chunks), else one ops.linear per item."""
+    ok = rt.compute_dtype() == torch.bfloat16 and all(
+        x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 8 == 0 and as2d(x).stride(1) == 1 and
+        as2d(x).stride(0) % 8 == 0 and as2d(x).data_ptr() % 16 == 0 for x in xs)
+    if not ok or len(xs) < 2:
+        return [linear(x, w, b, rows=rows, alpha=alpha, b_rows=b_rows) for x, (w, rows, b, b_rows, alpha) in zip(xs, specs)]
+    return list(GroupedLinearFn.apply(specs, *xs))
 
 
 def linear(x, w_param, b_param=None, rows=None, act=0, alpha=1.0, x_t=None, b_rows=None):
