@@ -5,7 +5,8 @@ sys.path.insert(0, '.')
 import tell_amd
 from tell_amd import ops
 
-shapes = [(8192, 3072, 1024), (8192, 4096, 1024), (8192, 1024, 4096), (8192, 1024, 1024), (8192, 2048, 1024),
+shapes = [(16384, 3072, 1024), (16384, 4096, 1024), (16384, 1024, 4096), (16384, 1024, 1024), (16384, 2048, 1024),
+          (8192, 3072, 1024), (8192, 4096, 1024), (8192, 1024, 4096), (8192, 1024, 1024), (8192, 2048, 1024),
           (784, 2048, 2048), (512, 4096, 1024), (512, 1024, 4096), (512, 2048, 1024)]
 
 
