@@ -77,6 +77,47 @@ __device__ __forceinline__ void stage32(T* tile, int stride, T* tileT, int strid
     }
   }
 }
+// stage32 split in two for software prefetch by ONE wave (64 lanes, 32 rows x D): load32 issues the tile's global loads
+// into registers (rows without a source read `dummy` and are zeroed at the store), store32 writes them to tile[row][D]
+// and / or tileT[d][row] later - the loads of key tile i+1 are in flight while tile i is being computed.
+template <typename T, int D> struct Tile32Regs { uint4 v[(32 * D / Elem<T>::VEC + 63) / 64]; unsigned ok; };
+template <typename T, int D, typename RowPtr>
+__device__ __forceinline__ void load32(Tile32Regs<T, D>& r, int lane, RowPtr rowptr, const T* dummy) {
+  constexpr int VEC = Elem<T>::VEC, CPR = D / VEC, N = (32 * CPR + 63) / 64;
+  r.ok = 0u;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int c = lane + 64 * i, row = c / CPR, ch = c % CPR;
+    const T* p = c < 32 * CPR ? rowptr(row) : nullptr;
+    const bool ok = p != nullptr;
+    r.v[i] = *reinterpret_cast<const uint4*>((ok ? p : dummy) + (ok ? ch * VEC : 0));
+    r.ok |= ok ? 1u << i : 0u;
+  }
+}
+template <typename T, int D>
+__device__ __forceinline__ void store32(const Tile32Regs<T, D>& r, T* tile, int stride, T* tileT, int strideT, int lane) {
+  constexpr int VEC = Elem<T>::VEC, CPR = D / VEC, N = (32 * CPR + 63) / 64;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int c = lane + 64 * i, row = c / CPR, ch = c % CPR;
+    if (c >= 32 * CPR) continue;
+    const uint4 v = (r.ok >> i) & 1u ? r.v[i] : make_uint4(0, 0, 0, 0);
+    if (tile) {
+      if constexpr (sizeof(T) == 2) {
+        *reinterpret_cast<uint4*>(tile + row * stride + ch * VEC) = v;
+      } else {
+        float* q = reinterpret_cast<float*>(tile) + row * stride + ch * VEC;
+        q[0] = __uint_as_float(v.x); q[1] = __uint_as_float(v.y);
+        q[2] = __uint_as_float(v.z); q[3] = __uint_as_float(v.w);
+      }
+    }
+    if (tileT) {
+      const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) tileT[(ch * VEC + k) * strideT + row] = e[k];
+    }
+  }
+}
 template <typename T>
 __device__ __forceinline__ void zero_lds(T* p, int n, int tid, int nthr) {
   for (int i = tid; i < n; i += nthr) p[i] = (T)0;
@@ -133,11 +174,13 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
   const T* bk = static_cast<const T*>(p.bias_k);
   const T* bv = static_cast<const T*>(p.bias_v);
 
-  stage32<T, D>(Qs, DS, (T*)nullptr, 0, lane, 64, [&](int row) -> const T* {
+  // every global load of the prologue is issued before the first use of any of them: Q, then this wave's first K / V
+  // tile (one round trip, not three)
+  Tile32Regs<T, D> rq;
+  load32<T, D>(rq, lane, [&](int row) -> const T* {
     int t = q0 + row;
     return (active && t < p.Tq) ? qg + t * p.q_st + b * p.q_sb + (long)h * D : nullptr;
   }, qg);
-  if (DP > D) zero_lds(Vt, DP * SS, lane, 64);   // rows d >= D stay zero
 
   f32x16 o[DF];
 #pragma unroll
@@ -147,24 +190,36 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
   float m_run = -INFINITY, l_run = 0.f;
   const int qi = lane & 31;
 
+  // this wave's key tiles are prefetched one iteration ahead (registers), so their global latency hides under the
+  // previous tile's MFMAs and softmax instead of standing in front of every tile
+  Tile32Regs<T, D> rk, rv;
+  auto fetch = [&](int kt_) __attribute__((always_inline)) {
+    const int s0_ = kt_ * 32;
+    load32<T, D>(rk, lane, [&](int row) -> const T* {
+      int s = s0_ + row;
+      if (s < p.S) return kg + s * p.k_ss + b * p.k_sb + (long)h * D;
+      if (s == p.S && p.has_bias) return bk + (long)h * D;
+      return nullptr;
+    }, qg);
+    load32<T, D>(rv, lane, [&](int row) -> const T* {
+      int s = s0_ + row;
+      if (s < p.S) return vg + s * p.v_ss + b * p.v_sb + (long)h * D;
+      if (s == p.S && p.has_bias) return bv + (long)h * D;
+      return nullptr;
+    }, qg);
+  };
+  if (active && ks < nkt) fetch(ks);
+  store32<T, D>(rq, Qs, DS, (T*)nullptr, 0, lane);
+  if (DP > D) zero_lds(Vt, DP * SS, lane, 64);   // rows d >= D stay zero
   for (int it = 0; it < iters; ++it) {
     const int kt = it * KSPLIT + ks;
     const bool tv = active && kt < nkt;
     const int s0 = kt * 32;
     __syncthreads();                              // previous tile fully consumed
     if (tv) {
-      stage32<T, D>(Ks, DS, (T*)nullptr, 0, lane, 64, [&](int row) -> const T* {
-        int s = s0 + row;
-        if (s < p.S) return kg + s * p.k_ss + b * p.k_sb + (long)h * D;
-        if (s == p.S && p.has_bias) return bk + (long)h * D;
-        return nullptr;
-      }, qg);
-      stage32<T, D>((T*)nullptr, 0, Vt, SS, lane, 64, [&](int row) -> const T* {
-        int s = s0 + row;
-        if (s < p.S) return vg + s * p.v_ss + b * p.v_sb + (long)h * D;
-        if (s == p.S && p.has_bias) return bv + (long)h * D;
-        return nullptr;
-      }, qg);
+      store32<T, D>(rk, Ks, DS, (T*)nullptr, 0, lane);
+      store32<T, D>(rv, (T*)nullptr, 0, Vt, SS, lane);
+      if (kt + KSPLIT < nkt) fetch(kt + KSPLIT);
       if (lane < 32) {                              // key-padding mask + range, branch-free in the softmax
         const int s = s0 + lane;
         bool ok = s < S_total;
@@ -784,25 +839,68 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(AttnArgs p) {
   for (int qb = 0; qb < QB; ++qb) {
     const int q0 = qb * 32;
     __syncthreads();                              // all waves done with the previous q block
-    auto qrow = [&](const T* base, long st, long sb) {
-      return [=](int row) -> const T* {
-        int t = q0 + row;
-        return t < p.Tq ? base + t * st + b * sb + (long)h * D : nullptr;
-      };
+    // Prologue in ONE global round trip: this wave's first K / V tile, then per thread one 16-byte chunk each of Q, dO
+    // and O (row c / CPR, chunk c % CPR) - Q and dO go to LDS (row-major and transposed), delta[q] = <dO[q], O[q]>
+    // folds over the CPR lanes of a row.  (Staged one after the other, with delta as a loop of per-row wave
+    // reductions, the prologue was ~12 dependent round trips: most of the 29 us a 4-key context cost.)
+    Tile32Regs<T, D> rk, rv;
+    auto fetch = [&](int kt_) __attribute__((always_inline)) {
+      const int s0_ = kt_ * 32;
+      load32<T, D>(rk, lane, [&](int row) -> const T* {
+        int s = s0_ + row;
+        if (s < p.S) return kg + s * p.k_ss + b * p.k_sb + (long)h * D;
+        if (s == p.S && p.has_bias) return bk + (long)h * D;
+        return nullptr;
+      }, qg);
+      load32<T, D>(rv, lane, [&](int row) -> const T* {
+        int s = s0_ + row;
+        if (s < p.S) return vg + s * p.v_ss + b * p.v_sb + (long)h * D;
+        if (s == p.S && p.has_bias) return bv + (long)h * D;
+        return nullptr;
+      }, qg);
     };
-    stage32<T, D>(Qs, DS, Qt, SS, tid, 64 * NW, qrow(qg, p.q_st, p.q_sb), qg);
-    stage32<T, D>(dOs, DS, dOt, SS, tid, 64 * NW, qrow(dog, p.o_st, p.o_sb), qg);
-    for (int row = wave; row < 32; row += NW) {   // delta[q] = <dO[q], O[q]>
-      const int t = q0 + row;
-      float s = 0.f;
-      if (t < p.Tq)
-        for (int d = lane; d < D; d += 64)
-          s += Elem<T>::ld(dog + t * p.o_st + b * p.o_sb + (long)h * D + d) *
-               Elem<T>::ld(og + t * p.o_st + b * p.o_sb + (long)h * D + d);
-      s = wave_sum(s);
-      if (lane == 0) {
-        delta_s[row] = s;
-        lse_s[row] = t < p.Tq ? p.lse[(long)bh * p.Tq + t] : INFINITY;
+    if (wave < nkt) fetch(wave);
+    {
+      constexpr int VEC = Elem<T>::VEC, CPR = D / VEC;
+      static_assert((32 * CPR) % 64 == 0 && CPR <= 16 && (CPR & (CPR - 1)) == 0, "whole waves, rows inside a wave");
+      for (int c = tid; c < 32 * CPR; c += 64 * NW) {
+        const int row = c / CPR, ch = c % CPR, t = q0 + row;
+        const bool ok = t < p.Tq;
+        const long qo = ok ? t * p.q_st + b * p.q_sb + (long)h * D + ch * VEC : 0;
+        const long oo = ok ? t * p.o_st + b * p.o_sb + (long)h * D + ch * VEC : 0;
+        uint4 vq = *reinterpret_cast<const uint4*>(qg + qo);
+        uint4 vdo = *reinterpret_cast<const uint4*>((ok ? dog : qg) + oo);
+        uint4 vo = *reinterpret_cast<const uint4*>((ok ? og : qg) + oo);
+        const float lse_row = p.lse[(long)bh * p.Tq + (ok ? t : 0)];
+        if (!ok) vq = vdo = vo = make_uint4(0, 0, 0, 0);
+        float fdo[VEC], fo[VEC];
+        unpack16(vdo, fdo, (const T*)nullptr);
+        unpack16(vo, fo, (const T*)nullptr);
+        float part = 0.f;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) part += fdo[k] * fo[k];
+#pragma unroll
+        for (int o = CPR / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        if (ch == 0) {
+          delta_s[row] = part;
+          lse_s[row] = ok ? lse_row : INFINITY;
+        }
+        if constexpr (sizeof(T) == 2) {
+          *reinterpret_cast<uint4*>(Qs + row * DS + ch * VEC) = vq;
+          *reinterpret_cast<uint4*>(dOs + row * DS + ch * VEC) = vdo;
+        } else {
+          float* q1 = reinterpret_cast<float*>(Qs) + row * DS + ch * VEC;
+          float* q2 = reinterpret_cast<float*>(dOs) + row * DS + ch * VEC;
+          q1[0] = __uint_as_float(vq.x); q1[1] = __uint_as_float(vq.y); q1[2] = __uint_as_float(vq.z); q1[3] = __uint_as_float(vq.w);
+          q2[0] = __uint_as_float(vdo.x); q2[1] = __uint_as_float(vdo.y); q2[2] = __uint_as_float(vdo.z); q2[3] = __uint_as_float(vdo.w);
+        }
+        const T* eq = reinterpret_cast<const T*>(&vq);
+        const T* ed = reinterpret_cast<const T*>(&vdo);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          Qt[(ch * VEC + k) * SS + row] = eq[k];
+          dOt[(ch * VEC + k) * SS + row] = ed[k];
+        }
       }
     }
     f32x16 dq[DF];
@@ -811,24 +909,16 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[f][r] = 0.f;
 
+    // (key tiles prefetched one iteration ahead, as in the forward kernel)
     for (int it = 0; it < iters; ++it) {
       const int kt = it * NW + wave;
       const bool tv = kt < nkt;
       const int s0 = kt * 32;
       __syncthreads();
       if (tv) {
-        stage32<T, D>(Ks, DS, Kt, SS, lane, 64, [&](int row) -> const T* {
-          int s = s0 + row;
-          if (s < p.S) return kg + s * p.k_ss + b * p.k_sb + (long)h * D;
-          if (s == p.S && p.has_bias) return bk + (long)h * D;
-          return nullptr;
-        }, qg);
-        stage32<T, D>(Vs, DS, (T*)nullptr, 0, lane, 64, [&](int row) -> const T* {
-          int s = s0 + row;
-          if (s < p.S) return vg + s * p.v_ss + b * p.v_sb + (long)h * D;
-          if (s == p.S && p.has_bias) return bv + (long)h * D;
-          return nullptr;
-        }, qg);
+        store32<T, D>(rk, Ks, DS, Kt, SS, lane);
+        store32<T, D>(rv, Vs, DS, (T*)nullptr, 0, lane);
+        if (kt + NW < nkt) fetch(kt + NW);
         if (lane < 32) {
           const int s = s0 + lane;
           bool ok = s < S_total;
@@ -1034,7 +1124,12 @@ extern "C" int tell_attn_bwd(const void* q, const void* k, const void* v, const 
   a.dbias_ld = (dbias_k && dbias_v == dbias_k + (long)H * D) ? 2L * H * D : (long)H * D;
   dim3 grid(B * H);
   if (dtype == TELL_BF16) {
-    if (D == 64) hipLaunchKernelGGL((attn_bwd_kernel<uint16_t, 64, 4>), grid, dim3(256), 0, stream, a);
+    // every wave of the workgroup owns 21.5 KB of LDS tiles (4 waves: 105 KB - one workgroup per CU, two rounds for
+    // B*H = 512): short contexts take only the waves that have a key tile to work on, so that all of B*H is resident
+    const int nkt = (S + (bias_k ? 1 : 0) + has_zero + 31) / 32;
+    if (D == 64 && nkt <= 1) hipLaunchKernelGGL((attn_bwd_kernel<uint16_t, 64, 1>), grid, dim3(64), 0, stream, a);
+    else if (D == 64 && nkt <= 4) hipLaunchKernelGGL((attn_bwd_kernel<uint16_t, 64, 2>), grid, dim3(128), 0, stream, a);
+    else if (D == 64) hipLaunchKernelGGL((attn_bwd_kernel<uint16_t, 64, 4>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((attn_bwd_kernel<uint16_t, 16, 4>), grid, dim3(256), 0, stream, a);
   } else {
     if (D == 64) hipLaunchKernelGGL((attn_bwd_kernel<float, 64, 2>), grid, dim3(128), 0, stream, a);
