@@ -178,6 +178,21 @@ int tell_layernorm_bwd(const void* dy, long ld_dy, const void* x, long ld_x, con
                        int dparam_accumulate, float* partial, int rows, int C, float p, uint32_t seed,
                        uint32_t salt, int dtype, tell_stream_t stream);
 
+/* n LayerNorms over ONE residual in one launch each way - the end of a decoder layer's context block
+   (decoder_faces_objects.py:283-352): y[:, i*C:(i+1)*C] = LayerNorm_i(res + dropout_p(x_i)), mean / rstd [n, rows].
+   Backward: dx_i (entries may be NULL), dres = sum_i dz_i (may be NULL), dgamma_i / dbeta_i ACCUMULATED; partial is a
+   workspace of n * tell_layernorm_bwd_blocks(rows) * 2 * C floats.  x, gamma, beta, dx, dgamma, dbeta, salts are HOST
+   arrays of n (<= 8) entries; every x_i / dx_i shares one row stride.  bf16, C = 512 or 1024, 16-byte aligned rows. */
+int tell_layernorm_cat_fwd(int n, const void* const* x, long ld_x, const void* res, long ld_r,
+                           const float* const* gamma, const float* const* beta, void* y, long ld_y, float* mean,
+                           float* rstd, int rows, int C, float eps, float p, uint32_t seed, const uint32_t* salts,
+                           int dtype, tell_stream_t stream);
+int tell_layernorm_cat_bwd(int n, const void* dcat, long ld_dcat, const void* const* x, long ld_x, const void* res,
+                           long ld_r, const float* const* gamma, const float* mean, const float* rstd,
+                           void* const* dx, long ld_dx, void* dres, long ld_dres, float* const* dgamma,
+                           float* const* dbeta, float* partial, int rows, int C, float p, uint32_t seed,
+                           const uint32_t* salts, int dtype, tell_stream_t stream);
+
 /* ---- LSTM decoder of the GloVe/LSTM baseline (tell/models/decoder_flattened_lstm.py) ----
  * nn.LSTMCell (:20-26, :160-161): g1 = x W_ih^T + b_ih and g2 = h W_hh^T + b_hh come from tell_gemm_nt ([B,4H], chunk
  * order i f g o); this applies the gate non-linearities and the state update.  gates: [B,4H] fp32, activated (saved). */

@@ -677,3 +677,45 @@ def test_grouped_linear_matches_single_linears():
         assert torch.equal(a, b)
     for a, b in zip(g0, g1):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize('C,rows,n', [(1024, 1024, 4), (512, 70, 2), (1024, 33, 3)])
+def test_layer_norm_cat_one_launch(C, rows, n):
+    """layer_norm_cat (n LayerNorms over one residual, one launch each way) == n ops.layer_norm calls + cat: same dropout
+    masks (same salt sequence), outputs bit for bit; gradients to bf16 rounding (the fused backward sums the residual
+    gradient in fp32 registers, the separate calls re-round it after every LayerNorm; < 1 % of the dx elements differ
+    in their last bit)."""
+    import tell_amd
+    from tell_amd import ops
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(17)
+    lns = [torch.nn.LayerNorm(C).to(DEV) for _ in range(n)]
+    for ln in lns:
+        ln.weight.data.uniform_(0.5, 1.5)
+        ln.bias.data.uniform_(-0.5, 0.5)
+    x0 = [torch.randn(rows, C, device=DEV).bfloat16() for _ in range(n)]
+    r0 = torch.randn(rows, C, device=DEV).bfloat16()
+    gy = torch.randn(rows, n * C, device=DEV).bfloat16()
+
+    def run(fused):
+        tell_amd.manual_seed(99)
+        for ln in lns:
+            ln.weight.grad = ln.bias.grad = None
+        xs = [x.clone().requires_grad_(True) for x in x0]
+        res = r0.clone().requires_grad_(True)
+        if fused:
+            y = ops.layer_norm_cat(xs, res, lns, 0.1, True)
+        else:
+            y = torch.cat([ops.layer_norm(x, res, ln.weight, ln.bias, ln.eps, 0.1, True) for x, ln in zip(xs, lns)], dim=-1)
+        y.backward(gy)
+        return y.detach(), [x.grad for x in xs], res.grad, [ln.weight.grad.clone() for ln in lns] + [ln.bias.grad.clone() for ln in lns]
+
+    y0, dx0, dr0, gp0 = run(False)
+    y1, dx1, dr1, gp1 = run(True)
+    assert torch.equal(y0, y1)
+    for a, b in zip(dx0, dx1):                      # (an fma here and there: last-bit differences before the bf16 rounding)
+        close(b, a.float().cpu(), torch.bfloat16)
+        assert (a != b).float().mean() < 0.01
+    close(dr1, dr0.float().cpu(), torch.bfloat16, scale=n)
+    for a, b in zip(gp0, gp1):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-3)

@@ -348,3 +348,247 @@ extern "C" int tell_layernorm_bwd(const void* dy, long ld_dy, const void* x, lon
   hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, stream, partial, nb, C, dgamma, dbeta, dparam_accumulate);
   return tell_check_launch("layernorm_bwd_finish");
 }
+
+// ---------------------------------------------------------------- n LayerNorms over one residual in one launch
+// cat_i LayerNorm_i(res + dropout(x_i)): the context block of a decoder layer (decoder_faces_objects.py:283-352) ends in
+// n = 4 LayerNorms of [rows, C] that share the residual and write adjacent column slices of context_fc's input.  One
+// launch each way instead of n (and, backward, n finish launches): forward is the vec kernel with the problem index on
+// blockIdx.y; backward walks the n problems of a row inside one wave, so the residual gradient sum_i dz_i is
+// accumulated in REGISTERS and written once (the per-problem launches re-read and re-rounded it n-1 times).
+#define LN_CAT_MAX 8
+struct LNCatArgs {
+  const void* x[LN_CAT_MAX];
+  const float* gamma[LN_CAT_MAX];
+  const float* beta[LN_CAT_MAX];
+  void* dx[LN_CAT_MAX];
+  float* dgamma[LN_CAT_MAX];
+  float* dbeta[LN_CAT_MAX];
+  uint32_t salt[LN_CAT_MAX];
+  int n;
+};
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_cat_fwd_kernel(LNCatArgs a, long ld_x, const T* __restrict__ res, long ld_r,
+                                                         T* __restrict__ y, long ld_y, float* __restrict__ mean,
+                                                         float* __restrict__ rstd, int rows, float eps, uint32_t thr,
+                                                         float inv_keep, uint32_t seed, const uint32_t* __restrict__ step) {
+  constexpr int VEC = Elem<T>::VEC, C = 64 * VEC * NCH;
+  const int i_p = blockIdx.y;
+  const uint32_t salt = tell_step_salt(a.salt[i_p], step);
+  const T* __restrict__ x = static_cast<const T*>(a.x[i_p]);
+  const float* __restrict__ gamma = a.gamma[i_p];
+  const float* __restrict__ beta = a.beta[i_p];
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[NCH][VEC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c0 = (lane + 64 * i) * VEC;
+    unpack16(*reinterpret_cast<const uint4*>(x + (long)row * ld_x + c0), v[i], (const T*)nullptr);
+    if (thr) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) v[i][k] *= tell_keep(seed, salt, (uint64_t)row * C + c0 + k, thr, inv_keep);
+    }
+    float r[VEC];
+    unpack16(*reinterpret_cast<const uint4*>(res + (long)row * ld_r + c0), r, (const T*)nullptr);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { v[i][k] += r[k]; s += v[i][k]; }
+  }
+  const float mu = wave_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { const float d = v[i][k] - mu; q += d * d; }
+  const float rs = rsqrtf(wave_sum(q) / C + eps);
+  if (lane == 0) { mean[(long)i_p * rows + row] = mu; rstd[(long)i_p * rows + row] = rs; }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c0 = (lane + 64 * i) * VEC;
+    float o[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) o[k] = (v[i][k] - mu) * rs * gamma[c0 + k] + beta[c0 + k];
+    *reinterpret_cast<uint4*>(y + (long)row * ld_y + (long)i_p * C + c0) = pack16(o, (const T*)nullptr);
+  }
+}
+
+// partial: [n][blocks][2][C]
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_cat_bwd_kernel(LNCatArgs a, const T* __restrict__ dcat, long ld_d, long ld_x,
+                                                         const T* __restrict__ res, long ld_r,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         long ld_dx, T* __restrict__ dres, long ld_dres,
+                                                         float* __restrict__ partial, int rows, uint32_t thr,
+                                                         float inv_keep, uint32_t seed, const uint32_t* __restrict__ step) {
+  constexpr int VEC = Elem<T>::VEC, C = 64 * VEC * NCH;
+  __shared__ float sm[4][2][C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * LN_BWD_ROWS + wave;
+  const bool live = row < rows;                                      // wave-uniform
+  float rres[NCH][VEC], dr[NCH][VEC];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    if (live) unpack16(*reinterpret_cast<const uint4*>(res + (long)row * ld_r + (lane + 64 * i) * VEC), rres[i], (const T*)nullptr);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) dr[i][k] = 0.f;
+  }
+  for (int i_p = 0; i_p < a.n; ++i_p) {
+    const uint32_t salt = tell_step_salt(a.salt[i_p], step);
+    const T* __restrict__ x = static_cast<const T*>(a.x[i_p]);
+    const float* __restrict__ gamma = a.gamma[i_p];
+    T* __restrict__ dx = static_cast<T*>(a.dx[i_p]);
+    float xh[NCH][VEC], g[NCH][VEC], keep[NCH][VEC];
+    float s1 = 0.f, s2 = 0.f, rs = 0.f;
+    if (live) {
+      const float mu = mean[(long)i_p * rows + row];
+      rs = rstd[(long)i_p * rows + row];
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c0 = (lane + 64 * i) * VEC;
+        float d[VEC];
+        unpack16(*reinterpret_cast<const uint4*>(x + (long)row * ld_x + c0), xh[i], (const T*)nullptr);
+        unpack16(*reinterpret_cast<const uint4*>(dcat + (long)row * ld_d + (long)i_p * C + c0), d, (const T*)nullptr);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          keep[i][k] = thr ? tell_keep(seed, salt, (uint64_t)row * C + c0 + k, thr, inv_keep) : 1.f;
+          xh[i][k] = (xh[i][k] * keep[i][k] + rres[i][k] - mu) * rs;
+          g[i][k] = d[k] * gamma[c0 + k];
+          s1 += g[i][k];
+          s2 += g[i][k] * xh[i][k];
+          sm[wave][0][c0 + k] = d[k] * xh[i][k];
+          sm[wave][1][c0 + k] = d[k];
+        }
+      }
+      s1 = wave_sum(s1) / C;
+      s2 = wave_sum(s2) / C;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c0 = (lane + 64 * i) * VEC;
+        float o[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          const float dz = rs * (g[i][k] - s1 - xh[i][k] * s2);
+          dr[i][k] += dz;
+          o[k] = dz * keep[i][k];
+        }
+        if (dx) *reinterpret_cast<uint4*>(dx + (long)row * ld_dx + c0) = pack16(o, (const T*)nullptr);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          sm[wave][0][(lane + 64 * i) * VEC + k] = 0.f;
+          sm[wave][1][(lane + 64 * i) * VEC + k] = 0.f;
+        }
+    }
+    __syncthreads();
+    float* out = partial + ((long)i_p * gridDim.x + blockIdx.x) * 2 * C;
+    const float* s = &sm[0][0][0];
+    for (int c = threadIdx.x; c < 2 * C; c += 256) out[c] = s[c] + s[2 * C + c] + s[4 * C + c] + s[6 * C + c];
+    __syncthreads();
+  }
+  if (live && dres) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      *reinterpret_cast<uint4*>(dres + (long)row * ld_dres + (lane + 64 * i) * VEC) = pack16(dr[i], (const T*)nullptr);
+  }
+}
+// as ln_bwd_finish_kernel, problem blockIdx.y (always accumulating)
+__global__ __launch_bounds__(1024) void ln_cat_bwd_finish_kernel(LNCatArgs a, const float* __restrict__ partial,
+                                                                 int n_blocks, int C) {
+  __shared__ float sm[16][64];
+  const int cx = threadIdx.x & 63, by = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  const float* part = partial + (long)blockIdx.y * n_blocks * 2 * C;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < 2 * C) {
+    const long ld = 2L * C;
+    int b = by;
+    for (; b + 48 < n_blocks; b += 64) {
+      s0 += part[(long)b * ld + c];
+      s1 += part[(long)(b + 16) * ld + c];
+      s2 += part[(long)(b + 32) * ld + c];
+      s3 += part[(long)(b + 48) * ld + c];
+    }
+    for (; b < n_blocks; b += 16) s0 += part[(long)b * ld + c];
+  }
+  sm[by][cx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (by == 0 && c < 2 * C) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += sm[k][cx];
+    float* dst = c < C ? a.dgamma[blockIdx.y] + c : a.dbeta[blockIdx.y] + (c - C);
+    *dst += s;
+  }
+}
+
+static int ln_cat_check(int n, int C, int dtype, const char* who) {
+  TELL_REQUIRE(n >= 1 && n <= LN_CAT_MAX, "layernorm_cat: 1..8 LayerNorms per launch");
+  TELL_REQUIRE(dtype == TELL_BF16 && (C == 512 || C == 1024), "layernorm_cat: bf16 rows of 512 or 1024 columns");
+  (void)who;
+  return TELL_OK;
+}
+// y[:, i*C:(i+1)*C] = LayerNorm_i(res + dropout_p(x_i)); mean / rstd: [n, rows].  Host arrays of n entries: x, gamma,
+// beta, salts.  bf16, C = 512 or 1024, 16-byte aligned rows.
+extern "C" int tell_layernorm_cat_fwd(int n, const void* const* x, long ld_x, const void* res, long ld_r,
+                                      const float* const* gamma, const float* const* beta, void* y, long ld_y,
+                                      float* mean, float* rstd, int rows, int C, float eps, float p, uint32_t seed,
+                                      const uint32_t* salts, int dtype, hipStream_t stream) {
+  if (rows <= 0) return TELL_OK;
+  int rc = ln_cat_check(n, C, dtype, "fwd");
+  if (rc) return rc;
+  TELL_REQUIRE(p >= 0.f && p < 1.f, "layernorm_cat_fwd: p must be in [0,1)");
+  TELL_REQUIRE(ld_x % 8 == 0 && ld_r % 8 == 0 && ld_y % 8 == 0 && (((uintptr_t)res | (uintptr_t)y) & 15) == 0,
+               "layernorm_cat_fwd: rows must be 16-byte aligned");
+  LNCatArgs a;
+  a.n = n;
+  for (int i = 0; i < n; ++i) {
+    TELL_REQUIRE(((uintptr_t)x[i] & 15) == 0, "layernorm_cat_fwd: rows must be 16-byte aligned");
+    a.x[i] = x[i]; a.gamma[i] = gamma[i]; a.beta[i] = beta[i]; a.salt[i] = salts[i];
+    a.dx[i] = nullptr; a.dgamma[i] = a.dbeta[i] = nullptr;
+  }
+  const uint32_t thr = p > 0.f ? tell_drop_threshold(p) : 0u;
+  const float ik = 1.f / (1.f - p);
+  const dim3 grid((rows + 3) / 4, n);
+  if (C == 512)
+    hipLaunchKernelGGL((ln_cat_fwd_kernel<uint16_t, 1>), grid, dim3(256), 0, stream, a, ld_x, (const uint16_t*)res, ld_r, (uint16_t*)y, ld_y, mean, rstd, rows, eps, thr, ik, seed, g_tell_rng_step);
+  else
+    hipLaunchKernelGGL((ln_cat_fwd_kernel<uint16_t, 2>), grid, dim3(256), 0, stream, a, ld_x, (const uint16_t*)res, ld_r, (uint16_t*)y, ld_y, mean, rstd, rows, eps, thr, ik, seed, g_tell_rng_step);
+  return tell_check_launch("layernorm_cat_fwd");
+}
+// Backward of the above: dx_i (NULL entries allowed), dres = sum_i dz_i (or NULL), dgamma_i / dbeta_i ACCUMULATED.
+// partial: workspace of n * tell_layernorm_bwd_blocks(rows) * 2 * C floats.
+extern "C" int tell_layernorm_cat_bwd(int n, const void* dcat, long ld_dcat, const void* const* x, long ld_x,
+                                      const void* res, long ld_r, const float* const* gamma, const float* mean,
+                                      const float* rstd, void* const* dx, long ld_dx, void* dres, long ld_dres,
+                                      float* const* dgamma, float* const* dbeta, float* partial, int rows, int C,
+                                      float p, uint32_t seed, const uint32_t* salts, int dtype, hipStream_t stream) {
+  if (rows <= 0) return TELL_OK;
+  int rc = ln_cat_check(n, C, dtype, "bwd");
+  if (rc) return rc;
+  TELL_REQUIRE(p >= 0.f && p < 1.f, "layernorm_cat_bwd: p must be in [0,1)");
+  TELL_REQUIRE(ld_x % 8 == 0 && ld_r % 8 == 0 && ld_dcat % 8 == 0 && ld_dx % 8 == 0 && ld_dres % 8 == 0 &&
+               (((uintptr_t)res | (uintptr_t)dcat | (uintptr_t)dres) & 15) == 0,
+               "layernorm_cat_bwd: rows must be 16-byte aligned");
+  LNCatArgs a;
+  a.n = n;
+  for (int i = 0; i < n; ++i) {
+    TELL_REQUIRE((((uintptr_t)x[i] | (uintptr_t)dx[i]) & 15) == 0, "layernorm_cat_bwd: rows must be 16-byte aligned");
+    a.x[i] = x[i]; a.gamma[i] = gamma[i]; a.beta[i] = nullptr; a.salt[i] = salts[i];
+    a.dx[i] = dx[i]; a.dgamma[i] = dgamma[i]; a.dbeta[i] = dbeta[i];
+  }
+  const uint32_t thr = p > 0.f ? tell_drop_threshold(p) : 0u;
+  const float ik = 1.f / (1.f - p);
+  const int nb = tell_layernorm_bwd_blocks(rows);
+  if (C == 512)
+    hipLaunchKernelGGL((ln_cat_bwd_kernel<uint16_t, 1>), dim3(nb), dim3(256), 0, stream, a, (const uint16_t*)dcat, ld_dcat, ld_x, (const uint16_t*)res, ld_r, mean, rstd, ld_dx, (uint16_t*)dres, ld_dres, partial, rows, thr, ik, seed, g_tell_rng_step);
+  else
+    hipLaunchKernelGGL((ln_cat_bwd_kernel<uint16_t, 2>), dim3(nb), dim3(256), 0, stream, a, (const uint16_t*)dcat, ld_dcat, ld_x, (const uint16_t*)res, ld_r, mean, rstd, ld_dx, (uint16_t*)dres, ld_dres, partial, rows, thr, ik, seed, g_tell_rng_step);
+  rc = tell_check_launch("layernorm_cat_bwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(ln_cat_bwd_finish_kernel, dim3((2 * C + 63) / 64, n), dim3(1024), 0, stream, a, partial, nb, C);
+  return tell_check_launch("layernorm_cat_bwd_finish");
+}

@@ -879,6 +879,9 @@ def layer_norm(x, res, gamma, beta, eps=1e-5, p=0.0, training=False):
     return LayerNormFn.apply(x, res, gamma, beta, eps, p, rt.next_salt() if p > 0 else 0)
 
 
+_LN_CAT = os.environ.get('TELL_LN_CAT', '1') != '0'          # A/B aid: 0 = one launch per LayerNorm
+
+
 class LNCatFn(Function):
     """cat_i LayerNorm_i(res + dropout(x_i)) along the feature axis: the n context branches of a decoder layer
     (decoder_faces_objects.py:283-352) write their normalised outputs straight into the [rows, n*C] input of
@@ -894,13 +897,25 @@ class LNCatFn(Function):
         mean = torch.empty(n, rows, dtype=torch.float32, device=res.device)
         rstd = torch.empty(n, rows, dtype=torch.float32, device=res.device)
         x2s = [as2d(x) for x in xs]
-        for i in range(n):
+        one = LNCatFn._one_launch(r2, x2s, C, n)
+        if one:
+            call('tell_layernorm_cat_fwd', n, _ptr_array(x2s), x2s[0].stride(0), r2, r2.stride(0),
+                 _ptr_array([g.detach() for g in gammas]), _ptr_array([b.detach() for b in betas]), cat, cat.stride(0),
+                 mean, rstd, rows, C, float(eps), float(p), rt.seed(), (ctypes.c_uint32 * n)(*salts), hip.dt(r2))
+        for i in range(0 if one else n):
             y = cat[:, i * C:(i + 1) * C]
             call('tell_layernorm_fwd', x2s[i], x2s[i].stride(0), r2, r2.stride(0), gammas[i].detach(), betas[i].detach(),
                  y, y.stride(0), mean[i], rstd[i], rows, C, float(eps), float(p), rt.seed(), salts[i], hip.dt(r2))
         ctx.save_for_backward(r2, mean, rstd, *x2s)
         ctx.meta = (gammas, betas, p, salts, n, res.shape, res.requires_grad, [x.requires_grad for x in xs])
         return cat.view(*res.shape[:-1], n * C)
+
+    @staticmethod
+    def _one_launch(r2, x2s, C, n):
+        """All n LayerNorms in one launch (tell_layernorm_cat_*): bf16, C = 512 / 1024, one row stride, 16-byte rows."""
+        return (_LN_CAT and r2.is_cuda and r2.dtype == torch.bfloat16 and C in (512, 1024) and 2 <= n <= 8 and
+                r2.stride(0) % 8 == 0 and r2.data_ptr() % 16 == 0 and
+                all(x.stride(0) == x2s[0].stride(0) and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0 for x in x2s))
 
     @staticmethod
     def backward(ctx, dcat):
@@ -912,6 +927,18 @@ class LNCatFn(Function):
         nb = hip.lib().tell_layernorm_bwd_blocks(rows)
         dres = torch.empty_like(r2) if need_dres else None
         dxs = []
+        if LNCatFn._one_launch(r2, x2s, C, n) and d2.stride(0) % 8 == 0 and d2.data_ptr() % 16 == 0:
+            partial = torch.empty(n * nb * 2 * C, dtype=torch.float32, device=r2.device)
+            dxl = [torch.empty_like(x2s[i]) if need_dx[i] else None for i in range(n)]
+            have = [d for d in dxl if d is not None]
+            call('tell_layernorm_cat_bwd', n, d2, d2.stride(0), _ptr_array(list(x2s)), x2s[0].stride(0), r2, r2.stride(0),
+                 _ptr_array([g.detach() for g in gammas]), mean, rstd,
+                 (ctypes.c_void_p * n)(*[d.data_ptr() if d is not None else None for d in dxl]),
+                 have[0].stride(0) if have else 0, dres, dres.stride(0) if dres is not None else 0,
+                 _ptr_array([grad_buffer(g) for g in gammas]), _ptr_array([grad_buffer(b) for b in betas]), partial,
+                 rows, C, float(p), rt.seed(), (ctypes.c_uint32 * n)(*salts), hip.dt(r2))
+            dxs = [d.view(shape) if d is not None else None for d in dxl]
+            return (dres.view(shape) if dres is not None else None, None, None, None, None, *dxs) + (None,) * (2 * n)
         for i in range(n):
             dy = d2[:, i * C:(i + 1) * C]
             partial = torch.empty(nb * 2 * C, dtype=torch.float32, device=r2.device)
