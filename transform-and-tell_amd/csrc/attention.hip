@@ -25,6 +25,13 @@ template <typename T, int D> struct ACfg {
   static constexpr int DF = DP / 32;
 };
 
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {   // -> v_cvt_pk_bf16_f32 (RNE)
+  f32x2_t f = {lo, hi};
+  bf16x2_t h = __builtin_convertvector(f, bf16x2_t);
+  return *reinterpret_cast<unsigned*>(&h);
+}
 template <typename T, int KD>
 __device__ __forceinline__ f32x16 mma32(f32x16 acc, const T* a, int as, const T* b, int bs, int lane) {
   if constexpr (sizeof(T) == 2) {
@@ -257,13 +264,34 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[f][r] *= alpha;
       const int t = q0 + qi;
+      if (p.thr) {                                            // one hash per aligned key pair when the row length is even
+        const uint64_t base = ((uint64_t)bh * p.Tq + t) * S_total + s0;
+        if ((S_total & 1) == 0) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kk = acc_row(r, lane);
-        float v = pr[r];
-        if (p.thr)
-          v *= tell_keep(p.seed, salt_eff, ((uint64_t)bh * p.Tq + t) * S_total + (s0 + kk), p.thr, p.inv_keep);
-        Elem<T>::st(Ps + qi * SS + kk, v);                    // P[q][key], key contiguous
+          for (int r = 0; r < 16; r += 2) {
+            float k0, k1;
+            tell_keep2(p.seed, salt_eff, base + acc_row(r, lane), p.thr, p.inv_keep, k0, k1);
+            pr[r] *= k0;
+            pr[r + 1] *= k1;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) pr[r] *= tell_keep(p.seed, salt_eff, base + acc_row(r, lane), p.thr, p.inv_keep);
+        }
+      }
+      // P[q][key], key contiguous: a register group holds 4 consecutive keys -> one 8-byte LDS write (bf16)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        T* pp = Ps + qi * SS + 8 * g + 4 * (lane >> 5);
+        if constexpr (sizeof(T) == 2) {
+          uint2 w;
+          w.x = pack_bf16x2(pr[4 * g], pr[4 * g + 1]);
+          w.y = pack_bf16x2(pr[4 * g + 2], pr[4 * g + 3]);
+          *reinterpret_cast<uint2*>(pp) = w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) Elem<T>::st(pp + e, pr[4 * g + e]);
+        }
       }
     }
     __syncthreads();
@@ -320,9 +348,18 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
   for (int f = 0; f < DF; ++f)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int d = f * 32 + acc_row(r, lane);
-      if (d < D) Elem<T>::st(og + d, o[f][r] * inv_l);
+    for (int g = 0; g < 4; ++g) {                     // 4 consecutive d per register group -> one 8-byte store (bf16)
+      const int d0 = f * 32 + 8 * g + 4 * (lane >> 5);
+      if (d0 >= D) continue;
+      if constexpr (sizeof(T) == 2) {
+        uint2 w;
+        w.x = pack_bf16x2(o[f][4 * g] * inv_l, o[f][4 * g + 1] * inv_l);
+        w.y = pack_bf16x2(o[f][4 * g + 2] * inv_l, o[f][4 * g + 3] * inv_l);
+        *reinterpret_cast<uint2*>(og + d0) = w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Elem<T>::st(og + d0 + e, o[f][4 * g + e] * inv_l);
+      }
     }
   if (lane < 32 && p.lse) p.lse[(long)bh * p.Tq + t] = l_run > 0.f ? m_run + __logf(l_run) : INFINITY;
 }
@@ -332,13 +369,6 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
 // K tile and the transposed V tile are staged ONCE per workgroup (all 256 threads, next tile
 // prefetched into registers under the MFMAs) and shared by the 4 waves; each wave keeps its own
 // Q tile, probability tile and O^T accumulators.  Per 64 keys and wave: 16 MFMA 32x32x16.
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {   // -> v_cvt_pk_bf16_f32 (RNE)
-  f32x2_t f = {lo, hi};
-  bf16x2_t h = __builtin_convertvector(f, bf16x2_t);
-  return *reinterpret_cast<unsigned*>(&h);
-}
 
 template <typename T, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_tile64_kernel(AttnArgs p) {
@@ -935,45 +965,99 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(AttnArgs p) {
         dp = mma32<T, D>(dp, Vs, DS, dOs, DS, lane);          // dPd^T[key][q] = V.dO^T
         const float lse = lse_s[qi], delta = delta_s[qi];
         const int t = q0 + qi;
+        // dropout factors of the lane's 16 keys: they come in aligned pairs (4 hh + 8 (r >> 2) + {0,1}, {2,3}) when
+        // the row length is even - one hash per pair instead of one per element
+        float keepv[16], dsv[16];
+        if (p.thr) {
+          const uint64_t base = ((uint64_t)bh * p.Tq + t) * S_total + s0;
+          if ((S_total & 1) == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2)
+              tell_keep2(p.seed, salt_eff, base + acc_row(r, lane), p.thr, p.inv_keep, keepv[r], keepv[r + 1]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) keepv[r] = tell_keep(p.seed, salt_eff, base + acc_row(r, lane), p.thr, p.inv_keep);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) keepv[r] = 1.f;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int kk = acc_row(r, lane), s = s0 + kk;
+          const int kk = acc_row(r, lane);
           const bool ok = key_ok[wave][kk] != 0.f && t < p.Tq;
           const float pv = ok ? __expf(st[r] - lse) : 0.f;
-          float keep = 1.f;
-          if (p.thr)
-            keep = tell_keep(p.seed, salt_eff, ((uint64_t)bh * p.Tq + t) * S_total + s, p.thr, p.inv_keep);
+          const float keep = keepv[r];
           const float ds = pv * (dp[r] * keep - delta);
           Elem<T>::st(PdT + kk * SS + qi, pv * keep);         // Pd^T[key][q]
           Elem<T>::st(dST + kk * SS + qi, ds);                // dS^T[key][q]
-          Elem<T>::st(dSs + qi * SS + kk, ds);                // dS[q][key]
+          dsv[r] = ds;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                         // dS[q][key]: 4 consecutive keys per register group
+          T* pd = dSs + qi * SS + 8 * g + 4 * (lane >> 5);
+          if constexpr (sizeof(T) == 2) {
+            uint2 w;
+            w.x = pack_bf16x2(dsv[4 * g], dsv[4 * g + 1]);
+            w.y = pack_bf16x2(dsv[4 * g + 2], dsv[4 * g + 3]);
+            *reinterpret_cast<uint2*>(pd) = w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Elem<T>::st(pd + e, dsv[4 * g + e]);
+          }
         }
       }
       __syncthreads();
       if (tv) {
 #pragma unroll
         for (int f = 0; f < DF; ++f) {
+          // dV^T[d][key] and dK^T[d][key]: with the operands in this order a lane owns ONE key row and, per register
+          // group, 4 consecutive d - its gradients leave as 8-byte (bf16) / 16-byte (fp32) pieces of that row instead
+          // of 32 two-byte stores each
           f32x16 dv, dk;
 #pragma unroll
           for (int r = 0; r < 16; ++r) { dv[r] = 0.f; dk[r] = 0.f; }
-          dv = mma32<T, 32>(dv, PdT, SS, dOt + f * 32 * SS, SS, lane);   // dV[key][d]
-          dk = mma32<T, 32>(dk, dST, SS, Qt + f * 32 * SS, SS, lane);    // dK[key][d]
+          dv = mma32<T, 32>(dv, dOt + f * 32 * SS, SS, PdT, SS, lane);
+          dk = mma32<T, 32>(dk, Qt + f * 32 * SS, SS, dST, SS, lane);
           dq[f] = mma32<T, 32>(dq[f], dSs, SS, Kt + f * 32 * SS, SS, lane);  // dQ[q][d]
-          const int d = f * 32 + (lane & 31);
-          if (d < D) {
+          const int s = s0 + (lane & 31);
+          const bool real = s < p.S, isb = s == p.S && p.has_bias;
+          T* pk = static_cast<T*>(p.dk) + (real ? s * p.k_ss + b * p.k_sb : 0) + (long)h * D;
+          T* pv_ = static_cast<T*>(p.dv) + (real ? s * p.v_ss + b * p.v_sb : 0) + (long)h * D;
+          float* gk = p.dbias_k ? p.dbias_k + (long)b * p.dbias_ld + (long)h * D : nullptr;
+          float* gv = p.dbias_v ? p.dbias_v + (long)b * p.dbias_ld + (long)h * D : nullptr;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int s = s0 + acc_row(r, lane);
-              if (s < p.S) {
-                T* pk = static_cast<T*>(p.dk) + s * p.k_ss + b * p.k_sb + (long)h * D + d;
-                T* pv_ = static_cast<T*>(p.dv) + s * p.v_ss + b * p.v_sb + (long)h * D + d;
-                if (qb == 0) { Elem<T>::st(pk, dk[r]); Elem<T>::st(pv_, dv[r]); }
-                else { Elem<T>::st(pk, Elem<T>::ld(pk) + dk[r]); Elem<T>::st(pv_, Elem<T>::ld(pv_) + dv[r]); }
-              } else if (s == p.S && p.has_bias) {
-                float* gk = p.dbias_k + (long)b * p.dbias_ld + (long)h * D + d;
-                float* gv = p.dbias_v + (long)b * p.dbias_ld + (long)h * D + d;
-                if (qb == 0) { *gk = dk[r]; *gv = dv[r]; }
-                else { *gk += dk[r]; *gv += dv[r]; }
+          for (int g = 0; g < 4; ++g) {
+            const int d0 = f * 32 + 8 * g + 4 * (lane >> 5);
+            if (d0 >= D) continue;
+            float vk[4], vv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { vk[e] = dk[4 * g + e]; vv[e] = dv[4 * g + e]; }
+            if (real) {
+              if (qb != 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { vk[e] += Elem<T>::ld(pk + d0 + e); vv[e] += Elem<T>::ld(pv_ + d0 + e); }
+              }
+              if constexpr (sizeof(T) == 2) {
+                uint2 wk, wv;
+                wk.x = pack_bf16x2(vk[0], vk[1]); wk.y = pack_bf16x2(vk[2], vk[3]);
+                wv.x = pack_bf16x2(vv[0], vv[1]); wv.y = pack_bf16x2(vv[2], vv[3]);
+                *reinterpret_cast<uint2*>(pk + d0) = wk;
+                *reinterpret_cast<uint2*>(pv_ + d0) = wv;
+              } else {
+                *reinterpret_cast<float4*>(pk + d0) = make_float4(vk[0], vk[1], vk[2], vk[3]);
+                *reinterpret_cast<float4*>(pv_ + d0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+              }
+            } else if (isb) {
+              float4* qk = reinterpret_cast<float4*>(gk + d0);
+              float4* qv = reinterpret_cast<float4*>(gv + d0);
+              if (qb == 0) {
+                *qk = make_float4(vk[0], vk[1], vk[2], vk[3]);
+                *qv = make_float4(vv[0], vv[1], vv[2], vv[3]);
+              } else {
+                const float4 ok_ = *qk, ov_ = *qv;
+                *qk = make_float4(ok_.x + vk[0], ok_.y + vk[1], ok_.z + vk[2], ok_.w + vk[3]);
+                *qv = make_float4(ov_.x + vv[0], ov_.y + vv[1], ov_.z + vv[2], ov_.w + vv[3]);
               }
             }
           }
