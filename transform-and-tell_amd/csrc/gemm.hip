@@ -1573,6 +1573,18 @@ extern "C" int tell_gemm_grouped(int n, const tell_gemm_problem* pr, hipStream_t
     const int b = (form_of[i] * 2 + f32) * 2 + (big ? 1 : 0);
     ids[b * n + cnt[b]++] = i;
   }
+  // inside a bucket: longest reductions first - a launch lasts until its last workgroup is done, and a 16384-row
+  // reduction dispatched behind twenty 1024-row problems would start when the others are already finishing
+  static const bool sort_env = !(getenv("TELL_GROUP_SORT") && atoi(getenv("TELL_GROUP_SORT")) == 0);   // A/B aid
+  for (int b = 0; b < BUCKETS && sort_env; ++b) {
+    int* v = ids + b * n;
+    for (int i = 1; i < cnt[b]; ++i) {                 // insertion sort (stable, n <= ~100)
+      const int x = v[i];
+      int j = i - 1;
+      while (j >= 0 && pr[v[j]].K < pr[x].K) { v[j + 1] = v[j]; --j; }
+      v[j + 1] = x;
+    }
+  }
 #define GROUP_RUN(B, KERN, BM, BN) if (cnt[B] && !rc) rc = launch_group(KERN, BM, BN, pr, ids + (B) * n, cnt[B], stream);
   GROUP_RUN(0, (gemm_nt_group_kernel<uint16_t, 64, 64>), 64, 64)
   GROUP_RUN(1, (gemm_nt_group_kernel<uint16_t, 128, 128>), 128, 128)
