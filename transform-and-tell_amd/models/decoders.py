@@ -99,8 +99,8 @@ class DynamicConvDecoderLayer(DecoderLayer):
             handles = ops.fan_out(X, nctx + 1)
         else:
             handles = (X,) * (nctx + 1)
-        grouped = (fused and tr and torch.is_grad_enabled() and kv is None and nctx > 1 and
-                   ops.rt.compute_dtype() == torch.bfloat16 and X.dtype == torch.bfloat16)
+        grouped = (fused and nctx > 1 and ops.rt.compute_dtype() == torch.bfloat16 and X.dtype == torch.bfloat16 and
+                   not (not tr and self.need_attn))        # (attention-weight export takes the per-context path)
         if grouped:
             # the n attentions only meet at the LayerNorms: their query projections and their output projections each
             # travel as ONE grouped launch (forward, input gradients; the weight gradients join the trainer's queue).
@@ -108,7 +108,8 @@ class DynamicConvDecoderLayer(DecoderLayer):
             # time is the kernel's fixed latency, not its work.)
             mods = [self.context_attns[n] for n in self.context_names]
             qs = ops.grouped_linear([handles[i] for i in range(nctx)], [m.q_spec() for m in mods])
-            cores = [m.core(q, contexts[n], contexts[n + '_mask']) for m, q, n in zip(mods, qs, self.context_names)]
+            cores = [m.core(q, contexts[n], contexts[n + '_mask'], None if kv is None else kv[n])
+                     for m, q, n in zip(mods, qs, self.context_names)]
             outs = ops.grouped_linear(cores, [m.out_spec() for m in mods])
         for i, name in enumerate(() if grouped else self.context_names):  # :271-352
             a, w = self.context_attns[name](

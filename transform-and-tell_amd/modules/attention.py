@@ -87,18 +87,31 @@ class MultiHeadAttention(nn.Module):
     def out_spec(self):
         return (self.out_proj.weight, None, self.out_proj.bias, None, 1.0)
 
-    def core(self, q, key, key_padding_mask=None):
-        """softmax(q K^T) V of a training step: q already projected and scaled, K / V projected here."""
-        if key.shape[0] > 0 and key.shape[2] > 0:
-            k, v = self.project_kv_packed(key), None       # K and V as one [S,B,2E] projection
+    def core(self, q, key, key_padding_mask=None, kv=None):
+        """softmax(q K^T) V between the two projections: q already projected and scaled; K / V projected here (one
+        packed projection when gradients are on) or taken from `kv` (generation: projected once per caption)."""
+        T, B, E = q.shape
+        packed = None
+        if kv is None and ops.rt.compute_dtype() == torch.bfloat16 and key.shape[0] > 0 and key.shape[2] > 0 \
+                and torch.is_grad_enabled():
+            packed = self.project_kv_packed(key)          # training: K and V as one [S,B,2E] projection
+            k = v = packed
         else:
-            k, v = self.project_kv(key)
+            k, v = kv if kv is not None else self.project_kv(key)
         mask = None
         if key_padding_mask is not None and k.shape[0] > 0:
             mask = key_padding_mask if key_padding_mask.dtype == torch.uint8 else \
                 key_padding_mask.to(torch.uint8).contiguous()
-        return ops.attention(q, k, v, mask, self.bias_k, self.bias_v, self.num_heads, self.add_zero_attn, self.dropout,
-                             self.training)
+        beams = 1
+        if kv is not None and T == 1 and k.shape[0] > 0 and B != k.shape[1] and B % k.shape[1] == 0:
+            # beam search: the n hypotheses of a sample attend to the SAME static context (see forward())
+            beams = B // k.shape[1]
+            q = q.view(k.shape[1], beams, E).transpose(0, 1)                      # [n, B/n, E] strided view
+        attn = ops.attention(q, k, None if packed is not None else v, mask, self.bias_k, self.bias_v, self.num_heads,
+                             self.add_zero_attn, self.dropout, self.training)
+        if beams > 1:
+            attn = attn.transpose(0, 1).reshape(1, B, E)
+        return attn
 
     def forward(self, query, key, value=None, key_padding_mask=None, incremental_state=None,
                 need_weights=True, static_kv=True, attn_mask=None, key_t=None, kv=None):
