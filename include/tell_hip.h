@@ -91,6 +91,12 @@ int tell_gemm_bf16(const void* A, long lda, int trans_a, const void* B, long ldb
    trans_a / trans_b as in tell_gemm_bf16: 0/0 the NT form (A [M,K], B [N,K]); 0/1 B stored [K,N] (dX = dY W);
    1/1 A stored [K,M] as well (dW = dY^T X), which may carry asum_i[m] += asum_scale_i * sum_k A_i[k][m] (the bias
    gradient).  bias: fp32 per column (bias_mode 1), NT form only; act: 0 none, 1 relu.  `problems` is a HOST array. */
+/* second half of a split-K product whose K slices ran as fp32 problems of tell_gemm_grouped (skinny decode-step GEMMs):
+   out[M,N] = act((sum_s partial[s][M][N] + bias) * alpha); partial slice s at partial + s * split_stride floats;
+   bias fp32 [N] or NULL; act 0 none / 1 relu / 2 gelu(erf); N and ldc multiples of 4. */
+int tell_splitk_reduce(const float* partial, int splits, long split_stride, int M, int N, const float* bias, int act,
+                       float alpha, void* out, long ldc, int out_dtype, tell_stream_t stream);
+
 typedef struct tell_gemm_problem {
   const void* A; long lda;
   const void* B; long ldb;

@@ -56,6 +56,9 @@ def grad_buffer(p):
 # --------------------------------------------------------------------------- #
 # raw kernels
 # --------------------------------------------------------------------------- #
+_SPLITK = os.environ.get('TELL_GEMM_SKINNY_SPLITK', '1') != '0'          # A/B aid
+
+
 def gemm(a, b, out=None, out_dtype=None, bias=None, bias_mode=0, act=0, aux=None, alpha=1.0,
          accumulate=False, m_dev=None):
     """out[M,N] = act((a[M,K] @ b[N,K]^T + bias) * alpha) (+ out).  K is zero padded to a
@@ -77,6 +80,20 @@ def gemm(a, b, out=None, out_dtype=None, bias=None, bias_mode=0, act=0, aux=None
     if out is None:
         out = torch.empty(M, N, dtype=out_dtype or a.dtype, device=a.device)
     assert out.stride(1) == 1
+    K = a.shape[1]
+    if (_SPLITK and M <= 128 and K >= 2048 and K % 512 == 0 and N % 64 == 0 and a.dtype == torch.bfloat16 and
+            bias_mode in (0, 1) and act in (0, 1, 2) and aux is None and not accumulate and m_dev is None and
+            out.stride(0) % 4 == 0):
+        # skinny and long (the decode step's context_fc / fc2: <= 128 rows x K = 4096): K slices as one grouped launch
+        # of fp32 partial tiles + one fold-and-epilogue launch, instead of 16-32 workgroups walking 64 K tiles each
+        splits = K // 512
+        partial = torch.empty(splits, M, N, dtype=torch.float32, device=a.device)
+        ks = K // splits
+        gemm_grouped([dict(a=a[:, i * ks:(i + 1) * ks], b=b[:, i * ks:(i + 1) * ks], out=partial[i], form='nt')
+                      for i in range(splits)])
+        call('tell_splitk_reduce', partial, splits, partial.stride(0), M, N, bias if bias_mode == 1 else None, act,
+             float(alpha), out, out.stride(0), hip.dt(out))
+        return out
     args = (a, a.stride(0), b, b.stride(0), out, out.stride(0), M, N, a.shape[1], hip.dt(a), hip.dt(out), bias, bias_mode,
             act, aux, float(alpha), int(accumulate), m_dev)
     rec = slot = None
