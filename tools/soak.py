@@ -9,9 +9,11 @@ from tell_amd.training import Trainer
 tell_amd.set_compute_dtype(torch.bfloat16)
 tell_amd.manual_seed(1234)
 torch.manual_seed(0)
-model = build_model('flattened', weigh_bert=False)
+kind = sys.argv[1] if len(sys.argv) > 1 else 'flattened'
+fo = kind == 'faces_objects'
+model = build_model(kind, weigh_bert=fo)
 tr = Trainer(model, device='cuda')
-bs = [synthetic_batch(16, 512, 33, False, seed=1234 + 97 * i, device='cuda') for i in range(2)]
+bs = [synthetic_batch(32 if fo else 16, 512, 33, fo, seed=1234 + 97 * i, device='cuda') for i in range(2)]
 fresh = lambda b: {k: (dict(v) if isinstance(v, dict) else v) for k, v in b.items()}
 for i in range(3001):
     l = tr.train_one_batch(fresh(bs[i % 2]), next_batch=fresh(bs[(i + 1) % 2]))
