@@ -284,11 +284,14 @@ int tell_adaptive_logprob_argmax(const float* head, long ld_head, int c0, int n_
 /* ---- BertAdam (config.yaml:126-149), flat fp32 buffers, tensors CHUNK-aligned */
 int tell_opt_chunk(void);
 /* shadow_bf16 (may be NULL): bf16 copy of the updated parameters, same flat layout - the working weights of the
- * next forward; zero_grad: clear the gradient buffer in the same pass (callback_apex_trainer.py:214). */
+ * next forward; zero_grad: clear the gradient buffer in the same pass (callback_apex_trainer.py:214);
+ * grad_wire_bf16 (may be NULL): the step's gradient in bf16, same flat layout - what a data-parallel exchange with
+ * bf16 on the wire leaves behind; it is then READ instead of `grad` (which is still the buffer that gets cleared). */
 int tell_bertadam_step(float* param, float* grad, float* m, float* v, const int* chunk_tensor,
                        const long* chunk_begin, long n_chunks, int n_tensors, float* partial, float* norms,
                        const float* lr_dev, float b1, float b2, float eps, float wd, float max_norm,
-                       float grad_scale, void* shadow_bf16, int zero_grad, int* skip, tell_stream_t stream);
+                       float grad_scale, void* shadow_bf16, int zero_grad, int* skip, const void* grad_wire_bf16,
+                       tell_stream_t stream);
 /* skip (int[2], may be NULL): skip[0] != 0 -> the step leaves parameters / moments untouched (gradient still cleared)
  * and skip[1] counts such steps; tell_loss_flag sets skip[0] = !isfinite(loss) (the NaN-loss skip of
  * callback_apex_trainer.py:225-227 without a host sync), the norm pass ORs in 2 for a non-finite gradient (what apex

@@ -652,7 +652,7 @@ def test_grouped_linear_matches_single_linears():
     specs = [(packed_w, (0, E), packed_b, (0, E), 0.125), (ws[0], None, bs[0], None, 1.0), (ws[1], None, None, None, 1.0),
              (ws[2], None, bs[2], None, 0.5), (ws[3], None, bs[3], None, 1.0)]
     xs0 = [torch.randn(32, 32, E, device=DEV).bfloat16(), torch.randn(32, 32, E, device=DEV).bfloat16(),
-           torch.randn(1024, E, device=DEV).bfloat16(), torch.randn(96, 2048, device=DEV).bfloat16(),
+           torch.randn(1024, E, device=DEV).bfloat16(), torch.randn(160, 2048, device=DEV).bfloat16(),   # (> 128 rows: not the split-K path)
            torch.randn(7, 3, 576, device=DEV).bfloat16()]
     gys = None
 

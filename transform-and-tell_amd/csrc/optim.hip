@@ -12,11 +12,21 @@
 #define OPT_CHUNK 1024
 
 // partial[c] = sum of squares of (grad * grad_scale) over chunk c
-__global__ __launch_bounds__(256) void sqsum_chunks_kernel(const float* __restrict__ grad, long n_chunks,
-                                                           float grad_scale, float* __restrict__ partial) {
+// (wire != NULL: the gradient of this step is the bf16 buffer the data-parallel exchange left - read it as it is
+//  instead of widening 2 B/param back into the fp32 buffer first)
+__device__ __forceinline__ float4 load_grad4(const float* __restrict__ grad, const uint16_t* __restrict__ wire, long o) {
+  if (wire) {
+    const uint2 w = reinterpret_cast<const uint2*>(wire)[o];
+    return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                       __uint_as_float(w.y & 0xffff0000u));
+  }
+  return reinterpret_cast<const float4*>(grad)[o];
+}
+__global__ __launch_bounds__(256) void sqsum_chunks_kernel(const float* __restrict__ grad, const uint16_t* __restrict__ wire,
+                                                           long n_chunks, float grad_scale, float* __restrict__ partial) {
   __shared__ float red[4];
   for (long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-    const float4 g = reinterpret_cast<const float4*>(grad + c * OPT_CHUNK)[threadIdx.x];
+    const float4 g = load_grad4(grad, wire, c * OPT_CHUNK / 4 + threadIdx.x);
     float s = (g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w) * grad_scale * grad_scale;
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -68,7 +78,8 @@ __global__ __launch_bounds__(256) void bertadam_update_kernel(float* __restrict_
                                                               const float* __restrict__ lr_dev, float b1,
                                                               float b2, float eps, float wd, float max_norm,
                                                               float grad_scale, uint16_t* __restrict__ shadow,
-                                                              int zero_grad, int* __restrict__ skip) {
+                                                              int zero_grad, int* __restrict__ skip,
+                                                              const uint16_t* __restrict__ wire) {
   const float lr = *lr_dev;
   if (skip && skip[0] != 0) {      // non-finite loss or gradient: leave p, m, v and the shadow alone, only clear the gradient
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skip + 1, 1);          // running count of skipped steps
@@ -84,7 +95,7 @@ __global__ __launch_bounds__(256) void bertadam_update_kernel(float* __restrict_
       if (cc < 1.f) coef *= cc;
     }
     const long o = c * OPT_CHUNK / 4 + threadIdx.x;
-    float4 g = reinterpret_cast<const float4*>(grad)[o];
+    float4 g = load_grad4(grad, wire, o);
     float4 p = reinterpret_cast<float4*>(param)[o];
     float4 mm = reinterpret_cast<float4*>(m)[o];
     float4 vv = reinterpret_cast<float4*>(v)[o];
@@ -116,15 +127,17 @@ extern "C" int tell_bertadam_step(float* param, float* grad, float* m, float* v,
                                   int n_tensors, float* partial, float* norms, const float* lr_dev,
                                   float b1, float b2, float eps, float wd, float max_norm,
                                   float grad_scale, void* shadow_bf16, int zero_grad, int* skip,
-                                  hipStream_t stream) {
+                                  const void* grad_wire_bf16, hipStream_t stream) {
   if (n_chunks <= 0) return TELL_OK;
+  TELL_REQUIRE(((uintptr_t)grad_wire_bf16 & 7) == 0, "bertadam: the bf16 gradient must be 8-byte aligned");
+  const uint16_t* wire = static_cast<const uint16_t*>(grad_wire_bf16);
   TELL_REQUIRE(((uintptr_t)param & 15) == 0 && ((uintptr_t)grad & 15) == 0, "bertadam: buffers must be 16-byte aligned");
   int g = n_chunks < 4096 ? (int)n_chunks : 4096;
   if (max_norm > 0.f) {
-    hipLaunchKernelGGL(sqsum_chunks_kernel, dim3(g), dim3(256), 0, stream, grad, n_chunks, grad_scale, partial);
+    hipLaunchKernelGGL(sqsum_chunks_kernel, dim3(g), dim3(256), 0, stream, grad, wire, n_chunks, grad_scale, partial);
     hipLaunchKernelGGL(tensor_norms_kernel, dim3(n_tensors), dim3(256), 0, stream, partial, chunk_begin, n_tensors, norms, skip);
   }
-  hipLaunchKernelGGL(bertadam_update_kernel, dim3(g), dim3(256), 0, stream, param, grad, m, v, chunk_tensor, norms, n_chunks, lr_dev, b1, b2, eps, wd, max_norm, grad_scale, (uint16_t*)shadow_bf16, zero_grad, skip);
+  hipLaunchKernelGGL(bertadam_update_kernel, dim3(g), dim3(256), 0, stream, param, grad, m, v, chunk_tensor, norms, n_chunks, lr_dev, b1, b2, eps, wd, max_norm, grad_scale, (uint16_t*)shadow_bf16, zero_grad, skip, wire);
   return tell_check_launch("bertadam_step");
 }
 

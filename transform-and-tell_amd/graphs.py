@@ -13,6 +13,27 @@ import torch
 
 from . import hip
 
+
+class no_gc:
+    """`with graphs.no_gc():` around a stream capture.  Python's cyclic collector may run at any allocation; if it
+    frees an object that owns a HIP resource (an old CUDAGraph, an event, a stream held by a dropped trainer) while a
+    capture is open, the destructor's hipGraphDestroy / hipEventDestroy is illegal there and the process ABORTS
+    ("Fatal Python error: Aborted ... Garbage-collecting" - seen once in ~30 test-suite runs).  Collect before, keep the
+    collector off inside, restore after."""
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was:
+            gc.enable()
+        return False
+
 ENABLED = os.environ.get('TELL_GRAPHS', '1') != '0'
 
 
@@ -78,7 +99,7 @@ class GraphedCall:
                         hip.call('tell_set_rng_step_ptr', counter)
                     # thread_local: calls made by OTHER threads while we capture (the RCCL watchdog of a data-parallel
                     # run polls events) must not invalidate the capture; everything captured is issued from this thread
-                    with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                    with no_gc(), torch.cuda.graph(g, capture_error_mode='thread_local'):
                         with hip.bound_stream():        # launches must go to the CAPTURING stream
                             static_out = self.fn(static_in)
                 finally:

@@ -416,7 +416,7 @@ class CaptionModel(Model):
                     try:
                         ops.call('tell_set_rng_step_ptr', h['counter'])
                         ops.call('tell_set_pos_step_ptr', h['counter'])
-                        with torch.cuda.graph(g):
+                        with graphs.no_gc(), torch.cuda.graph(g):
                             with ops.hip.bound_stream():
                                 h['out'] = run()
                     finally:

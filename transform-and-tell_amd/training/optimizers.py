@@ -99,11 +99,11 @@ class BertAdam:
             return self.lr * warmup_linear(self.step_count / self.t_total, self.warmup)
         return self.lr
 
-    def step(self, grad_scale=1.0, zero_grad=False, skip=None):
+    def step(self, grad_scale=1.0, zero_grad=False, skip=None, grad_wire=None):
         """zero_grad: also clear the gradient buffer (fused into the update pass).  skip: device int32[2] flag -
         a non-zero skip[0] (non-finite loss / gradient) turns the step into gradient zeroing only."""
         self.prepare()
-        self.launch(grad_scale, zero_grad, skip)
+        self.launch(grad_scale, zero_grad, skip, grad_wire)
         self.advance()
 
     # the three parts of step(), separable so that the kernel launches can live in a captured graph
@@ -111,11 +111,13 @@ class BertAdam:
         """Host part before the kernels: this step's learning rate into the device scalar the kernel reads."""
         self.lr_dev.fill_(self.current_lr())
 
-    def launch(self, grad_scale=1.0, zero_grad=False, skip=None):
+    def launch(self, grad_scale=1.0, zero_grad=False, skip=None, grad_wire=None):
+        """grad_wire: optional bf16 copy of the whole flat gradient (the data-parallel exchange's wire buffer after the
+        all-reduce): the kernels read it in place of flat.grad - no pass that widens it back first."""
         f = self.flat
         hip.call('tell_bertadam_step', f.flat, f.grad, f.m, f.v, f.chunk_tensor, f.chunk_begin, f.n_chunks,
                  len(f.params), f.partial, f.norms, self.lr_dev, self.b1, self.b2, self.e, self.weight_decay,
-                 self.max_grad_norm, float(grad_scale), f.shadow, int(zero_grad), skip)
+                 self.max_grad_norm, float(grad_scale), f.shadow, int(zero_grad), skip, grad_wire)
 
     def advance(self):
         """Host part after the kernels.  (A skipped step still advances the schedule by one: the host does not read

@@ -126,7 +126,7 @@ class StepGraph:
         try:
             ops.drop_trainable_cache()          # working weights of trainable parameters are rebuilt inside the graph
             hip.call('tell_set_rng_step_ptr', counter)
-            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+            with graphs.no_gc(), torch.cuda.graph(g, capture_error_mode='thread_local'):
                 with hip.bound_stream():
                     encs = EncodedBatch()
                     encs.stack, encs.x_image = st_big

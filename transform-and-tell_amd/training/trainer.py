@@ -246,7 +246,10 @@ class Trainer:
                 if a > lo:
                     self._start_reduce(lo, a, scale)
                 lo = max(lo, b)
-            self._finish_reduces()
+            wire = self._finish_reduces()
+            if wire is not None:                       # bf16 on the wire: BertAdam reads the reduced buffer as it is
+                self.optimizer.step(grad_scale=1.0 / self.world, zero_grad=True, skip=self.skip, grad_wire=wire)
+                return
         self.optimizer.step(grad_scale=1.0 / self.world, zero_grad=True, skip=self.skip)  # :238 (+ :214 of the next batch)
 
     def _cast(self, src, dst):
@@ -272,16 +275,25 @@ class Trainer:
         self._pending.append((lo, hi, handles))
 
     def _finish_reduces(self):
-        """The current stream waits for every exchange in flight; bf16 results are widened back into flat.grad."""
+        """The current stream waits for every exchange in flight.  -> the bf16 wire buffer when it now holds the WHOLE
+        reduced gradient and the optimizer kernel can read it directly (CUDA, bf16 on the wire, one exchange covering
+        all of flat.grad), else None after widening the bf16 results back into flat.grad."""
         pending, self._pending = self._pending, []
         for lo, hi, handles in pending:
             for h in handles:
                 h.wait()
+        direct = (self.allreduce_dtype == torch.bfloat16 and self._test_reduce_scale is None and
+                  self.flat.grad.is_cuda and len(pending) == 1 and pending[0][0] == 0 and
+                  pending[0][1] == self.flat.total and hasattr(self.optimizer, 'launch'))
+        if direct:
+            return self._wire
+        for lo, hi, handles in pending:
             grad = self.flat.grad[lo:hi]
             if self.allreduce_dtype == torch.bfloat16:
                 self._cast(self._wire[lo:hi], grad)
             if self._test_reduce_scale is not None:
                 grad.mul_(self._test_reduce_scale)
+        return None
 
 
 @TrainerBase.register('callback_apex')
