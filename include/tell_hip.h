@@ -281,6 +281,14 @@ int tell_adaptive_logprob_argmax(const float* head, long ld_head, int c0, int n_
                                  long ld2, int n2, int rows, float* log_probs, long ld_lp, int* token,
                                  float* token_lp, tell_stream_t stream);
 
+/* per-token bookkeeping of the greedy decode loop (transformer_faces_objects.py:443-494) for all B rows in one launch:
+   unfinished rows record tok / lp * inv_temp at step i, rows emitting eos are marked finished (done_step = i + 1),
+   cur = tok for the next step.  tok int32 [B], lp fp32 [B], finished uint8 [B], ids int64 [B, ld_ids], lps fp32
+   [B, ld_lps], done_step int64 [B], cur int64 [B]. */
+int tell_greedy_update(const int* tok, const float* lp, uint8_t* finished, long* ids, long ld_ids, float* lps,
+                       long ld_lps, long* done_step, long* cur, int B, int i, int eos, float inv_temp,
+                       tell_stream_t stream);
+
 /* ---- BertAdam (config.yaml:126-149), flat fp32 buffers, tensors CHUNK-aligned */
 int tell_opt_chunk(void);
 /* shadow_bf16 (may be NULL): bf16 copy of the updated parameters, same flat layout - the working weights of the

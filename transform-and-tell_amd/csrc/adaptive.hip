@@ -445,3 +445,35 @@ extern "C" int tell_adaptive_logprob_argmax(const float* head, long ld_head, int
   hipLaunchKernelGGL(logprob_argmax_kernel, dim3(rows), dim3(1024), 0, stream, p);
   return tell_check_launch("logprob_argmax");
 }
+
+// ------------------------------------------------------------------ greedy generation: one step's bookkeeping
+// What the loop of transformer_faces_objects.py:443-494 does per token after the arg-max, for all rows at once: a row
+// that has not finished records token and log-prob (divided by the sampling temperature), a row that emits EOS now is
+// marked finished and remembers the step; every row's token becomes the next step's input (finished rows keep decoding
+// into the void - the batch keeps its shape - and their outputs stay padding).  Sixteen elementwise ATen launches per
+// generated token before.
+__global__ void greedy_update_kernel(const int* __restrict__ tok, const float* __restrict__ lp,
+                                     uint8_t* __restrict__ finished, long* __restrict__ ids, long ld_ids,
+                                     float* __restrict__ lps, long ld_lps, long* __restrict__ done_step,
+                                     long* __restrict__ cur, int B, int i, int eos, float inv_temp) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const bool fin = finished[b] != 0;
+  const int t = tok[b];
+  if (!fin) {
+    ids[(long)b * ld_ids + i + 1] = t;
+    lps[(long)b * ld_lps + i] = lp[b] * inv_temp;
+    if (t == eos) { done_step[b] = i + 1; finished[b] = 1; }
+  }
+  cur[b] = t;
+}
+// tok int32 [B], lp fp32 [B], finished uint8 [B], ids int64 [B, ld_ids], lps fp32 [B, ld_lps], done_step int64 [B],
+// cur int64 [B] (the next step's input tokens); i = index of the step that produced tok
+extern "C" int tell_greedy_update(const int* tok, const float* lp, uint8_t* finished, long* ids, long ld_ids, float* lps,
+                                  long ld_lps, long* done_step, long* cur, int B, int i, int eos, float inv_temp,
+                                  hipStream_t stream) {
+  if (B <= 0) return TELL_OK;
+  hipLaunchKernelGGL(greedy_update_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, tok, lp, finished, ids, ld_ids, lps,
+                     ld_lps, done_step, cur, B, i, eos, inv_temp);
+  return tell_check_launch("greedy_update");
+}

@@ -327,7 +327,17 @@ class CaptionModel(Model):
         done_step = torch.full((B,), gen_len, dtype=torch.long, device=dev)   # steps this row took part in
         done_step[finished] = 0
         steps = gen_len
-        for i in range(gen_len):
+        fused = caption_ids.is_cuda and hasattr(step, 'cur')      # one bookkeeping launch per token (tell_greedy_update)
+        if fused:
+            fin8 = finished.to(torch.uint8)
+            step.cur.copy_(cur)
+        for i in range(gen_len if fused else 0):
+            tok, lp = step(i, None)
+            ops.call('tell_greedy_update', tok.reshape(B), lp.reshape(B), fin8, ids, ids.stride(0), lps, lps.stride(0),
+                     done_step, step.cur, B, i, int(eos), 1.0 / float(self.sampling_temp))
+            if (i + 1) % check_every == 0 and bool(fin8.all()):
+                break
+        for i in range(0 if fused else gen_len):
             tok, lp = step(i, cur)
             tok = tok.long().view(B)
             lp = lp.view(B) / self.sampling_temp
@@ -407,7 +417,8 @@ class CaptionModel(Model):
             return head(out[0][:, -1:])
 
         def step(i, cur):
-            h['cur'].copy_(cur)
+            if cur is not None:                                   # (None: the caller already wrote step.cur)
+                h['cur'].copy_(cur)
             if h['graph'] is None and i != 1:
                 return run()                                      # warm step(s) before the capture, or fallback
             if h['graph'] is None:                                # i == 1: the host position state is 1 now
@@ -437,6 +448,7 @@ class CaptionModel(Model):
                 if torch.is_tensor(s):
                     s.copy_(s.index_select(1, rows))
         step.reorder = reorder
+        step.cur = h['cur']
         return step
 
     @torch.no_grad()
