@@ -602,7 +602,8 @@ def test_grouped_wgrad_gemms_match_single_launches():
     tell_amd.set_compute_dtype(torch.bfloat16)
     torch.manual_seed(5)
     shapes = [(1024, 1024, 1024), (1024, 2048, 1024), (128, 2048, 512), (1568, 2048, 2048), (96, 200, 72),
-              (1024, 496, 1024), (64, 64, 64), (2048, 1024, 4096)] * 4                    # (K rows, M, N) x 32
+              (1024, 496, 1024), (64, 64, 64), (2048, 1024, 4096), (4160, 520, 264)] * 4  # (K rows, M, N) x 36
+    # (the last one is a long reduction: fp32 outputs of K >= 4096 take the 256x128-tile kernel, ragged edges included)
     probs = []
     for i, (K, M, N) in enumerate(shapes):
         a = torch.randn(K, M, device=DEV).bfloat16()

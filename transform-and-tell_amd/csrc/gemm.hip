@@ -1295,6 +1295,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tx_group_kernel(GemmGroup g) {
   const GemmArgs p = group_args(g.pr[i]);
   gemm_tx_body<OutT, BM, BN, 2, 2, TA, TB, PF>(p, blockIdx.x - g.start[i], g.start[i + 1] - g.start[i], 0, 1);
 }
+// 256x128 tiles, 8 waves (4 x 2): for the long reductions (the article K|V weight gradients: 16384 rows into
+// [2048, 1024]) the 128x128 body is bound by operand re-reads through L2; the taller tile halves the re-reads of B
+template <typename OutT, bool TA, bool TB>
+__global__ __launch_bounds__(512, 1) void gemm_tx_group_wide_kernel(GemmGroup g) {
+  const int i = group_find(g, blockIdx.x);
+  const GemmArgs p = group_args(g.pr[i]);
+  gemm_tx_body<OutT, 256, 128, 4, 2, TA, TB, 2>(p, blockIdx.x - g.start[i], g.start[i + 1] - g.start[i], 0, 1);
+}
 template <typename OutT, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_nt_group_kernel(GemmGroup g) {
   const int i = group_find(g, blockIdx.x);
@@ -1512,7 +1520,8 @@ extern "C" int tell_gemm_bf16(const void* A, long lda, int trans_a, const void* 
 // type and tile shape; each bucket runs as one launch per GROUP_MAX problems.  A problem the grouped kernels cannot take
 // (NT form with K % 64 != 0 or unaligned operands) is launched on its own through the ordinary dispatcher.
 template <typename Kern>
-static int launch_group(Kern kern, int bm, int bn, const tell_gemm_problem* pr, const int* ids, int n, hipStream_t stream) {
+static int launch_group(Kern kern, int bm, int bn, const tell_gemm_problem* pr, const int* ids, int n, hipStream_t stream,
+                        int threads = 256) {
   for (int base = 0; base < n; base += GROUP_MAX) {
     GemmGroup g;
     g.n = n - base < GROUP_MAX ? n - base : GROUP_MAX;
@@ -1526,7 +1535,7 @@ static int launch_group(Kern kern, int bm, int bn, const tell_gemm_problem* pr, 
       const long tiles = (long)((q.M + bm - 1) / bm) * ((q.N + bn - 1) / bn);
       g.start[i + 1] = g.start[i] + (int)((tiles + 7) / 8 * 8);
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)g.start[g.n]), dim3(256), 0, stream, g);
+    hipLaunchKernelGGL(kern, dim3((unsigned)g.start[g.n]), dim3(threads), 0, stream, g);
   }
   return tell_check_launch("gemm_grouped");
 }
@@ -1537,7 +1546,7 @@ extern "C" int tell_gemm_bf16(const void* A, long lda, int trans_a, const void* 
 extern "C" int tell_gemm_grouped(int n, const tell_gemm_problem* pr, hipStream_t stream) {
   if (n <= 0) return TELL_OK;
   static const int tile_env = getenv("TELL_GROUP_TILE") ? atoi(getenv("TELL_GROUP_TILE")) : 0;   // A/B aid: 64 / 128
-  enum { FORMS = 3, BUCKETS = FORMS * 2 * 2 };       // form x (bf16, f32) x (64, 128)
+  enum { FORMS = 3, BUCKETS = FORMS * 2 * 2 + 1, WIDE = FORMS * 2 * 2 };   // form x (bf16, f32) x (64, 128) + long fp32 TN
   int* ids = (int*)alloca(sizeof(int) * BUCKETS * n);
   int* form_of = (int*)alloca(sizeof(int) * n);
   int cnt[BUCKETS] = {0};
@@ -1570,7 +1579,9 @@ extern "C" int tell_gemm_grouped(int n, const tell_gemm_problem* pr, hipStream_t
     bool big = q.M >= 128 && q.N >= 128 && big_tiles[form_of[i]][f32] >= 512;
     if (tile_env == 64) big = false;
     if (tile_env == 128) big = q.M >= 128 && q.N >= 128;
-    const int b = (form_of[i] * 2 + f32) * 2 + (big ? 1 : 0);
+    int b = (form_of[i] * 2 + f32) * 2 + (big ? 1 : 0);
+    static const bool wide_env = !(getenv("TELL_GROUP_WIDE") && atoi(getenv("TELL_GROUP_WIDE")) == 0);   // A/B aid
+    if (wide_env && form_of[i] == 2 && f32 && q.K >= 4096 && q.M >= 256 && q.N >= 128) b = WIDE;
     ids[b * n + cnt[b]++] = i;
   }
   // inside a bucket: longest reductions first - a launch lasts until its last workgroup is done, and a 16384-row
@@ -1598,6 +1609,7 @@ extern "C" int tell_gemm_grouped(int n, const tell_gemm_problem* pr, hipStream_t
   GROUP_RUN(9, (gemm_tx_group_kernel<uint16_t, 128, 128, true, true, 2>), 128, 128)
   GROUP_RUN(10, (gemm_tx_group_kernel<float, 64, 64, true, true, 4>), 64, 64)
   GROUP_RUN(11, (gemm_tx_group_kernel<float, 128, 128, true, true, 2>), 128, 128)
+  if (cnt[WIDE] && !rc) rc = launch_group((gemm_tx_group_wide_kernel<float, true, true>), 256, 128, pr, ids + WIDE * n, cnt[WIDE], stream, 512);
 #undef GROUP_RUN
   return rc;
 }
