@@ -1,3 +1,7 @@
+"""Does de-synchronising the epilogues of the CUs help?  PROBE BUILD REQUIRED - not runnable against the committed
+kernel: in gemm_nt_pp_kernel let odd workgroups spin (s_sleep) for -p.alpha x ~3.5 us before their main loop when
+p.alpha < 0, rebuild, run, revert.  Recorded result: no stagger is as fast as any (qkv 131 us flat) - the epilogue is
+bound by per-CU store issue, not by an HBM write burst."""
 import sys, torch
 sys.path.insert(0, '/root/repo')
 import tell_amd
