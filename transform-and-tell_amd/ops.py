@@ -709,7 +709,10 @@ class KVLinearFn(Function):
             colsum_into(dy2, gb)
         dx = None
         if need_dx:
-            dx = gemm_nn(dy2, w)
+            # the article's dX (16384 x 1024 from K = 2048): as an NT product against the transposed stacked weight it
+            # runs on the 256x256 ping-pong kernel (transpose 14 us + 60 us against 97 us for the K-major 128x128 form,
+            # which is bound by operand re-reads through L2); gemm_nn only takes it for that size class
+            dx = gemm_nn(dy2, w, b_t=lambda: _cached(wk, ('kv_t', rk, id(wv), wv._version), lambda: transpose(w)[0]))
             dx = dx.reshape(xshape) if dx.is_contiguous() else dx.contiguous().view(xshape)
         return dx, None, None, None, None, None, None, None
 
