@@ -53,7 +53,8 @@ uint32_t tell_drop_threshold_host(float p);
 /* measurement aid (bench.py roofline): rate of the device wall clock in kHz (100 000 on MI355X) */
 int tell_wall_clock_khz(void);
 /* arm the NEXT tell_gemm_nt launch of this thread: its direct-to-LDS / ping-pong kernel records its execution span
- * into ts[0] (first workgroup in) / ts[1] (last workgroup out), device wall-clock ticks (uint64[2]) */
+ * into ts[0] (first workgroup in) / ts[1] (last workgroup out), device wall-clock ticks; ts is uint64[3], zero before
+ * the first use (ts[2] counts workgroup arrivals: every launch of the same grid re-opens the span by itself) */
 int tell_gemm_ts_next(void* ts, tell_stream_t stream);
 int tell_wall_clock_khz(void);
 

@@ -51,9 +51,9 @@ struct GemmArgs {
 };
 
 // In-kernel execution span (bench.py roofline for launches replayed from hipGraphs, where neither HIP events nor an
-// external profiler can bracket a kernel): every workgroup folds the device wall clock into ts[0] (min at entry) and
-// ts[1] (max at exit) - the interval rocprofv3 reports as the kernel's duration.  tell_gemm_ts_next arms it for the next
-// tell_gemm_nt launch only (the launcher first resets the two words).
+// external profiler can bracket a kernel): the first workgroup to arrive stores the device wall clock into ts[0], every
+// workgroup folds its exit time into ts[1] (max) - the interval rocprofv3 reports as the kernel's duration.
+// tell_gemm_ts_next arms it for the next tell_gemm_nt launch only.
 __device__ __forceinline__ void gemm_ts_enter(const GemmArgs& p);
 __device__ __forceinline__ void gemm_ts_exit(const GemmArgs& p);
 
@@ -167,8 +167,15 @@ template <> struct Vec4<uint16_t> {
   }
 };
 
+// ts[0] = entry time of the launch's first workgroup, ts[1] = latest exit, ts[2] = arrivals so far.  The workgroup
+// whose arrival ticket is a multiple of the grid size opens a new launch (stores its entry time, clears the exit word):
+// no reset launch in front of every sampled GEMM (22 five-microsecond launches per step on the critical stream before).
 __device__ __forceinline__ void gemm_ts_enter(const GemmArgs& p) {
-  if (p.ts && threadIdx.x == 0) atomicMin(p.ts, (unsigned long long)wall_clock64());
+  if (p.ts && threadIdx.x == 0) {
+    const unsigned long long now = wall_clock64();
+    const unsigned long long n = atomicAdd(p.ts + 2, 1ull);
+    if (n % gridDim.x == 0) { p.ts[1] = 0ull; p.ts[0] = now; }
+  }
 }
 __device__ __forceinline__ void gemm_ts_exit(const GemmArgs& p) {
   if (p.ts && threadIdx.x == 0) {
@@ -176,7 +183,6 @@ __device__ __forceinline__ void gemm_ts_exit(const GemmArgs& p) {
     atomicMax(p.ts + 1, (unsigned long long)wall_clock64());
   }
 }
-__global__ void gemm_ts_reset_kernel(unsigned long long* ts) { ts[0] = ~0ull; ts[1] = 0ull; }
 
 template <typename OutT, int MI, int NI, int ACT>
 __device__ __forceinline__ void gemm_epilogue_act(f32x16 (&acc)[MI][NI], const GemmArgs& p, int mw, int nw, int lane,
@@ -1461,7 +1467,6 @@ extern "C" int tell_gemm_nt(const void* A, long lda, const void* B, long ldb, vo
   if (g_gemm_ts_next && !g_gemm_plan) {
     a.ts = g_gemm_ts_next;
     g_gemm_ts_next = nullptr;
-    hipLaunchKernelGGL(gemm_ts_reset_kernel, dim3(1), dim3(1), 0, stream, a.ts);
   }
   if (in_dtype == TELL_BF16)
     return out_dtype == TELL_BF16 ? launch_gemm<uint16_t, uint16_t>(a, stream)

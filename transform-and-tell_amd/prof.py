@@ -38,7 +38,7 @@ def graph_begin(name, work):
     if n % GRAPH_SAMPLE:
         return None
     if _g['buf'] is None:
-        _g['buf'] = torch.zeros(2 * 4096, dtype=torch.int64, device='cuda')
+        _g['buf'] = torch.zeros(4 * 4096, dtype=torch.int64, device='cuda')      # 4 words per slot: in, out, arrivals, -
         _g['khz'] = hip.lib().tell_wall_clock_khz()
     i = _g['n']
     if i >= 4096:
@@ -48,7 +48,7 @@ def graph_begin(name, work):
     # the kernel itself records [first workgroup in, last workgroup out] (csrc/gemm.hip gemm_ts_enter / gemm_ts_exit):
     # the interval an external profiler reports as the kernel's duration, without the dispatch waits a bracket of
     # neighbouring launches would add when other streams keep the CUs busy
-    hip.call('tell_gemm_ts_next', _g['buf'][2 * i:])
+    hip.call('tell_gemm_ts_next', _g['buf'][4 * i:])
     return i
 
 
@@ -62,9 +62,9 @@ def graph_summary():
     out = {}
     if _g['buf'] is None or not _g['khz']:
         return out
-    v = _g['buf'][:2 * _g['n']].tolist()
+    v = _g['buf'][:4 * _g['n']].tolist()
     for i, (name, work) in enumerate(_g['slots']):
-        t0, t1 = v[2 * i], v[2 * i + 1]
+        t0, t1 = v[4 * i], v[4 * i + 1]
         if t0 == 0 or t1 <= t0:
             continue                                   # a graph that was captured but not replayed since
         if t0 < 0 or t1 < 0:
