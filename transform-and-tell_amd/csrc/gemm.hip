@@ -310,6 +310,57 @@ __device__ __forceinline__ void glds_store_tile(f32x16 (&acc)[MI][NI], const Gem
     default: glds_store_tile_act<BM, BN, WM, WN, MI, NI, CS, NT, 0, LAY>(acc, p, m0, n0, wm, wn, lane, tid, cs); break;
   }
 }
+// fp32 outputs (adaptive-softmax logits: [rows, 30265] from K = 64 ... 1024): the tile leaves through LDS as whole
+// 16-byte row pieces as well.  Straight from the accumulators a wave-store touches 32 rows x 32 bytes - the 124 MB of
+// tail logits took 141 us (0.9 TB/s).  LDS: BM rows of BN floats, 16-byte chunks XORed with the row (32 lanes of a
+// store hit 32 rows at the same column).
+template <int BM, int BN, int WM, int WN, int MI, int NI, int NT, int ACT>
+__device__ __forceinline__ void glds_store_tile_f32_act(f32x16 (&acc)[MI][NI], const GemmArgs& p, int m0, int n0, int wm,
+                                                        int wn, int lane, int tid, float* cs) {
+  constexpr int CPRW = BN / 4;                                     // 16-byte chunks per tile row
+  static_assert((CPRW & (CPRW - 1)) == 0, "power-of-two chunks per row");
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int row = wm * WM + i * 32 + (lane & 31);
+    const float bm = p.bias_mode == 2 ? p.bias[m0 + row] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = wn * WN + j * 32 + 8 * g + 4 * (lane >> 5);
+        f32x4_t b4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias_mode == 1) b4 = *reinterpret_cast<const f32x4_t*>(p.bias + n0 + col);
+        f32x4_t v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][4 * g + e] + b4[e] + bm) * p.alpha;
+        epi_act4<ACT>(v);
+        const int ch = (col >> 2) ^ (row & (CPRW - 1));
+        *reinterpret_cast<f32x4_t*>(cs + row * BN + ch * 4) = v;
+      }
+  }
+  __syncthreads();
+  float* C = static_cast<float*>(p.C);
+#pragma unroll
+  for (int i = 0; i < BM * CPRW / NT; ++i) {
+    const int c = tid + i * NT, row = c / CPRW, ch = c % CPRW;
+    *reinterpret_cast<f32x4_t*>(C + (long)(m0 + row) * p.ldc + n0 + ch * 4) =
+        *reinterpret_cast<const f32x4_t*>(cs + row * BN + ((ch ^ (row & (CPRW - 1))) << 2));
+  }
+}
+template <int BM, int BN, int WM, int WN, int MI, int NI, int NT>
+__device__ __forceinline__ void glds_store_tile_f32(f32x16 (&acc)[MI][NI], const GemmArgs& p, int m0, int n0, int wm,
+                                                    int wn, int lane, int tid, float* cs) {
+  switch (p.act) {
+    case 1: glds_store_tile_f32_act<BM, BN, WM, WN, MI, NI, NT, 1>(acc, p, m0, n0, wm, wn, lane, tid, cs); break;
+    case 2: glds_store_tile_f32_act<BM, BN, WM, WN, MI, NI, NT, 2>(acc, p, m0, n0, wm, wn, lane, tid, cs); break;
+    default: glds_store_tile_f32_act<BM, BN, WM, WN, MI, NI, NT, 0>(acc, p, m0, n0, wm, wn, lane, tid, cs); break;
+  }
+}
+__device__ __forceinline__ bool glds_fast_tile_f32(const GemmArgs& p, int m0, int n0, int BM, int BN, int M, int N) {
+  return !p.accumulate && !p.atomic_out && p.act != 3 && m0 + BM <= M && n0 + BN <= N && (p.ldc & 3) == 0 &&
+         (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 &&
+         (p.bias_mode != 1 || ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0 && (n0 & 3) == 0));
+}
 __device__ __forceinline__ bool glds_fast_tile(const GemmArgs& p, int m0, int n0, int BM, int BN, int M, int N) {
   return !p.accumulate && p.act != 3 && m0 + BM <= M && n0 + BN <= N && (p.ldc & 7) == 0 &&
          (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 &&
@@ -569,6 +620,15 @@ __device__ __forceinline__ void gemm_nt_glds_body(const GemmArgs& p, const int b
     if (glds_fast_tile(p, m0, n0, BM, BN, M, N)) {       // block-uniform
       glds_store_tile<BM, BN, WM, WN, MI, NI, CS, 64 * NW>(acc, p, m0, n0, wm, wn, lane, tid,
                                                            reinterpret_cast<uint16_t*>(smem));
+      gemm_ts_exit(p);
+      return;
+    }
+  }
+  if constexpr (sizeof(OutT) == 4 && BM * BN * 4 <= 2 * STAGE && !CONV) {
+    if (!p.stat_mean && glds_fast_tile_f32(p, m0, n0, BM, BN, M, N)) {       // block-uniform
+      __syncthreads();                                                       // every wave is done reading the stages
+      glds_store_tile_f32<BM, BN, WM, WN, MI, NI, 64 * NW>(acc, p, m0, n0, wm, wn, lane, tid,
+                                                           reinterpret_cast<float*>(smem));
       gemm_ts_exit(p);
       return;
     }

@@ -1398,7 +1398,10 @@ class AdaptiveLossFn(Function):
         w_head = torch.empty(n_head, E, dtype=dtype, device=dev)
         w_head[:c0] = weight(emb0)
         w_head[c0:] = weight(class_proj)
-        head_logits = gemm(x2, w_head, out_dtype=torch.float32)
+        # (rows of every fp32 logits buffer start on 16 bytes: an odd row length - 5002, 30265 - would make every store
+        #  of the GEMM epilogue a 4-byte one: the 124 MB of tail logits took 137 us that way, 28 us as whole row pieces)
+        head_logits = torch.empty(N, _round_up(n_head, 4), dtype=torch.float32, device=dev)[:, :n_head]
+        gemm(x2, w_head, out=head_logits)
         lse_h = torch.empty(N, dtype=torch.float32, device=dev)
         loss_rows = torch.empty(N, dtype=torch.float32, device=dev)
         call('tell_ce_fwd', head_logits, head_logits.stride(0), N, n_head, part['head_target'], None, None,
@@ -1415,7 +1418,7 @@ class AdaptiveLossFn(Function):
             h = torch.zeros(N, proj.shape[0], dtype=dtype, device=dev)
             gemm(xg, weight(proj), out=h, m_dev=cnt)
             V = emb.shape[0]
-            logits = torch.empty(N, V, dtype=torch.float32, device=dev)
+            logits = torch.empty(N, _round_up(V, 4), dtype=torch.float32, device=dev)[:, :V]
             gemm(h, weight(emb), out=logits, m_dev=cnt)
             lse_t = torch.empty(N, dtype=torch.float32, device=dev)
             lrow = torch.empty(N, dtype=torch.float32, device=dev)
@@ -1489,12 +1492,15 @@ def adaptive_log_probs(x2, cutoffs, emb0, class_proj, tails, want_full=False, to
     n_tails = len(tails) // 2
     w_head = _cached(emb0, ('whead', class_proj._version, class_proj.data_ptr()), lambda: torch.cat(
         [weight(emb0), weight(class_proj)], dim=0).contiguous())
-    head = gemm(x2, w_head, out_dtype=torch.float32)
+    def logits(a, w):                    # fp32 rows start on 16 bytes (see AdaptiveLossFn): vector stores in the epilogue
+        out = torch.empty(a.shape[0], _round_up(w.shape[0], 4), dtype=torch.float32, device=dev)[:, :w.shape[0]]
+        return gemm(a, w, out=out)
+    head = logits(x2, w_head)
     tl, ld, nn_ = [None] * 3, [0] * 3, [0] * 3
     for i in range(n_tails):
         proj, emb = tails[2 * i], tails[2 * i + 1]
         h = gemm(x2, weight(proj))
-        tl[i] = gemm(h, weight(emb), out_dtype=torch.float32)
+        tl[i] = logits(h, weight(emb))
         ld[i], nn_[i] = tl[i].stride(0), tl[i].shape[1]
     vocab = c0 + sum(nn_)
     if topk:
