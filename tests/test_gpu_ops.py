@@ -739,3 +739,23 @@ def test_skinny_gemm_split_k(monkeypatch, M, N, K, act):
     close(y1, ref.cpu(), torch.bfloat16, scale=2)
     assert (y1.float() - y0.float()).abs().max() <= 2e-2 * max(1.0, y0.float().abs().max().item())
     assert (y1 != y0).float().mean() < 0.02           # the two differ only where the fp32 sum rounds the other way
+
+
+def test_long_reduction_few_columns_split_k(monkeypatch):
+    """gemm_nn with few output columns and a very long reduction (adaptive-softmax tails with a reduced dimension:
+    dh[rows, 64] = dlogits[rows, 30265] . W) runs as K slices of one grouped launch + the fold; zero padding columns of
+    the left operand beyond K and a ragged last slice included."""
+    from tell_amd import ops
+    torch.manual_seed(23)
+    M, N, K = 256, 64, 8200 + 57
+    a = torch.zeros(M, ops._round_up(K, 8), device=DEV).bfloat16()
+    a[:200, :K] = torch.randn(200, K, device=DEV).bfloat16()
+    w = (torch.randn(K, N, device=DEV) * 0.05).bfloat16()
+    out = torch.zeros(M, N, device=DEV).bfloat16()
+    y1 = ops.gemm_nn(a, w, out=out, alpha=0.5).clone()
+    monkeypatch.setattr(ops, '_SPLITK', False)
+    y0 = ops.gemm_nn(a, w, alpha=0.5)
+    ref = (a[:, :K].float() @ w.float()) * 0.5
+    close(y1, ref.cpu(), torch.bfloat16, scale=math.sqrt(K) * 0.05)
+    close(y0, ref.cpu(), torch.bfloat16, scale=math.sqrt(K) * 0.05)
+    assert (y1[200:] == 0).all()

@@ -224,6 +224,22 @@ def gemm_nn(a, b_kn, b_t=None, out=None, out_dtype=None, alpha=1.0, act=0, aux=N
     K, N = b_kn.shape                  # `a` may carry zero padding columns beyond K (never garbage: 0 * NaN)
     assert a.shape[1] >= K
     big = ((M + 127) // 128) * ((N + 127) // 128) >= 256 and K % 64 == 0     # direct-to-LDS NT kernel territory
+    if (_SPLITK and K >= 8192 and N <= 256 and N % 4 == 0 and _kmajor_ok(b_kn) and a.dtype == torch.bfloat16 and
+            a.stride(1) == 1 and a.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and a.shape[1] >= _round_up(K, 8) and
+            act == 0 and aux is None and (out is None or out.stride(0) % 4 == 0)):
+        # few output columns from a very long reduction (the adaptive-softmax tails' dh = dlogits . W: [1024, 64] from
+        # K = 30265): 16-64 output tiles walking hundreds of K tiles each (162 us).  K slices as one grouped launch
+        # of fp32 partial tiles + the fold.  (Rows past *m_dev are computed too: they are zeros in, zeros out.)
+        if out is None:
+            out = torch.empty(M, N, dtype=out_dtype or a.dtype, device=a.device)
+        ks = 2048
+        splits = (K + ks - 1) // ks
+        partial = torch.empty(splits, M, N, dtype=torch.float32, device=a.device)
+        gemm_grouped([dict(a=a[:, i * ks:min(_round_up(K, 8), (i + 1) * ks)], b=b_kn[i * ks:min(K, (i + 1) * ks)],
+                           out=partial[i], form='nn') for i in range(splits)])
+        call('tell_splitk_reduce', partial, splits, partial.stride(0), M, N, None, 0, float(alpha), out, out.stride(0),
+             hip.dt(out))
+        return out
     if (_kmajor_ok(b_kn) and a.dtype == torch.bfloat16 and a.stride(1) == 1 and a.stride(0) % 8 == 0 and
             (K % 8 == 0 or a.shape[1] >= _round_up(K, 8)) and a.data_ptr() % 16 == 0 and
             not (big and b_t is not None)):
