@@ -167,7 +167,7 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
     torch.manual_seed(0)                                     # same initial weights on all ranks
     tell_amd.manual_seed(1234 + rank)
     model = build_model(model_name, weigh_bert=fo)
-    trainer = Trainer(model, device=dev)
+    trainer = Trainer(model, device=dev, capture_after=1)       # fixed shapes: capture at first sight
     batches = [synthetic_batch(batch_size, 512, 33, fo, seed=1234 + rank + 97 * i, device=dev) for i in range(2)]
 
     def fresh(b):

@@ -10,7 +10,11 @@
  *
  * Conventions
  *   - plain pointers + sizes, no torch types; caller owns all memory; the library
- *     allocates nothing and keeps no state except a thread-local error string;
+ *     allocates nothing.  Its only state: a thread-local error string, three
+ *     REGISTERED device pointers that kernels read while a hipGraph is recorded /
+ *     replayed (tell_set_rng_step_ptr, tell_set_pos_step_ptr: the dropout step and
+ *     decode position counters) and a thread-local one-shot hook that arms the next
+ *     tell_gemm_nt launch with a span stamp (tell_gemm_ts_next);
  *   - every call is asynchronous on `stream` (pass torch's current stream);
  *   - return 0 on success, <0 on error (tell_last_error() explains);
  *   - `dtype`: TELL_F32 = 0 (exact-f32 parity mode, f32 MFMA), TELL_BF16 = 1;
@@ -56,7 +60,6 @@ int tell_wall_clock_khz(void);
  * into ts[0] (first workgroup in) / ts[1] (last workgroup out), device wall-clock ticks; ts is uint64[3], zero before
  * the first use (ts[2] counts workgroup arrivals: every launch of the same grid re-opens the span by itself) */
 int tell_gemm_ts_next(void* ts, tell_stream_t stream);
-int tell_wall_clock_khz(void);
 
 /* ---- GEMM (every nn.Linear / F.linear / 1x1 conv on the path) --------------
  * C[M,N] = act((A[M,K] . B[N,K]^T + bias) * alpha) (+ C if accumulate)
@@ -300,7 +303,11 @@ int tell_bertadam_step(float* param, float* grad, float* m, float* v, const int*
                        const long* chunk_begin, long n_chunks, int n_tensors, float* partial, float* norms,
                        const float* lr_dev, float b1, float b2, float eps, float wd, float max_norm,
                        float grad_scale, void* shadow_bf16, int zero_grad, int* skip, const void* grad_wire_bf16,
-                       tell_stream_t stream);
+                       int* step_dev, float lr_base, float warmup, float t_total, tell_stream_t stream);
+/* step_dev (device int32, may be NULL): the count of updates APPLIED so far.  When given, the library first writes
+ * *lr_dev = lr_base * warmup_linear(*step_dev / t_total, warmup) (t_total <= 0: lr_base) and the update kernel
+ * increments *step_dev only when the step is not skipped - a skipped batch costs no tick of the schedule, exactly as in
+ * the reference, where it never reaches optimizer.step().  NULL: the caller filled *lr_dev itself. */
 /* skip (int[2], may be NULL): skip[0] != 0 -> the step leaves parameters / moments untouched (gradient still cleared)
  * and skip[1] counts such steps; tell_loss_flag sets skip[0] = !isfinite(loss) (the NaN-loss skip of
  * callback_apex_trainer.py:225-227 without a host sync), the norm pass ORs in 2 for a non-finite gradient (what apex

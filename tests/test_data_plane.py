@@ -143,6 +143,34 @@ def test_shards_reader_and_batch_contract(tmp_path):
     assert sum(b['context']['roberta'].shape[0] for b in b2) == 8          # the cursor continues (3 left + 5 new)
 
 
+def test_reader_limits_faces_to_caption_person_names(tmp_path):
+    """nytimes_faces_ner_matched.py:125-130,168-170: n_faces wins; else with use_caption_names the number of PERSON names
+    in the caption (recorded by the shard writer as n_person_names) limits the faces - 0 names = the empty field; a
+    shard without the count is taken as pre-trimmed, and more than 4 faces in it is an error, not a silent truncation."""
+    from tell_amd.data import DatasetReader, write_shard
+    samples = _samples(6, seed=3, with_obj=False)
+    names = [0, 1, 2, 4, 3, 1]
+    for s, n in zip(samples, names):
+        s['face_embeds'] = np.random.RandomState(n).randn(4, 512).astype(np.float32)
+        s['n_person_names'] = n
+    write_shard(str(tmp_path / 'a' / 'train-00000.npz'), samples)
+    mk = lambda d, **kw: DatasetReader.by_name('nytimes_faces_ner_matched')(shard_dir=str(tmp_path / d), seed=0, **kw)  # noqa: E731
+    by_img = {s['image'].tobytes(): n for s, n in zip(samples, names)}
+    for inst in mk('a', use_caption_names=True)._read('train'):
+        n = by_img[inst['image'].tobytes()]
+        assert inst['face_embeds'].shape == ((n, 512) if n else (1, 0))
+    for inst in mk('a', use_caption_names=True, n_faces=2)._read('train'):       # n_faces overrides (:125-126)
+        assert inst['face_embeds'].shape == (2, 512)
+    for inst in mk('a', use_caption_names=False)._read('train'):                 # neither: the top 4 faces (:129-130)
+        assert inst['face_embeds'].shape == (4, 512)
+    for s in samples:
+        del s['n_person_names']
+        s['face_embeds'] = np.zeros((5, 512), np.float32)
+    write_shard(str(tmp_path / 'b' / 'train-00000.npz'), samples)
+    with pytest.raises(ValueError):
+        list(mk('b', use_caption_names=True)._read('train'))
+
+
 def test_bucket_iterator_semantics():
     from tell_amd.data import BucketIterator, NYTimesFacesNERMatchedReader
     reader = NYTimesFacesNERMatchedReader(use_objects=True, synthetic_samples=40)

@@ -243,11 +243,11 @@ def test_roberta_graph_replay_dropout_step_counter():
     assert g.entries[(tuple(ids.shape), ids.dtype, ids.device.index, 'eval')]['state'] == 'ready'
     m.train()
     eager = fn(ids).float()
-    outs = [g(ids, key='train').float().clone() for _ in range(4)]       # call 0 eager (+ capture), 1-3 replay
+    outs = [g(ids, key='train').float().clone() for _ in range(5)]       # calls 0-1 eager (1: + capture), 2-4 replay
     e = g.entries[(tuple(ids.shape), ids.dtype, ids.device.index, 'train')]
     assert e['state'] == 'ready', e.get('error')
     assert e['replays'] == 4 and len(e['slots']) == 2       # two captures used round-robin, one step value per replay
-    for a, b in ((1, 2), (2, 3), (1, 3)):
+    for a, b in ((2, 3), (3, 4), (2, 4)):
         d = (outs[a] - outs[b]).norm() / outs[a].norm()
         assert d > 1e-2, (a, b, float(d))                                # different masks every replay
     for o in outs:

@@ -59,7 +59,7 @@ def test_step_graph_equals_eager(kind, dtype):
         lb = tb.train_one_batch(_clone(batches[s % 2]))
         tol = 1e-6 if dtype == torch.float32 else 1e-3
         assert abs(float(la) - float(lb)) <= tol * abs(float(la)), (s, float(la), float(lb))
-    assert tb.step_graph.replays == 6 and [e['state'] for e in tb.step_graph.entries.values()] == ['ready']
+    assert tb.step_graph.replays == 5 and [e['state'] for e in tb.step_graph.entries.values()] == ['ready']
     assert tb.optimizer.step_count == ta.optimizer.step_count == 7
     num = float((ta.flat.flat - tb.flat.flat).norm())
     assert num <= (1e-6 if dtype == torch.float32 else 2e-3) * float(ta.flat.flat.norm()), num
@@ -81,9 +81,9 @@ def test_step_graph_draws_fresh_dropout_masks():
     tr = Trainer(m, dict(lr=0.0, warmup=-1, t_total=-1, weight_decay=0.0), device=DEV)
     batch = _dev(synthetic_batch(B=4, article_len=24, caption_len=12, faces_objects=True, vocab=600,
                                  cutoffs=(100, 300), seed=7))
-    losses = [float(tr.train_one_batch(_clone(batch))) for _ in range(6)]
-    assert tr.step_graph.replays == 5
-    assert len({round(x, 5) for x in losses[1:]}) >= 4, losses
+    losses = [float(tr.train_one_batch(_clone(batch))) for _ in range(7)]
+    assert tr.step_graph.replays == 5            # (a shape is captured at its second sighting)
+    assert len({round(x, 5) for x in losses[2:]}) >= 4, losses
     assert max(losses) - min(losses) < 0.2 * abs(losses[0]), losses        # same weights: only the masks differ
 
 
@@ -118,6 +118,11 @@ def test_non_finite_step_is_skipped_on_device(graph):
     loss = tr.train_one_batch(_clone(good))
     assert torch.isfinite(loss) and not torch.equal(tr.flat.flat, w0) and tr.skipped_steps() == 1
     assert bool(torch.isfinite(tr.flat.flat).all())
+    # the skipped batch costs no tick of the schedule (it never reaches optimizer.step() in the reference): 4 steps
+    # issued, 3 applied, and the learning rate the last step used is the one of applied-step index 2
+    opt = tr.optimizer
+    assert opt.step_count == 4 and opt.applied_steps() == 3
+    assert abs(float(opt.lr_dev) - opt.current_lr(2)) <= 1e-6 * opt.current_lr(2)
 
 
 def test_generate_after_training_step_does_not_replay_stale_decode_graph():
@@ -186,4 +191,4 @@ def test_two_dp_ranks_equal_one_process_on_concatenated_batch(graph):
     assert rc == 0, out[-3000:]
     assert 'RESULT dp == single' in out, out[-3000:]
     if graph == '1':
-        assert 'graph replays 4' in out, out[-3000:]
+        assert 'graph replays 3' in out, out[-3000:]

@@ -13,7 +13,7 @@ kind = sys.argv[1] if len(sys.argv) > 1 else 'faces_objects'
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 fo = kind == 'faces_objects'
 model = build_model(kind, weigh_bert=fo)
-tr = Trainer(model, device='cuda')
+tr = Trainer(model, device='cuda', capture_after=1)
 batches = [synthetic_batch(B, 512, 33, fo, seed=1234 + i, device='cuda') for i in range(2)]
 fresh = lambda b: {k: (dict(v) if isinstance(v, dict) else v) for k, v in b.items()}
 run_res, run_rob = model._run_resnet, model._run_roberta

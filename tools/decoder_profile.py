@@ -26,7 +26,7 @@ class NoEncoder(torch.nn.Module):          # never called: the features are hand
 
 
 model = build_model(kind, NoEncoder(), NoEncoder(), weigh_bert=fo)
-tr = Trainer(model, device='cuda')
+tr = Trainer(model, device='cuda', capture_after=1)
 b = synthetic_batch(B, 512, 33, fo, seed=1234, device='cuda')
 enc = EncodedBatch()
 g = torch.Generator(device='cuda').manual_seed(5)

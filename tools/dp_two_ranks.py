@@ -22,7 +22,7 @@ for m in model.modules():                                    # no dropout: the t
     for a in ('dropout', 'input_dropout', 'relu_dropout', 'weight_dropout', 'attention_dropout'):
         if isinstance(getattr(m, a, None), float):
             setattr(m, a, 0.0)
-tr = Trainer(model, device='cuda')
+tr = Trainer(model, device='cuda', capture_after=1)
 assert tr.dp and tr.world == 2
 fresh = lambda b: {k: (dict(v) if isinstance(v, dict) else v) for k, v in b.items()}
 ok = True

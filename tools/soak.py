@@ -12,7 +12,7 @@ torch.manual_seed(0)
 kind = sys.argv[1] if len(sys.argv) > 1 else 'flattened'
 fo = kind == 'faces_objects'
 model = build_model(kind, weigh_bert=fo)
-tr = Trainer(model, device='cuda')
+tr = Trainer(model, device='cuda', capture_after=1)
 bs = [synthetic_batch(32 if fo else 16, 512, 33, fo, seed=1234 + 97 * i, device='cuda') for i in range(2)]
 fresh = lambda b: {k: (dict(v) if isinstance(v, dict) else v) for k, v in b.items()}
 for i in range(3001):

@@ -12,7 +12,7 @@ tell_amd.set_compute_dtype(torch.bfloat16)
 tell_amd.manual_seed(1234)
 torch.manual_seed(0)
 model = build_model('flattened', weigh_bert=False)
-tr = Trainer(model, device='cuda')
+tr = Trainer(model, device='cuda', capture_after=1)
 batches = [synthetic_batch(16, 512, 33, False, seed=1234 + i, device='cuda') for i in range(4)]
 marks = []
 

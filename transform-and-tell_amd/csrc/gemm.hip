@@ -1478,8 +1478,10 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
   // wins (11.8 us against 20 us per launch).  TELL_GEMM_SMALL=0 restores the register-staged kernel everywhere (A/B).
   if constexpr (sizeof(T) == 2) {
     static const bool small_glds = !(getenv("TELL_GEMM_SMALL") && atoi(getenv("TELL_GEMM_SMALL")) == 0);
-    if (small_glds && a.M >= 512 && a.K <= 2048 && a.K % 64 == 0 && !a.stat_mean &&   // (K = 4096: 35.6 us against 23.7 us) (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 &&
-        (reinterpret_cast<uintptr_t>(a.B) & 15) == 0 && (a.lda & 7) == 0 && (a.ldb & 7) == 0) {
+    // (K = 4096: 35.6 us against 23.7 us for the register-staged kernel below)
+    if (small_glds && a.M >= 512 && a.K <= 2048 && a.K % 64 == 0 && !a.stat_mean &&
+        (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0 &&
+        (a.lda & 7) == 0 && (a.ldb & 7) == 0) {
       *bm_used = 64;
       TELL_GEMM_LAUNCH(gemm_label("gemm_nt_glds_kernel", -1, sizeof(OutT) == 2, 64, 64), (gemm_nt_glds_kernel<OutT, 64, 64, 2, 2>), dim3((unsigned)tiles(64, 64)), dim3(256));
       return g_gemm_plan ? TELL_OK : tell_check_launch("gemm_nt_glds");

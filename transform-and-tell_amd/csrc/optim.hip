@@ -68,6 +68,19 @@ extern "C" int tell_loss_flag(const float* loss, int* skip, hipStream_t stream) 
   hipLaunchKernelGGL(loss_flag_kernel, dim3(1), dim3(1), 0, stream, loss, skip);
   return tell_check_launch("loss_flag");
 }
+// warmup_linear (pytorch_pretrained_bert WarmupLinearSchedule.get_lr_) evaluated on the device from a device step counter
+// that only SUCCESSFUL updates advance: a batch skipped for a non-finite loss / gradient never reached optimizer.step()
+// in the reference (callback_apex_trainer.py:225-227), so it must not cost a tick of the schedule either - and the host
+// cannot know about the skip without a synchronisation.  t_total <= 0: constant learning rate.
+__global__ void lr_schedule_kernel(const int* __restrict__ step, float lr, float warmup, float t_total,
+                                   float* __restrict__ lr_dev) {
+  double f = 1.0;
+  if (t_total > 0.f) {
+    const double x = (double)step[0] / (double)t_total, w = (double)warmup;
+    f = x < w ? x / w : fmax((x - 1.0) / (w - 1.0), 0.0);
+  }
+  lr_dev[0] = (float)((double)lr * f);
+}
 // One pass over the flat buffers: BertAdam update of the fp32 masters, the bf16 working copy the next forward
 // reads (shadow; no per-tensor cast kernels), and the zeroing of the gradient for the next step.
 __global__ __launch_bounds__(256) void bertadam_update_kernel(float* __restrict__ param,
@@ -79,7 +92,8 @@ __global__ __launch_bounds__(256) void bertadam_update_kernel(float* __restrict_
                                                               float b2, float eps, float wd, float max_norm,
                                                               float grad_scale, uint16_t* __restrict__ shadow,
                                                               int zero_grad, int* __restrict__ skip,
-                                                              const uint16_t* __restrict__ wire) {
+                                                              const uint16_t* __restrict__ wire,
+                                                              int* __restrict__ step_dev) {
   const float lr = *lr_dev;
   if (skip && skip[0] != 0) {      // non-finite loss or gradient: leave p, m, v and the shadow alone, only clear the gradient
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skip + 1, 1);          // running count of skipped steps
@@ -88,6 +102,7 @@ __global__ __launch_bounds__(256) void bertadam_update_kernel(float* __restrict_
         reinterpret_cast<float4*>(grad)[c * OPT_CHUNK / 4 + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
     return;
   }
+  if (step_dev && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(step_dev, 1);   // (nobody reads it inside this launch)
   for (long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     float coef = grad_scale;
     if (max_norm > 0.f) {
@@ -127,8 +142,12 @@ extern "C" int tell_bertadam_step(float* param, float* grad, float* m, float* v,
                                   int n_tensors, float* partial, float* norms, const float* lr_dev,
                                   float b1, float b2, float eps, float wd, float max_norm,
                                   float grad_scale, void* shadow_bf16, int zero_grad, int* skip,
-                                  const void* grad_wire_bf16, hipStream_t stream) {
+                                  const void* grad_wire_bf16, int* step_dev, float lr_base, float warmup, float t_total,
+                                  hipStream_t stream) {
   if (n_chunks <= 0) return TELL_OK;
+  if (step_dev)      // device-side schedule: this step's learning rate from the count of updates applied so far
+    hipLaunchKernelGGL(lr_schedule_kernel, dim3(1), dim3(1), 0, stream, step_dev, lr_base, warmup, t_total,
+                       const_cast<float*>(lr_dev));
   TELL_REQUIRE(((uintptr_t)grad_wire_bf16 & 7) == 0, "bertadam: the bf16 gradient must be 8-byte aligned");
   const uint16_t* wire = static_cast<const uint16_t*>(grad_wire_bf16);
   TELL_REQUIRE(((uintptr_t)param & 15) == 0 && ((uintptr_t)grad & 15) == 0, "bertadam: buffers must be 16-byte aligned");
@@ -137,7 +156,7 @@ extern "C" int tell_bertadam_step(float* param, float* grad, float* m, float* v,
     hipLaunchKernelGGL(sqsum_chunks_kernel, dim3(g), dim3(256), 0, stream, grad, wire, n_chunks, grad_scale, partial);
     hipLaunchKernelGGL(tensor_norms_kernel, dim3(n_tensors), dim3(256), 0, stream, partial, chunk_begin, n_tensors, norms, skip);
   }
-  hipLaunchKernelGGL(bertadam_update_kernel, dim3(g), dim3(256), 0, stream, param, grad, m, v, chunk_tensor, norms, n_chunks, lr_dev, b1, b2, eps, wd, max_norm, grad_scale, (uint16_t*)shadow_bf16, zero_grad, skip, wire);
+  hipLaunchKernelGGL(bertadam_update_kernel, dim3(g), dim3(256), 0, stream, param, grad, m, v, chunk_tensor, norms, n_chunks, lr_dev, b1, b2, eps, wd, max_norm, grad_scale, (uint16_t*)shadow_bf16, zero_grad, skip, wire, step_dev);
   return tell_check_launch("bertadam_step");
 }
 

@@ -55,7 +55,19 @@ class NYTimesFacesNERMatchedReader(DatasetReader):
         for p in [paths[i] for i in self.rs.permutation(len(paths))]:
             for s in read_shard(p):
                 faces = s['face_embeds']
-                n_persons = 4 if self.n_faces is None else self.n_faces        # (:125-128; caption names live upstream)
+                if self.n_faces is not None:                                   # :125-130
+                    n_persons = self.n_faces
+                elif self.use_caption_names:
+                    # PERSON names of the caption: recorded by the shard writer, or already applied by it (shards.py)
+                    n_persons = s.get('n_person_names')
+                    if n_persons is None:
+                        if len(faces) > 4:
+                            raise ValueError('shard %s: %d faces for one sample and no n_person_names - with '
+                                             'use_caption_names the writer must record the name count or pre-trim'
+                                             % (p, len(faces)))
+                        n_persons = len(faces)
+                else:
+                    n_persons = 4
                 faces = faces[:n_persons] if n_persons else faces[:0]
                 obj = s.get('obj_embeds') if self.use_objects else None
                 yield self.ids_to_instance(s['context_ids'], s['caption_ids'], s['image'], faces, obj, s['metadata'],

@@ -9,9 +9,14 @@ scripts/process_images.py:37-39 produces).  Ragged fields are stored concatenate
         context_copy int8  [sum L]      caption_copy int8 [sum T]    (entity copy masks of the indexer; optional)
         image        uint8 [N,224,224,3]
         face_embeds  float32 [sum F,512]   face_off int64 [N+1]      (F <= 4; 0 rows = the reference's empty [1,0] field)
+        n_person_names int32 [N]                                       (PERSON entities in the caption, :125-130; optional)
         obj_embeds   float32 [sum O,2048]  obj_off  int64 [N+1]      (O <= 64; absent when use_objects is false)
         metadata     str [N]                                          (JSON: caption, context, web_url, image_path, ...)
-"""
+
+Faces and `use_caption_names` (nytimes_faces_ner_matched.py:125-130,168-170): the reference keeps only as many faces as
+the caption has PERSON names.  A shard either records that count per sample (`n_person_names`: the reader trims) or its
+writer has ALREADY trimmed `face_embeds` to it - a shard without the field is taken as pre-trimmed, and the reader
+checks the only invariant it can (F <= 4, the largest count any config reaches)."""
 import glob
 import json
 import os
@@ -37,6 +42,8 @@ def write_shard(path, samples):
         out['caption_copy'], _ = ragged('caption_copy', np.int8)
     out['image'] = np.stack([np.asarray(s['image'], dtype=np.uint8) for s in samples])
     out['face_embeds'], out['face_off'] = ragged('face_embeds', np.float32, 512)
+    if all('n_person_names' in s for s in samples):
+        out['n_person_names'] = np.array([int(s['n_person_names']) for s in samples], dtype=np.int32)
     if all(s.get('obj_embeds') is not None for s in samples):
         out['obj_embeds'], out['obj_off'] = ragged('obj_embeds', np.float32, 2048)
     out['metadata'] = np.array([json.dumps(s.get('metadata', {})) for s in samples])
@@ -62,6 +69,8 @@ def read_shard(path):
         s = {'context_ids': arrays['context_ids'][c0:c1], 'caption_ids': arrays['caption_ids'][t0:t1],
              'image': arrays['image'][i], 'face_embeds': arrays['face_embeds'][f0:f1],
              'metadata': json.loads(str(arrays['metadata'][i]))}
+        if 'n_person_names' in arrays:
+            s['n_person_names'] = int(arrays['n_person_names'][i])
         if has_copy:
             s['context_copy'] = arrays['context_copy'][c0:c1]
             s['caption_copy'] = arrays['caption_copy'][t0:t1]

@@ -37,11 +37,58 @@ class no_gc:
 ENABLED = os.environ.get('TELL_GRAPHS', '1') != '0'
 
 
-MAX_SIGNATURES = 4      # every captured signature keeps its activations in a private pool; further ones run eagerly
+MAX_SIGNATURES = 4      # every captured signature keeps its activations in a private pool
+# A signature is captured at its CAPTURE_AFTER-th sighting: real BucketIterator batches pad to the per-batch maximum,
+# so most shapes are seen once - capturing each of them would cost a host capture pass and pin a private activation
+# pool per shape for nothing.  Fixed-shape runs (bench.py) pass capture_after=1.
+CAPTURE_AFTER = max(1, int(os.environ.get('TELL_GRAPH_AFTER', '2')))
+MAX_ENTRIES = 256       # bookkeeping entries (sighting counters) kept per cache; the oldest are forgotten beyond that
+
+
+class SignatureCache:
+    """signature -> entry dict, in least-recently-used order.  Entries start as {'state': 'seen', 'hits': 0}; the owner
+    turns one into 'ready' (with its graph objects) after a capture.  make_room() evicts the least recently used READY
+    entries down to max_ready - 1 (dropping the graph releases its private pool) and forgets the oldest counters
+    beyond MAX_ENTRIES: neither the captured pools nor the dict grow with the number of distinct shapes seen."""
+
+    def __init__(self, max_ready, capture_after=None):
+        from collections import OrderedDict
+        self.entries = OrderedDict()
+        self.max_ready = max(1, int(max_ready))
+        self.capture_after = CAPTURE_AFTER if capture_after is None else max(1, int(capture_after))
+        self.evictions = 0
+
+    def touch(self, sig):
+        """-> the entry of sig (created on first sight), counted as one more sighting and made most recently used."""
+        e = self.entries.get(sig)
+        if e is None:
+            e = self.entries[sig] = {'state': 'seen', 'hits': 0}
+        e['hits'] += 1
+        self.entries.move_to_end(sig)
+        return e
+
+    def due(self, e):
+        return e['state'] == 'seen' and e['hits'] >= self.capture_after
+
+    def make_room(self):
+        """Call right before a capture (never inside one: destroying a graph while capturing is illegal)."""
+        ready = [k for k, v in self.entries.items() if v['state'] == 'ready']
+        if len(ready) >= self.max_ready and torch.cuda.is_available():
+            torch.cuda.synchronize()                # the victim's last replay may still be running (evictions are rare)
+        while len(ready) >= self.max_ready:
+            k = ready.pop(0)
+            self.entries.pop(k).clear()             # drops the graph, its static buffers and its pool
+            self.evictions += 1
+        if len(self.entries) > MAX_ENTRIES:
+            for k in [k for k, v in self.entries.items() if v['state'] != 'ready'][:len(self.entries) - MAX_ENTRIES]:
+                del self.entries[k]
+
+    def clear(self):
+        self.entries.clear()
 
 
 class GraphedCall:
-    def __init__(self, fn, name='graph', rng=False, buffers=2):
+    def __init__(self, fn, name='graph', rng=False, buffers=2, capture_after=None):
         """rng: the function contains dropout.  Its kernels are captured with a device step counter registered
         (tell_set_rng_step_ptr) and the counter is bumped before every replay, so the frozen seed/salt arguments
         still give fresh masks (csrc/common.h tell_step_salt).
@@ -49,15 +96,19 @@ class GraphedCall:
         buffers: a replay writes its result into buffers owned by the graph, so every signature is captured
         `buffers` times and the captures are used round-robin: the tensor returned by a call stays intact until
         `buffers` further calls - the step pipeline needs 2 (the encoders of batch N+1 are replayed while the
-        decoder step of batch N is still reading the outputs for batch N)."""
+        decoder step of batch N is still reading the outputs for batch N).
+
+        capture_after: sightings of a signature before it is captured (default graphs.CAPTURE_AFTER); at most
+        MAX_SIGNATURES signatures stay captured, least recently used evicted first."""
         self.fn = fn
         self.name = name
         self.rng = rng
         self.buffers = max(1, int(os.environ.get('TELL_GRAPH_BUFFERS', buffers)))   # env: test aid
-        self.entries = {}          # signature -> dict(state=..., slots=[dict(graph, static_in, static_out, counter)], turn)
+        self.cache = SignatureCache(MAX_SIGNATURES, capture_after)
+        self.entries = self.cache.entries  # signature -> dict(state=..., slots=[dict(graph, static_in, static_out, counter)], turn)
 
     def reset(self):
-        self.entries.clear()
+        self.cache.clear()
 
     def __call__(self, x, key=()):
         """x: the single tensor input; key: extra hashable state the kernel sequence depends on."""
@@ -65,13 +116,12 @@ class GraphedCall:
         if not ENABLED or not x.is_cuda:
             return self.fn(x)
         sig = (tuple(x.shape), x.dtype, x.device.index, key)
-        e = self.entries.get(sig)
-        if e is None:
-            ready = sum(1 for v in self.entries.values() if v['state'] == 'ready')
-            e = self.entries[sig] = {'state': 'eager', 'slots': [], 'turn': 0}
+        e = self.cache.touch(sig)
+        if e['state'] == 'seen':
             out = self.fn(x)                            # eager: also builds the weight caches the capture relies on
-            if ready < MAX_SIGNATURES:
-                self._capture(e, x)                     # records, does not execute: the first call pays for it,
+            if self.cache.due(e):
+                self.cache.make_room()
+                self._capture(e, x)                     # records, does not execute: this call pays for it,
             return out                                  # not a later (timed) one
         if e['state'] != 'ready':
             return self.fn(x)
@@ -108,5 +158,5 @@ class GraphedCall:
                 slots.append({'graph': g, 'static_in': static_in, 'static_out': static_out, 'counter': counter})
             e.update(state='ready', slots=slots, turn=0, replays=1)
         except Exception as exc:                        # noqa: BLE001 - any capture problem -> eager for good
-            e['state'] = 'eager'
+            e['state'] = 'failed'
             e['error'] = repr(exc)

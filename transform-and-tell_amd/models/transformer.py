@@ -100,6 +100,13 @@ class CaptionModel(Model):
         self.__dict__.pop('_decode_graphs', None)
         self.__dict__.pop('_decode_graphs_stamp', None)
 
+    def set_capture_after(self, n):
+        """Sightings of an input shape before the encoder graphs capture it (graphs.CAPTURE_AFTER by default)."""
+        self.__dict__['_capture_after'] = n
+        self.reset_graphs()
+        for k in ('_resnet_graph', '_roberta_graph'):
+            self.__dict__.pop(k, None)
+
     def _run_resnet(self, image):
         """The frozen trunk as one hipGraph replay per step (graphs.GraphedCall); eager for the first call."""
         from .resnet import ResNetFeatureExtractor
@@ -107,7 +114,8 @@ class CaptionModel(Model):
             return self.resnet(image)
         g = self.__dict__.get('_resnet_graph')
         if g is None:
-            g = self.__dict__['_resnet_graph'] = graphs.GraphedCall(self.resnet, 'resnet152')
+            g = self.__dict__['_resnet_graph'] = graphs.GraphedCall(self.resnet, 'resnet152',
+                                                                    capture_after=self.__dict__.get('_capture_after'))
         w = self.resnet.conv1.weight                 # a reloaded / moved / re-typed trunk must not replay stale pointers
         return g(image, key=(self.resnet.training, ops.rt.compute_dtype(), w._version, w.data_ptr()))
 
@@ -119,7 +127,8 @@ class CaptionModel(Model):
         g = self.__dict__.get('_roberta_graph')
         if g is None:
             g = self.__dict__['_roberta_graph'] = graphs.GraphedCall(
-                lambda ids: self.roberta.extract_features(ids, return_all_hiddens=True), 'roberta-large', rng=True)
+                lambda ids: self.roberta.extract_features(ids, return_all_hiddens=True), 'roberta-large', rng=True,
+                capture_after=self.__dict__.get('_capture_after'))
         w = self.roberta.model.decoder.sentence_encoder.layers[0].fc1.weight
         return g(article_ids, key=(self.roberta.training, ops.rt.compute_dtype(), w._version, w.data_ptr()))
 

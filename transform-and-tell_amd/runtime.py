@@ -7,6 +7,7 @@ _state = {
     'dtype': torch.bfloat16,   # activations / working weights; torch.float32 = exact parity mode
     'seed': 0x5EED,
     'salt': 0,
+    'rank': 0,                 # data-parallel rank: folded into seed() so that every rank draws its own masks
     'epoch': 0,                # bumped whenever master weights change (optimizer step / load)
 }
 
@@ -33,8 +34,14 @@ def next_salt():
     return _state['salt']
 
 
+def set_rank(rank):
+    """Data-parallel rank of this process.  seed() mixes it in at use time, so manual_seed(s) stays idempotent (the
+    same call on every rank, any number of times, any number of Trainers) and ranks still never share a mask."""
+    _state['rank'] = int(rank)
+
+
 def seed():
-    return _state['seed']
+    return (_state['seed'] + 0x9E3779B1 * _state['rank']) & 0xFFFFFFFF
 
 
 def weights_epoch():

@@ -90,13 +90,24 @@ class BertAdam:
         self.flat = flat
         self.lr, self.warmup, self.t_total = lr, warmup, t_total
         self.b1, self.b2, self.e, self.weight_decay, self.max_grad_norm = b1, b2, e, weight_decay, max_grad_norm
-        self.step_count = 0
-        self.lr_dev = torch.zeros(1, dtype=torch.float32, device=flat.flat.device)
+        self.step_count = 0         # optimisation steps ISSUED by the host (incl. steps the device skipped)
+        dev = flat.flat.device
+        self.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        # updates APPLIED: advanced by the update kernel itself, only when the step is not skipped for a non-finite
+        # loss / gradient; the learning rate of a step is computed from it on the device (csrc/optim.hip)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.parameter_groups = parameter_groups    # all groups of the configs carry `{}` overrides
 
-    def current_lr(self):
+    def applied_steps(self):
+        """Updates applied so far = issued steps minus the skipped ones (one host sync)."""
+        return int(self.step_dev.item())
+
+    def current_lr(self, step=None):
+        """Learning rate of the step that follows `step` applied updates (default: the host's count of issued steps;
+        pass applied_steps() for what the device will actually use after skipped batches)."""
+        step = self.step_count if step is None else step
         if self.t_total != -1:
-            return self.lr * warmup_linear(self.step_count / self.t_total, self.warmup)
+            return self.lr * warmup_linear(step / self.t_total, self.warmup)
         return self.lr
 
     def step(self, grad_scale=1.0, zero_grad=False, skip=None, grad_wire=None):
@@ -108,8 +119,7 @@ class BertAdam:
 
     # the three parts of step(), separable so that the kernel launches can live in a captured graph
     def prepare(self):
-        """Host part before the kernels: this step's learning rate into the device scalar the kernel reads."""
-        self.lr_dev.fill_(self.current_lr())
+        """Host part before the kernels: nothing any more - the schedule lives on the device (step_dev)."""
 
     def launch(self, grad_scale=1.0, zero_grad=False, skip=None, grad_wire=None):
         """grad_wire: optional bf16 copy of the whole flat gradient (the data-parallel exchange's wire buffer after the
@@ -117,20 +127,22 @@ class BertAdam:
         f = self.flat
         hip.call('tell_bertadam_step', f.flat, f.grad, f.m, f.v, f.chunk_tensor, f.chunk_begin, f.n_chunks,
                  len(f.params), f.partial, f.norms, self.lr_dev, self.b1, self.b2, self.e, self.weight_decay,
-                 self.max_grad_norm, float(grad_scale), f.shadow, int(zero_grad), skip, grad_wire)
+                 self.max_grad_norm, float(grad_scale), f.shadow, int(zero_grad), skip, grad_wire,
+                 self.step_dev, float(self.lr), float(self.warmup), float(self.t_total))
 
     def advance(self):
-        """Host part after the kernels.  (A skipped step still advances the schedule by one: the host does not read
-        the device flag; the reference's skipped batches do not reach optimizer.step() - a difference of one
-        warmup/decay tick per non-finite batch out of 437 600.)"""
+        """Host part after the kernels.  The host cannot see a device-side skip without a synchronisation, so it bumps
+        the weights epoch regardless: after a skipped step that costs one needless rebuild of the cached working
+        weights in the eager schedule (the step graph rebuilds them inside the graph anyway) - never a stale one."""
         self.step_count += 1
         rt.bump_weights_epoch()
 
     def state_dict(self):
-        return {'step': self.step_count, 'm': self.flat.m, 'v': self.flat.v}
+        return {'step': self.applied_steps(), 'm': self.flat.m, 'v': self.flat.v}
 
     def load_state_dict(self, sd):
         self.step_count = sd['step']
+        self.step_dev.fill_(int(sd['step']))
         self.flat.m.copy_(sd['m'])
         self.flat.v.copy_(sd['v'])
 

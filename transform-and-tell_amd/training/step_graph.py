@@ -12,7 +12,7 @@ What makes the capture legal:
   * weight gradients accumulate into the flat fp32 gradient buffer, parameters / moments / the bf16 shadow live in
     flat static buffers (training/optimizers.py) - every pointer a kernel sees is stable;
   * the weight-normalised working weights are rebuilt INSIDE the graph (ops._cached runs its makers while capturing);
-  * the learning rate is a device scalar filled before each replay.
+  * the learning rate is computed on the device from the count of applied updates (csrc/optim.hip lr_schedule_kernel).
 
 Inputs: the outputs of the frozen encoders are consumed in place when they are graph-owned static buffers (the
 encoder GraphedCalls; one capture per buffer slot), copied into static buffers otherwise (stand-in encoders of the
@@ -33,13 +33,20 @@ COPY_LIMIT = 256 << 20          # encoder outputs that are not graph-owned are c
 
 
 class StepGraph:
-    def __init__(self, trainer):
+    """Captured decoder steps, one per shape signature.  Real batches vary in shape (the iterator pads to the per-batch
+    maximum): the trainer pads them to a small set of buckets first (Trainer.shape_buckets), a signature is only
+    captured at its `capture_after`-th sighting, at most 2 * graphs.MAX_SIGNATURES captures are kept (least recently
+    used evicted, which releases their activation pools) and the sighting counters themselves are bounded
+    (graphs.SignatureCache)."""
+
+    def __init__(self, trainer, capture_after=None):
         self.tr = trainer
-        self.entries = {}
+        self.cache = graphs.SignatureCache(2 * graphs.MAX_SIGNATURES, capture_after)
+        self.entries = self.cache.entries
         self.replays = 0
 
     def reset(self):
-        self.entries.clear()
+        self.cache.clear()
 
     # ------------------------------------------------------------------ signature
     def _plan(self, batch, enc):
@@ -72,18 +79,18 @@ class StepGraph:
     # ------------------------------------------------------------------ one step
     def run(self, batch, enc, eager_step):
         """-> detached loss, or None when this batch cannot go through a graph (caller runs the eager step).
-        eager_step(batch, enc) is the uncaptured step; it runs once per signature (that call also builds every cache
-        the capture relies on), the graph is recorded right after it and replayed from the next call on."""
+        eager_step(batch, enc) is the uncaptured step; a signature runs eagerly until its capture_after-th sighting
+        (that call also builds every cache the capture relies on), the graph is recorded right after it and replayed
+        from the next call on."""
         plan = self._plan(batch, enc)
         if plan is None:
             return None
         sig, small, big, by_ptr = plan
-        e = self.entries.get(sig)
-        if e is None:
-            ready = sum(1 for v in self.entries.values() if v['state'] == 'ready')
-            e = self.entries[sig] = {'state': 'eager'}
+        e = self.cache.touch(sig)
+        if e['state'] == 'seen':
             loss = eager_step(batch, enc)
-            if ready < 2 * graphs.MAX_SIGNATURES:
+            if self.cache.due(e):
+                self.cache.make_room()
                 self._capture(e, batch, small, big, by_ptr, enc)
             return loss
         if e['state'] != 'ready':

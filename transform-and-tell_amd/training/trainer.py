@@ -27,9 +27,17 @@ class TrainerBase(Registrable):
 
 class Trainer:
     def __init__(self, model, optimizer_cfg=None, no_grad=(r'^resnet', r'^roberta'), device='cuda',
-                 nan_check=False, bucket_mb=256, async_update=None, allreduce_dtype=None, data_parallel=None):
+                 nan_check=False, bucket_mb=256, async_update=None, allreduce_dtype=None, data_parallel=None,
+                 capture_after=None, shape_buckets=(64, 8)):
         """nan_check=True: the reference's host-synchronous NaN test (returns None for a skipped batch, no step graph);
-        the default skips non-finite steps on the device instead (self.skip, skipped_steps())."""
+        the default skips non-finite steps on the device instead (self.skip, skipped_steps()).
+
+        capture_after: sightings of a batch shape before its step / encoder graphs are captured (default
+        graphs.CAPTURE_AFTER = 2; fixed-shape runs pass 1).  shape_buckets = (article, caption): when graphs are in
+        use, article ids are right-padded (pad id) to a multiple of `article` tokens and captions to a multiple of
+        `caption`, faces to 4 and objects to 64 NaN rows - a handful of shapes instead of one per batch.  Padding is
+        invisible to the loss: padded keys are masked in every attention, padded targets are ignore_index, the
+        DynamicConv is causal.  None: leave batches as the iterator made them."""
         import torch.distributed as dist
         # data_parallel=False: a single-process trainer even though a process group exists (equivalence tests)
         self.dist = dist if (dist.is_available() and dist.is_initialized() and data_parallel is not False) else None
@@ -57,10 +65,10 @@ class Trainer:
                                                  torch.device(device).type == 'cuda' and
                                                  os.environ.get('TELL_ALLREDUCE_FP32') != '1') else torch.float32
         self.allreduce_dtype, self._wire = allreduce_dtype, None
-        if self.dp and self.rank:
+        if self.dp:
             # every rank draws its own dropout masks: the counter-hash seed is process-global with the same default on
-            # all ranks (runtime.py); offset it once here instead of relying on every caller to do so
-            rt.manual_seed(rt.seed() + 0x9E3779B1 * self.rank, rt._state['salt'])
+            # all ranks; the rank is mixed in where the seed is READ (runtime.seed), not written into the global seed
+            rt.set_rank(self.rank)
         if self.dp:                           # identical initial weights on every rank
             self.dist.broadcast(self.flat.flat, src=0)
             self.flat.refresh_shadow()
@@ -87,7 +95,10 @@ class Trainer:
         # skip of a NaN batch (:225-227) and apex O2's overflow skip without a host synchronisation
         self.skip = torch.zeros(2, dtype=torch.int32, device=device) if on_gpu else None
         from .step_graph import StepGraph
-        self.step_graph = StepGraph(self) if on_gpu else None
+        self.step_graph = StepGraph(self, capture_after) if on_gpu else None
+        self.shape_buckets = tuple(shape_buckets) if shape_buckets else None
+        if capture_after is not None and hasattr(model, 'set_capture_after'):
+            model.set_capture_after(capture_after)                 # the encoder graphs follow the same policy
         self.bucketed_reduces = 0
         self._test_reduce_scale = None              # tests: emulate world_size 2 with identical ranks (x2 after a reduce)
         # The bucketed exchange needs Python inside backward, i.e. the eager schedule: it is used when the step graph is
@@ -147,9 +158,48 @@ class Trainer:
             return pre[1]           # (stale: other encode() / generate() calls in between reused the graph's buffers)
         return None
 
+    def _bucketed(self, batch):
+        """The batch padded to the shape buckets (see __init__); a batch that already fits is returned as it is."""
+        from . import step_graph as _sg
+        from .. import graphs
+        if self.shape_buckets is None or self.step_graph is None or not (_sg.ENABLED and graphs.ENABLED):
+            return batch
+        idx = getattr(self.model, 'index', 'roberta')
+        pad = int(getattr(self.model, 'padding_idx', 1))
+        out = None
+
+        def grow(t, dim, n, value):
+            shape = list(t.shape)
+            shape[dim] = n - t.shape[dim]
+            return torch.cat([t, t.new_full(shape, value)], dim=dim)
+        # a caption of T + 1 tokens makes T decoder positions: T is what gets bucketed
+        for key, mult, extra in (('context', self.shape_buckets[0], 0), ('caption', self.shape_buckets[1], 1)):
+            field = batch.get(key)
+            ids = field.get(idx) if isinstance(field, dict) else None
+            if not (torch.is_tensor(ids) and ids.is_cuda and ids.dim() == 2):
+                continue
+            n = -(-(ids.shape[1] - extra) // mult) * mult + extra
+            if n != ids.shape[1]:
+                out = dict(batch) if out is None else out
+                f = dict(field)
+                f[idx] = grow(ids, 1, n, pad)
+                m = f.get(idx + '_copy_masks')
+                if torch.is_tensor(m) and m.dim() == 2 and m.shape[1] == ids.shape[1]:
+                    f[idx + '_copy_masks'] = grow(m, 1, n, -1)
+                out[key] = f
+        for key, rows in (('face_embeds', 4), ('obj_embeds', 64)):
+            t = batch.get(key)
+            if torch.is_tensor(t) and t.is_cuda and t.dim() == 3 and t.shape[2] > 0 and t.shape[1] < rows:
+                out = dict(batch) if out is None else out
+                out[key] = grow(t, 1, rows, float('nan'))
+        return batch if out is None else out
+
     def _train_one_batch(self, batch, next_batch=None):
         if not self.model.training:              # (recursing through ~650 modules costs 2.5 ms of host time)
             self.model.train()                   # (:214 zero_grad: done right after the previous update)
+        batch = self._bucketed(batch)
+        if next_batch is not None:
+            next_batch = self._bucketed(next_batch)
         enc = None
         if hasattr(self.model, 'encode') and torch.is_tensor(batch.get('image')) and batch['image'].is_cuda:
             enc = self._encoded_for(batch)
