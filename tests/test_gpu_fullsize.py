@@ -227,3 +227,107 @@ def test_full_size_greedy_decode_bit_exact_fp32_and_bf16_agreement():
           % (results[torch.float32], results[torch.bfloat16]))
     assert results[torch.float32] == 1.0
     assert results[torch.bfloat16] >= 0.9, results
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# The shapes bench.py times, through the captured step graph.
+# B = 4 above runs the per-token GEMMs at M = 128 rows (register-staged 64x64 kernel); at B = 32 / 16 they have
+# M = 1024 / 512 rows: the direct-to-LDS 64x64 / 128x128 kernels, the grouped query / output projections, the grouped
+# weight-gradient launches with 1024-row reductions, the 256x256 ping-pong kernel for the article K|V projection (B = 32).
+# --------------------------------------------------------------------------------------------------------------------
+class _StandInRoberta(torch.nn.Module):
+    """Three 'hidden states' looked up from a table: the article encoder as far as the decoder half is concerned."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(3)
+        self.register_buffer('tab', torch.randn(3, 64, 1024, generator=g) * 0.5)
+
+    def extract_features(self, ids, return_all_hiddens=False):
+        import tell_amd
+        out = self.tab[:, ids % 64]
+        if out.is_cuda:
+            return out.to(tell_amd.compute_dtype())
+        return list(out)
+
+
+class _StandInResnet(torch.nn.Module):
+    def __init__(self, nhwc):
+        super().__init__()
+        g = torch.Generator().manual_seed(4)
+        self.register_buffer('proj', torch.randn(2048, 3, generator=g) * 0.3)
+        self.nhwc = nhwc
+
+    def forward(self, image):
+        import tell_amd
+        f = torch.relu(torch.einsum('oc,bchw->bohw', self.proj, torch.nn.functional.avg_pool2d(image, 32)))
+        if not self.nhwc:
+            return f
+        return f.permute(0, 2, 3, 1).reshape(f.shape[0], 49, 2048).to(tell_amd.compute_dtype()).contiguous()
+
+
+@pytest.mark.parametrize('kind,batch', [('faces_objects', 32), ('flattened', 16)])
+def test_bench_shape_step_through_the_step_graph_matches_oracle(kind, batch):
+    """BASELINE configs[2] (4 contexts, B = 32) and configs[1] (2 contexts, B = 16) at full decoder size, 512-token
+    articles, 33-token captions, bf16: one optimisation step's decoder half - loss and EVERY gradient tensor (decoder
+    and the RoBERTa layer-mix weights) - as the captured step graph REPLAYS it (training/step_graph.py), against the
+    CPU oracle on the same batch; reference: decoder_faces_objects.py:255-365, transformer_faces_objects.py:67-140.
+    Bounds as in the B = 4 test: each gradient within BF16_VS_AUTOCAST x the error the oracle itself shows under CPU
+    bf16 autocast on this batch.  (The encoders are table look-ups here; their own bench-size parity lives in
+    test_gpu_encoders.py.)"""
+    import tell_amd
+    from oracle.build import build_model as obuild
+    from tell_amd.build import build_model
+    from tell_amd.data import synthetic_batch
+    from tell_amd.training import Trainer
+    fo = kind == 'faces_objects'
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(0)
+    gpu = build_model(kind, _StandInResnet(True), _StandInRoberta(), n_bert_layers=3)
+    _no_dropout(gpu)
+    cpu = obuild(kind, _StandInResnet(False), _StandInRoberta(), n_bert_layers=3).train()
+    cpu.load_state_dict({k: v for k, v in gpu.state_dict().items() if k in cpu.state_dict()}, strict=False)
+    _no_dropout(cpu)
+    bt = synthetic_batch(B=batch, article_len=512, caption_len=33, faces_objects=fo, seed=77, variable=True)
+    clone = lambda x: {k: (dict(v) if isinstance(v, dict) else v.clone()) for k, v in x.items()}      # noqa: E731
+    # ---- oracle: fp32, then the bf16-autocast yardstick
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ref = cpu(**clone(bt))
+    ref['loss'].backward()
+    want = {k: p.grad.detach().clone() for k, p in cpu.named_parameters() if p.grad is not None}
+    cpu.zero_grad(set_to_none=True)
+    with torch.autocast('cpu', dtype=torch.bfloat16):
+        ref16 = cpu(**clone(bt))
+    ref16['loss'].float().backward()
+    yard = {k: _rel(p.grad, want[k]) for k, p in cpu.named_parameters()
+            if p.grad is not None and want[k].norm().item() >= 1e-12}
+    # ---- HIP: eager step (records the graph), then the REPLAY whose gradients are compared
+    tr = Trainer(gpu, dict(lr=0.0, warmup=-1, t_total=-1), device=DEV, capture_after=1)
+    tr.defer_update = True
+    dev = {k: ({kk: vv.to(DEV) for kk, vv in v.items()} if isinstance(v, dict) else v.to(DEV)) for k, v in bt.items()}
+    l0 = float(tr.train_one_batch(clone(dev)))
+    tr.flat.zero_grad()
+    loss = float(tr.train_one_batch(clone(dev)))
+    torch.cuda.synchronize()
+    e = next(iter(tr.step_graph.entries.values()))
+    assert e['state'] == 'ready' and tr.step_graph.replays == 1, e.get('error')
+    assert abs(loss - l0) <= 1e-5 * abs(l0), (loss, l0)                    # eager and replay run the same kernels
+    assert abs(loss - float(ref['loss'])) <= BF16_LOSS * abs(float(ref['loss'])), (loss, float(ref['loss']))
+    assert int(e['sample_size']) == int(ref['sample_size'])
+    pd = dict(gpu.named_parameters())
+    report, worst = [], 0.0
+    for k, gref in want.items():
+        g = pd[k].grad
+        assert g is not None, k
+        if gref.norm().item() < 1e-12:
+            assert g.float().abs().max().item() <= 1e-6, k
+            continue
+        r = _rel(g, gref)
+        report.append((r, k))
+        worst = max(worst, r)
+        assert r <= BF16_VS_AUTOCAST * yard[k] + BF16_FLOOR, (k, r, yard[k])
+    report.sort(reverse=True)
+    print('\n%s B=%d through the step graph: loss rel %.2e; %d gradient tensors, median %.2e, worst %s' % (
+        kind, batch, abs(loss - float(ref['loss'])) / abs(float(ref['loss'])), len(report), report[len(report) // 2][0],
+        ', '.join('%s %.2e (autocast %.2e)' % (k.replace('decoder.', ''), r, yard[k]) for r, k in report[:4])))
+    assert worst <= BF16_CEIL, report[:6]

@@ -4,6 +4,7 @@ concatenated batch ("N-GPU result == 1-GPU result on the concatena
 second copy of the model single-process on the concatenation of both ranks' batches; after every step the data-parallel
 weights must equal the single-process weights.  Runs the eager schedule (bucketed exchange during backward, loss
 weighted before backward) or the step-graph schedule (TELL_STEP_GRAPH, gradient weighted on the way to the wire).
+DP_EQ_WIRE=bf16 + DP_EQ_TOL bound the drift of the bf16 wire format.
 launch: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29660 tools/dp_equivalence.py"""
 import copy, os, sys, torch, torch.distributed as dist
 sys.path.insert(0, '.')
@@ -25,7 +26,10 @@ for m in model.modules():
         m.dropout = 0.0
 single = copy.deepcopy(model) if rank == 0 else None
 ocfg = dict(lr=5e-3, warmup=0.5, t_total=8, b1=0.9, b2=0.98, e=1e-6, weight_decay=1e-5, max_grad_norm=0.1)
-tr = Trainer(model, dict(ocfg), device='cuda')
+# DP_EQ_WIRE=bf16: the production wire format (gradients rounded to bf16 for the exchange, BertAdam reads the reduced
+# bf16 buffer) while everything else stays fp32 - the drift against the single process is then the wire's rounding alone
+wire = torch.bfloat16 if os.environ.get('DP_EQ_WIRE') == 'bf16' else None
+tr = Trainer(model, dict(ocfg), device='cuda', allreduce_dtype=wire)
 assert tr.dp and tr.world == 2
 ts = Trainer(single, dict(ocfg), device='cuda', data_parallel=False) if rank == 0 else None
 STEPS = int(os.environ.get('DP_EQ_STEPS', '5'))

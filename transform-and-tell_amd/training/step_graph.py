@@ -73,7 +73,7 @@ class StepGraph:
                 small[k] = batch[k]
         sig = (tuple((k, tuple(v.shape), v.dtype) for k, v in small.items()),
                tuple((tuple(t.shape), t.dtype, t.data_ptr() if by_ptr else 0) for t in big),
-               by_ptr, rt.compute_dtype(), tr.dp, ops._WGRAD['enabled'])
+               by_ptr, rt.compute_dtype(), tr.dp, ops._WGRAD['enabled'], tr.defer_update)
         return sig, small, big, by_ptr
 
     # ------------------------------------------------------------------ one step
@@ -113,7 +113,7 @@ class StepGraph:
         model.n_batches += 1
         if tr.dp:
             tr._update(n_local=e['sample_size'])
-        else:
+        elif not tr.defer_update:
             tr.optimizer.advance()
         return e['loss'].clone()
 
@@ -144,7 +144,7 @@ class StepGraph:
                     loss = out['loss']
                     tr._flag_loss(loss)
                     tr._backward(loss)
-                    if not tr.dp:
+                    if not tr.dp and not tr.defer_update:
                         tr.optimizer.launch(grad_scale=1.0, zero_grad=True, skip=tr.skip)
             e.update(state='ready', graph=g, small=st_small, big=st_big, counter=counter, replays=1,
                      loss=loss.detach(), sample_size=out['sample_size'])

@@ -90,6 +90,11 @@ class Trainer:
         # adaptive tables, 35 % of the bytes) is exchanged after backward.
         self._ranges, self._reduced, self._pending, self._in_backward = {}, [], [], False
         self._capturing = False
+        # defer_update = True: a step stops after backward - gradients stay in flat.grad (they accumulate over calls
+        # until the caller runs optimizer.step(zero_grad=True) or flat.zero_grad()); the captured step graph then ends
+        # after backward as well.  Gradient accumulation over micro-batches, and how the parity tests read the
+        # gradients a graph REPLAY produced.
+        self.defer_update = False
         on_gpu = torch.device(device).type == 'cuda'
         # device-side NaN / Inf skip: [flag, count] read by the optimizer kernel (csrc/optim.hip) - the reference's
         # skip of a NaN batch (:225-227) and apex O2's overflow skip without a host synchronisation
@@ -284,6 +289,8 @@ class Trainer:
         """Gradient exchange (data parallel) + BertAdam + gradient zeroing.  n_local: this rank's token count when
         the loss was NOT weighted before backward (graph replay, unbucketed eager): the weight n_local * world /
         n_global is then applied to the gradient on its way to the wire."""
+        if self.defer_update:
+            return
         if self.dp:
             scale = None
             if n_local is not None:
