@@ -68,7 +68,7 @@ int tell_gemm_ts_next(void* ts, tell_stream_t stream);
  * softmax.py:24-40,182-189 (head / tail projections), adaptive.py:73 (band
  * projections) and the convolutions of resnet.py:92-108 (NHWC rows).
  * bias_mode 0 none | 1 bias[n] | 2 bias[m];  act 0 none | 1 relu | 2 gelu(erf) |
- * 3 multiply by (aux[m,n] > 0) (relu backward);  m_dev: optional device row count. */
+ * 3 multiply by (aux[m,n] > 0) (relu backward) | 4 relu(result + aux[m,n]) (residual block);  m_dev: optional device row count. */
 int tell_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                  int in_dtype, int out_dtype, const float* bias, int bias_mode, int act, const void* aux,
                  float alpha, int accumulate, const int* m_dev, tell_stream_t stream);
@@ -330,6 +330,21 @@ int tell_conv_bn_stats(const void* x, const void* w, void* y, int B, int H, int 
                        int pad, int OH, int OW, int Cout, float eps, float momentum, float* mean, float* invstd,
                        float* running_mean, float* running_var, float* workspace, const void* zero_page,
                        tell_stream_t stream);
+/* conv -> train-mode BatchNorm (-> + residual) (-> ReLU) of a Bottleneck (resnet.py:92-108 via torchvision; the frozen
+ * trunk runs in train mode, callback_apex_trainer.py:259): the implicit-GEMM convolution of tell_conv_bn_stats, then the
+ * combine of the per-row-chunk statistics AND the normalisation as ONE launch (two when the activation has more than
+ * 128 row chunks).  y [B*OH*OW, Cout] bf16 receives the finished activation; residual (same shape) or NULL;
+ * running_mean / running_var get the momentum update.  workspace: 2 * ceil(M / 64) * Cout + 2 * Cout floats. */
+int tell_conv_bn_act(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int KH, int KW, int stride,
+                     int pad, int OH, int OW, int Cout, float eps, float momentum, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, const void* residual, int relu, float* workspace,
+                     const void* zero_page, tell_stream_t stream);
+/* the same block with the trunk in eval mode (running statistics): BatchNorm folded into the convolution by the host
+ * (w' = w * gamma / sqrt(running_var + eps), bias = beta - running_mean * that): y = act(conv(x, w') + bias [+ residual])
+ * in ONE launch; relu = 1 with a residual gives relu(conv + bias + residual). */
+int tell_conv_bias_act(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int KH, int KW, int stride,
+                       int pad, int OH, int OW, int Cout, const float* bias, const void* residual, int relu,
+                       const void* zero_page, tell_stream_t stream);
 int tell_im2col(const void* x, void* col, int B, int H, int W, int Cin, int KH, int KW, int stride, int pad,
                 int OH, int OW, int Kp, int dtype, tell_stream_t stream);
 /* im2col of y = relu(BatchNorm(x)): the producer's normalisation is applied while gathering (resnet.py Bottleneck:

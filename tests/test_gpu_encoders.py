@@ -53,6 +53,55 @@ def test_resnet_matches_oracle(dtype, train):
         assert r2 < (1e-4 if dtype == torch.float32 else 3e-2) and r3 < (1e-4 if dtype == torch.float32 else 3e-2)
 
 
+def test_resnet_eval_folds_batchnorm_and_refolds_after_a_train_mode_pass():
+    """eval mode (resnet.py:92-108 under model.eval(), generation): every BatchNorm is folded into its convolution
+    (csrc tell_conv_bias_act / act 4 epilogue - no bn_* launch in the pass); a train-mode pass updates the running
+    statistics from inside kernels, so the next eval pass must fold again (models/resnet.py _STATS_EPOCH), including a
+    graph-captured eval pass."""
+    import tell_amd
+    from oracle.encoders import ResNetFeatureExtractor as ORes
+    from tell_amd import graphs, hip
+    from tell_amd.models.resnet import ResNetFeatureExtractor as HRes
+    for dtype, width in ((torch.float32, 16), (torch.bfloat16, 64)):
+        tell_amd.set_compute_dtype(dtype)
+        torch.manual_seed(3)
+        ora = ORes((2, 1, 1, 1), width=width)
+        _randomise_bn(ora, seed=4)
+        hipm = HRes((2, 1, 1, 1), width=width)
+        hipm.load_state_dict(ora.state_dict())
+        hipm.to(DEV)
+        tol = 2e-4 if dtype == torch.float32 else 6e-2
+        img = torch.randn(3, 3, 96, 96)
+        launched = []
+        real = hip.call
+
+        def spy(name, *a):
+            launched.append(name)
+            return real(name, *a)
+        g = graphs.GraphedCall(hipm, 'eval-trunk', capture_after=1)
+        for rnd in range(2):
+            ora.eval()
+            hipm.eval()
+            with torch.no_grad():
+                ref = ora(img).permute(0, 2, 3, 1).reshape(3, -1, ora.fc.in_features)
+            from tell_amd.models import resnet as R
+            R.call = spy
+            try:
+                out = hipm(img.to(DEV))
+            finally:
+                R.call = real
+            assert not [n for n in launched if n.startswith('tell_bn_')], launched
+            assert rel(out, ref) < tol, (rnd, rel(out, ref))
+            for _ in range(2):                                  # eager + capture, then a replay of the folded pass
+                got = g(img.to(DEV), key=('eval', dtype, R.stats_epoch()))
+                assert rel(got, ref) < tol, rnd
+            ora.train()
+            hipm.train()
+            with torch.no_grad():
+                ora(img * 1.5 + 0.3)
+            hipm((img * 1.5 + 0.3).to(DEV))                    # running statistics move on both sides
+
+
 def _randomise_bn(net, seed=1):
     g = torch.Generator().manual_seed(seed)
     for m in net.modules():

@@ -117,6 +117,11 @@ def test_gemm_nt(dtype, M, N, K):
     acc = torch.ones(M, N, device=DEV)
     ops.gemm(ad, bd, out=acc, accumulate=True)
     close(acc, ref + 1, dtype, scale=math.sqrt(K))
+    # act 4: relu(result + residual) - the tail of a residual block with its BatchNorm folded into the weights
+    res = torch.randn(M, N, generator=g)
+    resd = res.to(DEV, dtype)
+    out5 = ops.gemm(ad, bd, bias=bias.to(DEV), bias_mode=1, act=4, aux=resd)
+    close(out5, torch.relu(ref + bias + resd.float().cpu()), dtype, scale=math.sqrt(K))
     mdev = torch.tensor([M // 2], dtype=torch.int32, device=DEV)
     part = torch.full((M, N), 7.0, device=DEV)
     ops.gemm(ad, bd, out=part, m_dev=mdev)

@@ -358,6 +358,94 @@ extern "C" int tell_bn_apply(const void* x, const float* mean, const float* invs
   return tell_check_launch("bn_apply");
 }
 
+// Train-mode BatchNorm behind a convolution whose GEMM epilogue left per-row-chunk statistics (pmean / pm2: [n_chunks][C],
+// csrc/gemm.hip staged_store_stats): the Chan combine of the chunks AND the normalisation (+ residual) (+ ReLU) in ONE
+// launch.  A workgroup owns 64 channels x a slab of rows; its prologue merges the n_chunks partials of its 64 channels
+// (thread = channel x one of 4 chunk strides, then a fixed-order fold through LDS: deterministic), which costs
+// n_chunks x 512 bytes of L2 reads per workgroup - used for n_chunks <= 128 (layer3 / layer4 of the trunk at B = 32:
+// 25-98 chunks), where that is a fraction of the slab itself; beyond, the combine stays a launch of its own.
+// The workgroups of the first row slab also write the running statistics (momentum update, unbiased variance).
+__global__ __launch_bounds__(256) void bn_finish_apply_kernel(const float* __restrict__ pmean, const float* __restrict__ pm2,
+                                                              long M, int C, int n_chunks, int rows_per_chunk, float eps,
+                                                              float momentum, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var,
+                                                              const uint16_t* __restrict__ residual, uint16_t* __restrict__ y,
+                                                              int relu, int rows_per_block) {
+  __shared__ float smu[4][64], sm2[4][64], s_mean[64], s_scale[64], s_beta[64];
+  const int tid = threadIdx.x, cl = tid & 63, g = tid >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  // Combine of the chunks in two passes of INDEPENDENT loads (the sequential Chan update - a division and a dependent
+  // load per chunk - cost 7 us of serial round trips per workgroup): the global mean from the chunk means, then
+  // M2 = sum_k (M2_k + n_k (mean_k - mean)^2), both folded over the 4 chunk strides in a fixed order (deterministic).
+  const float n_last = (float)(M - (long)(n_chunks - 1) * rows_per_chunk), n_full = (float)rows_per_chunk;
+  {
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = g; k < n_chunks; k += 4) acc += (k == n_chunks - 1 ? n_last : n_full) * pmean[(long)k * C + c];
+    smu[g][cl] = acc;
+  }
+  __syncthreads();
+  const float mu = ((smu[0][cl] + smu[1][cl]) + (smu[2][cl] + smu[3][cl])) / (float)M;
+  {
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = g; k < n_chunks; k += 4) {
+      const float d = pmean[(long)k * C + c] - mu;
+      acc += pm2[(long)k * C + c] + (k == n_chunks - 1 ? n_last : n_full) * d * d;
+    }
+    sm2[g][cl] = acc;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const float m2 = (sm2[0][cl] + sm2[1][cl]) + (sm2[2][cl] + sm2[3][cl]), n = (float)M;
+    const float var = m2 / n;
+    s_mean[cl] = mu;
+    s_scale[cl] = rsqrtf(var + eps) * gamma[c];
+    s_beta[cl] = beta[c];
+    if (blockIdx.y == 0 && running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
+    }
+  }
+  __syncthreads();
+  const int o = tid & 7, rl = tid >> 3;                       // 8 channels (16 bytes) per thread, 32 rows per pass
+  float mean8[8], scale8[8], beta8[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { mean8[k] = s_mean[o * 8 + k]; scale8[k] = s_scale[o * 8 + k]; beta8[k] = s_beta[o * 8 + k]; }
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  const long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  const long col = (long)blockIdx.x * 64 + o * 8;
+  for (long r = r0 + rl; r < r1; r += 32) {
+    float v[8], rs[8];
+    unpack16(*reinterpret_cast<const uint4*>(y + r * C + col), v, (const uint16_t*)nullptr);
+    if (residual) unpack16(*reinterpret_cast<const uint4*>(residual + r * C + col), rs, (const uint16_t*)nullptr);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float t = (v[k] - mean8[k]) * scale8[k] + beta8[k];
+      if (residual) t += rs[k];
+      v[k] = relu ? fmaxf(t, 0.f) : t;
+    }
+    *reinterpret_cast<uint4*>(y + r * C + col) = pack16(v, (const uint16_t*)nullptr);
+  }
+}
+// -> TELL_OK after launching, or 1 when the shape is not one the fused kernel takes (the caller runs finish + apply)
+int tell_bn_finish_apply_launch(const float* pmean, const float* pm2, long M, int C, int n_chunks, int rows_per_chunk,
+                                float eps, float momentum, const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, const void* residual, void* y, int relu, hipStream_t stream) {
+  if (n_chunks > 128 || C % 64 != 0 || ((uintptr_t)y & 15) != 0 || ((uintptr_t)residual & 15) != 0) return 1;
+  const int slabs = C / 64;
+  // ~512-1024 workgroups, at least 32 rows (one pass) each
+  long per = (M * slabs + 767) / 768;
+  per = (per + 31) / 32 * 32;
+  if (per < 32) per = 32;
+  const unsigned gy = (unsigned)((M + per - 1) / per);
+  hipLaunchKernelGGL(bn_finish_apply_kernel, dim3(slabs, gy), dim3(256), 0, stream, pmean, pm2, M, C, n_chunks,
+                     rows_per_chunk, eps, momentum, gamma, beta, running_mean, running_var, (const uint16_t*)residual,
+                     (uint16_t*)y, relu, (int)per);
+  return tell_check_launch("bn_finish_apply");
+}
+
 // ToTensor + Normalize of the readers (nytimes_faces_ner_matched.py:67-69) on the device: uint8 [B,H,W,3] (decoded
 // pixels as the shards store them) -> float32 [B,3,H,W] = (x / 255 - mean[c]) / std[c], the model's `image` input
 __global__ __launch_bounds__(256) void image_normalize_kernel(const uint8_t* __restrict__ x, float* __restrict__ y,

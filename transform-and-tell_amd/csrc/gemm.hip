@@ -29,12 +29,12 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // 16-byte sta
 struct GemmArgs {
   const void* A; const void* B; void* C;
   const float* bias;      // fp32, length N (mode 1) or M (mode 2)
-  const void* aux;        // relu-mask source (same layout/dtype as C) for act==3
+  const void* aux;        // act 3: relu-mask source, act 4: residual added before the relu (same layout/dtype as C)
   const int* m_dev;       // optional device-side effective M (rows >= *m_dev are skipped)
   long lda, ldb, ldc;
   int M, N, K;
   int bias_mode;          // 0 none, 1 per column n, 2 per row m
-  int act;                // 0 none, 1 relu, 2 gelu(erf), 3 multiply by (aux > 0)
+  int act;                // 0 none, 1 relu, 2 gelu(erf), 3 multiply by (aux > 0), 4 relu(result + aux) (residual block)
   int accumulate;         // C = C + result  (beta = 1)
   float alpha;            // result = act((acc + bias) * alpha)
   float* asum;            // K-major A only: asum[m] += asum_scale * sum_k A[k][m]  (bias gradient of a wgrad GEMM)
@@ -191,7 +191,7 @@ __device__ __forceinline__ void gemm_epilogue_act(f32x16 (&acc)[MI][NI], const G
   const OutT* aux = static_cast<const OutT*>(p.aux);
   constexpr uintptr_t AL = 4 * sizeof(OutT) - 1;
   const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & AL) == 0 &&
-                      (ACT != 3 || (reinterpret_cast<uintptr_t>(aux) & AL) == 0);
+                      ((ACT != 3 && ACT != 4) || (reinterpret_cast<uintptr_t>(aux) & AL) == 0);
   f32x4_t bn[NI][4];                                               // per-column bias of this lane's 4-column groups
 #pragma unroll
   for (int j = 0; j < NI; ++j)
@@ -215,13 +215,18 @@ __device__ __forceinline__ void gemm_epilogue_act(f32x16 (&acc)[MI][NI], const G
         f32x4_t v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][4 * g + e] + bn[j][g][e] + bm) * p.alpha;
-        epi_act4<ACT == 3 ? 0 : ACT>(v);
+        epi_act4<(ACT == 3 || ACT == 4) ? 0 : ACT>(v);
         OutT* dst = C + (long)m * p.ldc + n;
         if (vec_ok && n + 3 < N) {
           if constexpr (ACT == 3) {
             const f32x4_t mk = Vec4<OutT>::ld(aux + (long)m * p.ldc + n);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+          }
+          if constexpr (ACT == 4) {
+            const f32x4_t rs = Vec4<OutT>::ld(aux + (long)m * p.ldc + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + rs[e], 0.f);
           }
           if constexpr (std::is_same<OutT, float>::value) {
             if (p.atomic_out) {                                     // block-uniform
@@ -238,6 +243,7 @@ __device__ __forceinline__ void gemm_epilogue_act(f32x16 (&acc)[MI][NI], const G
             if (n + e < N) {
               float x = v[e];
               if constexpr (ACT == 3) x = Elem<OutT>::ld(aux + (long)m * p.ldc + n + e) > 0.f ? x : 0.f;
+              if constexpr (ACT == 4) x = fmaxf(x + Elem<OutT>::ld(aux + (long)m * p.ldc + n + e), 0.f);
               if constexpr (std::is_same<OutT, float>::value) {
                 if (p.atomic_out) { unsafeAtomicAdd(reinterpret_cast<float*>(dst) + e, x); continue; }
               }
@@ -255,6 +261,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmA
     case 1: gemm_epilogue_act<OutT, MI, NI, 1>(acc, p, mw, nw, lane, M, N); break;
     case 2: gemm_epilogue_act<OutT, MI, NI, 2>(acc, p, mw, nw, lane, M, N); break;
     case 3: gemm_epilogue_act<OutT, MI, NI, 3>(acc, p, mw, nw, lane, M, N); break;
+    case 4: gemm_epilogue_act<OutT, MI, NI, 4>(acc, p, mw, nw, lane, M, N); break;
     default: gemm_epilogue_act<OutT, MI, NI, 0>(acc, p, mw, nw, lane, M, N); break;
   }
 }
@@ -283,7 +290,7 @@ __device__ __forceinline__ void glds_store_tile_act(f32x16 (&acc)[MI][NI], const
         f32x4_t v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][4 * g + e] + b4[e] + bm) * p.alpha;
-        epi_act4<ACT>(v);
+        epi_act4<ACT == 4 ? 0 : ACT>(v);
         int ch = col >> 3;
         if constexpr (SWZ) ch ^= row & (CPRW - 1) & 15;
         u32x2 w = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
@@ -297,8 +304,17 @@ __device__ __forceinline__ void glds_store_tile_act(f32x16 (&acc)[MI][NI], const
     const int c = tid + i * NT, row = c / CPRW;
     int ch = c % CPRW;
     const int sch = SWZ ? ch ^ (row & (CPRW - 1) & 15) : ch;
-    *reinterpret_cast<u32x4*>(C + (long)(m0 + row) * p.ldc + n0 + ch * 8) =
-        *reinterpret_cast<const u32x4*>(cs + row * CS + sch * 8);
+    u32x4 o = *reinterpret_cast<const u32x4*>(cs + row * CS + sch * 8);
+    if constexpr (ACT == 4) {                          // relu(tile + residual): the residual arrives as whole 16-byte pieces too
+      const u32x4 r = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(p.aux) + (long)(m0 + row) * p.ldc + n0 + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = fmaxf(__uint_as_float(o[e] << 16) + __uint_as_float(r[e] << 16), 0.f);
+        const float hi = fmaxf(__uint_as_float(o[e] & 0xffff0000u) + __uint_as_float(r[e] & 0xffff0000u), 0.f);
+        o[e] = pack2_bf16(lo, hi);
+      }
+    }
+    *reinterpret_cast<u32x4*>(C + (long)(m0 + row) * p.ldc + n0 + ch * 8) = o;
   }
 }
 template <int BM, int BN, int WM, int WN, int MI, int NI, int CS, int NT, int LAY = 0>
@@ -307,6 +323,7 @@ __device__ __forceinline__ void glds_store_tile(f32x16 (&acc)[MI][NI], const Gem
   switch (p.act) {
     case 1: glds_store_tile_act<BM, BN, WM, WN, MI, NI, CS, NT, 1, LAY>(acc, p, m0, n0, wm, wn, lane, tid, cs); break;
     case 2: glds_store_tile_act<BM, BN, WM, WN, MI, NI, CS, NT, 2, LAY>(acc, p, m0, n0, wm, wn, lane, tid, cs); break;
+    case 4: glds_store_tile_act<BM, BN, WM, WN, MI, NI, CS, NT, 4, LAY>(acc, p, m0, n0, wm, wn, lane, tid, cs); break;
     default: glds_store_tile_act<BM, BN, WM, WN, MI, NI, CS, NT, 0, LAY>(acc, p, m0, n0, wm, wn, lane, tid, cs); break;
   }
 }
@@ -357,13 +374,13 @@ __device__ __forceinline__ void glds_store_tile_f32(f32x16 (&acc)[MI][NI], const
   }
 }
 __device__ __forceinline__ bool glds_fast_tile_f32(const GemmArgs& p, int m0, int n0, int BM, int BN, int M, int N) {
-  return !p.accumulate && !p.atomic_out && p.act != 3 && m0 + BM <= M && n0 + BN <= N && (p.ldc & 3) == 0 &&
+  return !p.accumulate && !p.atomic_out && p.act != 3 && p.act != 4 && m0 + BM <= M && n0 + BN <= N && (p.ldc & 3) == 0 &&
          (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 &&
          (p.bias_mode != 1 || ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0 && (n0 & 3) == 0));
 }
 __device__ __forceinline__ bool glds_fast_tile(const GemmArgs& p, int m0, int n0, int BM, int BN, int M, int N) {
   return !p.accumulate && p.act != 3 && m0 + BM <= M && n0 + BN <= N && (p.ldc & 7) == 0 &&
-         (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 &&
+         (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (p.act != 4 || (reinterpret_cast<uintptr_t>(p.aux) & 15) == 0) &&
          (p.bias_mode != 1 || ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0 && (n0 & 3) == 0));
 }
 
@@ -442,14 +459,33 @@ __device__ __forceinline__ void staged_store_stats(f32x16 (&acc)[MI][NI], const 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-template <typename OutT, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV = false>
+// s_waitcnt vmcnt(n) with a run-time n out of {0, PER, 2 PER, ...}: the count field is an immediate
+template <int PER, int T>
+__device__ __forceinline__ void wait_tiles_in_flight(int t) {
+  if constexpr (T == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    if (t >= T) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER * T) : "memory");
+    else wait_tiles_in_flight<PER, T - 1>(t);
+  }
+}
+
+// NS = number of LDS stages.  NS = 2 keeps ONE K tile in flight while the current one is multiplied - enough when the
+// MFMAs of a tile outlast a DMA round trip (128x64 wave tiles).  The small tiles do not: a 64x64 workgroup (one 32x32
+// MFMA per wave and k-step) spends 128 clk of matrix time per K tile against 500-900 clk of L2 / HBM latency, so with
+// two stages it advances one K tile per round trip (the decoder's M = 1024 GEMMs and the ResNet bottleneck convolutions:
+// 16-64 dependent round trips per launch).  NS > 2 is a ring: NS - 1 tiles in flight, counted vmcnt (a wave waits for
+// its own pieces of tile kt only), ONE raw s_barrier per K tile - after it every wave's pieces of tile kt have landed
+// (RAW) and everyone has finished the MFMAs that read the stage the next issue overwrites (WAR).
+template <typename OutT, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV = false, int NS = 2>
 __device__ __forceinline__ void gemm_nt_glds_body(const GemmArgs& p, const int block, const int n_blocks) {
   constexpr int NW = WAVES_M * WAVES_N, BK = 64;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int IA = BM / 8 / NW, IB = BN / 8 / NW;   // wave-instructions (1 KiB each) per wave per tile
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 32, NI = WN / 32;
   static_assert(IA >= 1 && IB >= 1, "tile too small for the wave count");
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+  static_assert(NS >= 2 && (IA + IB) * (NS - 2) <= 48, "ring depth against the 6-bit vmcnt field");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
 
   gemm_ts_enter(p);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -561,15 +597,22 @@ __device__ __forceinline__ void gemm_nt_glds_body(const GemmArgs& p, const int b
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = K / BK;
-  issue(0, 0, -1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) issue(s, s, -1);
+  int st = 0, nst = NS - 1;                              // stage of tile kt / of tile kt + NS - 1
   for (int kt = 0; kt < nk; ++kt) {
-    const int st = kt & 1;
-    // tile kt+1 streams in under the MFMAs below, a quarter of its DMA instructions per k-substep: the LDS port
+    // tile kt has landed once at most min(NS - 2, tiles left) younger tiles of THIS wave are still in flight
+    {
+      const int left = nk - 1 - kt;
+      wait_tiles_in_flight<IA + IB, NS - 2>(left < NS - 2 ? left : NS - 2);
+    }
+    __builtin_amdgcn_s_barrier();                        // (raw: __syncthreads() would drain the DMA queue, vmcnt(0))
+    __builtin_amdgcn_sched_barrier(0);
+    // tile kt+NS-1 streams in under the MFMAs below, a quarter of its DMA instructions per k-substep: the LDS port
     // is shared by these writes and the fragment reads, and a burst of 8 at the top of the iteration stalls both
     // (probe: tools/probes/gemm_ablate.hip, +3..9 %)
-    const bool more = kt + 1 < nk;
+    const bool more = kt + NS - 1 < nk;
     const unsigned char* ta = smem + st * STAGE;
     const unsigned char* tb = ta + A_BYTES;
     // Large wave tiles (128x64: 8 MFMAs per k-substep): fragments of substep ks+1 are read into a second
@@ -595,7 +638,7 @@ __device__ __forceinline__ void gemm_nt_glds_body(const GemmArgs& p, const int b
       } else {
         ldfrag(ks, ks & 1);
       }
-      if (more) issue(kt + 1, st ^ 1, ks);
+      if (more) issue(kt + NS - 1, nst, ks);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -603,9 +646,10 @@ __device__ __forceinline__ void gemm_nt_glds_body(const GemmArgs& p, const int b
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ks & 1][j], a[ks & 1][i], acc[i][j], 0, 0, 0);
       if constexpr (PREFETCH) __builtin_amdgcn_sched_barrier(0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMA pieces of tile kt+1 have landed
-    __syncthreads();                                     // everyone's have, and buffer `st` is free again
+    st = st + 1 == NS ? 0 : st + 1;
+    nst = nst + 1 == NS ? 0 : nst + 1;
   }
+  __syncthreads();                                       // every wave is done with the stages: they become the staging area
   // ---- epilogue.  Full interior bf16 tiles go through LDS (the tile buffers are free now).
   if constexpr (sizeof(OutT) == 2 && BM * (BN + 8) * 2 + 64 * NW * 4 <= 2 * STAGE && (64 * NW) % BN == 0) {
     if (p.stat_mean) {                                   // block-uniform: conv + BatchNorm statistics
@@ -636,9 +680,9 @@ __device__ __forceinline__ void gemm_nt_glds_body(const GemmArgs& p, const int b
   gemm_epilogue<OutT, MI, NI>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, M, N);
   gemm_ts_exit(p);
 }
-template <typename OutT, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV = false>
+template <typename OutT, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV = false, int NS = 2>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_glds_kernel(GemmArgs p) {
-  gemm_nt_glds_body<OutT, BM, BN, WAVES_M, WAVES_N, CONV>(p, blockIdx.x, gridDim.x);
+  gemm_nt_glds_body<OutT, BM, BN, WAVES_M, WAVES_N, CONV, NS>(p, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------- 256x256 ping-pong kernel (bf16, full tiles only)
@@ -1369,11 +1413,22 @@ __global__ __launch_bounds__(512, 1) void gemm_tx_group_wide_kernel(GemmGroup g)
   const GemmArgs p = group_args(g.pr[i]);
   gemm_tx_body<OutT, 256, 128, 4, 2, TA, TB, 2>(p, blockIdx.x - g.start[i], g.start[i + 1] - g.start[i], 0, 1);
 }
-template <typename OutT, int BM, int BN>
+template <typename OutT, int BM, int BN, int NS = 2>
 __global__ __launch_bounds__(256) void gemm_nt_group_kernel(GemmGroup g) {
   const int i = group_find(g, blockIdx.x);
   const GemmArgs p = group_args(g.pr[i]);
-  gemm_nt_glds_body<OutT, BM, BN, 2, 2, false>(p, blockIdx.x - g.start[i], g.start[i + 1] - g.start[i]);
+  gemm_nt_glds_body<OutT, BM, BN, 2, 2, false, NS>(p, blockIdx.x - g.start[i], g.start[i + 1] - g.start[i]);
+}
+// LDS stages of the 64x64 direct-to-LDS tile (see gemm_nt_glds_body): 4 = three K tiles in flight (64 KB of LDS, two
+// workgroups per CU), 2 = the two-stage form (32 KB, five per CU).  The ring pays where the launch is a short chain of
+// round trips - at most two workgroups per CU and a reduction of >= 8 K tiles (tools/bench_conv.py, MI355X, B = 32:
+// layer4 conv1 24.5 -> 18.4 us, conv2 53.3 -> 38.3; ResNet-152 5.78 -> 5.50 ms) - and LOSES where many workgroups per
+// CU already hide each other's latency (layer1 conv3, K = 64: 43 -> 61 us; layer3 conv3, K = 256: 18.0 -> 24.1).
+// TELL_GEMM_RING = 2 / 3 / 4 forces a depth everywhere (A/B aid).
+static int small_ring_stages(long tiles64, int K) {
+  static const int v = getenv("TELL_GEMM_RING") ? atoi(getenv("TELL_GEMM_RING")) : 0;
+  if (v) return v;
+  return (tiles64 <= 512 && K >= 512) ? 4 : 2;
 }
 
 template <typename OutT, bool TA, bool TB>
@@ -1438,7 +1493,7 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
         return g_gemm_plan ? TELL_OK : tell_check_launch("gemm_nt_glds");
       }
       if constexpr (std::is_same<OutT, uint16_t>::value) {
-        const bool full = a.M % 256 == 0 && a.N % 256 == 0 && !a.accumulate && a.act != 3 && !a.m_dev && !a.stat_mean &&
+        const bool full = a.M % 256 == 0 && a.N % 256 == 0 && !a.accumulate && a.act != 3 && a.act != 4 && !a.m_dev && !a.stat_mean &&
                           (a.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0 &&
                           (a.bias_mode != 1 || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
         // ping-pong 256x256: whole rounds of full tiles (fc1 of RoBERTa: 878 vs 838 TFLOP/s, 4096^3: 1171 vs 1022,
@@ -1483,7 +1538,13 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
         (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0 &&
         (a.lda & 7) == 0 && (a.ldb & 7) == 0) {
       *bm_used = 64;
-      TELL_GEMM_LAUNCH(gemm_label("gemm_nt_glds_kernel", -1, sizeof(OutT) == 2, 64, 64), (gemm_nt_glds_kernel<OutT, 64, 64, 2, 2>), dim3((unsigned)tiles(64, 64)), dim3(256));
+      const int ring = small_ring_stages(tiles(64, 64), a.K);
+      if (ring == 4)
+        TELL_GEMM_LAUNCH(gemm_label("gemm_nt_glds_kernel", -1, sizeof(OutT) == 2, 64, 64), (gemm_nt_glds_kernel<OutT, 64, 64, 2, 2, false, 4>), dim3((unsigned)tiles(64, 64)), dim3(256));
+      else if (ring == 3)
+        TELL_GEMM_LAUNCH(gemm_label("gemm_nt_glds_kernel", -1, sizeof(OutT) == 2, 64, 64), (gemm_nt_glds_kernel<OutT, 64, 64, 2, 2, false, 3>), dim3((unsigned)tiles(64, 64)), dim3(256));
+      else
+        TELL_GEMM_LAUNCH(gemm_label("gemm_nt_glds_kernel", -1, sizeof(OutT) == 2, 64, 64), (gemm_nt_glds_kernel<OutT, 64, 64, 2, 2>), dim3((unsigned)tiles(64, 64)), dim3(256));
       return g_gemm_plan ? TELL_OK : tell_check_launch("gemm_nt_glds");
     }
   }
@@ -1520,7 +1581,7 @@ extern "C" int tell_gemm_nt(const void* A, long lda, const void* B, long ldb, vo
                "gemm_nt: K, lda, ldb must be multiples of one 16-byte chunk");
   TELL_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "gemm_nt: A/B must be 16-byte aligned");
   TELL_REQUIRE(bias_mode == 0 || bias != nullptr, "gemm_nt: bias_mode set without bias");
-  TELL_REQUIRE(act != 3 || aux != nullptr, "gemm_nt: act=3 needs aux");
+  TELL_REQUIRE((act != 3 && act != 4) || aux != nullptr, "gemm_nt: act=3 / act=4 need aux");
   GemmArgs a;
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux; a.m_dev = m_dev;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
@@ -1663,7 +1724,15 @@ extern "C" int tell_gemm_grouped(int n, const tell_gemm_problem* pr, hipStream_t
       v[j + 1] = x;
     }
   }
-#define GROUP_RUN(B, KERN, BM, BN) if (cnt[B] && !rc) rc = launch_group(KERN, BM, BN, pr, ids + (B) * n, cnt[B], stream);
+#define GROUP_RUN(B, KERN, BM, BN) if (cnt[B] && !rc) { rc = launch_group(KERN, BM, BN, pr, ids + (B) * n, cnt[B], stream); cnt[B] = 0; }
+  {
+    long t0 = 0, t2 = 0;
+    int k0 = 1 << 30, k2 = 1 << 30;
+    for (int i = 0; i < cnt[0]; ++i) { const tell_gemm_problem& q = pr[ids[i]]; t0 += (long)((q.M + 63) / 64) * ((q.N + 63) / 64); k0 = q.K < k0 ? q.K : k0; }
+    for (int i = 0; i < cnt[2]; ++i) { const tell_gemm_problem& q = pr[ids[2 * n + i]]; t2 += (long)((q.M + 63) / 64) * ((q.N + 63) / 64); k2 = q.K < k2 ? q.K : k2; }
+    if (cnt[0] && small_ring_stages(t0, k0) >= 3) { GROUP_RUN(0, (gemm_nt_group_kernel<uint16_t, 64, 64, 4>), 64, 64) }
+    if (cnt[2] && small_ring_stages(t2, k2) >= 3) { GROUP_RUN(2, (gemm_nt_group_kernel<float, 64, 64, 4>), 64, 64) }
+  }
   GROUP_RUN(0, (gemm_nt_group_kernel<uint16_t, 64, 64>), 64, 64)
   GROUP_RUN(1, (gemm_nt_group_kernel<uint16_t, 128, 128>), 128, 128)
   GROUP_RUN(2, (gemm_nt_group_kernel<float, 64, 64>), 64, 64)
@@ -1764,10 +1833,11 @@ extern "C" int tell_gemm_bn_stats(const void* A, long lda, const void* B, long l
 //     that shape, 85 us for layer1 - one workgroup's dependent loads become the critical path;
 //   * column sums / sums of squares from the accumulator registers (lane shuffles) added to [2, Cout] with float
 //     atomics: 31-49 us, 320-620 us for layer1 - thousands of same-address atomics serialise in L2.
-extern "C" int tell_conv_bn_stats(const void* X, const void* Wt, void* Y, int B, int H, int W, int Cin, int KH, int KW,
-                                  int stride, int pad, int OH, int OW, int Cout, float eps, float momentum, float* mean,
-                                  float* invstd, float* running_mean, float* running_var, float* workspace,
-                                  const void* zero_page, hipStream_t stream) {
+// the convolution launch itself; stats_ws != NULL: the epilogue also leaves the per-row-chunk statistics there
+// ([chunks][Cout] means, then [chunks][Cout] M2 at stats_ws + ceil(M / 64) * Cout); *bm_out = rows per chunk
+static int conv_launch(const void* X, const void* Wt, void* Y, int B, int H, int W, int Cin, int KH, int KW, int stride,
+                       int pad, int OH, int OW, int Cout, float* stats_ws, const void* zero_page, int* bm_out,
+                       hipStream_t stream, const float* bias = nullptr, int act = 0, const void* aux = nullptr) {
   const long Ml = (long)B * OH * OW;
   TELL_REQUIRE(Ml > 0 && Ml < (1L << 31) && Cout > 0, "conv_bn_stats: bad dimension");
   int cshift = 0;
@@ -1779,18 +1849,17 @@ extern "C" int tell_conv_bn_stats(const void* X, const void* Wt, void* Y, int B,
                ((uintptr_t)zero_page & 15) == 0 && zero_page != nullptr, "conv_bn_stats: 16-byte alignment");
   const int M = (int)Ml, N = Cout, K = KH * KW * Cin;
   GemmArgs a;
-  a.A = X; a.B = Wt; a.C = Y; a.bias = nullptr; a.aux = nullptr; a.m_dev = nullptr;
+  a.A = X; a.B = Wt; a.C = Y; a.bias = bias; a.aux = aux; a.m_dev = nullptr;
   a.lda = Cin; a.ldb = K; a.ldc = N; a.M = M; a.N = N; a.K = K;
-  a.bias_mode = 0; a.act = 0; a.accumulate = 0; a.alpha = 1.f; a.asum = nullptr; a.asum_scale = 0.f; a.atomic_out = 0;
+  a.bias_mode = bias ? 1 : 0; a.act = act; a.accumulate = 0; a.alpha = 1.f; a.asum = nullptr; a.asum_scale = 0.f; a.atomic_out = 0;
   a.ts = nullptr;
   a.conv_zero = (KH == 1 && stride == 1) ? nullptr : zero_page;          // 1x1 / stride 1: A is the activation matrix
   a.conv_H = H; a.conv_W = W; a.conv_OH = OH; a.conv_OW = OW; a.conv_KW = KW; a.conv_stride = stride; a.conv_pad = pad;
   a.conv_cshift = cshift;
   a.stat_mean = a.stat_m2 = nullptr;
-  if (mean) {
-    TELL_REQUIRE(invstd && workspace, "conv_bn_stats: statistics need invstd and workspace");
-    a.stat_mean = workspace;
-    a.stat_m2 = workspace + (((long)M + 63) / 64) * N;
+  if (stats_ws) {
+    a.stat_mean = stats_ws;
+    a.stat_m2 = stats_ws + (((long)M + 63) / 64) * N;
   }
   auto tiles = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
   const char* fe = getenv("TELL_CONV_TILE");                       // tuning / test aid: 1 / 2 / 3 forces a tile shape
@@ -1801,16 +1870,74 @@ extern "C" int tell_conv_bn_stats(const void* X, const void* Wt, void* Y, int B,
   // ties once there are thousands of tiles
   int pick = (tiles(64, 64) >= 6000 && N % 64 == 0) ? 2 : 3;
   if (force) pick = force;
-#define CONV_LAUNCH(BM_, BN_, CV)                                                                                   \
-  hipLaunchKernelGGL((gemm_nt_glds_kernel<uint16_t, BM_, BN_, 2, 2, CV>), dim3((unsigned)tiles(BM_, BN_)), dim3(256), 0, stream, a)
+#define CONV_LAUNCH(BM_, BN_, CV, NS_)                                                                              \
+  hipLaunchKernelGGL((gemm_nt_glds_kernel<uint16_t, BM_, BN_, 2, 2, CV, NS_>), dim3((unsigned)tiles(BM_, BN_)), dim3(256), 0, stream, a)
   const bool cv = a.conv_zero != nullptr;
-  if (pick == 1) { if (cv) CONV_LAUNCH(128, 128, true); else CONV_LAUNCH(128, 128, false); }
-  else if (pick == 2) { if (cv) CONV_LAUNCH(128, 64, true); else CONV_LAUNCH(128, 64, false); }
-  else { if (cv) CONV_LAUNCH(64, 64, true); else CONV_LAUNCH(64, 64, false); }
+  const bool ring = small_ring_stages(tiles(64, 64), K) >= 3;
+  if (pick == 1) { if (cv) CONV_LAUNCH(128, 128, true, 2); else CONV_LAUNCH(128, 128, false, 2); }
+  else if (pick == 2) { if (cv) CONV_LAUNCH(128, 64, true, 2); else CONV_LAUNCH(128, 64, false, 2); }
+  else if (ring) { if (cv) CONV_LAUNCH(64, 64, true, 4); else CONV_LAUNCH(64, 64, false, 4); }
+  else { if (cv) CONV_LAUNCH(64, 64, true, 2); else CONV_LAUNCH(64, 64, false, 2); }
 #undef CONV_LAUNCH
-  int rc = tell_check_launch("conv_bn_stats");
+  *bm_out = pick == 3 ? 64 : 128;
+  return tell_check_launch("conv_bn_stats");
+}
+extern "C" int tell_conv_bn_stats(const void* X, const void* Wt, void* Y, int B, int H, int W, int Cin, int KH, int KW,
+                                  int stride, int pad, int OH, int OW, int Cout, float eps, float momentum, float* mean,
+                                  float* invstd, float* running_mean, float* running_var, float* workspace,
+                                  const void* zero_page, hipStream_t stream) {
+  if (mean) TELL_REQUIRE(invstd && workspace, "conv_bn_stats: statistics need invstd and workspace");
+  int bm = 64;
+  int rc = conv_launch(X, Wt, Y, B, H, W, Cin, KH, KW, stride, pad, OH, OW, Cout, mean ? workspace : nullptr, zero_page, &bm,
+                       stream);
   if (rc || !mean) return rc;
-  const int bm = pick == 3 ? 64 : 128;
-  return tell_bn_finish_launch(a.stat_mean, a.stat_m2, M, N, (M + bm - 1) / bm, bm, eps, momentum, mean, invstd,
-                               running_mean, running_var, stream);
+  const long M = (long)B * OH * OW;
+  return tell_bn_finish_launch(workspace, workspace + ((M + 63) / 64) * Cout, M, Cout, (int)((M + bm - 1) / bm), bm, eps,
+                               momentum, mean, invstd, running_mean, running_var, stream);
+}
+// Inference form (model.eval(): running statistics): the BatchNorm is FOLDED into the convolution - w' = w * gamma /
+// sqrt(var + eps) per output channel, bias = beta - mean * that (the host builds both once per state of the weights) - so
+// conv -> bn (-> + residual) (-> relu) is ONE launch: y = act(conv(x, w') + bias [+ residual]).  relu with a residual:
+// relu(... + residual), the Bottleneck's order (resnet.py via torchvision: out += identity; relu).
+extern "C" int tell_conv_bias_act(const void* X, const void* Wt, void* Y, int B, int H, int W, int Cin, int KH, int KW,
+                                  int stride, int pad, int OH, int OW, int Cout, const float* bias, const void* residual,
+                                  int relu, const void* zero_page, hipStream_t stream) {
+  TELL_REQUIRE(!residual || relu, "conv_bias_act: a residual without the relu is not a form of the trunk");
+  int bm = 64;
+  return conv_launch(X, Wt, Y, B, H, W, Cin, KH, KW, stride, pad, OH, OW, Cout, nullptr, zero_page, &bm, stream, bias,
+                     residual ? 4 : (relu ? 1 : 0), residual);
+}
+int tell_bn_finish_apply_launch(const float* pmean, const float* pm2, long M, int C, int n_chunks, int rows_per_chunk,
+                                float eps, float momentum, const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, const void* residual, void* y, int relu, hipStream_t stream);   // conv.hip
+extern "C" int tell_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                             const void* residual, void* y, long M, int C, int relu, int dtype, hipStream_t stream);
+// conv -> train-mode BatchNorm (-> + residual) (-> ReLU), y in place: the implicit-GEMM convolution above with the
+// statistics in its epilogue, then ONE launch that combines the row chunks and normalises (conv.hip
+// bn_finish_apply_kernel) when the combine is cheap enough to repeat per workgroup (<= 128 chunks), else the combine and
+// the elementwise pass as two launches.  workspace: 2 * ceil(M / 64) * Cout + 2 * Cout floats.
+extern "C" int tell_conv_bn_act(const void* X, const void* Wt, void* Y, int B, int H, int W, int Cin, int KH, int KW,
+                                int stride, int pad, int OH, int OW, int Cout, float eps, float momentum, const float* gamma,
+                                const float* beta, float* running_mean, float* running_var, const void* residual, int relu,
+                                float* workspace, const void* zero_page, hipStream_t stream) {
+  TELL_REQUIRE(workspace && gamma && beta, "conv_bn_act: workspace, gamma and beta are required");
+  int bm = 64;
+  int rc = conv_launch(X, Wt, Y, B, H, W, Cin, KH, KW, stride, pad, OH, OW, Cout, workspace, zero_page, &bm, stream);
+  if (rc) return rc;
+  const long M = (long)B * OH * OW;
+  const long chunks64 = (M + 63) / 64;
+  const float* pmean = workspace;
+  const float* pm2 = workspace + chunks64 * Cout;
+  const int n_chunks = (int)((M + bm - 1) / bm);
+  static const bool fuse = !(getenv("TELL_BN_FUSE") && atoi(getenv("TELL_BN_FUSE")) == 0);                 // A/B aid
+  if (fuse) {
+    rc = tell_bn_finish_apply_launch(pmean, pm2, M, Cout, n_chunks, bm, eps, momentum, gamma, beta, running_mean, running_var,
+                                     residual, Y, relu, stream);
+    if (rc <= 0) return rc;
+  }
+  float* mean = workspace + 2 * chunks64 * Cout;
+  float* invstd = mean + Cout;
+  rc = tell_bn_finish_launch(pmean, pm2, M, Cout, n_chunks, bm, eps, momentum, mean, invstd, running_mean, running_var, stream);
+  if (rc) return rc;
+  return tell_bn_apply(Y, mean, invstd, gamma, beta, residual, Y, M, Cout, relu, TELL_BF16, stream);
 }

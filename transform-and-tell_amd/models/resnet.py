@@ -50,8 +50,31 @@ class _Conv(nn.Module):
             return ops.cast(wp, rt.compute_dtype())
         return ops._cached(self.weight, ('convw',), make)
 
+    def folded(self, bn):
+        """Eval mode (running statistics, resnet.py:92-108 under model.eval()): the BatchNorm behind this convolution
+        folded into it - ([Cout, KH*KW*Cin padded] working weight w * gamma / sqrt(var + eps), fp32 bias beta - mean *
+        that) - cached per state of the weights AND of the running statistics (_STATS_EPOCH: train-mode passes update
+        those buffers from inside kernels, behind torch's version counters)."""
+        def make():
+            scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+            w = self.weight.detach().float().permute(0, 2, 3, 1).reshape(self.cout, -1) * scale[:, None]
+            K = w.shape[1]
+            Kp = ops._round_up(K, 8)
+            wp = torch.zeros(self.cout, Kp, dtype=torch.float32, device=w.device)
+            wp[:, :K] = w
+            bias = (bn.bias.detach().float() - bn.running_mean.float() * scale).contiguous()
+            return ops.cast(wp, rt.compute_dtype()), bias
+        key = ('fold', _STATS_EPOCH[0], bn.weight._version, bn.bias._version, bn.running_mean._version,
+               bn.running_var._version, bn.weight.data_ptr(), bn.running_var.data_ptr())
+        return ops._cached(self.weight, key, make)
+
 
 _BN_WS = {}
+_STATS_EPOCH = [0]       # bumped by every train-mode pass of a trunk: the running statistics changed (see _Conv.folded)
+
+
+def stats_epoch():
+    return _STATS_EPOCH[0]
 
 
 def _stat_buffers(device, need_ws, C):
@@ -105,7 +128,7 @@ def conv_stats(x, B, H, W, conv, bn, training, pre=None, slot=0):
     else:
         y = ops.gemm(a, wq)
         mean = bn.running_mean
-        invstd = ops._cached(bn.running_var, ('invstd',), lambda: torch.rsqrt(bn.running_var + bn.eps))
+        invstd = ops._cached(bn.running_var, ('invstd', _STATS_EPOCH[0]), lambda: torch.rsqrt(bn.running_var + bn.eps))
     return y, OH, OW, mean, invstd
 
 
@@ -118,6 +141,19 @@ def bn_apply(y, mean, invstd, bn, relu, residual=None):
 
 def conv_bn_act(x, B, H, W, conv, bn, relu, residual, training):
     """x: [B*H*W, Cin] NHWC rows -> ([B*OH*OW, Cout], OH, OW) with BN (+residual) (+ReLU) applied."""
+    if not training and (residual is None or relu):
+        # eval: the BatchNorm is folded into the weights, bias / residual / ReLU ride in the GEMM epilogue
+        k, s, p = conv.k, conv.stride, conv.padding
+        OH = (H + 2 * p - k) // s + 1
+        OW = (W + 2 * p - k) // s + 1
+        wq, bias = conv.folded(bn)
+        if k == 1 and s == 1:
+            a = x
+        else:
+            a = torch.empty(B * OH * OW, wq.shape[1], dtype=x.dtype, device=x.device)
+            call('tell_im2col', x, a, B, H, W, conv.cin, k, k, s, p, OH, OW, wq.shape[1], hip.dt(x.dtype))
+        act = 4 if residual is not None else int(bool(relu))
+        return ops.gemm(a, wq, bias=bias, bias_mode=1, act=act, aux=residual), OH, OW
     y, OH, OW, mean, invstd = conv_stats(x, B, H, W, conv, bn, training)
     return bn_apply(y, mean, invstd, bn, relu, residual), OH, OW
 
@@ -150,15 +186,20 @@ def conv_bn_implicit(x, B, H, W, conv, bn, relu, residual, training, slot=0):
     wq = conv.gemm_weight()
     y = torch.empty(M, C, dtype=x.dtype, device=x.device)
     if training:
-        ws, slots = _stat_buffers(x.device, 2 * ((M + 63) // 64) * C, C)
-        mean, invstd = slots[slot]
-        call('tell_conv_bn_stats', x, wq, y, B, H, W, conv.cin, k, k, s, p, OH, OW, C, bn.eps, bn.momentum, mean,
-             invstd, bn.running_mean, bn.running_var, ws, _zero_page(x.device))
-    else:
-        call('tell_conv_bn_stats', x, wq, y, B, H, W, conv.cin, k, k, s, p, OH, OW, C, bn.eps, bn.momentum, None,
-             None, None, None, None, _zero_page(x.device))
-        mean = bn.running_mean
-        invstd = ops._cached(bn.running_var, ('invstd',), lambda: torch.rsqrt(bn.running_var + bn.eps))
+        ws, _ = _stat_buffers(x.device, 2 * ((M + 63) // 64) * C + 2 * C, C)
+        call('tell_conv_bn_act', x, wq, y, B, H, W, conv.cin, k, k, s, p, OH, OW, C, bn.eps, bn.momentum,
+             bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, residual, int(relu), ws,
+             _zero_page(x.device))
+        return y, OH, OW
+    if residual is None or relu:
+        wf, bias = conv.folded(bn)                 # eval: BatchNorm folded into the weights, ONE launch per convolution
+        call('tell_conv_bias_act', x, wf, y, B, H, W, conv.cin, k, k, s, p, OH, OW, C, bias, residual, int(bool(relu)),
+             _zero_page(x.device))
+        return y, OH, OW
+    call('tell_conv_bn_stats', x, wq, y, B, H, W, conv.cin, k, k, s, p, OH, OW, C, bn.eps, bn.momentum, None,
+         None, None, None, None, _zero_page(x.device))
+    mean = bn.running_mean
+    invstd = ops._cached(bn.running_var, ('invstd', _STATS_EPOCH[0]), lambda: torch.rsqrt(bn.running_var + bn.eps))
     return bn_apply(y, mean, invstd, bn, relu, residual), OH, OW
 
 
@@ -190,7 +231,7 @@ class Bottleneck(nn.Module):
         if self.downsample is not None:
             idt, _, _ = conv_bn_act(x, B, H, W, self.downsample[0], self.downsample[1], False, None, training)
         vec = 8 if x.dtype == torch.bfloat16 else 4
-        if self.conv2.cin % vec == 0:
+        if self.conv2.cin % vec == 0 and training:
             # bn1 + ReLU are applied inside conv2's im2col gather: conv1's raw output is the only copy in HBM
             y1, _, _, m1, i1 = conv_stats(x, B, H, W, self.conv1, self.bn1, training, slot=0)
             y, OH, OW, m2, i2 = conv_stats(y1, B, H, W, self.conv2, self.bn2, training, pre=(m1, i1, self.bn1), slot=1)
@@ -233,6 +274,8 @@ class ResNetFeatureExtractor(nn.Module):
         x = torch.empty(B * H * W, C, dtype=dtype, device=image.device)
         call('tell_nchw_to_nhwc', image.float().contiguous(), x, B, C, H, W, hip.dt(dtype))
         tr = self.training
+        if tr:
+            _STATS_EPOCH[0] += 1                   # this pass rewrites every running_mean / running_var
         x, H, W = conv_bn_act(x, B, H, W, self.conv1, self.bn1, True, None, tr)        # :94-97
         OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
         y = torch.empty(B * OH * OW, x.shape[1], dtype=dtype, device=x.device)

@@ -117,7 +117,10 @@ class CaptionModel(Model):
             g = self.__dict__['_resnet_graph'] = graphs.GraphedCall(self.resnet, 'resnet152',
                                                                     capture_after=self.__dict__.get('_capture_after'))
         w = self.resnet.conv1.weight                 # a reloaded / moved / re-typed trunk must not replay stale pointers
-        return g(image, key=(self.resnet.training, ops.rt.compute_dtype(), w._version, w.data_ptr()))
+        from .resnet import stats_epoch
+        # (eval captures bake in weights folded with the running statistics: a train-mode pass in between retires them)
+        return g(image, key=(self.resnet.training, ops.rt.compute_dtype(), w._version, w.data_ptr(),
+                             0 if self.resnet.training else stats_epoch()))
 
     def _run_roberta(self, article_ids):
         """RoBERTa-large (~170 launches, dropout active in train mode) as one hipGraph replay per step."""

@@ -167,7 +167,7 @@ class Trainer:
         """The batch padded to the shape buckets (see __init__); a batch that already fits is returned as it is."""
         from . import step_graph as _sg
         from .. import graphs
-        if self.shape_buckets is None or self.step_graph is None or not (_sg.ENABLED and graphs.ENABLED):
+        if self.shape_buckets is None or not (_sg.ENABLED and graphs.ENABLED) or self.nan_check:
             return batch
         idx = getattr(self.model, 'index', 'roberta')
         pad = int(getattr(self.model, 'padding_idx', 1))
