@@ -188,6 +188,22 @@ int tell_layernorm_bwd(const void* dy, long ld_dy, const void* x, long ld_x, con
                        int dparam_accumulate, float* partial, int rows, int C, float p, uint32_t seed,
                        uint32_t salt, int dtype, tell_stream_t stream);
 
+/* ---- batched small launches of the training step (csrc/multi.hip) ------------------------------------------------
+ * n column sums in one launch: dst0[i][c] += sum_r src[i][r][c] for c < w0[i], dst1[i][c - w0[i]] += ... for the rest
+ * (fp32, deterministic order).  The jobs: LayerNorm gamma / beta gradients from the per-row-block partials that
+ * tell_layernorm_bwd / tell_layernorm_cat_bwd leave when called with dgamma == NULL ([blocks][2C] each), and the
+ * bias_k / bias_v gradients of the context attentions (multi_head.py:355-374 backward: per-batch rows [B][2E]).
+ * All arrays are HOST arrays of length n. */
+int tell_colsum_multi(int n, const void* const* src, const long* ld, const int* rows, const int* width, const int* w0,
+                      void* const* dst0, void* const* dst1, tell_stream_t stream);
+/* n bf16 transposes in one launch, dst[i][c][r] = src[i][r][c]: the per-step W^T copies of the backward pass's
+ * large input-gradient GEMMs (fc2, context_fc, the stacked article K|V projection). */
+int tell_transpose_multi(int n, const void* const* src, const long* ld_src, void* const* dst, const long* ld_dst,
+                         const int* rows, const int* cols, tell_stream_t stream);
+/* out = add + dropout(x) with tell_dropout's mask (same seed / salt / element index): the gradient of a block input
+ * that is both the residual and, through the input dropout, the branch input (decoder_faces_objects.py:256-266). */
+int tell_dropout_add(const void* x, const void* add, void* out, long n, float p, uint32_t seed, uint32_t salt, int dtype,
+                     tell_stream_t stream);
 /* n LayerNorms over ONE residual in one launch each way - the end of a decoder layer's context block
    (decoder_faces_objects.py:283-352): y[:, i*C:(i+1)*C] = LayerNorm_i(res + dropout_p(x_i)), mean / rstd [n, rows].
    Backward: dx_i (entries may be NULL), dres = sum_i dz_i (may be NULL), dgamma_i / dbeta_i ACCUMULATED; partial is a

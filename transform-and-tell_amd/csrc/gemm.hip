@@ -290,7 +290,7 @@ __device__ __forceinline__ void glds_store_tile_act(f32x16 (&acc)[MI][NI], const
         f32x4_t v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][4 * g + e] + b4[e] + bm) * p.alpha;
-        epi_act4<ACT == 4 ? 0 : ACT>(v);
+        epi_act4<(ACT == 4 || ACT == 3) ? 0 : ACT>(v);
         int ch = col >> 3;
         if constexpr (SWZ) ch ^= row & (CPRW - 1) & 15;
         u32x2 w = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
@@ -305,6 +305,15 @@ __device__ __forceinline__ void glds_store_tile_act(f32x16 (&acc)[MI][NI], const
     int ch = c % CPRW;
     const int sch = SWZ ? ch ^ (row & (CPRW - 1) & 15) : ch;
     u32x4 o = *reinterpret_cast<const u32x4*>(cs + row * CS + sch * 8);
+    if constexpr (ACT == 3) {                          // relu backward: keep where the forward output (aux) was positive
+      const u32x4 r = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(p.aux) + (long)(m0 + row) * p.ldc + n0 + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {                    // bf16 > 0: sign clear and not zero
+        const uint32_t lo = ((r[e] & 0x8000u) == 0 && (r[e] & 0x7fffu) != 0) ? 0x0000ffffu : 0u;
+        const uint32_t hi = ((r[e] & 0x80000000u) == 0 && (r[e] & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
+        o[e] &= lo | hi;
+      }
+    }
     if constexpr (ACT == 4) {                          // relu(tile + residual): the residual arrives as whole 16-byte pieces too
       const u32x4 r = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(p.aux) + (long)(m0 + row) * p.ldc + n0 + ch * 8);
 #pragma unroll
@@ -323,6 +332,7 @@ __device__ __forceinline__ void glds_store_tile(f32x16 (&acc)[MI][NI], const Gem
   switch (p.act) {
     case 1: glds_store_tile_act<BM, BN, WM, WN, MI, NI, CS, NT, 1, LAY>(acc, p, m0, n0, wm, wn, lane, tid, cs); break;
     case 2: glds_store_tile_act<BM, BN, WM, WN, MI, NI, CS, NT, 2, LAY>(acc, p, m0, n0, wm, wn, lane, tid, cs); break;
+    case 3: glds_store_tile_act<BM, BN, WM, WN, MI, NI, CS, NT, 3, LAY>(acc, p, m0, n0, wm, wn, lane, tid, cs); break;
     case 4: glds_store_tile_act<BM, BN, WM, WN, MI, NI, CS, NT, 4, LAY>(acc, p, m0, n0, wm, wn, lane, tid, cs); break;
     default: glds_store_tile_act<BM, BN, WM, WN, MI, NI, CS, NT, 0, LAY>(acc, p, m0, n0, wm, wn, lane, tid, cs); break;
   }
@@ -379,8 +389,8 @@ __device__ __forceinline__ bool glds_fast_tile_f32(const GemmArgs& p, int m0, in
          (p.bias_mode != 1 || ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0 && (n0 & 3) == 0));
 }
 __device__ __forceinline__ bool glds_fast_tile(const GemmArgs& p, int m0, int n0, int BM, int BN, int M, int N) {
-  return !p.accumulate && p.act != 3 && m0 + BM <= M && n0 + BN <= N && (p.ldc & 7) == 0 &&
-         (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (p.act != 4 || (reinterpret_cast<uintptr_t>(p.aux) & 15) == 0) &&
+  return !p.accumulate && m0 + BM <= M && n0 + BN <= N && (p.ldc & 7) == 0 &&
+         (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && ((p.act != 4 && p.act != 3) || (reinterpret_cast<uintptr_t>(p.aux) & 15) == 0) &&
          (p.bias_mode != 1 || ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0 && (n0 & 3) == 0));
 }
 

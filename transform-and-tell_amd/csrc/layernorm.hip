@@ -345,6 +345,7 @@ extern "C" int tell_layernorm_bwd(const void* dy, long ld_dy, const void* x, lon
   int rc = tell_check_launch("layernorm_bwd");
   if (rc) return rc;
 #undef LNB
+  if (!dgamma) return TELL_OK;      // the caller folds `partial` ([blocks][2C]: gamma | beta terms) later (tell_colsum_multi)
   hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, stream, partial, nb, C, dgamma, dbeta, dparam_accumulate);
   return tell_check_launch("layernorm_bwd_finish");
 }
@@ -578,7 +579,7 @@ extern "C" int tell_layernorm_cat_bwd(int n, const void* dcat, long ld_dcat, con
   for (int i = 0; i < n; ++i) {
     TELL_REQUIRE((((uintptr_t)x[i] | (uintptr_t)dx[i]) & 15) == 0, "layernorm_cat_bwd: rows must be 16-byte aligned");
     a.x[i] = x[i]; a.gamma[i] = gamma[i]; a.beta[i] = nullptr; a.salt[i] = salts[i];
-    a.dx[i] = dx[i]; a.dgamma[i] = dgamma[i]; a.dbeta[i] = dbeta[i];
+    a.dx[i] = dx[i]; a.dgamma[i] = dgamma ? dgamma[i] : nullptr; a.dbeta[i] = dbeta ? dbeta[i] : nullptr;
   }
   const uint32_t thr = p > 0.f ? tell_drop_threshold(p) : 0u;
   const float ik = 1.f / (1.f - p);
@@ -589,6 +590,7 @@ extern "C" int tell_layernorm_cat_bwd(int n, const void* dcat, long ld_dcat, con
     hipLaunchKernelGGL((ln_cat_bwd_kernel<uint16_t, 2>), dim3(nb), dim3(256), 0, stream, a, (const uint16_t*)dcat, ld_dcat, ld_x, (const uint16_t*)res, ld_r, mean, rstd, ld_dx, (uint16_t*)dres, ld_dres, partial, rows, thr, ik, seed, g_tell_rng_step);
   rc = tell_check_launch("layernorm_cat_bwd");
   if (rc) return rc;
+  if (!dgamma) return TELL_OK;      // deferred: partial is [n][blocks][2C]
   hipLaunchKernelGGL(ln_cat_bwd_finish_kernel, dim3((2 * C + 63) / 64, n), dim3(1024), 0, stream, a, partial, nb, C);
   return tell_check_launch("layernorm_cat_bwd_finish");
 }

@@ -5,10 +5,15 @@ registration names and keeps both sets of constructor arguments / state_dict key
 import torch
 import torch.nn as nn
 
-from .. import ops
+import os
+
+from .. import blocks, ops
 from ..common.registrable import Registrable
 from ..modules import AdaptiveSoftmax, DynamicConv1dTBC, GehringLinear, LightweightConv1dTBC, MultiHeadAttention
 from ..modules.token_embedders import AdaptiveEmbedding
+
+
+_BLOCKS = os.environ.get('TELL_BLOCKS', '1') != '0'      # A/B aid: 0 = the per-op composition everywhere
 
 
 def eval_str_list(x, type=float):
@@ -80,16 +85,20 @@ class DynamicConvDecoderLayer(DecoderLayer):
             return res + ops.dropout(h, self.dropout, self.training)
         return self._ln(ln, h, res, self.dropout, self.training)
 
-    def forward(self, X, contexts, incremental_state, contexts_t=None, kv=None):
+    def forward(self, X, contexts, incremental_state, contexts_t=None, kv=None, kv_packed=None):
         tr = self.training
-        res = X                                                            # :256-266
-        h = ops.dropout(self._pre(self.conv_layer_norm, X), self.input_dropout, tr)
-        h = self.linear1(h)
-        if self.glu:
-            h = ops.glu(h)
-        h = self.conv(h, incremental_state=incremental_state)
-        h = self.linear2(h)
-        X = self._post(self.conv_layer_norm, h, res)
+        use_blocks = _BLOCKS and incremental_state is None and blocks.usable(self, X) and X.requires_grad
+        if use_blocks:                                                     # :256-266 as one autograd node
+            X = blocks.conv_block(self, X)
+        else:
+            res = X
+            h = ops.dropout(self._pre(self.conv_layer_norm, X), self.input_dropout, tr)
+            h = self.linear1(h)
+            if self.glu:
+                h = ops.glu(h)
+            h = self.conv(h, incremental_state=incremental_state)
+            h = self.linear2(h)
+            X = self._post(self.conv_layer_norm, h, res)
 
         attns, outs = {}, []
         fused = not self.normalize_before and X.is_cuda     # post-LN layers (every expt/ config): LN_c writes its slice
@@ -108,7 +117,8 @@ class DynamicConvDecoderLayer(DecoderLayer):
             # time is the kernel's fixed latency, not its work.)
             mods = [self.context_attns[n] for n in self.context_names]
             qs = ops.grouped_linear([handles[i] for i in range(nctx)], [m.q_spec() for m in mods])
-            cores = [m.core(q, contexts[n], contexts[n + '_mask'], None if kv is None else kv[n])
+            cores = [m.core(q, contexts[n], contexts[n + '_mask'], None if kv is None else kv[n],
+                            None if kv_packed is None else kv_packed.get(n))
                      for m, q, n in zip(mods, qs, self.context_names)]
             outs = ops.grouped_linear(cores, [m.out_spec() for m in mods])
         for i, name in enumerate(() if grouped else self.context_names):  # :271-352
@@ -126,6 +136,8 @@ class DynamicConvDecoderLayer(DecoderLayer):
         else:
             cat = torch.cat(outs, dim=-1)
         X = self.context_fc(cat)                                          # :354-355
+        if use_blocks:
+            return blocks.ffn_block(self, X), attns                        # :357-364 as one autograd node
 
         res = X                                                            # :357-364
         h = self.fc1(self._pre(self.final_layer_norm, X), act=1)
@@ -204,6 +216,16 @@ class _DynamicConvDecoderBase(Decoder):
                         src = bm if (bm.is_contiguous() and not c.is_contiguous()) else c.contiguous()
                         contexts_t[name] = ops.transpose(ops.as2d(src))[0]
                 contexts['_transposed'] = contexts_t
+        kv_packed = None
+        if (_BLOCKS and self.training and torch.is_grad_enabled() and X.is_cuda and X.requires_grad and
+                incremental_state is None and kv_cache is None and ops.rt.compute_dtype() == torch.bfloat16 and
+                len(self.CONTEXTS) > 1 and not any(l.normalize_before or l.need_attn for l in self.layers) and
+                ops.rt.grad_ready_callback() is None):      # (a bucketed DP exchange needs a layer's gradients final
+                                                            #  when backward leaves the layer: no cross-layer node then)
+            # nothing below depends on the decoder state: the W^T copies the backward pass will want, and the K|V
+            # projections of every (layer, context) pair, as one launch each before the layer loop
+            blocks.prepare_transposes(self.layers, X.shape[0] * X.shape[1])
+            kv_packed = blocks.kv_project_all(self.layers, [n for n, _ in self.CONTEXTS], contexts)
         attns, inner_states = [], [X]
         if X.is_cuda:                        # key-padding masks as the uint8 the attention kernels read: once, not per layer
             contexts = dict(contexts)
@@ -215,7 +237,7 @@ class _DynamicConvDecoderBase(Decoder):
             if not use_layers or i in use_layers:
                 X = ops.grad_ready_marker(X, 'decoder.layers.%d.' % i)    # DP: layer i's gradients are final here
                 X, attn = layer(X, contexts, incremental_state, contexts_t,
-                                None if kv_cache is None else kv_cache[i])
+                                None if kv_cache is None else kv_cache[i], None if kv_packed is None else kv_packed[i])
                 inner_states.append(X)
             attns.append(attn)
         if self.normalize:                                                         # :125-126

@@ -87,12 +87,14 @@ class MultiHeadAttention(nn.Module):
     def out_spec(self):
         return (self.out_proj.weight, None, self.out_proj.bias, None, 1.0)
 
-    def core(self, q, key, key_padding_mask=None, kv=None):
+    def core(self, q, key, key_padding_mask=None, kv=None, packed=None):
         """softmax(q K^T) V between the two projections: q already projected and scaled; K / V projected here (one
-        packed projection when gradients are on) or taken from `kv` (generation: projected once per caption)."""
+        packed projection when gradients are on), taken from `kv` (generation: projected once per caption) or from
+        `packed` (training: the [S,B,2E] projection blocks.kv_project_all computed for all layers at once)."""
         T, B, E = q.shape
-        packed = None
-        if kv is None and ops.rt.compute_dtype() == torch.bfloat16 and key.shape[0] > 0 and key.shape[2] > 0 \
+        if packed is not None:
+            k = v = packed
+        elif kv is None and ops.rt.compute_dtype() == torch.bfloat16 and key.shape[0] > 0 and key.shape[2] > 0 \
                 and torch.is_grad_enabled():
             packed = self.project_kv_packed(key)          # training: K and V as one [S,B,2E] projection
             k = v = packed

@@ -217,8 +217,8 @@ def _launch_wgrad_group(items):
                   for a, b, out, alpha, acc, asum, asum_scale in items])
 
 
-def gemm_nn(a, b_kn, b_t=None, out=None, out_dtype=None, alpha=1.0, act=0, aux=None, m_dev=None):
-    """out[M,N] = act(alpha * a[M,K] @ b_kn[K,N]) (dgrad: a = dY, b_kn = the weight as stored [N_out, K_in]).
+def gemm_nn(a, b_kn, b_t=None, out=None, out_dtype=None, alpha=1.0, act=0, aux=None, m_dev=None, accumulate=False):
+    """out[M,N] = act(alpha * a[M,K] @ b_kn[K,N]) (+ out) (dgrad: a = dY, b_kn = the weight as stored [N_out, K_in]).
     `b_t`: callable returning b_kn^T [N, K] for the fallback path."""
     M = a.shape[0]
     K, N = b_kn.shape                  # `a` may carry zero padding columns beyond K (never garbage: 0 * NaN)
@@ -226,7 +226,7 @@ def gemm_nn(a, b_kn, b_t=None, out=None, out_dtype=None, alpha=1.0, act=0, aux=N
     big = ((M + 127) // 128) * ((N + 127) // 128) >= 256 and K % 64 == 0     # direct-to-LDS NT kernel territory
     if (_SPLITK and K >= 8192 and N <= 256 and N % 4 == 0 and _kmajor_ok(b_kn) and a.dtype == torch.bfloat16 and
             a.stride(1) == 1 and a.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and a.shape[1] >= _round_up(K, 8) and
-            act == 0 and aux is None and (out is None or out.stride(0) % 4 == 0)):
+            act == 0 and aux is None and not accumulate and (out is None or out.stride(0) % 4 == 0)):
         # few output columns from a very long reduction (the adaptive-softmax tails' dh = dlogits . W: [1024, 64] from
         # K = 30265): 16-64 output tiles walking hundreds of K tiles each (162 us).  K slices as one grouped launch
         # of fp32 partial tiles + the fold.  (Rows past *m_dev are computed too: they are zeros in, zeros out.)
@@ -246,7 +246,7 @@ def gemm_nn(a, b_kn, b_t=None, out=None, out_dtype=None, alpha=1.0, act=0, aux=N
         if out is None:
             out = torch.empty(M, N, dtype=out_dtype or a.dtype, device=a.device)
         call('tell_gemm_bf16', a, a.stride(0), 0, b_kn, b_kn.stride(0), 1, out, out.stride(0), M, N, K,
-             hip.dt(out), None, 0, act, aux, float(alpha), 0, m_dev, None, 0.0)
+             hip.dt(out), None, 0, act, aux, float(alpha), int(accumulate), m_dev, None, 0.0)
         return out
     bt = b_t() if b_t is not None else transpose(b_kn)[0]
     if bt.shape[1] != a.shape[1]:                       # bring both to one (zero padded) K width
@@ -259,7 +259,7 @@ def gemm_nn(a, b_kn, b_t=None, out=None, out_dtype=None, alpha=1.0, act=0, aux=N
             a2 = torch.zeros(a.shape[0], Kp, dtype=a.dtype, device=a.device)
             a2[:, :a.shape[1]] = a
             a = a2
-    res = gemm(a, bt, out=out, out_dtype=out_dtype, alpha=alpha, act=act, aux=aux, m_dev=m_dev)
+    res = gemm(a, bt, out=out, out_dtype=out_dtype, alpha=alpha, act=act, aux=aux, m_dev=m_dev, accumulate=accumulate)
     return res if out is not None else res[:, :N]
 
 
@@ -285,6 +285,41 @@ def cast(x, dtype):
     y = torch.empty_like(x, dtype=dtype)
     call('tell_cast', x, hip.dt(x), y, hip.dt(y), x.numel())
     return y
+
+
+# Deferred column sums: gradients that only the optimizer reads (LayerNorm gamma / beta from per-row-block partials,
+# bias_k / bias_v of the attentions from per-batch rows) are folded by ONE launch when the backward pass is over
+# (tell_colsum_multi) instead of one or two ~5 us launches each on the critical stream: the trainer turns the queue on
+# around backward, like the weight-gradient queue.
+_FINISH = {'defer': False, 'jobs': []}
+
+
+def finish_defer(on):
+    _FINISH['defer'] = bool(on)
+
+
+def finish_drop():
+    _FINISH['jobs'] = []
+
+
+def finish_job(src, dst0, w0, dst1):
+    """dst0[c] += sum_r src[r][c] (c < w0), dst1[c - w0] += ... (c >= w0).  src: fp32 [rows, width]; queued while
+    deferring (the tensors are kept alive by the queue), else done now."""
+    _FINISH['jobs'].append((src, dst0, int(w0), dst1))
+    if not _FINISH['defer']:
+        finish_flush()
+
+
+def finish_flush():
+    jobs, _FINISH['jobs'] = _FINISH['jobs'], []
+    if not jobs:
+        return
+    n = len(jobs)
+    call('tell_colsum_multi', n, _ptr_array([j[0] for j in jobs]), (ctypes.c_long * n)(*[j[0].stride(0) for j in jobs]),
+         _int_array([j[0].shape[0] for j in jobs]), _int_array([j[0].shape[1] for j in jobs]),
+         _int_array([j[2] for j in jobs]),
+         (ctypes.c_void_p * n)(*[j[1].data_ptr() if j[1] is not None else None for j in jobs]),
+         (ctypes.c_void_p * n)(*[j[3].data_ptr() if j[3] is not None else None for j in jobs]))
 
 
 def colsum_into(x2, out, scale=1.0, m_dev=None):
@@ -781,6 +816,36 @@ class WNLinearFn(Function):
         return dx, None, None, None, None, None
 
 
+def wn_wgrad(dy2, x2, g, v, b, norms):
+    """Weight / bias gradients of a GehringLinear from dY [rows, out] and X [rows, in] (both as the forward pass left
+    them): dW into a fresh fp32 tile set (queued with the pass's other weight gradients), the weight-norm chain rule
+    dW -> dg, dv deferred to the pass's single wn_backward launch, the bias gradient on the GEMM's A tiles."""
+    gb = grad_buffer(b) if (b is not None and b.requires_grad) else None
+    if v.requires_grad:
+        dW = gemm_tn(dy2, x2, out_dtype=torch.float32, asum=gb)
+        if _WN_PENDING['defer']:
+            _WN_PENDING['items'].append((dW, g, v, norms))
+        else:
+            call('tell_wn_backward', dW, g.detach(), v.detach(), norms, v.shape[0], v.shape[1], grad_buffer(g),
+                 grad_buffer(v))
+    elif gb is not None:
+        colsum_into(dy2, gb)
+
+
+def linear_wgrad(dy2, x2, w_param, rows=None, b_param=None, b_rows=None, alpha=1.0):
+    """Weight / bias gradients of a plain linear (rows of w_param), accumulated into the flat gradient buffer."""
+    r0, r1 = rows if rows is not None else (0, w_param.shape[0])
+    gb = None
+    if b_param is not None and b_param.requires_grad:
+        gb = grad_buffer(b_param)
+        gb = gb if b_rows is None else gb[b_rows[0]:b_rows[1]]
+    if w_param.requires_grad:
+        gw = grad_buffer(w_param)
+        gemm_tn(dy2, x2, out=gw.view(gw.shape[0], -1)[r0:r1], alpha=alpha, accumulate=True, asum=gb, asum_scale=alpha)
+    elif gb is not None:
+        colsum_into(dy2, gb, scale=alpha)
+
+
 def wn_linear(x, g, v, b=None, act=0):
     return WNLinearFn.apply(x, g, v, b, act, x.requires_grad)
 
@@ -900,12 +965,15 @@ class LayerNormFn(Function):
         dres = None
         if need_dres and r2 is not None:
             dres = dx if same else torch.empty_like(x2)
+        defer = _FINISH['defer'] and x2.is_cuda
         call('tell_layernorm_bwd', dy2, dy2.stride(0), x2, x2.stride(0), r2,
              r2.stride(0) if r2 is not None else 0, gamma.detach(), mean, rstd,
              dx, dx.stride(0) if dx is not None else 0,
              None if (dres is None or same) else dres, dres.stride(0) if dres is not None else 0, 0,
-             grad_buffer(gamma), grad_buffer(beta), 1, partial, rows, C, float(p), rt.seed(), salt,
-             hip.dt(x2))
+             None if defer else grad_buffer(gamma), None if defer else grad_buffer(beta), 1, partial, rows, C, float(p),
+             rt.seed(), salt, hip.dt(x2))
+        if defer:
+            finish_job(partial.view(nb, 2 * C), grad_buffer(gamma), C, grad_buffer(beta))
         return (dx.view(shape) if dx is not None else None,
                 dres.view(shape) if dres is not None else None, None, None, None, None, None)
 
@@ -967,12 +1035,18 @@ class LNCatFn(Function):
             partial = torch.empty(n * nb * 2 * C, dtype=torch.float32, device=r2.device)
             dxl = [torch.empty_like(x2s[i]) if need_dx[i] else None for i in range(n)]
             have = [d for d in dxl if d is not None]
+            defer = _FINISH['defer']
             call('tell_layernorm_cat_bwd', n, d2, d2.stride(0), _ptr_array(list(x2s)), x2s[0].stride(0), r2, r2.stride(0),
                  _ptr_array([g.detach() for g in gammas]), mean, rstd,
                  (ctypes.c_void_p * n)(*[d.data_ptr() if d is not None else None for d in dxl]),
                  have[0].stride(0) if have else 0, dres, dres.stride(0) if dres is not None else 0,
-                 _ptr_array([grad_buffer(g) for g in gammas]), _ptr_array([grad_buffer(b) for b in betas]), partial,
+                 None if defer else _ptr_array([grad_buffer(g) for g in gammas]),
+                 None if defer else _ptr_array([grad_buffer(b) for b in betas]), partial,
                  rows, C, float(p), rt.seed(), (ctypes.c_uint32 * n)(*salts), hip.dt(r2))
+            if defer:
+                pv = partial.view(n, nb, 2 * C)
+                for i in range(n):
+                    finish_job(pv[i], grad_buffer(gammas[i]), C, grad_buffer(betas[i]))
             dxs = [d.view(shape) if d is not None else None for d in dxl]
             return (dres.view(shape) if dres is not None else None, None, None, None, None, *dxs) + (None,) * (2 * n)
         for i in range(n):
@@ -1072,12 +1146,15 @@ class DotAttnFn(Function):
         ctx.save_for_backward(src, probs, x)
         ctx.need_dsrc = src.requires_grad
         ctx.mark_non_differentiable(probs)
+        ctx.set_materialize_grads(False)          # (no zero tensor for the unused probs gradient)
         return out, probs
 
     @staticmethod
     def backward(ctx, dctx, _dprobs):
         src, probs, x = ctx.saved_tensors
         L, B, D = src.shape
+        if dctx is None:
+            return None, None, None
         dx = torch.empty(B, D, dtype=src.dtype, device=src.device)
         dsrc = torch.empty(L, B, D, dtype=src.dtype, device=src.device) if ctx.need_dsrc else None
         call('tell_dot_attn_bwd', src, src.stride(0), src.stride(1), probs, dctx.contiguous(), x, dx, dsrc, L, B, D,
@@ -1157,6 +1234,9 @@ def _bias_row(p, dtype):
     return cast(p.detach().reshape(-1), dtype)
 
 
+_DKV_TARGET = {}      # data_ptr of a packed K|V projection -> the gradient view its attention backward must fill
+
+
 class AttnFn(Function):
     """softmax(q k^T + mask) v with the virtual bias_k/bias_v row and zero row.
     q: [T,B,E] (already scaled); k, v: [S,B,E] views; mask: [B,S] uint8 or None.
@@ -1173,6 +1253,7 @@ class AttnFn(Function):
             kv = k
             assert kv.stride(2) == 1 and kv.shape[2] == 2 * E
             ctx.kv_layout = (tuple(kv.shape), tuple(kv.stride()))
+            ctx.kv_ptr = kv.data_ptr()
             k, v = kv[..., :E], kv[..., E:]
         if q.stride(2) != 1:
             q = q.contiguous()
@@ -1188,6 +1269,7 @@ class AttnFn(Function):
         ctx.save_for_backward(q, k, v, out, lse, mask, bk, bv)
         ctx.meta = (bias_k, bias_v, H, has_zero, p, salt, S, packed)
         ctx.mark_non_differentiable(lse)
+        ctx.set_materialize_grads(False)          # autograd would fill a zero [B*H,T] gradient for lse per call
         return out, lse
 
     @staticmethod
@@ -1196,6 +1278,8 @@ class AttnFn(Function):
         bias_k, bias_v, H, has_zero, p, salt, S, packed = ctx.meta
         T, B, E = q.shape
         D = E // H
+        if dout is None:
+            return (None,) * 10
         dout = dout.contiguous()
         dq = torch.empty_like(q)
         # (every element is ASSIGNED by the workgroup of its (b, h) while it handles q block 0: no zero fill)
@@ -1213,9 +1297,13 @@ class AttnFn(Function):
         kc, vc = k, v
         dkv = None
         if packed and S > 0:
-            # one [S,B,2E] gradient buffer laid out like the packed projection; the K / V halves are views of it
+            # one [S,B,2E] gradient buffer laid out like the packed projection; the K / V halves are views of it.
+            # A projection that computed several layers' K|V side by side (blocks.KVAllFn) has reserved this layer's
+            # slice of ONE gradient buffer: the input gradient of all layers is then a single long-K GEMM
             kshape, kstride = ctx.kv_layout
-            dkv = torch.empty_strided(kshape, kstride, dtype=k.dtype, device=k.device)
+            dkv = _DKV_TARGET.pop(ctx.kv_ptr, None)
+            if dkv is None:
+                dkv = torch.empty_strided(kshape, kstride, dtype=k.dtype, device=k.device)
         if dkv is not None:
             dk, dv = dkv[..., :E], dkv[..., E:]
         else:
@@ -1229,7 +1317,9 @@ class AttnFn(Function):
         call('tell_attn_bwd', q, kc, vc, out, dout, lse, mask, bk, bv, dq, dk, dv, dbk, dbv, B, H, T, S, D,
              q.stride(0), q.stride(1), kc.stride(0), kc.stride(1), vc.stride(0), vc.stride(1),
              out.stride(0), out.stride(1), int(has_zero), float(p), rt.seed(), salt, hip.dt(q))
-        if dbkv is not None:
+        if dbkv is not None and _FINISH['defer']:
+            finish_job(dbkv, gbk, E, gbv)
+        elif dbkv is not None:
             colsum_into(dbkv, torch.as_strided(gbk, (2 * E,), (1,)))
         elif bias_k is not None and bias_k.requires_grad:
             colsum_into(dbk, grad_buffer(bias_k).view(-1))
@@ -1447,12 +1537,15 @@ class AdaptiveLossFn(Function):
         ctx.params = (emb0, class_proj, tails, cutoffs, pad_idx)
         ctx.xshape = x.shape
         ctx.mark_non_differentiable(part['n_valid'])
+        ctx.set_materialize_grads(False)
         return total, part['n_valid']
 
     @staticmethod
     def backward(ctx, gtotal, _gn):
         x2, w_head, head_logits, lse_h, part, saved_tails = ctx.saved
         emb0, class_proj, tails, cutoffs, pad_idx = ctx.params
+        if gtotal is None:
+            return (None,) * (6 + len(tails))
         N, E = x2.shape
         dtype, dev = x2.dtype, x2.device
         c0 = cutoffs[0]

@@ -233,19 +233,23 @@ class Trainer:
         # leave during backward (a layer's gradients have to be final at its marker then)
         ops.wn_defer(not self._ranges)
         ops.wgrad_group_defer(not self._ranges)                          # ... and so do the weight-gradient GEMMs
+        ops.finish_defer(not self._ranges)                               # ... and the small column-sum finishers
         try:
             scaled.backward()                                            # :229-231
         except BaseException:
             ops.wn_drop()
             ops.wgrad_group_drop()
+            ops.finish_drop()
             raise
         finally:
             self._in_backward = False
             ops.wn_defer(False)
             ops.wgrad_group_defer(False)
+            ops.finish_defer(False)
         ops.join_wgrad_stream()                                          # weight-gradient side stream (ops.py)
         ops.wgrad_group_flush()
         ops.wn_flush()
+        ops.finish_flush()
 
     def skipped_steps(self):
         """Number of optimisation steps the device-side NaN / Inf check turned into no-ops so far (one host sync)."""
