@@ -13,8 +13,9 @@
  *     allocates nothing.  Its only state: a thread-local error string, three
  *     REGISTERED device pointers that kernels read while a hipGraph is recorded /
  *     replayed (tell_set_rng_step_ptr, tell_set_pos_step_ptr: the dropout step and
- *     decode position counters) and a thread-local one-shot hook that arms the next
- *     tell_gemm_nt launch with a span stamp (tell_gemm_ts_next);
+ *     decode position counters), the registered tile-counter buffer of the persistent
+ *     GEMM launches (tell_gemm_set_tile_queue) and a thread-local one-shot hook that arms
+ *     the next tell_gemm_nt launch with a span stamp (tell_gemm_ts_next);
  *   - every call is asynchronous on `stream` (pass torch's current stream);
  *   - return 0 on success, <0 on error (tell_last_error() explains);
  *   - `dtype`: TELL_F32 = 0 (exact-f32 parity mode, f32 MFMA), TELL_BF16 = 1;
@@ -60,6 +61,12 @@ int tell_wall_clock_khz(void);
  * into ts[0] (first workgroup in) / ts[1] (last workgroup out), device wall-clock ticks; ts is uint64[3], zero before
  * the first use (ts[2] counts workgroup arrivals: every launch of the same grid re-opens the span by itself) */
 int tell_gemm_ts_next(void* ts, tell_stream_t stream);
+/* register the tile counters of the PERSISTENT 256x256 GEMM launches: `counters` = n zero-initialised int32 on the
+ * device, owned by the caller and alive for as long as GEMMs are launched (NULL / 0 unregisters: every 256x256 launch is
+ * then one workgroup per tile).  Each persistent launch (more tiles than CUs) takes the next slot as its work queue and
+ * leaves it zero; n must exceed the number of such launches that can be in flight or captured in live graphs at once by a
+ * wide margin (the host mirror registers 65536). */
+int tell_gemm_set_tile_queue(void* counters, int n, tell_stream_t stream);
 
 /* ---- GEMM (every nn.Linear / F.linear / 1x1 conv on the path) --------------
  * C[M,N] = act((A[M,K] . B[N,K]^T + bias) * alpha) (+ C if accumulate)

@@ -15,6 +15,7 @@
 // (S^T[key][q] = K.Q^T) so that each lane owns one query column: the softmax
 // row-reduction is 16 in-register values + one cross-half wavefront shuffle.
 #include "common.h"
+#include <type_traits>
 
 template <typename T, int D> struct ACfg {
   static constexpr int VEC = Elem<T>::VEC;
@@ -594,8 +595,8 @@ __device__ __forceinline__ bf16x8 attn_tr_frag(const uint16_t* p0, const uint16_
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <bool DROP>
-__global__ __launch_bounds__(256) void attn_fwd_reg_kernel(AttnArgs p) {
+template <bool DROP, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void attn_fwd_reg_kernel(AttnArgs p) {
   const uint32_t salt_eff = tell_step_salt(p.salt, p.step);   // hoisted: one scalar load per kernel
   using T = uint16_t;
   constexpr int D = 64, KT = 64, NW = 4;
@@ -810,6 +811,244 @@ __global__ __launch_bounds__(256) void attn_fwd_reg_kernel(AttnArgs p) {
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {                     // 4 consecutive d per register group -> one 8-byte store
+      const int d0 = dt * 32 + 8 * g + 4 * hh;
+      uint2 w;
+      w.x = pack_bf16x2(o[dt][4 * g] * inv_l, o[dt][4 * g + 1] * inv_l);
+      w.y = pack_bf16x2(o[dt][4 * g + 2] * inv_l, o[dt][4 * g + 3] * inv_l);
+      *reinterpret_cast<uint2*>(og + d0) = w;
+    }
+  if (lane < 32 && p.lse) p.lse[(long)bh * p.Tq + t] = l_run > 0.f ? m_run + __logf(l_run) : INFINITY;
+}
+
+// ------------------------------------------------------------------ self-attention of the article encoder (bf16)
+// fairseq's RoBERTa self-attention as transformer_faces_objects.py:352-353 runs it (T = S = 512, 16 heads of 64, key
+// padding mask, attention dropout in train mode) is the second largest kernel of the step after the encoder GEMMs and it
+// is VALU-bound: the softmax + dropout arithmetic of a 64-key tile takes ~4x the cycles of its 16 MFMAs.  Same tiling and
+// register-resident probabilities as attn_fwd_reg_kernel, specialised to what this caller guarantees - no bias_k / zero
+// rows, S a multiple of 64 (every tile full) - and rebuilt around the VALU budget:
+//   * tile loads are `uniform base + per-lane 32-bit offset` (the per-tile part of every address lives in scalar
+//     registers: zero vector instructions per tile for addressing; the generic kernel spent ~80 on row classification
+//     and 64-bit pointer arithmetic), LDS store addresses are immediates of a 2x unrolled loop;
+//   * the running maximum is only moved when some row's tile maximum exceeds it by more than 8 (wave-uniform test):
+//     after the first tiles the 32-multiply rescale of the output accumulators and the exp of the correction factor
+//     disappear; probabilities are then bounded by e^8 instead of 1, which bf16 / fp32 accumulation carry without loss
+//     of relative precision, and the log-sum-exp is exact either way;
+//   * three-input maxima; three waves per SIMD (168 registers, launch bounds) instead of two.
+// Dropout masks are the generic kernel's (same element indices, same hash): bit-identical selections.
+#define ATTN_SELF_THR 8.0f
+template <bool DROP, int ABL = 0>
+__global__ __launch_bounds__(256, 3) void attn_self_fwd_kernel(AttnArgs p) {
+  const uint32_t salt_eff = tell_step_salt(p.salt, p.step);
+  using T = uint16_t;
+  constexpr int D = 64, KT = 64, NW = 4;
+  constexpr int KS = 72, VS = 96;                    // as attn_fwd_reg_kernel
+  __shared__ __attribute__((aligned(16))) T Ks[2][KT * KS];
+  __shared__ __attribute__((aligned(16))) T Vs[2][KT * VS];
+  __shared__ __attribute__((aligned(16))) float key_bias[2][KT];
+  __shared__ int tile_masked[2];
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  typedef __attribute__((ext_vector_type(4))) float f32x4;
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, qi = lane & 31;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+  const int QB = (p.Tq + 31) / 32;
+  const int qb = blockIdx.x * NW + wave;
+  const bool active = qb < QB;
+  const int t = qb * 32 + qi;
+  const int nkt = p.S / KT;
+  const T* qg = static_cast<const T*>(p.q);
+  const T* kb = static_cast<const T*>(p.k) + (long)b * p.k_sb + (long)h * D;      // uniform
+  const T* vb = static_cast<const T*>(p.v) + (long)b * p.v_sb + (long)h * D;
+  const uint8_t* mrow = p.mask ? p.mask + (long)b * p.S : nullptr;
+
+  bf16x8 qf[4];
+  {
+    const bool ok = active && t < p.Tq;
+    const T* qp = ok ? qg + (long)t * p.q_st + (long)b * p.q_sb + (long)h * D : qg;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(qp + (ok ? 16 * ks + 8 * hh : 0));
+      if (!ok) v = zero4;
+      qf[ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+  // staging: chunk c = tid + 256 i covers key c >> 3, 16-byte column c & 7
+  unsigned koff[2], voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 256 * i;
+    koff[i] = (unsigned)((c >> 3) * (int)p.k_ss + (c & 7) * 8);
+    voff[i] = (unsigned)((c >> 3) * (int)p.v_ss + (c & 7) * 8);
+  }
+  const int kw0 = (tid >> 3) * KS + (tid & 7) * 8, vw0 = (tid >> 3) * VS + (tid & 7) * 8;   // chunk i: + 32 * stride
+  u32x4 rk[2], rv[2];
+  auto rload = [&](int kt) __attribute__((always_inline)) {
+    const T* kt_b = kb + (long)kt * KT * p.k_ss;      // scalar
+    const T* vt_b = vb + (long)kt * KT * p.v_ss;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      rk[i] = *reinterpret_cast<const u32x4*>(kt_b + koff[i]);
+      rv[i] = *reinterpret_cast<const u32x4*>(vt_b + voff[i]);
+    }
+  };
+  auto rstore = [&](int kt, auto buf_c) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf_c)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<u32x4*>(&Ks[BUF][kw0 + i * 32 * KS]) = rk[i];
+      *reinterpret_cast<u32x4*>(&Vs[BUF][vw0 + i * 32 * VS]) = rv[i];
+    }
+    if (tid < KT) {                                   // exactly wave 0
+      const bool ok = mrow ? mrow[kt * KT + tid] == 0 : true;
+      key_bias[BUF][tid] = ok ? 0.f : -INFINITY;
+      const bool any_masked = __ballot(!ok) != 0;
+      if (tid == 0) tile_masked[BUF] = any_masked;
+    }
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  rload(0);
+  rstore(0, B0{});
+  __syncthreads();
+
+  f32x16 o[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[f][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int k_off = qi * KS + 8 * hh;
+  const int v_off = (4 * hh + ((lane & 15) >> 2)) * VS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const uint64_t row_base = ((uint64_t)bh * p.Tq + t) * (uint64_t)p.S + 4 * hh;
+  constexpr float LOG2E = 1.4426950408889634f;
+
+  auto tile = [&](int kt, auto buf_c) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf_c)::value;
+    if ((ABL & 2) == 0 && kt + 1 < nkt) rload(kt + 1);                  // streams in under the MFMAs below
+    if (active) {
+      const T* Kb = &Ks[BUF][k_off];
+      const T* Vb = &Vs[BUF][v_off];
+      f32x16 st[2];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[f][r] = 0.f;
+      // the two 32-key halves alternate: a 32x32x16 MFMA issues every 32 cycles but its accumulator is only back after
+      // 64 - one chain of four dependent MFMAs per half, interleaved, keeps the pipe busy
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kb + f * 32 * KS + 16 * ks);
+          st[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[f], 0, 0, 0);   // S^T[key][q]
+        }
+      if (__builtin_amdgcn_readfirstlane(tile_masked[BUF])) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 kb4 = *reinterpret_cast<const f32x4*>(&key_bias[BUF][f * 32 + 8 * g + 4 * hh]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st[f][4 * g + e] += kb4[e];
+          }
+      }
+      float mx = fmaxf(st[0][0], st[0][1]);
+#pragma unroll
+      for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, st[0][r]), st[0][r + 1]);      // v_max3_f32
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, st[1][r]), st[1][r + 1]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      // move the running maximum only when a row outgrows it by more than the threshold (NaN compares - an all-masked
+      // history, -inf - -inf - count as "move": the update below is the exact one)
+      const float m_cand = fmaxf(m_run, mx);
+      if (__any(!(m_cand - m_run <= ATTN_SELF_THR))) {
+        const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_cand);
+        m_run = m_cand;
+        l_run *= alpha;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[f][r] *= alpha;
+      }
+      const float neg_m = (m_run == -INFINITY) ? 0.f : -m_run * LOG2E;
+      f32x2 ls2 = {0.f, 0.f};
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 s2 = {st[f][r], st[f][r + 1]};
+          const f32x2 e2 = s2 * LOG2E + neg_m;
+          const f32x2 pv = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
+          ls2 += pv;
+          st[f][r] = pv[0];
+          st[f][r + 1] = pv[1];
+        }
+      float ls = ls2[0] + ls2[1];
+      if constexpr (DROP) {
+        const uint64_t base = row_base + (uint64_t)kt * KT;
+        if (tell_keep_row_ok(base >> 2, 16)) {
+          const TellKeepRow row = tell_keep_row(p.seed, salt_eff, base >> 2);    // S % 64 == 0: base is a multiple of 4
+          uint32_t x = row.x0;
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+              bool k0, k1, k2, k3;
+              tell_keep4_bits(x, row.y, p.thr, k0, k1, k2, k3);
+              st[f][r] = k0 ? st[f][r] : 0.f;
+              st[f][r + 1] = k1 ? st[f][r + 1] : 0.f;
+              st[f][r + 2] = k2 ? st[f][r + 2] : 0.f;
+              st[f][r + 3] = k3 ? st[f][r + 3] : 0.f;
+              x += 2u * TELL_QUAD_STRIDE;
+            }
+        } else {
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              float k0, k1;
+              tell_keep2(p.seed, salt_eff, base + (f * 32 + (r & 3) + 8 * (r >> 2)), p.thr, p.inv_keep, k0, k1);
+              st[f][r] = k0 != 0.f ? st[f][r] : 0.f;
+              st[f][r + 1] = k1 != 0.f ? st[f][r + 1] : 0.f;
+            }
+        }
+      }
+      ls += __shfl_xor(ls, 32, 64);
+      l_run += ls;
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          typedef __attribute__((ext_vector_type(4))) unsigned int pk4;
+          const pk4 w = {pack_bf16x2(st[f][8 * j], st[f][8 * j + 1]), pack_bf16x2(st[f][8 * j + 2], st[f][8 * j + 3]),
+                         pack_bf16x2(st[f][8 * j + 4], st[f][8 * j + 5]), pack_bf16x2(st[f][8 * j + 6], st[f][8 * j + 7])};
+          const bf16x8 pf = __builtin_bit_cast(bf16x8, w);
+          const T* vrow = Vb + (f * 32 + j * 16) * VS;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const bf16x8 vf = attn_tr_frag(vrow + dt * 32, vrow + 8 * VS + dt * 32);
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+          }
+        }
+    }
+    if ((ABL & 2) == 0 && kt + 1 < nkt) {
+      if constexpr (BUF == 0) rstore(kt + 1, B1{}); else rstore(kt + 1, B0{});
+    }
+    if ((ABL & 1) == 0) __syncthreads();
+  };
+  for (int kt = 0; kt < nkt; kt += 2) {
+    tile(kt, B0{});
+    if (kt + 1 < nkt) tile(kt + 1, B1{});
+  }
+  if (!active || t >= p.Tq) return;
+  const float inv_l = (l_run > 0.f ? 1.f / l_run : 0.f) * (DROP ? p.inv_keep : 1.f);
+  T* og = static_cast<T*>(p.out) + (long)t * p.o_st + (long)b * p.o_sb + (long)h * D;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
       const int d0 = dt * 32 + 8 * g + 4 * hh;
       uint2 w;
       w.x = pack_bf16x2(o[dt][4 * g] * inv_l, o[dt][4 * g + 1] * inv_l);
@@ -1162,8 +1401,20 @@ extern "C" int tell_attn_fwd(const void* q, const void* k, const void* v, void* 
   if (D == 64 && QB >= 4) {            // long sequences: shared 64-key tiles
     dim3 grid((QB + 3) / 4, B * H);
     static const int old_path = getenv("TELL_ATTN_TILE64") ? atoi(getenv("TELL_ATTN_TILE64")) : 0;   // A/B aid
+    static const bool self_env = !(getenv("TELL_ATTN_SELF") && atoi(getenv("TELL_ATTN_SELF")) == 0);      // A/B aid
+    if (dtype == TELL_BF16 && !old_path && self_env && !a.has_bias && !a.has_zero && S % 64 == 0 &&
+        (long)63 * k_ss + 64 < (1L << 31) && (long)63 * v_ss + 64 < (1L << 31)) {
+      if (false) {}
+      else if (a.thr) hipLaunchKernelGGL((attn_self_fwd_kernel<true>), grid, dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((attn_self_fwd_kernel<false>), grid, dim3(256), 0, stream, a);
+      return tell_check_launch("attn_self_fwd");
+    }
     if (dtype == TELL_BF16 && !old_path) {
-      if (a.thr) hipLaunchKernelGGL((attn_fwd_reg_kernel<true>), grid, dim3(256), 0, stream, a);
+      static const int occ = getenv("TELL_ATTN_OCC") ? atoi(getenv("TELL_ATTN_OCC")) : 2;     // A/B aid
+      if (occ == 3) {
+        if (a.thr) hipLaunchKernelGGL((attn_fwd_reg_kernel<true, 3>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((attn_fwd_reg_kernel<false, 3>), grid, dim3(256), 0, stream, a);
+      } else if (a.thr) hipLaunchKernelGGL((attn_fwd_reg_kernel<true>), grid, dim3(256), 0, stream, a);
       else hipLaunchKernelGGL((attn_fwd_reg_kernel<false>), grid, dim3(256), 0, stream, a);
       return tell_check_launch("attn_fwd_reg");
     } else if (dtype == TELL_BF16) {

@@ -41,6 +41,7 @@ struct GemmArgs {
   float asum_scale;
   unsigned long long* ts; // measurement aid: ts[0] = min over workgroups of the wall clock at entry, ts[1] = max at exit
   int atomic_out;         // fp32 output shared by several workgroups (split K): accumulate with hardware float atomics
+  int* queue;             // persistent ping-pong kernel: the launch's tile counter (zero between launches), or NULL
   // implicit convolution (direct-to-LDS kernel): A is not a matrix but the NHWC activation [B,H,W,Cin]; row m is output
   // pixel (b, oh, ow), K = KH*KW*Cin in (kh, kw, c) order - each 64-wide K tile lies inside one tap (Cin % 64 == 0), and
   // every lane's DMA source is the shifted input pixel (a 128-byte zero page for the padding ring): no im2col matrix
@@ -715,16 +716,45 @@ template <typename OutT>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
   constexpr int BM = 256, BN = 256, BK = 64;
   constexpr int HALF = 128 * 128, TILE = 4 * HALF;        // bytes: one half-tile image, one K tile (A0 A1 B0 B1)
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * TILE];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * TILE + 16];   // (+ the tile-queue broadcast word)
   gemm_ts_enter(p);
-  const int tid = threadIdx.x, lane = tid & 63, lh = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int M = p.M, N = p.N, K = p.K;
   const int tiles_n = N / BN, tiles_m = M / BM;
+  const int n_tiles = tiles_m * tiles_n;
+  // PERSISTENT when p.queue is set: gridDim.x <= #CUs workgroups pull tile indices from the launch's device counter
+  // until it runs past n_tiles.  A 256x256 workgroup needs a whole CU (128 KB of LDS, 2 x 228 registers per SIMD); as
+  // one workgroup per TILE it had to win a CU again for every tile against the small kernels of the other two streams
+  // of the step, and inside the timed region this kernel ran 1.7x slower than alone.  A resident workgroup keeps its CU
+  // for the whole GEMM; late starters simply take fewer tiles.  The very last fetch of a launch (value n_tiles +
+  // gridDim.x - 1: every workgroup fetches once past the end) zeroes the counter for the next launch that uses it.
+  int vb = blockIdx.x;
+  volatile int* sq = reinterpret_cast<volatile int*>(smem + 2 * TILE);
+  for (bool first = true;; first = false) {
+  // every lane-derived value (fragment offsets, DMA source offsets) is re-derived per tile from an opaque copy of the
+  // thread index: hoisted out of the tile loop they would have to survive the epilogue, whose staging needs every
+  // register - the allocator then spills INSIDE the main loop (79 registers, 2x slower: measured)
+  int tid = tid0;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, lh = lane >> 5;
+  if (p.queue) {
+    if (tid == 0) {
+      const int got = atomicAdd(p.queue, 1);
+      if (got == n_tiles + (int)gridDim.x - 1) atomicExch(p.queue, 0);
+      *sq = got;
+    }
+    __syncthreads();
+    vb = *sq;
+    __syncthreads();                                       // (the word is rewritten by the next fetch)
+    if (vb >= n_tiles) break;
+  } else if (!first) {
+    break;
+  }
   int tile_id;
   {
-    const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int nwg = n_tiles, orig = vb, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
   int tm, tn;
@@ -854,6 +884,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
   // every wave has passed its last phase: the tile buffers are free for the staged store
   glds_store_tile<BM, BN, 128, 64, 4, 2, BN, 512, 1>(acc, p, m0, n0, wr, wc, lane, tid,
                                                      reinterpret_cast<uint16_t*>(smem));
+  __syncthreads();                                        // staging area read out: the next tile may stream in
+  }
   gemm_ts_exit(p);
 }
 
@@ -1405,7 +1437,7 @@ __device__ __forceinline__ GemmArgs group_args(const GroupProblem& q) {
   p.A = q.A; p.B = q.B; p.C = q.C; p.bias = q.bias; p.aux = nullptr; p.m_dev = nullptr;
   p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc; p.M = q.M; p.N = q.N; p.K = q.K;
   p.bias_mode = q.bias_mode; p.act = q.act; p.accumulate = q.accumulate; p.alpha = q.alpha;
-  p.asum = q.asum; p.asum_scale = q.asum_scale; p.ts = nullptr; p.atomic_out = 0; p.conv_zero = nullptr;
+  p.asum = q.asum; p.asum_scale = q.asum_scale; p.ts = nullptr; p.atomic_out = 0; p.conv_zero = nullptr; p.queue = nullptr;
   p.stat_mean = nullptr; p.stat_m2 = nullptr;
   return p;
 }
@@ -1473,6 +1505,18 @@ static int launch_gemm_tx(const GemmArgs& a_in, hipStream_t stream) {
 // Which kernel a call runs is decided here and only here: every launch goes through TELL_GEMM_LAUNCH, which records a
 // readable label; tell_gemm_nt_plan() runs the same decision with the launch suppressed (bench.py's roofline block
 // names kernels by asking, not by mirroring the heuristics).
+// Tile counters of the persistent ping-pong launches: a caller-owned, zero-initialised int32 buffer registered once
+// (tell_gemm_set_tile_queue).  Every persistent launch takes the next slot; a launch leaves its slot zero again, so a
+// slot can be reused by any later launch that does not run concurrently with it - with thousands of slots that only
+// requires that no two launches 2^16 apart (in host issue / capture order) are in flight at once.
+static int* g_tile_queue = nullptr;
+static unsigned g_tile_queue_n = 0, g_tile_queue_next = 0;
+extern "C" int tell_gemm_set_tile_queue(void* counters, int n, hipStream_t) {
+  g_tile_queue = static_cast<int*>(counters);
+  g_tile_queue_n = n > 0 ? (unsigned)n : 0u;
+  if (!g_tile_queue_n) g_tile_queue = nullptr;
+  return TELL_OK;
+}
 static thread_local char g_gemm_label[96] = "";
 static thread_local bool g_gemm_plan = false;
 static const char* gemm_label(const char* base, int in_bf16, int out_bf16, int bm, int bn) {
@@ -1514,6 +1558,17 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
           return g_gemm_plan ? TELL_OK : tell_check_launch("gemm_nt_w4");
         }
         if (full && !no_pp && ((force == 0 && tiles(256, 256) % n_cu == 0) || (force == 8 && tiles(256, 256) >= n_cu))) {
+          // persistent form (tile queue registered, more than one tile per CU): one workgroup per CU pulls tiles
+          // MEASURED (MI355X, same box A/B, configs[2]): 1406 / 1420 samples/s without, 1415 / 1404 with; alone qkv 130.2 ->
+          // 125.6 us, the other shapes unchanged.  Holding the CU does not buy back the in-step slowdown - the other
+          // streams' kernels are work that has to run somewhere - so the form stays opt-in (TELL_GEMM_PERSIST=1).
+          static const bool persist_env = getenv("TELL_GEMM_PERSIST") && atoi(getenv("TELL_GEMM_PERSIST")) == 1;
+          if (persist_env && g_tile_queue && !g_gemm_plan && tiles(256, 256) > n_cu) {
+            GemmArgs ap = a;
+            ap.queue = g_tile_queue + (g_tile_queue_next++ % g_tile_queue_n);
+            hipLaunchKernelGGL((gemm_nt_pp_kernel<OutT>), dim3((unsigned)n_cu), dim3(512), 0, stream, ap);
+            return tell_check_launch("gemm_nt_pp");
+          }
           TELL_GEMM_LAUNCH(gemm_label("gemm_nt_pp_kernel", -1, sizeof(OutT) == 2, 256, 256), (gemm_nt_pp_kernel<OutT>), dim3((unsigned)tiles(256, 256)), dim3(512));
           return g_gemm_plan ? TELL_OK : tell_check_launch("gemm_nt_pp");
         }
@@ -1596,7 +1651,7 @@ extern "C" int tell_gemm_nt(const void* A, long lda, const void* B, long ldb, vo
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux; a.m_dev = m_dev;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
   a.bias_mode = bias_mode; a.act = act; a.accumulate = accumulate; a.alpha = alpha;
-  a.asum = nullptr; a.asum_scale = 0.f; a.stat_mean = nullptr; a.stat_m2 = nullptr; a.atomic_out = 0; a.ts = nullptr; a.conv_zero = nullptr;
+  a.asum = nullptr; a.asum_scale = 0.f; a.stat_mean = nullptr; a.stat_m2 = nullptr; a.atomic_out = 0; a.ts = nullptr; a.conv_zero = nullptr; a.queue = nullptr;
   if (g_gemm_ts_next && !g_gemm_plan) {
     a.ts = g_gemm_ts_next;
     g_gemm_ts_next = nullptr;
@@ -1646,7 +1701,7 @@ extern "C" int tell_gemm_bf16(const void* A, long lda, int trans_a, const void* 
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux; a.m_dev = m_dev;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
   a.bias_mode = bias_mode; a.act = act; a.accumulate = accumulate; a.alpha = alpha;
-  a.asum = a_colsum; a.asum_scale = a_colsum_scale; a.stat_mean = nullptr; a.stat_m2 = nullptr; a.atomic_out = 0; a.ts = nullptr; a.conv_zero = nullptr;
+  a.asum = a_colsum; a.asum_scale = a_colsum_scale; a.stat_mean = nullptr; a.stat_m2 = nullptr; a.atomic_out = 0; a.ts = nullptr; a.conv_zero = nullptr; a.queue = nullptr;
   if (trans_a && trans_b)
     return out_dtype == TELL_BF16 ? launch_gemm_tx<uint16_t, true, true>(a, stream) : launch_gemm_tx<float, true, true>(a, stream);
   if (trans_b)
@@ -1818,7 +1873,7 @@ extern "C" int tell_gemm_bn_stats(const void* A, long lda, const void* B, long l
   GemmArgs a;
   a.A = A; a.B = B; a.C = C; a.bias = nullptr; a.aux = nullptr; a.m_dev = nullptr;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
-  a.bias_mode = 0; a.act = 0; a.accumulate = 0; a.alpha = 1.f; a.asum = nullptr; a.asum_scale = 0.f; a.atomic_out = 0; a.ts = nullptr; a.conv_zero = nullptr;
+  a.bias_mode = 0; a.act = 0; a.accumulate = 0; a.alpha = 1.f; a.asum = nullptr; a.asum_scale = 0.f; a.atomic_out = 0; a.ts = nullptr; a.conv_zero = nullptr; a.queue = nullptr;
   const long max_tiles = ((long)M + 63) / 64;
   a.stat_mean = workspace;
   a.stat_m2 = workspace + max_tiles * N;
@@ -1862,7 +1917,7 @@ static int conv_launch(const void* X, const void* Wt, void* Y, int B, int H, int
   a.A = X; a.B = Wt; a.C = Y; a.bias = bias; a.aux = aux; a.m_dev = nullptr;
   a.lda = Cin; a.ldb = K; a.ldc = N; a.M = M; a.N = N; a.K = K;
   a.bias_mode = bias ? 1 : 0; a.act = act; a.accumulate = 0; a.alpha = 1.f; a.asum = nullptr; a.asum_scale = 0.f; a.atomic_out = 0;
-  a.ts = nullptr;
+  a.ts = nullptr; a.queue = nullptr;
   a.conv_zero = (KH == 1 && stride == 1) ? nullptr : zero_page;          // 1x1 / stride 1: A is the activation matrix
   a.conv_H = H; a.conv_W = W; a.conv_OH = OH; a.conv_OW = OW; a.conv_KW = KW; a.conv_stride = stride; a.conv_pad = pad;
   a.conv_cshift = cshift;

@@ -70,11 +70,18 @@ def lib():
     return _lib
 
 
+_tile_queue = {}
+
+
 def require_gpu():
     if not torch.cuda.is_available():
         raise RuntimeError('tell_amd: no HIP device visible (torch.cuda.is_available() is False); '
                            'the MI355X kernels have no CPU fallback')
     lib()
+    dev = torch.cuda.current_device()
+    if dev not in _tile_queue:            # work-queue counters of the persistent 256x256 GEMM launches (csrc/gemm.hip)
+        _tile_queue[dev] = torch.zeros(65536, dtype=torch.int32, device='cuda')
+        lib().tell_gemm_set_tile_queue(_tile_queue[dev].data_ptr(), 65536, None)
 
 
 def dt(t):
