@@ -435,6 +435,7 @@ def main():
                          'durations are then well defined - the mode of the roofline leg and of the committed '
                          'rocprofv3 kernel summaries')
     ap.add_argument('--generate', action='store_true', help='BASELINE configs[4]: caption generation throughput')
+    ap.add_argument('--no-generation', action='store_true', help='skip the configs[4] generation block of the default line')
     ap.add_argument('--beam', type=int, default=4, help='beam size of --generate (1 = greedy, what the reference does)')
     ap.add_argument('--roofline-steps', type=int, default=3,
                     help='extra single-stream steps after the timed region that time the GEMM kernels in isolation')
@@ -502,6 +503,27 @@ def main():
                                    'host_issue_ms_per_step': sec['host_issue_ms_per_step'],
                                    'step_mfma': sec['step_mfma'], 'steps': args.steps, 'warmup': args.warmup}
             del tr2
+        if world == 1 and args.model == 'faces_objects' and not args.no_generation and not args.serial \
+                and args.dtype == 'bf16':
+            # configs[4] in the same line: beam-4 (the config's metric) and greedy (what the reference decodes) caption
+            # generation of the full model, encoders included, 3 timed batches of 32 captions x 100 steps each
+            trainer = None
+            import gc
+            gc.collect()
+            tell_amd.ops.clear_weight_cache()
+            torch.cuda.empty_cache()
+            result['generation'] = {}
+            for beam in (4, 1):
+                ga = argparse.Namespace(**vars(args))
+                ga.batch, ga.beam, ga.steps, ga.warmup = 32, beam, 3, 2
+                g = generate_bench(ga, dev, world, rank, dist)
+                result['generation']['beam%d' % beam if beam > 1 else 'greedy'] = {
+                    'workload': g['config']['workload'], 'value': g['value'], 'unit': g['unit'],
+                    'ms_per_batch': g['ms_per_step'], 'steps': g['steps'], 'warmup': g['warmup'],
+                    'decode_steps': g['config']['decode_steps'], 'roofline': g['roofline']}
+                gc.collect()
+                tell_amd.ops.clear_weight_cache()
+                torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.model, args.cpu_sample)
         print(json.dumps(result))

@@ -211,6 +211,42 @@ int tell_transpose_multi(int n, const void* const* src, const long* ld_src, void
  * that is both the residual and, through the input dropout, the branch input (decoder_faces_objects.py:256-266). */
 int tell_dropout_add(const void* x, const void* add, void* out, long n, float p, uint32_t seed, uint32_t salt, int dtype,
                      tell_stream_t stream);
+/* ---- the generation step (transformer_faces_objects.py:443-494, decoder_faces_objects.py:224-352 at T = 1), csrc/decode.hip
+ * At M = batch x beam <= 128 rows every linear layer is a weight-streaming problem; these three replace the training
+ * kernels on that path (12 launches per decoder layer instead of ~24).
+ *
+ * tell_skinny_linear: out[p] = (act(prologue(in[p]) . w[p]^T + bias[p])) * scale + residual, n_prob <= 4 problems of one
+ * shape per launch (HOST arrays of n_prob pointers), bf16 weights [N (2N with GLU), K], M <= 128, K % 256 == 0.
+ *   pro 0: in bf16 [M,K].  pro 1: in fp32 [M,K] (a pre-norm `residual + branch`), LayerNorm(gamma[0], beta[0], eps) first;
+ *   stats_out (optional, [M][2] fp32) receives (mean, rstd) per row.  pro 2: one LayerNorm per `seg` columns of in
+ *   (gamma[s], beta[s], K / seg <= 4): the four LayerNorms that end the context block feeding context_fc.  pro 1 / 2 are
+ *   one extra launch into ws (bf16 [M,K], required then, NULL otherwise); all problems must read the same input; rows /
+ *   segments of 1024 .. 4096 columns.
+ *   act 0 none, 1 ReLU, 2 GLU (gate rows at n + N, fairseq's linear1 + F.glu, dynamic.py / decoder_faces_objects.py:229-233).
+ *   residual: res (bf16 [M,N], may be NULL) and / or LayerNorm(res_raw) rebuilt from res_stats ([M][2]), res_gamma, res_beta.
+ *   out bf16 or (out_f32) fp32 [M,N]. */
+int tell_skinny_linear(int n_prob, const void* const* in, long ld_in, int pro, const void* const* gamma,
+                       const void* const* beta, int seg, float eps, float* stats_out, void* ws, const void* const* w,
+                       long ldw, const void* const* bias, int act, float scale, const void* res, long ld_res,
+                       const float* res_raw, long ld_res_raw, const float* res_stats, const float* res_gamma,
+                       const float* res_beta, void* const* out, long ld_out, int out_f32, int M, int N, int K,
+                       tell_stream_t stream);
+/* y (bf16) = LayerNorm(x) of fp32 rows [M, C], C = 1024 .. 4096; stats_out (optional): (mean, rstd) per row [M][2]. */
+int tell_layernorm_rows(const float* x, long ld_x, const float* gamma, const float* beta, float eps, void* y, long ld_y,
+                        float* stats_out, int M, int C, tell_stream_t stream);
+/* DynamicConv1dTBC with an input buffer, one step (dynamic.py:85-120, :285-336 at T = 1): x [M,C] bf16, hist [K-1][M][C]
+ * bf16 (previous K-1 inputs, zero before the caption starts; shifted in place), wt [H*K, C] bf16 (weight_linear, no bias),
+ * y [M,C] bf16.  C = H * 64, K <= 32. */
+int tell_dynconv_step(const void* x, void* hist, const void* wt, void* y, int M, int C, int H, int K, tell_stream_t stream);
+/* MultiHeadAttention at Tq = 1 against n_ctx <= 4 static key / value caches in one launch (multi_head.py:330-352,
+ * :376-475): HOST arrays of n_ctx entries; q[c] / out[c] [B, H*64] with row strides q_sb / o_sb, element (b,s,h,d) of
+ * k[c] at k + s*k_ss + (b / beams)*k_sb + h*64 + d (the `beams` hypotheses of a sample - rows b*beams + j - share its
+ * cache), mask[c] [B / beams, S[c]] uint8 or NULL, bias_k[c] / bias_v[c] [H*64] (:355-364) or NULL, has_zero: the zero
+ * row (:416-421).  bf16, q pre-scaled, S <= 2048 (S = 0 allowed with a bias / zero row: the empty context :349-374). */
+int tell_attn_decode(int n_ctx, const void* const* q, const long* q_sb, const void* const* k, const long* k_ss,
+                     const long* k_sb, const void* const* v, const long* v_ss, const long* v_sb, const void* const* mask,
+                     const void* const* bias_k, const void* const* bias_v, int has_zero, const int* S, void* const* out,
+                     const long* o_sb, int B, int H, int beams, tell_stream_t stream);
 /* n LayerNorms over ONE residual in one launch each way - the end of a decoder layer's context block
    (decoder_faces_objects.py:283-352): y[:, i*C:(i+1)*C] = LayerNorm_i(res + dropout_p(x_i)), mean / rstd [n, rows].
    Backward: dx_i (entries may be NULL), dres = sum_i dz_i (may be NULL), dgamma_i / dbeta_i ACCUMULATED; partial is a

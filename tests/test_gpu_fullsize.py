@@ -229,6 +229,60 @@ def test_full_size_greedy_decode_bit_exact_fp32_and_bf16_agreement():
     assert results[torch.bfloat16] >= 0.9, results
 
 
+@pytest.mark.parametrize('beams', [1, 4, 16])
+def test_fused_decode_step_matches_layer_by_layer_step_and_fp32(beams):
+    """The generation step as weight-streaming launches (tell_amd/decode.py, csrc/decode.hip: skinny linears with
+    LayerNorm prologues, DynamicConv step, grouped one-query attention) against (a) the layer-by-layer bf16 step it
+    replaces and (b) the fp32 full-sequence decoder (itself bit-exact-greedy against the oracle above), teacher-forced
+    on the oracle's tokens.  beams > 1: the hypotheses of a sample (rows b*beams + j) share its K/V cache; M = 64 rows
+    (beams = 16) runs the 128-row kernel geometry."""
+    import tell_amd
+    from tell_amd import decode
+    from tell_amd.build import build_decoder
+    o = _oracle('faces_objects')
+    ctx, ids, _ = o['inputs']
+    STEPS = 8
+    seq = ids[:, :STEPS].to(DEV)
+    tell_amd.set_compute_dtype(torch.float32)
+    dec32 = build_decoder('faces_objects')
+    dec32.load_state_dict(o['sd'])
+    dec32.to(DEV).eval()
+    with torch.no_grad():
+        want = dec32({'roberta': seq}, _to_dev(ctx, torch.float32))[0].float()            # [B, STEPS, E]
+    del dec32
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    dec = build_decoder('faces_objects')
+    dec.load_state_dict(o['sd'])
+    dec.to(DEV).eval()
+    dctx = _to_dev(ctx, torch.bfloat16)
+    outs = {}
+    prev, prev_rows = decode.ENABLED, decode.MAX_ROWS
+    decode.MAX_ROWS = 128                  # (the default keeps > 32 rows on the MFMA layer-by-layer step: faster there)
+    try:
+        with torch.no_grad():
+            kv = dec.project_contexts(dctx)
+            for fused in (False, True):
+                decode.ENABLED = fused
+                state = dec.static_incremental_state(B * beams, DEV, torch.bfloat16)
+                xs = []
+                for i in range(STEPS):
+                    cur = seq[:, i:i + 1].repeat_interleave(beams, dim=0).contiguous()
+                    assert decode.usable(dec, torch.empty(1, B * beams, 1024, dtype=torch.bfloat16, device=DEV),
+                                         state, kv) == fused
+                    xs.append(dec({'roberta': cur}, dctx, incremental_state=state, kv_cache=kv)[0][:, 0].float())
+                outs[fused] = torch.stack(xs, 1)                                           # [B*beams, STEPS, E]
+    finally:
+        decode.ENABLED, decode.MAX_ROWS = prev, prev_rows
+    w = want.repeat_interleave(beams, dim=0)
+    e_fused, e_plain, e_pair = _rel(outs[True], w), _rel(outs[False], w), _rel(outs[True], outs[False])
+    print('\ndecode step, beams %d: fused vs fp32 %.3e, layer-by-layer vs fp32 %.3e, fused vs layer-by-layer %.3e'
+          % (beams, e_fused, e_plain, e_pair))
+    assert e_fused < BF16_OUT and e_fused < 1.25 * e_plain + 1e-3, (e_fused, e_plain)
+    if beams > 1:                                   # identical tokens, identical state: the rows of a sample agree
+        r = outs[True].view(B, beams, STEPS, -1)
+        assert torch.equal(r, r[:, :1].expand_as(r))
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # The shapes bench.py times, through the captured step graph.
 # B = 4 above runs the per-token GEMMs at M = 128 rows (register-staged 64x64 kernel); at B = 32 / 16 they have

@@ -1404,8 +1404,7 @@ extern "C" int tell_attn_fwd(const void* q, const void* k, const void* v, void* 
     static const bool self_env = !(getenv("TELL_ATTN_SELF") && atoi(getenv("TELL_ATTN_SELF")) == 0);      // A/B aid
     if (dtype == TELL_BF16 && !old_path && self_env && !a.has_bias && !a.has_zero && S % 64 == 0 &&
         (long)63 * k_ss + 64 < (1L << 31) && (long)63 * v_ss + 64 < (1L << 31)) {
-      if (false) {}
-      else if (a.thr) hipLaunchKernelGGL((attn_self_fwd_kernel<true>), grid, dim3(256), 0, stream, a);
+      if (a.thr) hipLaunchKernelGGL((attn_self_fwd_kernel<true>), grid, dim3(256), 0, stream, a);
       else hipLaunchKernelGGL((attn_self_fwd_kernel<false>), grid, dim3(256), 0, stream, a);
       return tell_check_launch("attn_self_fwd");
     }

@@ -1,0 +1,576 @@
+// The generation step (transformer_faces_objects.py:443-494: one new token per caption and step) as a short chain of
+// weight-streaming kernels.
+//
+// At M = B x beam <= 128 rows every linear layer of the decoder is a GEMV-class problem: 2-8 MB of weights read once,
+// a few MFLOP.  Run through the training GEMMs a decode step was 107 launches of 5-25 us - 16-64 workgroups walking
+// dependent K tiles, split-K partials folded by a second launch, GLU / dropout / LayerNorm / concatenation launches in
+// between - at 5-8 % of the HBM roofline.  Here a layer is 12 launches:
+//   skinny_gemm_kernel   out[M,N] = epilogue(in[M,K] . W[N,K]^T): every workgroup owns 4-16 output columns for ALL rows
+//                        and the whole reduction (256 workgroups stream the weight matrix exactly once, no partial
+//                        sums in memory, deterministic), the activation rows are staged in LDS once per workgroup.
+//                        Epilogues: bias, scale, ReLU, GLU (the gate column j + N travels with column j), residual
+//                        (bf16 rows, or LayerNorm of fp32 rows rebuilt from row statistics), bf16 or fp32 output.
+//                        Up to 4 problems per launch (the query / output projections of a layer's context attentions).
+//   ln_rows_kernel       LayerNorm of the fp32 `residual + branch` rows a producer left behind, to bf16, per 1024-column
+//                        segment (the four LayerNorms that end the context block, decoder_faces_objects.py:283-352, are
+//                        one launch).  Doing this inside the consumer's staging was measured: every one of its 256-512
+//                        workgroups then normalises all rows again (~1000 VALU instructions per wave and chunk,
+//                        +6 us per 1024 columns) - the 3 us launch wins.
+//   dynconv_step_kernel  the DynamicConv1dTBC step (dynamic.py:85-120 with an input buffer): tap logits of a head
+//                        (K x 1024 dot products), softmax over the taps, the K-tap sum over the buffered rows and the
+//                        buffer shift.
+//   attn_decode_kernel   the 2 / 4 one-query context attentions against the projected K/V cache, one launch.
+// VALU dot products (v_dot2_f32_bf16), not MFMA: the arithmetic is nothing (33 MFLOP per 1024 x 1024 layer at M = 32);
+// what matters is that all CUs pull weights at once and that a workgroup's chain of memory round trips is short.
+#include "common.h"
+#include "../../include/tell_hip.h"
+
+#define SK_MAXP 4
+struct SkinnyArgs {
+  const void* in[SK_MAXP];              // bf16 [M,K]
+  const uint16_t* w[SK_MAXP];           // bf16 [N (2N with GLU), K]
+  const float* bias[SK_MAXP];           // fp32 [N (2N)] or null
+  void* out[SK_MAXP];                   // bf16 or fp32 [M,N]
+  const float* gamma[SK_MAXP];          // ln_rows_kernel: one per column segment
+  const float* beta[SK_MAXP];
+  long ld_in, ldw, ld_out, ld_res, ld_res_raw;
+  float* stats_out;                     // ln_rows_kernel: (mean, rstd) per row, [M][2], or null
+  const uint16_t* res;                  // epilogue residual, bf16 [M,N] - or
+  const float* res_raw;                 //   LayerNorm(res_raw)[m][n] rebuilt from res_stats [M][2], res_gamma, res_beta
+  const float* res_stats; const float* res_gamma; const float* res_beta;
+  float eps, scale;
+  int M, N, K, seg, out_f32;
+};
+
+typedef __attribute__((ext_vector_type(2))) __bf16 sk_bf16x2;
+// Register arrays that live across a conditional (the prefetch of the next chunk) are native vectors: arrays of HIP's
+// uint4 / float4 structs assigned under a condition are not promoted to registers by the compiler (they go to scratch).
+typedef uint32_t sk_u4 __attribute__((ext_vector_type(4)));
+typedef float sk_f4 __attribute__((ext_vector_type(4)));
+template <typename VA, typename VB>
+__device__ __forceinline__ float sk_dot8(const VA& a, const VB& b, float acc) {
+#if __has_builtin(__builtin_amdgcn_fdot2_f32_bf16)
+  // (elements copied out first: __builtin_bit_cast applied directly to an ext-vector element expression reads .x for all)
+  const uint32_t a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w, b0 = b.x, b1 = b.y, b2 = b.z, b3 = b.w;
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(sk_bf16x2, a0), __builtin_bit_cast(sk_bf16x2, b0), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(sk_bf16x2, a1), __builtin_bit_cast(sk_bf16x2, b1), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(sk_bf16x2, a2), __builtin_bit_cast(sk_bf16x2, b2), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(sk_bf16x2, a3), __builtin_bit_cast(sk_bf16x2, b3), acc, false);
+#else
+  const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    acc = fmaf(__uint_as_float(aw[i] << 16), __uint_as_float(bw[i] << 16), acc);
+    acc = fmaf(__uint_as_float(aw[i] & 0xffff0000u), __uint_as_float(bw[i] & 0xffff0000u), acc);
+  }
+#endif
+  return acc;
+}
+
+// 64-lane sum on the VALU (DPP butterflies inside each row of 16 lanes, then the four row totals through SGPRs): the
+// LayerNorm prologues and the tap softmax issue dozens of these per workgroup; through ds_bpermute (__shfl_xor) each
+// is a chain of six LDS round trips.
+template <int CTRL>
+__device__ __forceinline__ float sk_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sk_wave_sum(float v) {
+  v += sk_dpp<0xB1>(v);        // quad_perm [1,0,3,2]
+  v += sk_dpp<0x4E>(v);        // quad_perm [2,3,0,1]
+  v += sk_dpp<0x141>(v);       // row_half_mirror
+  v += sk_dpp<0x140>(v);       // row_mirror
+  const int i = __builtin_bit_cast(int, v);
+  return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16))) +
+         (__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48)));
+}
+
+// MT: rows (padded), KC: K chunk staged in LDS, BN: output columns per workgroup, KS: k-slices.  256 threads = RG row
+// groups x KS k-slices; a thread accumulates an RM x BN tile (RM = MT / RG rows, every column of the workgroup) over the
+// 16-byte pieces {ks + KS * step} of each staged row: RM + BN LDS reads feed RM * BN * 4 dot2 instructions, consecutive
+// lanes read consecutive 16 bytes.  The KS partial tiles are folded through LDS (fixed order: deterministic).
+// ACT 0 none | 1 relu | 2 GLU.
+// Everything a chunk needs from memory is requested before anything waits on it (a workgroup is one dependent chain of
+// round trips: their count, not the bytes, is the kernel's duration), and the next chunk's requests fly under the dot
+// products of the current one.
+template <int MT, int KC, int BN, int KS, int ACT>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs p) {
+  constexpr int WR = ACT == 2 ? 2 * BN : BN;
+  constexpr int NA = MT * (KC / 8) / 256;                           // 16-byte activation pieces per thread
+  constexpr int NW = (WR * (KC / 8) + 255) / 256;                   // 16-byte weight pieces per thread
+  constexpr int RG = 256 / KS, RM = MT / RG;
+  constexpr int AS = KC + 8;                          // LDS row stride (elements): +16 bytes against bank conflicts
+  constexpr int STEPS = KC / 8 / KS;
+  static_assert(MT % RG == 0 && (KC / 8) % KS == 0, "geometry");
+  extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
+  uint16_t* As = reinterpret_cast<uint16_t*>(sk_smem);                 // [MT][AS]
+  uint16_t* Ws = As + MT * AS;                                         // [WR][AS]
+  float* red = reinterpret_cast<float*>(sk_smem);                      // [KS][MT][WR], after the last chunk
+  const int tid = threadIdx.x, prob = blockIdx.y, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * BN;
+  const int M = p.M, N = p.N, K = p.K;
+  const int ks = tid % KS, rg = tid / KS;
+  const uint16_t* W = p.w[prob];
+  sk_u4 ra[NA], rw[NW];               // the chunk in flight: activations, weights
+
+  auto request = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int c = tid + i * 256, r = (c / (KC / 8)) % WR, ch = c % (KC / 8);
+      int col = r < BN ? n0 + r : n0 + r - BN;                       // GLU: the gate rows live N rows further down
+      col = col < N ? col : N - 1;                                    // (columns past N: computed, never stored)
+      rw[i] = *reinterpret_cast<const sk_u4*>(W + (long)(r < BN ? col : N + col) * p.ldw + k0 + ch * 8);
+    }
+    const uint16_t* X = static_cast<const uint16_t*>(p.in[prob]);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int c = tid + i * 256, m = c / (KC / 8), ch = c % (KC / 8);
+      ra[i] = *reinterpret_cast<const sk_u4*>(X + (long)(m < M ? m : M - 1) * p.ld_in + k0 + ch * 8);
+    }
+  };
+  auto deposit = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int c = tid + i * 256, r = c / (KC / 8), ch = c % (KC / 8);
+      if (r < WR) *reinterpret_cast<sk_u4*>(Ws + r * AS + ch * 8) = rw[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int c = tid + i * 256, m = c / (KC / 8), ch = c % (KC / 8);
+      *reinterpret_cast<sk_u4*>(As + m * AS + ch * 8) = ra[i];
+    }
+  };
+
+  float acc[RM][WR];
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int c = 0; c < WR; ++c) acc[i][c] = 0.f;
+
+  request(0);
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    deposit(k0);
+    __syncthreads();
+    if (k0 + KC < K) request(k0 + KC);
+    // ---- this thread's pieces of the chunk
+#pragma unroll
+    for (int sp = 0; sp < STEPS; ++sp) {
+      const int kk = (ks + sp * KS) * 8;
+      sk_u4 av[RM], wv[WR];
+#pragma unroll
+      for (int i = 0; i < RM; ++i) av[i] = *reinterpret_cast<const sk_u4*>(As + (rg + i * RG) * AS + kk);
+#pragma unroll
+      for (int c = 0; c < WR; ++c) wv[c] = *reinterpret_cast<const sk_u4*>(Ws + c * AS + kk);
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int c = 0; c < WR; ++c) acc[i][c] = sk_dot8(av[i], wv[c], acc[i][c]);
+    }
+    __syncthreads();
+  }
+  // ---- fold the k-slices (the partial tiles overwrite the staged rows), epilogue
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int c = 0; c < WR; c += 4)
+      *reinterpret_cast<float4*>(red + ((long)ks * MT + rg + i * RG) * WR + c) =
+          make_float4(acc[i][c], acc[i][c + 1], acc[i][c + 2], acc[i][c + 3]);
+  __syncthreads();
+  for (int o = tid; o < MT * BN; o += 256) {
+    const int m = o / BN, c = o % BN, n = n0 + c;
+    float v = 0.f, g = 0.f;
+#pragma unroll 8
+    for (int q = 0; q < KS; ++q) {
+      v += red[((long)q * MT + m) * WR + c];
+      if constexpr (ACT == 2) g += red[((long)q * MT + m) * WR + BN + c];
+    }
+    if (m >= M || n >= N) continue;
+    const float* bias = p.bias[prob];
+    if (bias) v += bias[n];
+    if constexpr (ACT == 1) v = fmaxf(v, 0.f);
+    if constexpr (ACT == 2) {
+      if (bias) g += bias[N + n];
+      v = v / (1.f + __expf(-g));
+    }
+    v *= p.scale;
+    if (p.res) v += __uint_as_float((uint32_t)p.res[(long)m * p.ld_res + n] << 16);
+    if (p.res_raw)
+      v += (p.res_raw[(long)m * p.ld_res_raw + n] - p.res_stats[m * 2]) * p.res_stats[m * 2 + 1] * p.res_gamma[n] + p.res_beta[n];
+    if (p.out_f32) static_cast<float*>(p.out[prob])[(long)m * p.ld_out + n] = v;
+    else static_cast<uint16_t*>(p.out[prob])[(long)m * p.ld_out + n] = f2bf(v);
+  }
+}
+
+template <int MT, int KC, int BN, int KS, int ACT>
+static int skinny_launch(const SkinnyArgs& a, int n_prob, hipStream_t stream) {
+  constexpr int WR = ACT == 2 ? 2 * BN : BN;
+  constexpr size_t stage = (size_t)(MT + WR) * (KC + 8) * 2, fold = (size_t)KS * MT * WR * 4;   // (the fold reuses the stage)
+  const size_t smem = stage > fold ? stage : fold;
+  auto kern = skinny_gemm_kernel<MT, KC, BN, KS, ACT>;
+  static bool attr_done = false;
+  if (!attr_done && smem > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((a.N + BN - 1) / BN, n_prob), dim3(256), smem, stream, a);
+  return tell_check_launch("skinny_linear");
+}
+template <int MT, int KC, int BN, int KS>
+static int skinny_dispatch(const SkinnyArgs& a, int n_prob, int act, hipStream_t stream) {
+  if (act == 0) return skinny_launch<MT, KC, BN, KS, 0>(a, n_prob, stream);
+  if (act == 1) return skinny_launch<MT, KC, BN, KS, 1>(a, n_prob, stream);
+  return skinny_launch<MT, KC, BN, KS, 2>(a, n_prob, stream);
+}
+
+// LayerNorm of fp32 rows, one per `span` columns, to bf16 (the prologue as its own launch where the rows do not fit the
+// in-kernel form: M > 32).  grid (M, nseg), one workgroup per row segment.
+__global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, long ld_x, SkinnyArgs p, int span,
+                                                      uint16_t* __restrict__ y, long ld_y) {
+  __shared__ float redw[8];
+  const int m = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = x + (long)m * ld_x + (long)s * span;
+  const int nv = span / 1024;                       // float4 per thread (span: 1024 .. 4096)
+  sk_f4 v[4], gg[4], bb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (j < nv) {
+      v[j] = *reinterpret_cast<const sk_f4*>(row + tid * 4 + j * 1024);
+      gg[j] = *reinterpret_cast<const sk_f4*>(p.gamma[s] + tid * 4 + j * 1024);
+      bb[j] = *reinterpret_cast<const sk_f4*>(p.beta[s] + tid * 4 + j * 1024);
+    }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (j < nv) sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  sum = sk_wave_sum(sum);
+  if (lane == 0) redw[wave] = sum;
+  __syncthreads();
+  const float mean = ((redw[0] + redw[1]) + (redw[2] + redw[3])) / (float)span;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (j < nv) {
+      const float a0 = v[j].x - mean, a1 = v[j].y - mean, a2 = v[j].z - mean, a3 = v[j].w - mean;
+      sq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+  sq = sk_wave_sum(sq);
+  if (lane == 0) redw[4 + wave] = sq;
+  __syncthreads();
+  const float rstd = rsqrtf(((redw[4] + redw[5]) + (redw[6] + redw[7])) / (float)span + p.eps);
+  if (tid == 0 && p.stats_out && gridDim.y == 1) { p.stats_out[m * 2] = mean; p.stats_out[m * 2 + 1] = rstd; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (j < nv) {
+      uint2 o;
+      o.x = (uint32_t)f2bf((v[j].x - mean) * rstd * gg[j].x + bb[j].x) | ((uint32_t)f2bf((v[j].y - mean) * rstd * gg[j].y + bb[j].y) << 16);
+      o.y = (uint32_t)f2bf((v[j].z - mean) * rstd * gg[j].z + bb[j].z) | ((uint32_t)f2bf((v[j].w - mean) * rstd * gg[j].w + bb[j].w) << 16);
+      *reinterpret_cast<uint2*>(y + (long)m * ld_y + (long)s * span + tid * 4 + j * 1024) = o;
+    }
+}
+
+// LayerNorm of fp32 pre-norm rows [M, C] to bf16 (the decoder output of a generation step, in front of the softmax head).
+extern "C" int tell_layernorm_rows(const float* x, long ld_x, const float* gamma, const float* beta, float eps, void* y,
+                                   long ld_y, float* stats_out, int M, int C, hipStream_t stream) {
+  TELL_REQUIRE(M > 0 && C % 1024 == 0 && C <= 4096 && ld_x % 4 == 0 && ld_y % 4 == 0, "layernorm_rows: C = 1024 .. 4096");
+  SkinnyArgs a = {};
+  a.gamma[0] = gamma; a.beta[0] = beta; a.eps = eps; a.stats_out = stats_out;
+  hipLaunchKernelGGL(ln_rows_kernel, dim3(M, 1), dim3(256), 0, stream, x, ld_x, a, C, static_cast<uint16_t*>(y), ld_y);
+  return tell_check_launch("layernorm_rows");
+}
+
+// out[p] = epilogue(prologue(in[p]) . w[p]^T) for n_prob <= 4 problems of one shape (host arrays of n_prob pointers).
+//   pro 0: in bf16 [M,K];  1: in fp32 [M,K], LayerNorm(gamma[0], beta[0]) first (stats_out: optional [M][2]);
+//       2: in fp32 [M,K], one LayerNorm per `seg` columns first (gamma[s], beta[s]; K / seg <= 4).
+//      pro 1 / 2 are one extra launch into `ws` (bf16 [M,K], required then) ahead of the GEMM launch; all problems
+//      must read the same input; rows / segments of 1024 .. 4096 columns.
+//   act 0 none, 1 relu, 2 GLU (w [2N,K], bias [2N]: out = (a + b_a) * sigmoid(g + b_g), gate rows at n + N)
+//   out = (act(acc + bias)) * scale + residual;  residual: res (bf16 [M,N]) and / or LayerNorm(res_raw) from res_stats
+extern "C" int tell_skinny_linear(int n_prob, const void* const* in, long ld_in, int pro, const void* const* gamma,
+                                  const void* const* beta, int seg, float eps, float* stats_out, void* ws,
+                                  const void* const* w, long ldw, const void* const* bias, int act, float scale,
+                                  const void* res, long ld_res, const float* res_raw, long ld_res_raw,
+                                  const float* res_stats, const float* res_gamma, const float* res_beta,
+                                  void* const* out, long ld_out, int out_f32, int M, int N, int K, hipStream_t stream) {
+  TELL_REQUIRE(n_prob >= 1 && n_prob <= SK_MAXP && M >= 1 && M <= 128 && N >= 1 && K >= 256, "skinny_linear: bad shape");
+  TELL_REQUIRE(K % 256 == 0 && ldw % 8 == 0 && ld_in % 8 == 0, "skinny_linear: K % 256, 16-byte rows");
+  TELL_REQUIRE(pro >= 0 && pro <= 2 && act >= 0 && act <= 2, "skinny_linear: bad mode");
+  TELL_REQUIRE(pro != 2 || (seg > 0 && seg % 256 == 0 && K % seg == 0 && K / seg <= SK_MAXP), "skinny_linear: bad segments");
+  TELL_REQUIRE(!res_raw || (res_stats && res_gamma && res_beta), "skinny_linear: res_raw needs statistics and affine");
+  SkinnyArgs a;
+  for (int i = 0; i < SK_MAXP; ++i) {
+    const int j = i < n_prob ? i : 0;
+    a.in[i] = in[j]; a.w[i] = static_cast<const uint16_t*>(w[j]); a.bias[i] = bias ? static_cast<const float*>(bias[j]) : nullptr;
+    a.out[i] = out[j];
+    a.gamma[i] = a.beta[i] = nullptr;
+  }
+  const int nseg = pro == 2 ? K / seg : (pro == 1 ? 1 : 0);
+  for (int s = 0; s < nseg; ++s) {
+    TELL_REQUIRE(gamma && beta && gamma[s] && beta[s], "skinny_linear: LayerNorm prologue without gamma / beta");
+    a.gamma[s] = static_cast<const float*>(gamma[s]); a.beta[s] = static_cast<const float*>(beta[s]);
+  }
+  a.ld_in = ld_in; a.ldw = ldw; a.ld_out = ld_out; a.ld_res = ld_res; a.ld_res_raw = ld_res_raw;
+  a.stats_out = stats_out; a.res = static_cast<const uint16_t*>(res); a.res_raw = res_raw; a.res_stats = res_stats;
+  a.res_gamma = res_gamma; a.res_beta = res_beta; a.eps = eps; a.scale = scale; a.M = M; a.N = N; a.K = K;
+  a.seg = seg > 0 ? seg : K; a.out_f32 = out_f32;
+  if (pro != 0) {
+    TELL_REQUIRE((pro == 1 ? K : seg) % 1024 == 0 && (pro == 1 ? K : seg) <= 4096, "skinny_linear: LayerNorm over 1024 .. 4096 columns");
+    TELL_REQUIRE(ws, "skinny_linear: the LayerNorm prologue needs ws [M,K] bf16");
+    for (int i = 1; i < n_prob; ++i) TELL_REQUIRE(in[i] == in[0], "skinny_linear: separate prologue: one shared input");
+    const int span = pro == 1 ? K : seg;
+    hipLaunchKernelGGL(ln_rows_kernel, dim3(M, K / span), dim3(256), 0, stream, static_cast<const float*>(in[0]), ld_in,
+                       a, span, static_cast<uint16_t*>(ws), (long)K);
+    int rc = tell_check_launch("skinny_linear (LayerNorm rows)");
+    if (rc) return rc;
+    for (int i = 0; i < SK_MAXP; ++i) a.in[i] = ws;
+    a.ld_in = K; a.stats_out = nullptr;
+  }
+  // columns per workgroup: one round of workgroups over the 256 CUs where the layer allows
+  const int bn_env = getenv("TELL_SK_BN") ? atoi(getenv("TELL_SK_BN")) : 0;
+  const bool wide = bn_env ? bn_env == 8 : (long)N * n_prob >= 2048;
+  if (M <= 32 && K % 1024 == 0 && (bn_env ? bn_env == 16 : (long)N * n_prob >= 4096))
+    return skinny_dispatch<32, 1024, 16, 32>(a, n_prob, act, stream);
+  if (M <= 32) {
+    if (K % 1024 == 0) return wide ? skinny_dispatch<32, 1024, 8, 32>(a, n_prob, act, stream)
+                                   : skinny_dispatch<32, 1024, 4, 32>(a, n_prob, act, stream);
+    return wide ? skinny_dispatch<32, 256, 8, 32>(a, n_prob, act, stream)
+                : skinny_dispatch<32, 256, 4, 32>(a, n_prob, act, stream);
+  }
+  return skinny_dispatch<128, 256, 4, 16>(a, n_prob, act, stream);
+}
+
+// ------------------------------------------------------------------ DynamicConv step (T = 1, fixed K-1 row buffer)
+// x [M, C] bf16 (the GLU output of this step), hist [K-1][M][C] bf16 (the previous K-1 inputs, zero rows before the
+// caption starts), wt [H*K, C] bf16 (weight_linear).  One wave per (row m, head h), lane = channel d of the head:
+//   logits[k] = x[m,:] . wt[h*K + k,:]; taps = softmax_k(logits)            (dynamic.py:300-304, eval: no DropConnect)
+//   y[m, h*64 + d] = sum_k taps[k] * window[k][m, h*64 + d],  window = hist rows then x   (:306-336, causal)
+//   hist <- window[1:]                                                                   (:95-99)
+// One workgroup per (head, 4 rows): the head's K x C tap weights are staged in LDS once (all requests in flight
+// together), then one wave per row.
+__global__ __launch_bounds__(256) void dynconv_step_kernel(const uint16_t* __restrict__ x, uint16_t* hist,
+                                                           const uint16_t* __restrict__ wt, uint16_t* __restrict__ y,
+                                                           int M, int C, int H, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dc_smem[];
+  uint16_t* Wl = reinterpret_cast<uint16_t*>(dc_smem);                  // [K][C + 8]
+  const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = blockIdx.y * 4 + wave;
+  const int WS = C + 8, cpr = C / 8, total = K * cpr;
+  sk_u4 wreg[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = tid + i * 256;
+    if (c < total) wreg[i] = *reinterpret_cast<const sk_u4*>(wt + (long)(h * K + c / cpr) * C + (c % cpr) * 8);
+  }
+  const bool live = m < M;
+  const uint16_t* xr = x + (long)(live ? m : 0) * C;
+  const int nx = C / 512;                                               // 16-byte pieces of the row per lane (<= 4)
+  sk_u4 xv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (j < nx) xv[j] = *reinterpret_cast<const sk_u4*>(xr + lane * 8 + j * 512);
+  const int ch = h * 64 + lane;
+  const long plane = (long)M * C;
+  uint16_t hv[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) hv[k] = (live && k < K - 1) ? hist[k * plane + (long)m * C + ch] : (uint16_t)0;
+  const uint16_t cur = xr[ch];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = tid + i * 256;
+    if (c < total) *reinterpret_cast<sk_u4*>(Wl + (c / cpr) * WS + (c % cpr) * 8) = wreg[i];
+  }
+  __syncthreads();
+  if (!live) return;
+  float logit[32];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    logit[k] = 0.f;
+    if (k < K) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < nx) logit[k] = sk_dot8(xv[j], *reinterpret_cast<const sk_u4*>(Wl + k * WS + lane * 8 + j * 512), logit[k]);
+      logit[k] = sk_wave_sum(logit[k]);
+      mx = fmaxf(mx, logit[k]);
+    }
+  }
+  float den = 0.f;
+#pragma unroll
+  for (int k = 0; k < 32; ++k)
+    if (k < K) { logit[k] = __expf(logit[k] - mx); den += logit[k]; }
+  const float inv = 1.f / den;
+  float out = 0.f;
+  // window[k] = hist[k] for k < K-1, x for k = K-1; the shifted window is written back
+#pragma unroll
+  for (int k = 0; k < 32; ++k)
+    if (k < K - 1) {
+      out += logit[k] * inv * __uint_as_float((uint32_t)hv[k] << 16);
+      if (k > 0) hist[(k - 1) * plane + (long)m * C + ch] = hv[k];
+    }
+  float last = 0.f;
+#pragma unroll
+  for (int k = 0; k < 32; ++k)
+    if (k == K - 1) last = logit[k];
+  out += last * inv * __uint_as_float((uint32_t)cur << 16);
+  if (K > 1) hist[(long)(K - 2) * plane + (long)m * C + ch] = cur;
+  y[(long)m * C + ch] = f2bf(out);
+}
+extern "C" int tell_dynconv_step(const void* x, void* hist, const void* wt, void* y, int M, int C, int H, int K,
+                                 hipStream_t stream) {
+  TELL_REQUIRE(M > 0 && H > 0 && C == H * 64 && K >= 1 && K <= 32 && C % 512 == 0 && C <= 2048, "dynconv_step: head width 64, K <= 32");
+  const size_t smem = (size_t)K * (C + 8) * 2;
+  TELL_REQUIRE(K * (C / 8) <= 16 * 256 && smem <= 160 * 1024, "dynconv_step: tap weights of a head must fit LDS");
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dynconv_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(dynconv_step_kernel, dim3(H, (M + 3) / 4), dim3(256), smem, stream, (const uint16_t*)x, (uint16_t*)hist,
+                     (const uint16_t*)wt, (uint16_t*)y, M, C, H, K);
+  return tell_check_launch("dynconv_step");
+}
+
+// ------------------------------------------------------------------ one-query attention over up to 4 cached contexts
+// multi_head.py:376-475 at Tq = 1 against static keys / values (:330-352): scores = K q (q already scaled), key-padding
+// mask, fp32 softmax, P V.  The 32-row MFMA tile of the training kernel carries one real row here; this is a
+// bandwidth problem (the cached K and V of every (row, head) are read once per step), so: one workgroup per
+// (row, head, context), 8 lanes share a key (16 bytes of its 128 each - a wave load covers 8 keys = 1 KB contiguous),
+// scores parked in LDS, two passes.  The learned bias_k / bias_v row (:355-364) and the zero row (:416-421) are two more
+// keys after the S cached ones, never masked.  The `beams` hypotheses of a sample (rows b*beams + j) share its cache.
+#define AD_MAXS 2048
+struct AttnDecCtx {
+  const uint16_t *q, *k, *v; uint16_t* out; const uint8_t* mask;
+  const uint16_t *bias_k, *bias_v;      // [H*64] or null
+  long q_sb, k_ss, k_sb, v_ss, v_sb, o_sb;
+  int S, has_zero;
+};
+struct AttnDecArgs { AttnDecCtx c[SK_MAXP]; int B, H, beams; };
+
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecArgs g) {
+  const AttnDecCtx& p = g.c[blockIdx.y];
+  __shared__ float sc[AD_MAXS + 2];
+  __shared__ float redw[4];
+  __shared__ float part[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / g.H, h = blockIdx.x % g.H;
+  const int ks = lane >> 3, dc = lane & 7, S = p.S;
+  float q[8];
+  unpack16(*reinterpret_cast<const uint4*>(p.q + (long)b * p.q_sb + h * 64 + dc * 8), q, (const uint16_t*)nullptr);
+  const int bs = b / g.beams;
+  const uint16_t* kb = p.k + (long)bs * p.k_sb + h * 64 + dc * 8;
+  const uint16_t* vb = p.v + (long)bs * p.v_sb + h * 64 + dc * 8;
+  const uint8_t* mk = p.mask ? p.mask + (long)bs * S : nullptr;
+  const int ST = S + (p.bias_k ? 1 : 0) + p.has_zero;
+  const int S8 = (S + 7) & ~7;
+  for (int s0 = wave * 8; s0 < S8; s0 += 128) {            // 4 key groups per trip: their loads fly together
+    uint4 kr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s = s0 + u * 32 + ks;
+      kr[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (s < S) kr[u] = *reinterpret_cast<const uint4*>(kb + (long)s * p.k_ss);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s = s0 + u * 32 + ks;
+      float kf[8], d = 0.f;
+      unpack16(kr[u], kf, (const uint16_t*)nullptr);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d = fmaf(q[e], kf[e], d);
+      d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
+      if (dc == 0 && s < S) sc[s] = (mk && mk[s]) ? -INFINITY : d;
+    }
+  }
+  if (wave == 0) {
+    if (p.bias_k) {
+      float kf[8], d = 0.f;
+      unpack16(*reinterpret_cast<const uint4*>(p.bias_k + h * 64 + dc * 8), kf, (const uint16_t*)nullptr);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d = fmaf(q[e], kf[e], d);
+      d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
+      if (lane == 0) sc[S] = d;
+    }
+    if (p.has_zero && lane == 0) sc[ST - 1] = 0.f;
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int s = tid; s < ST; s += 256) mx = fmaxf(mx, sc[s]);
+  mx = wave_max(mx);
+  if (lane == 0) redw[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(redw[0], redw[1]), fmaxf(redw[2], redw[3]));
+  __syncthreads();
+  float l = 0.f;
+  for (int s = tid; s < ST; s += 256) {
+    const float e = mx == -INFINITY ? 0.f : __expf(sc[s] - mx);
+    sc[s] = e; l += e;
+  }
+  l = wave_sum(l);
+  if (lane == 0) redw[wave] = l;
+  __syncthreads();
+  l = (redw[0] + redw[1]) + (redw[2] + redw[3]);
+  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s0 = wave * 8; s0 < S8; s0 += 128) {
+    uint4 vr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s = s0 + u * 32 + ks;
+      vr[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (s < S) vr[u] = *reinterpret_cast<const uint4*>(vb + (long)s * p.v_ss);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s = s0 + u * 32 + ks;
+      float vf[8];
+      unpack16(vr[u], vf, (const uint16_t*)nullptr);
+      const float pr = s < S ? sc[s] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = fmaf(pr, vf[e], o[e]);
+    }
+  }
+  if (p.bias_v && wave == 0 && ks == 0) {
+    float vf[8];
+    unpack16(*reinterpret_cast<const uint4*>(p.bias_v + h * 64 + dc * 8), vf, (const uint16_t*)nullptr);
+    const float pr = sc[S];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = fmaf(pr, vf[e], o[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    o[e] += __shfl_xor(o[e], 8); o[e] += __shfl_xor(o[e], 16); o[e] += __shfl_xor(o[e], 32);
+  }
+  if (ks == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[wave][dc * 8 + e] = o[e];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const float v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+    p.out[(long)b * p.o_sb + h * 64 + tid] = f2bf(l > 0.f ? v / l : 0.f);
+  }
+}
+
+// n_ctx <= 4 contexts of one decode step in one launch (host arrays of n_ctx entries).  bf16, head width 64, Tq = 1.
+// q[c] [B, H*64] (row stride q_sb[c]), k[c] / v[c]: element (b / beams, s, h, d) at k + s*k_ss + (b/beams)*k_sb + h*64 + d,
+// mask[c] [B / beams, S[c]] uint8 or null, bias_k[c] / bias_v[c] [H*64] or null, out[c] [B, H*64] (row stride o_sb[c]).
+extern "C" int tell_attn_decode(int n_ctx, const void* const* q, const long* q_sb, const void* const* k, const long* k_ss,
+                                const long* k_sb, const void* const* v, const long* v_ss, const long* v_sb,
+                                const void* const* mask, const void* const* bias_k, const void* const* bias_v,
+                                int has_zero, const int* S, void* const* out, const long* o_sb, int B, int H, int beams,
+                                hipStream_t stream) {
+  TELL_REQUIRE(n_ctx >= 1 && n_ctx <= SK_MAXP && B > 0 && H > 0 && beams >= 1 && B % beams == 0, "attn_decode: 1-4 contexts");
+  AttnDecArgs g;
+  g.B = B; g.H = H; g.beams = beams;
+  for (int c = 0; c < SK_MAXP; ++c) {
+    const int j = c < n_ctx ? c : 0;
+    TELL_REQUIRE(S[j] >= 0 && S[j] <= AD_MAXS, "attn_decode: S <= 2048");
+    TELL_REQUIRE(S[j] + (bias_k && bias_k[j] ? 1 : 0) + has_zero >= 1, "attn_decode: no keys");
+    TELL_REQUIRE(q_sb[j] % 8 == 0 && k_ss[j] % 8 == 0 && k_sb[j] % 8 == 0 && v_ss[j] % 8 == 0 && v_sb[j] % 8 == 0,
+                 "attn_decode: 16-byte aligned rows");
+    g.c[c].q = (const uint16_t*)q[j]; g.c[c].k = (const uint16_t*)k[j]; g.c[c].v = (const uint16_t*)v[j];
+    g.c[c].out = (uint16_t*)out[j]; g.c[c].mask = mask ? (const uint8_t*)mask[j] : nullptr;
+    g.c[c].q_sb = q_sb[j]; g.c[c].k_ss = k_ss[j]; g.c[c].k_sb = k_sb[j]; g.c[c].v_ss = v_ss[j]; g.c[c].v_sb = v_sb[j];
+    g.c[c].o_sb = o_sb[j]; g.c[c].S = S[j]; g.c[c].has_zero = has_zero ? 1 : 0;
+    g.c[c].bias_k = bias_k ? (const uint16_t*)bias_k[j] : nullptr; g.c[c].bias_v = bias_v ? (const uint16_t*)bias_v[j] : nullptr;
+  }
+  hipLaunchKernelGGL(attn_decode_kernel, dim3(B * H, n_ctx), dim3(256), 0, stream, g);
+  return tell_check_launch("attn_decode");
+}

@@ -1,0 +1,164 @@
+"""One generation step of the DynamicConv decoders (decoder_faces_objects.py:224-352 / decoder_flattened.py at T = 1,
+driven by transformer_faces_objects.py:443-494) as 12 launches per layer - csrc/decode.hip.
+
+The training kernels treat a [1, M, E] step as a tiny GEMM problem; here every linear layer streams its weights once
+with all CUs (tell_skinny_linear), the producer of a LayerNorm input leaves `residual + branch` in fp32 and one small
+launch normalises it for the consumers, the DynamicConv step is one kernel (tell_dynconv_step) and the 2 / 4 context
+attentions are one launch against the projected K/V cache (tell_attn_decode).  Same arithmetic as the layer-by-layer
+path up to bf16 rounding points (pre-norm sums stay fp32 here); tests/test_gpu_fullsize.py bounds the difference.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import ops
+from .hip import call
+
+ENABLED = os.environ.get('TELL_DECODE_FUSED', '1') != '0'       # A/B aid: 0 = the layer-by-layer step
+# rows (batch x beam) up to which the weight-streaming step is used; above, the MFMA GEMMs of the layer-by-layer step are
+# faster (measured at 128 rows: 1.51 ms against 1.29 ms per step) - the kernels themselves take up to 128 rows
+MAX_ROWS = int(os.environ.get('TELL_DECODE_ROWS', '32'))
+
+
+def _ptrs(items):
+    return (ctypes.c_void_p * len(items))(*[(t.data_ptr() if torch.is_tensor(t) else (t or 0)) for t in items])
+
+
+def _longs(vals):
+    return (ctypes.c_long * len(vals))(*vals)
+
+
+def _ints(vals):
+    return (ctypes.c_int * len(vals))(*vals)
+
+
+def usable(dec, X, incremental_state, kv_cache):
+    """The fused step covers what the expt/ configs build: post-LN layers, GLU + DynamicConv with 64-wide heads,
+    bf16, eval, a static (fixed-shape) incremental state and projected K/V."""
+    if not (ENABLED and kv_cache is not None and incremental_state is not None and incremental_state.get('_static')):
+        return False
+    if dec.training or not X.is_cuda or X.dtype != torch.bfloat16 or ops.rt.compute_dtype() != torch.bfloat16:
+        return False
+    if X.shape[0] != 1 or X.shape[1] > MAX_ROWS or getattr(dec, 'normalize', False):
+        return False
+    E = X.shape[2]
+    for layer in dec.layers:
+        conv = layer.conv
+        if (layer.normalize_before or layer.need_attn or not layer.glu or type(conv).__name__ != 'DynamicConv1dTBC' or
+                layer.conv_dim != E or E % 512 or conv.num_heads * 64 != E or conv.kernel_size > 32 or
+                conv.weight_linear.bias is not None or not 1 <= len(layer.context_names) <= 4 or
+                layer.fc1.out_features % 256):
+            return False
+        for name in layer.context_names:
+            m = layer.context_attns[name]
+            if m.head_dim != 64 or m.bias_k is None or not m.add_zero_attn or kv_cache[0][name][0].shape[0] > 2048:
+                return False
+    return True
+
+
+def _skinny(ins, ld_in, ws, biases, outs, ld_out, M, N, K, pro=0, gammas=None, betas=None, seg=0, eps=1e-5,
+            stats_out=None, act=0, scale=1.0, res=None, ld_res=0, res_raw=None, res_stats=None, res_ln=None,
+            out_f32=False):
+    n = len(ins)
+    work = None
+    if pro:                                                              # LayerNorm rows as their own launch
+        work = torch.empty(M, K, dtype=torch.bfloat16, device=ws[0].device)
+    call('tell_skinny_linear', n, _ptrs(ins), ld_in, pro, _ptrs(gammas) if gammas else None,
+         _ptrs(betas) if betas else None, seg, eps, stats_out, work, _ptrs(ws), ws[0].stride(0),
+         _ptrs(biases) if biases is not None else None, act, scale, res, ld_res, res_raw,
+         res_raw.stride(0) if res_raw is not None else 0, res_stats,
+         res_ln.weight if res_ln is not None else None, res_ln.bias if res_ln is not None else None,
+         _ptrs(outs), ld_out, 1 if out_f32 else 0, M, N, K)
+
+
+def decoder_step(dec, X, contexts, state, kv_cache):
+    """X [1, M, E] bf16 (embedded tokens of this step) -> [1, M, E] bf16 after all layers; the DynamicConv input
+    buffers in `state` are shifted in place."""
+    M, E = X.shape[1], X.shape[2]
+    dev = X.device
+    x_bf = X.reshape(M, E)
+    raw_in, st_in, ln_in = None, None, None           # from layer 1 on: fp32 pre-norm rows of the previous layer
+    f32 = dict(dtype=torch.float32, device=dev)
+    bf = dict(dtype=torch.bfloat16, device=dev)
+    for li, layer in enumerate(dec.layers):
+        conv = layer.conv
+        C, H, K = layer.conv_dim, conv.num_heads, conv.kernel_size
+        names = layer.context_names
+        n = len(names)
+        mods = [layer.context_attns[nm] for nm in names]
+        # ---- conv block (:256-266): linear1 + GLU | tap projection, softmax, K-tap sum, buffer shift | linear2 + res
+        w1, _ = ops.wn_weight(layer.linear1.weight_g, layer.linear1.weight_v)
+        g = torch.empty(M, C, **bf)
+        if raw_in is None:
+            _skinny([x_bf], E, [w1], [layer.linear1.bias], [g], C, M, C, E, act=2)
+        else:
+            st_in = torch.empty(M, 2, **f32)
+            _skinny([raw_in], E, [w1], [layer.linear1.bias], [g], C, M, C, E, pro=1, gammas=[ln_in.weight],
+                    betas=[ln_in.bias], eps=ln_in.eps, stats_out=st_in, act=2)
+        c = torch.empty(M, C, **bf)
+        hist = state[conv._state_key]
+        assert hist.is_contiguous() and hist.shape[1] == M
+        call('tell_dynconv_step', g, hist, ops.weight(conv.weight_linear.weight), c, M, C, H, K)
+        w2, _ = ops.wn_weight(layer.linear2.weight_g, layer.linear2.weight_v)
+        raw3 = torch.empty(M, E, **f32)
+        if raw_in is None:
+            _skinny([c], C, [w2], [layer.linear2.bias], [raw3], E, M, E, C, res=x_bf, ld_res=E, out_f32=True)
+        else:
+            _skinny([c], C, [w2], [layer.linear2.bias], [raw3], E, M, E, C, res_raw=raw_in, res_stats=st_in,
+                    res_ln=ln_in, out_f32=True)
+        # ---- context block (:271-355): n query projections of LN(raw3) | n attentions | n output projections + LN(raw3)
+        ln3 = layer.conv_layer_norm
+        st3 = torch.empty(M, 2, **f32)
+        q_all = torch.empty(n, M, E, **bf)
+        wq, bq = [], []
+        for m in mods:
+            wp, rows = m._wrows(0)
+            wq.append(ops.weight(wp, rows))
+            bq.append(m.in_proj_bias.detach()[0:E])
+        _skinny([raw3] * n, E, wq, bq, [q_all[i] for i in range(n)], E, M, E, E, pro=1, gammas=[ln3.weight],
+                betas=[ln3.bias], eps=ln3.eps, stats_out=st3, scale=mods[0].scaling)
+        a_all = torch.empty(n, M, E, **bf)
+        ks, vs, k_ss, k_sb, v_ss, v_sb, masks, S, bk, bv = [], [], [], [], [], [], [], [], [], []
+        beams = 1
+        for i, (nm, m) in enumerate(zip(names, mods)):
+            k, v = kv_cache[li][nm]
+            if k.shape[0] == 0:                                     # empty context: bias and zero rows only
+                ks.append(q_all[i]); vs.append(q_all[i]); masks.append(None)
+                k_ss.append(0); k_sb.append(0); v_ss.append(0); v_sb.append(0); S.append(0)
+            else:
+                assert k.stride(2) == 1 and v.stride(2) == 1 and M % k.shape[1] == 0
+                beams = M // k.shape[1]
+                ks.append(k); vs.append(v)
+                k_ss.append(k.stride(0)); k_sb.append(k.stride(1)); v_ss.append(v.stride(0)); v_sb.append(v.stride(1))
+                S.append(k.shape[0])
+                mk = contexts.get(nm + '_mask')
+                if mk is not None and mk.dtype != torch.uint8:
+                    mk = mk.to(torch.uint8)
+                masks.append(mk.contiguous() if mk is not None else None)
+            bk.append(ops._bias_row(m.bias_k, torch.bfloat16))
+            bv.append(ops._bias_row(m.bias_v, torch.bfloat16))
+        call('tell_attn_decode', n, _ptrs([q_all[i] for i in range(n)]), _longs([E] * n), _ptrs(ks), _longs(k_ss),
+             _longs(k_sb), _ptrs(vs), _longs(v_ss), _longs(v_sb), _ptrs(masks), _ptrs(bk), _ptrs(bv), 1, _ints(S),
+             _ptrs([a_all[i] for i in range(n)]), _longs([E] * n), M, mods[0].num_heads, beams)
+        raw6 = torch.empty(M, n * E, **f32)
+        _skinny([a_all[i] for i in range(n)], E, [ops.weight(m.out_proj.weight) for m in mods],
+                [m.out_proj.bias for m in mods], [raw6[:, i * E:(i + 1) * E] for i in range(n)], n * E, M, E, E,
+                res_raw=raw3, res_stats=st3, res_ln=ln3, out_f32=True)
+        lns = [layer.context_attn_lns[nm] for nm in names]
+        wc, _ = ops.wn_weight(layer.context_fc.weight_g, layer.context_fc.weight_v)
+        x2 = torch.empty(M, E, **bf)
+        _skinny([raw6], n * E, [wc], [layer.context_fc.bias], [x2], E, M, E, n * E, pro=2,
+                gammas=[ln.weight for ln in lns], betas=[ln.bias for ln in lns], seg=E, eps=lns[0].eps)
+        # ---- FFN (:357-364)
+        F = layer.fc1.out_features
+        wf1, _ = ops.wn_weight(layer.fc1.weight_g, layer.fc1.weight_v)
+        wf2, _ = ops.wn_weight(layer.fc2.weight_g, layer.fc2.weight_v)
+        hmid = torch.empty(M, F, **bf)
+        _skinny([x2], E, [wf1], [layer.fc1.bias], [hmid], F, M, F, E, act=1)
+        raw9 = torch.empty(M, E, **f32)
+        _skinny([hmid], F, [wf2], [layer.fc2.bias], [raw9], E, M, E, F, res=x2, ld_res=E, out_f32=True)
+        raw_in, ln_in = raw9, layer.final_layer_norm
+    y = torch.empty(M, E, **bf)
+    call('tell_layernorm_rows', raw_in, E, ln_in.weight, ln_in.bias, ln_in.eps, y, E, None, M, E)
+    return y.view(1, M, E)

@@ -7,7 +7,7 @@ import torch.nn as nn
 
 import os
 
-from .. import blocks, ops
+from .. import blocks, decode, ops
 from ..common.registrable import Registrable
 from ..modules import AdaptiveSoftmax, DynamicConv1dTBC, GehringLinear, LightweightConv1dTBC, MultiHeadAttention
 from ..modules.token_embedders import AdaptiveEmbedding
@@ -233,6 +233,10 @@ class _DynamicConvDecoderBase(Decoder):
                 m = contexts.get(name + '_mask')
                 if torch.is_tensor(m) and m.dtype == torch.bool:
                     contexts[name + '_mask'] = m.to(torch.uint8).contiguous()
+        if not use_layers and decode.usable(self, X, incremental_state, kv_cache):
+            # generation: the whole layer stack of this step as weight-streaming launches (decode.py)
+            X = decode.decoder_step(self, X, contexts, incremental_state, kv_cache)
+            return X.transpose(0, 1), {'attn': [], 'inner_states': []}
         for i, layer in enumerate(self.layers):
             if not use_layers or i in use_layers:
                 X = ops.grad_ready_marker(X, 'decoder.layers.%d.' % i)    # DP: layer i's gradients are final here

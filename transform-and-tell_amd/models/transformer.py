@@ -405,7 +405,9 @@ class CaptionModel(Model):
                 'graph': None, 'counter': torch.zeros(1, dtype=torch.int32, device=dev),
                 'cur': torch.zeros(B, 1, dtype=torch.long, device=dev),
                 'kv': [{n: tuple(torch.empty_like(t) for t in pair) for n, pair in lk.items()} for lk in kv],
-                'ctx': {k: torch.empty_like(v) for k, v in contexts.items() if torch.is_tensor(v)},
+                # (key-padding masks as the uint8 the attention kernels read: converted once per caption batch)
+                'ctx': {k: torch.empty_like(v, dtype=torch.uint8 if v.dtype == torch.bool else v.dtype)
+                        for k, v in contexts.items() if torch.is_tensor(v)},
                 'state': dec.static_incremental_state(B, dev, dtype),
             }
             po = dec.embedder.token_embedder_position            # the table must already cover the longest caption
