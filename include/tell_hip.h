@@ -223,17 +223,29 @@ int tell_dropout_add(const void* x, const void* add, void* out, long n, float p,
  *   one extra launch into ws (bf16 [M,K], required then, NULL otherwise); all problems must read the same input; rows /
  *   segments of 1024 .. 4096 columns.
  *   act 0 none, 1 ReLU, 2 GLU (gate rows at n + N, fairseq's linear1 + F.glu, dynamic.py / decoder_faces_objects.py:229-233).
- *   residual: res (bf16 [M,N], may be NULL) and / or LayerNorm(res_raw) rebuilt from res_stats ([M][2]), res_gamma, res_beta.
- *   out bf16 or (out_f32) fp32 [M,N]. */
+ *   residual: res (bf16 [M,N]), LayerNorm(res_raw) rebuilt from res_stats ([M][2]), res_gamma, res_beta, res_f32 (fp32
+ *   [M,N]); each may be NULL.
+ *   out bf16 or (out_f32) fp32 [M,N]; out2 (optional, bf16): columns n >= out2_from of the result once more, at
+ *   out2[m][n - out2_from] (the softmax head: cluster logits in fp32 and the tails' projected inputs in bf16 from one
+ *   launch).  K % 256 == 0, or K % 64 == 0 for M <= 32. */
 int tell_skinny_linear(int n_prob, const void* const* in, long ld_in, int pro, const void* const* gamma,
                        const void* const* beta, int seg, float eps, float* stats_out, void* ws, const void* const* w,
                        long ldw, const void* const* bias, int act, float scale, const void* res, long ld_res,
                        const float* res_raw, long ld_res_raw, const float* res_stats, const float* res_gamma,
-                       const float* res_beta, void* const* out, long ld_out, int out_f32, int M, int N, int K,
+                       const float* res_beta, const float* res_f32, long ld_res_f32, void* out2, long ld_out2,
+                       int out2_from, void* const* out, long ld_out, int out_f32, int M, int N, int K,
                        tell_stream_t stream);
 /* y (bf16) = LayerNorm(x) of fp32 rows [M, C], C = 1024 .. 4096; stats_out (optional): (mean, rstd) per row [M][2]. */
 int tell_layernorm_rows(const float* x, long ld_x, const float* gamma, const float* beta, float eps, void* y, long ld_y,
                         float* stats_out, int M, int C, tell_stream_t stream);
+/* Front half of the step's token embedding (adaptive.py:61-76 + positional.py:167-211 at T = 1): cat[m] (bf16 [M, ktot])
+ * = the token's band-table row placed at columns off_b .. off_b + dim_b - 1 of its band b (zeros elsewhere), pos_out[m]
+ * (fp32 [M,E]) = the sinusoid row of this step (pad -> row pos_pad; offset start_pos + the captured step's device
+ * counter).  scale * (cat . [proj_0 | proj_1 | ..]^T) + pos_out - one tell_skinny_linear - is the embedding.
+ * tables / lo / hi / dim / off: HOST arrays of nb <= 4 bands (ids lo_b .. hi_b - 1). */
+int tell_embed_gather_step(const long* ids, int M, int nb, const void* const* tables, const int* lo, const int* hi,
+                           const int* dim, const int* off, void* cat, int ktot, const float* pos_table, int pos_rows,
+                           int pos_pad, int start_pos, float* pos_out, int E, tell_stream_t stream);
 /* DynamicConv1dTBC with an input buffer, one step (dynamic.py:85-120, :285-336 at T = 1): x [M,C] bf16, hist [K-1][M][C]
  * bf16 (previous K-1 inputs, zero before the caption starts; shifted in place), wt [H*K, C] bf16 (weight_linear, no bias),
  * y [M,C] bf16.  C = H * 64, K <= 32. */

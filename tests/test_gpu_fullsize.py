@@ -182,6 +182,38 @@ def test_full_vocabulary_argmax_bit_exact_fp32():
     torch.testing.assert_close(full, lp, rtol=1e-4, atol=2e-5)
 
 
+def test_generation_head_as_skinny_launches_matches_gemm_head_bf16():
+    """The bf16 greedy head of a generation step (tell_amd/decode.py head_step: one skinny linear for head logits +
+    cluster logits + the tails' projections, one per tail table, register-resident arg-max) against the GEMM head it
+    replaces, at the real vocabulary, with every cluster winning somewhere: log-probs within bf16-accumulation-order
+    noise, the same token wherever the two best log-probs are not a near tie."""
+    import tell_amd
+    from tell_amd import decode
+    from tell_amd.build import build_decoder
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(3)
+    dec = build_decoder('flattened')
+    asm = dec.adaptive_softmax
+    with torch.no_grad():
+        asm.head.class_proj.weight.mul_(6.0)
+    dec.to(DEV).eval()
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(32, 1, 1024, generator=g) * 2.0).to(DEV, torch.bfloat16)
+    prev = decode.ENABLED
+    try:
+        decode.ENABLED = False
+        tok0, lp0 = asm.greedy(x)
+        decode.ENABLED = True
+        tok1, lp1 = asm.greedy(x)
+    finally:
+        decode.ENABLED = prev
+    tok0, tok1, lp0, lp1 = tok0.reshape(-1).cpu(), tok1.reshape(-1).cpu(), lp0.reshape(-1).cpu(), lp1.reshape(-1).cpu()
+    assert len({int(i >= 5000) + int(i >= 20000) for i in tok1.tolist()}) == 3, 'all clusters should win somewhere'
+    torch.testing.assert_close(lp1, lp0, rtol=0, atol=2e-2)
+    same = tok0 == tok1
+    assert same.float().mean() >= 0.9 and bool(((lp0 - lp1).abs()[~same] < 2e-2).all()), (tok0, tok1)
+
+
 def test_full_size_greedy_decode_bit_exact_fp32_and_bf16_agreement():
     """The 4-context decoder at full size: (a) fp32 cached / graphed greedy ids == the oracle's reference-flow greedy
     ids, (b) the bf16 path under teacher forcing: fraction of positions whose arg-max equals the fp32 token (reported;

@@ -338,6 +338,127 @@ __global__ __launch_bounds__(1024) void logprob_argmax_kernel(LogProbArgs p) {
     if (p.token_lp) p.token_lp[i] = bv;
   }
 }
+// The same arg-max with every logit of the row in registers: all loads of a row are requested at once (the three-pass
+// form above is a chain of ~36 dependent load groups per row: 33 us of a 600 us decode step), the max / sum-exp /
+// arg-max passes then run over registers.  Same comparisons as above (v = logit - lse, lowest index wins a tie).
+// Capacity (float4 per thread x 1024 threads): head 2 (8192 logits), tails 4 / 8 / 2 (16384 / 32768 / 8192); rows start
+// on 16 bytes.  64 of the 128 registers a 1024-thread workgroup leaves each thread.
+__device__ constexpr int LPF_CAP[4] = {2, 4, 8, 2};
+__device__ constexpr int LPF_OFF[4] = {0, 2, 6, 14};
+__global__ __launch_bounds__(1024) void logprob_argmax_regs_kernel(LogProbArgs p) {
+  __shared__ float red[4][16];
+  __shared__ float best_v[16];
+  __shared__ int best_i[16];
+  const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nseg = 1 + p.n_tails;
+  const float* rowp[4]; int n[4];
+  rowp[0] = p.head + (long)i * p.ld_head; n[0] = p.head_n;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    rowp[c + 1] = c < p.n_tails ? p.tail[c] + (long)i * p.ld_tail[c] : rowp[0];
+    n[c + 1] = c < p.n_tails ? p.tail_n[c] : 0;
+  }
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 x[16];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int q = 0; q < LPF_CAP[s]; ++q) {
+      const int j = (q * 1024 + tid) * 4;
+      f4 v = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      if (j + 3 < n[s]) v = *reinterpret_cast<const f4*>(rowp[s] + j);
+      else if (j < n[s]) {
+        v.x = rowp[s][j];
+        if (j + 1 < n[s]) v.y = rowp[s][j + 1];
+        if (j + 2 < n[s]) v.z = rowp[s][j + 2];
+      }
+      x[LPF_OFF[s] + q] = v;
+    }
+  float mx[4], sm[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < LPF_CAP[s]; ++q) {
+      const f4 v = x[LPF_OFF[s] + q];
+      m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    m = wave_max(m);
+    if (lane == 0) red[s][wave] = m;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float m = red[s][0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, red[s][w]);
+    mx[s] = m;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float t = 0.f;
+    if (s < nseg) {
+#pragma unroll
+      for (int q = 0; q < LPF_CAP[s]; ++q) {
+        const f4 v = x[LPF_OFF[s] + q];
+        t += (__expf(v.x - mx[s]) + __expf(v.y - mx[s])) + (__expf(v.z - mx[s]) + __expf(v.w - mx[s]));
+      }
+    }
+    t = wave_sum(t);
+    if (lane == 0) red[s][wave] = t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[s][w];
+    sm[s] = t;
+  }
+  const float lse_h = mx[0] + __logf(sm[0]);
+  float bv = -INFINITY; int bi = 0x7fffffff;
+  auto consider = [&](float v, int j) { if (v > bv || (v == bv && j < bi)) { bv = v; bi = j; } };
+#pragma unroll
+  for (int q = 0; q < LPF_CAP[0]; ++q) {
+    const int j = (q * 1024 + tid) * 4;
+    if (j < p.c0) consider(x[q].x - lse_h, j);
+    if (j + 1 < p.c0) consider(x[q].y - lse_h, j + 1);
+    if (j + 2 < p.c0) consider(x[q].z - lse_h, j + 2);
+    if (j + 3 < p.c0) consider(x[q].w - lse_h, j + 3);
+  }
+  int base = p.c0;
+#pragma unroll
+  for (int s = 1; s < 4; ++s) {
+    if (s < nseg) {
+      const float off = (rowp[0][p.c0 + s - 1] - lse_h) - (mx[s] + __logf(sm[s]));
+#pragma unroll
+      for (int q = 0; q < LPF_CAP[s]; ++q) {
+        const int j = (q * 1024 + tid) * 4;
+        const f4 v = x[LPF_OFF[s] + q];
+        if (j < n[s]) consider(v.x + off, base + j);
+        if (j + 1 < n[s]) consider(v.y + off, base + j + 1);
+        if (j + 2 < n[s]) consider(v.z + off, base + j + 2);
+        if (j + 3 < n[s]) consider(v.w + off, base + j + 3);
+      }
+      base += n[s];
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) { best_v[wave] = bv; best_i[wave] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; ++w)
+      if (best_v[w] > bv || (best_v[w] == bv && best_i[w] < bi)) { bv = best_v[w]; bi = best_i[w]; }
+    if (p.token) p.token[i] = bi;
+    if (p.token_lp) p.token_lp[i] = bv;
+  }
+}
+
 // Top-k variant for beam search: per row the k best (log-prob, token) pairs of the adaptive softmax, sorted best
 // first, without materialising [rows, vocab] (a beam of k only ever needs each hypothesis' own k best tokens).
 // Every thread keeps its k best in registers while streaming the row; the block then pops the global best k times.
@@ -442,6 +563,16 @@ extern "C" int tell_adaptive_logprob_argmax(const float* head, long ld_head, int
   p.tail[1] = tail1; p.ld_tail[1] = ld1; p.tail_n[1] = n1;
   p.tail[2] = tail2; p.ld_tail[2] = ld2; p.tail_n[2] = n2;
   p.log_probs = log_probs; p.ld_lp = ld_lp; p.token = token; p.token_lp = token_lp;
+  const bool aligned = ld_head % 4 == 0 && ((uintptr_t)head % 16) == 0 &&
+                       (n_tails < 1 || (ld0 % 4 == 0 && ((uintptr_t)tail0 % 16) == 0)) &&
+                       (n_tails < 2 || (ld1 % 4 == 0 && ((uintptr_t)tail1 % 16) == 0)) &&
+                       (n_tails < 3 || (ld2 % 4 == 0 && ((uintptr_t)tail2 % 16) == 0));
+  static const bool regs_env = !(getenv("TELL_ARGMAX_REGS") && atoi(getenv("TELL_ARGMAX_REGS")) == 0);      // A/B aid
+  if (!log_probs && regs_env && aligned && p.head_n <= 2 * 4096 && (n_tails < 1 || n0 <= 4 * 4096) &&
+      (n_tails < 2 || n1 <= 8 * 4096) && (n_tails < 3 || n2 <= 2 * 4096)) {
+    hipLaunchKernelGGL(logprob_argmax_regs_kernel, dim3(rows), dim3(1024), 0, stream, p);
+    return tell_check_launch("logprob_argmax (registers)");
+  }
   hipLaunchKernelGGL(logprob_argmax_kernel, dim3(rows), dim3(1024), 0, stream, p);
   return tell_check_launch("logprob_argmax");
 }

@@ -38,6 +38,8 @@ struct SkinnyArgs {
   const uint16_t* res;                  // epilogue residual, bf16 [M,N] - or
   const float* res_raw;                 //   LayerNorm(res_raw)[m][n] rebuilt from res_stats [M][2], res_gamma, res_beta
   const float* res_stats; const float* res_gamma; const float* res_beta;
+  const float* res_f32; long ld_res_f32;   //   and / or fp32 rows [M,N]
+  uint16_t* out2; long ld_out2; int out2_from;   // columns n >= out2_from also as bf16 at out2[m][n - out2_from], or null
   float eps, scale;
   int M, N, K, seg, out_f32;
 };
@@ -195,6 +197,8 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs p) {
     if (p.res) v += __uint_as_float((uint32_t)p.res[(long)m * p.ld_res + n] << 16);
     if (p.res_raw)
       v += (p.res_raw[(long)m * p.ld_res_raw + n] - p.res_stats[m * 2]) * p.res_stats[m * 2 + 1] * p.res_gamma[n] + p.res_beta[n];
+    if (p.res_f32) v += p.res_f32[(long)m * p.ld_res_f32 + n];
+    if (p.out2 && n >= p.out2_from) p.out2[(long)m * p.ld_out2 + n - p.out2_from] = f2bf(v);
     if (p.out_f32) static_cast<float*>(p.out[prob])[(long)m * p.ld_out + n] = v;
     else static_cast<uint16_t*>(p.out[prob])[(long)m * p.ld_out + n] = f2bf(v);
   }
@@ -283,15 +287,17 @@ extern "C" int tell_layernorm_rows(const float* x, long ld_x, const float* gamma
 //      pro 1 / 2 are one extra launch into `ws` (bf16 [M,K], required then) ahead of the GEMM launch; all problems
 //      must read the same input; rows / segments of 1024 .. 4096 columns.
 //   act 0 none, 1 relu, 2 GLU (w [2N,K], bias [2N]: out = (a + b_a) * sigmoid(g + b_g), gate rows at n + N)
-//   out = (act(acc + bias)) * scale + residual;  residual: res (bf16 [M,N]) and / or LayerNorm(res_raw) from res_stats
+//   out = (act(acc + bias)) * scale + residual;  residual: res (bf16 [M,N]), LayerNorm(res_raw) from res_stats, res_f32
+//   out2 (optional): columns n >= out2_from of the result a second time, as bf16, at out2[m][n - out2_from]
 extern "C" int tell_skinny_linear(int n_prob, const void* const* in, long ld_in, int pro, const void* const* gamma,
                                   const void* const* beta, int seg, float eps, float* stats_out, void* ws,
                                   const void* const* w, long ldw, const void* const* bias, int act, float scale,
                                   const void* res, long ld_res, const float* res_raw, long ld_res_raw,
                                   const float* res_stats, const float* res_gamma, const float* res_beta,
+                                  const float* res_f32, long ld_res_f32, void* out2, long ld_out2, int out2_from,
                                   void* const* out, long ld_out, int out_f32, int M, int N, int K, hipStream_t stream) {
-  TELL_REQUIRE(n_prob >= 1 && n_prob <= SK_MAXP && M >= 1 && M <= 128 && N >= 1 && K >= 256, "skinny_linear: bad shape");
-  TELL_REQUIRE(K % 256 == 0 && ldw % 8 == 0 && ld_in % 8 == 0, "skinny_linear: K % 256, 16-byte rows");
+  TELL_REQUIRE(n_prob >= 1 && n_prob <= SK_MAXP && M >= 1 && M <= 128 && N >= 1 && K >= 64, "skinny_linear: bad shape");
+  TELL_REQUIRE((K % 256 == 0 || (K % 64 == 0 && M <= 32)) && ldw % 8 == 0 && ld_in % 8 == 0, "skinny_linear: K % 256 (K % 64 up to 32 rows), 16-byte rows");
   TELL_REQUIRE(pro >= 0 && pro <= 2 && act >= 0 && act <= 2, "skinny_linear: bad mode");
   TELL_REQUIRE(pro != 2 || (seg > 0 && seg % 256 == 0 && K % seg == 0 && K / seg <= SK_MAXP), "skinny_linear: bad segments");
   TELL_REQUIRE(!res_raw || (res_stats && res_gamma && res_beta), "skinny_linear: res_raw needs statistics and affine");
@@ -309,7 +315,8 @@ extern "C" int tell_skinny_linear(int n_prob, const void* const* in, long ld_in,
   }
   a.ld_in = ld_in; a.ldw = ldw; a.ld_out = ld_out; a.ld_res = ld_res; a.ld_res_raw = ld_res_raw;
   a.stats_out = stats_out; a.res = static_cast<const uint16_t*>(res); a.res_raw = res_raw; a.res_stats = res_stats;
-  a.res_gamma = res_gamma; a.res_beta = res_beta; a.eps = eps; a.scale = scale; a.M = M; a.N = N; a.K = K;
+  a.res_gamma = res_gamma; a.res_beta = res_beta; a.res_f32 = res_f32; a.ld_res_f32 = ld_res_f32;
+  a.out2 = static_cast<uint16_t*>(out2); a.ld_out2 = ld_out2; a.out2_from = out2_from; a.eps = eps; a.scale = scale; a.M = M; a.N = N; a.K = K;
   a.seg = seg > 0 ? seg : K; a.out_f32 = out_f32;
   if (pro != 0) {
     TELL_REQUIRE((pro == 1 ? K : seg) % 1024 == 0 && (pro == 1 ? K : seg) <= 4096, "skinny_linear: LayerNorm over 1024 .. 4096 columns");
@@ -331,6 +338,8 @@ extern "C" int tell_skinny_linear(int n_prob, const void* const* in, long ld_in,
   if (M <= 32) {
     if (K % 1024 == 0) return wide ? skinny_dispatch<32, 1024, 8, 32>(a, n_prob, act, stream)
                                    : skinny_dispatch<32, 1024, 4, 32>(a, n_prob, act, stream);
+    if (K % 256) return skinny_dispatch<32, 64, 16, 8>(a, n_prob, act, stream);       // short reductions: the tails' tables
+    if ((long)N * n_prob >= 4096) return skinny_dispatch<32, 256, 16, 32>(a, n_prob, act, stream);
     return wide ? skinny_dispatch<32, 256, 8, 32>(a, n_prob, act, stream)
                 : skinny_dispatch<32, 256, 4, 32>(a, n_prob, act, stream);
   }
@@ -573,4 +582,54 @@ extern "C" int tell_attn_decode(int n_ctx, const void* const* q, const long* q_s
   }
   hipLaunchKernelGGL(attn_decode_kernel, dim3(B * H, n_ctx), dim3(256), 0, stream, g);
   return tell_check_launch("attn_decode");
+}
+
+// ------------------------------------------------------------------ the step's token embedding, front half
+// adaptive.py:61-76 at T = 1: a token's embedding is proj_band . table_band[id - lo] with band-dependent width.  As ONE
+// skinny linear: row m of `cat` holds the token's table row in its band's column range (zeros elsewhere), the weight is
+// [proj_0 | proj_1 | ...] along K.  This kernel builds `cat` (bf16 [M, ktot]) and gathers the sinusoid rows
+// (positional.py:167-211: pad -> row pad_idx, else pad_idx + 1 + start_pos + device step) as the fp32 residual.
+struct EmbedStepArgs {
+  const uint16_t* table[4]; int lo[4], hi[4], dim[4], off[4];
+  int nb, ktot, E, pos_rows, pos_pad, start_pos;
+};
+__global__ __launch_bounds__(256) void embed_gather_step_kernel(const long* __restrict__ ids, EmbedStepArgs p,
+                                                                uint16_t* __restrict__ cat,
+                                                                const float* __restrict__ pos_table,
+                                                                float* __restrict__ pos_out,
+                                                                const uint32_t* __restrict__ step) {
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const long id = ids[m];
+  int band = -1;
+  for (int b = 0; b < p.nb; ++b)
+    if (id >= p.lo[b] && id < p.hi[b]) band = b;
+  uint16_t* dst = cat + (long)m * p.ktot;
+  const uint16_t* src = band >= 0 ? p.table[band] + (id - p.lo[band]) * p.dim[band] : nullptr;
+  const int c0 = band >= 0 ? p.off[band] : 0, c1 = band >= 0 ? c0 + p.dim[band] : 0;
+  for (int c = tid * 8; c < p.ktot; c += 2048) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (c >= c0 && c < c1) v = *reinterpret_cast<const uint4*>(src + (c - c0));
+    *reinterpret_cast<uint4*>(dst + c) = v;
+  }
+  int pos = id == p.pos_pad ? p.pos_pad : p.pos_pad + 1 + p.start_pos + (step ? (int)*step : 0);
+  if (pos >= p.pos_rows) pos = p.pos_rows - 1;
+  for (int c = tid * 4; c < p.E; c += 1024)
+    *reinterpret_cast<float4*>(pos_out + (long)m * p.E + c) = *reinterpret_cast<const float4*>(pos_table + (long)pos * p.E + c);
+}
+// ids [M] int64; nb <= 4 bands: tables[b] bf16 [hi_b - lo_b, dim_b] (dim_b % 8 == 0), band b covers ids lo_b .. hi_b - 1
+// and columns off_b .. off_b + dim_b - 1 of cat [M, ktot] (HOST arrays); pos_out fp32 [M, E].
+extern "C" int tell_embed_gather_step(const long* ids, int M, int nb, const void* const* tables, const int* lo, const int* hi,
+                                      const int* dim, const int* off, void* cat, int ktot, const float* pos_table,
+                                      int pos_rows, int pos_pad, int start_pos, float* pos_out, int E, hipStream_t stream) {
+  TELL_REQUIRE(M > 0 && nb >= 1 && nb <= 4 && ktot % 8 == 0 && E % 4 == 0, "embed_gather_step: bad shape");
+  EmbedStepArgs a;
+  for (int b = 0; b < 4; ++b) {
+    const int j = b < nb ? b : 0;
+    TELL_REQUIRE(dim[j] % 8 == 0 && off[j] % 8 == 0 && off[j] + dim[j] <= ktot, "embed_gather_step: 16-byte bands inside cat");
+    a.table[b] = static_cast<const uint16_t*>(tables[j]); a.lo[b] = lo[j]; a.hi[b] = hi[j]; a.dim[b] = dim[j]; a.off[b] = off[j];
+  }
+  a.nb = nb; a.ktot = ktot; a.E = E; a.pos_rows = pos_rows; a.pos_pad = pos_pad; a.start_pos = start_pos;
+  hipLaunchKernelGGL(embed_gather_step_kernel, dim3(M), dim3(256), 0, stream, ids, a, static_cast<uint16_t*>(cat), pos_table,
+                     pos_out, g_tell_pos_step);
+  return tell_check_launch("embed_gather_step");
 }

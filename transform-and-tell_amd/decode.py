@@ -59,7 +59,7 @@ def usable(dec, X, incremental_state, kv_cache):
 
 def _skinny(ins, ld_in, ws, biases, outs, ld_out, M, N, K, pro=0, gammas=None, betas=None, seg=0, eps=1e-5,
             stats_out=None, act=0, scale=1.0, res=None, ld_res=0, res_raw=None, res_stats=None, res_ln=None,
-            out_f32=False):
+            res_f32=None, out2=None, out2_from=0, out_f32=False):
     n = len(ins)
     work = None
     if pro:                                                              # LayerNorm rows as their own launch
@@ -69,7 +69,83 @@ def _skinny(ins, ld_in, ws, biases, outs, ld_out, M, N, K, pro=0, gammas=None, b
          _ptrs(biases) if biases is not None else None, act, scale, res, ld_res, res_raw,
          res_raw.stride(0) if res_raw is not None else 0, res_stats,
          res_ln.weight if res_ln is not None else None, res_ln.bias if res_ln is not None else None,
-         _ptrs(outs), ld_out, 1 if out_f32 else 0, M, N, K)
+         res_f32, res_f32.stride(0) if res_f32 is not None else 0, out2,
+         out2.stride(0) if out2 is not None else 0, out2_from, _ptrs(outs), ld_out, 1 if out_f32 else 0, M, N, K)
+
+
+def embed_usable(embedder, ids, incremental_state):
+    ad = embedder.token_embedder_adaptive
+    return (ENABLED and incremental_state is not None and incremental_state.get('_static') and not embedder.training and
+            ids.is_cuda and ids.shape[1] == 1 and ids.shape[0] <= MAX_ROWS and
+            ops.rt.compute_dtype() == torch.bfloat16 and len(ad.cutoff) <= 4 and ad.embed_size % 1024 == 0 and
+            all(s[0].weight.shape[1] % 8 == 0 for s in ad.embeddings))
+
+
+def embed_step(embedder, ids, start):
+    """scale * proj_band(table_band[id]) + sinusoid[position] of one token per row (sum_text_field_embedder.py:117-118 at
+    T = 1) as two launches: the table rows placed side by side by band, then ONE skinny linear against
+    [proj_0 | proj_1 | ..] with the scale and the sinusoid row in its epilogue.  -> [1, M, E] bf16."""
+    ad, po = embedder.token_embedder_adaptive, embedder.token_embedder_position
+    M, E = ids.shape[0], ad.embed_size
+    dims = [s[0].weight.shape[1] for s in ad.embeddings]
+    offs = [sum(dims[:i]) for i in range(len(dims))]
+    ktot = -(-sum(dims) // 1024) * 1024
+    lo = [0] + list(ad.cutoff[:-1])
+    projs = [s[1].weight for s in ad.embeddings]
+
+    def make():
+        w = torch.zeros(E, ktot, dtype=torch.bfloat16, device=ids.device)
+        for o, d, p in zip(offs, dims, projs):
+            w[:, o:o + d] = ops.weight(p)
+        return w
+    w_cat = ops._cached(projs[0], ('embed_cat',) + tuple((p._version, p.data_ptr()) for p in projs[1:]), make)
+    cat = torch.empty(M, ktot, dtype=torch.bfloat16, device=ids.device)
+    pos = torch.empty(M, E, dtype=torch.float32, device=ids.device)
+    call('tell_embed_gather_step', ids.reshape(M), M, len(dims), _ptrs([ops.weight(s[0].weight) for s in ad.embeddings]),
+         _ints(lo), _ints(list(ad.cutoff)), _ints(dims), _ints(offs), cat, ktot, po.weights, po.weights.shape[0],
+         int(po.padding_idx), int(start), pos, E)
+    out = torch.empty(M, E, dtype=torch.bfloat16, device=ids.device)
+    _skinny([cat], ktot, [w_cat], None, [out], E, M, E, ktot, scale=float(ad.embed_scale), res_f32=pos)
+    return out.view(1, M, E)
+
+
+def head_step(x2, cutoffs, emb0, class_proj, tails):
+    """Greedy head of a generation step (softmax.py:193-222 + topk(1)) as four launches: head logits | cluster logits |
+    the tails' projected inputs from ONE skinny linear over [emb_0; class_proj; proj_1; proj_2] (logits fp32, the
+    projections once more in bf16), one skinny linear per tail table, the register-resident arg-max.
+    -> (token int32 [N], log-prob fp32 [N], None)."""
+    N, E = x2.shape
+    dev = x2.device
+    c0, n_tails = cutoffs[0], len(tails) // 2
+    projs = [tails[2 * i] for i in range(n_tails)]
+    w_all = ops._cached(emb0, ('whead_all', class_proj._version, class_proj.data_ptr()) +
+                        tuple((p._version, p.data_ptr()) for p in projs),
+                        lambda: torch.cat([ops.weight(emb0), ops.weight(class_proj)] + [ops.weight(p) for p in projs],
+                                          dim=0).contiguous())
+    n_head = c0 + n_tails
+    n_all = w_all.shape[0]
+    ld = -(-n_all // 4) * 4
+    head = torch.empty(N, ld, dtype=torch.float32, device=dev)
+    hdims = [p.shape[0] for p in projs]
+    h = torch.empty(N, sum(hdims), dtype=torch.bfloat16, device=dev)
+    _skinny([x2], x2.stride(0), [w_all], None, [head], ld, N, n_all, E, out2=h, out2_from=n_head, out_f32=True)
+    tl, lds, ns = [None] * 3, [0] * 3, [0] * 3
+    off = 0
+    for i in range(n_tails):
+        emb = ops.weight(tails[2 * i + 1])
+        n_i = emb.shape[0]
+        lds[i], ns[i] = -(-n_i // 4) * 4, n_i
+        tl[i] = torch.empty(N, lds[i], dtype=torch.float32, device=dev)
+        if n_i * hdims[i] <= 4096 * 1024:
+            _skinny([h[:, off:off + hdims[i]]], h.stride(0), [emb], None, [tl[i]], lds[i], N, n_i, hdims[i], out_f32=True)
+        else:       # tens of MB of table: the MFMA GEMM's 64-column tiles re-read the rows 4x less often per weight byte
+            ops.gemm(h[:, off:off + hdims[i]], emb, out=tl[i][:, :n_i])
+        off += hdims[i]
+    token = torch.empty(N, dtype=torch.int32, device=dev)
+    token_lp = torch.empty(N, dtype=torch.float32, device=dev)
+    call('tell_adaptive_logprob_argmax', head, ld, c0, n_tails, tl[0], lds[0], ns[0], tl[1], lds[1], ns[1], tl[2], lds[2],
+         ns[2], N, None, 0, token, token_lp)
+    return token, token_lp, None
 
 
 def decoder_step(dec, X, contexts, state, kv_cache):

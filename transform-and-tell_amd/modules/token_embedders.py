@@ -135,6 +135,9 @@ class SumTextFieldEmbedder(TextFieldEmbedder):
         ids = text_field_input[src]
         B, T = ids.shape
         start = po.next_start(T, incremental_state)
+        from .. import decode
+        if decode.embed_usable(self, ids, incremental_state):          # generation step: two launches (decode.py)
+            return decode.embed_step(self, ids.contiguous(), start).transpose(0, 1)
         tbc = ops.adaptive_embed(ids, po.weights, ad.cutoff, ad.embed_scale, po.padding_idx, start,
                                  ad.padding_idx, ad.tables())
         return tbc.transpose(0, 1)            # [B,T,E] view of the decoder's T x B x C buffer
