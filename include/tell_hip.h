@@ -216,7 +216,7 @@ int tell_dropout_add(const void* x, const void* add, void* out, long n, float p,
  * kernels on that path (12 launches per decoder layer instead of ~24).
  *
  * tell_skinny_linear: out[p] = (act(prologue(in[p]) . w[p]^T + bias[p])) * scale + residual, n_prob <= 4 problems of one
- * shape per launch (HOST arrays of n_prob pointers), bf16 weights [N (2N with GLU), K], M <= 128, K % 256 == 0.
+ * shape per launch (HOST arrays of n_prob pointers), bf16 weights [N (2N with GLU), K], M <= 1024, K % 256 == 0.
  *   pro 0: in bf16 [M,K].  pro 1: in fp32 [M,K] (a pre-norm `residual + branch`), LayerNorm(gamma[0], beta[0], eps) first;
  *   stats_out (optional, [M][2] fp32) receives (mean, rstd) per row.  pro 2: one LayerNorm per `seg` columns of in
  *   (gamma[s], beta[s], K / seg <= 4): the four LayerNorms that end the context block feeding context_fc.  pro 1 / 2 are
@@ -227,7 +227,7 @@ int tell_dropout_add(const void* x, const void* add, void* out, long n, float p,
  *   [M,N]); each may be NULL.
  *   out bf16 or (out_f32) fp32 [M,N]; out2 (optional, bf16): columns n >= out2_from of the result once more, at
  *   out2[m][n - out2_from] (the softmax head: cluster logits in fp32 and the tails' projected inputs in bf16 from one
- *   launch).  K % 256 == 0, or K % 64 == 0 for M <= 32. */
+ *   launch). */
 int tell_skinny_linear(int n_prob, const void* const* in, long ld_in, int pro, const void* const* gamma,
                        const void* const* beta, int seg, float eps, float* stats_out, void* ws, const void* const* w,
                        long ldw, const void* const* bias, int act, float scale, const void* res, long ld_res,

@@ -289,7 +289,7 @@ def test_fused_decode_step_matches_layer_by_layer_step_and_fp32(beams):
     dctx = _to_dev(ctx, torch.bfloat16)
     outs = {}
     prev, prev_rows = decode.ENABLED, decode.MAX_ROWS
-    decode.MAX_ROWS = 128                  # (the default keeps > 32 rows on the MFMA layer-by-layer step: faster there)
+    decode.MAX_ROWS = 128
     try:
         with torch.no_grad():
             kv = dec.project_contexts(dctx)

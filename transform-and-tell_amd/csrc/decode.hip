@@ -5,12 +5,14 @@
 // a few MFLOP.  Run through the training GEMMs a decode step was 107 launches of 5-25 us - 16-64 workgroups walking
 // dependent K tiles, split-K partials folded by a second launch, GLU / dropout / LayerNorm / concatenation launches in
 // between - at 5-8 % of the HBM roofline.  Here a layer is 12 launches:
-//   skinny_gemm_kernel   out[M,N] = epilogue(in[M,K] . W[N,K]^T): every workgroup owns 4-16 output columns for ALL rows
-//                        and the whole reduction (256 workgroups stream the weight matrix exactly once, no partial
-//                        sums in memory, deterministic), the activation rows are staged in LDS once per workgroup.
+//   skinny_mfma_kernel   out[M,N] = epilogue(in[M,K] . W[N,K]^T): a workgroup owns 32 rows x 4-16 output columns and the
+//                        whole reduction (no partial sums in memory, deterministic); its 4 waves split K and load
+//                        their MFMA fragments straight from memory (no LDS staging, no barrier before the first
+//                        MFMA: the weight matrix is streamed exactly once with one round trip per wave).
 //                        Epilogues: bias, scale, ReLU, GLU (the gate column j + N travels with column j), residual
-//                        (bf16 rows, or LayerNorm of fp32 rows rebuilt from row statistics), bf16 or fp32 output.
-//                        Up to 4 problems per launch (the query / output projections of a layer's context attentions).
+//                        (bf16 rows, fp32 rows, or LayerNorm of fp32 rows rebuilt from row statistics), bf16 or fp32
+//                        output (+ a bf16 copy of the trailing columns).  Up to 4 problems per launch (the query /
+//                        output projections of a layer's context attentions).
 //   ln_rows_kernel       LayerNorm of the fp32 `residual + branch` rows a producer left behind, to bf16, per 1024-column
 //                        segment (the four LayerNorms that end the context block, decoder_faces_objects.py:283-352, are
 //                        one launch).  Doing this inside the consumer's staging was measured: every one of its 256-512
@@ -20,8 +22,9 @@
 //                        (K x 1024 dot products), softmax over the taps, the K-tap sum over the buffered rows and the
 //                        buffer shift.
 //   attn_decode_kernel   the 2 / 4 one-query context attentions against the projected K/V cache, one launch.
-// VALU dot products (v_dot2_f32_bf16), not MFMA: the arithmetic is nothing (33 MFLOP per 1024 x 1024 layer at M = 32);
-// what matters is that all CUs pull weights at once and that a workgroup's chain of memory round trips is short.
+// A first version of the linear ran on the VALU (v_dot2_f32_bf16) with the activation rows staged in LDS by every
+// workgroup: 256 workgroups re-reading 64-256 KB of rows each made it L2-bound (10-30 us per launch at 32-128 rows);
+// the register-direct MFMA form measures 5-8 us at 32 rows and 5-17 us at 128.
 #include "common.h"
 #include "../../include/tell_hip.h"
 
@@ -40,6 +43,7 @@ struct SkinnyArgs {
   const float* res_stats; const float* res_gamma; const float* res_beta;
   const float* res_f32; long ld_res_f32;   //   and / or fp32 rows [M,N]
   uint16_t* out2; long ld_out2; int out2_from;   // columns n >= out2_from also as bf16 at out2[m][n - out2_from], or null
+  int cn;                                  // mfma kernel: columns per workgroup (4 / 8 / 16)
   float eps, scale;
   int M, N, K, seg, out_f32;
 };
@@ -86,143 +90,135 @@ __device__ __forceinline__ float sk_wave_sum(float v) {
          (__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48)));
 }
 
-// MT: rows (padded), KC: K chunk staged in LDS, BN: output columns per workgroup, KS: k-slices.  256 threads = RG row
-// groups x KS k-slices; a thread accumulates an RM x BN tile (RM = MT / RG rows, every column of the workgroup) over the
-// 16-byte pieces {ks + KS * step} of each staged row: RM + BN LDS reads feed RM * BN * 4 dot2 instructions, consecutive
-// lanes read consecutive 16 bytes.  The KS partial tiles are folded through LDS (fixed order: deterministic).
-// ACT 0 none | 1 relu | 2 GLU.
-// Everything a chunk needs from memory is requested before anything waits on it (a workgroup is one dependent chain of
-// round trips: their count, not the bytes, is the kernel's duration), and the next chunk's requests fly under the dot
-// products of the current one.
-template <int MT, int KC, int BN, int KS, int ACT>
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs p) {
-  constexpr int WR = ACT == 2 ? 2 * BN : BN;
-  constexpr int NA = MT * (KC / 8) / 256;                           // 16-byte activation pieces per thread
-  constexpr int NW = (WR * (KC / 8) + 255) / 256;                   // 16-byte weight pieces per thread
-  constexpr int RG = 256 / KS, RM = MT / RG;
-  constexpr int AS = KC + 8;                          // LDS row stride (elements): +16 bytes against bank conflicts
-  constexpr int STEPS = KC / 8 / KS;
-  static_assert(MT % RG == 0 && (KC / 8) % KS == 0, "geometry");
+// ------------------------------------------------------------------ skinny linear on the matrix cores, register-direct
+// Up to 16 output columns per workgroup, the reduction split over its 4 waves; a wave loads its A (activation rows) and B
+// (weight rows) fragments of mfma_f32_16x16x32_bf16 straight from memory in the instruction's own layout - lane l holds
+// 8 consecutive k of row / column (l & 15) at k-group (l >> 4) - so there is no LDS staging, no barrier before the
+// first MFMA, and the whole K range of a wave can be in flight at once: one round trip, then RT x K/128 MFMAs, one LDS
+// fold of the 4 partial tiles, the epilogue.  (A and B use the same k placement, so the product does not depend on
+// the hardware's k order inside the instruction; C/D: column = lane & 15, row = (lane >> 4) * 4 + register.)
+// A workgroup covers 32 rows (blockIdx.z: row group) x cn <= 16 columns: with few column tiles (N = 1024: 64) a tile
+// is shared out over 2 or 4 workgroups by COLUMNS (cn = 8 / 4; the other lanes of the B fragment repeat a column and
+// their results are dropped) - every workgroup still owns its outputs entirely.  (Splitting the reduction over
+// workgroups instead, with a last-arriver fix-up, was measured: the device-scope fence it needs writes back the XCD's
+// L2 - 25 us per launch against 6.)
+// U: k-steps of 32 per batch of loads (two batches are in flight).
+typedef __attribute__((ext_vector_type(8))) __bf16 sk_bf16x8;
+__device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& p, int prob, int m, int n, float v, float g, int act) {
+  const int N = p.N;
+  const float* bias = p.bias[prob];
+  if (bias) v += bias[n];
+  if (act == 1) v = fmaxf(v, 0.f);
+  if (act == 2) {
+    if (bias) g += bias[N + n];
+    v = v / (1.f + __expf(-g));
+  }
+  v *= p.scale;
+  if (p.res) v += __uint_as_float((uint32_t)p.res[(long)m * p.ld_res + n] << 16);
+  if (p.res_raw)
+    v += (p.res_raw[(long)m * p.ld_res_raw + n] - p.res_stats[m * 2]) * p.res_stats[m * 2 + 1] * p.res_gamma[n] + p.res_beta[n];
+  if (p.res_f32) v += p.res_f32[(long)m * p.ld_res_f32 + n];
+  if (p.out2 && n >= p.out2_from) p.out2[(long)m * p.ld_out2 + n - p.out2_from] = f2bf(v);
+  if (p.out_f32) static_cast<float*>(p.out[prob])[(long)m * p.ld_out + n] = v;
+  else static_cast<uint16_t*>(p.out[prob])[(long)m * p.ld_out + n] = f2bf(v);
+}
+
+template <int ACT, int U>
+__global__ __launch_bounds__(256) void skinny_mfma_kernel(SkinnyArgs p) {
+  constexpr int RT = 2, NB = ACT == 2 ? 2 : 1, MT = RT * 16, CW = 16 * NB;
   extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
-  uint16_t* As = reinterpret_cast<uint16_t*>(sk_smem);                 // [MT][AS]
-  uint16_t* Ws = As + MT * AS;                                         // [WR][AS]
-  float* red = reinterpret_cast<float*>(sk_smem);                      // [KS][MT][WR], after the last chunk
+  float* red = reinterpret_cast<float*>(sk_smem);                      // [4 waves][MT][CW]
   const int tid = threadIdx.x, prob = blockIdx.y, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * BN;
-  const int M = p.M, N = p.N, K = p.K;
-  const int ks = tid % KS, rg = tid / KS;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int cn = p.cn, n0 = blockIdx.x * cn, m0 = blockIdx.z * MT, M = p.M, N = p.N, K = p.K;
+  const int kw = K / 4, nbatch = kw / (32 * U), kbeg = wave * kw;
+  const uint16_t* X = static_cast<const uint16_t*>(p.in[prob]);
   const uint16_t* W = p.w[prob];
-  sk_u4 ra[NA], rw[NW];               // the chunk in flight: activations, weights
-
-  auto request = [&](int k0) __attribute__((always_inline)) {
+  const uint16_t* ap[RT];
+  const uint16_t* bp[NB];
 #pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const int c = tid + i * 256, r = (c / (KC / 8)) % WR, ch = c % (KC / 8);
-      int col = r < BN ? n0 + r : n0 + r - BN;                       // GLU: the gate rows live N rows further down
-      col = col < N ? col : N - 1;                                    // (columns past N: computed, never stored)
-      rw[i] = *reinterpret_cast<const sk_u4*>(W + (long)(r < BN ? col : N + col) * p.ldw + k0 + ch * 8);
-    }
-    const uint16_t* X = static_cast<const uint16_t*>(p.in[prob]);
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int c = tid + i * 256, m = c / (KC / 8), ch = c % (KC / 8);
-      ra[i] = *reinterpret_cast<const sk_u4*>(X + (long)(m < M ? m : M - 1) * p.ld_in + k0 + ch * 8);
-    }
-  };
-  auto deposit = [&](int k0) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const int c = tid + i * 256, r = c / (KC / 8), ch = c % (KC / 8);
-      if (r < WR) *reinterpret_cast<sk_u4*>(Ws + r * AS + ch * 8) = rw[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int c = tid + i * 256, m = c / (KC / 8), ch = c % (KC / 8);
-      *reinterpret_cast<sk_u4*>(As + m * AS + ch * 8) = ra[i];
-    }
-  };
-
-  float acc[RM][WR];
-#pragma unroll
-  for (int i = 0; i < RM; ++i)
-#pragma unroll
-    for (int c = 0; c < WR; ++c) acc[i][c] = 0.f;
-
-  request(0);
-  for (int k0 = 0; k0 < K; k0 += KC) {
-    deposit(k0);
-    __syncthreads();
-    if (k0 + KC < K) request(k0 + KC);
-    // ---- this thread's pieces of the chunk
-#pragma unroll
-    for (int sp = 0; sp < STEPS; ++sp) {
-      const int kk = (ks + sp * KS) * 8;
-      sk_u4 av[RM], wv[WR];
-#pragma unroll
-      for (int i = 0; i < RM; ++i) av[i] = *reinterpret_cast<const sk_u4*>(As + (rg + i * RG) * AS + kk);
-#pragma unroll
-      for (int c = 0; c < WR; ++c) wv[c] = *reinterpret_cast<const sk_u4*>(Ws + c * AS + kk);
-#pragma unroll
-      for (int i = 0; i < RM; ++i)
-#pragma unroll
-        for (int c = 0; c < WR; ++c) acc[i][c] = sk_dot8(av[i], wv[c], acc[i][c]);
-    }
-    __syncthreads();
+  for (int rt = 0; rt < RT; ++rt) {
+    const int m = m0 + rt * 16 + lr;
+    ap[rt] = X + (long)(m < M ? m : M - 1) * p.ld_in + kbeg + lg * 8;
   }
-  // ---- fold the k-slices (the partial tiles overwrite the staged rows), epilogue
+  const int cl = n0 + (lr < cn ? lr : 0);                              // (lanes past cn repeat column n0: dropped)
+  const int col = cl < N ? cl : N - 1;                                  // (columns past N: computed, never stored)
 #pragma unroll
-  for (int i = 0; i < RM; ++i)
+  for (int b = 0; b < NB; ++b) bp[b] = W + (long)(b * N + col) * p.ldw + kbeg + lg * 8;
+  typedef float c4 __attribute__((ext_vector_type(4)));
+  c4 acc[RT][NB];
 #pragma unroll
-    for (int c = 0; c < WR; c += 4)
-      *reinterpret_cast<float4*>(red + ((long)ks * MT + rg + i * RG) * WR + c) =
-          make_float4(acc[i][c], acc[i][c + 1], acc[i][c + 2], acc[i][c + 3]);
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[rt][b] = c4{0.f, 0.f, 0.f, 0.f};
+  sk_u4 fa0[U][RT], fb0[U][NB], fa1[U][RT], fb1[U][NB];
+  auto load = [&](sk_u4 (&fa)[U][RT], sk_u4 (&fb)[U][NB], int batch) __attribute__((always_inline)) {
+    const int k = batch * 32 * U;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) fb[u][b] = *reinterpret_cast<const sk_u4*>(bp[b] + k + u * 32);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) fa[u][rt] = *reinterpret_cast<const sk_u4*>(ap[rt] + k + u * 32);
+    }
+  };
+  auto compute = [&](const sk_u4 (&fa)[U][RT], const sk_u4 (&fb)[U][NB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const sk_u4 bw = fb[u][b];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const sk_u4 aw = fa[u][rt];
+          acc[rt][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sk_bf16x8, aw), __builtin_bit_cast(sk_bf16x8, bw),
+                                                               acc[rt][b], 0, 0, 0);
+        }
+      }
+  };
+  load(fa0, fb0, 0);
+  int b = 0;
+  for (; b + 1 < nbatch; b += 2) {
+    load(fa1, fb1, b + 1);
+    compute(fa0, fb0);
+    if (b + 2 < nbatch) load(fa0, fb0, b + 2);
+    compute(fa1, fb1);
+  }
+  if (b < nbatch) compute(fa0, fb0);
+  // ---- fold the 4 waves' partial tiles, epilogue
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((long)wave * MT + rt * 16 + lg * 4 + r) * CW + nb * 16 + lr] = acc[rt][nb][r];
   __syncthreads();
-  for (int o = tid; o < MT * BN; o += 256) {
-    const int m = o / BN, c = o % BN, n = n0 + c;
-    float v = 0.f, g = 0.f;
-#pragma unroll 8
-    for (int q = 0; q < KS; ++q) {
-      v += red[((long)q * MT + m) * WR + c];
-      if constexpr (ACT == 2) g += red[((long)q * MT + m) * WR + BN + c];
-    }
-    if (m >= M || n >= N) continue;
-    const float* bias = p.bias[prob];
-    if (bias) v += bias[n];
-    if constexpr (ACT == 1) v = fmaxf(v, 0.f);
-    if constexpr (ACT == 2) {
-      if (bias) g += bias[N + n];
-      v = v / (1.f + __expf(-g));
-    }
-    v *= p.scale;
-    if (p.res) v += __uint_as_float((uint32_t)p.res[(long)m * p.ld_res + n] << 16);
-    if (p.res_raw)
-      v += (p.res_raw[(long)m * p.ld_res_raw + n] - p.res_stats[m * 2]) * p.res_stats[m * 2 + 1] * p.res_gamma[n] + p.res_beta[n];
-    if (p.res_f32) v += p.res_f32[(long)m * p.ld_res_f32 + n];
-    if (p.out2 && n >= p.out2_from) p.out2[(long)m * p.ld_out2 + n - p.out2_from] = f2bf(v);
-    if (p.out_f32) static_cast<float*>(p.out[prob])[(long)m * p.ld_out + n] = v;
-    else static_cast<uint16_t*>(p.out[prob])[(long)m * p.ld_out + n] = f2bf(v);
+  for (int o = tid; o < MT * 16; o += 256) {
+    const int r = o >> 4, c = o & 15, m = m0 + r, n = n0 + c;
+    if (c >= cn || m >= M || n >= N) continue;
+    const float v = (red[((long)0 * MT + r) * CW + c] + red[((long)1 * MT + r) * CW + c]) +
+                    (red[((long)2 * MT + r) * CW + c] + red[((long)3 * MT + r) * CW + c]);
+    float g = 0.f;
+    if constexpr (ACT == 2)
+      g = (red[((long)0 * MT + r) * CW + 16 + c] + red[((long)1 * MT + r) * CW + 16 + c]) +
+          (red[((long)2 * MT + r) * CW + 16 + c] + red[((long)3 * MT + r) * CW + 16 + c]);
+    skinny_epilogue(p, prob, m, n, v, g, ACT);
   }
 }
-
-template <int MT, int KC, int BN, int KS, int ACT>
-static int skinny_launch(const SkinnyArgs& a, int n_prob, hipStream_t stream) {
-  constexpr int WR = ACT == 2 ? 2 * BN : BN;
-  constexpr size_t stage = (size_t)(MT + WR) * (KC + 8) * 2, fold = (size_t)KS * MT * WR * 4;   // (the fold reuses the stage)
-  const size_t smem = stage > fold ? stage : fold;
-  auto kern = skinny_gemm_kernel<MT, KC, BN, KS, ACT>;
-  static bool attr_done = false;
-  if (!attr_done && smem > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(kern, dim3((a.N + BN - 1) / BN, n_prob), dim3(256), smem, stream, a);
-  return tell_check_launch("skinny_linear");
+template <int ACT, int U>
+static int skinny_mfma_launch(SkinnyArgs a, int n_prob, hipStream_t stream) {
+  constexpr size_t smem = (size_t)4 * 32 * 16 * (ACT == 2 ? 2 : 1) * 4;
+  const int groups = (a.M + 31) / 32;
+  const long tiles = (long)((a.N + 15) / 16) * n_prob * groups;
+  a.cn = tiles >= 192 ? 16 : (tiles >= 96 ? 8 : 4);          // at least ~256 workgroups where the layer has the columns
+  hipLaunchKernelGGL((skinny_mfma_kernel<ACT, U>), dim3((a.N + a.cn - 1) / a.cn, n_prob, groups), dim3(256), smem, stream, a);
+  return tell_check_launch("skinny_linear (mfma)");
 }
-template <int MT, int KC, int BN, int KS>
-static int skinny_dispatch(const SkinnyArgs& a, int n_prob, int act, hipStream_t stream) {
-  if (act == 0) return skinny_launch<MT, KC, BN, KS, 0>(a, n_prob, stream);
-  if (act == 1) return skinny_launch<MT, KC, BN, KS, 1>(a, n_prob, stream);
-  return skinny_launch<MT, KC, BN, KS, 2>(a, n_prob, stream);
+template <int U>
+static int skinny_mfma_dispatch(const SkinnyArgs& a, int n_prob, int act, hipStream_t stream) {
+  if (act == 0) return skinny_mfma_launch<0, U>(a, n_prob, stream);
+  if (act == 1) return skinny_mfma_launch<1, U>(a, n_prob, stream);
+  return skinny_mfma_launch<2, U>(a, n_prob, stream);
 }
 
 // LayerNorm of fp32 rows, one per `span` columns, to bf16 (the prologue as its own launch where the rows do not fit the
@@ -296,8 +292,8 @@ extern "C" int tell_skinny_linear(int n_prob, const void* const* in, long ld_in,
                                   const float* res_stats, const float* res_gamma, const float* res_beta,
                                   const float* res_f32, long ld_res_f32, void* out2, long ld_out2, int out2_from,
                                   void* const* out, long ld_out, int out_f32, int M, int N, int K, hipStream_t stream) {
-  TELL_REQUIRE(n_prob >= 1 && n_prob <= SK_MAXP && M >= 1 && M <= 128 && N >= 1 && K >= 64, "skinny_linear: bad shape");
-  TELL_REQUIRE((K % 256 == 0 || (K % 64 == 0 && M <= 32)) && ldw % 8 == 0 && ld_in % 8 == 0, "skinny_linear: K % 256 (K % 64 up to 32 rows), 16-byte rows");
+  TELL_REQUIRE(n_prob >= 1 && n_prob <= SK_MAXP && M >= 1 && M <= 1024 && N >= 1 && K >= 256, "skinny_linear: bad shape");
+  TELL_REQUIRE(K % 256 == 0 && ldw % 8 == 0 && ld_in % 8 == 0, "skinny_linear: K % 256, 16-byte rows");
   TELL_REQUIRE(pro >= 0 && pro <= 2 && act >= 0 && act <= 2, "skinny_linear: bad mode");
   TELL_REQUIRE(pro != 2 || (seg > 0 && seg % 256 == 0 && K % seg == 0 && K / seg <= SK_MAXP), "skinny_linear: bad segments");
   TELL_REQUIRE(!res_raw || (res_stats && res_gamma && res_beta), "skinny_linear: res_raw needs statistics and affine");
@@ -317,7 +313,7 @@ extern "C" int tell_skinny_linear(int n_prob, const void* const* in, long ld_in,
   a.stats_out = stats_out; a.res = static_cast<const uint16_t*>(res); a.res_raw = res_raw; a.res_stats = res_stats;
   a.res_gamma = res_gamma; a.res_beta = res_beta; a.res_f32 = res_f32; a.ld_res_f32 = ld_res_f32;
   a.out2 = static_cast<uint16_t*>(out2); a.ld_out2 = ld_out2; a.out2_from = out2_from; a.eps = eps; a.scale = scale; a.M = M; a.N = N; a.K = K;
-  a.seg = seg > 0 ? seg : K; a.out_f32 = out_f32;
+  a.seg = seg > 0 ? seg : K; a.out_f32 = out_f32; a.cn = 16;
   if (pro != 0) {
     TELL_REQUIRE((pro == 1 ? K : seg) % 1024 == 0 && (pro == 1 ? K : seg) <= 4096, "skinny_linear: LayerNorm over 1024 .. 4096 columns");
     TELL_REQUIRE(ws, "skinny_linear: the LayerNorm prologue needs ws [M,K] bf16");
@@ -330,20 +326,7 @@ extern "C" int tell_skinny_linear(int n_prob, const void* const* in, long ld_in,
     for (int i = 0; i < SK_MAXP; ++i) a.in[i] = ws;
     a.ld_in = K; a.stats_out = nullptr;
   }
-  // columns per workgroup: one round of workgroups over the 256 CUs where the layer allows
-  const int bn_env = getenv("TELL_SK_BN") ? atoi(getenv("TELL_SK_BN")) : 0;
-  const bool wide = bn_env ? bn_env == 8 : (long)N * n_prob >= 2048;
-  if (M <= 32 && K % 1024 == 0 && (bn_env ? bn_env == 16 : (long)N * n_prob >= 4096))
-    return skinny_dispatch<32, 1024, 16, 32>(a, n_prob, act, stream);
-  if (M <= 32) {
-    if (K % 1024 == 0) return wide ? skinny_dispatch<32, 1024, 8, 32>(a, n_prob, act, stream)
-                                   : skinny_dispatch<32, 1024, 4, 32>(a, n_prob, act, stream);
-    if (K % 256) return skinny_dispatch<32, 64, 16, 8>(a, n_prob, act, stream);       // short reductions: the tails' tables
-    if ((long)N * n_prob >= 4096) return skinny_dispatch<32, 256, 16, 32>(a, n_prob, act, stream);
-    return wide ? skinny_dispatch<32, 256, 8, 32>(a, n_prob, act, stream)
-                : skinny_dispatch<32, 256, 4, 32>(a, n_prob, act, stream);
-  }
-  return skinny_dispatch<128, 256, 4, 16>(a, n_prob, act, stream);
+  return K % 1024 == 0 ? skinny_mfma_dispatch<8>(a, n_prob, act, stream) : skinny_mfma_dispatch<2>(a, n_prob, act, stream);
 }
 
 // ------------------------------------------------------------------ DynamicConv step (T = 1, fixed K-1 row buffer)

@@ -16,9 +16,9 @@ from . import ops
 from .hip import call
 
 ENABLED = os.environ.get('TELL_DECODE_FUSED', '1') != '0'       # A/B aid: 0 = the layer-by-layer step
-# rows (batch x beam) up to which the weight-streaming step is used; above, the MFMA GEMMs of the layer-by-layer step are
-# faster (measured at 128 rows: 1.51 ms against 1.29 ms per step) - the kernels themselves take up to 128 rows
-MAX_ROWS = int(os.environ.get('TELL_DECODE_ROWS', '32'))
+# rows (batch x beam) up to which the weight-streaming step is used (measured at 32 and 128 rows: 0.51 / 1.07 ms per step
+# against 0.83 / 1.29 ms layer by layer); larger batches are GEMM-shaped again
+MAX_ROWS = int(os.environ.get('TELL_DECODE_ROWS', '128'))
 
 
 def _ptrs(items):
@@ -136,7 +136,7 @@ def head_step(x2, cutoffs, emb0, class_proj, tails):
         n_i = emb.shape[0]
         lds[i], ns[i] = -(-n_i // 4) * 4, n_i
         tl[i] = torch.empty(N, lds[i], dtype=torch.float32, device=dev)
-        if n_i * hdims[i] <= 4096 * 1024:
+        if n_i * hdims[i] <= 4096 * 1024 and hdims[i] % 256 == 0:
             _skinny([h[:, off:off + hdims[i]]], h.stride(0), [emb], None, [tl[i]], lds[i], N, n_i, hdims[i], out_f32=True)
         else:       # tens of MB of table: the MFMA GEMM's 64-column tiles re-read the rows 4x less often per weight byte
             ops.gemm(h[:, off:off + hdims[i]], emb, out=tl[i][:, :n_i])
