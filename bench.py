@@ -210,6 +210,8 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
     sync()
     if want_prof:
         prof.reset_records()
+    if world > 1:
+        trainer.dp_timing = []
     dec_ev = []
     t0 = time.perf_counter()
     loss = None
@@ -242,12 +244,26 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
            'step_graph_replays': graph_replays, 'skipped_steps': trainer.skipped_steps(),
            'resnet_hipgraph': sorted({e['state'] for e in getattr(model.__dict__.get('_resnet_graph'),
                                                                   'entries', {}).values()})}
+    if world > 1:
+        # the gradient exchange of every timed step on this rank (HIP events on the update stream), max over ranks
+        times = trainer.dp_times()
+        tt = torch.tensor([sum(a for a, _ in times) / max(len(times), 1), sum(b for _, b in times) / max(len(times), 1)],
+                          dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        res['dp'] = {'allreduce_ms': round(float(tt[0]), 3), 'exposed_allreduce_ms': round(float(tt[1]), 3),
+                     'wire_dtype': str(trainer.allreduce_dtype).replace('torch.', ''),
+                     'gradient_mbytes': round(trainer.flat.total * (2 if trainer.allreduce_dtype == torch.bfloat16 else 4)
+                                              / 1e6, 1),
+                     'bucketed_during_backward': trainer.bucketed_reduces > 0,
+                     'note': 'per step, max over ranks; exposed = the update stream idle-waiting for the last bucket '
+                             '(the next batch\'s encoder streams keep running underneath)'}
     gf = GF[model_name]
     tf = (gf['encoders'] + gf['decoder']) * 1e-3 * world * batch_size / (ms * 1e-3)
     res['step_mfma'] = {'gflop_per_sample': gf['encoders'] + gf['decoder'], 'achieved': round(tf, 1),
                         'peak': 2500.0 * world, 'unit': 'TFLOP/s', 'frac': round(tf / (2500.0 * world), 4)}
-    if not (want_prof and rank == 0):
+    if not want_prof:
         return res, trainer
+    # (with several ranks EVERY rank runs the legs below - their steps contain the gradient exchange - rank 0 reports)
     # ---- decoder-only step (the number north_star sets its MFMA target on): the decoder half alone on an idle GPU
     #      (encoder outputs already there), HIP events on its stream; and the same half inside the timed region,
     #      where it shares the CUs with the next batch's encoders

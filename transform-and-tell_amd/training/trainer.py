@@ -105,6 +105,10 @@ class Trainer:
         if capture_after is not None and hasattr(model, 'set_capture_after'):
             model.set_capture_after(capture_after)                 # the encoder graphs follow the same policy
         self.bucketed_reduces = 0
+        # dp_timing = []: every update then records three events on the update's stream - before the exchange is
+        # handed to RCCL, after (casts + collective launches issued), and after the stream has waited for the last
+        # bucket; dp_times() turns them into (allreduce_ms, exposed_allreduce_ms) per step
+        self.dp_timing = None
         self._test_reduce_scale = None              # tests: emulate world_size 2 with identical ranks (x2 after a reduce)
         # The bucketed exchange needs Python inside backward, i.e. the eager schedule: it is used when the step graph is
         # off (TELL_STEP_GRAPH=0); with the graph the exchange follows backward and hides under the next batch's encoders
@@ -141,6 +145,16 @@ class Trainer:
             self._start_reduce(*rng_)
         self._reduced.append(rng_)
         self.bucketed_reduces += 1
+
+    def dp_times(self):
+        """-> [(allreduce_ms, exposed_allreduce_ms)] of the updates recorded since dp_timing was set (call after a device
+        synchronisation).  allreduce_ms: from handing the gradient to RCCL until the update stream holds the reduced
+        gradient; exposed: the part of it the update stream spent waiting (nothing of its own left to run) - the
+        other streams (the next batch's encoders) keep the GPU busy meanwhile."""
+        out = [(e[0].elapsed_time(e[2]), e[1].elapsed_time(e[2])) for e in (self.dp_timing or [])]
+        if self.dp_timing is not None:
+            self.dp_timing = []
+        return out
 
     def finish_update(self):
         """Make the current stream wait for an in-flight weight update (checkpointing, evaluation, ...)."""
@@ -297,6 +311,10 @@ class Trainer:
             return
         if self.dp:
             scale = None
+            ev = None
+            if self.dp_timing is not None and self.flat.grad.is_cuda:      # bench / diagnosis: events, read after a sync
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record()
             if n_local is not None:
                 scale = dp.loss_weight(n_local.to(torch.float32).reshape(1), self.dist, self.world)
             if self.skip is not None and self.skip.is_cuda:
@@ -307,7 +325,12 @@ class Trainer:
                 if a > lo:
                     self._start_reduce(lo, a, scale)
                 lo = max(lo, b)
+            if ev is not None:
+                ev[1].record()
             wire = self._finish_reduces()
+            if ev is not None:
+                ev[2].record()
+                self.dp_timing.append(ev)
             if wire is not None:                       # bf16 on the wire: BertAdam reads the reduced buffer as it is
                 self.optimizer.step(grad_scale=1.0 / self.world, zero_grad=True, skip=self.skip, grad_wire=wire)
                 return
