@@ -45,6 +45,43 @@ def test_byte_bpe_known_answers_and_round_trip(tmp_path):
     assert len(rb.encode_ids('x ' * 600, max_len=512)) == 512
 
 
+GPT2_CASES = ["I'm I'M  it's 12,345.67  end  ", "a\n\nb\t c", "naïve café 中文 \U0001f600!!! ...x", "don't they'll we've I'd he's you're",
+              "  leading and trailing\n", "tabs\t\tand\r\nCRLF", "x" * 40 + " 3.14159e-10 #hash_tag @user http://a.b/c?d=e",
+              "\u00a0non-breaking\u2003em space", "\x00\x7f\xad bytes"]
+
+
+def test_gpt2_pretokenizer_byte_map_and_merges_against_the_tokenizers_library(tmp_path):
+    """Known answers for the pre-tokenizer regex and the byte fallback (reference call site
+    roberta_indexer.py:89-109 -> fairseq's GPT-2 encoder).  The independent implementation is Hugging Face's
+    `tokenizers` (Rust): its ByteLevel pre-tokenizer is the published GPT-2 regex + byte -> unicode map, its BPE model the
+    ranked-merge loop.  Contractions are case sensitive, a run of spaces leaves its last space to the next word, letters
+    / digits / other split, any byte without a merge stays a single byte symbol (space -> U+0120, newline -> U+010A, the
+    three non-printable ranges map to U+0100..U+0143)."""
+    tokenizers = pytest.importorskip('tokenizers')
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from tell_amd.data.bpe import RobertaBPE, bytes_to_unicode
+    b2u = bytes_to_unicode()
+    assert len(b2u) == 256 and len(set(b2u.values())) == 256
+    assert (b2u[0x20], b2u[0x0a], b2u[0x09], b2u[0x00], b2u[0x7f], b2u[0xa0], b2u[0xad]) == \
+        ('\u0120', '\u010a', '\u0109', '\u0100', '\u0121', '\u0142', '\u0143')
+    assert all(b2u[b] == chr(b) for b in list(range(33, 127)) + list(range(161, 173)) + list(range(174, 256)))
+    enc, _ = _write_vocab(str(tmp_path))
+    rb = RobertaBPE(str(tmp_path))
+    ref_pre = pre_tokenizers.ByteLevel(add_prefix_space=False, use_regex=True)
+    with open(os.path.join(str(tmp_path), 'vocab.bpe'), encoding='utf-8') as f:
+        merges = [tuple(ln.split()) for ln in f.read().split('\n')[1:] if ln.strip()]
+    ref = Tokenizer(models.BPE(vocab=enc, merges=merges))
+    ref.pre_tokenizer = ref_pre
+    for text in GPT2_CASES:
+        mine = [''.join(b2u[b] for b in tok.encode('utf-8')) for tok in rb.bpe.pretokenize(text)]
+        assert mine == [t for t, _ in ref_pre.pre_tokenize_str(text)], text
+        assert rb.bpe.encode(text) == ref.encode(text).ids, text
+        assert rb.bpe.decode(rb.bpe.encode(text)) == text
+    assert rb.bpe.pretokenize("I'm I'M") == ['I', "'m", ' I', "'", 'M']
+    assert rb.bpe.pretokenize('a  b   ') == ['a', ' ', ' b', '   ']
+    assert rb.bpe.pretokenize('abc123!?') == ['abc', '123', '!?']
+
+
 def test_roberta_indexer_contract(tmp_path):
     """roberta_indexer.py:89-109,185-200: <s> ... </s>, truncation to max_len, entity copy masks, padding 1 / -1."""
     from tell_amd.data import RobertaTokenIndexer, TokenIndexer
