@@ -184,6 +184,13 @@ int tell_mix_fwd(const void* H, const float* w, int L, long n, void* out, int dt
 int tell_mix_bwd(const void* H, const void* dOut, int L, long n, float* partial, int n_blocks, int dtype,
                  tell_stream_t stream);
 
+/* gw[l] += softmax(w)[l] * (d[l] - sum_j softmax(w)[j] d[j]), d = column sums of tell_mix_bwd's partial [n_blocks, L]:
+ * the gradient of the mixing logits, one launch (25 scalars). */
+int tell_mix_wgrad(const float* partial, int n_blocks, int L, const float* w, float* gw, tell_stream_t stream);
+/* out[0] = x[0] / (ln 2 * n_valid[0]): summed cross entropy (nats) -> bits per target token, transformer_faces_objects.py:85-88
+ * (and the gradient of the sum from the gradient of the loss). */
+int tell_loss_bits(const float* x, const int* n_valid, float* out, tell_stream_t stream);
+
 /* ---- LayerNorm: y = LN(res + dropout(x)), decoder_faces_objects.py:263-266,367-372 */
 int tell_layernorm_fwd(const void* x, long ld_x, const void* res, long ld_r, const float* gamma,
                        const float* beta, void* y, long ld_y, float* mean, float* rstd, int rows, int C,

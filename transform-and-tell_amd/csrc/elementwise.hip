@@ -615,6 +615,45 @@ extern "C" int tell_mix_bwd(const void* H, const void* dOut, int L, long n, floa
   return tell_check_launch("mix_bwd");
 }
 
+// gw[l] += sm[l] * (d[l] - sum_j sm[j] d[j]),  sm = softmax(w), d[l] = sum over the n_blocks partial rows of tell_mix_bwd:
+// the gradient of the 25 mixing logits (transformer_faces_objects.py:355-364 backward), one workgroup.
+__global__ __launch_bounds__(64) void mix_wgrad_kernel(const float* __restrict__ partial, int n_blocks, int L,
+                                                       const float* __restrict__ w, float* __restrict__ gw) {
+  __shared__ float d[64], sm[64];
+  const int lane = threadIdx.x;
+  for (int l = 0; l < L; ++l) {
+    float s = 0.f;
+    for (int b = lane; b < n_blocks; b += 64) s += partial[(long)b * L + l];
+    s = wave_sum(s);
+    if (lane == 0) d[l] = s;
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int l = 0; l < L; ++l) mx = fmaxf(mx, w[l]);
+  float den = 0.f;
+  for (int l = 0; l < L; ++l) den += __expf(w[l] - mx);
+  if (lane < L) sm[lane] = __expf(w[lane] - mx) / den;
+  __syncthreads();
+  float dot = 0.f;
+  for (int l = 0; l < L; ++l) dot += sm[l] * d[l];
+  if (lane < L) gw[lane] += sm[lane] * (d[lane] - dot);
+}
+extern "C" int tell_mix_wgrad(const float* partial, int n_blocks, int L, const float* w, float* gw, hipStream_t stream) {
+  TELL_REQUIRE(L >= 1 && L <= 64 && n_blocks >= 1, "mix_wgrad: L must be in [1,64]");
+  hipLaunchKernelGGL(mix_wgrad_kernel, dim3(1), dim3(64), 0, stream, partial, n_blocks, L, w, gw);
+  return tell_check_launch("mix_wgrad");
+}
+
+// out = x / (ln 2 * n): the summed cross entropy in nats -> bits per target token (transformer_faces_objects.py:85-88),
+// and - same arithmetic - the gradient of that sum from the gradient of the loss.
+__global__ void loss_bits_kernel(const float* __restrict__ x, const int* __restrict__ n, float* __restrict__ out) {
+  out[0] = x[0] / 0.69314718055994531f / (float)n[0];
+}
+extern "C" int tell_loss_bits(const float* x, const int* n_valid, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(loss_bits_kernel, dim3(1), dim3(1), 0, stream, x, n_valid, out);
+  return tell_check_launch("loss_bits");
+}
+
 // ---------------------------------------------------------------- y += alpha * x (fp32 or T), used for grad accumulation of tied weights
 template <typename T>
 __global__ void axpy_kernel(const T* __restrict__ x, T* __restrict__ y, long n, float alpha) {

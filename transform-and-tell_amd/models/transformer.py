@@ -155,7 +155,7 @@ class CaptionModel(Model):
                 rs.wait_event(start)
                 is_.wait_event(start)
                 with torch.cuda.stream(rs), ops.hip.bound_stream():
-                    enc.article_mask = article_ids == self.padding_idx                 # :347
+                    enc.article_mask = self._pad_mask(article_ids)                      # :347
                     enc.stack = self._run_roberta(article_ids)
                     article_ids.record_stream(rs)
                     enc.events.append(torch.cuda.Event())
@@ -169,7 +169,7 @@ class CaptionModel(Model):
                 self._note_slots(enc)
                 return enc
             side = _side_stream(image.device, 'resnet') if _OVERLAP else None
-            enc.article_mask = article_ids == self.padding_idx                         # :347
+            enc.article_mask = self._pad_mask(article_ids)                              # :347
             if side is not None:
                 start = torch.cuda.Event()
                 start.record(main)
@@ -197,6 +197,21 @@ class CaptionModel(Model):
             if g is not None and getattr(g, 'last_replayed', False):
                 enc.slots.append((g.last_slot, g.last_slot['generation']))
 
+    def _pad_mask(self, ids):
+        """Key-padding mask of the article (:347).  On the GPU as the uint8 the attention kernels read - produced once,
+        inside the encoder graph - instead of a bool that every decoder call converts."""
+        m = ids == self.padding_idx
+        return m.to(torch.uint8) if ids.is_cuda else m
+
+    def _no_mask(self, B, P, device):
+        """The all-visible mask of the image regions (:371): a constant, built once per shape."""
+        cache = self.__dict__.setdefault('_no_mask_cache', {})
+        key = (B, P, str(device))
+        if key not in cache:
+            cache[key] = torch.zeros(B, P, dtype=torch.uint8 if torch.device(device).type == 'cuda' else torch.bool,
+                                     device=device)
+        return cache[key]
+
     # ---- :311-397 -----------------------------------------------------------------
     def _forward(self, context, image, caption, face_embeds=None, obj_embeds=None, encoded=None):
         dtype = ops.rt.compute_dtype()
@@ -216,7 +231,7 @@ class CaptionModel(Model):
             x_article = stack[-1]
         contexts = {
             'image': x_image.transpose(0, 1),
-            'image_mask': torch.zeros(B, P, dtype=torch.bool, device=image.device),   # :371
+            'image_mask': self._no_mask(B, P, image.device),                  # :371
             'article': x_article.transpose(0, 1),
             'article_mask': article_mask,
         }
@@ -233,7 +248,7 @@ class CaptionModel(Model):
                 mask = torch.empty(Bf, n, dtype=torch.uint8, device=emb.device)
                 ops.call('tell_nan_rows', emb.float().contiguous(), Bf * n, dim, clean, ops.hip.dt(dtype), mask)
                 contexts[key] = clean.transpose(0, 1)
-                contexts[key + '_mask'] = mask.bool()
+                contexts[key + '_mask'] = mask if mask.is_cuda else mask.bool()    # (uint8 is what the kernels read)
         return caption_ids, target_ids, contexts
 
     # ---- :67-140 ------------------------------------------------------------------
@@ -243,8 +258,7 @@ class CaptionModel(Model):
         caption_ids, target_ids, contexts = self._forward(context, image, caption, face_embeds, obj_embeds, encoded)
         decoder_out = self.decoder(caption, contexts)
         loss_sum, sample_size = self.criterion(self.decoder.adaptive_softmax, decoder_out, target_ids)
-        n = sample_size.to(torch.float32)
-        loss = (loss_sum / math.log(2) / n).reshape(())                    # :85-88, bits per token
+        loss = ops.loss_bits(loss_sum, sample_size)                        # :85-88, bits per token
         output_dict = {'loss': loss, 'sample_size': sample_size.reshape(())}
         if not self.training and self.evaluate_mode:                       # :92-116
             _, gen_ids, attns = self._generate(caption_ids, contexts, beam_size=getattr(self, 'eval_beam_size', 1))

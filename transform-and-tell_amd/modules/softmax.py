@@ -60,6 +60,10 @@ class AdaptiveSoftmax(nn.Module):
 
     def loss(self, x, target, padding_idx):
         """-> (loss_sum in nats [1], sample_size [1] int32), both on the device."""
+        if x.dim() == 3 and not x.is_contiguous() and x.transpose(0, 1).is_contiguous():
+            # the decoder hands its T x B x C buffer over as a [B,T,C] view: the summed loss does not care about the row
+            # order, so the (tiny) target is transposed instead of the activations (and of their gradient)
+            x, target = x.transpose(0, 1), target.t().contiguous()
         return ops.adaptive_loss(x, target, self.cutoff, padding_idx, self.head.word_proj.weight,
                                  self.head.class_proj.weight, self._tails())
 

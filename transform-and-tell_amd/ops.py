@@ -278,6 +278,30 @@ def transpose(x, out_dtype=None, row_scale=None, want_plain=False, want_t=True):
     return xt, plain
 
 
+def zeros_group(specs, device):
+    """[(shape, dtype), ...] -> zero tensors carved from ONE allocation cleared by ONE launch (a training step clears a
+    dozen scratch buffers - count-limited gathers / GEMMs only write their first `count` rows)."""
+    sizes = []
+    for shape, dtype in specs:
+        n = 1
+        for d in shape:
+            n *= d
+        sizes.append(_round_up(n * torch.empty(0, dtype=dtype).element_size(), 256))
+    flat = torch.empty(sum(sizes) // 4, dtype=torch.float32, device=device)
+    if flat.is_cuda:
+        call('tell_fill_f32', flat, flat.numel(), 0.0)
+    else:
+        flat.zero_()
+    out, off = [], 0
+    for (shape, dtype), nb in zip(specs, sizes):
+        n = 1
+        for d in shape:
+            n *= d
+        out.append(flat[off // 4:(off + nb) // 4].view(dtype)[:n].view(*shape))
+        off += nb
+    return out
+
+
 def cast(x, dtype):
     if x.dtype == dtype:
         return x
@@ -1379,11 +1403,12 @@ class MixFn(Function):
         nb = 1024                       # 4 workgroups per CU keep 25 x 16-byte loads per lane in flight: 159 us (5.5 TB/s); 512 blocks took 248
         partial = torch.empty(nb, L, dtype=torch.float32, device=stack.device)
         call('tell_mix_bwd', stack, dout.contiguous(), L, n, partial, nb, hip.dt(stack))
-        dsm = torch.zeros(L, dtype=torch.float32, device=stack.device)       # d loss / d softmax(w)
-        colsum_into(partial, dsm)
-        # softmax backward over 25 scalars: host-side plumbing on a 25-vector
-        sm = torch.softmax(w.detach().float(), dim=0)
         gw = grad_buffer(w)
+        if partial.is_cuda:         # column sums + the softmax chain rule over the 25 logits: one launch
+            call('tell_mix_wgrad', partial, nb, L, w.detach().float().contiguous(), gw)
+            return None, None
+        dsm = partial.sum(0)                                                 # d loss / d softmax(w)
+        sm = torch.softmax(w.detach().float(), dim=0)
         gw.add_(sm * (dsm - (sm * dsm).sum()))
         return None, None
 
@@ -1432,10 +1457,11 @@ class AdaptiveEmbedFn(Function):
         part = partition_ids(ids_flat, cutoffs, pad_idx=-1)
         band_out = torch.empty(nb * N, E, dtype=dtype, device=ids.device)
         rows_saved = []
+        rows_all = zeros_group([((N, tables[2 * b].shape[1]), dtype) for b in range(nb)], ids.device)
         for b in range(nb):
             emb, proj = tables[2 * b], tables[2 * b + 1]
             dim = emb.shape[1]
-            rows_b = torch.zeros(N, dim, dtype=dtype, device=ids.device)   # rows >= count must be 0, not garbage
+            rows_b = rows_all[b]                                           # rows >= count must be 0, not garbage
             call('tell_gather_rows', weight(emb), dim, part['local'][b], part['count'][b:b + 1], N, rows_b, dim,
                  dim, hip.dt(dtype))
             gemm(rows_b, weight(proj), out=band_out[b * N:(b + 1) * N], m_dev=part['count'][b:b + 1])
@@ -1453,7 +1479,7 @@ class AdaptiveEmbedFn(Function):
         B, T, E, nb, scale, padding_idx = ctx.meta
         N = B * T
         dout = dout.contiguous()
-        dband = torch.zeros(nb * N, E, dtype=dout.dtype, device=dout.device)
+        dband, = zeros_group([((nb * N, E), dout.dtype)], dout.device)
         call('tell_embed_finalize_bwd', dout, part['slot'], dband, B, T, E, float(scale), 1, hip.dt(dout))
         for b in range(nb):
             emb, proj = tables[2 * b], tables[2 * b + 1]
@@ -1502,8 +1528,12 @@ class AdaptiveLossFn(Function):
         # ---- head: [emb0 ; class_proj] x
         n_head = c0 + n_tails
         w_head = torch.empty(n_head, E, dtype=dtype, device=dev)
-        w_head[:c0] = weight(emb0)
-        w_head[c0:] = weight(class_proj)
+        if w_head.is_cuda:
+            call('tell_cast', weight(emb0), hip.dt(dtype), w_head, hip.dt(dtype), c0 * E)
+            call('tell_cast', weight(class_proj), hip.dt(dtype), w_head[c0:], hip.dt(dtype), (n_head - c0) * E)
+        else:
+            w_head[:c0] = weight(emb0)
+            w_head[c0:] = weight(class_proj)
         # (rows of every fp32 logits buffer start on 16 bytes: an odd row length - 5002, 30265 - would make every store
         #  of the GEMM epilogue a 4-byte one: the 124 MB of tail logits took 137 us that way, 28 us as whole row pieces)
         head_logits = torch.empty(N, _round_up(n_head, 4), dtype=torch.float32, device=dev)[:, :n_head]
@@ -1512,16 +1542,19 @@ class AdaptiveLossFn(Function):
         loss_rows = torch.empty(N, dtype=torch.float32, device=dev)
         call('tell_ce_fwd', head_logits, head_logits.stride(0), N, n_head, part['head_target'], None, None,
              int(pad_idx), lse_h, loss_rows)
-        total = torch.zeros(1, dtype=torch.float32, device=dev)
+        zs = zeros_group([((1,), torch.float32)] +
+                         [spec for i in range(n_tails) for spec in (((N, E), dtype), ((N, tails[2 * i].shape[0]), dtype))],
+                         dev)
+        total = zs[0]
         call('tell_sum_f32', loss_rows, N, None, total, 1)
         saved_tails = []
         for i in range(n_tails):
             proj, emb = tails[2 * i], tails[2 * i + 1]
             band = i + 1
             cnt = part['count'][band:band + 1]
-            xg = torch.zeros(N, E, dtype=dtype, device=dev)
+            xg = zs[1 + 2 * i]
             call('tell_gather_rows', x2, E, part['rows'][band], cnt, N, xg, E, E, hip.dt(dtype))
-            h = torch.zeros(N, proj.shape[0], dtype=dtype, device=dev)
+            h = zs[2 + 2 * i]
             gemm(xg, weight(proj), out=h, m_dev=cnt)
             V = emb.shape[0]
             logits = torch.empty(N, _round_up(V, 4), dtype=torch.float32, device=dev)[:, :V]
@@ -1553,7 +1586,11 @@ class AdaptiveLossFn(Function):
         n_head = c0 + n_tails
         gscale = gtotal.reshape(1).float().contiguous()
         # ---- head
-        dl = torch.zeros(N, _round_up(n_head, _vec(dtype)), dtype=dtype, device=dev)
+        zs = zeros_group([((N, _round_up(n_head, _vec(dtype))), dtype)] +
+                         [spec for i in range(n_tails) for spec in
+                          (((N, _round_up(tails[2 * i + 1].shape[0], _vec(dtype))), dtype), ((N, tails[2 * i].shape[0]), dtype))],
+                         dev)
+        dl = zs[0]
         call('tell_ce_bwd', head_logits, head_logits.stride(0), N, n_head, part['head_target'], None, None,
              int(pad_idx), lse_h, gscale, dl, dl.stride(0), hip.dt(dtype))
         dx = gemm_nn(dl, w_head)                                  # [N, E]; dl's padding columns are zero
@@ -1570,10 +1607,10 @@ class AdaptiveLossFn(Function):
             cnt = part['count'][band:band + 1]
             xg, h, logits, lse_t = saved_tails[i]
             V = emb.shape[0]
-            dlt = torch.zeros(N, _round_up(V, _vec(dtype)), dtype=dtype, device=dev)
+            dlt = zs[1 + 2 * i]
             call('tell_ce_bwd', logits, logits.stride(0), N, V, part['local'][band], None, cnt, int(pad_idx),
                  lse_t, gscale, dlt, dlt.stride(0), hip.dt(dtype))
-            dh = torch.zeros(N, proj.shape[0], dtype=dtype, device=dev)
+            dh = zs[2 + 2 * i]
             gemm_nn(dlt, weight(emb), b_t=lambda emb=emb: weight_t(emb), out=dh, m_dev=cnt)
             if emb.requires_grad:                                  # rows >= count of dlt are zero
                 gemm_tn(dlt[:, :V], h, out=grad_buffer(emb), accumulate=True)
@@ -1585,6 +1622,30 @@ class AdaptiveLossFn(Function):
             call('tell_scatter_add_rows', dxg, dxg.stride(0), part['rows'][band], cnt, N, dx, dx.stride(0), E,
                  hip.dt(dtype))
         return (dx.view(ctx.xshape),) + (None,) * (5 + len(tails))
+
+
+class LossBitsFn(Function):
+    """sum of nats -> bits per target token (transformer_faces_objects.py:85-88): loss = total / ln 2 / n, one launch
+    each way instead of the five elementwise ones of the expression."""
+
+    @staticmethod
+    def forward(ctx, total, n_valid):
+        out = torch.empty(1, dtype=torch.float32, device=total.device)
+        call('tell_loss_bits', total, n_valid, out)
+        ctx.n = n_valid
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gt = torch.empty(1, dtype=torch.float32, device=g.device)
+        call('tell_loss_bits', g.reshape(1).float().contiguous(), ctx.n, gt)
+        return gt, None
+
+
+def loss_bits(total, n_valid):
+    if total.is_cuda and n_valid.dtype == torch.int32:
+        return LossBitsFn.apply(total.reshape(1), n_valid.reshape(1)).reshape(())
+    return (total / math.log(2) / n_valid.to(torch.float32)).reshape(())
 
 
 def adaptive_loss(x, target, cutoffs, pad_idx, emb0, class_proj, tails):
