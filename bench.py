@@ -314,7 +314,7 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
         achieved = d['work'] / (d['total_ms'] * 1e-3) / 1e12
         peak = 2500.0 if 'bf16' in name.split(',')[0] else 157.3
         traffic, tnote = None, None
-        for fn in ('r02_pmc_gemm_traffic.json', 'r01_pmc_gemm_traffic.json'):
+        for fn in ('r03_pmc_gemm_traffic.json', 'r01_pmc_gemm_traffic.json'):
             pmc = os.path.join(ROOT, 'profiles', fn)
             if os.path.exists(pmc):      # HBM bytes per launch of this kernel from the committed PMC passes
                 j = json.load(open(pmc))
