@@ -191,6 +191,18 @@ int tell_mix_wgrad(const float* partial, int n_blocks, int L, const float* w, fl
  * (and the gradient of the sum from the gradient of the loss). */
 int tell_loss_bits(const float* x, const int* n_valid, float* out, tell_stream_t stream);
 
+/* ---- beam search bookkeeping (the loop of transformer_faces_objects.py:443-494 widened to K hypotheses)
+ * tk int32 / lp fp32 [B,K,K]: the K best continuations of every hypothesis (tell_adaptive_logprob_topk); per sample the
+ * K best of cum[parent] + lp / temperature (a finished hypothesis continues with pad at no cost; lowest index wins a
+ * tie); in place: cum fp32 [B,K], finished uint8 [B,K], seqs int64 [B,K,L] (column step + 1 written), lps fp32
+ * [B,K,L-1] (column step); out: cur int64 [B*K] next input tokens, rows int64 [B*K] the row each survivor descends from. */
+int tell_beam_update(const int* tk, const float* lp, float* cum, uint8_t* finished, long* seqs, float* lps, long* cur,
+                     long* rows, int B, int K, int L, int step, int pad, int eos, float inv_temp, tell_stream_t stream);
+/* buf[i][p][r][:] <- buf[i][p][rows[r]][:] in place for n <= 8 bf16 buffers [planes[i], M, 1024] (HOST arrays); rows[r]
+ * must lie inside r's group of K consecutive rows (dynamic.py:338-342 reorder_incremental_state, all layers at once). */
+int tell_reorder_rows(int n, void* const* bufs, const int* planes, const long* rows, int M, int C, int K,
+                      tell_stream_t stream);
+
 /* ---- LayerNorm: y = LN(res + dropout(x)), decoder_faces_objects.py:263-266,367-372 */
 int tell_layernorm_fwd(const void* x, long ld_x, const void* res, long ld_r, const float* gamma,
                        const float* beta, void* y, long ld_y, float* mean, float* rstd, int rows, int C,

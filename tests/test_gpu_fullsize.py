@@ -205,8 +205,15 @@ def test_generation_head_as_skinny_launches_matches_gemm_head_bf16():
         tok0, lp0 = asm.greedy(x)
         decode.ENABLED = True
         tok1, lp1 = asm.greedy(x)
+        tk1, tl1 = asm.topk(x, 4)                      # beam search's head: the 4 best of every row, best first
+        decode.ENABLED = False
+        tk0, tl0 = asm.topk(x, 4)
+        decode.ENABLED = True
     finally:
         decode.ENABLED = prev
+    torch.testing.assert_close(tl1.cpu(), tl0.cpu(), rtol=0, atol=2e-2)
+    assert (tk1 == tk0).float().mean() >= 0.9 and bool((tl1[..., :-1] >= tl1[..., 1:]).all())
+    assert torch.equal(tk1[..., 0].reshape(-1).cpu(), tok1.reshape(-1).cpu())          # top-1 == the greedy token
     tok0, tok1, lp0, lp1 = tok0.reshape(-1).cpu(), tok1.reshape(-1).cpu(), lp0.reshape(-1).cpu(), lp1.reshape(-1).cpu()
     assert len({int(i >= 5000) + int(i >= 20000) for i in tok1.tolist()}) == 3, 'all clusters should win somewhere'
     torch.testing.assert_close(lp1, lp0, rtol=0, atol=2e-2)

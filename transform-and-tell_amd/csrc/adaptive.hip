@@ -345,10 +345,15 @@ __global__ __launch_bounds__(1024) void logprob_argmax_kernel(LogProbArgs p) {
 // on 16 bytes.  64 of the 128 registers a 1024-thread workgroup leaves each thread.
 __device__ constexpr int LPF_CAP[4] = {2, 4, 8, 2};
 __device__ constexpr int LPF_OFF[4] = {0, 2, 6, 14};
-__global__ __launch_bounds__(1024) void logprob_argmax_regs_kernel(LogProbArgs p) {
+// K = 1: arg-max (token, token_lp); K = 4 / 8: every thread keeps its K best while scanning its registers, the block pops
+// the global best k times (beam search: tokens / lps [rows, k], best first).
+template <int K>
+__global__ __launch_bounds__(1024) void logprob_regs_kernel(LogProbArgs p, int k, int* __restrict__ tokens,
+                                                            float* __restrict__ lps) {
   __shared__ float red[4][16];
   __shared__ float best_v[16];
   __shared__ int best_i[16];
+  __shared__ int win_i;
   const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nseg = 1 + p.n_tails;
   const float* rowp[4]; int n[4];
@@ -417,8 +422,20 @@ __global__ __launch_bounds__(1024) void logprob_argmax_regs_kernel(LogProbArgs p
     sm[s] = t;
   }
   const float lse_h = mx[0] + __logf(sm[0]);
-  float bv = -INFINITY; int bi = 0x7fffffff;
-  auto consider = [&](float v, int j) { if (v > bv || (v == bv && j < bi)) { bv = v; bi = j; } };
+  float tv[K]; int ti[K];
+#pragma unroll
+  for (int q = 0; q < K; ++q) { tv[q] = -INFINITY; ti[q] = 0x7fffffff; }
+  auto better = [](float v, int j, float w, int m) { return v > w || (v == w && j < m); };
+  auto consider = [&](float v, int j) {
+    if (!better(v, j, tv[K - 1], ti[K - 1])) return;
+    tv[K - 1] = v; ti[K - 1] = j;
+#pragma unroll
+    for (int q = K - 1; q > 0; --q)
+      if (better(tv[q], ti[q], tv[q - 1], ti[q - 1])) {
+        const float fv = tv[q]; tv[q] = tv[q - 1]; tv[q - 1] = fv;
+        const int fi = ti[q]; ti[q] = ti[q - 1]; ti[q - 1] = fi;
+      }
+  };
 #pragma unroll
   for (int q = 0; q < LPF_CAP[0]; ++q) {
     const int j = (q * 1024 + tid) * 4;
@@ -444,18 +461,35 @@ __global__ __launch_bounds__(1024) void logprob_argmax_regs_kernel(LogProbArgs p
       base += n[s];
     }
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(bv, o, 64);
-    const int oi = __shfl_xor(bi, o, 64);
-    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-  }
-  if (lane == 0) { best_v[wave] = bv; best_i[wave] = bi; }
-  __syncthreads();
-  if (tid == 0) {
-    for (int w = 1; w < 16; ++w)
-      if (best_v[w] > bv || (best_v[w] == bv && best_i[w] < bi)) { bv = best_v[w]; bi = best_i[w]; }
-    if (p.token) p.token[i] = bi;
-    if (p.token_lp) p.token_lp[i] = bv;
+  for (int r = 0; r < k; ++r) {                       // pop the block-wide best k times (lowest index wins ties)
+    float bv = tv[0]; int bi = ti[0];
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    __syncthreads();                                   // previous round's win_i / best_* consumed
+    if (lane == 0) { best_v[wave] = bv; best_i[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 16; ++w)
+        if (better(best_v[w], best_i[w], bv, bi)) { bv = best_v[w]; bi = best_i[w]; }
+      if (K == 1) {
+        if (p.token) p.token[i] = bi;
+        if (p.token_lp) p.token_lp[i] = bv;
+      } else {
+        tokens[(long)i * k + r] = bi;
+        lps[(long)i * k + r] = bv;
+      }
+      win_i = bi;
+    }
+    if (K == 1) break;
+    __syncthreads();
+    if (ti[0] == win_i) {                              // the owner of the winner advances its list
+#pragma unroll
+      for (int q = 0; q < K - 1; ++q) { tv[q] = tv[q + 1]; ti[q] = ti[q + 1]; }
+      tv[K - 1] = -INFINITY; ti[K - 1] = 0x7fffffff;
+    }
   }
 }
 
@@ -545,6 +579,17 @@ extern "C" int tell_adaptive_logprob_topk(const float* head, long ld_head, int c
   p.tail[1] = tail1; p.ld_tail[1] = ld1; p.tail_n[1] = n1;
   p.tail[2] = tail2; p.ld_tail[2] = ld2; p.tail_n[2] = n2;
   p.log_probs = nullptr; p.ld_lp = 0; p.token = nullptr; p.token_lp = nullptr;
+  const bool aligned = ld_head % 4 == 0 && ((uintptr_t)head % 16) == 0 &&
+                       (n_tails < 1 || (ld0 % 4 == 0 && ((uintptr_t)tail0 % 16) == 0)) &&
+                       (n_tails < 2 || (ld1 % 4 == 0 && ((uintptr_t)tail1 % 16) == 0)) &&
+                       (n_tails < 3 || (ld2 % 4 == 0 && ((uintptr_t)tail2 % 16) == 0));
+  static const bool regs_env = !(getenv("TELL_ARGMAX_REGS") && atoi(getenv("TELL_ARGMAX_REGS")) == 0);      // A/B aid
+  if (regs_env && aligned && p.head_n <= 2 * 4096 && (n_tails < 1 || n0 <= 4 * 4096) && (n_tails < 2 || n1 <= 8 * 4096) &&
+      (n_tails < 3 || n2 <= 2 * 4096)) {
+    if (k <= 4) hipLaunchKernelGGL((logprob_regs_kernel<4>), dim3(rows), dim3(1024), 0, stream, p, k, tokens, lps);
+    else hipLaunchKernelGGL((logprob_regs_kernel<8>), dim3(rows), dim3(1024), 0, stream, p, k, tokens, lps);
+    return tell_check_launch("logprob_topk (registers)");
+  }
   if (k <= 4) hipLaunchKernelGGL((logprob_topk_kernel<4>), dim3(rows), dim3(256), 0, stream, p, k, tokens, lps);
   else hipLaunchKernelGGL((logprob_topk_kernel<8>), dim3(rows), dim3(256), 0, stream, p, k, tokens, lps);
   return tell_check_launch("logprob_topk");
@@ -570,7 +615,7 @@ extern "C" int tell_adaptive_logprob_argmax(const float* head, long ld_head, int
   static const bool regs_env = !(getenv("TELL_ARGMAX_REGS") && atoi(getenv("TELL_ARGMAX_REGS")) == 0);      // A/B aid
   if (!log_probs && regs_env && aligned && p.head_n <= 2 * 4096 && (n_tails < 1 || n0 <= 4 * 4096) &&
       (n_tails < 2 || n1 <= 8 * 4096) && (n_tails < 3 || n2 <= 2 * 4096)) {
-    hipLaunchKernelGGL(logprob_argmax_regs_kernel, dim3(rows), dim3(1024), 0, stream, p);
+    hipLaunchKernelGGL((logprob_regs_kernel<1>), dim3(rows), dim3(1024), 0, stream, p, 1, (int*)nullptr, (float*)nullptr);
     return tell_check_launch("logprob_argmax (registers)");
   }
   hipLaunchKernelGGL(logprob_argmax_kernel, dim3(rows), dim3(1024), 0, stream, p);

@@ -436,17 +436,25 @@ struct AttnDecCtx {
 };
 struct AttnDecArgs { AttnDecCtx c[SK_MAXP]; int B, H, beams; };
 
+// NQ: hypotheses of one sample served by a workgroup (beam search: the NQ rows b*beams + j read the SAME cached keys
+// and values - loaded once, used NQ times).
+template <int NQ>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecArgs g) {
   const AttnDecCtx& p = g.c[blockIdx.y];
-  __shared__ float sc[AD_MAXS + 2];
-  __shared__ float redw[4];
-  __shared__ float part[4][64];
+  __shared__ float sc[NQ][AD_MAXS + 2];
+  __shared__ float redw[NQ][4];
+  __shared__ float part[NQ][4][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x / g.H, h = blockIdx.x % g.H;
+  const int groups = (g.beams + NQ - 1) / NQ;                 // workgroups per (sample, head)
+  const int h = blockIdx.x % g.H, bg = blockIdx.x / g.H, bs = bg / groups, j0 = (bg % groups) * NQ;
+  const int nq = g.beams - j0 < NQ ? g.beams - j0 : NQ;       // live hypotheses of this workgroup
+  const int b0 = bs * g.beams + j0;                            // first row
   const int ks = lane >> 3, dc = lane & 7, S = p.S;
-  float q[8];
-  unpack16(*reinterpret_cast<const uint4*>(p.q + (long)b * p.q_sb + h * 64 + dc * 8), q, (const uint16_t*)nullptr);
-  const int bs = b / g.beams;
+  float q[NQ][8];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i)
+    unpack16(*reinterpret_cast<const uint4*>(p.q + (long)(b0 + (i < nq ? i : 0)) * p.q_sb + h * 64 + dc * 8), q[i],
+             (const uint16_t*)nullptr);
   const uint16_t* kb = p.k + (long)bs * p.k_sb + h * 64 + dc * 8;
   const uint16_t* vb = p.v + (long)bs * p.v_sb + h * 64 + dc * 8;
   const uint8_t* mk = p.mask ? p.mask + (long)bs * S : nullptr;
@@ -463,43 +471,68 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecArgs g) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int s = s0 + u * 32 + ks;
-      float kf[8], d = 0.f;
+      float kf[8];
       unpack16(kr[u], kf, (const uint16_t*)nullptr);
+      const bool masked = s < S && mk && mk[s];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) d = fmaf(q[e], kf[e], d);
-      d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
-      if (dc == 0 && s < S) sc[s] = (mk && mk[s]) ? -INFINITY : d;
+      for (int i = 0; i < NQ; ++i) {
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d = fmaf(q[i][e], kf[e], d);
+        d += sk_dpp<0xB1>(d); d += sk_dpp<0x4E>(d); d += sk_dpp<0x141>(d);     // over the 8 lanes that share the key
+        if (dc == 0 && s < S) sc[i][s] = masked ? -INFINITY : d;
+      }
     }
   }
   if (wave == 0) {
     if (p.bias_k) {
-      float kf[8], d = 0.f;
+      float kf[8];
       unpack16(*reinterpret_cast<const uint4*>(p.bias_k + h * 64 + dc * 8), kf, (const uint16_t*)nullptr);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) d = fmaf(q[e], kf[e], d);
-      d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
-      if (lane == 0) sc[S] = d;
+      for (int i = 0; i < NQ; ++i) {
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d = fmaf(q[i][e], kf[e], d);
+        d += sk_dpp<0xB1>(d); d += sk_dpp<0x4E>(d); d += sk_dpp<0x141>(d);
+        if (lane == 0) sc[i][S] = d;
+      }
     }
-    if (p.has_zero && lane == 0) sc[ST - 1] = 0.f;
+    if (p.has_zero && lane == 0) {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) sc[i][ST - 1] = 0.f;
+    }
   }
   __syncthreads();
-  float mx = -INFINITY;
-  for (int s = tid; s < ST; s += 256) mx = fmaxf(mx, sc[s]);
-  mx = wave_max(mx);
-  if (lane == 0) redw[wave] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(redw[0], redw[1]), fmaxf(redw[2], redw[3]));
-  __syncthreads();
-  float l = 0.f;
-  for (int s = tid; s < ST; s += 256) {
-    const float e = mx == -INFINITY ? 0.f : __expf(sc[s] - mx);
-    sc[s] = e; l += e;
+  float mx[NQ], l[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    float m = -INFINITY;
+    for (int s = tid; s < ST; s += 256) m = fmaxf(m, sc[i][s]);
+    m = wave_max(m);
+    if (lane == 0) redw[i][wave] = m;
   }
-  l = wave_sum(l);
-  if (lane == 0) redw[wave] = l;
   __syncthreads();
-  l = (redw[0] + redw[1]) + (redw[2] + redw[3]);
-  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) mx[i] = fmaxf(fmaxf(redw[i][0], redw[i][1]), fmaxf(redw[i][2], redw[i][3]));
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    float t = 0.f;
+    for (int s = tid; s < ST; s += 256) {
+      const float e = mx[i] == -INFINITY ? 0.f : __expf(sc[i][s] - mx[i]);
+      sc[i][s] = e; t += e;
+    }
+    t = sk_wave_sum(t);
+    if (lane == 0) redw[i][wave] = t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) l[i] = (redw[i][0] + redw[i][1]) + (redw[i][2] + redw[i][3]);
+  float o[NQ][8];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[i][e] = 0.f;
   for (int s0 = wave * 8; s0 < S8; s0 += 128) {
     uint4 vr[4];
 #pragma unroll
@@ -513,30 +546,43 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecArgs g) {
       const int s = s0 + u * 32 + ks;
       float vf[8];
       unpack16(vr[u], vf, (const uint16_t*)nullptr);
-      const float pr = s < S ? sc[s] : 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = fmaf(pr, vf[e], o[e]);
+      for (int i = 0; i < NQ; ++i) {
+        const float pr = s < S ? sc[i][s] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[i][e] = fmaf(pr, vf[e], o[i][e]);
+      }
     }
   }
   if (p.bias_v && wave == 0 && ks == 0) {
     float vf[8];
     unpack16(*reinterpret_cast<const uint4*>(p.bias_v + h * 64 + dc * 8), vf, (const uint16_t*)nullptr);
-    const float pr = sc[S];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = fmaf(pr, vf[e], o[e]);
+    for (int i = 0; i < NQ; ++i) {
+      const float pr = sc[i][S];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[i][e] = fmaf(pr, vf[e], o[i][e]);
+    }
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    o[e] += __shfl_xor(o[e], 8); o[e] += __shfl_xor(o[e], 16); o[e] += __shfl_xor(o[e], 32);
-  }
-  if (ks == 0) {
+  for (int i = 0; i < NQ; ++i) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) part[wave][dc * 8 + e] = o[e];
+    for (int e = 0; e < 8; ++e) {
+      float v = o[i][e];
+      v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+      o[i][e] = v;
+    }
+    if (ks == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part[i][wave][dc * 8 + e] = o[i][e];
+    }
   }
   __syncthreads();
-  if (tid < 64) {
-    const float v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-    p.out[(long)b * p.o_sb + h * 64 + tid] = f2bf(l > 0.f ? v / l : 0.f);
+  for (int t = tid; t < NQ * 64; t += 256) {
+    const int i = t >> 6, d = t & 63;
+    if (i >= nq) continue;
+    const float v = (part[i][0][d] + part[i][1][d]) + (part[i][2][d] + part[i][3][d]);
+    p.out[(long)(b0 + i) * p.o_sb + h * 64 + d] = f2bf(l[i] > 0.f ? v / l[i] : 0.f);
   }
 }
 
@@ -563,7 +609,10 @@ extern "C" int tell_attn_decode(int n_ctx, const void* const* q, const long* q_s
     g.c[c].o_sb = o_sb[j]; g.c[c].S = S[j]; g.c[c].has_zero = has_zero ? 1 : 0;
     g.c[c].bias_k = bias_k ? (const uint16_t*)bias_k[j] : nullptr; g.c[c].bias_v = bias_v ? (const uint16_t*)bias_v[j] : nullptr;
   }
-  hipLaunchKernelGGL(attn_decode_kernel, dim3(B * H, n_ctx), dim3(256), 0, stream, g);
+  const int samples = B / beams;
+  if (beams == 1) hipLaunchKernelGGL((attn_decode_kernel<1>), dim3(B * H, n_ctx), dim3(256), 0, stream, g);
+  else if (beams == 2) hipLaunchKernelGGL((attn_decode_kernel<2>), dim3(samples * H, n_ctx), dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL((attn_decode_kernel<4>), dim3(samples * ((beams + 3) / 4) * H, n_ctx), dim3(256), 0, stream, g);
   return tell_check_launch("attn_decode");
 }
 
@@ -615,4 +664,122 @@ extern "C" int tell_embed_gather_step(const long* ids, int M, int nb, const void
   hipLaunchKernelGGL(embed_gather_step_kernel, dim3(M), dim3(256), 0, stream, ids, a, static_cast<uint16_t*>(cat), pos_table,
                      pos_out, g_tell_pos_step);
   return tell_check_launch("embed_gather_step");
+}
+
+// ------------------------------------------------------------------ beam search: one step's bookkeeping
+// What the host loop does per token after the top-k head (scoring = sum of token log-probs, a finished
+// hypothesis has one continuation: pad at no cost): per sample the K best of the K x K candidates
+// cum[parent] + lp[parent][m] (lowest flat index wins a tie), the surviving sequences / per-token log-probs gathered
+// by parent and extended, the parent ROW of every surviving hypothesis for the state reorder, the next input tokens.
+// One 64-thread workgroup per sample; K <= 8.  Thirty-five elementwise / gather / top-k launches per token before.
+__global__ __launch_bounds__(64) void beam_update_kernel(const int* __restrict__ tk, const float* __restrict__ lp,
+                                                         float* __restrict__ cum, uint8_t* __restrict__ finished,
+                                                         long* __restrict__ seqs, float* __restrict__ lps,
+                                                         long* __restrict__ cur, long* __restrict__ rows, int K, int L,
+                                                         int step, int pad, int eos, float inv_temp) {
+  __shared__ long s_seq[8 * 256];
+  __shared__ float s_lp[8 * 256];
+  __shared__ int s_parent[8], s_tok[8];
+  __shared__ float s_top[8], s_dlp[8];
+  __shared__ uint8_t s_fin[8];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int j = t / K, m = t % K;
+  float score = -INFINITY;
+  int token = pad;
+  bool was_fin = false;
+  if (t < K * K) {
+    was_fin = finished[b * K + j] != 0;
+    const float l = was_fin ? (m == 0 ? 0.f : -INFINITY) : lp[((long)b * K + j) * K + m] * inv_temp;
+    token = was_fin ? pad : tk[((long)b * K + j) * K + m];
+    score = cum[b * K + j] + l;
+  }
+  bool taken = false;
+  for (int r = 0; r < K; ++r) {
+    float bv = taken ? -INFINITY : score;
+    int bi = taken || t >= K * K ? 0x7fffffff : t;
+    if (bv != bv) { bv = -INFINITY; }                       // (a NaN score never wins)
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (t == bi) {
+      taken = true;
+      s_parent[r] = j; s_top[r] = score;
+      s_tok[r] = token;
+      s_fin[r] = (was_fin || token == eos) ? 1 : 0;
+      s_dlp[r] = was_fin ? 0.f : score - cum[b * K + j];
+    }
+  }
+  __syncthreads();
+  // gather the surviving histories by parent (through LDS: the permutation is in place)
+  const int Lp = L - 1;
+  for (int e = t; e < K * L; e += 64) s_seq[e] = seqs[(long)b * K * L + e];
+  for (int e = t; e < K * Lp; e += 64) s_lp[e] = lps[(long)b * K * Lp + e];
+  __syncthreads();
+  for (int e = t; e < K * L; e += 64) {
+    const int r = e / L, c = e % L;
+    seqs[(long)b * K * L + e] = c == step + 1 ? (long)s_tok[r] : s_seq[s_parent[r] * L + c];
+  }
+  for (int e = t; e < K * Lp; e += 64) {
+    const int r = e / Lp, c = e % Lp;
+    lps[(long)b * K * Lp + e] = c == step ? s_dlp[r] : s_lp[s_parent[r] * Lp + c];
+  }
+  if (t < K) {
+    cum[b * K + t] = s_top[t];
+    finished[b * K + t] = s_fin[t];
+    cur[b * K + t] = s_tok[t];
+    rows[b * K + t] = (long)b * K + s_parent[t];
+  }
+}
+// tk int32 / lp fp32 [B,K,K] (the K best continuations of every hypothesis, best first), cum fp32 [B,K], finished uint8
+// [B,K], seqs int64 [B,K,L], lps fp32 [B,K,L-1] - all updated in place -, cur int64 [B*K] (next input tokens), rows
+// int64 [B*K] (row each surviving hypothesis descends from).  K <= 8, L <= 256.
+extern "C" int tell_beam_update(const int* tk, const float* lp, float* cum, uint8_t* finished, long* seqs, float* lps,
+                                long* cur, long* rows, int B, int K, int L, int step, int pad, int eos, float inv_temp,
+                                hipStream_t stream) {
+  TELL_REQUIRE(B > 0 && K >= 1 && K <= 8 && L >= 2 && L <= 256 && step >= 0 && step + 1 < L, "beam_update: K <= 8, L <= 256");
+  hipLaunchKernelGGL(beam_update_kernel, dim3(B), dim3(64), 0, stream, tk, lp, cum, finished, seqs, lps, cur, rows, K, L,
+                     step, pad, eos, inv_temp);
+  return tell_check_launch("beam_update");
+}
+
+// Rows of the DynamicConv input buffers follow their hypotheses (dynamic.py:338-342 reorder_incremental_state):
+// buf[p][r][:] <- buf[p][rows[r]][:] for every plane p of up to 8 buffers [planes, M, C] bf16, in place - rows[r] stays
+// inside r's group of K consecutive rows (a sample's hypotheses), so a workgroup that owns (plane, group) reads its K
+// rows into registers and writes them back permuted.  C == 1024.
+struct ReorderArgs { uint16_t* buf[8]; int plane0[9]; int n; };
+__global__ __launch_bounds__(128) void reorder_rows_kernel(ReorderArgs a, const long* __restrict__ rows, int M, int C, int K) {
+  int pl = blockIdx.x, bi = 0;
+  while (bi + 1 < a.n && pl >= a.plane0[bi + 1]) ++bi;
+  pl -= a.plane0[bi];
+  const int g = blockIdx.y, t = threadIdx.x;
+  uint16_t* base = a.buf[bi] + ((long)pl * M + (long)g * K) * C + t * 8;
+  sk_u4 v[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+    if (r < K) v[r] = *reinterpret_cast<const sk_u4*>(base + (long)r * C);
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+    if (r < K) {
+      const int src = (int)(rows[g * K + r] - (long)g * K);
+      sk_u4 w = v[0];
+#pragma unroll
+      for (int q = 1; q < 8; ++q)
+        if (q == src) w = v[q];
+      *reinterpret_cast<sk_u4*>(base + (long)r * C) = w;
+    }
+}
+extern "C" int tell_reorder_rows(int n, void* const* bufs, const int* planes, const long* rows, int M, int C, int K,
+                                 hipStream_t stream) {
+  TELL_REQUIRE(n >= 1 && n <= 8 && C == 1024 && K >= 1 && K <= 8 && M % K == 0, "reorder_rows: C = 1024, K <= 8 rows per group");
+  ReorderArgs a;
+  a.n = n; a.plane0[0] = 0;
+  for (int i = 0; i < 8; ++i) {
+    a.buf[i] = static_cast<uint16_t*>(bufs[i < n ? i : 0]);
+    a.plane0[i + 1] = a.plane0[i] + (i < n ? planes[i] : 0);
+  }
+  if (a.plane0[n] == 0) return TELL_OK;
+  hipLaunchKernelGGL(reorder_rows_kernel, dim3(a.plane0[n], M / K), dim3(128), 0, stream, a, rows, M, C, K);
+  return tell_check_launch("reorder_rows");
 }

@@ -109,11 +109,12 @@ def embed_step(embedder, ids, start):
     return out.view(1, M, E)
 
 
-def head_step(x2, cutoffs, emb0, class_proj, tails):
+def head_step(x2, cutoffs, emb0, class_proj, tails, topk=0):
     """Greedy head of a generation step (softmax.py:193-222 + topk(1)) as four launches: head logits | cluster logits |
     the tails' projected inputs from ONE skinny linear over [emb_0; class_proj; proj_1; proj_2] (logits fp32, the
     projections once more in bf16), one skinny linear per tail table, the register-resident arg-max.
-    -> (token int32 [N], log-prob fp32 [N], None)."""
+    -> (token int32 [N], log-prob fp32 [N], None); topk = k > 0 (beam search): the k best of every row, best first,
+    (tokens int32 [N,k], log-probs fp32 [N,k], None)."""
     N, E = x2.shape
     dev = x2.device
     c0, n_tails = cutoffs[0], len(tails) // 2
@@ -141,6 +142,12 @@ def head_step(x2, cutoffs, emb0, class_proj, tails):
         else:       # tens of MB of table: the MFMA GEMM's 64-column tiles re-read the rows 4x less often per weight byte
             ops.gemm(h[:, off:off + hdims[i]], emb, out=tl[i][:, :n_i])
         off += hdims[i]
+    if topk:
+        tokens = torch.empty(N, topk, dtype=torch.int32, device=dev)
+        lps = torch.empty(N, topk, dtype=torch.float32, device=dev)
+        call('tell_adaptive_logprob_topk', head, ld, c0, n_tails, tl[0], lds[0], ns[0], tl[1], lds[1], ns[1], tl[2], lds[2],
+             ns[2], N, int(topk), tokens, lps)
+        return tokens, lps, None
     token = torch.empty(N, dtype=torch.int32, device=dev)
     token_lp = torch.empty(N, dtype=torch.float32, device=dev)
     call('tell_adaptive_logprob_argmax', head, ld, c0, n_tails, tl[0], lds[0], ns[0], tl[1], lds[1], ns[1], tl[2], lds[2],

@@ -471,10 +471,16 @@ class CaptionModel(Model):
             h['graph'].replay()
             return h['out']
 
-        def reorder(rows):                                        # in place: the buffers are part of the graph
-            for k, s in h['state'].items():
-                if torch.is_tensor(s):
-                    s.copy_(s.index_select(1, rows))
+        def reorder(rows, group=0):                               # in place: the buffers are part of the graph
+            bufs = [s for s in h['state'].values() if torch.is_tensor(s) and s.shape[0] > 0]
+            if (group and 1 <= group <= 8 and bufs and all(s.dtype == torch.bfloat16 and s.is_contiguous() and
+                                                           s.shape[2] == 1024 for s in bufs) and len(bufs) <= 8):
+                # rows[r] lies inside r's group of `group` hypotheses: every layer's buffer in ONE launch
+                ops.call('tell_reorder_rows', len(bufs), ops._ptr_array(bufs), ops._int_array([s.shape[0] for s in bufs]),
+                         rows, bufs[0].shape[1], 1024, int(group))
+                return
+            for s in bufs:
+                s.copy_(s.index_select(1, rows))
         step.reorder = reorder
         step.cur = h['cur']
         return step
@@ -506,7 +512,22 @@ class CaptionModel(Model):
         lps = torch.zeros(B, K, gen_len, dtype=torch.float32, device=dev)
         base = (torch.arange(B, device=dev) * K).view(B, 1)
         n_steps = gen_len
-        for i in range(gen_len):
+        fused = caption_ids.is_cuda and hasattr(step, 'cur') and K <= 8 and gen_len + 1 <= 256
+        if fused:
+            # one bookkeeping launch per token (tell_beam_update: candidate scores, top-K per sample, histories gathered
+            # by parent, next inputs) + one launch that moves every layer's DynamicConv buffer rows to their descendants
+            fin8 = finished.to(torch.uint8).contiguous()
+            rows = torch.empty(B * K, dtype=torch.long, device=dev)
+            step.cur.copy_(cur)
+            for i in range(gen_len):
+                tk, lp = step(i, None)
+                ops.call('tell_beam_update', tk, lp, cum, fin8, seqs, lps, step.cur, rows, B, K, gen_len + 1, i, int(pad),
+                         int(eos), 1.0 / float(self.sampling_temp))
+                step.reorder(rows, K)
+                if (i + 1) % check_every == 0 and bool(fin8.all()):
+                    n_steps = i + 1
+                    break
+        for i in range(0 if fused else gen_len):
             # each hypothesis contributes its own K best tokens (the best K of K x V always lie among them)
             tk, lp = step(i, cur)
             tk, lp = tk.view(B, K, K).long(), lp.view(B, K, K) / self.sampling_temp

@@ -1661,9 +1661,9 @@ def adaptive_log_probs(x2, cutoffs, emb0, class_proj, tails, want_full=False, to
     c0 = cutoffs[0]
     n_tails = len(tails) // 2
     from . import decode
-    if (not topk and not want_full and decode.ENABLED and N <= decode.MAX_ROWS and x2.dtype == torch.bfloat16 and
+    if (not want_full and decode.ENABLED and N <= decode.MAX_ROWS and x2.dtype == torch.bfloat16 and
             E % 1024 == 0 and n_tails >= 1 and all(tails[2 * i].shape[0] % 8 == 0 for i in range(n_tails))):
-        return decode.head_step(x2, cutoffs, emb0, class_proj, tails)
+        return decode.head_step(x2, cutoffs, emb0, class_proj, tails, topk)
     w_head = _cached(emb0, ('whead', class_proj._version, class_proj.data_ptr()), lambda: torch.cat(
         [weight(emb0), weight(class_proj)], dim=0).contiguous())
     def logits(a, w):                    # fp32 rows start on 16 bytes (see AdaptiveLossFn): vector stores in the epilogue
