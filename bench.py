@@ -564,7 +564,7 @@ def main():
 
     if args.generate:
         if args.steps == 20 and args.warmup == 5:          # defaults are sized for training steps; a batch of captions
-            args.steps, args.warmup = 4, 1                 # is ~0.2 s
+            args.steps, args.warmup = 4, 2                 # is ~0.1 s; the encoder graphs are captured at the 2nd sighting
         result = generate_bench(args, dev, world, rank, dist)
         if rank == 0:
             print(json.dumps(result))
