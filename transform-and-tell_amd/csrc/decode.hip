@@ -123,9 +123,9 @@ __device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& p, int prob, i
   else static_cast<uint16_t*>(p.out[prob])[(long)m * p.ld_out + n] = f2bf(v);
 }
 
-template <int ACT, int U>
+template <int RT, int ACT, int U>
 __global__ __launch_bounds__(256) void skinny_mfma_kernel(SkinnyArgs p) {
-  constexpr int RT = 2, NB = ACT == 2 ? 2 : 1, MT = RT * 16, CW = 16 * NB;
+  constexpr int NB = ACT == 2 ? 2 : 1, MT = RT * 16, CW = 16 * NB;
   extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
   float* red = reinterpret_cast<float*>(sk_smem);                      // [4 waves][MT][CW]
   const int tid = threadIdx.x, prob = blockIdx.y, lane = tid & 63, wave = tid >> 6;
@@ -205,20 +205,27 @@ __global__ __launch_bounds__(256) void skinny_mfma_kernel(SkinnyArgs p) {
     skinny_epilogue(p, prob, m, n, v, g, ACT);
   }
 }
-template <int ACT, int U>
+template <int RT, int ACT, int U>
 static int skinny_mfma_launch(SkinnyArgs a, int n_prob, hipStream_t stream) {
-  constexpr size_t smem = (size_t)4 * 32 * 16 * (ACT == 2 ? 2 : 1) * 4;
-  const int groups = (a.M + 31) / 32;
+  constexpr int MT = RT * 16;
+  constexpr size_t smem = (size_t)4 * MT * 16 * (ACT == 2 ? 2 : 1) * 4;
+  const int groups = (a.M + MT - 1) / MT;
   const long tiles = (long)((a.N + 15) / 16) * n_prob * groups;
   a.cn = tiles >= 192 ? 16 : (tiles >= 96 ? 8 : 4);          // at least ~256 workgroups where the layer has the columns
-  hipLaunchKernelGGL((skinny_mfma_kernel<ACT, U>), dim3((a.N + a.cn - 1) / a.cn, n_prob, groups), dim3(256), smem, stream, a);
+  auto kern = skinny_mfma_kernel<RT, ACT, U>;
+  static bool attr_done = false;
+  if (!attr_done && smem > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((a.N + a.cn - 1) / a.cn, n_prob, groups), dim3(256), smem, stream, a);
   return tell_check_launch("skinny_linear (mfma)");
 }
-template <int U>
+template <int RT, int U>
 static int skinny_mfma_dispatch(const SkinnyArgs& a, int n_prob, int act, hipStream_t stream) {
-  if (act == 0) return skinny_mfma_launch<0, U>(a, n_prob, stream);
-  if (act == 1) return skinny_mfma_launch<1, U>(a, n_prob, stream);
-  return skinny_mfma_launch<2, U>(a, n_prob, stream);
+  if (act == 0) return skinny_mfma_launch<RT, 0, U>(a, n_prob, stream);
+  if (act == 1) return skinny_mfma_launch<RT, 1, U>(a, n_prob, stream);
+  return skinny_mfma_launch<RT, 2, U>(a, n_prob, stream);
 }
 
 // LayerNorm of fp32 rows, one per `span` columns, to bf16 (the prologue as its own launch where the rows do not fit the
@@ -326,7 +333,12 @@ extern "C" int tell_skinny_linear(int n_prob, const void* const* in, long ld_in,
     for (int i = 0; i < SK_MAXP; ++i) a.in[i] = ws;
     a.ld_in = K; a.stats_out = nullptr;
   }
-  return K % 1024 == 0 ? skinny_mfma_dispatch<8>(a, n_prob, act, stream) : skinny_mfma_dispatch<2>(a, n_prob, act, stream);
+  // rows per workgroup: 32 (more workgroups) unless 128-row groups alone already fill the chip - then the weight
+  // fragments of a column tile are loaded once for 128 rows instead of four times
+  static const int rt_env = getenv("TELL_SK_ROWS") ? atoi(getenv("TELL_SK_ROWS")) : 0;          // A/B aid: 32 / 128
+  const bool tall = rt_env ? rt_env == 128 : (M > 64 && (long)((N + 15) / 16) * n_prob * ((M + 127) / 128) >= 192);
+  if (tall) return skinny_mfma_dispatch<8, 2>(a, n_prob, act, stream);
+  return K % 1024 == 0 ? skinny_mfma_dispatch<2, 8>(a, n_prob, act, stream) : skinny_mfma_dispatch<2, 2>(a, n_prob, act, stream);
 }
 
 // ------------------------------------------------------------------ DynamicConv step (T = 1, fixed K-1 row buffer)
