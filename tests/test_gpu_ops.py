@@ -764,3 +764,25 @@ def test_long_reduction_few_columns_split_k(monkeypatch):
     close(y1, ref.cpu(), torch.bfloat16, scale=math.sqrt(K) * 0.05)
     close(y0, ref.cpu(), torch.bfloat16, scale=math.sqrt(K) * 0.05)
     assert (y1[200:] == 0).all()
+
+
+@pytest.mark.parametrize('L', [3, 25])
+def test_weigh_bert_mix_forward_and_logit_gradient(L):
+    """sum_l softmax(w)[l] * H[l] (transformer_faces_objects.py:355-364): output and the gradient of the L mixing logits
+    (tell_mix_bwd partial sums + tell_mix_wgrad: column sums and the softmax chain rule in one launch) vs autograd."""
+    import tell_amd
+    from tell_amd import ops
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    g = torch.Generator().manual_seed(L)
+    stack = (torch.randn(L, 4, 64, 1024, generator=g) * 0.5).to(DEV, torch.bfloat16)
+    w = torch.nn.Parameter((torch.randn(L, generator=g) * 0.7).to(DEV))
+    dout = (torch.randn(4, 64, 1024, generator=g) * 0.1).to(DEV, torch.bfloat16)
+    out = ops.mix_layers(stack, w)
+    out.backward(dout)
+    got = ops.grad_buffer(w).clone()
+    w2 = w.detach().clone().requires_grad_(True)
+    ref = (torch.softmax(w2, 0).view(L, 1, 1, 1) * stack.float()).sum(0)
+    ref.backward(dout.float())
+    rel = ((out.float() - ref).norm() / ref.norm()).item()
+    assert rel < 5e-3, rel
+    torch.testing.assert_close(got, w2.grad, rtol=2e-2, atol=2e-3 * float(w2.grad.abs().max()))

@@ -617,30 +617,35 @@ extern "C" int tell_mix_bwd(const void* H, const void* dOut, int L, long n, floa
 
 // gw[l] += sm[l] * (d[l] - sum_j sm[j] d[j]),  sm = softmax(w), d[l] = sum over the n_blocks partial rows of tell_mix_bwd:
 // the gradient of the 25 mixing logits (transformer_faces_objects.py:355-364 backward), one workgroup.
-__global__ __launch_bounds__(64) void mix_wgrad_kernel(const float* __restrict__ partial, int n_blocks, int L,
-                                                       const float* __restrict__ w, float* __restrict__ gw) {
+__global__ __launch_bounds__(1024) void mix_wgrad_kernel(const float* __restrict__ partial, int n_blocks, int L,
+                                                         const float* __restrict__ w, float* __restrict__ gw) {
+  __shared__ float part[16][64];
   __shared__ float d[64], sm[64];
-  const int lane = threadIdx.x;
-  for (int l = 0; l < L; ++l) {
-    float s = 0.f;
-    for (int b = lane; b < n_blocks; b += 64) s += partial[(long)b * L + l];
-    s = wave_sum(s);
-    if (lane == 0) d[l] = s;
-  }
+  const int t = threadIdx.x, l = t & 63, g = t >> 6;              // 16 row groups x 64 columns (coalesced over l)
+  float s = 0.f;
+  if (l < L)
+    for (int b = g; b < n_blocks; b += 16) s += partial[(long)b * L + l];
+  part[g][l] = s;
   __syncthreads();
+  if (t < 64) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += part[q][t];
+    d[t] = v;
+  }
   float mx = -INFINITY;
-  for (int l = 0; l < L; ++l) mx = fmaxf(mx, w[l]);
+  for (int j = 0; j < L; ++j) mx = fmaxf(mx, w[j]);
   float den = 0.f;
-  for (int l = 0; l < L; ++l) den += __expf(w[l] - mx);
-  if (lane < L) sm[lane] = __expf(w[lane] - mx) / den;
+  for (int j = 0; j < L; ++j) den += __expf(w[j] - mx);
+  if (t < L) sm[t] = __expf(w[t] - mx) / den;
   __syncthreads();
   float dot = 0.f;
-  for (int l = 0; l < L; ++l) dot += sm[l] * d[l];
-  if (lane < L) gw[lane] += sm[lane] * (d[lane] - dot);
+  for (int j = 0; j < L; ++j) dot += sm[j] * d[j];
+  if (t < L) gw[t] += sm[t] * (d[t] - dot);
 }
 extern "C" int tell_mix_wgrad(const float* partial, int n_blocks, int L, const float* w, float* gw, hipStream_t stream) {
   TELL_REQUIRE(L >= 1 && L <= 64 && n_blocks >= 1, "mix_wgrad: L must be in [1,64]");
-  hipLaunchKernelGGL(mix_wgrad_kernel, dim3(1), dim3(64), 0, stream, partial, n_blocks, L, w, gw);
+  hipLaunchKernelGGL(mix_wgrad_kernel, dim3(1), dim3(1024), 0, stream, partial, n_blocks, L, w, gw);
   return tell_check_launch("mix_wgrad");
 }
 
