@@ -268,8 +268,8 @@ def test_full_size_greedy_decode_bit_exact_fp32_and_bf16_agreement():
     assert results[torch.bfloat16] >= 0.9, results
 
 
-@pytest.mark.parametrize('beams', [1, 4, 16])
-def test_fused_decode_step_matches_layer_by_layer_step_and_fp32(beams):
+@pytest.mark.parametrize('kind,beams', [('faces_objects', 1), ('faces_objects', 4), ('faces_objects', 16), ('flattened', 4)])
+def test_fused_decode_step_matches_layer_by_layer_step_and_fp32(kind, beams):
     """The generation step as weight-streaming launches (tell_amd/decode.py, csrc/decode.hip: skinny linears with
     LayerNorm prologues, DynamicConv step, grouped one-query attention) against (a) the layer-by-layer bf16 step it
     replaces and (b) the fp32 full-sequence decoder (itself bit-exact-greedy against the oracle above), teacher-forced
@@ -278,19 +278,19 @@ def test_fused_decode_step_matches_layer_by_layer_step_and_fp32(beams):
     import tell_amd
     from tell_amd import decode
     from tell_amd.build import build_decoder
-    o = _oracle('faces_objects')
+    o = _oracle(kind)
     ctx, ids, _ = o['inputs']
     STEPS = 8
     seq = ids[:, :STEPS].to(DEV)
     tell_amd.set_compute_dtype(torch.float32)
-    dec32 = build_decoder('faces_objects')
+    dec32 = build_decoder(kind)
     dec32.load_state_dict(o['sd'])
     dec32.to(DEV).eval()
     with torch.no_grad():
         want = dec32({'roberta': seq}, _to_dev(ctx, torch.float32))[0].float()            # [B, STEPS, E]
     del dec32
     tell_amd.set_compute_dtype(torch.bfloat16)
-    dec = build_decoder('faces_objects')
+    dec = build_decoder(kind)
     dec.load_state_dict(o['sd'])
     dec.to(DEV).eval()
     dctx = _to_dev(ctx, torch.bfloat16)
