@@ -356,13 +356,17 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
 
 
 
-def loader_bench(args, dev, n_batches=12, warm=4):
+def loader_bench(args, dev, n_batches=12, warm=4, variable=False):
     """the training step fed by the data plane instead of resident tensors - pre-tokenised `.npz` shards on
     tmpfs -> reader (`nytimes_faces_ner_matched`) -> BucketIterator -> collate (ids padded, faces / objects NaN-padded,
     uint8 pixels to the device + tell_image_normalize) -> train_one_batch with the NEXT batch's encoders launched
     underneath.  A background thread reads shards and builds instances one batch ahead; collate and the host->device
     copies run on the training thread.  -> samples/s over `n_batches` timed batches (bench shape: 512-token articles,
-    33-token captions, 4 faces, 64 objects, batch 32)."""
+    33-token captions, 4 faces, 64 objects, batch 32).
+    variable=True: article / caption lengths, face and object counts drawn as SURVEY 8d describes real data
+    (L ~ U{128..512}, T+1 ~ U{9..41}, faces U{0..4}, objects U{0..64}); the BucketIterator sorts by length with padding
+    noise, so batches differ in shape: the trainer pads to its shape buckets (64 article tokens, 8 caption tokens) and
+    captures a step graph per bucket signature at its second sighting - this leg times that policy."""
     import queue
     import shutil
     import tempfile
@@ -382,23 +386,36 @@ def loader_bench(args, dev, n_batches=12, warm=4):
         for sh in range(0, total, 128):
             samples = []
             for i in range(sh, min(sh + 128, total)):
-                cap = np.r_[0, g.randint(4, 50265, 31), 2]
-                samples.append({'context_ids': np.r_[0, g.randint(4, 50265, 510), 2], 'caption_ids': cap,
+                L, T = (g.randint(128, 513), g.randint(9, 42)) if variable else (512, 33)
+                F, O = (g.randint(0, 5), g.randint(0, 65)) if variable else (4, 64)
+                cap = np.r_[0, g.randint(4, 50265, T - 2), 2]
+                samples.append({'context_ids': np.r_[0, g.randint(4, 50265, L - 2), 2], 'caption_ids': cap,
                                 'image': g.randint(0, 256, (224, 224, 3)).astype(np.uint8),
-                                'face_embeds': g.randn(4, 512).astype(np.float32),
-                                'obj_embeds': np.abs(g.randn(64, 2048)).astype(np.float32),
+                                'face_embeds': g.randn(F, 512).astype(np.float32),
+                                'obj_embeds': np.abs(g.randn(O, 2048)).astype(np.float32),
                                 'metadata': {'caption': '', 'context': '', 'web_url': 'u%d' % i, 'image_path': '', 'image_pos': 0}})
             write_shard(os.path.join(root, 'train-%05d.npz' % (sh // 128)), samples)
         shard_mb = sum(os.path.getsize(os.path.join(root, f)) for f in os.listdir(root)) / 1e6
         write_s = time.perf_counter() - t0
         torch.manual_seed(0)
         model = build_model('faces_objects', weigh_bert=True)
-        trainer = Trainer(model, device=dev, capture_after=1)
+        trainer = Trainer(model, device=dev, capture_after=2 if variable else 1)
         reader = DatasetReader.by_name('nytimes_faces_ner_matched')(use_objects=True, shard_dir=root)
         it = BucketIterator(sorting_keys=[['context', 'num_tokens'], ['caption', 'num_tokens']], batch_size=B)
         q = queue.Queue(maxsize=2)
 
+        epochs = 3 if variable else 1
+
         def produce():                                  # shard decode + instance building, one batch ahead
+            if variable:                                # the iterator's own batching: sorted by length, padding noise
+                instances = list(reader._read('train'))
+                for ep in range(epochs):
+                    for group in it._batches(instances, shuffle=True):
+                        if len(group) == B:
+                            q.put(group)
+                    q.put('epoch')
+                q.put(None)
+                return
             group = []
             for inst in reader._read('train'):
                 group.append(inst)
@@ -409,11 +426,21 @@ def loader_bench(args, dev, n_batches=12, warm=4):
         th = threading.Thread(target=produce, daemon=True)
         th.start()
         host_ms, n_done, t_start = [], 0, None
-        cur = collate(q.get(), device=dev)
+        marks = []                                     # (steps done, wall clock) at every epoch end (variable leg)
+
+        def fetch():
+            while True:
+                g_ = q.get()
+                if isinstance(g_, str):                # epoch boundary
+                    torch.cuda.synchronize()
+                    marks.append((n_done + 1, time.perf_counter()))
+                    continue
+                return g_
+        cur = collate(fetch(), device=dev)
         with tell_amd.hip.bound_stream():
             while cur is not None:
                 h0 = time.perf_counter()
-                group = q.get()
+                group = fetch()
                 nxt = collate(group, device=dev) if group is not None else None
                 host_ms.append(1e3 * (time.perf_counter() - h0))
                 trainer.train_one_batch(cur, next_batch=nxt)
@@ -426,7 +453,16 @@ def loader_bench(args, dev, n_batches=12, warm=4):
         elapsed = time.perf_counter() - t_start
         timed = n_done - warm
         host = sorted(host_ms[warm:])
-        return {'value': round(B * timed / elapsed, 2), 'unit': 'samples/s', 'ms_per_step': round(1e3 * elapsed / timed, 3),
+        extra = {}
+        if variable:
+            sg = trainer.step_graph
+            extra = {'step_graph_replays': sg.replays if sg is not None else 0, 'steps_total': n_done,
+                     'shape_buckets': list(trainer.shape_buckets or ()), 'epochs': epochs}
+            if len(marks) >= 3:                        # steady state: the last epoch (every bucket signature captured)
+                (n1, t1), (n2, t2) = marks[-2], marks[-1]
+                extra['first_epochs_value'] = round(B * timed / elapsed, 2)
+                timed, elapsed = n2 - n1, t2 - t1
+        return {**extra, 'value': round(B * timed / elapsed, 2), 'unit': 'samples/s', 'ms_per_step': round(1e3 * elapsed / timed, 3),
                 'batches': timed, 'host_collate_ms_per_batch': round(host[len(host) // 2], 2),
                 'shard_mbytes': round(shard_mb, 1), 'shard_write_s': round(write_s, 1),
                 'pipeline': 'npz shards on tmpfs -> nytimes_faces_ner_matched reader (background thread, one batch ahead) '
@@ -629,6 +665,10 @@ def main():
             torch.cuda.empty_cache()
             result['loader'] = loader_bench(args, dev)
             result['loader']['resident_input_value'] = result['value']
+            gc.collect()
+            tell_amd.ops.clear_weight_cache()
+            torch.cuda.empty_cache()
+            result['loader_variable_lengths'] = loader_bench(args, dev, n_batches=22, warm=2, variable=True)
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.model, args.cpu_sample)
         print(json.dumps(result))

@@ -37,7 +37,7 @@ class no_gc:
 ENABLED = os.environ.get('TELL_GRAPHS', '1') != '0'
 
 
-MAX_SIGNATURES = 4      # every captured signature keeps its activations in a private pool
+MAX_SIGNATURES = 8      # every captured signature keeps its activations in a private pool (2-4 GB at B = 32; 288 GB HBM)
 # A signature is captured at its CAPTURE_AFTER-th sighting: real BucketIterator batches pad to the per-batch maximum,
 # so most shapes are seen once - capturing each of them would cost a host capture pass and pin a private activation
 # pool per shape for nothing.  Fixed-shape runs (bench.py) pass capture_after=1.

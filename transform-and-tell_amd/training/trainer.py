@@ -28,7 +28,7 @@ class TrainerBase(Registrable):
 class Trainer:
     def __init__(self, model, optimizer_cfg=None, no_grad=(r'^resnet', r'^roberta'), device='cuda',
                  nan_check=False, bucket_mb=256, async_update=None, allreduce_dtype=None, data_parallel=None,
-                 capture_after=None, shape_buckets=(64, 8)):
+                 capture_after=None, shape_buckets=(128, 16)):
         """nan_check=True: the reference's host-synchronous NaN test (returns None for a skipped batch, no step graph);
         the default skips non-finite steps on the device instead (self.skip, skipped_steps()).
 
