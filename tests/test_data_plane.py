@@ -271,3 +271,65 @@ def test_bleu_scorer_known_answers():
     s = BleuScorer(n=4)
     s += ('a b c', ['a b c d e f', 'a b'])
     assert s.ctest[0]['reflen'] == [6, 2] and s._single_reflen([6, 2], 'closest', 3) == 2
+
+
+def test_rouge_l_and_cider_known_answers():
+    """f4 (scripts/compute_metrics.py:146-148,178-179): ROUGE-L (beta 1.2) and CIDEr (n = 4, sigma = 6, clipped, Gaussian
+    length penalty) as pycocoevalcap's scorers compute them - hand-computed cases."""
+    import math
+    from tell_amd.metrics import CiderScorer, Rouge
+    # LCS("the cat sat on mat", "the cat is on the mat") = the cat on mat = 4: p = 4/5, r = 4/6
+    p_, r_, b2 = 4 / 5, 4 / 6, 1.2 ** 2
+    assert abs(Rouge().calc_score(['the cat sat on mat'], ['the cat is on the mat']) - (1 + b2) * p_ * r_ / (r_ + b2 * p_)) < 1e-12
+    assert Rouge().calc_score(['a b c'], ['x y z']) == 0.0
+    assert abs(Rouge().calc_score(['a b c'], ['a b c']) - 1.0) < 1e-12
+    assert abs(Rouge().calc_score(['a b'], ['x', 'a b c']) - (1 + b2) * 1.0 * (2 / 3) / (2 / 3 + b2 * 1.0)) < 1e-12   # best ref per side
+    # CIDEr: a hypothesis equal to its reference scores 10 once every order has an n-gram with non-zero idf
+    c = CiderScorer(n=4, sigma=6.0)
+    c += ('a b c d e', ['a b c d e'])
+    c += ('f g h i j', ['k l m n o'])
+    c += ('p q r s', ['p q r s t u'])
+    corpus, per = c.compute_score()
+    assert abs(per[0] - 10.0) < 1e-9 and per[1] == 0.0
+    # third sample by hand: idf = ln 3 for every n-gram (each occurs in one reference set); hyp n-grams are a subset of
+    # the reference's: cos_n = sqrt(#hyp n-grams / #ref n-grams) = sqrt((4-n)/(6-n)) for n = 0..3 (n+1 = order);
+    # lengths are bigram counts 3 and 5: penalty exp(-4 / 72)
+    want = 10.0 * math.exp(-4 / 72) * sum(math.sqrt((4 - k) / (6 - k)) for k in range(4)) / 4
+    assert abs(per[2] - want) < 1e-9 and abs(corpus - (10.0 + want) / 3) < 1e-9
+    # clipping: a repeated word cannot collect more than the reference holds
+    d = CiderScorer(n=1, sigma=6.0)
+    d += ('a a a a', ['a b'])
+    d += ('x', ['y'])
+    idf = math.log(2.0)
+    vh, vr_a, vr_b = 4 * idf, idf, idf
+    # (with n = 1 there are no bigrams: the scorer's 'length' is 0 on both sides, no penalty)
+    want1 = 10.0 * (min(vh, vr_a) * vr_a) / (vh * math.sqrt(vr_a ** 2 + vr_b ** 2))
+    assert abs(d.compute_score()[1][0] - want1) < 1e-9
+
+
+def test_compute_metrics_over_a_generations_file(tmp_path):
+    """The metric table of scripts/compute_metrics.py:179-298 over a generations.jsonl: text metrics always, name /
+    entity / readability tables when the records carry the NLP-derived keys."""
+    from collections import Counter
+    from tell_amd.commands import compute_metrics
+    recs = [
+        {'raw_caption': 'Ann Lee, left, and Bob Ray in Paris.', 'generation': 'Ann Lee and Bob Ray in Paris',
+         'caption_names': ['Ann Lee', 'Bob Ray'], 'generated_names': ['Ann Lee', 'Bob Ray'],
+         'caption_entities': [{'text': 'Ann Lee', 'label': 'PERSON'}, {'text': 'Paris', 'label': 'GPE'}],
+         'generated_entities': [{'text': 'Ann Lee', 'label': 'PERSON'}, {'text': 'Rome', 'label': 'GPE'}],
+         'caption_np': {'basic_ttr': 1.0}, 'gen_np': {'basic_ttr': 0.5}},
+        {'raw_caption': 'A quiet street in Rome.', 'generation': 'Cy Doe on a street',
+         'caption_names': [], 'generated_names': ['Cy Doe'], 'caption_np': {'basic_ttr': 0.8}, 'gen_np': {'basic_ttr': 0.7}},
+    ]
+    path = tmp_path / 'generations.jsonl'
+    path.write_text('\n'.join(json.dumps(r) for r in recs) + '\n')
+    m = compute_metrics(str(path), counters={'caption': Counter({'Ann Lee': 3}), 'context': Counter({'Bob Ray': 1})})
+    assert 0 < m['BLEU-4'] < m['BLEU-1'] <= 1 and 0 < m['ROUGE'] < 1 and m['CIDEr'] > 0 and m['METEOR'] is None
+    assert m['All names - recall'] == {'count': 2, 'total': 2, 'percentage': 1.0}
+    assert m['All names - precision'] == {'count': 2, 'total': 3, 'percentage': 2 / 3}
+    assert m['Caption rare names - recall'] == {'count': 1, 'total': 1, 'percentage': 1.0}        # Bob Ray (Ann Lee is frequent)
+    assert m['Article rare names - precision']['total'] == 1                                        # only Cy Doe is unseen
+    assert m['Length - generation'] == (7 + 5) / 2 and m['Length - reference'] == (8 + 5) / 2
+    assert m['Entity all - recall'] == {'count': 1, 'total': 2, 'percentage': 0.5}
+    assert m['Entity GPE - precision'] == {'count': 0, 'total': 1, 'percentage': 0.0}
+    assert abs(m['Generation TTR'] - 0.6) < 1e-12 and 'Generation Flesch Reading Ease' not in m
