@@ -424,7 +424,8 @@ int tell_conv_bn_stats(const void* x, const void* w, void* y, int B, int H, int 
  * trunk runs in train mode, callback_apex_trainer.py:259): the implicit-GEMM convolution of tell_conv_bn_stats, then the
  * combine of the per-row-chunk statistics AND the normalisation as ONE launch (two when the activation has more than
  * 128 row chunks).  y [B*OH*OW, Cout] bf16 receives the finished activation; residual (same shape) or NULL;
- * running_mean / running_var get the momentum update.  workspace: 2 * ceil(M / 64) * Cout + 2 * Cout floats. */
+ * running_mean / running_var get the momentum update.  workspace: 2 * ceil(M / 64) * Cout + 258 * Cout floats (chunk statistics, mean / invstd, and the
+ * super-chunk statistics of the > 128-chunk case: one parallel merge launch in front of the fused finish + apply). */
 int tell_conv_bn_act(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int KH, int KW, int stride,
                      int pad, int OH, int OW, int Cout, float eps, float momentum, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, const void* residual, int relu, float* workspace,

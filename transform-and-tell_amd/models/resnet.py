@@ -186,7 +186,7 @@ def conv_bn_implicit(x, B, H, W, conv, bn, relu, residual, training, slot=0):
     wq = conv.gemm_weight()
     y = torch.empty(M, C, dtype=x.dtype, device=x.device)
     if training:
-        ws, _ = _stat_buffers(x.device, 2 * ((M + 63) // 64) * C + 2 * C, C)
+        ws, _ = _stat_buffers(x.device, 2 * ((M + 63) // 64) * C + 2 * C + 256 * C, C)
         call('tell_conv_bn_act', x, wq, y, B, H, W, conv.cin, k, k, s, p, OH, OW, C, bn.eps, bn.momentum,
              bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, residual, int(relu), ws,
              _zero_page(x.device))
