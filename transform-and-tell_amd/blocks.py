@@ -19,6 +19,8 @@ Parameter gradients never travel through autograd here either: weight gradients 
 launches (ops.gemm_tn), LayerNorm gamma / beta and bias rows for its single column-sum launch (ops.finish_job)."""
 import ctypes
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -208,6 +210,9 @@ def _kv_weight(m):
     return w, m.in_proj_bias.detach()[E:3 * E], (wk, rk, wv, rv)
 
 
+_KV_PP = os.environ.get('TELL_KV_PP', '1') != '0'          # A/B aid
+
+
 class KVAllFn(Function):
     """The packed K|V projection [S,B,2E] of EVERY (layer, context) pair as one grouped launch: they depend on the
     static contexts and the layers' weights only, not on the decoder state, so none of them belongs inside the layer
@@ -256,7 +261,15 @@ class KVAllFn(Function):
                 meta[j] = (w, wmeta, s2)
                 if ci in cat:
                     ops._DKV_TARGET[outs[j].data_ptr()] = as_sbe(cat[ci][1][:, k * E2:(k + 1) * E2], ci, E2)
-        ops.gemm_grouped(probs)
+        # the article's projections (B*S = 16384 rows at B = 32) are whole rounds of 256x256 tiles: the ping-pong GEMM
+        # runs them at ~800 TFLOP/s, the grouped 128x128 kernel at ~520; everything small stays one grouped launch
+        big = [q for q in probs if _KV_PP and q['a'].shape[0] >= 8192 and q['a'].shape[0] % 256 == 0 and
+               q['b'].shape[0] % 256 == 0]
+        for q in big:
+            ops.gemm(q['a'], q['b'], out=q['out'], bias=q['bias'], bias_mode=1 if q['bias'] is not None else 0)
+        rest = [q for q in probs if not any(q is b_ for b_ in big)]
+        if rest:
+            ops.gemm_grouped(rest)
         ctx.jobs, ctx.meta, ctx.cat, ctx.by_ctx, ctx.bmaj = jobs, meta, cat, by_ctx, bmaj
         ctx.need_dx = [t.requires_grad for t in ctxs]
         ctx.src_shapes = [tuple(t.shape) for t in srcs]
