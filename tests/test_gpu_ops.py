@@ -786,3 +786,62 @@ def test_weigh_bert_mix_forward_and_logit_gradient(L):
     rel = ((out.float() - ref).norm() / ref.norm()).item()
     assert rel < 5e-3, rel
     torch.testing.assert_close(got, w2.grad, rtol=2e-2, atol=2e-3 * float(w2.grad.abs().max()))
+
+
+def test_beam_bookkeeping_kernels_match_the_tensor_formulation():
+    """tell_beam_update (candidate scores, top-K per sample, histories gathered by parent, next inputs, parent rows) and
+    tell_reorder_rows (every layer's DynamicConv buffer rows follow their hypotheses, in place) against the elementwise /
+    gather / topk formulation they replace in CaptionModel._generate_beam, over several steps with random head outputs,
+    finished hypotheses and an EOS token in play."""
+    from tell_amd import ops
+    B, K, L, pad, eos, temp = 5, 4, 12, 1, 2, 0.7
+    g = torch.Generator().manual_seed(3)
+    cum = torch.full((B, K), float('-inf'), device=DEV)
+    cum[:, 0] = 0.0
+    finished = torch.zeros(B, K, dtype=torch.bool, device=DEV)
+    seqs = torch.full((B, K, L), pad, dtype=torch.long, device=DEV)
+    seqs[:, :, 0] = 0
+    lps = torch.zeros(B, K, L - 1, device=DEV)
+    k_cum, k_fin, k_seqs, k_lps = cum.clone(), finished.to(torch.uint8), seqs.clone(), lps.clone()
+    k_cur = torch.zeros(B * K, dtype=torch.long, device=DEV)
+    k_rows = torch.zeros(B * K, dtype=torch.long, device=DEV)
+    bufs = [torch.randn(p, B * K, 1024, generator=g).to(DEV, torch.bfloat16) for p in (2, 6, 0, 14)]
+    ref_bufs = [b.clone() for b in bufs]
+    base = (torch.arange(B, device=DEV) * K).view(B, 1)
+    for i in range(L - 1):
+        lp_raw = torch.log_softmax(torch.randn(B, K, 50, generator=g), -1).topk(K, dim=-1)
+        tk = lp_raw.indices.to(DEV, torch.int32).contiguous()
+        tk[tk == 7] = eos                                              # some hypotheses end
+        lp_t = lp_raw.values.to(DEV).contiguous()
+        # ---- tensor formulation (transformer.py, the non-fused branch)
+        tkl, lp = tk.long(), lp_t / temp
+        fin = finished.unsqueeze(-1)
+        first = torch.zeros(K, dtype=torch.bool, device=DEV)
+        first[0] = True
+        lp = torch.where(fin, torch.where(first, torch.zeros_like(lp), torch.full_like(lp, float('-inf'))), lp)
+        tkl = torch.where(fin, torch.full_like(tkl, pad), tkl)
+        top, idx = (cum.unsqueeze(-1) + lp).view(B, K * K).topk(K, dim=1)
+        parent = idx // K
+        tok = tkl.view(B, K * K).gather(1, idx)
+        rows = (base + parent).view(-1)
+        was = finished.gather(1, parent)
+        tok = torch.where(was, torch.full_like(tok, pad), tok)
+        seqs = seqs.view(B * K, -1).index_select(0, rows).view(B, K, -1)
+        lps = lps.view(B * K, -1).index_select(0, rows).view(B, K, -1)
+        seqs[:, :, i + 1] = tok
+        lps[:, :, i] = torch.where(was, torch.zeros_like(top), top - cum.gather(1, parent))
+        finished = was | (tok == eos)
+        cum = top
+        ref_bufs = [b.index_select(1, rows) for b in ref_bufs]
+        # ---- kernels
+        ops.call('tell_beam_update', tk, lp_t, k_cum, k_fin, k_seqs, k_lps, k_cur, k_rows, B, K, L, i, pad, eos, 1.0 / temp)
+        live = [b for b in bufs if b.shape[0] > 0]
+        ops.call('tell_reorder_rows', len(live), ops._ptr_array(live), ops._int_array([b.shape[0] for b in live]), k_rows,
+                 B * K, 1024, K)
+        assert torch.equal(k_rows, rows) and torch.equal(k_cur, tok.reshape(-1)), i
+        assert torch.equal(k_seqs, seqs) and torch.equal(k_fin.bool(), finished), i
+        torch.testing.assert_close(k_cum, cum, rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(k_lps, lps, rtol=1e-6, atol=1e-6)
+        for a_, b_ in zip(bufs, ref_bufs):
+            assert torch.equal(a_, b_), i
+    assert bool(finished.any()) and not bool(finished.all())
