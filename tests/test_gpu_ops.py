@@ -845,3 +845,139 @@ def test_beam_bookkeeping_kernels_match_the_tensor_formulation():
         for a_, b_ in zip(bufs, ref_bufs):
             assert torch.equal(a_, b_), i
     assert bool(finished.any()) and not bool(finished.all())
+
+
+@pytest.mark.parametrize('beams', [1, 2, 4, 6])
+def test_one_query_attention_over_cached_contexts(beams):
+    """tell_attn_decode (generation step: up to 4 contexts in one launch, the hypotheses of a beam share their sample's
+    K/V, bias_k / bias_v and the zero row as extra keys) against tell_attn_fwd with the hypotheses presented as query
+    positions - including an EMPTY context (S = 0: only the two virtual keys), a fully masked sample and ragged masks."""
+    import ctypes
+    import tell_amd
+    from tell_amd import ops
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    n, H, E = 3, 16, 1024                      # samples
+    M = n * beams
+    g = torch.Generator().manual_seed(beams)
+    S_list = [0, 5, 70, 512]
+    bf = dict(dtype=torch.bfloat16, device=DEV)
+    q = [(torch.randn(M, E, generator=g) * 0.3).to(**bf) for _ in S_list]
+    ks = [(torch.randn(S, n, E, generator=g) * 0.5).to(**bf) for S in S_list]
+    vs = [(torch.randn(S, n, E, generator=g) * 0.5).to(**bf) for S in S_list]
+    masks = []
+    for S in S_list:
+        lens = torch.randint(0, S + 1, (n,), generator=g)
+        lens[0] = 0                                             # sample 0: every real key masked
+        masks.append((torch.arange(S)[None, :] >= lens[:, None]).to(torch.uint8).to(DEV).contiguous())
+    bk = [torch.nn.Parameter((torch.randn(1, 1, E, generator=g) * 0.3).to(DEV)) for _ in S_list]
+    bv = [torch.nn.Parameter((torch.randn(1, 1, E, generator=g) * 0.3).to(DEV)) for _ in S_list]
+    want = []
+    for c, S in enumerate(S_list):
+        qq = q[c].view(n, beams, E).transpose(0, 1)             # [beams, n, E]: hypotheses as query positions
+        out, _ = ops.attention(qq, ks[c], vs[c], masks[c] if S else None, bk[c], bv[c], H, True, 0.0, False,
+                               return_lse=True)
+        want.append(out.transpose(0, 1).reshape(M, E))
+    outs = [torch.empty(M, E, **bf) for _ in S_list]
+    P = lambda ts: (ctypes.c_void_p * len(ts))(*[(t.data_ptr() if t is not None else 0) for t in ts])   # noqa: E731
+    Lg = lambda v: (ctypes.c_long * len(v))(*v)                                                        # noqa: E731
+    kk = [k if k.shape[0] else q[c] for c, k in enumerate(ks)]
+    vv = [v if v.shape[0] else q[c] for c, v in enumerate(vs)]
+    ops.call('tell_attn_decode', 4, P(q), Lg([E] * 4), P(kk), Lg([k.stride(0) if k.dim() == 3 else 0 for k in kk]),
+             Lg([k.stride(1) if k.dim() == 3 else 0 for k in kk]), P(vv),
+             Lg([v.stride(0) if v.dim() == 3 else 0 for v in vv]), Lg([v.stride(1) if v.dim() == 3 else 0 for v in vv]),
+             P([m if S else None for m, S in zip(masks, S_list)]),
+             P([ops._bias_row(b, torch.bfloat16) for b in bk]), P([ops._bias_row(b, torch.bfloat16) for b in bv]), 1,
+             (ctypes.c_int * 4)(*S_list), P(outs), Lg([E] * 4), M, H, beams)
+    for c in range(4):
+        rel = ((outs[c].float() - want[c].float()).norm() / want[c].float().norm()).item()
+        assert rel < 1e-2, (S_list[c], rel)          # bf16 outputs; the MFMA kernel rounds probabilities to bf16, this one does not
+
+
+@pytest.mark.parametrize('M', [5, 32, 70, 128])
+def test_generation_step_linears_layernorm_and_dynconv_step(M):
+    """csrc/decode.hip entry points against torch at the shapes of one decoder layer: tell_skinny_linear with every
+    prologue / epilogue the step uses (GLU, ReLU, scale, bf16 / fp32 / LayerNorm-rebuilt residuals, 4 problems per launch,
+    the four-segment LayerNorm in front of context_fc, the bf16 side copy of trailing columns), tell_layernorm_rows,
+    tell_dynconv_step (K = 3 and 31: tap softmax, window sum, in-place buffer shift)."""
+    import torch.nn.functional as Fn
+    import tell_amd
+    from tell_amd import decode, ops
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    E, F = 1024, 4096
+    g = torch.Generator().manual_seed(M)
+    bf, f32 = dict(dtype=torch.bfloat16, device=DEV), dict(dtype=torch.float32, device=DEV)
+    R = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k)                         # noqa: E731
+
+    class LN:
+        def __init__(self):
+            self.weight, self.bias, self.eps = (torch.rand(E, generator=g) + 0.5).to(**f32), R(E, k=0.1).to(**f32), 1e-5
+    rel = lambda a, b: ((a.float() - b.float()).norm() / (b.float().norm() + 1e-20)).item()   # noqa: E731
+    lnf = lambda t, l: Fn.layer_norm(t, (E,), l.weight, l.bias, l.eps)                        # noqa: E731
+    W = lambda n_, k_: R(n_, k_, k=0.03).to(**bf)                                             # noqa: E731
+    Bv = lambda n_: R(n_, k=0.1).to(**f32)                                                    # noqa: E731
+    x, x4 = R(M, E).to(**bf), R(M, F).to(**bf)
+    raw, raw4 = (R(M, E, k=2.0) + 0.3).to(**f32), (R(M, 4 * E, k=2.0) - 0.2).to(**f32)
+    ln, lns = LN(), [LN() for _ in range(4)]
+    xn = lnf(raw, ln)
+    # linear1 + GLU, from bf16 rows and from LayerNorm(fp32 rows) (+ row statistics)
+    w, b = W(2 * E, E), Bv(2 * E)
+    out = torch.empty(M, E, **bf)
+    decode._skinny([x], E, [w], [b], [out], E, M, E, E, act=2)
+    assert rel(out, Fn.glu(x.float() @ w.float().t() + b, dim=-1)) < 4e-3
+    st = torch.zeros(M, 2, **f32)
+    decode._skinny([raw], E, [w], [b], [out], E, M, E, E, pro=1, gammas=[ln.weight], betas=[ln.bias], stats_out=st, act=2)
+    assert rel(out, Fn.glu(xn.bfloat16().float() @ w.float().t() + b, dim=-1)) < 4e-3
+    torch.testing.assert_close(st[:, 0], raw.mean(1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(st[:, 1], (raw.var(1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-5, atol=1e-6)
+    # linear2 + bf16 residual / + LayerNorm(fp32 rows) rebuilt from the statistics / + fp32 residual, fp32 out
+    w, b = W(E, E), Bv(E)
+    o32 = torch.empty(M, E, **f32)
+    decode._skinny([x], E, [w], [b], [o32], E, M, E, E, res=x, ld_res=E, out_f32=True)
+    assert rel(o32, x.float() @ w.float().t() + b + x.float()) < 1e-5
+    decode._skinny([x], E, [w], [b], [o32], E, M, E, E, res_raw=raw, res_stats=st, res_ln=ln, out_f32=True)
+    assert rel(o32, x.float() @ w.float().t() + b + xn) < 1e-5
+    decode._skinny([x], E, [w], None, [o32], E, M, E, E, scale=0.5, res_f32=raw, out_f32=True)
+    assert rel(o32, (x.float() @ w.float().t()) * 0.5 + raw) < 1e-5
+    # 4 problems per launch: query projections (LayerNorm first, scaled), output projections into column slices
+    wq, bq = [W(E, E) for _ in range(4)], [Bv(E) for _ in range(4)]
+    q4 = torch.empty(4, M, E, **bf)
+    decode._skinny([raw] * 4, E, wq, bq, [q4[i] for i in range(4)], E, M, E, E, pro=1, gammas=[ln.weight], betas=[ln.bias],
+                   stats_out=st, scale=0.125)
+    r6 = torch.empty(M, 4 * E, **f32)
+    decode._skinny([q4[i] for i in range(4)], E, wq, bq, [r6[:, i * E:(i + 1) * E] for i in range(4)], 4 * E, M, E, E,
+                   res_raw=raw, res_stats=st, res_ln=ln, out_f32=True)
+    for i in range(4):
+        assert rel(q4[i], (xn.bfloat16().float() @ wq[i].float().t() + bq[i]) * 0.125) < 4e-3
+        assert rel(r6[:, i * E:(i + 1) * E], q4[i].float() @ wq[i].float().t() + bq[i] + xn) < 1e-5
+    # context_fc behind the four LayerNorms; fc1 + ReLU; fc2 (K = 4096) + residual; the side copy of trailing columns
+    wc, bc = W(E, 4 * E), Bv(E)
+    decode._skinny([raw4], 4 * E, [wc], [bc], [out], E, M, E, 4 * E, pro=2, gammas=[l.weight for l in lns],
+                   betas=[l.bias for l in lns], seg=E)
+    cat = torch.cat([lnf(raw4[:, i * E:(i + 1) * E], lns[i]) for i in range(4)], 1)
+    assert rel(out, cat.bfloat16().float() @ wc.float().t() + bc) < 4e-3
+    w1, b1, w2, b2 = W(F, E), Bv(F), W(E, F), Bv(E)
+    h = torch.empty(M, F, **bf)
+    decode._skinny([x], E, [w1], [b1], [h], F, M, F, E, act=1)
+    assert rel(h, torch.relu(x.float() @ w1.float().t() + b1)) < 4e-3
+    decode._skinny([x4], F, [w2], [b2], [o32], E, M, E, F, res=x, ld_res=E, out_f32=True)
+    assert rel(o32, x4.float() @ w2.float().t() + b2 + x.float()) < 1e-5
+    wo = W(1000 + 24, E)                                     # 1000 fp32 logits + 24 projected columns also as bf16
+    lo = torch.empty(M, 1024, **f32)
+    side = torch.empty(M, 24, **bf)
+    decode._skinny([x], E, [wo], None, [lo], 1024, M, 1024, E, out2=side, out2_from=1000, out_f32=True)
+    assert rel(lo, x.float() @ wo.float().t()) < 1e-5 and torch.equal(side, lo[:, 1000:].bfloat16())
+    # LayerNorm of fp32 rows to bf16
+    y = torch.empty(M, E, **bf)
+    ops.call('tell_layernorm_rows', raw, E, ln.weight, ln.bias, ln.eps, y, E, None, M, E)
+    assert rel(y, xn) < 4e-3
+    # DynamicConv step
+    for K in (3, 31):
+        H = 16
+        wt = W(H * K, E)
+        hist = R(K - 1, M, E).to(**bf)
+        h0 = hist.clone()
+        ops.call('tell_dynconv_step', x, hist, wt, out, M, E, H, K)
+        taps = torch.softmax((x.float() @ wt.float().t()).view(M, H, K), -1)
+        win = torch.cat([h0, x[None]], 0).float().view(K, M, H, 64)
+        assert rel(out, torch.einsum('mhk,kmhd->mhd', taps, win).reshape(M, E)) < 4e-3
+        assert torch.equal(hist, torch.cat([h0[1:], x[None]], 0))
