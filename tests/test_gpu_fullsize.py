@@ -180,6 +180,11 @@ def test_full_vocabulary_argmax_bit_exact_fp32():
     torch.testing.assert_close(got_lp.reshape(-1).cpu(), want_lp, rtol=1e-5, atol=1e-5)
     full = asm.get_log_prob(x.to(DEV)).reshape(-1, 50265).cpu()
     torch.testing.assert_close(full, lp, rtol=1e-4, atol=2e-5)
+    # beam search's head: the 4 best of every row (register-resident top-k), best first == topk of the full row
+    tk, tl = asm.topk(x.to(DEV), 4)
+    want_tl, want_tk = lp.topk(4, dim=-1)
+    assert torch.equal(tk.reshape(-1, 4).cpu().long(), want_tk)
+    torch.testing.assert_close(tl.reshape(-1, 4).cpu(), want_tl, rtol=1e-5, atol=1e-5)
 
 
 def test_generation_head_as_skinny_launches_matches_gemm_head_bf16():
