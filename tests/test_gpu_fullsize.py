@@ -267,6 +267,33 @@ def test_full_size_greedy_decode_bit_exact_fp32_and_bf16_agreement():
             tok, _ = dec.adaptive_softmax.greedy(out)
             valid = (want[:, :-1] != 1) & (want[:, 1:] != 1)
             results[dtype] = float((tok.cpu().long() == want[:, 1:])[valid].float().mean())
+    # the bf16 generators themselves (captured decode step, device position counter): the weight-streaming step
+    # (tell_amd/decode.py) and the layer-by-layer step, greedy and beam 4, against the fp32 oracle's greedy tokens
+    from tell_amd import decode
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    prev = decode.ENABLED
+    gen = {}
+    try:
+        for fused in (True, False):
+            decode.ENABLED = fused
+            m.__dict__.pop('_decode_graphs', None)
+            with torch.no_grad():
+                for rep in range(2):                         # second call: every step is a graph replay
+                    _, got, _ = m._generate_cached(ids[:, :1].to(DEV), dctx, gen_len=GEN, eos=2)
+                _, beam, _ = m._generate_beam(ids[:, :1].to(DEV), dctx, 4, gen_len=GEN, eos=2)
+            if tell_amd.graphs.ENABLED:
+                hs = list(m.__dict__.get('_decode_graphs', {}).values())
+                assert hs and all(h['graph'] not in (None, False) for h in hs), [h.get('error') for h in hs]
+            gen[fused] = (got.cpu(), beam.cpu())
+    finally:
+        decode.ENABLED = prev
+    n = min(gen[True][0].shape[1], want.shape[1])
+    agree = {f: float((gen[f][0][:, :n] == want[:, :n]).float().mean()) for f in gen}
+    print('\nbf16 captured greedy decode vs the fp32 oracle tokens: weight-streaming step %.3f, layer-by-layer %.3f'
+          % (agree[True], agree[False]))
+    assert agree[True] >= 0.9 and agree[True] >= agree[False] - 0.1, agree
+    nb = min(gen[True][1].shape[1], gen[False][1].shape[1])
+    assert float((gen[True][1][:, :nb] == gen[False][1][:, :nb]).float().mean()) >= 0.8
     print('\nfull-size greedy, teacher-forced arg-max agreement with the fp32 oracle tokens: fp32 %.3f  bf16 %.3f'
           % (results[torch.float32], results[torch.bfloat16]))
     assert results[torch.float32] == 1.0
