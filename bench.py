@@ -524,6 +524,12 @@ def generate_bench(args, dev, world, rank, dist):
     kv_bytes = 2 * 4 * B * (512 + 49 + 64 + 4 + 8) * 2 * E
     step_us = 1e3 * dec_ms / max(n_steps, 1)
     tbs = (w_bytes + kv_bytes) / (step_us * 1e-6) / 1e12
+    traffic, tnote = None, None
+    pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_generate_%s_traffic.json' % ('beam%d' % beam if beam > 1 else 'greedy'))
+    if os.path.exists(pmc) and B == 32:          # HBM bytes of one captured decode step from the committed PMC passes
+        traffic = json.load(open(pmc))['traffic_bytes_per_step']
+        tnote = 'bytes per decode step, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE summed over the ' \
+                'kernels of one step (tools/pmc_generate_traffic.sh), profiles/' + os.path.basename(pmc)
     return {
         'metric': 'caption generation throughput (img+article->caption), beam %d' % beam if beam > 1 else
                   'caption generation throughput (img+article->caption), greedy',
@@ -539,7 +545,7 @@ def generate_bench(args, dev, world, rank, dist):
                    'parallelism': 'replicas x%d' % world},
         'roofline': {'bound': 'hbm', 'kernel': 'captured decode step (one hipGraph replay per generated token)',
                      'achieved': round(tbs, 3), 'peak': 8.0, 'unit': 'TB/s', 'frac': round(tbs / 8.0, 4),
-                     'traffic': None, 'avg_step_us': round(step_us, 1),
+                     'traffic': traffic, 'traffic_note': tnote, 'avg_step_us': round(step_us, 1),
                      'algorithmic_bytes_per_step': int(w_bytes + kv_bytes),
                      'note': 'decoder per-token weights + tied softmax tables (%.0f MB) + projected K/V of the 4 '
                              'contexts read once per sample (%.0f MB), per decode step; duration = HIP events around '
