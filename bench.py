@@ -360,8 +360,9 @@ def loader_bench(args, dev, n_batches=12, warm=4, variable=False):
     """the training step fed by the data plane instead of resident tensors - pre-tokenised `.npz` shards on
     tmpfs -> reader (`nytimes_faces_ner_matched`) -> BucketIterator -> collate (ids padded, faces / objects NaN-padded,
     uint8 pixels to the device + tell_image_normalize) -> train_one_batch with the NEXT batch's encoders launched
-    underneath.  A background thread reads shards and builds instances one batch ahead; collate and the host->device
-    copies run on the training thread.  -> samples/s over `n_batches` timed batches (bench shape: 512-token articles,
+    underneath.  A background thread reads shards, builds instances and collates them into pinned host tensors one
+    batch ahead (`collate_host`); the training thread only issues the asynchronous host->device copies + the normalize
+    kernel (`to_device`).  -> samples/s over `n_batches` timed batches (bench shape: 512-token articles,
     33-token captions, 4 faces, 64 objects, batch 32).
     variable=True: article / caption lengths, face and object counts drawn as SURVEY 8d describes real data
     (L ~ U{128..512}, T+1 ~ U{9..41}, faces U{0..4}, objects U{0..64}); the BucketIterator sorts by length with padding
@@ -375,7 +376,7 @@ def loader_bench(args, dev, n_batches=12, warm=4, variable=False):
     import tell_amd
     from tell_amd.build import build_model
     from tell_amd.data import BucketIterator, DatasetReader, write_shard
-    from tell_amd.data.iterators import collate
+    from tell_amd.data.iterators import collate_host, to_device
     from tell_amd.training import Trainer
     B = args.batch
     root = tempfile.mkdtemp(prefix='tell_shards_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
@@ -403,6 +404,7 @@ def loader_bench(args, dev, n_batches=12, warm=4, variable=False):
         reader = DatasetReader.by_name('nytimes_faces_ner_matched')(use_objects=True, shard_dir=root)
         it = BucketIterator(sorting_keys=[['context', 'num_tokens'], ['caption', 'num_tokens']], batch_size=B)
         q = queue.Queue(maxsize=2)
+        PIN = os.environ.get('TELL_LOADER_PIN', '0') == '1'      # page-locking 21 MB per batch costs more than it saves
 
         epochs = 3 if variable else 1
 
@@ -412,7 +414,7 @@ def loader_bench(args, dev, n_batches=12, warm=4, variable=False):
                 for ep in range(epochs):
                     for group in it._batches(instances, shuffle=True):
                         if len(group) == B:
-                            q.put(group)
+                            q.put(collate_host(group, pin=PIN))
                     q.put('epoch')
                 q.put(None)
                 return
@@ -420,7 +422,7 @@ def loader_bench(args, dev, n_batches=12, warm=4, variable=False):
             for inst in reader._read('train'):
                 group.append(inst)
                 if len(group) == B:
-                    q.put(group)
+                    q.put(collate_host(group, pin=PIN))
                     group = []
             q.put(None)
         th = threading.Thread(target=produce, daemon=True)
@@ -436,12 +438,12 @@ def loader_bench(args, dev, n_batches=12, warm=4, variable=False):
                     marks.append((n_done + 1, time.perf_counter()))
                     continue
                 return g_
-        cur = collate(fetch(), device=dev)
+        cur = to_device(fetch(), dev)
         with tell_amd.hip.bound_stream():
             while cur is not None:
                 h0 = time.perf_counter()
                 group = fetch()
-                nxt = collate(group, device=dev) if group is not None else None
+                nxt = to_device(group, dev) if group is not None else None
                 host_ms.append(1e3 * (time.perf_counter() - h0))
                 trainer.train_one_batch(cur, next_batch=nxt)
                 n_done += 1
@@ -463,10 +465,11 @@ def loader_bench(args, dev, n_batches=12, warm=4, variable=False):
                 extra['first_epochs_value'] = round(B * timed / elapsed, 2)
                 timed, elapsed = n2 - n1, t2 - t1
         return {**extra, 'value': round(B * timed / elapsed, 2), 'unit': 'samples/s', 'ms_per_step': round(1e3 * elapsed / timed, 3),
-                'batches': timed, 'host_collate_ms_per_batch': round(host[len(host) // 2], 2),
+                'batches': timed, 'host_ms_per_batch_on_the_training_thread': round(host[len(host) // 2], 2),
                 'shard_mbytes': round(shard_mb, 1), 'shard_write_s': round(write_s, 1),
-                'pipeline': 'npz shards on tmpfs -> nytimes_faces_ner_matched reader (background thread, one batch ahead) '
-                            '-> collate -> H2D + tell_image_normalize -> Trainer.train_one_batch(next_batch=...)'}
+                'pipeline': 'npz shards on tmpfs -> nytimes_faces_ner_matched reader -> collate_host into pinned tensors '
+                            '(background thread, one batch ahead) -> async H2D + tell_image_normalize -> '
+                            'Trainer.train_one_batch(next_batch=...)'}
     finally:
         shutil.rmtree(root, ignore_errors=True)
 

@@ -25,7 +25,7 @@ def padding_length(instance, field, key='num_tokens'):
 
 def normalize_images(images_u8, device):
     """uint8 [B,H,W,3] -> float32 [B,3,H,W]: ToTensor + Normalize on the device (one HIP kernel on the GPU)."""
-    x = torch.as_tensor(np.ascontiguousarray(images_u8)).to(device)
+    x = images_u8.to(device) if torch.is_tensor(images_u8) else torch.as_tensor(np.ascontiguousarray(images_u8)).to(device)
     B, H, W, C = x.shape
     if x.is_cuda:
         from .. import hip
@@ -36,8 +36,13 @@ def normalize_images(images_u8, device):
     return (x - torch.tensor(MEAN).view(1, 3, 1, 1)) / torch.tensor(STD).view(1, 3, 1, 1)
 
 
-def collate(instances, device='cpu', padding_value=1):
-    """list of reader instances -> the kwargs of Model.forward (transformer_faces_objects.py:67-76)."""
+def collate_host(instances, padding_value=1, pin=False):
+    """list of reader instances -> the batch as HOST tensors (ids padded, faces / objects NaN-padded, pixels still uint8
+    NHWC): everything of `collate` that needs no device, so that a loader thread can run it one batch ahead.
+    pin=True: page-locked buffers (the copies of `to_device` are then asynchronous)."""
+    def host(arr):
+        t = torch.from_numpy(arr)
+        return t.pin_memory() if pin and torch.cuda.is_available() else t
     batch = {}
     for field in ('context', 'caption'):
         keys = instances[0][field].keys()
@@ -45,9 +50,12 @@ def collate(instances, device='cpu', padding_value=1):
         batch[field] = {}
         for k in keys:
             pad = -1 if 'copy_masks' in k else padding_value
-            rows = [list(i[field][k]) + [pad] * (n - len(i[field][k])) for i in instances]
-            batch[field][k] = torch.tensor(rows, dtype=torch.long, device=device)
-    batch['image'] = normalize_images(np.stack([i['image'] for i in instances]), device)
+            rows = np.full((len(instances), n), pad, dtype=np.int64)
+            for j, inst in enumerate(instances):
+                v = inst[field][k]
+                rows[j, :len(v)] = v
+            batch[field][k] = host(rows)
+    batch['image_u8'] = host(np.stack([i['image'] for i in instances]))
     for field in ('face_embeds', 'obj_embeds'):
         if field not in instances[0]:
             continue
@@ -57,9 +65,31 @@ def collate(instances, device='cpu', padding_value=1):
         out = np.full((len(arrs), rows, dim), np.nan, dtype=np.float32)
         for j, a in enumerate(arrs):
             out[j, :a.shape[0], :a.shape[1]] = a
-        batch[field] = torch.from_numpy(out).to(device)
+        batch[field] = host(out)
     batch['metadata'] = [i['metadata'] for i in instances]
     return batch
+
+
+def to_device(host_batch, device='cpu'):
+    """The host batch of `collate_host` on `device`, pixels through ToTensor + Normalize (one HIP kernel on the GPU):
+    the kwargs of Model.forward (transformer_faces_objects.py:67-76)."""
+    nb = torch.device(device).type == 'cuda'
+    batch = {}
+    for k, v in host_batch.items():
+        if k == 'image_u8':
+            batch['image'] = normalize_images(v.to(device, non_blocking=nb) if nb else v.numpy(), device)
+        elif isinstance(v, dict):
+            batch[k] = {kk: vv.to(device, non_blocking=nb) for kk, vv in v.items()}
+        elif torch.is_tensor(v):
+            batch[k] = v.to(device, non_blocking=nb)
+        else:
+            batch[k] = v
+    return batch
+
+
+def collate(instances, device='cpu', padding_value=1):
+    """list of reader instances -> the kwargs of Model.forward (transformer_faces_objects.py:67-76)."""
+    return to_device(collate_host(instances, padding_value), device)
 
 
 @DataIterator.register('bucket')

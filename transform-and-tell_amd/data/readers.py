@@ -107,8 +107,8 @@ class NYTimesFacesNERMatchedReader(DatasetReader):
         n = self.index_name
 
         def field(ids, copy):
-            ids = [int(i) for i in ids]
-            return {n: ids, n + '_copy_masks': [int(c) for c in copy] if copy is not None else [0] * len(ids)}
+            ids = np.asarray(ids).tolist()
+            return {n: ids, n + '_copy_masks': np.asarray(copy).tolist() if copy is not None else [0] * len(ids)}
         faces = np.asarray(face_embeds, dtype=np.float32)
         inst = {'context': field(context_ids, context_copy), 'caption': field(caption_ids, caption_copy),
                 'image': np.asarray(image, dtype=np.uint8),
