@@ -159,7 +159,7 @@ def test_shards_reader_and_batch_contract(tmp_path):
         assert row[n - 1] == 2 and (row[n:] == 1).all()
     assert (batch['caption']['roberta_copy_masks'][cap == 1] == -1).all()
     assert batch['image'].shape == (5, 3, 224, 224) and batch['image'].dtype == torch.float32
-    want = (torch.from_numpy(inst[0]['image']).permute(2, 0, 1).float() / 255 -
+    want = (torch.from_numpy(np.array(inst[0]['image'])).permute(2, 0, 1).float() / 255 -
             torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)) / torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
     torch.testing.assert_close(batch['image'][0], want)
     fe, oe = batch['face_embeds'], batch['obj_embeds']
