@@ -427,7 +427,7 @@ def loader_bench(args, dev, n_batches=12, warm=4, variable=False):
             q.put(None)
         th = threading.Thread(target=produce, daemon=True)
         th.start()
-        host_ms, n_done, t_start = [], 0, None
+        host_ms, issue_ms, n_done, t_start = [], [], 0, None
         marks = []                                     # (steps done, wall clock) at every epoch end (variable leg)
 
         def fetch():
@@ -445,7 +445,9 @@ def loader_bench(args, dev, n_batches=12, warm=4, variable=False):
                 group = fetch()
                 nxt = to_device(group, dev) if group is not None else None
                 host_ms.append(1e3 * (time.perf_counter() - h0))
+                h1 = time.perf_counter()
                 trainer.train_one_batch(cur, next_batch=nxt)
+                issue_ms.append(1e3 * (time.perf_counter() - h1))
                 n_done += 1
                 if n_done == warm:
                     torch.cuda.synchronize()
@@ -466,6 +468,7 @@ def loader_bench(args, dev, n_batches=12, warm=4, variable=False):
                 timed, elapsed = n2 - n1, t2 - t1
         return {**extra, 'value': round(B * timed / elapsed, 2), 'unit': 'samples/s', 'ms_per_step': round(1e3 * elapsed / timed, 3),
                 'batches': timed, 'host_ms_per_batch_on_the_training_thread': round(host[len(host) // 2], 2),
+                'step_issue_ms': round(sorted(issue_ms[-timed:])[timed // 2], 2),
                 'shard_mbytes': round(shard_mb, 1), 'shard_write_s': round(write_s, 1),
                 'pipeline': 'npz shards on tmpfs -> nytimes_faces_ner_matched reader -> collate_host into pinned tensors '
                             '(background thread, one batch ahead) -> async H2D + tell_image_normalize -> '
