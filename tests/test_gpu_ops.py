@@ -132,7 +132,7 @@ def test_gemm_nt(dtype, M, N, K):
 @pytest.mark.parametrize('M,N,K', [(4096, 4096, 64), (4096, 4096, 128), (4096, 4096, 192), (8192, 2048, 320),
                                    (2048, 8192, 1024)])
 def test_gemm_pingpong_kernel(M, N, K):
-    """gemm_nt_pp_kernel (whole rounds of full 256x256 bf16 tiles): K-tile counts 1, 2, 3, 5, 16 walk the prologue /
+    """gemm_nt_pp2_kernel / gemm_nt_pp_kernel (whole rounds of full 256x256 bf16 tiles; the resident form is the default): K-tile counts 1, 2, 3, 5, 16 walk the prologue /
     steady state / tail of the counted-vmcnt pipeline; every epilogue form; repeated launches must be bit-identical
     (a staging race shows up as run-to-run differences long before it shows up as a tolerance failure)."""
     from tell_amd import ops
@@ -164,8 +164,23 @@ def test_gemm_pingpong_kernel(M, N, K):
     def plan(x, y, o):
         return hip.query('tell_gemm_nt_plan', x, x.stride(0), y, y.stride(0), o, o.stride(0), x.shape[0], y.shape[0],
                          x.shape[1], hip.BF16, hip.BF16, None, 0, 0, None, 1.0, 0, None)
-    assert plan(ad, bd, out) == 'gemm_nt_pp_kernel<bf16,256,256>'
+    assert plan(ad, bd, out) in ('gemm_nt_pp2_kernel<bf16,256,256>', 'gemm_nt_pp_kernel<bf16,256,256>')   # TELL_GEMM_PP2=0 selects the latter
     assert plan(ad[:M - 8], bd, out_small).startswith('gemm_nt_glds_kernel<bf16,')
+
+
+@pytest.mark.parametrize('env', [{'TELL_GEMM_PP2': '0'}, {'TELL_GEMM_PP2': '1'}, {'TELL_GEMM_DUO': '2'},
+                                 {'TELL_GEMM_DUO': '2', 'TELL_DUO_REG': '1'}], ids=['pp', 'pp2-multi-round', 'duo', 'duo-reg'])
+def test_gemm_kernel_variants_behind_switches(env):
+    """The GEMM kernels that are not the default choice (one-workgroup-per-tile ping-pong, the 256x128 two-per-CU forms)
+    stay correct: the switches are read once per process, so each runs tools/probes/gemm_variant_check.py in its own."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'probes', 'gemm_variant_check.py')], env=e,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'ALL OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    want = 'gemm_nt_duo_kernel' if 'TELL_GEMM_DUO' in env else ('gemm_nt_pp_kernel' if env['TELL_GEMM_PP2'] == '0' else 'gemm_nt_pp2_kernel')
+    assert want in r.stdout, r.stdout[-2000:]
 
 
 @pytest.mark.parametrize('dtype', DTYPES)

@@ -24,39 +24,7 @@
 #include <alloca.h>
 #include <stdio.h>
 
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // 16-byte staging chunk (native vector: stays in VGPRs)
-
-struct GemmArgs {
-  const void* A; const void* B; void* C;
-  const float* bias;      // fp32, length N (mode 1) or M (mode 2)
-  const void* aux;        // act 3: relu-mask source, act 4: residual added before the relu (same layout/dtype as C)
-  const int* m_dev;       // optional device-side effective M (rows >= *m_dev are skipped)
-  long lda, ldb, ldc;
-  int M, N, K;
-  int bias_mode;          // 0 none, 1 per column n, 2 per row m
-  int act;                // 0 none, 1 relu, 2 gelu(erf), 3 multiply by (aux > 0), 4 relu(result + aux) (residual block)
-  int accumulate;         // C = C + result  (beta = 1)
-  float alpha;            // result = act((acc + bias) * alpha)
-  float* asum;            // K-major A only: asum[m] += asum_scale * sum_k A[k][m]  (bias gradient of a wgrad GEMM)
-  float asum_scale;
-  unsigned long long* ts; // measurement aid: ts[0] = min over workgroups of the wall clock at entry, ts[1] = max at exit
-  int atomic_out;         // fp32 output shared by several workgroups (split K): accumulate with hardware float atomics
-  int* queue;             // persistent ping-pong kernel: the launch's tile counter (zero between launches), or NULL
-  // implicit convolution (direct-to-LDS kernel): A is not a matrix but the NHWC activation [B,H,W,Cin]; row m is output
-  // pixel (b, oh, ow), K = KH*KW*Cin in (kh, kw, c) order - each 64-wide K tile lies inside one tap (Cin % 64 == 0), and
-  // every lane's DMA source is the shifted input pixel (a 128-byte zero page for the padding ring): no im2col matrix
-  const void* conv_zero;  // != NULL selects the mode
-  int conv_H, conv_W, conv_OH, conv_OW, conv_KW, conv_stride, conv_pad, conv_cshift;   // Cin = 64 << conv_cshift
-  float* stat_mean;       // bf16 NT kernels: per (m-tile, column) mean / M2 of the STORED (bf16-rounded) outputs over
-  float* stat_m2;         //   the tile's valid rows, [tiles_m][N] each - the first stage of train-mode BatchNorm
-};
-
-// In-kernel execution span (bench.py roofline for launches replayed from hipGraphs, where neither HIP events nor an
-// external profiler can bracket a kernel): the first workgroup to arrive stores the device wall clock into ts[0], every
-// workgroup folds its exit time into ts[1] (max) - the interval rocprofv3 reports as the kernel's duration.
-// tell_gemm_ts_next arms it for the next tell_gemm_nt launch only.
-__device__ __forceinline__ void gemm_ts_enter(const GemmArgs& p);
-__device__ __forceinline__ void gemm_ts_exit(const GemmArgs& p);
+#include "gemm_common.h"
 
 template <typename T> struct Mma;
 template <> struct Mma<uint16_t> {
@@ -106,84 +74,6 @@ __device__ __forceinline__ void static_for(F&& f) {
 // bf16 conversion a packed v_cvt_pk_bf16_f32.  The activation is a template parameter (one block-uniform
 // switch per tile instead of branches per element).
 
-// exact-erf GELU without exp: Abramowitz-Stegun 7.1.28,  erfc(x) = 1 / (1 + a1 x + ... + a6 x^6)^16  for x >= 0
-// (|error| <= 3e-7), and  gelu(v) = v Phi(v) = max(v, 0) - |v| erfc(|v| / sqrt 2) / 2.  One v_rcp_f32 and fourteen
-// multiply-adds per element (the compiler packs pairs into v_pk_fma_f32 / v_pk_mul_f32) instead of rcp + exp + two
-// more multiplies for the 7.1.26 form: the epilogue of the fc1 GEMM is pure VALU work with nothing to overlap it
-// (one workgroup per CU), so every instruction there is wall time.  A large argument overflows the power to +inf and
-// v_rcp_f32 returns 0, which is the right limit.
-typedef __attribute__((ext_vector_type(2))) float f32x2e_t;
-__device__ __forceinline__ f32x2e_t gelu_erf2(f32x2e_t v) {          // two elements per instruction (packed fp32 VALU)
-  const f32x2e_t av = {fabsf(v[0]), fabsf(v[1])};
-  const f32x2e_t x = av * 0.70710678118654752f;
-  f32x2e_t q = x * 0.0000430638f + 0.0002765672f;
-  q = q * x + 0.0001520143f;
-  q = q * x + 0.0092705272f;
-  q = q * x + 0.0422820123f;
-  q = q * x + 0.0705230784f;
-  q = q * x + 1.f;
-  q *= q; q *= q; q *= q; q *= q;                                   // ^16
-  const f32x2e_t erfc_x = {__builtin_amdgcn_rcpf(q[0]), __builtin_amdgcn_rcpf(q[1])};
-  const f32x2e_t relu = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
-  return (av * -0.5f) * erfc_x + relu;
-}
-template <int ACT> __device__ __forceinline__ float epi_act(float v) {
-  if constexpr (ACT == 1) return fmaxf(v, 0.f);
-  else if constexpr (ACT == 2) { const f32x2e_t r = gelu_erf2(f32x2e_t{v, v}); return r[0]; }
-  else return v;
-}
-// four consecutive outputs at once (what every epilogue holds per register quad)
-template <int ACT> __device__ __forceinline__ void epi_act4(__attribute__((ext_vector_type(4))) float& v) {
-  if constexpr (ACT == 2) {
-    const f32x2e_t lo = gelu_erf2(f32x2e_t{v[0], v[1]}), hi = gelu_erf2(f32x2e_t{v[2], v[3]});
-    v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
-  } else {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = epi_act<ACT>(v[e]);
-  }
-}
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2e_t;
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {      // v_cvt_pk_bf16_f32 (RNE)
-  f32x2e_t f = {lo, hi};
-  bf16x2e_t h = __builtin_convertvector(f, bf16x2e_t);
-  return *reinterpret_cast<unsigned*>(&h);
-}
-template <typename OutT> struct Vec4;
-template <> struct Vec4<float> {
-  __device__ static __forceinline__ f32x4_t ld(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
-  __device__ static __forceinline__ void st(float* p, f32x4_t v) { *reinterpret_cast<f32x4_t*>(p) = v; }
-};
-template <> struct Vec4<uint16_t> {
-  __device__ static __forceinline__ f32x4_t ld(const uint16_t* p) {
-    const u32x2 w = *reinterpret_cast<const u32x2*>(p);
-    f32x4_t v = {__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u),
-                 __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)};
-    return v;
-  }
-  __device__ static __forceinline__ void st(uint16_t* p, f32x4_t v) {
-    u32x2 w = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
-    *reinterpret_cast<u32x2*>(p) = w;
-  }
-};
-
-// ts[0] = entry time of the launch's first workgroup, ts[1] = latest exit, ts[2] = arrivals so far.  The workgroup
-// whose arrival ticket is a multiple of the grid size opens a new launch (stores its entry time, clears the exit word):
-// no reset launch in front of every sampled GEMM (22 five-microsecond launches per step on the critical stream before).
-__device__ __forceinline__ void gemm_ts_enter(const GemmArgs& p) {
-  if (p.ts && threadIdx.x == 0) {
-    const unsigned long long now = wall_clock64();
-    const unsigned long long n = atomicAdd(p.ts + 2, 1ull);
-    if (n % gridDim.x == 0) { p.ts[1] = 0ull; p.ts[0] = now; }
-  }
-}
-__device__ __forceinline__ void gemm_ts_exit(const GemmArgs& p) {
-  if (p.ts && threadIdx.x == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's stores have left
-    atomicMax(p.ts + 1, (unsigned long long)wall_clock64());
-  }
-}
 
 template <typename OutT, int MI, int NI, int ACT>
 __device__ __forceinline__ void gemm_epilogue_act(f32x16 (&acc)[MI][NI], const GemmArgs& p, int mw, int nw, int lane,
@@ -202,11 +92,52 @@ __device__ __forceinline__ void gemm_epilogue_act(f32x16 (&acc)[MI][NI], const G
 #pragma unroll
       for (int e = 0; e < 4; ++e) bn[j][g][e] = (p.bias_mode == 1 && n + e < N) ? p.bias[n + e] : 0.f;
     }
+  // Everything an output row needs from memory - its bias, the previous contents of C (accumulate), the mask / residual
+  // pieces (act 3 / 4) - is fetched as ONE batch per 32-row block before any of it is used.  Fetched inside the column
+  // loop (under the block-uniform accumulate test) every 4-column group waited for its own round trip: 8-16 dependent
+  // HBM / L2 latencies per row block, which for the 16-K-step weight-gradient and residual-accumulating input-gradient
+  // GEMMs of the decoder was longer than their main loop.
+  float bmr[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = mw + i * 32 + (lane & 31);
+    bmr[i] = (p.bias_mode == 2 && m < M) ? p.bias[m] : 0.f;
+  }
+  bool rmw = p.accumulate != 0;
+  if constexpr (std::is_same<OutT, float>::value) rmw = rmw && !p.atomic_out;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int m = mw + i * 32 + (lane & 31);
     if (m >= M) continue;
-    const float bm = p.bias_mode == 2 ? p.bias[m] : 0.f;
+    const float bm = bmr[i];
+    f32x4_t prev[NI][4], ax[NI][4];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        prev[j][g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        ax[j][g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+    if (vec_ok && rmw) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = nw + j * 32 + 8 * g + 4 * (lane >> 5);
+          if (n + 3 < N) prev[j][g] = Vec4<OutT>::ld(C + (long)m * p.ldc + n);
+        }
+    }
+    if constexpr (ACT == 3 || ACT == 4) {
+      if (vec_ok) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int n = nw + j * 32 + 8 * g + 4 * (lane >> 5);
+            if (n + 3 < N) ax[j][g] = Vec4<OutT>::ld(aux + (long)m * p.ldc + n);
+          }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
@@ -220,14 +151,12 @@ __device__ __forceinline__ void gemm_epilogue_act(f32x16 (&acc)[MI][NI], const G
         OutT* dst = C + (long)m * p.ldc + n;
         if (vec_ok && n + 3 < N) {
           if constexpr (ACT == 3) {
-            const f32x4_t mk = Vec4<OutT>::ld(aux + (long)m * p.ldc + n);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+            for (int e = 0; e < 4; ++e) v[e] = ax[j][g][e] > 0.f ? v[e] : 0.f;
           }
           if constexpr (ACT == 4) {
-            const f32x4_t rs = Vec4<OutT>::ld(aux + (long)m * p.ldc + n);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + rs[e], 0.f);
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + ax[j][g][e], 0.f);
           }
           if constexpr (std::is_same<OutT, float>::value) {
             if (p.atomic_out) {                                     // block-uniform
@@ -236,7 +165,7 @@ __device__ __forceinline__ void gemm_epilogue_act(f32x16 (&acc)[MI][NI], const G
               continue;
             }
           }
-          if (p.accumulate) v += Vec4<OutT>::ld(dst);
+          if (p.accumulate) v += prev[j][g];
           Vec4<OutT>::st(dst, v);
         } else {
 #pragma unroll
@@ -277,20 +206,39 @@ __device__ __forceinline__ void glds_store_tile_act(f32x16 (&acc)[MI][NI], const
                                                     int wn, int lane, int tid, uint16_t* cs) {
   constexpr bool SWZ = CS == BN;
   constexpr int CPRW = BN / 8;                                     // 16-byte chunks per tile row
+  // Bias pieces of this lane's column quads / rows: ONE batch of loads in front of the block loops.  Loaded where they
+  // are used, under the block-uniform mode test, every (i, j, g) block waited for its own round trip (s_waitcnt vmcnt(0)
+  // x MI*NI*4 in the ISA: 32 dependent L2 round trips in the epilogue of a 128x64 wave tile).
+  f32x4_t b4[NI][4];
+  float bmr[MI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b4[j][g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < MI; ++i) bmr[i] = 0.f;
+  if (p.bias_mode == 1) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        b4[j][g] = *reinterpret_cast<const f32x4_t*>(p.bias + n0 + (LAY ? j * (BN / 2) + wn * 32 : wn * WN + j * 32) + 8 * g + 4 * (lane >> 5));
+  } else if (p.bias_mode == 2) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+      bmr[i] = p.bias[m0 + (LAY ? (i >> 1) * (BM / 2) + wm * 64 + (i & 1) * 32 + (lane & 31) : wm * WM + i * 32 + (lane & 31))];
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int row = LAY ? (i >> 1) * (BM / 2) + wm * 64 + (i & 1) * 32 + (lane & 31) : wm * WM + i * 32 + (lane & 31);
-    const float bm = p.bias_mode == 2 ? p.bias[m0 + row] : 0.f;
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int col = (LAY ? j * (BN / 2) + wn * 32 : wn * WN + j * 32) + 8 * g + 4 * (lane >> 5);
-        f32x4_t b4 = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias_mode == 1) b4 = *reinterpret_cast<const f32x4_t*>(p.bias + n0 + col);
         f32x4_t v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][4 * g + e] + b4[e] + bm) * p.alpha;
+        for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][4 * g + e] + b4[j][g][e] + bmr[i]) * p.alpha;
         epi_act4<(ACT == 4 || ACT == 3) ? 0 : ACT>(v);
         int ch = col >> 3;
         if constexpr (SWZ) ch ^= row & (CPRW - 1) & 15;
@@ -347,20 +295,35 @@ __device__ __forceinline__ void glds_store_tile_f32_act(f32x16 (&acc)[MI][NI], c
                                                         int wn, int lane, int tid, float* cs) {
   constexpr int CPRW = BN / 4;                                     // 16-byte chunks per tile row
   static_assert((CPRW & (CPRW - 1)) == 0, "power-of-two chunks per row");
+  f32x4_t b4[NI][4];                                               // one batch of bias loads (see the bf16 form above)
+  float bmr[MI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b4[j][g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < MI; ++i) bmr[i] = 0.f;
+  if (p.bias_mode == 1) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        b4[j][g] = *reinterpret_cast<const f32x4_t*>(p.bias + n0 + wn * WN + j * 32 + 8 * g + 4 * (lane >> 5));
+  } else if (p.bias_mode == 2) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) bmr[i] = p.bias[m0 + wm * WM + i * 32 + (lane & 31)];
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int row = wm * WM + i * 32 + (lane & 31);
-    const float bm = p.bias_mode == 2 ? p.bias[m0 + row] : 0.f;
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int col = wn * WN + j * 32 + 8 * g + 4 * (lane >> 5);
-        f32x4_t b4 = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias_mode == 1) b4 = *reinterpret_cast<const f32x4_t*>(p.bias + n0 + col);
         f32x4_t v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][4 * g + e] + b4[e] + bm) * p.alpha;
+        for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][4 * g + e] + b4[j][g][e] + bmr[i]) * p.alpha;
         epi_act4<ACT>(v);
         const int ch = (col >> 2) ^ (row & (CPRW - 1));
         *reinterpret_cast<f32x4_t*>(cs + row * BN + ch * 4) = v;
@@ -1552,6 +1515,17 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
                           (a.bias_mode != 1 || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
         // ping-pong 256x256: whole rounds of full tiles (fc1 of RoBERTa: 878 vs 838 TFLOP/s, 4096^3: 1171 vs 1022,
         // 8192^3: 1333 vs 1164); partial rounds lose to the smaller tiles below.  TELL_GEMM_TILE=8 forces it.
+        // 256x128 tiles, two co-resident workgroups per CU (gemm_duo.hip): prologue and epilogue of one under the main loop
+        // of the other - the K <= 2048 shapes, where those are 40 % of a 256x256 tile's life.  TELL_GEMM_DUO=0 / 2: never / always.
+        static const int duo_env = getenv("TELL_GEMM_DUO") ? atoi(getenv("TELL_GEMM_DUO")) : 0;
+        const bool duo_ok = a.M % 256 == 0 && a.N % 128 == 0 && a.K % 32 == 0 && a.K >= 64 && !a.accumulate && a.act != 3 && a.act != 4 &&
+                            !a.m_dev && !a.stat_mean && !a.conv_zero && (a.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0 &&
+                            (a.bias_mode != 1 || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) && (a.lda & 7) == 0 && (a.ldb & 7) == 0 &&
+                            (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0;
+        if (duo_ok && force == 0 && (duo_env == 2 || (duo_env == 1 && a.K <= 2048)) && tiles(256, 128) >= 2 * n_cu) {
+          if (g_gemm_plan) { (void)gemm_label("gemm_nt_duo_kernel", -1, 1, 256, 128); return TELL_OK; }
+          return launch_gemm_duo(a, stream);
+        }
         static const bool use_w4 = getenv("TELL_GEMM_W4") && atoi(getenv("TELL_GEMM_W4")) == 1;
         if (use_w4 && full && !no_pp && ((force == 0 && tiles(256, 256) % n_cu == 0) || (force == 8 && tiles(256, 256) >= n_cu))) {
           TELL_GEMM_LAUNCH(gemm_label("gemm_nt_w4_kernel", -1, sizeof(OutT) == 2, 256, 256), (gemm_nt_w4_kernel<OutT>), dim3((unsigned)tiles(256, 256)), dim3(256));
@@ -1562,6 +1536,15 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
           // MEASURED (MI355X, same box A/B, configs[2]): 1406 / 1420 samples/s without, 1415 / 1404 with; alone qkv 130.2 ->
           // 125.6 us, the other shapes unchanged.  Holding the CU does not buy back the in-step slowdown - the other
           // streams' kernels are work that has to run somewhere - so the form stays opt-in (TELL_GEMM_PERSIST=1).
+          // resident form with next-tile prefetch under the epilogue (gemm_pp2.hip) - the default.  MEASURED (MI355X, same
+          // box A/B): RoBERTa layer GEMMs alone 442-444 -> 436 us; configs[2] 1500 / 1506 samples/s without, 1524 / 1526 with
+          // (in-step launch 148-157 -> 122-139 us).  TELL_GEMM_PP2=0: one workgroup per tile (gemm_nt_pp_kernel), 1: only
+          // launches of two rounds or more.
+          static const int pp2_env = getenv("TELL_GEMM_PP2") ? atoi(getenv("TELL_GEMM_PP2")) : 2;
+          if (pp2_env && force == 0 && tiles(256, 256) >= (pp2_env == 2 ? 1 : 2) * (long)n_cu && a.lda % 8 == 0 && a.ldb % 8 == 0 && !a.conv_zero) {
+            if (g_gemm_plan) { (void)gemm_label("gemm_nt_pp2_kernel", -1, 1, 256, 256); return TELL_OK; }
+            return launch_gemm_pp2(a, stream, n_cu);
+          }
           static const bool persist_env = getenv("TELL_GEMM_PERSIST") && atoi(getenv("TELL_GEMM_PERSIST")) == 1;
           if (persist_env && g_tile_queue && !g_gemm_plan && tiles(256, 256) > n_cu) {
             GemmArgs ap = a;
