@@ -384,3 +384,34 @@ def test_roberta_graph_replay_dropout_step_counter():
     for o in outs:
         assert torch.isfinite(o).all()
         assert abs(float(o[-1].std()) - float(eager[-1].std())) < 0.1 * float(eager[-1].std())
+
+
+@pytest.mark.parametrize('shape', [(3, 37, 41, 3, 7, 2, 3, 192), (2, 19, 23, 3, 7, 2, 3, 152), (2, 12, 9, 5, 3, 1, 1, 48),
+                                   (32, 224, 224, 3, 7, 2, 3, 192)])
+def test_stem_im2col_chunked_and_vector_maxpool_bit_exact(shape):
+    """tell_im2col for channel counts below one 16-byte chunk (the 7x7 / 3-channel stem: im2col_chunk_kernel, LDS offset
+    table, 16-byte output pieces, zero K padding and zero padding ring) against torch's unfold, and the 16-byte max-pool
+    against F.max_pool2d - both are pure data movement / selection on bf16 values, so the comparison is exact
+    (resnet.py:94-98 of the reference: conv1 -> bn1 -> relu -> maxpool)."""
+    from tell_amd import hip
+    B, H, W, C, k, s, p, Kp = shape
+    g = torch.Generator().manual_seed(B * H + W)
+    x = torch.randn(B, H, W, C, generator=g).bfloat16()
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    xd = x.to(DEV).view(B * H * W, C)
+    col = torch.full((B * OH * OW, Kp), 7.0, dtype=torch.bfloat16, device=DEV)
+    hip.call('tell_im2col', xd, col, B, H, W, C, k, k, s, p, OH, OW, Kp, hip.BF16)
+    # unfold gives [B, C*k*k, L] in (c, kh, kw) order; the matrix is (kh, kw, c)
+    u = torch.nn.functional.unfold(x.float().permute(0, 3, 1, 2), k, padding=p, stride=s)
+    u = u.view(B, C, k, k, OH * OW).permute(0, 4, 2, 3, 1).reshape(B * OH * OW, k * k * C)
+    got = col.float().cpu()
+    assert torch.equal(got[:, :k * k * C], u)
+    assert (got[:, k * k * C:] == 0).all()
+    if B * H * W <= 4096:
+        C2 = 24
+        y = torch.randn(B, H, W, C2, generator=g).bfloat16()
+        PH, PW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        out = torch.empty(B * PH * PW, C2, dtype=torch.bfloat16, device=DEV)
+        hip.call('tell_maxpool3x3s2', y.to(DEV).view(B * H * W, C2), out, B, H, W, C2, PH, PW, hip.BF16)
+        ref = torch.nn.functional.max_pool2d(y.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).reshape(B * PH * PW, C2)
+        assert torch.equal(out.float().cpu(), ref)

@@ -5,6 +5,7 @@
 // weights stored [Cout, KH, KW, Cin].  BatchNorm runs with BATCH statistics in
 // training (callback_apex_trainer.py:259 puts the frozen trunk in train mode).
 #include "common.h"
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;   // native 16-byte vector (stays in VGPRs)
 
 template <typename S, typename D>
 __global__ void nchw_to_nhwc_kernel(const S* __restrict__ x, D* __restrict__ y, int B, int C, int H, int W) {
@@ -49,6 +50,48 @@ __global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ x, T*
       if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = x[(((long)b * H + ih) * W + iw) * Cin + c];
     }
     col[i] = v;
+  }
+}
+// The 3-channel 7x7 stem (bf16, Kp % 8 == 0): one thread per 16-byte OUTPUT chunk (8 consecutive k of one row).  The
+// element-per-thread kernel above spends its time in five integer divisions per 2-byte store (195 us for the 154 MB
+// matrix of a 32-image batch: 0.8 TB/s); here the k -> (kh, kw, c) decomposition is a table in LDS built once per
+// workgroup (input offset and tap coordinates per k), the row decomposition is done once per chunk, and the matrix
+// leaves as whole 16-byte pieces.  The gathers are 2-byte loads from a 9.6 MB input that lives in L2.
+__global__ __launch_bounds__(256) void im2col_chunk_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ col,
+                                                           int B, int H, int W, int Cin, int KH, int KW, int stride,
+                                                           int pad, int OH, int OW, int Kp) {
+  extern __shared__ int tab[];                     // [Kp]: (offset << 8) | (kh << 4) | kw ; -1 for the K padding
+  const int Kreal = KH * KW * Cin;
+  for (int k = threadIdx.x; k < Kp; k += blockDim.x) {
+    int v = -1;
+    if (k < Kreal) {
+      const int c = k % Cin, kk = k / Cin, kw = kk % KW, kh = kk / KW;
+      v = (((kh * W + kw) * Cin + c) << 8) | (kh << 4) | kw;
+    }
+    tab[k] = v;
+  }
+  __syncthreads();
+  const int cpr = Kp >> 3;                         // chunks per row
+  const long n = (long)B * OH * OW * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cpr);
+    const long m = i / cpr;
+    const int ow = (int)(m % OW);
+    const long r = m / OW;
+    const int oh = (int)(r % OH), b = (int)(r / OH);
+    const int ih0 = oh * stride - pad, iw0 = ow * stride - pad;
+    const uint16_t* base = x + (((long)b * H + ih0) * W + iw0) * Cin;
+    uint16_t e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int t = tab[ch * 8 + j];
+      const int kh = (t >> 4) & 15, kw = t & 15;
+      const bool in = t >= 0 && (unsigned)(ih0 + kh) < (unsigned)H && (unsigned)(iw0 + kw) < (unsigned)W;
+      e[j] = in ? base[t >> 8] : (uint16_t)0;
+    }
+    u32x4_t o = {(uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
+                 (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16)};
+    *reinterpret_cast<u32x4_t*>(col + m * Kp + ch * 8) = o;
   }
 }
 // 16-byte-chunk variant for Cin % VEC == 0 (every conv except the 3-channel stem)
@@ -144,6 +187,14 @@ extern "C" int tell_im2col(const void* x, void* col, int B, int H, int W, int Ci
     if (dtype == TELL_BF16) hipLaunchKernelGGL((im2col_vec_kernel<uint16_t>), dim3(gv), dim3(256), 0, stream, (const uint16_t*)x, (uint16_t*)col, B, H, W, Cin, KH, KW, stride, pad, OH, OW);
     else hipLaunchKernelGGL((im2col_vec_kernel<float>), dim3(gv), dim3(256), 0, stream, (const float*)x, (float*)col, B, H, W, Cin, KH, KW, stride, pad, OH, OW);
     return tell_check_launch("im2col_vec");
+  }
+  if (dtype == TELL_BF16 && Kp % 8 == 0 && KH < 16 && KW < 16 && Kp <= 4096 && (long)KH * W * Cin < (1 << 22) &&
+      ((uintptr_t)col & 15) == 0) {
+    const long nc = n / 8;
+    const int gc = (int)((nc + 255) / 256 > 16384 ? 16384 : (nc + 255) / 256);
+    hipLaunchKernelGGL(im2col_chunk_kernel, dim3(gc), dim3(256), Kp * sizeof(int), stream, (const uint16_t*)x, (uint16_t*)col,
+                       B, H, W, Cin, KH, KW, stride, pad, OH, OW, Kp);
+    return tell_check_launch("im2col_chunk");
   }
   int g = (int)((n + 1023) / 1024 > 8192 ? 8192 : (n + 1023) / 1024);
   if (dtype == TELL_BF16) hipLaunchKernelGGL((im2col_kernel<uint16_t>), dim3(g), dim3(256), 0, stream, (const uint16_t*)x, (uint16_t*)col, B, H, W, Cin, KH, KW, stride, pad, OH, OW, Kp);
@@ -539,10 +590,51 @@ __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B
     Elem<T>::st(y + i, m);
   }
 }
+// bf16, C % 8 == 0: one thread per (output pixel, 8-channel chunk) - nine 16-byte loads, one 16-byte store (the scalar
+// kernel above: 62 us for the stem's 51 MB -> 13 MB; this is the ~15 us the traffic costs)
+__global__ __launch_bounds__(256) void maxpool_vec_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int B,
+                                                          int H, int W, int C, int OH, int OW) {
+  const int cpp = C >> 3;
+  const long n = (long)B * OH * OW * cpp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cpp);
+    long r = i / cpp;
+    const int ow = (int)(r % OW); r /= OW;
+    const int oh = (int)(r % OH);
+    const int b = (int)(r / OH);
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+          const u32x4_t v = *reinterpret_cast<const u32x4_t*>(x + (((long)b * H + ih) * W + iw) * C + cc * 8);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            m[2 * q] = fmaxf(m[2 * q], __uint_as_float(v[q] << 16));
+            m[2 * q + 1] = fmaxf(m[2 * q + 1], __uint_as_float(v[q] & 0xffff0000u));
+          }
+        }
+      }
+    u32x4_t o;                                     // maxima of bf16 values are bf16 values: truncation is exact
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = (__float_as_uint(m[2 * q]) >> 16) | (__float_as_uint(m[2 * q + 1]) & 0xffff0000u);
+    *reinterpret_cast<u32x4_t*>(y + i * 8) = o;
+  }
+}
 extern "C" int tell_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int OH, int OW, int dtype,
                                  hipStream_t stream) {
   long n = (long)B * OH * OW * C;
   if (n <= 0) return TELL_OK;
+  if (dtype == TELL_BF16 && C % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0) {
+    const long nc = n / 8;
+    const int gc = (int)((nc + 255) / 256 > 16384 ? 16384 : (nc + 255) / 256);
+    hipLaunchKernelGGL(maxpool_vec_kernel, dim3(gc), dim3(256), 0, stream, (const uint16_t*)x, (uint16_t*)y, B, H, W, C, OH, OW);
+    return tell_check_launch("maxpool_vec");
+  }
   int g = (int)((n + 1023) / 1024 > 8192 ? 8192 : (n + 1023) / 1024);
   if (dtype == TELL_BF16) hipLaunchKernelGGL((maxpool_kernel<uint16_t>), dim3(g), dim3(256), 0, stream, (const uint16_t*)x, (uint16_t*)y, B, H, W, C, OH, OW);
   else hipLaunchKernelGGL((maxpool_kernel<float>), dim3(g), dim3(256), 0, stream, (const float*)x, (float*)y, B, H, W, C, OH, OW);
