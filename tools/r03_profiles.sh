@@ -9,7 +9,7 @@ bash tools/profile_cmd.sh r03_resnet "ResNet-152 alone, B=32, train-mode BatchNo
 bash tools/profile_cmd.sh r03_resnet_eval "ResNet-152 alone, B=32, eval (BatchNorm folded): python tools/resnet_profile.py 32 20 eval" python tools/resnet_profile.py 32 20 eval
 SEQ_ANCHOR=greedy_update bash tools/profile_cmd.sh r03_generate "greedy generation, B=32: python bench.py --generate --beam 1 --steps 1 --warmup 1" python bench.py --generate --beam 1 --steps 1 --warmup 1
 SEQ_ANCHOR=beam_update bash tools/profile_cmd.sh r03_beam "beam-4 generation, B=32: python bench.py --generate --beam 4 --steps 1 --warmup 1" python bench.py --generate --beam 4 --steps 1 --warmup 1
-bash tools/pmc_traffic.sh gemm_nt_pp gpurun_out/r03_pmc_gemm_traffic.json "gemm_nt_pp_kernel<bf16,256,256>" > /dev/null
+bash tools/pmc_traffic.sh gemm_nt_pp2 gpurun_out/r03_pmc_gemm_traffic.json "gemm_nt_pp2_kernel<bf16,256,256>" > /dev/null
 bash tools/pmc_kernel.sh attn_self gpurun_out/r03_pmc_attention.txt SQ_BUSY_CYCLES,SQ_ACTIVE_INST_ANY,SQ_ACTIVE_INST_VALU,SQ_ACTIVE_INST_LDS,SQ_INST_CYCLES_VMEM,SQ_VALU_MFMA_BUSY_CYCLES -- python tools/bench_attention.py > /dev/null
 python tools/bench_attention.py > gpurun_out/r03_attention.txt 2>&1
 python tools/bench_skinny.py 32 > gpurun_out/r03_skinny_bench.txt 2>&1

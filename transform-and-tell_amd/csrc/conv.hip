@@ -5,6 +5,7 @@
 // weights stored [Cout, KH, KW, Cin].  BatchNorm runs with BATCH statistics in
 // training (callback_apex_trainer.py:259 puts the frozen trunk in train mode).
 #include "common.h"
+#include <stdlib.h>
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;   // native 16-byte vector (stays in VGPRs)
 
 template <typename S, typename D>
@@ -535,7 +536,8 @@ int tell_bn_finish_apply_launch(const float* pmean, const float* pm2, long M, in
     pmean = qmean; pm2 = qm2; n_chunks = G; rows_per_chunk *= S;
   }
   // ~512-1024 workgroups, at least 32 rows (one pass) each
-  long per = (M * slabs + 767) / 768;
+  static const long wgs = getenv("TELL_BN_WGS") ? atol(getenv("TELL_BN_WGS")) : 768;   // tuning aid
+  long per = (M * slabs + wgs - 1) / wgs;
   per = (per + 31) / 32 * 32;
   if (per < 32) per = 32;
   const unsigned gy = (unsigned)((M + per - 1) / per);
