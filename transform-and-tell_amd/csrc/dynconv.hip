@@ -148,12 +148,24 @@ __global__ __launch_bounds__(256) void dynconv_fwd_lds_kernel(const T* __restric
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / H, h = blockIdx.x % H, C = H * DC_R;
   dc_stage<T, DC_R>(x, xs, Tn, B, b, C, h, tid);
-  for (int i = tid; i < Tn * K; i += 256) {
-    const int t = i / K, k = i % K;
-    lgs[t * DC_KMAX + k] = Elem<T>::ld(logits + ((long)t * B + b) * (long)H * K + (long)h * K + k);
+  // thread -> (row tid / 32 + 8 u, tap tid % 32): four rows' loads in flight per thread, no divisions (K <= 32)
+  for (int t0 = 0; t0 < Tn; t0 += 32) {
+    float v[4];
+    const int k = tid & 31;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * 8 + (tid >> 5);
+      v[u] = (t < Tn && k < K) ? Elem<T>::ld(logits + ((long)t * B + b) * (long)H * K + (long)h * K + k) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * 8 + (tid >> 5);
+      if (t < Tn && k < K) lgs[t * DC_KMAX + k] = v[u];
+    }
   }
   __syncthreads();
-  for (int t = wave; t < Tn; t += 4) {
+#pragma unroll 4
+  for (int t = wave; t < Tn; t += 4) {      // (unrolled: the shuffle / LDS chains of four rows interleave)
     const long tb = (long)t * B + b, wid = tb * H + h;
     const float lg = lane < K ? lgs[t * DC_KMAX + lane] : -INFINITY;
     const float m = wave_max(lg);
@@ -163,8 +175,12 @@ __global__ __launch_bounds__(256) void dynconv_fwd_lds_kernel(const T* __restric
     float wd = w;
     if (thr && lane < K) wd *= tell_keep(seed, salt, (uint64_t)(wid * K + lane), thr, inv_keep);
     const int k_lo = (K - 1 - t) > 0 ? (K - 1 - t) : 0;       // taps reaching before t = 0 see zeros
+    // (K is a run-time value: without the unroll hint every tap was its own LDS round trip - 60 clk per tap and row with
+    //  two waves per SIMD to hide it; eight taps' reads are now in flight together)
     float acc = 0.f;
-    for (int k = k_lo; k < K; ++k) acc += __shfl(wd, k, 64) * xs[(t - (K - 1) + k) * DC_R + lane];
+#pragma unroll 8
+    for (int k = k_lo; k < K; ++k)                       // (k is wave-uniform: v_readlane, not an LDS permute)
+      acc += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wd), k)) * xs[(t - (K - 1) + k) * DC_R + lane];
     Elem<T>::st(y + tb * C + (long)h * DC_R + lane, acc);
   }
 }
@@ -186,14 +202,27 @@ __global__ __launch_bounds__(256) void dynconv_bwd_lds_kernel(const T* __restric
   const int b = blockIdx.x / H, h = blockIdx.x % H, C = H * DC_R;
   dc_stage<T, XS>(x, xs, Tn, B, b, C, h, tid);
   dc_stage<T, DC_R>(dy, dys, Tn, B, b, C, h, tid);
-  for (int i = tid; i < Tn * K; i += 256) {
-    const int t = i / K, k = i % K;
-    const long wid = ((long)t * B + b) * H + h;
-    tw[i] = taps[wid * K + k];
-    tk[i] = thr ? tell_keep(seed, salt, (uint64_t)(wid * K + k), thr, inv_keep) : 1.f;
+  for (int t0 = 0; t0 < Tn; t0 += 32) {                 // as in the forward kernel: (row, tap) from the thread index
+    float v[4];
+    const int k = tid & 31;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * 8 + (tid >> 5);
+      v[u] = (t < Tn && k < K) ? taps[(((long)t * B + b) * H + h) * K + k] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * 8 + (tid >> 5);
+      if (t < Tn && k < K) {
+        const long wid = ((long)t * B + b) * H + h;
+        tw[t * K + k] = v[u];
+        tk[t * K + k] = thr ? tell_keep(seed, salt, (uint64_t)(wid * K + k), thr, inv_keep) : 1.f;
+      }
+    }
   }
   __syncthreads();
-  for (int t = wave; t < Tn; t += 4) {
+#pragma unroll 4
+  for (int t = wave; t < Tn; t += 4) {      // (unrolled: the shuffle / LDS chains of four rows interleave)
     const long tb = (long)t * B + b;
     // ---- tap-logit gradients of row t: lane k owns dtapd[k] = <dy[t,:], x[t-(K-1)+k,:]> (dy broadcast, x rows on
     //      distinct banks): no cross-lane reduction per tap; then DropConnect and the softmax backward by shuffles
@@ -211,9 +240,10 @@ __global__ __launch_bounds__(256) void dynconv_bwd_lds_kernel(const T* __restric
     if (lane < K) Elem<T>::st(dlogits + tb * (long)H * K + (long)h * K + lane, w * (dw - dot));
     // ---- dx of row t: sum_k tapsd[t+(K-1)-k][k] * dy[t+(K-1)-k][:]   (lane = channel)
     float acc = 0.f;
-    for (int k = K - 1; k >= 0; --k) {
-      const int tt = t + (K - 1) - k;
-      if (tt >= Tn) break;
+    const int n_src = Tn - t < K ? Tn - t : K;            // rows t .. t + n_src - 1 reach row t through tap K - 1 - j
+#pragma unroll 8
+    for (int j = 0; j < n_src; ++j) {
+      const int tt = t + j, k = K - 1 - j;
       acc += tw[tt * K + k] * tk[tt * K + k] * dys[tt * DC_R + lane];
     }
     T* d = dx + tb * C + (long)h * DC_R + lane;
