@@ -110,8 +110,13 @@ class GraphedCall:
     def reset(self):
         self.cache.clear()
 
-    def __call__(self, x, key=()):
-        """x: the single tensor input; key: extra hashable state the kernel sequence depends on."""
+    def __call__(self, x, key=(), slot=None):
+        """x: the single tensor input; key: extra hashable state the kernel sequence depends on.  slot: which of the
+        signature's `buffers` captures to replay (modulo) instead of this signature's own round-robin turn - callers that
+        run several GraphedCalls per step pass ONE shared counter, so the buffer addresses a consumer sees depend on the
+        step parity alone and not on how often each signature has been seen (training/step_graph.py keys its captures on
+        those addresses: with per-signature turns, 3 article lengths x 2 RoBERTa slots x 2 ResNet slots were 12 step
+        graphs, each an eager step and a capture away)."""
         self.last_replayed = False          # True: the result just returned lives in a graph-owned static buffer
         if not ENABLED or not x.is_cuda:
             return self.fn(x)
@@ -125,8 +130,11 @@ class GraphedCall:
             return out                                  # not a later (timed) one
         if e['state'] != 'ready':
             return self.fn(x)
-        s = e['slots'][e['turn']]
-        e['turn'] = (e['turn'] + 1) % len(e['slots'])
+        if slot is None:
+            s = e['slots'][e['turn']]
+            e['turn'] = (e['turn'] + 1) % len(e['slots'])
+        else:
+            s = e['slots'][slot % len(e['slots'])]
         s['generation'] = s.get('generation', 0) + 1       # consumers holding this slot's output can detect reuse
         self.last_slot = s
         s['static_in'].copy_(x)

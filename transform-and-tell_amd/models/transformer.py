@@ -107,7 +107,7 @@ class CaptionModel(Model):
         for k in ('_resnet_graph', '_roberta_graph'):
             self.__dict__.pop(k, None)
 
-    def _run_resnet(self, image):
+    def _run_resnet(self, image, slot=None):
         """The frozen trunk as one hipGraph replay per step (graphs.GraphedCall); eager for the first call."""
         from .resnet import ResNetFeatureExtractor
         if not isinstance(self.resnet, ResNetFeatureExtractor):      # a user-supplied trunk: no assumptions
@@ -120,9 +120,9 @@ class CaptionModel(Model):
         from .resnet import stats_epoch
         # (eval captures bake in weights folded with the running statistics: a train-mode pass in between retires them)
         return g(image, key=(self.resnet.training, ops.rt.compute_dtype(), w._version, w.data_ptr(),
-                             0 if self.resnet.training else stats_epoch()))
+                             0 if self.resnet.training else stats_epoch()), slot=slot)
 
-    def _run_roberta(self, article_ids):
+    def _run_roberta(self, article_ids, slot=None):
         """RoBERTa-large (~170 launches, dropout active in train mode) as one hipGraph replay per step."""
         from .roberta import RobertaEncoder
         if not isinstance(self.roberta, RobertaEncoder):
@@ -133,7 +133,7 @@ class CaptionModel(Model):
                 lambda ids: self.roberta.extract_features(ids, return_all_hiddens=True), 'roberta-large', rng=True,
                 capture_after=self.__dict__.get('_capture_after'))
         w = self.roberta.model.decoder.sentence_encoder.layers[0].fc1.weight
-        return g(article_ids, key=(self.roberta.training, ops.rt.compute_dtype(), w._version, w.data_ptr()))
+        return g(article_ids, key=(self.roberta.training, ops.rt.compute_dtype(), w._version, w.data_ptr()), slot=slot)
 
     # ---- frozen encoders -------------------------------------------------------------
     def encode(self, context, image, ahead=False):
@@ -148,6 +148,9 @@ class CaptionModel(Model):
             main = torch.cuda.current_stream()
             article_ids = context[self.index]
             enc = EncodedBatch()
+            # both encoder graphs replay into the buffer set of this call's parity: consecutive batches never share a
+            # buffer, and the addresses the decoder step graph is keyed on depend on the parity alone (graphs.py)
+            par = self.__dict__['_enc_parity'] = self.__dict__.get('_enc_parity', -1) + 1
             if ahead:
                 rs, is_ = _side_stream(image.device, 'roberta'), _side_stream(image.device, 'resnet')
                 start = torch.cuda.Event()
@@ -156,12 +159,12 @@ class CaptionModel(Model):
                 is_.wait_event(start)
                 with torch.cuda.stream(rs), ops.hip.bound_stream():
                     enc.article_mask = self._pad_mask(article_ids)                      # :347
-                    enc.stack = self._run_roberta(article_ids)
+                    enc.stack = self._run_roberta(article_ids, par)
                     article_ids.record_stream(rs)
                     enc.events.append(torch.cuda.Event())
                     enc.events[-1].record(rs)
                 with torch.cuda.stream(is_), ops.hip.bound_stream():
-                    enc.x_image = self._run_resnet(image)
+                    enc.x_image = self._run_resnet(image, par)
                     image.record_stream(is_)
                     enc.events.append(torch.cuda.Event())
                     enc.events[-1].record(is_)
@@ -175,15 +178,15 @@ class CaptionModel(Model):
                 start.record(main)
             # RoBERTa is issued FIRST: its ~300 launches keep the main stream busy for ~10 ms of GPU time
             # while the host is still issuing ResNet's small launches onto the side stream.
-            enc.stack = self._run_roberta(article_ids)                                        # [L,B,S,E]
+            enc.stack = self._run_roberta(article_ids, par)                                   # [L,B,S,E]
             if side is not None:
                 side.wait_event(start)
                 with torch.cuda.stream(side), ops.hip.bound_stream():
-                    enc.x_image = self._run_resnet(image)                  # [B,49,2048] (NHWC == :335-341)
+                    enc.x_image = self._run_resnet(image, par)             # [B,49,2048] (NHWC == :335-341)
                     enc.events.append(torch.cuda.Event())
                     enc.events[-1].record(side)
             else:
-                enc.x_image = self._run_resnet(image)
+                enc.x_image = self._run_resnet(image, par)
             enc.static = self._encoders_replayed()
             self._note_slots(enc)
             return enc
