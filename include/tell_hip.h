@@ -68,6 +68,17 @@ int tell_gemm_ts_next(void* ts, tell_stream_t stream);
  * wide margin (the host mirror registers 65536). */
 int tell_gemm_set_tile_queue(void* counters, int n, tell_stream_t stream);
 
+/* ---- GEMM with the transformer sub-layer residual in its epilogue -----------
+ * out[M,N] = res[M,N] + dropout_p(A[M,K] . B[N,K]^T + bias[n]), bf16, mask = the one tell_layernorm_fwd draws for
+ * (seed, salt) over an [M,N] input.  Replaces  x = residual + F.dropout(self.out_proj(attn)) / F.dropout(self.fc2(h))
+ * of fairseq's TransformerSentenceEncoderLayer as called by roberta.extract_features
+ * (transformer_faces_objects.py:352-353); the LayerNorm that follows then reads ONE tensor.
+ * Returns 1 (nothing launched) when the shape is not whole rounds of 256x256 tiles: run tell_gemm_nt +
+ * tell_layernorm_fwd(res) instead. */
+int tell_gemm_nt_dropout_residual(const void* A, long lda, const void* B, long ldb, const float* bias, const void* res,
+                                  long ld_res, void* C, long ldc, int M, int N, int K, float p, uint32_t seed,
+                                  uint32_t salt, tell_stream_t stream);
+
 /* ---- GEMM (every nn.Linear / F.linear / 1x1 conv on the path) --------------
  * C[M,N] = act((A[M,K] . B[N,K]^T + bias) * alpha) (+ C if accumulate)
  * Replaces F.linear in tell/modules/linear.py:8-33 (GehringLinear),

@@ -324,6 +324,19 @@ def test_roberta_large_at_bench_size_matches_oracle():
             else:
                 assert errs[l] < 4e-2 and errs4[l] <= 2.5 * yard[l] + 4e-3, (l, errs[l], errs4[l], yard[l])
         assert (out[0].cpu()[~keep] == 0).all()
+        if dtype == torch.bfloat16:
+            # opt-in path: residual (+ dropout, off in eval) inside the out-proj / fc2 GEMM epilogues (csrc/gemm_pp2.hip,
+            # tell_gemm_nt_dropout_residual) - one more bf16 rounding of the pre-norm sum, nothing else
+            os.environ['TELL_GEMM_RESIDUAL'] = '1'
+            try:
+                out2 = hipm.extract_features(ids.to(DEV), return_all_hiddens=True)
+            finally:
+                del os.environ['TELL_GEMM_RESIDUAL']
+            for l in range(L + 1):
+                e2 = rel(out2[l].cpu()[keep], ref[l][keep])
+                assert e2 < 4e-2 and rel(out2[l, :4].cpu()[keep[:4]], ref[l, :4][keep[:4]]) <= 2.5 * yard[l] + 4e-3, (l, e2)
+            assert rel(out2[L].cpu()[keep], out[L].cpu()[keep]) < 8e-3
+            del out2
         del hipm, out
         torch.cuda.empty_cache()
 

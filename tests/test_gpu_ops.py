@@ -168,6 +168,41 @@ def test_gemm_pingpong_kernel(M, N, K):
     assert plan(ad[:M - 8], bd, out_small).startswith('gemm_nt_glds_kernel<bf16,')
 
 
+@pytest.mark.parametrize('p', [0.0, 0.1])
+@pytest.mark.parametrize('M,N,K', [(16384, 1024, 1024), (8192, 2048, 192), (4096, 4096, 64)])
+def test_gemm_dropout_residual_epilogue(M, N, K, p):
+    """tell_gemm_nt_dropout_residual (fairseq's  x = residual + dropout(out_proj(.)) / dropout(fc2(.))  inside the GEMM
+    epilogue, transformer_faces_objects.py:352-353) against the tensor formulation with the mask rebuilt by the RNG
+    restatement - i.e. the mask tell_layernorm_fwd draws for the same (seed, salt) - and the decline code for shapes the
+    resident kernel does not take."""
+    from tell_amd import hip, rng
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).bfloat16()
+    b = torch.randn(N, K, generator=g).bfloat16()
+    res = torch.randn(M, N, generator=g).bfloat16()
+    bias = torch.randn(N, generator=g)
+    ad, bd, rd, biasd = a.to(DEV), b.to(DEV), res.to(DEV), bias.to(DEV)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    rc = hip.call_rc('tell_gemm_nt_dropout_residual', ad, K, bd, K, biasd, rd, N, out, N, M, N, K, p, 17, 23)
+    assert rc == 0
+    lin = (ad.float() @ bd.float().t() + biasd).cpu()
+    keep = torch.from_numpy(rng.keep_mask(17, 23, M * N, p)).view(M, N) / (1 - p) if p > 0 else 1.0
+    ref = res.float() + (lin * keep).bfloat16().float()          # the kernel rounds the dropped-out product, then adds
+    got = out.float().cpu()
+    assert (got - ref).abs().max() <= 2.0 ** -7 * ref.abs().max() and (got - ref).norm() / ref.norm() < 3e-3
+    if p > 0:                                                    # dropped elements are exactly the residual
+        dropped = torch.from_numpy(rng.keep_mask(17, 23, M * N, p)).view(M, N) == 0
+        assert 0.08 < dropped.float().mean() < 0.12
+        assert torch.equal(got[dropped], res.float()[dropped])
+    for _ in range(2):
+        out2 = torch.empty_like(out)
+        assert hip.call_rc('tell_gemm_nt_dropout_residual', ad, K, bd, K, biasd, rd, N, out2, N, M, N, K, p, 17, 23) == 0
+        assert torch.equal(out2, out)
+    # shapes it declines: ragged rows, fewer tiles than CUs
+    assert hip.call_rc('tell_gemm_nt_dropout_residual', ad, K, bd, K, biasd, rd, N, out, N, M - 8, N, K, p, 17, 23) == 1
+    assert hip.call_rc('tell_gemm_nt_dropout_residual', ad, K, bd, K, biasd, rd, N, out, N, 256, N, K, p, 17, 23) == 1
+
+
 @pytest.mark.parametrize('env', [{'TELL_GEMM_PP2': '0'}, {'TELL_GEMM_PP2': '1'}, {'TELL_GEMM_DUO': '2'},
                                  {'TELL_GEMM_DUO': '2', 'TELL_DUO_REG': '1'}], ids=['pp', 'pp2-multi-round', 'duo', 'duo-reg'])
 def test_gemm_kernel_variants_behind_switches(env):

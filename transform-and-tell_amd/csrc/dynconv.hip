@@ -164,8 +164,7 @@ __global__ __launch_bounds__(256) void dynconv_fwd_lds_kernel(const T* __restric
     }
   }
   __syncthreads();
-#pragma unroll 4
-  for (int t = wave; t < Tn; t += 4) {      // (unrolled: the shuffle / LDS chains of four rows interleave)
+  for (int t = wave; t < Tn; t += 4) {
     const long tb = (long)t * B + b, wid = tb * H + h;
     const float lg = lane < K ? lgs[t * DC_KMAX + lane] : -INFINITY;
     const float m = wave_max(lg);
@@ -221,8 +220,7 @@ __global__ __launch_bounds__(256) void dynconv_bwd_lds_kernel(const T* __restric
     }
   }
   __syncthreads();
-#pragma unroll 4
-  for (int t = wave; t < Tn; t += 4) {      // (unrolled: the shuffle / LDS chains of four rows interleave)
+  for (int t = wave; t < Tn; t += 4) {
     const long tb = (long)t * B + b;
     // ---- tap-logit gradients of row t: lane k owns dtapd[k] = <dy[t,:], x[t-(K-1)+k,:]> (dy broadcast, x rows on
     //      distinct banks): no cross-lane reduction per tap; then DropConnect and the softmax backward by shuffles

@@ -22,6 +22,11 @@ struct GemmArgs {
   int atomic_out;         // fp32 output shared by several workgroups (split K): accumulate with hardware float atomics
   int* queue;             // persistent ping-pong kernel: the launch's tile counter (zero between launches), or NULL
   int stagger;            // duo kernel: start delay of the second resident workgroup of a CU (x 8128 clocks)
+  // pp2 kernel, act 5: C = aux2[m,n] + dropout(result): the transformer sub-layer residual (fairseq: x = residual +
+  // dropout(out_proj(.)) / dropout(fc2(.))) in the epilogue - the mask is the one tell_layernorm_fwd would draw for the
+  // same (seed, salt): element index m * N + n, csrc/common.h quad hash
+  const void* res; long ld_res; uint32_t drop_thr; float drop_inv_keep; uint32_t drop_seed, drop_salt;
+  const uint32_t* drop_step;
   // implicit convolution (direct-to-LDS kernel): A is not a matrix but the NHWC activation [B,H,W,Cin]; row m is output
   // pixel (b, oh, ow), K = KH*KW*Cin in (kh, kw, c) order - each 64-wide K tile lies inside one tap (Cin % 64 == 0), and
   // every lane's DMA source is the shifted input pixel (a 128-byte zero page for the padding ring): no im2col matrix

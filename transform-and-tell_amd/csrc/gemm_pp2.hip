@@ -50,9 +50,21 @@ __device__ __forceinline__ void pp2_store(f32x16 (&acc)[4][2], const GemmArgs& p
     for (int i = 0; i < 4; ++i) bm[i] = p.bias[m0 + (i >> 1) * 128 + wr * 64 + (i & 1) * 32 + (lane & 31)];
   }
   uint16_t* C = static_cast<uint16_t*>(p.C);
+  const uint16_t* R = static_cast<const uint16_t*>(p.res);
+  uint32_t dsalt = 0;
+  if constexpr (ACT == 5) dsalt = tell_step_salt(p.drop_salt, p.drop_step);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = wr * 32 + (lane & 31);                 // row inside the pass: 64 rows x 512 bytes
+    u32x4 rres[4];                                         // act 5: this thread's residual pieces of the pass, fetched
+    if constexpr (ACT == 5) {                              // before the arithmetic so they land underneath it
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int c = tid + it * 512, row2 = c >> 5, ch = c & 31;
+        const int grow = m0 + (i >> 1) * 128 + (row2 >> 5) * 64 + (i & 1) * 32 + (row2 & 31);
+        rres[it] = *reinterpret_cast<const u32x4*>(R + (long)grow * p.ld_res + n0 + ch * 8);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -61,7 +73,18 @@ __device__ __forceinline__ void pp2_store(f32x16 (&acc)[4][2], const GemmArgs& p
         f32x4_t v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][4 * g + e] + b4[j][g][e] + bm[i]) * p.alpha;
-        epi_act4<ACT>(v);
+        if constexpr (ACT == 5) {                          // dropout of the aligned quad (m, n .. n + 3)
+          if (p.drop_thr) {
+            const int gm = m0 + (i >> 1) * 128 + wr * 64 + (i & 1) * 32 + (lane & 31);
+            const uint64_t quad = ((uint64_t)gm * (uint64_t)p.N + (uint64_t)(n0 + col)) >> 2;
+            bool k0, k1, k2, k3;
+            tell_keep4_bits(tell_quad_x(p.drop_seed, quad), tell_quad_y(dsalt, quad), p.drop_thr, k0, k1, k2, k3);
+            v[0] = k0 ? v[0] * p.drop_inv_keep : 0.f; v[1] = k1 ? v[1] * p.drop_inv_keep : 0.f;
+            v[2] = k2 ? v[2] * p.drop_inv_keep : 0.f; v[3] = k3 ? v[3] * p.drop_inv_keep : 0.f;
+          }
+        } else {
+          epi_act4<ACT>(v);
+        }
         const int ch = (col >> 3) ^ (row & 15);
         u32x2 w = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
         *reinterpret_cast<u32x2*>(cs + row * BN + ch * 8 + (col & 7)) = w;
@@ -70,15 +93,25 @@ __device__ __forceinline__ void pp2_store(f32x16 (&acc)[4][2], const GemmArgs& p
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int c = tid + it * 512, row2 = c >> 5, ch = c & 31;
-      const u32x4 o = *reinterpret_cast<const u32x4*>(cs + row2 * BN + ((ch ^ (row2 & 15)) << 3));
+      u32x4 o = *reinterpret_cast<const u32x4*>(cs + row2 * BN + ((ch ^ (row2 & 15)) << 3));
       const int grow = m0 + (i >> 1) * 128 + (row2 >> 5) * 64 + (i & 1) * 32 + (row2 & 31);
+      if constexpr (ACT == 5) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = __uint_as_float(o[e] << 16) + __uint_as_float(rres[it][e] << 16);
+          const float hi = __uint_as_float(o[e] & 0xffff0000u) + __uint_as_float(rres[it][e] & 0xffff0000u);
+          o[e] = pack2_bf16(lo, hi);
+        }
+      }
       if (ABL != 2 || o[0] == 0x12345678u) *reinterpret_cast<u32x4*>(C + (long)grow * p.ldc + n0 + ch * 8) = o;
     }
     if (i < 3) __syncthreads();
   }
 }
 
-template <int ABL>
+// RES: the dropout + residual epilogue (act 5) as its own instantiation - compiled into the plain kernel it cost the main
+// loop 14 registers (240 -> 254) and 2-3 % of its speed
+template <int ABL, bool RES>
 __global__ __launch_bounds__(512) void gemm_nt_pp2_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * TILE + SPARE];
   gemm_ts_enter(p);
@@ -259,11 +292,14 @@ __global__ __launch_bounds__(512) void gemm_nt_pp2_kernel(GemmArgs p) {
       prefetch(m1, n1);
     }
     uint16_t* cs = reinterpret_cast<uint16_t*>(smem + 2 * TILE);
-    if (ABL != 1 || acc[0][0][0] == 12345.678f)
-    switch (p.act) {                                       // block-uniform
-      case 1: pp2_store<1, ABL>(acc, p, m0, n0, wr, wc, lane, tid, cs); break;
-      case 2: pp2_store<2, ABL>(acc, p, m0, n0, wr, wc, lane, tid, cs); break;
-      default: pp2_store<0, ABL>(acc, p, m0, n0, wr, wc, lane, tid, cs); break;
+    if constexpr (RES) {
+      pp2_store<5, ABL>(acc, p, m0, n0, wr, wc, lane, tid, cs);
+    } else if (ABL != 1 || acc[0][0][0] == 12345.678f) {
+      switch (p.act) {                                     // block-uniform
+        case 1: pp2_store<1, ABL>(acc, p, m0, n0, wr, wc, lane, tid, cs); break;
+        case 2: pp2_store<2, ABL>(acc, p, m0, n0, wr, wc, lane, tid, cs); break;
+        default: pp2_store<0, ABL>(acc, p, m0, n0, wr, wc, lane, tid, cs); break;
+      }
     }
     if (nvb >= n_tiles) break;
     vb = nvb; m0 = m1; n0 = n1;                            // (the spare area is next written a whole main loop of barriers later)
@@ -274,10 +310,40 @@ __global__ __launch_bounds__(512) void gemm_nt_pp2_kernel(GemmArgs p) {
 
 int launch_gemm_pp2(const GemmArgs& a, hipStream_t stream, int n_cu) {
   const int n_tiles = (a.M / BM) * (a.N / BN);
-  const unsigned grid = (unsigned)(n_tiles < n_cu ? n_tiles : n_cu);
+  // TELL_PP2_GRID: resident workgroups per launch (default: one per CU) - a tuning aid for how many CUs the step's other
+  // two streams are left with while a GEMM runs
+  static const int grid_env = getenv("TELL_PP2_GRID") ? atoi(getenv("TELL_PP2_GRID")) : 0;
+  const int cap = grid_env > 0 && grid_env < n_cu ? grid_env : n_cu;
+  const unsigned grid = (unsigned)(n_tiles < cap ? n_tiles : cap);
   static const int abl = getenv("TELL_PP2_ABL") ? atoi(getenv("TELL_PP2_ABL")) : 0;   // timing probes (wrong results): 1 no epilogue, 2 no global stores
-  if (abl == 1) hipLaunchKernelGGL(gemm_nt_pp2_kernel<1>, dim3(grid), dim3(512), 0, stream, a);
-  else if (abl == 2) hipLaunchKernelGGL(gemm_nt_pp2_kernel<2>, dim3(grid), dim3(512), 0, stream, a);
-  else hipLaunchKernelGGL(gemm_nt_pp2_kernel<0>, dim3(grid), dim3(512), 0, stream, a);
+  if (a.act == 5) hipLaunchKernelGGL((gemm_nt_pp2_kernel<0, true>), dim3(grid), dim3(512), 0, stream, a);
+  else if (abl == 1) hipLaunchKernelGGL((gemm_nt_pp2_kernel<1, false>), dim3(grid), dim3(512), 0, stream, a);
+  else if (abl == 2) hipLaunchKernelGGL((gemm_nt_pp2_kernel<2, false>), dim3(grid), dim3(512), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_nt_pp2_kernel<0, false>), dim3(grid), dim3(512), 0, stream, a);
   return tell_check_launch("gemm_nt_pp2");
+}
+
+// out[M,N] = res[M,N] + dropout_p(A[M,K] . B[N,K]^T + bias[n])   (bf16; the transformer sub-layer residual in the GEMM
+// epilogue).  MEASURED (MI355X, M = 16384): out-proj 38.1 -> 44.3 us and the LayerNorm behind it 22.0 -> 12.6 (reads one
+// tensor), fc2 119.7 -> 121.5 / 16.2 -> 12.6: 3 + 2 us per layer better alone - and 1 % WORSE inside the training step
+// (1420-1425 against 1436 samples/s, same box): the 6 us move from a bandwidth-bound kernel that shares the chip with
+// the other two streams into the epilogue of a kernel that holds every CU exclusively.  The host mirror therefore uses
+// it only on request (TELL_GEMM_RESIDUAL=1).  -> TELL_OK, or 1 when the shape is not one this kernel takes (whole 256x256 tiles, at least one per CU,
+// 16-byte aligned rows): the caller then runs tell_gemm_nt and lets tell_layernorm_fwd add the residual.
+extern "C" int tell_gemm_nt_dropout_residual(const void* A, long lda, const void* B, long ldb, const float* bias,
+                                             const void* res, long ld_res, void* C, long ldc, int M, int N, int K, float p,
+                                             uint32_t seed, uint32_t salt, hipStream_t stream) {
+  TELL_REQUIRE(p >= 0.f && p < 1.f, "gemm_nt_dropout_residual: p must be in [0,1)");
+  static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); (void)hipGetDeviceProperties(&pr, d); return pr.multiProcessorCount; }();
+  const long tiles = (long)(M / BM) * (N / BN);
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (M <= 0 || M % BM || N % BN || K % BK || K < BK || tiles < n_cu || tiles % n_cu || (lda & 7) || (ldb & 7) || (ldc & 7) ||
+      (ld_res & 7) || !al16(A) || !al16(B) || !al16(C) || !al16(res) || (bias && !al16(bias)) || !res)
+    return 1;
+  GemmArgs a{};
+  a.A = A; a.B = B; a.C = C; a.bias = bias; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+  a.bias_mode = bias ? 1 : 0; a.act = 5; a.alpha = 1.f;
+  a.res = res; a.ld_res = ld_res; a.drop_thr = p > 0.f ? tell_drop_threshold(p) : 0u; a.drop_inv_keep = 1.f / (1.f - p);
+  a.drop_seed = seed; a.drop_salt = salt; a.drop_step = g_tell_rng_step;
+  return launch_gemm_pp2(a, stream, n_cu);
 }

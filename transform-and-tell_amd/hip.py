@@ -127,6 +127,19 @@ def query(name, *args):
     return res.decode() if res is not None else ''
 
 
+def call_rc(name, *args):
+    """call() for the entry points that may DECLINE a shape: -> the positive return code (0 = launched, 1 = not a shape
+    this kernel takes, nothing launched); errors still raise."""
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(lib(), name)
+    stream = _bound_stream if _bound_stream is not None else torch.cuda.current_stream().cuda_stream
+    rc = fn(*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args], stream)
+    if rc < 0:
+        raise RuntimeError('%s failed (%d): %s' % (name, rc, lib().tell_last_error().decode()))
+    return rc
+
+
 def call(name, *args):
     """Call a C-ABI entry point; tensors -> device pointers; last arg (stream) added here."""
     fn = _fns.get(name)

@@ -77,6 +77,25 @@ class RobertaEncoder(nn.Module):
             return ops.cast(w, rt.compute_dtype()), b
         return ops._cached(attn.in_proj_weight, ('qkv', attn.in_proj_bias._version), make)
 
+    @staticmethod
+    def _proj_residual_ln(inp, lin, residual, ln, scratch, out, M, E, p, fused):
+        """out = LayerNorm(residual + dropout_p(lin(inp)))  (fairseq TransformerSentenceEncoderLayer, post-norm).  bf16 at
+        shapes the resident 256x256 GEMM takes: the residual and the dropout ride in the GEMM epilogue
+        (tell_gemm_nt_dropout_residual, same mask as the LayerNorm kernel would draw) and the LayerNorm reads one tensor;
+        otherwise GEMM, then LayerNorm(dropout(x) + residual) as one launch."""
+        w, b = ops.weight(lin.weight), lin.bias.detach()
+        salt = rt.next_salt() if p > 0 else 0
+        dcode = hip.dt(inp.dtype)
+        if fused and hip.call_rc('tell_gemm_nt_dropout_residual', inp, inp.stride(0), w, w.stride(0), b, residual,
+                                 residual.stride(0), scratch, scratch.stride(0), M, E, inp.shape[1], p, rt.seed(),
+                                 salt) == 0:
+            call('tell_layernorm_fwd', scratch, E, None, 0, ln.weight.detach(), ln.bias.detach(), out, E, None, None, M,
+                 E, ln.eps, 0.0, 0, 0, dcode)
+            return
+        ops.gemm(inp, w, out=scratch, bias=b, bias_mode=1)
+        call('tell_layernorm_fwd', scratch, E, residual, E, ln.weight.detach(), ln.bias.detach(), out, E, None, None, M, E,
+             ln.eps, p, rt.seed(), salt, dcode)
+
     @torch.no_grad()
     def extract_features(self, ids, return_all_hiddens=False):
         hip.require_gpu()
@@ -114,6 +133,8 @@ class RobertaEncoder(nn.Module):
         mid = torch.empty(M, E, dtype=dtype, device=dev)
         FF = enc.layers[0].fc1.weight.shape[0]
         hbuf = torch.empty(M, FF, dtype=dtype, device=dev)
+        # (residual + dropout in the GEMM epilogue: faster alone, slower inside the training step - csrc/gemm_pp2.hip)
+        fused = dtype == torch.bfloat16 and os.environ.get('TELL_GEMM_RESIDUAL', '0') == '1'
         for li, layer in enumerate(enc.layers):
             a = layer.self_attn
             wqkv, bqkv = self._qkv(a)
@@ -122,16 +143,12 @@ class RobertaEncoder(nn.Module):
             call('tell_attn_fwd', qkv, qkv[:, E:], qkv[:, 2 * E:], attn_out, None, pad_mask, None, None, B, H, S, S,
                  E // H, ldq, S * ldq, ldq, S * ldq, ldq, S * ldq, E, S * E, 0,
                  self.attention_dropout if tr else 0.0, rt.seed(), rt.next_salt() if tr else 0, dcode)
-            ops.gemm(attn_out, ops.weight(a.out_proj.weight), out=proj, bias=a.out_proj.bias.detach(), bias_mode=1)
             l1 = layer.self_attn_layer_norm
-            call('tell_layernorm_fwd', proj, E, x, E, l1.weight.detach(), l1.bias.detach(), mid, E, None, None, M, E,
-                 l1.eps, p_h, rt.seed(), rt.next_salt() if p_h > 0 else 0, dcode)
+            self._proj_residual_ln(attn_out, a.out_proj, x, l1, proj, mid, M, E, p_h, fused)
             ops.gemm(mid, ops.weight(layer.fc1.weight), out=hbuf, bias=layer.fc1.bias.detach(), bias_mode=1, act=2)
-            ops.gemm(hbuf, ops.weight(layer.fc2.weight), out=proj, bias=layer.fc2.bias.detach(), bias_mode=1)
             l2 = layer.final_layer_norm
             xn = stack[li + 1].view(M, E)
-            call('tell_layernorm_fwd', proj, E, mid, E, l2.weight.detach(), l2.bias.detach(), xn, E, None, None, M, E,
-                 l2.eps, p_h, rt.seed(), rt.next_salt() if p_h > 0 else 0, dcode)
+            self._proj_residual_ln(hbuf, layer.fc2, mid, l2, proj, xn, M, E, p_h, fused)
             x = xn
         return stack if return_all_hiddens else stack[-1]
 
