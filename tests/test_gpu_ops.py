@@ -204,7 +204,9 @@ def test_gemm_dropout_residual_epilogue(M, N, K, p):
 
 
 @pytest.mark.parametrize('env', [{'TELL_GEMM_PP2': '0'}, {'TELL_GEMM_PP2': '1'}, {'TELL_GEMM_DUO': '2'},
-                                 {'TELL_GEMM_DUO': '2', 'TELL_DUO_REG': '1'}], ids=['pp', 'pp2-multi-round', 'duo', 'duo-reg'])
+                                 {'TELL_GEMM_DUO': '2', 'TELL_DUO_REG': '1'}, {'TELL_GEMM_PP2': '2', 'TELL_PP2_DYNAMIC': '1'},
+                                 {'TELL_GEMM_PP2': '2', 'TELL_PP2_DYNAMIC': '0'}],
+                         ids=['pp', 'pp2-multi-round', 'duo', 'duo-reg', 'pp2-tile-queue', 'pp2-static'])
 def test_gemm_kernel_variants_behind_switches(env):
     """The GEMM kernels that are not the default choice (one-workgroup-per-tile ping-pong, the 256x128 two-per-CU forms)
     stay correct: the switches are read once per process, so each runs tools/probes/gemm_variant_check.py in its own."""

@@ -4,6 +4,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tell_amd
 from tell_amd import hip, ops
+hip.require_gpu()        # (registers the tile-counter buffer of the resident GEMM launches)
 REP = 10
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 M = B * 512

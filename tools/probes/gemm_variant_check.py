@@ -8,6 +8,7 @@ import math, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import tell_amd
 from tell_amd import hip, ops
+hip.require_gpu()        # (registers the tile-counter buffer of the resident GEMM launches)
 ok = True
 SHAPES = ((4096, 4096, 64), (4096, 4096, 96), (4096, 4096, 128), (8192, 2048, 160), (16384, 1024, 1024), (16384, 3072, 1024))
 if not os.environ.get('TELL_GEMM_DUO'):

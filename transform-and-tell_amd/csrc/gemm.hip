@@ -1480,6 +1480,12 @@ extern "C" int tell_gemm_set_tile_queue(void* counters, int n, hipStream_t) {
   if (!g_tile_queue_n) g_tile_queue = nullptr;
   return TELL_OK;
 }
+// `words` consecutive zeroed counters for one launch (gemm_pp2.hip: one per XCD), or NULL when no buffer is registered
+int* gemm_tile_queue_slot(int words) {
+  if (!g_tile_queue || g_tile_queue_n < (unsigned)words * 2) return nullptr;
+  const unsigned slots = g_tile_queue_n / (unsigned)words;
+  return g_tile_queue + (size_t)(g_tile_queue_next++ % slots) * words;
+}
 static thread_local char g_gemm_label[96] = "";
 static thread_local bool g_gemm_plan = false;
 static const char* gemm_label(const char* base, int in_bf16, int out_bf16, int bm, int bn) {

@@ -176,11 +176,33 @@ __global__ __launch_bounds__(512) void gemm_nt_pp2_kernel(GemmArgs p) {
     }
   };
 
+  // Tile order.  Static (p.queue == NULL): tiles b, b + grid, ...  Dynamic: one counter per XCD (workgroup b lives on XCD
+  // b & 7 and keeps taking tiles k * 8 + (b & 7), so the XCD-local tile order above is preserved); a workgroup that
+  // gets its CU late - inside the training step the other two streams' workgroups hold CUs when a launch begins -
+  // simply takes fewer tiles instead of finishing its static share late.  The fetch for the NEXT tile is issued right
+  // after the top-of-tile barrier and consumed after the main loop, so its round trip is never waited for; the fetch
+  // that can only be the last one of the launch (value per_x + workgroups per XCD - 1) zeroes the counter again.
+  const bool dyn = p.queue != nullptr;
+  const int xcd_id = blockIdx.x & 7, per_x = n_tiles >> 3, wg_x = (int)gridDim.x >> 3;
+  int* const qx = dyn ? p.queue + xcd_id : nullptr;
+  volatile int* sq = reinterpret_cast<volatile int*>(smem + 2 * TILE);     // first word of the (idle) spare area
   int vb = blockIdx.x;
+  if (dyn) {
+    if (tid0 == 0) {
+      const int k = atomicAdd(qx, 1);
+      if (k == per_x + wg_x - 1) atomicExch(qx, 0);
+      *sq = k;
+    }
+    __syncthreads();
+    const int k = *sq;
+    __syncthreads();
+    vb = k < per_x ? k * 8 + xcd_id : n_tiles;
+  }
   if (vb >= n_tiles) return;
   int m0, n0;
   tile_origin(vb, m0, n0);
   prefetch(m0, n0);
+  bool first_tile = true;
   for (;;) {
     int tid = tid0;
     asm volatile("" : "+v"(tid));
@@ -257,9 +279,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp2_kernel(GemmArgs p) {
 
     // K tile 0 (and the stores of the previous epilogue, which share the counter) must have retired; A0 B0 of K tile 1
     // may still fly on the first tile of the launch
-    if (vb == (int)blockIdx.x && nk >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (first_tile && nk >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    first_tile = false;
     __builtin_amdgcn_s_barrier();
+    int knext = 0;
+    if (dyn && tid0 == 0) knext = atomicAdd(qx, 1);        // (older than every load of this tile: retired by the counted waits)
     if (wr == 1) __builtin_amdgcn_s_barrier();            // group 1 runs one barrier behind
     for (int t = 0; t < nk; ++t) {
       read_a(t, 0); read_b(t, 0);
@@ -285,7 +310,17 @@ __global__ __launch_bounds__(512) void gemm_nt_pp2_kernel(GemmArgs p) {
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
     // every wave has passed its last phase: the stages are free - the next output tile's operands start streaming in
-    const int nvb = vb + (int)gridDim.x;
+    int nvb = vb + (int)gridDim.x;
+    if (dyn) {
+      if (tid0 == 0) {
+        if (knext == per_x + wg_x - 1) atomicExch(qx, 0);
+        *sq = knext;
+      }
+      __syncthreads();
+      const int k = *sq;
+      nvb = k < per_x ? k * 8 + xcd_id : n_tiles;
+      __syncthreads();                                     // (the epilogue stages through the word's area)
+    }
     int m1 = 0, n1 = 0;
     if (nvb < n_tiles) {
       tile_origin(nvb, m1, n1);
@@ -316,10 +351,17 @@ int launch_gemm_pp2(const GemmArgs& a, hipStream_t stream, int n_cu) {
   const int cap = grid_env > 0 && grid_env < n_cu ? grid_env : n_cu;
   const unsigned grid = (unsigned)(n_tiles < cap ? n_tiles : cap);
   static const int abl = getenv("TELL_PP2_ABL") ? atoi(getenv("TELL_PP2_ABL")) : 0;   // timing probes (wrong results): 1 no epilogue, 2 no global stores
-  if (a.act == 5) hipLaunchKernelGGL((gemm_nt_pp2_kernel<0, true>), dim3(grid), dim3(512), 0, stream, a);
-  else if (abl == 1) hipLaunchKernelGGL((gemm_nt_pp2_kernel<1, false>), dim3(grid), dim3(512), 0, stream, a);
-  else if (abl == 2) hipLaunchKernelGGL((gemm_nt_pp2_kernel<2, false>), dim3(grid), dim3(512), 0, stream, a);
-  else hipLaunchKernelGGL((gemm_nt_pp2_kernel<0, false>), dim3(grid), dim3(512), 0, stream, a);
+  // per-XCD tile counters (default on; TELL_PP2_DYNAMIC=0: static tile lists).  MEASURED (same box A/B, configs[2]): 1444 / 1450
+  // samples/s static, 1456 / 1468 dynamic; the launch inside the step 160-164 -> 142-146 us (100 alone either way)
+  static const int dyn_env = getenv("TELL_PP2_DYNAMIC") ? atoi(getenv("TELL_PP2_DYNAMIC")) : 1;
+  GemmArgs ad = a;
+  ad.queue = nullptr;
+  if (dyn_env && n_tiles > (int)grid && grid % 8 == 0 && n_tiles % 8 == 0) ad.queue = gemm_tile_queue_slot(8);
+  const GemmArgs& a2 = ad;
+  if (a.act == 5) hipLaunchKernelGGL((gemm_nt_pp2_kernel<0, true>), dim3(grid), dim3(512), 0, stream, a2);
+  else if (abl == 1) hipLaunchKernelGGL((gemm_nt_pp2_kernel<1, false>), dim3(grid), dim3(512), 0, stream, a2);
+  else if (abl == 2) hipLaunchKernelGGL((gemm_nt_pp2_kernel<2, false>), dim3(grid), dim3(512), 0, stream, a2);
+  else hipLaunchKernelGGL((gemm_nt_pp2_kernel<0, false>), dim3(grid), dim3(512), 0, stream, a2);
   return tell_check_launch("gemm_nt_pp2");
 }
 
