@@ -61,11 +61,12 @@ int tell_wall_clock_khz(void);
  * into ts[0] (first workgroup in) / ts[1] (last workgroup out), device wall-clock ticks; ts is uint64[3], zero before
  * the first use (ts[2] counts workgroup arrivals: every launch of the same grid re-opens the span by itself) */
 int tell_gemm_ts_next(void* ts, tell_stream_t stream);
-/* register the tile counters of the PERSISTENT 256x256 GEMM launches: `counters` = n zero-initialised int32 on the
- * device, owned by the caller and alive for as long as GEMMs are launched (NULL / 0 unregisters: every 256x256 launch is
- * then one workgroup per tile).  Each persistent launch (more tiles than CUs) takes the next slot as its work queue and
- * leaves it zero; n must exceed the number of such launches that can be in flight or captured in live graphs at once by a
- * wide margin (the host mirror registers 65536). */
+/* register the tile counters of the RESIDENT 256x256 GEMM launches (gemm_nt_pp2_kernel): `counters` = n zero-initialised
+ * int32 on the device, owned by the caller and alive for as long as GEMMs are launched (NULL / 0 unregisters: resident
+ * launches then walk static tile lists).  A launch with more tiles than workgroups takes 8 counters (one per XCD) as its
+ * work queues and leaves them zero.  Launches recorded into a hipGraph keep theirs for good and come out of the first half
+ * of the buffer, each slot handed out once (when the half is used up, later captures use static lists); eager launches
+ * walk a ring over the second half.  The host mirror registers 2^20 counters. */
 int tell_gemm_set_tile_queue(void* counters, int n, tell_stream_t stream);
 
 /* ---- GEMM with the transformer sub-layer residual in its epilogue -----------

@@ -1473,18 +1473,29 @@ static int launch_gemm_tx(const GemmArgs& a_in, hipStream_t stream) {
 // slot can be reused by any later launch that does not run concurrently with it - with thousands of slots that only
 // requires that no two launches 2^16 apart (in host issue / capture order) are in flight at once.
 static int* g_tile_queue = nullptr;
-static unsigned g_tile_queue_n = 0, g_tile_queue_next = 0;
+static unsigned g_tile_queue_n = 0, g_tile_queue_next = 0, g_tile_queue_captured = 0;
 extern "C" int tell_gemm_set_tile_queue(void* counters, int n, hipStream_t) {
   g_tile_queue = static_cast<int*>(counters);
+  g_tile_queue_captured = 0;
   g_tile_queue_n = n > 0 ? (unsigned)n : 0u;
   if (!g_tile_queue_n) g_tile_queue = nullptr;
   return TELL_OK;
 }
-// `words` consecutive zeroed counters for one launch (gemm_pp2.hip: one per XCD), or NULL when no buffer is registered
-int* gemm_tile_queue_slot(int words) {
-  if (!g_tile_queue || g_tile_queue_n < (unsigned)words * 2) return nullptr;
-  const unsigned slots = g_tile_queue_n / (unsigned)words;
-  return g_tile_queue + (size_t)(g_tile_queue_next++ % slots) * words;
+// `words` consecutive zeroed counters for one launch (gemm_pp2.hip: one per XCD), or NULL (-> static tile lists) when no
+// buffer is registered / the capture half is used up.  A launch leaves its counters zero, so a slot may be reused by any
+// launch that cannot overlap it in time.  Launches recorded into a hipGraph keep their slot for the graph's lifetime and
+// replay concurrently with whatever the other streams run, so they take slots from the FIRST half of the buffer, each
+// handed out once; eager launches walk a ring over the second half (thousands of launches deep).
+int* gemm_tile_queue_slot(int words, hipStream_t stream) {
+  if (!g_tile_queue || g_tile_queue_n < (unsigned)words * 4) return nullptr;
+  const unsigned half = g_tile_queue_n / (unsigned)words / 2;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (st != hipStreamCaptureStatusNone) {
+    if (g_tile_queue_captured >= half) return nullptr;
+    return g_tile_queue + (size_t)(g_tile_queue_captured++) * words;
+  }
+  return g_tile_queue + (size_t)(half + g_tile_queue_next++ % half) * words;
 }
 static thread_local char g_gemm_label[96] = "";
 static thread_local bool g_gemm_plan = false;
@@ -1552,9 +1563,10 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
             return launch_gemm_pp2(a, stream, n_cu);
           }
           static const bool persist_env = getenv("TELL_GEMM_PERSIST") && atoi(getenv("TELL_GEMM_PERSIST")) == 1;
-          if (persist_env && g_tile_queue && !g_gemm_plan && tiles(256, 256) > n_cu) {
+          int* pq = (persist_env && !g_gemm_plan && tiles(256, 256) > n_cu) ? gemm_tile_queue_slot(1, stream) : nullptr;
+          if (pq) {
             GemmArgs ap = a;
-            ap.queue = g_tile_queue + (g_tile_queue_next++ % g_tile_queue_n);
+            ap.queue = pq;
             hipLaunchKernelGGL((gemm_nt_pp_kernel<OutT>), dim3((unsigned)n_cu), dim3(512), 0, stream, ap);
             return tell_check_launch("gemm_nt_pp");
           }

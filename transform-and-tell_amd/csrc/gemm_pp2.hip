@@ -356,7 +356,7 @@ int launch_gemm_pp2(const GemmArgs& a, hipStream_t stream, int n_cu) {
   static const int dyn_env = getenv("TELL_PP2_DYNAMIC") ? atoi(getenv("TELL_PP2_DYNAMIC")) : 1;
   GemmArgs ad = a;
   ad.queue = nullptr;
-  if (dyn_env && n_tiles > (int)grid && grid % 8 == 0 && n_tiles % 8 == 0) ad.queue = gemm_tile_queue_slot(8);
+  if (dyn_env && n_tiles > (int)grid && grid % 8 == 0 && n_tiles % 8 == 0) ad.queue = gemm_tile_queue_slot(8, stream);
   const GemmArgs& a2 = ad;
   if (a.act == 5) hipLaunchKernelGGL((gemm_nt_pp2_kernel<0, true>), dim3(grid), dim3(512), 0, stream, a2);
   else if (abl == 1) hipLaunchKernelGGL((gemm_nt_pp2_kernel<1, false>), dim3(grid), dim3(512), 0, stream, a2);

@@ -80,8 +80,9 @@ def require_gpu():
     lib()
     dev = torch.cuda.current_device()
     if dev not in _tile_queue:            # work-queue counters of the persistent 256x256 GEMM launches (csrc/gemm.hip)
-        _tile_queue[dev] = torch.zeros(65536, dtype=torch.int32, device='cuda')
-        lib().tell_gemm_set_tile_queue(_tile_queue[dev].data_ptr(), 65536, None)
+        # 4 MB: 8 counters per launch; launches recorded into hipGraphs keep theirs (first half: 65536 launches' worth)
+        _tile_queue[dev] = torch.zeros(1 << 20, dtype=torch.int32, device='cuda')
+        lib().tell_gemm_set_tile_queue(_tile_queue[dev].data_ptr(), 1 << 20, None)
 
 
 def dt(t):
