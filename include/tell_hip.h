@@ -69,6 +69,11 @@ int tell_gemm_ts_next(void* ts, tell_stream_t stream);
  * walk a ring over the second half.  The host mirror registers 2^20 counters. */
 int tell_gemm_set_tile_queue(void* counters, int n, tell_stream_t stream);
 
+/* ---- exact-erf GELU as its own launch (bf16; y may be x) ----------------------
+ * the activation between fc1 and fc2 of fairseq's TransformerSentenceEncoderLayer (activation_fn = gelu) when it is kept
+ * out of the fc1 GEMM's epilogue (act 2 of tell_gemm_nt is the fused form; same formula). */
+int tell_gelu(const void* x, void* y, long n, int dtype, tell_stream_t stream);
+
 /* ---- GEMM with the transformer sub-layer residual in its epilogue -----------
  * out[M,N] = res[M,N] + dropout_p(A[M,K] . B[N,K]^T + bias[n]), bf16, mask = the one tell_layernorm_fwd draws for
  * (seed, salt) over an [M,N] input.  Replaces  x = residual + F.dropout(self.out_proj(attn)) / F.dropout(self.fc2(h))

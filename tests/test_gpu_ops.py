@@ -168,6 +168,30 @@ def test_gemm_pingpong_kernel(M, N, K):
     assert plan(ad[:M - 8], bd, out_small).startswith('gemm_nt_glds_kernel<bf16,')
 
 
+def test_gelu_launch_matches_torch_and_the_gemm_epilogue():
+    """tell_gelu (exact-erf GELU as its own bf16 launch, in place) against torch's erf GELU, and against act 2 of the GEMM
+    epilogue on the same pre-activation (identical up to the one extra bf16 rounding of the pre-activation)."""
+    from tell_amd import hip, ops
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(4096, 1024, generator=g) * 2.5).bfloat16()
+    x[0, :8] = torch.tensor([0.0, -0.0, 9.0, -9.0, 40.0, -40.0, 1e-3, -1e-3]).bfloat16()
+    xd = x.to(DEV)
+    y = torch.empty_like(xd)
+    hip.call('tell_gelu', xd, y, xd.numel(), hip.BF16)
+    ref = torch.nn.functional.gelu(x.float())
+    got = y.float().cpu()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max() <= 2.0 ** -8 * ref.abs().max() and (got - ref.bfloat16().float()).norm() / ref.norm() < 2e-3
+    hip.call('tell_gelu', xd, xd, xd.numel(), hip.BF16)                      # in place
+    assert torch.equal(xd, y)
+    a = torch.randn(4096, 256, generator=g).bfloat16().to(DEV)
+    w = torch.randn(1024, 256, generator=g).bfloat16().to(DEV)
+    fused = ops.gemm(a, w, act=2)
+    pre = ops.gemm(a, w)
+    hip.call('tell_gelu', pre, pre, pre.numel(), hip.BF16)
+    assert (fused.float() - pre.float()).norm() / fused.float().norm() < 4e-3
+
+
 @pytest.mark.parametrize('p', [0.0, 0.1])
 @pytest.mark.parametrize('M,N,K', [(16384, 1024, 1024), (8192, 2048, 192), (4096, 4096, 64)])
 def test_gemm_dropout_residual_epilogue(M, N, K, p):

@@ -3,6 +3,7 @@
 // gather / scatter, NaN-row masking, RoBERTa layer mix.
 // All loops are grid-stride over 16-byte chunks where the layout allows.
 #include "common.h"
+#include "gemm_common.h"    // gelu_erf2, pack2_bf16, u32x4
 
 static inline int grid_for(long work, int per_block) {
   long g = (work + per_block - 1) / per_block;
@@ -362,6 +363,32 @@ extern "C" int tell_dropout(const void* x, void* y, long n, float p, uint32_t se
   if (dtype == TELL_BF16) hipLaunchKernelGGL((dropout_kernel<uint16_t>), dim3(g), dim3(256), 0, stream, (const uint16_t*)x, (uint16_t*)y, n, thr, ik, seed, salt, g_tell_rng_step);
   else hipLaunchKernelGGL((dropout_kernel<float>), dim3(g), dim3(256), 0, stream, (const float*)x, (float*)y, n, thr, ik, seed, salt, g_tell_rng_step);
   return tell_check_launch("dropout");
+}
+
+// ---------------------------------------------------------------- exact-erf GELU as its own launch (bf16, in place or not)
+// y = gelu(x), 16 bytes per thread and trip.  Same formula as the GEMM epilogue's act 2 (gemm_common.h gelu_erf2); used
+// where the activation is kept OUT of the dominant GEMM's epilogue: that kernel owns every CU it runs on, so arithmetic in
+// its epilogue is paid with idle matrix cores, while this launch is bandwidth-bound and shares the chip.
+__global__ __launch_bounds__(256) void gelu_vec_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, long nv) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(x + i * 8);
+    u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x2e_t r = gelu_erf2(f32x2e_t{__uint_as_float(v[q] << 16), __uint_as_float(v[q] & 0xffff0000u)});
+      o[q] = pack2_bf16(r[0], r[1]);
+    }
+    *reinterpret_cast<u32x4*>(y + i * 8) = o;
+  }
+}
+extern "C" int tell_gelu(const void* x, void* y, long n, int dtype, hipStream_t stream) {
+  if (n <= 0) return TELL_OK;
+  TELL_REQUIRE(dtype == TELL_BF16 && n % 8 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0,
+               "gelu: bf16, a multiple of 8 elements, 16-byte aligned buffers");
+  const long nv = n / 8;
+  const int g = (int)((nv + 255) / 256 > 16384 ? 16384 : (nv + 255) / 256);
+  hipLaunchKernelGGL(gelu_vec_kernel, dim3(g), dim3(256), 0, stream, (const uint16_t*)x, (uint16_t*)y, nv);
+  return tell_check_launch("gelu");
 }
 
 // ---------------------------------------------------------------- column sums (bias grads): out[c] (+)= scale * sum_r x[r][c]

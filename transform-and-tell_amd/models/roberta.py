@@ -135,6 +135,7 @@ class RobertaEncoder(nn.Module):
         hbuf = torch.empty(M, FF, dtype=dtype, device=dev)
         # (residual + dropout in the GEMM epilogue: faster alone, slower inside the training step - csrc/gemm_pp2.hip)
         fused = dtype == torch.bfloat16 and os.environ.get('TELL_GEMM_RESIDUAL', '0') == '1'
+        split_gelu = dtype == torch.bfloat16 and (M * FF) % 8 == 0 and os.environ.get('TELL_GELU_SPLIT', '0') == '1'
         for li, layer in enumerate(enc.layers):
             a = layer.self_attn
             wqkv, bqkv = self._qkv(a)
@@ -145,7 +146,11 @@ class RobertaEncoder(nn.Module):
                  self.attention_dropout if tr else 0.0, rt.seed(), rt.next_salt() if tr else 0, dcode)
             l1 = layer.self_attn_layer_norm
             self._proj_residual_ln(attn_out, a.out_proj, x, l1, proj, mid, M, E, p_h, fused)
-            ops.gemm(mid, ops.weight(layer.fc1.weight), out=hbuf, bias=layer.fc1.bias.detach(), bias_mode=1, act=2)
+            if split_gelu:
+                ops.gemm(mid, ops.weight(layer.fc1.weight), out=hbuf, bias=layer.fc1.bias.detach(), bias_mode=1)
+                call('tell_gelu', hbuf, hbuf, M * FF, dcode)
+            else:
+                ops.gemm(mid, ops.weight(layer.fc1.weight), out=hbuf, bias=layer.fc1.bias.detach(), bias_mode=1, act=2)
             l2 = layer.final_layer_norm
             xn = stack[li + 1].view(M, E)
             self._proj_residual_ln(hbuf, layer.fc2, mid, l2, proj, xn, M, E, p_h, fused)
