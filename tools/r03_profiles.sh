@@ -17,3 +17,5 @@ python tools/bench_skinny.py 128 >> gpurun_out/r03_skinny_bench.txt 2>&1
 python tools/bench_roberta_gemms.py > gpurun_out/r03_roberta_gemms.txt 2>&1
 for b in 1 4; do python bench.py --generate --beam $b 2>/dev/null | tail -1 > gpurun_out/r03_generate_beam$b.json; done
 python bench.py 2> gpurun_out/r03_bench.err | tail -1 > gpurun_out/r03_bench.json
+python tools/bench_dynconv.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_dynconv.txt
+bash tools/pmc_kernel.sh gemm_nt_pp2 gpurun_out/r03_pmc_gemm_mfma.txt SQ_BUSY_CYCLES,SQ_ACTIVE_INST_ANY,SQ_ACTIVE_INST_VALU,SQ_ACTIVE_INST_LDS,SQ_INST_CYCLES_VMEM,SQ_VALU_MFMA_BUSY_CYCLES,SQ_WAVE_CYCLES,SQ_WAIT_ANY -- python tools/bench_roberta_gemms.py > /dev/null
