@@ -1557,6 +1557,14 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
           // box A/B): RoBERTa layer GEMMs alone 442-444 -> 436 us; configs[2] 1500 / 1506 samples/s without, 1524 / 1526 with
           // (in-step launch 148-157 -> 122-139 us).  TELL_GEMM_PP2=0: one workgroup per tile (gemm_nt_pp_kernel), 1: only
           // launches of two rounds or more.
+          // four waves x 128x128, hand-placed K loop (gemm_q4.hip): TELL_GEMM_Q4=1
+          static const int q4_env = getenv("TELL_GEMM_Q4") ? atoi(getenv("TELL_GEMM_Q4")) : 0;
+          if (q4_env && (force == 0 || force == 8) && a.K % 128 == 0 && a.K >= 128 && a.K / 64 < 65536 && a.lda % 8 == 0 && a.ldb % 8 == 0 && !a.conv_zero &&
+              a.act <= 2 && (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0 &&
+              256L * a.lda * 2 < (1L << 31) && 256L * a.ldb * 2 < (1L << 31)) {
+            if (g_gemm_plan) { (void)gemm_label("gemm_nt_q4_kernel", -1, 1, 256, 256); return TELL_OK; }
+            return launch_gemm_q4(a, stream, n_cu);
+          }
           static const int pp2_env = getenv("TELL_GEMM_PP2") ? atoi(getenv("TELL_GEMM_PP2")) : 2;
           if (pp2_env && force == 0 && tiles(256, 256) >= (pp2_env == 2 ? 1 : 2) * (long)n_cu && a.lda % 8 == 0 && a.ldb % 8 == 0 && !a.conv_zero) {
             if (g_gemm_plan) { (void)gemm_label("gemm_nt_pp2_kernel", -1, 1, 256, 256); return TELL_OK; }

@@ -126,4 +126,6 @@ __device__ __forceinline__ void gemm_ts_exit(const GemmArgs& p) {
 int launch_gemm_duo(const GemmArgs& a, hipStream_t stream);
 // gemm_pp2.hip: the 256x256 ping-pong kernel as resident workgroups that prefetch the next output tile under the epilogue
 int launch_gemm_pp2(const GemmArgs& a, hipStream_t stream, int n_cu);
+// gemm_q4.hip: 256x256 tiles, four waves of 128x128, hand-placed K loop (round 4)
+int launch_gemm_q4(const GemmArgs& a, hipStream_t stream, int n_cu);
 int* gemm_tile_queue_slot(int words, hipStream_t stream);    // gemm.hip: `words` zeroed tile counters for one launch, or NULL
