@@ -190,6 +190,72 @@ def test_resnet152_full_trunk_matches_oracle(train, monkeypatch):
         assert r16 < 6e-2, r16
 
 
+def _device_kernel_names(fn):
+    """Names of the device kernels fn() launches (torch.profiler / roctracer sees every kernel of the process)."""
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        fn()
+        torch.cuda.synchronize()
+    return {e.name for e in prof.events()}
+
+
+@pytest.mark.parametrize('stage', [1, 2, 3])
+def test_resnet152_first_blocks_at_bench_batch_match_oracle(stage):
+    """ResNet-152 AT THE BENCH BATCH (B = 32; resnet.py:92-108 as configs[2] runs it): the first bottleneck of layer1 /
+    layer2 / layer3 - with their downsampling branches and, for layer2 / layer3, the stride-2 3x3 convolution - teacher
+    forced on one random post-ReLU input, train-mode BatchNorm.  At B = 32 these blocks have 100 352 / 25 088 / 6 272
+    output rows: more than 128 row chunks of 64, i.e. the BatchNorm statistics take the many-chunk path of
+    tell_conv_bn_act (bn_finish_kernel + bn_apply_vec_kernel, or bn_combine_kernel + the fused launch) and the
+    convolutions the tile / ring choice of the full-size launch - neither is reached by the B = 2 full-trunk test.
+    fp32 block vs oracle < 1e-5; bf16 implicit-GEMM block vs the fp32 oracle block < 3 %; running statistics too."""
+    import tell_amd
+    from oracle.encoders import resnet152 as ores
+    from tell_amd.models import resnet as R
+    B = 32
+    torch.manual_seed(10 + stage)
+    ora = ores()
+    _randomise_bn(ora, seed=20 + stage)
+    oblk = getattr(ora, 'layer%d' % stage)[0].train()
+    cin, hw = {1: (64, 56), 2: (256, 56), 3: (512, 28)}[stage]
+    x = torch.relu(torch.randn(B, cin, hw, hw))
+    sd = {k: v.clone() for k, v in oblk.state_dict().items()}
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        yref = oblk(x)
+    OHW = yref.shape[-1]
+    yref_rows = yref.permute(0, 2, 3, 1).reshape(B * OHW * OHW, -1)
+    rows = x.permute(0, 2, 3, 1).reshape(B * hw * hw, cin).contiguous()
+    assert (B * OHW * OHW + 63) // 64 > (128 if stage < 3 else 64)
+    for dtype in DTYPES:
+        tell_amd.set_compute_dtype(dtype)
+        hblk = getattr(R.resnet152(), 'layer%d' % stage)[0]
+        hblk.load_state_dict(sd)
+        hblk.to(DEV).train()
+        xin = rows.to(DEV).to(dtype)
+        out = {}
+
+        def run():
+            out['y'] = hblk.run(xin, B, hw, hw, True)
+        names = _device_kernel_names(run)
+        y, OH, OW = out['y']
+        assert (OH, OW) == (OHW, OHW) and y.shape == yref_rows.shape
+        r = rel(y, yref_rows)
+        rv = rel(hblk.bn3.running_var, oblk.bn3.running_var)
+        rm = rel(hblk.bn2.running_mean, oblk.bn2.running_mean)
+        print('\nResNet-152 layer%d[0] at B=32, %s: block %.2e, running_var(bn3) %.2e, running_mean(bn2) %.2e' % (stage, dtype, r, rv, rm))
+        if dtype == torch.float32:
+            assert r < 1e-5 and rv < 1e-4 and rm < 1e-4, (r, rv, rm)
+        else:
+            assert all(R.implicit_ok(c, dtype) for c in (hblk.conv1, hblk.conv2, hblk.conv3))
+            assert r < 3e-2 and rv < 3e-2 and rm < 3e-2, (r, rv, rm)
+            joined = ' '.join(sorted(names))
+            assert 'gemm_nt_glds_kernel' in joined, joined                    # implicit-GEMM convolutions
+            many = ('bn_finish_kernel' in joined and 'bn_apply' in joined) or 'bn_combine_kernel' in joined
+            assert many, joined                                                # the > 128-chunk statistics path ran
+        del hblk, y
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize('train', [False, True])
 @pytest.mark.parametrize('tile', ['0', '1', '2', '3'])
 def test_implicit_conv_path_equals_im2col_path_bf16(train, tile, monkeypatch):
@@ -310,7 +376,7 @@ def test_roberta_large_at_bench_size_matches_oracle():
                 bias = torch.zeros(n, dtype=torch.float32, device=DEV)
                 name = hip.query('tell_gemm_nt_plan', a, a.stride(0), w, w.stride(0), out, out.stride(0), B * S, n,
                                  a.shape[1], hip.dt(a), hip.dt(out), bias, 1, 0, None, 1.0, 0, None)
-                assert name.startswith(('gemm_nt_pp2_kernel', 'gemm_nt_pp_kernel')), (n, name)
+                assert name.startswith(('gemm_nt_q4_kernel', 'gemm_nt_pp2_kernel', 'gemm_nt_pp_kernel')), (n, name)
             del x, h, out
         out = hipm.extract_features(ids.to(DEV), return_all_hiddens=True)
         assert out.shape == ref.shape

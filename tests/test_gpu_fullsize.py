@@ -300,6 +300,122 @@ def test_full_size_greedy_decode_bit_exact_fp32_and_bf16_agreement():
     assert results[torch.bfloat16] >= 0.9, results
 
 
+def _inputs_batch(batch, seed):
+    """4-context inputs at an arbitrary batch (ragged masks, some samples without faces)."""
+    g = torch.Generator().manual_seed(seed)
+    ctx = {}
+    for n in ('image', 'article', 'faces', 'obj'):
+        S, C = SHAPES[n]
+        x = torch.randn(S, batch, C, generator=g) * 0.5
+        if n in ('image', 'obj'):
+            x = x.abs()
+        lens = torch.randint(max(S // 2, 1), S + 1, (batch,), generator=g)
+        if n == 'image':
+            lens = torch.full((batch,), S)
+        if n == 'faces':
+            lens = torch.randint(0, S + 1, (batch,), generator=g)
+            lens[0] = 0
+        mask = torch.arange(S)[None, :] >= lens[:, None]
+        ctx[n], ctx[n + '_mask'] = x * (~mask).t()[:, :, None], mask
+    start = torch.zeros(batch, 1, dtype=torch.long)                       # <s>
+    return ctx, start
+
+
+def _shell_models(ref, dec):
+    """The generators live on the model classes: bare CaptionModel shells around an oracle and a HIP decoder."""
+    from oracle.models import CaptionModel as OModel
+    from tell_amd.models.transformer import CaptionModel
+    om = OModel.__new__(OModel)
+    torch.nn.Module.__init__(om)
+    om.decoder, om.padding_idx, om.index, om.sampling_topk, om.sampling_temp = ref, 1, 'roberta', 1, 1.0
+    m = CaptionModel.__new__(CaptionModel)
+    torch.nn.Module.__init__(m)
+    m.decoder, m.padding_idx, m.index, m.sampling_topk, m.sampling_temp = dec, 1, 'roberta', 1, 1.0
+    m.training = False
+    return om, m
+
+
+def _sharpened_eos(sd, factor):
+    """A copy of the weights whose EOS row (tied input / output table, band 0) is scaled: its logit dominates wherever
+    it is positive, so hypotheses end at different, data-dependent steps."""
+    sd = {k: v.clone() for k, v in sd.items()}
+    done = set()
+    for k, v in sd.items():
+        if (k.endswith('adaptive_softmax.head.word_proj.weight') or k.endswith('embed_tokens.embeddings.0.weight') or
+                k.endswith('embedders.adaptive.embeddings.0.weight')) and v.data_ptr() not in done:
+            v[2] *= factor
+            done.add(v.data_ptr())
+    return sd
+
+
+def test_full_size_greedy_at_bench_batch_with_early_eos_bit_exact_fp32():
+    """transformer_faces_objects.py:443-494 AT THE BENCH BATCH (B = 32): the cached / graphed fp32 greedy generator
+    against the oracle's reference-flow loop, with an EOS row sharp enough that rows finish at different steps - the
+    finished-row bookkeeping of tell_greedy_update (rows that have emitted </s> keep emitting pad, the loop ends when
+    every row is done or at the cap) is compared at the batch the bench decodes, not only at fixture size."""
+    import tell_amd
+    from oracle.build import build_decoder as obuild
+    from tell_amd.build import build_decoder
+    BB, GEN = 32, 12
+    o = _oracle('faces_objects')
+    sd = _sharpened_eos(o['sd'], 3.0)
+    ref = obuild('faces_objects').eval()
+    ref.load_state_dict({k: v for k, v in sd.items() if k in ref.state_dict()}, strict=False)
+    ctx, start = _inputs_batch(BB, seed=41)
+    tell_amd.set_compute_dtype(torch.float32)
+    dec = build_decoder('faces_objects')
+    dec.load_state_dict(sd)
+    dec.to(DEV).eval()
+    om, m = _shell_models(ref, dec)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        _, want, _ = om._generate(start, {k: v.clone() for k, v in ctx.items()}, gen_len=GEN, eos=2)
+        _, got, _ = m._generate_cached(start.to(DEV), _to_dev(ctx, torch.float32), gen_len=GEN, eos=2)
+    got = got.cpu()
+    ended = (want == 2).any(1)
+    first = torch.where(ended, (want == 2).float().argmax(1), torch.full((BB,), want.shape[1]))
+    print('\nfull-size fp32 greedy at B=32: %d of %d rows end early (first </s> at steps %s), %d steps run'
+          % (int(ended.sum()), BB, sorted(set(first[ended].tolist())), got.shape[1]))
+    assert 4 <= int(ended.sum()) and len(set(first.tolist())) >= 3, first         # genuinely ragged
+    n = min(got.shape[1], want.shape[1])
+    assert torch.equal(got[:, :n], want[:, :n]), (got, want)
+    assert (got[:, n:] == 1).all() and (want[:, n:] == 1).all()
+    for b in range(BB):                                                           # pad after the first </s>
+        if ended[b]:
+            assert (got[b, int(first[b]) + 1:] == 1).all()
+
+
+def test_full_size_beam4_matches_oracle_definition_fp32():
+    """BASELINE configs[4] is a beam-4 configuration: the cached beam generator (K/V shared by a sample's hypotheses,
+    DynamicConv buffers reordered by parent - dynamic.py:338-342) AT FULL SIZE against the prefix-re-decoding
+    definition of oracle/beam.py, fp32: identical token ids and summed log-probabilities; also beam 2."""
+    import tell_amd
+    from oracle.beam import beam_search
+    from oracle.build import build_decoder as obuild
+    from tell_amd.build import build_decoder
+    BB, GEN = 2, 8
+    o = _oracle('faces_objects')
+    sd = _sharpened_eos(o['sd'], 2.0)
+    ref = obuild('faces_objects').eval()
+    ref.load_state_dict({k: v for k, v in sd.items() if k in ref.state_dict()}, strict=False)
+    ctx, start = _inputs_batch(BB, seed=43)
+    tell_amd.set_compute_dtype(torch.float32)
+    dec = build_decoder('faces_objects')
+    dec.load_state_dict(sd)
+    dec.to(DEV).eval()
+    om, m = _shell_models(ref, dec)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        for K in (4, 2):
+            ref_ids, ref_score = beam_search(om, start, {k: v.clone() for k, v in ctx.items()}, K, gen_len=GEN)
+            lp, got, _ = m._generate_beam(start.to(DEV), _to_dev(ctx, torch.float32), K, gen_len=GEN, eos=2)
+            got = got.cpu()
+            n = min(got.shape[1], ref_ids.shape[1])
+            assert torch.equal(got[:, :n], ref_ids[:, :n]), (K, got, ref_ids)
+            assert (got[:, n:] == 1).all() and (ref_ids[:, n:] == 1).all()
+            assert torch.allclose(lp.sum(1).cpu(), ref_score, rtol=1e-4, atol=5e-4), (lp.sum(1), ref_score)
+
+
 @pytest.mark.parametrize('kind,beams', [('faces_objects', 1), ('faces_objects', 4), ('faces_objects', 16), ('flattened', 4)])
 def test_fused_decode_step_matches_layer_by_layer_step_and_fp32(kind, beams):
     """The generation step as weight-streaming launches (tell_amd/decode.py, csrc/decode.hip: skinny linears with

@@ -4,6 +4,7 @@ fp32 mode: tight tolerances (f32 MFMA == fmaf chain).  bf16 mode: bf16-level tol
 import math
 
 import numpy as np
+import os
 import pytest
 import torch
 
@@ -164,7 +165,10 @@ def test_gemm_pingpong_kernel(M, N, K):
     def plan(x, y, o):
         return hip.query('tell_gemm_nt_plan', x, x.stride(0), y, y.stride(0), o, o.stride(0), x.shape[0], y.shape[0],
                          x.shape[1], hip.BF16, hip.BF16, None, 0, 0, None, 1.0, 0, None)
-    assert plan(ad, bd, out) in ('gemm_nt_pp2_kernel<bf16,256,256>', 'gemm_nt_pp_kernel<bf16,256,256>')   # TELL_GEMM_PP2=0 selects the latter
+    # (K a multiple of 128: the four-wave kernel of round 4, csrc/gemm_q4.hip; TELL_GEMM_Q4=0 / TELL_GEMM_PP2=0 select the others)
+    assert plan(ad, bd, out) in ('gemm_nt_q4_kernel<bf16,256,256>', 'gemm_nt_pp2_kernel<bf16,256,256>', 'gemm_nt_pp_kernel<bf16,256,256>')
+    if K % 128 == 0 and not os.environ.get('TELL_GEMM_Q4'):
+        assert plan(ad, bd, out) == 'gemm_nt_q4_kernel<bf16,256,256>'
     assert plan(ad[:M - 8], bd, out_small).startswith('gemm_nt_glds_kernel<bf16,')
 
 
@@ -237,11 +241,29 @@ def test_gemm_kernel_variants_behind_switches(env):
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     e = dict(os.environ); e.update(env)
+    e['TELL_GEMM_Q4'] = '0'                                   # (the default since round 4 takes the K % 128 == 0 shapes otherwise)
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'probes', 'gemm_variant_check.py')], env=e,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'ALL OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     want = 'gemm_nt_duo_kernel' if 'TELL_GEMM_DUO' in env else ('gemm_nt_pp_kernel' if env['TELL_GEMM_PP2'] == '0' else 'gemm_nt_pp2_kernel')
     assert want in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize('env', [{}, {'TELL_GEMM_TILE': '8'}, {'TELL_Q4_VAR': '1'}, {'TELL_Q4_VAR': '2'}],
+                         ids=['default', 'partial-rounds', 'schedule-1', 'schedule-2'])
+def test_gemm_q4_kernel(env):
+    """gemm_nt_q4_kernel (csrc/gemm_q4.hip: four waves of 128x128, hand-placed K loop - the default for whole rounds of
+    256x256 bf16 tiles with K % 128 == 0) through tools/probes/q4_check.py: 2 to 64 K tiles (first / steady-state / last
+    body of the generated stream), 1 to 4 output tiles per resident workgroup incl. a last round with fewer tiles than
+    workgroups (forced), every epilogue form, strided operands and output, repeated launches bit-identical; the
+    alternative instruction schedules kept behind TELL_Q4_VAR."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'probes', 'q4_check.py')], env=e,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'ALL OK' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count('gemm_nt_q4_kernel') >= 9, r.stdout[-3000:]
 
 
 @pytest.mark.parametrize('dtype', DTYPES)

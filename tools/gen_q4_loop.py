@@ -34,10 +34,12 @@ V_CLOBBER = list(range(V_FRAG, V_TOGW + 1))
 S_CLOBBER = list(range(36, 76))
 
 # ---- operand numbers of the main statement
-OP_ACC = 0             # %0..%15  acc[i][j] -> 4 i + j   ("=&a", f32x16)
-OP_XRD, OP_WRD, OP_XVO, OP_WVO = 16, 17, 18, 19          # "v"
-OP_XCUR, OP_WCUR, OP_XNEXT, OP_WNEXT = 20, 21, 22, 23    # "s", 64 bit
-OP_LDA32, OP_LDB32, OP_NKF, OP_DSTW = 24, 25, 26, 27     # "s"
+# accumulators are PHYSICAL: acc[i][j] = a[16 (4 i + j) : + 15] (clobbers; the epilogue reads them with v_accvgpr_read)
+OP_XRD, OP_WRD, OP_XVO, OP_WVO = 0, 1, 2, 3          # "v"
+OP_XCUR, OP_WCUR, OP_XNEXT, OP_WNEXT = 4, 5, 6, 7    # "s", 64 bit
+OP_LDA32, OP_LDB32, OP_NKF, OP_DSTW = 8, 9, 10, 11   # "s"
+# the instrumented statement (timing probe) has two 64-bit "=&s" outputs in front: %0 = s_memtime behind the tile-top
+# barrier, %1 = s_memtime behind the last MFMA; its inputs are the ones above shifted by 2
 
 
 def frag(setn, op, s, f):
@@ -46,7 +48,8 @@ def frag(setn, op, s, f):
 
 
 def acc(i, j):
-    return '%%%d' % (OP_ACC + 4 * i + j)
+    b = 16 * (4 * i + j)
+    return 'a[%d:%d]' % (b, b + 15)
 
 
 def mfma(kh, q, zero_c):
@@ -83,29 +86,56 @@ def soff_setup(lda_op, ldb_op):
     return o
 
 
-def body(first, last):
+# Schedule variants (positions = "after MFMA p" of the 64 MFMAs of a body).  The kernel is instantiated once per variant;
+# TELL_Q4_VAR picks one at run time (A/B inside one process, same box).
+#   0: X reads 0-7 | lgkm(0) barrier 9 | DMA X / W reads interleaved 11-23 | lgkm(0) barrier 25 | ...
+#   1: X reads 0-7, W reads 8-15 back to back | lgkm(8) barrier 12 (X done: LDS returns in order) | DMA X 14-28 |
+#      lgkm(0) barrier 19 | DMA W from 30: the waits sit >= 4 MFMAs behind the reads they cover
+#   2: variant 0 with both read waits one MFMA later (10 / 26)
+VARIANTS = (0, 1, 2)
+
+
+def body(first, last, var=0):
     ev = {}
 
     def at(p, *ins):
         ev.setdefault(p, []).extend(ins)
 
-    # X(t) k-half 1 -> set 1
-    for n in range(8):
-        at(n, read(0, 1, 1, n))
-    at(7, 'v_xor_b32 v%d, v%d, v%d' % (V_XRD, V_TOGX, V_XRD))
-    at(9, 's_waitcnt lgkmcnt(0)', 's_barrier')
-    at(10, 's_mov_b32 m0, s%d' % S_DSTX, 's_nop 0')
-    for n, p in enumerate((11, 13, 15, 17, 19)):
-        at(p, *dma(0, n))
-    for n, p in enumerate((12, 14, 16, 18, 20, 21, 22, 23)):
-        at(p, read(1, 1, 1, n))
-    at(23, 'v_xor_b32 v%d, v%d, v%d' % (V_WRD, V_TOGW, V_WRD))
-    at(25, 's_waitcnt lgkmcnt(0)', 's_barrier')
-    at(26, *dma(0, 5))
-    at(27, *dma(0, 6))
-    at(28, dma(0, 7)[0], 's_mov_b32 m0, s%d' % S_DSTW)
-    at(30, *dma(1, 0))
-    at(31, *dma(1, 1))
+    xorx = 'v_xor_b32 v%d, v%d, v%d' % (V_XRD, V_TOGX, V_XRD)
+    xorw = 'v_xor_b32 v%d, v%d, v%d' % (V_WRD, V_TOGW, V_WRD)
+    if var == 1:
+        for n in range(8):
+            at(n, read(0, 1, 1, n))
+        at(7, xorx)
+        for n in range(8):
+            at(8 + n, read(1, 1, 1, n))
+        at(15, xorw)
+        at(12, 's_waitcnt lgkmcnt(5)', 's_barrier')                # issued so far: 8 X + 5 W reads -> the X reads are done
+        at(13, 's_mov_b32 m0, s%d' % S_DSTX, 's_nop 0')
+        for n, p in enumerate((14, 16, 18, 20, 22, 24, 26)):
+            at(p, *dma(0, n))
+        at(19, 's_waitcnt lgkmcnt(0)', 's_barrier')
+        at(28, dma(0, 7)[0], 's_mov_b32 m0, s%d' % S_DSTW)
+        at(30, *dma(1, 0))
+        at(31, *dma(1, 1))
+    else:
+        w1, w2 = (9, 25) if var == 0 else (10, 26)
+        for n in range(8):
+            at(n, read(0, 1, 1, n))
+        at(7, xorx)
+        at(w1, 's_waitcnt lgkmcnt(0)', 's_barrier')
+        at(w1 + 1, 's_mov_b32 m0, s%d' % S_DSTX, 's_nop 0')
+        for n, p in enumerate((w1 + 2, w1 + 4, w1 + 6, w1 + 8, w1 + 10)):
+            at(p, *dma(0, n))
+        for n, p in enumerate((12, 14, 16, 18, 20, 21, 22, 23)):
+            at(p, read(1, 1, 1, n))
+        at(23, xorw)
+        at(w2, 's_waitcnt lgkmcnt(0)', 's_barrier')
+        at(w2 + 1, *dma(0, 5))
+        at(w2 + 2, *dma(0, 6))
+        at(w2 + 3, dma(0, 7)[0], 's_mov_b32 m0, s%d' % S_DSTW)
+        at(30 if var == 0 else 31, *dma(1, 0))
+        at(31 if var == 0 else 32, *dma(1, 1))
     if not last:
         at(33, 's_waitcnt vmcnt(18)', 's_barrier')
         for n in range(8):
@@ -135,7 +165,15 @@ def body(first, last):
     return out
 
 
-def main_statement():
+def main_statement(var=0, dbg=False):
+    text = _main_statement(var, dbg)
+    if dbg:                                                 # shift the input operand numbers behind the two outputs
+        import re
+        text = [re.sub(r'%(\d+)', lambda m: '%%%d' % (int(m.group(1)) + 2), ln) if not ln.startswith('s_memtime') else ln for ln in text]
+    return text
+
+
+def _main_statement(var=0, dbg=False):
     o = []
     # ---- tile top: state into physical registers
     o += ['v_mov_b32 v%d, %%%d' % (V_XRD, OP_XRD), 'v_mov_b32 v%d, %%%d' % (V_WRD, OP_WRD),
@@ -164,15 +202,19 @@ def main_statement():
     # K tiles 0 and 1 of this output tile were put in flight by the previous statement: wait (this also retires the
     # previous epilogue's stores, which share the counter), then read k-half 0 of K tile 0
     o += ['s_waitcnt vmcnt(0)', 's_barrier']
+    if dbg:
+        o.append('s_memtime %0')
     for n in range(8):
         o.append(read(0, 0, 0, n))
     for n in range(8):
         o.append(read(1, 0, 0, n))
-    o += body(True, False)
+    o += body(True, False, var)
     o += ['s_cmp_eq_u32 s%d, 0' % S_MID, 's_cbranch_scc1 2f', '.p2align 6', '1:']
-    o += body(False, False)
+    o += body(False, False, var)
     o += ['s_sub_u32 s%d, s%d, 1' % (S_MID, S_MID), 's_cmp_eq_u32 s%d, 0' % S_MID, 's_cbranch_scc0 1b', '2:']
-    o += body(False, True)
+    o += body(False, True, var)
+    if dbg:
+        o += ['s_memtime %1', 's_waitcnt lgkmcnt(0)']
     o += ['s_nop 15', 's_nop 15']
     return o
 
@@ -200,8 +242,8 @@ def c_string(lines):
     return '\n'.join('  "%s\\n\\t"' % ln for ln in lines)
 
 
-def clobbers(v, s):
-    return ', '.join(['"memory"', '"scc"'] + ['"v%d"' % r for r in v] + ['"s%d"' % r for r in s])
+def clobbers(v, s, a=()):
+    return ', '.join(['"memory"', '"scc"'] + ['"v%d"' % r for r in v] + ['"s%d"' % r for r in s] + ['"a%d"' % r for r in a])
 
 
 def main():
@@ -210,8 +252,11 @@ def main():
     with open(path, 'w') as f:
         f.write('// GENERATED by tools/gen_q4_loop.py - do not edit.  The K loop of gemm_nt_q4_kernel (csrc/gemm_q4.hip) as inline-asm text.\n')
         f.write('#define Q4_PIECE %d\n#define Q4_OPER %d\n#define Q4_BUF %d\n' % (PIECE, OPER, BUF))
-        f.write('#define Q4_MAIN_ASM \\\n' + c_string(main_statement()).replace('\n', ' \\\n') + '\n')
-        f.write('#define Q4_MAIN_CLOBBERS ' + clobbers(V_CLOBBER, S_CLOBBER) + '\n')
+        for var in VARIANTS:
+            f.write('#define Q4_MAIN_ASM_%d \\\n' % var + c_string(main_statement(var)).replace('\n', ' \\\n') + '\n')
+        f.write('#define Q4_MAIN_ASM_DBG \\\n' + c_string(main_statement(0, True)).replace('\n', ' \\\n') + '\n')
+        f.write('#define Q4_N_VARIANTS %d\n' % len(VARIANTS))
+        f.write('#define Q4_MAIN_CLOBBERS ' + clobbers(V_CLOBBER, S_CLOBBER, range(256)) + '\n')
         f.write('#define Q4_PROLOGUE_ASM \\\n' + c_string(prologue_statement()).replace('\n', ' \\\n') + '\n')
         f.write('#define Q4_PROLOGUE_CLOBBERS ' + clobbers([], list(range(36, 60))) + '\n')
     print('wrote', os.path.normpath(path))

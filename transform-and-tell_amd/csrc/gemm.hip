@@ -1557,8 +1557,10 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
           // box A/B): RoBERTa layer GEMMs alone 442-444 -> 436 us; configs[2] 1500 / 1506 samples/s without, 1524 / 1526 with
           // (in-step launch 148-157 -> 122-139 us).  TELL_GEMM_PP2=0: one workgroup per tile (gemm_nt_pp_kernel), 1: only
           // launches of two rounds or more.
-          // four waves x 128x128, hand-placed K loop (gemm_q4.hip): TELL_GEMM_Q4=1
-          static const int q4_env = getenv("TELL_GEMM_Q4") ? atoi(getenv("TELL_GEMM_Q4")) : 0;
+          // four waves x 128x128, hand-placed K loop (gemm_q4.hip) - the default since round 4.  MEASURED (MI355X, interleaved
+          // inside one process, M = 16384): RoBERTa layer GEMMs 419-422 us (ping-pong) -> 364-365 us: qkv 968 -> 1124 TFLOP/s,
+          // out 922 -> 993, fc1 + GELU 855 -> 1036, fc2 1197 -> 1313 (tools/probes/q4_variants.py).  TELL_GEMM_Q4=0: ping-pong.
+          const int q4_env = getenv("TELL_GEMM_Q4") ? atoi(getenv("TELL_GEMM_Q4")) : 1;   // (per launch: A/B inside one process)
           if (q4_env && (force == 0 || force == 8) && a.K % 128 == 0 && a.K >= 128 && a.K / 64 < 65536 && a.lda % 8 == 0 && a.ldb % 8 == 0 && !a.conv_zero &&
               a.act <= 2 && (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0 &&
               256L * a.lda * 2 < (1L << 31) && 256L * a.ldb * 2 < (1L << 31)) {

@@ -3,64 +3,154 @@
 // site of the reference is tell/models/transformer_faces_objects.py:352-353).
 //
 // Round 4's answer to "the two LDS consumers of the ping-pong kernel collide" (DESIGN 3): FOUR waves own 128x128 of the
-// tile each (16 v_mfma_f32_32x32x16_bf16 accumulators = 256 AGPRs per lane, one wave per SIMD), which cuts the fragment
-// reads from 192 KB to 128 KB per K tile, and the whole K loop is ONE hand-placed instruction stream
+// tile each (16 v_mfma_f32_32x32x16_bf16 accumulators = all 256 AGPRs of a lane, one wave per SIMD), which cuts the
+// fragment reads from 192 KB to 128 KB per K tile, and the whole K loop is ONE hand-placed instruction stream
 // (gemm_q4_loop.inc, written by tools/gen_q4_loop.py - read its header for the schedule): one LDS read or one
 // LDS-DMA instruction per MFMA gap, four barriers per K tile, the DMA stream two K tiles ahead in two LDS buffers and
 // running on across output-tile boundaries (resident workgroups as in gemm_pp2.hip: the first two K tiles of the next
-// output tile land while the epilogue runs).  The epilogue stores straight from registers: with the row mapping of the
-// LDS image a lane owns 8 consecutive output columns per 16-byte store, and a store instruction costs its ~70 clk per CU
-// whether its lanes cover whole lines or not - no LDS staging, no barriers.
+// output tile land while the epilogue runs).  Accumulators are PHYSICAL registers a[0:255] (clobbers of the statement):
+// the epilogue fetches them eight at a time with v_accvgpr_read just before use - as "=a" operands hipcc copied all 256
+// into VGPRs right behind the loop (and spilled).  The epilogue stores straight from registers: with the row mapping of
+// the LDS image a lane owns 8 consecutive output columns per 16-byte store, and a store instruction costs its ~70 clk
+// per CU whether its lanes cover whole lines or not - no LDS staging, no barriers.
+// PMC (profiles/r04_pmc_gemm_lds.txt, RoBERTa's four shapes): SQ_LDS_BANK_CONFLICT 590 k -> 0 per launch, SQ_LDS_IDX_ACTIVE
+// 10.9 M -> 6.3 M, matrix pipes busy 54 % -> 64 % of wave cycles.
 #include "gemm_common.h"
 #include "gemm_q4_loop.inc"
+#include <utility>
 
 namespace {
 constexpr int QBM = 256, QBN = 256, QBK = 64;
 
-template <int ACT>
-__device__ __forceinline__ void q4_store(f32x16 (&acc)[4][4], const GemmArgs& p, int m0, int n0, int w_r, int w_c, int lane) {
+template <typename F, int... Is>
+__device__ __forceinline__ void q4_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void q4_static_for(F&& f) {
+  q4_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+typedef __attribute__((ext_vector_type(8))) float f32x8_t;
+// gemm_common.h's exact-erf GELU (Abramowitz-Stegun 7.1.28) on the EIGHT values of a 16-byte store at once: four independent
+// v_pk_* chains that the scheduler interleaves - one pair at a time the 14 dependent packed operations (each with its
+// wait state) ran back to back with nothing between them
+__device__ __forceinline__ f32x8_t q4_gelu8(f32x8_t v) {
+  const f32x8_t av = __builtin_elementwise_abs(v);
+  const f32x8_t x = av * 0.70710678118654752f;
+  f32x8_t q = x * 0.0000430638f + 0.0002765672f;
+  q = q * x + 0.0001520143f;
+  q = q * x + 0.0092705272f;
+  q = q * x + 0.0422820123f;
+  q = q * x + 0.0705230784f;
+  q = q * x + 1.f;
+  q *= q; q *= q; q *= q; q *= q;
+  f32x8_t e;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) e[k] = __builtin_amdgcn_rcpf(q[k]);
+  const f32x8_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  return (av * -0.5f) * e + __builtin_elementwise_max(v, zero);
+}
+
+// the 8 accumulator values behind one 16-byte store: acc[I][j][2 Q + t], j = 0..3, t = 0, 1 (a[16 (4 I + j) + 2 Q + t])
+template <int I, int Q> __device__ __forceinline__ void q4_read8(float (&v)[8]) {
+  asm volatile(
+      "v_accvgpr_read_b32 %0, a[%c8]\n\tv_accvgpr_read_b32 %1, a[%c9]\n\tv_accvgpr_read_b32 %2, a[%c10]\n\t"
+      "v_accvgpr_read_b32 %3, a[%c11]\n\tv_accvgpr_read_b32 %4, a[%c12]\n\tv_accvgpr_read_b32 %5, a[%c13]\n\t"
+      "v_accvgpr_read_b32 %6, a[%c14]\n\tv_accvgpr_read_b32 %7, a[%c15]"
+      : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(v[4]), "=v"(v[5]), "=v"(v[6]), "=v"(v[7])
+      : "i"(16 * (4 * I + 0) + 2 * Q), "i"(16 * (4 * I + 0) + 2 * Q + 1), "i"(16 * (4 * I + 1) + 2 * Q),
+        "i"(16 * (4 * I + 1) + 2 * Q + 1), "i"(16 * (4 * I + 2) + 2 * Q), "i"(16 * (4 * I + 2) + 2 * Q + 1),
+        "i"(16 * (4 * I + 3) + 2 * Q), "i"(16 * (4 * I + 3) + 2 * Q + 1));
+}
+
+// Output mapping (tools/gen_q4_loop.py): lane (r = lane & 31, h = lane >> 5) of wave (w_r, w_c) owns for X fragment i the
+// row m = 128 w_r + 8 (r >> 1) + 2 i + (r & 1) and, per (q = e >> 1), the 8 columns 128 w_c + 8 G .. + 7 with
+// G = 4 (q >> 1) + 2 (q & 1) + h: column 8 G + 2 j + t holds acc[i][j][2 q + t].
+// Arithmetic per value: ONE fused multiply-add  acc * alpha + bias'  (bias' = bias * alpha, per column - BROW false - or
+// per row), two values per v_pk_fma_f32; with the 8 v_accvgpr_read and 4 v_cvt_pk_bf16_f32 that is 16 VALU issues per
+// 16-byte store (the first version spent 34: separate add / multiply per value, and measured 5 us of arithmetic per tile).
+template <int ACT, bool BROW, int ABL>
+__device__ __forceinline__ void q4_store(const GemmArgs& p, int m0, int n0, int w_r, int w_c, int lane) {
   const int r = lane & 31, h = lane >> 5;
-  const int nb = n0 + 128 * w_c;
-  f32x4_t b4[8][2];
-  float bm[4];
+  const int nb = n0 + 128 * w_c + 8 * h;
+  const float alpha = p.alpha;
+  const f32x2e_t alpha2 = {alpha, alpha};
+  f32x2e_t b2[8][4];                                       // BROW false: bias' of the lane's 64 columns
+  float bm[4];                                             // BROW true: bias' of the lane's 4 rows
+  if constexpr (!BROW) {
+    if (p.bias_mode == 1) {
 #pragma unroll
-  for (int q = 0; q < 8; ++q) { b4[q][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; b4[q][1] = b4[q][0]; }
+      for (int q = 0; q < 8; ++q) {
+        const int G8 = 16 * (q & 1) + 32 * (q >> 1);
+        const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(p.bias + nb + G8);
+        const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(p.bias + nb + G8 + 4);
+        b2[q][0] = f32x2e_t{lo[0], lo[1]} * alpha2; b2[q][1] = f32x2e_t{lo[2], lo[3]} * alpha2;
+        b2[q][2] = f32x2e_t{hi[0], hi[1]} * alpha2; b2[q][3] = f32x2e_t{hi[2], hi[3]} * alpha2;
+      }
+    } else {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) bm[i] = 0.f;
-  if (p.bias_mode == 1) {
+      for (int q = 0; q < 8; ++q)
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int G = (q & 1) + 4 * (q >> 1) + 2 * h;
-      b4[q][0] = *reinterpret_cast<const f32x4_t*>(p.bias + nb + 8 * G);
-      b4[q][1] = *reinterpret_cast<const f32x4_t*>(p.bias + nb + 8 * G + 4);
+        for (int k = 0; k < 4; ++k) b2[q][k] = f32x2e_t{0.f, 0.f};
     }
-  } else if (p.bias_mode == 2) {
+  } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bm[i] = p.bias[m0 + 128 * w_r + 8 * (r >> 1) + 2 * i + (r & 1)];
+    for (int i = 0; i < 4; ++i) bm[i] = p.bias[m0 + 128 * w_r + 8 * (r >> 1) + 2 * i + (r & 1)] * alpha;
   }
   uint16_t* C = static_cast<uint16_t*>(p.C);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + 128 * w_r + 8 * (r >> 1) + 2 * i + (r & 1);
+  q4_static_for<4>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int I = decltype(ic)::value;
+    const int m = m0 + 128 * w_r + 8 * (r >> 1) + 2 * I + (r & 1);
     uint16_t* crow = C + (long)m * p.ldc + nb;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int G = (q & 1) + 4 * (q >> 1) + 2 * h;
+    q4_static_for<8>([&](auto qc) __attribute__((always_inline)) {
+      constexpr int Q = decltype(qc)::value;
+      constexpr int G8 = 16 * (Q & 1) + 32 * (Q >> 1);
+      float a8[8];
+      q4_read8<I, Q>(a8);
       u32x4 o;
+      f32x8_t v;                                           // columns G8 + 2 k + t: acc[I][k][2 Q + t]
 #pragma unroll
-      for (int jp = 0; jp < 2; ++jp) {                   // columns 8 G + 4 jp .. + 3: (j = 2 jp, 2 jp + 1) x (e & 1)
-        f32x4_t v = {acc[i][2 * jp][2 * q], acc[i][2 * jp][2 * q + 1], acc[i][2 * jp + 1][2 * q], acc[i][2 * jp + 1][2 * q + 1]};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (v[e] + b4[q][jp][e] + bm[i]) * p.alpha;
-        epi_act4<ACT>(v);
-        o[2 * jp] = pack2_bf16(v[0], v[1]);
-        o[2 * jp + 1] = pack2_bf16(v[2], v[3]);
+      for (int k = 0; k < 4; ++k) {
+        f32x2e_t w = {a8[2 * k], a8[2 * k + 1]};
+        if constexpr (BROW) w = __builtin_elementwise_fma(w, alpha2, f32x2e_t{bm[I], bm[I]});
+        else w = __builtin_elementwise_fma(w, alpha2, b2[Q][k]);
+        v[2 * k] = w[0]; v[2 * k + 1] = w[1];
       }
-      *reinterpret_cast<u32x4*>(crow + 8 * G) = o;
+      if constexpr (ACT == 1) v = __builtin_elementwise_max(v, f32x8_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
+      else if constexpr (ACT == 2) v = q4_gelu8(v);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = pack2_bf16(v[2 * k], v[2 * k + 1]);
+      if (ABL != 2 || o[0] == 0x12345678u) *reinterpret_cast<u32x4*>(crow + G8) = o;
+    });
+  });
+}
+template <int ABL>
+__device__ __forceinline__ void q4_epilogue(const GemmArgs& p, int m0, int n0, int w_r, int w_c, int lane) {
+  if (p.bias_mode == 2) {                                  // block-uniform
+    switch (p.act) {
+      case 1: q4_store<1, true, ABL>(p, m0, n0, w_r, w_c, lane); break;
+      case 2: q4_store<2, true, ABL>(p, m0, n0, w_r, w_c, lane); break;
+      default: q4_store<0, true, ABL>(p, m0, n0, w_r, w_c, lane); break;
+    }
+  } else {
+    switch (p.act) {
+      case 1: q4_store<1, false, ABL>(p, m0, n0, w_r, w_c, lane); break;
+      case 2: q4_store<2, false, ABL>(p, m0, n0, w_r, w_c, lane); break;
+      default: q4_store<0, false, ABL>(p, m0, n0, w_r, w_c, lane); break;
     }
   }
 }
 
+#define Q4_RUN_MAIN(TEXT)                                                                                             \
+  asm volatile(TEXT                                                                                                   \
+               :                                                                                                      \
+               : "v"(xrd), "v"(wrd), "v"(xvo), "v"(wvo), "s"(xc), "s"(wc), "s"(xn), "s"(wn), "s"(lda32), "s"(ldb32),  \
+                 "s"(nkf), "s"(dstw)                                                                                  \
+               : Q4_MAIN_CLOBBERS)
+
+// VAR: schedule variant of the K loop (tools/gen_q4_loop.py VARIANTS); ABL: timing probes with wrong results (1: no
+// epilogue at all, 2: epilogue arithmetic without the global stores)
+template <int VAR, int ABL>
 __global__ __launch_bounds__(256) void gemm_nt_q4_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * Q4_BUF + 64];
   gemm_ts_enter(p);
@@ -88,7 +178,12 @@ __global__ __launch_bounds__(256) void gemm_nt_q4_kernel(GemmArgs p) {
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   const int r = lane & 31, h = lane >> 5;
   const unsigned xrd = lds0 + (16 * w_r + (r >> 1)) * Q4_PIECE + (r & 1) * 128 + h * 16;
-  const unsigned wrd = lds0 + Q4_OPER + (16 * w_c + (r >> 1)) * Q4_PIECE + (r & 1) * 128 + h * 16;
+  // W rows: bits 0 and 1 of the piece index swapped, so that the two half-waves of a lane pair own ADJACENT 16-byte column
+  // groups (G = 4 (q >> 1) + 2 (q & 1) + h): a store instruction then writes 32 rows x 32 contiguous bytes instead of
+  // 64 separate 16-byte pieces (the reads stay conflict-free: the 16 lanes of a ds_read_b128 group still cover 8 pieces
+  // x 2 row parities)
+  const int rp = ((r >> 1) & ~3) | (((r >> 1) & 1) << 1) | (((r >> 1) >> 1) & 1);
+  const unsigned wrd = lds0 + Q4_OPER + (16 * w_c + rp) * Q4_PIECE + (r & 1) * 128 + h * 16;
   const unsigned xvo = (unsigned)((8 * wave + (lane >> 3)) * (int)p.lda * 2 + (lane & 7) * 16);
   const unsigned wvo = (unsigned)((8 * wave + (lane >> 3)) * (int)p.ldb * 2 + (lane & 7) * 16);
   const unsigned lda32 = (unsigned)p.lda * 64u, ldb32 = (unsigned)p.ldb * 64u;     // bytes per 32 rows
@@ -96,7 +191,8 @@ __global__ __launch_bounds__(256) void gemm_nt_q4_kernel(GemmArgs p) {
 
   int vb = blockIdx.x;
   if (vb >= n_tiles) return;
-  int m0, n0;
+  int m0, n0, tile_no = 0;
+  (void)tile_no;
   tile_origin(vb, m0, n0);
   {
     const unsigned long long x0 = reinterpret_cast<unsigned long long>(A + (long)m0 * p.lda);
@@ -116,19 +212,28 @@ __global__ __launch_bounds__(256) void gemm_nt_q4_kernel(GemmArgs p) {
     const unsigned long long xn = reinterpret_cast<unsigned long long>(A + (long)m1 * p.lda);
     const unsigned long long wn = reinterpret_cast<unsigned long long>(B + (long)n1 * p.ldb);
     const unsigned nkf = (unsigned)nk | (has_next ? 0x10000u : 0u);
-    f32x16 acc[4][4];
-    asm volatile(Q4_MAIN_ASM
-                 : "=&a"(acc[0][0]), "=&a"(acc[0][1]), "=&a"(acc[0][2]), "=&a"(acc[0][3]),
-                   "=&a"(acc[1][0]), "=&a"(acc[1][1]), "=&a"(acc[1][2]), "=&a"(acc[1][3]),
-                   "=&a"(acc[2][0]), "=&a"(acc[2][1]), "=&a"(acc[2][2]), "=&a"(acc[2][3]),
-                   "=&a"(acc[3][0]), "=&a"(acc[3][1]), "=&a"(acc[3][2]), "=&a"(acc[3][3])
-                 : "v"(xrd), "v"(wrd), "v"(xvo), "v"(wvo), "s"(xc), "s"(wc), "s"(xn), "s"(wn), "s"(lda32), "s"(ldb32),
-                   "s"(nkf), "s"(dstw)
-                 : Q4_MAIN_CLOBBERS);
-    switch (p.act) {                                       // block-uniform
-      case 1: q4_store<1>(acc, p, m0, n0, w_r, w_c, lane); break;
-      case 2: q4_store<2>(acc, p, m0, n0, w_r, w_c, lane); break;
-      default: q4_store<0>(acc, p, m0, n0, w_r, w_c, lane); break;
+    if constexpr (ABL == 3) {                              // instrumented: s_memtime stamps of wave 0 into p.aux
+      unsigned long long* dbg = const_cast<unsigned long long*>(static_cast<const unsigned long long*>(p.aux));
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      unsigned long long ta, tb;
+      asm volatile(Q4_MAIN_ASM_DBG
+                   : "=&s"(ta), "=&s"(tb)
+                   : "v"(xrd), "v"(wrd), "v"(xvo), "v"(wvo), "s"(xc), "s"(wc), "s"(xn), "s"(wn), "s"(lda32), "s"(ldb32),
+                     "s"(nkf), "s"(dstw)
+                   : Q4_MAIN_CLOBBERS);
+      const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+      q4_epilogue<0>(p, m0, n0, w_r, w_c, lane);
+      const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+      if (dbg && tid == 0 && blockIdx.x < 256 && tile_no < 8) {
+        unsigned long long* d = dbg + ((long)blockIdx.x * 8 + tile_no) * 8;
+        d[0] = t0; d[1] = ta; d[2] = tb; d[3] = t1; d[4] = t2;
+      }
+      ++tile_no;
+    } else {
+      if constexpr (VAR == 1) Q4_RUN_MAIN(Q4_MAIN_ASM_1);
+      else if constexpr (VAR == 2) Q4_RUN_MAIN(Q4_MAIN_ASM_2);
+      else Q4_RUN_MAIN(Q4_MAIN_ASM_0);
+      if constexpr (ABL != 1) q4_epilogue<ABL>(p, m0, n0, w_r, w_c, lane);
     }
     if (!has_next) break;
     vb = nvb; m0 = m1; n0 = n1;
@@ -141,6 +246,14 @@ __global__ __launch_bounds__(256) void gemm_nt_q4_kernel(GemmArgs p) {
 int launch_gemm_q4(const GemmArgs& a, hipStream_t stream, int n_cu) {
   const int n_tiles = (a.M / QBM) * (a.N / QBN);
   const unsigned grid = (unsigned)(n_tiles < n_cu ? n_tiles : n_cu);
-  hipLaunchKernelGGL(gemm_nt_q4_kernel, dim3(grid), dim3(256), 0, stream, a);
+  // (read per launch: tools/probes/q4_variants.py switches them inside one process)
+  const int var = getenv("TELL_Q4_VAR") ? atoi(getenv("TELL_Q4_VAR")) : 0;
+  const int abl = getenv("TELL_Q4_ABL") ? atoi(getenv("TELL_Q4_ABL")) : 0;   // timing probes (1, 2: wrong results; 3: stamps into aux)
+  if (abl == 3) hipLaunchKernelGGL((gemm_nt_q4_kernel<0, 3>), dim3(grid), dim3(256), 0, stream, a);
+  else if (abl == 1) hipLaunchKernelGGL((gemm_nt_q4_kernel<0, 1>), dim3(grid), dim3(256), 0, stream, a);
+  else if (abl == 2) hipLaunchKernelGGL((gemm_nt_q4_kernel<0, 2>), dim3(grid), dim3(256), 0, stream, a);
+  else if (var == 1) hipLaunchKernelGGL((gemm_nt_q4_kernel<1, 0>), dim3(grid), dim3(256), 0, stream, a);
+  else if (var == 2) hipLaunchKernelGGL((gemm_nt_q4_kernel<2, 0>), dim3(grid), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_nt_q4_kernel<0, 0>), dim3(grid), dim3(256), 0, stream, a);
   return tell_check_launch("gemm_nt_q4");
 }
