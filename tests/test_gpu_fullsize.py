@@ -344,6 +344,7 @@ def _sharpened_eos(sd, factor):
         if (k.endswith('adaptive_softmax.head.word_proj.weight') or k.endswith('embed_tokens.embeddings.0.weight') or
                 k.endswith('embedders.adaptive.embeddings.0.weight')) and v.data_ptr() not in done:
             v[2] *= factor
+            v[1] = 0.0                                  # pad is never the arg-max (a trained model never emits it; its embedding row is zero in fairseq)
             done.add(v.data_ptr())
     return sd
 
@@ -358,7 +359,7 @@ def test_full_size_greedy_at_bench_batch_with_early_eos_bit_exact_fp32():
     from tell_amd.build import build_decoder
     BB, GEN = 32, 12
     o = _oracle('faces_objects')
-    sd = _sharpened_eos(o['sd'], 3.0)
+    sd = _sharpened_eos(o['sd'], 12.0)          # (measured on the oracle: about one row in five ends within 12 steps)
     ref = obuild('faces_objects').eval()
     ref.load_state_dict({k: v for k, v in sd.items() if k in ref.state_dict()}, strict=False)
     ctx, start = _inputs_batch(BB, seed=41)
@@ -376,7 +377,7 @@ def test_full_size_greedy_at_bench_batch_with_early_eos_bit_exact_fp32():
     first = torch.where(ended, (want == 2).float().argmax(1), torch.full((BB,), want.shape[1]))
     print('\nfull-size fp32 greedy at B=32: %d of %d rows end early (first </s> at steps %s), %d steps run'
           % (int(ended.sum()), BB, sorted(set(first[ended].tolist())), got.shape[1]))
-    assert 4 <= int(ended.sum()) and len(set(first.tolist())) >= 3, first         # genuinely ragged
+    assert 3 <= int(ended.sum()) < BB and len(set(first.tolist())) >= 3, first    # genuinely ragged
     n = min(got.shape[1], want.shape[1])
     assert torch.equal(got[:, :n], want[:, :n]), (got, want)
     assert (got[:, n:] == 1).all() and (want[:, n:] == 1).all()

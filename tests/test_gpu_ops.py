@@ -249,14 +249,18 @@ def test_gemm_kernel_variants_behind_switches(env):
     assert want in r.stdout, r.stdout[-2000:]
 
 
-@pytest.mark.parametrize('env', [{}, {'TELL_GEMM_TILE': '8'}, {'TELL_Q4_VAR': '1'}, {'TELL_Q4_VAR': '2'}],
-                         ids=['default', 'partial-rounds', 'schedule-1', 'schedule-2'])
+@pytest.mark.parametrize('env', [{}, {'TELL_GEMM_TILE': '8'}, {'TELL_Q4_DYNAMIC': '1'}, {'TELL_GEMM_Q4E': '2'},
+                                 {'TELL_GEMM_Q4E': '2', 'TELL_Q4_DYNAMIC': '1'}, {'TELL_GEMM_Q4E': '0', 'TELL_Q4_VAR': '1'},
+                                 {'TELL_GEMM_Q4E': '0', 'TELL_Q4_VAR': '2'}],
+                         ids=['default', 'partial-rounds', 'tile-queue', 'q4e-everywhere', 'q4e-tile-queue', 'schedule-1', 'schedule-2'])
 def test_gemm_q4_kernel(env):
     """gemm_nt_q4_kernel (csrc/gemm_q4.hip: four waves of 128x128, hand-placed K loop - the default for whole rounds of
     256x256 bf16 tiles with K % 128 == 0) through tools/probes/q4_check.py: 2 to 64 K tiles (first / steady-state / last
     body of the generated stream), 1 to 4 output tiles per resident workgroup incl. a last round with fewer tiles than
     workgroups (forced), every epilogue form, strided operands and output, repeated launches bit-identical; the
-    alternative instruction schedules kept behind TELL_Q4_VAR."""
+    alternative instruction schedules kept behind TELL_Q4_VAR; gemm_nt_q4e_kernel (csrc/gemm_q4e.hip: the previous tile's
+    epilogue inside the K loop; default for act 0 / 1 with per-column bias and >= 2 tiles per workgroup, everywhere it
+    applies - also with GELU and one tile per workgroup - under TELL_GEMM_Q4E=2); per-XCD tile counters (TELL_Q4_DYNAMIC=1)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     e = dict(os.environ); e.update(env)

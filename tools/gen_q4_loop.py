@@ -95,7 +95,7 @@ def soff_setup(lda_op, ldb_op):
 VARIANTS = (0, 1, 2)
 
 
-def body(first, last, var=0):
+def body(first, last, var=0, extra=None):
     ev = {}
 
     def at(p, *ins):
@@ -157,6 +157,8 @@ def body(first, last, var=0):
        's_cselect_b32 s%d, s%d, s%d' % (S_SRDW, S_WN, S_SRDW), 's_cselect_b32 s%d, s%d, s%d' % (S_SRDW + 1, S_WN + 1, S_SRDW + 1),
        's_cselect_b32 s%d, s%d, s%d' % (S_SRDW + 2, S_NREC, S_SRDW + 2))
     at(63, 's_xor_b32 s%d, s%d, s%d' % (S_DSTX, S_DSTX, S_TOGX), 's_xor_b32 s%d, s%d, s%d' % (S_DSTW, S_DSTW, S_TOGW))
+    for p_, ins in (extra or {}).items():                   # (gen_q4e_loop.py: deferred stores, the bias DMA)
+        ev.setdefault(p_, []).extend(ins)
     out = ['s_waitcnt lgkmcnt(0)']
     for m in range(64):
         kh, q = m // 32, m % 32

@@ -1564,7 +1564,19 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
           if (q4_env && (force == 0 || force == 8) && a.K % 128 == 0 && a.K >= 128 && a.K / 64 < 65536 && a.lda % 8 == 0 && a.ldb % 8 == 0 && !a.conv_zero &&
               a.act <= 2 && (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0 &&
               256L * a.lda * 2 < (1L << 31) && 256L * a.ldb * 2 < (1L << 31)) {
-            if (g_gemm_plan) { (void)gemm_label("gemm_nt_q4_kernel", -1, 1, 256, 256); return TELL_OK; }
+            // epilogue inside the next tile's K loop (gemm_q4e.hip): per-column bias, K >= 576.  TELL_GEMM_Q4E=0: plain q4
+            const int q4e_env = getenv("TELL_GEMM_Q4E") ? atoi(getenv("TELL_GEMM_Q4E")) : 1;
+            // MEASURED (static tile lists, M = 16384): qkv (3 tiles per workgroup) 90.2 -> 86.6 us; one tile per workgroup (out,
+            // fc2) has no next K loop to hide anything in; with GELU the in-asm drain is slower than hipcc's (fc1 130.5 -> 135.0):
+            // taken for act 0 / 1 with at least two tiles per workgroup (TELL_GEMM_Q4E=2: wherever it applies)
+            const bool q4e_ok = q4e_env && a.bias_mode == 1 && a.K / 64 >= 13 && 512L * a.ldc < (1L << 31) && tiles(256, 256) % n_cu == 0 &&
+                                (q4e_env == 2 || (a.act != 2 && tiles(256, 256) >= 2L * n_cu)) &&
+                                !(getenv("TELL_Q4_ABL") && atoi(getenv("TELL_Q4_ABL")));
+            if (g_gemm_plan) { (void)gemm_label(q4e_ok ? "gemm_nt_q4e_kernel" : "gemm_nt_q4_kernel", -1, 1, 256, 256); return TELL_OK; }
+            if (q4e_ok) {
+              const int rc = launch_gemm_q4e(a, stream, n_cu);
+              if (rc <= 0) return rc;
+            }
             return launch_gemm_q4(a, stream, n_cu);
           }
           static const int pp2_env = getenv("TELL_GEMM_PP2") ? atoi(getenv("TELL_GEMM_PP2")) : 2;

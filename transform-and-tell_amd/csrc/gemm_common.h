@@ -128,4 +128,6 @@ int launch_gemm_duo(const GemmArgs& a, hipStream_t stream);
 int launch_gemm_pp2(const GemmArgs& a, hipStream_t stream, int n_cu);
 // gemm_q4.hip: 256x256 tiles, four waves of 128x128, hand-placed K loop (round 4)
 int launch_gemm_q4(const GemmArgs& a, hipStream_t stream, int n_cu);
+// gemm_q4e.hip: the same K loop with the previous tile's epilogue inside it (-> 1: not a call it takes)
+int launch_gemm_q4e(const GemmArgs& a, hipStream_t stream, int n_cu);
 int* gemm_tile_queue_slot(int words, hipStream_t stream);    // gemm.hip: `words` zeroed tile counters for one launch, or NULL

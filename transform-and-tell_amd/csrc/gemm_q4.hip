@@ -30,6 +30,16 @@ template <int N, typename F> __device__ __forceinline__ void q4_static_for(F&& f
   q4_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
+// "s" operands of the asm statements must be PROVABLY wave-uniform: tile coordinates that went through the LDS broadcast of
+// the tile queue are not (to the compiler), so the operand values themselves are passed through v_readfirstlane
+__device__ __forceinline__ unsigned long long q4_uni64(unsigned long long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+template <typename T> __device__ __forceinline__ unsigned long long q4_ptr(const T* q) {
+  return q4_uni64(reinterpret_cast<unsigned long long>(q));
+}
+
 typedef __attribute__((ext_vector_type(8))) float f32x8_t;
 // gemm_common.h's exact-erf GELU (Abramowitz-Stegun 7.1.28) on the EIGHT values of a 16-byte store at once: four independent
 // v_pk_* chains that the scheduler interleaves - one pair at a time the 14 dependent packed operations (each with its
@@ -189,29 +199,60 @@ __global__ __launch_bounds__(256) void gemm_nt_q4_kernel(GemmArgs p) {
   const unsigned lda32 = (unsigned)p.lda * 64u, ldb32 = (unsigned)p.ldb * 64u;     // bytes per 32 rows
   const unsigned dstw = __builtin_amdgcn_readfirstlane(lds0 + wave * Q4_PIECE);
 
-  int vb = blockIdx.x;
+  // Tile order.  Static (p.queue == NULL): tiles b, b + grid, ...  Dynamic (as gemm_pp2.hip): one counter per XCD, workgroup b
+  // lives on XCD b & 7 and takes tiles k * 8 + (b & 7); a workgroup that gets its CU late inside the training step takes
+  // fewer tiles.  The K loop needs the NEXT tile when it starts (its last two bodies fetch that tile's operands), so the
+  // counter is read one tile further ahead than in gemm_pp2.hip: the fetch issued at the top of tile i names tile i + 2
+  // and is consumed behind the epilogue.  A workgroup stops fetching at its first out-of-range value, so a launch makes
+  // exactly per_x + wg_x fetches per XCD and the one that draws the last value zeroes the counter again.
+  const bool dyn = p.queue != nullptr;
+  const int xcd_id = blockIdx.x & 7, per_x = n_tiles >> 3, wg_x = (int)gridDim.x >> 3;
+  int* const qx = dyn ? p.queue + xcd_id : nullptr;
+  volatile int* sq = reinterpret_cast<volatile int*>(smem + 2 * Q4_BUF);
+  auto fetch = [&]() __attribute__((always_inline)) {      // thread 0 only
+    const int k = atomicAdd(qx, 1);
+    if (k == per_x + wg_x - 1) atomicExch(qx, 0);
+    return k;
+  };
+  auto share = [&](int k) __attribute__((always_inline)) { // thread 0's value to the workgroup
+    if (tid == 0) *sq = k;
+    __syncthreads();
+    const int v = __builtin_amdgcn_readfirstlane(*sq);      // (an LDS read is not provably wave-uniform: "s" operands need this)
+    __syncthreads();
+    return v;
+  };
+  int vb = blockIdx.x, nvb = vb + (int)gridDim.x;
+  if (dyn) {
+    const int k0 = share(tid == 0 ? fetch() : 0);
+    vb = k0 < per_x ? k0 * 8 + xcd_id : n_tiles;
+  }
   if (vb >= n_tiles) return;
   int m0, n0, tile_no = 0;
   (void)tile_no;
   tile_origin(vb, m0, n0);
   {
-    const unsigned long long x0 = reinterpret_cast<unsigned long long>(A + (long)m0 * p.lda);
-    const unsigned long long w0 = reinterpret_cast<unsigned long long>(B + (long)n0 * p.ldb);
+    const unsigned long long x0 = q4_ptr(A + (long)m0 * p.lda);
+    const unsigned long long w0 = q4_ptr(B + (long)n0 * p.ldb);
     asm volatile(Q4_PROLOGUE_ASM
                  :
                  : "v"(xvo), "v"(wvo), "s"(x0), "s"(w0), "s"(lda32), "s"(ldb32), "s"(dstw)
                  : Q4_PROLOGUE_CLOBBERS);
   }
+  if (dyn) {                                               // (its round trip overlaps the first operand round trip)
+    const int k1 = share(tid == 0 ? fetch() : 0);
+    nvb = k1 < per_x ? k1 * 8 + xcd_id : n_tiles;
+  }
   for (;;) {
-    const int nvb = vb + (int)gridDim.x;
     const bool has_next = nvb < n_tiles;
+    int kq = 0;
+    if (dyn && has_next && tid == 0) kq = fetch();         // names the tile after the next one; consumed behind the epilogue
     int m1 = m0, n1 = n0;
     if (has_next) tile_origin(nvb, m1, n1);
-    const unsigned long long xc = reinterpret_cast<unsigned long long>(A + (long)m0 * p.lda + 2 * QBK);
-    const unsigned long long wc = reinterpret_cast<unsigned long long>(B + (long)n0 * p.ldb + 2 * QBK);
-    const unsigned long long xn = reinterpret_cast<unsigned long long>(A + (long)m1 * p.lda);
-    const unsigned long long wn = reinterpret_cast<unsigned long long>(B + (long)n1 * p.ldb);
-    const unsigned nkf = (unsigned)nk | (has_next ? 0x10000u : 0u);
+    const unsigned long long xc = q4_ptr(A + (long)m0 * p.lda + 2 * QBK);
+    const unsigned long long wc = q4_ptr(B + (long)n0 * p.ldb + 2 * QBK);
+    const unsigned long long xn = q4_ptr(A + (long)m1 * p.lda);
+    const unsigned long long wn = q4_ptr(B + (long)n1 * p.ldb);
+    const unsigned nkf = __builtin_amdgcn_readfirstlane((unsigned)nk | (has_next ? 0x10000u : 0u));
     if constexpr (ABL == 3) {                              // instrumented: s_memtime stamps of wave 0 into p.aux
       unsigned long long* dbg = const_cast<unsigned long long*>(static_cast<const unsigned long long*>(p.aux));
       const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -237,15 +278,27 @@ __global__ __launch_bounds__(256) void gemm_nt_q4_kernel(GemmArgs p) {
     }
     if (!has_next) break;
     vb = nvb; m0 = m1; n0 = n1;
+    if (dyn) {
+      const int k2 = share(kq);
+      nvb = k2 < per_x ? k2 * 8 + xcd_id : n_tiles;
+    } else {
+      nvb = vb + (int)gridDim.x;
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (no LDS-DMA may outlive the workgroup)
   gemm_ts_exit(p);
 }
 }  // namespace
 
-int launch_gemm_q4(const GemmArgs& a, hipStream_t stream, int n_cu) {
-  const int n_tiles = (a.M / QBM) * (a.N / QBN);
+int launch_gemm_q4(const GemmArgs& a_in, hipStream_t stream, int n_cu) {
+  const int n_tiles = (a_in.M / QBM) * (a_in.N / QBN);
   const unsigned grid = (unsigned)(n_tiles < n_cu ? n_tiles : n_cu);
+  // per-XCD tile counters for launches of more than one round (TELL_Q4_DYNAMIC=0: static tile lists)
+  const int dyn_env = getenv("TELL_Q4_DYNAMIC") ? atoi(getenv("TELL_Q4_DYNAMIC")) : 0;
+  GemmArgs ad = a_in;
+  ad.queue = nullptr;
+  if (dyn_env && n_tiles > (int)grid && grid % 8 == 0 && n_tiles % 8 == 0) ad.queue = gemm_tile_queue_slot(8, stream);
+  const GemmArgs& a = ad;
   // (read per launch: tools/probes/q4_variants.py switches them inside one process)
   const int var = getenv("TELL_Q4_VAR") ? atoi(getenv("TELL_Q4_VAR")) : 0;
   const int abl = getenv("TELL_Q4_ABL") ? atoi(getenv("TELL_Q4_ABL")) : 0;   // timing probes (1, 2: wrong results; 3: stamps into aux)
