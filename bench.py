@@ -314,7 +314,7 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
         achieved = d['work'] / (d['total_ms'] * 1e-3) / 1e12
         peak = 2500.0 if 'bf16' in name.split(',')[0] else 157.3
         traffic, tnote = None, None
-        for fn in ('r03_pmc_gemm_traffic.json', 'r01_pmc_gemm_traffic.json'):
+        for fn in ('r04_pmc_gemm_traffic.json', 'r03_pmc_gemm_traffic.json', 'r01_pmc_gemm_traffic.json'):
             pmc = os.path.join(ROOT, 'profiles', fn)
             if os.path.exists(pmc):      # HBM bytes per launch of this kernel from the committed PMC passes
                 j = json.load(open(pmc))
@@ -531,7 +531,7 @@ def generate_bench(args, dev, world, rank, dist):
     step_us = 1e3 * dec_ms / max(n_steps, 1)
     tbs = (w_bytes + kv_bytes) / (step_us * 1e-6) / 1e12
     traffic, tnote = None, None
-    pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_generate_%s_traffic.json' % ('beam%d' % beam if beam > 1 else 'greedy'))
+    pmc = os.path.join(ROOT, 'profiles', 'r04_pmc_generate_%s_traffic.json' % ('beam%d' % beam if beam > 1 else 'greedy'))
     if os.path.exists(pmc) and B == 32:          # HBM bytes of one captured decode step from the committed PMC passes
         traffic = json.load(open(pmc))['traffic_bytes_per_step']
         tnote = 'bytes per decode step, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE summed over the ' \

@@ -180,6 +180,35 @@ def test_shards_reader_and_batch_contract(tmp_path):
     assert sum(b['context']['roberta'].shape[0] for b in b2) == 8          # the cursor continues (3 left + 5 new)
 
 
+def test_many_live_shards_hold_one_descriptor_each(tmp_path):
+    """A validation / test pass keeps every instance of the split alive (BucketIterator materialises list(it)): views of
+    more than 400 memory-mapped shards at once under RLIMIT_NOFILE = 256 - one mapping, and no lingering descriptor, per
+    shard (three np.memmap objects per shard died here with EMFILE 'Too many open files')."""
+    import resource
+    import numpy as np
+    from tell_amd.data import shards
+    rng = np.random.RandomState(0)
+    base = dict(context_ids=[0, 5, 6, 2], caption_ids=[0, 7, 2], image=np.zeros((224, 224, 3), np.uint8),
+                face_embeds=rng.rand(1, 512).astype(np.float32), obj_embeds=rng.rand(2, 2048).astype(np.float32), metadata={})
+    first = str(tmp_path / 'test-00000.npz')
+    shards.write_shard(first, [base])
+    import shutil
+    for i in range(1, 420):
+        shutil.copyfile(first, str(tmp_path / ('test-%05d.npz' % i)))
+    soft, hard = resource.getrlimit(resource.RLIMIT_NOFILE)
+    resource.setrlimit(resource.RLIMIT_NOFILE, (256, hard))
+    try:
+        live = []
+        for path in shards.shard_paths(str(tmp_path), 'test'):
+            live.extend(shards.read_shard(path))
+        assert len(live) == 420
+        assert all(isinstance(s['image'].base, (np.ndarray, np.memmap)) or s['image'].base is not None for s in live)
+        assert float(live[-1]['obj_embeds'].sum()) == float(np.asarray(base['obj_embeds']).sum())
+        assert live[7]['context_ids'].tolist() == [0, 5, 6, 2]
+    finally:
+        resource.setrlimit(resource.RLIMIT_NOFILE, (soft, hard))
+
+
 def test_reader_limits_faces_to_caption_person_names(tmp_path):
     """nytimes_faces_ner_matched.py:125-130,168-170: n_faces wins; else with use_caption_names the number of PERSON names
     in the caption (recorded by the shard writer as n_person_names) limits the faces - 0 names = the empty field; a

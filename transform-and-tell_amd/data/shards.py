@@ -55,14 +55,44 @@ def shard_paths(directory, split):
     return sorted(glob.glob(os.path.join(directory, '%s-*.npz' % split)))
 
 
+def _map_file(path):
+    """Read-only mapping of a whole file as a uint8 array that pins NO file descriptor: np.memmap / mmap.mmap keep a
+    duplicated descriptor for the life of the mapping, so every live shard cost one; libc's mmap keeps the pages after
+    close().  The mapping is released when the last view of the returned array dies."""
+    import ctypes
+    import mmap as _mmap
+    import weakref
+    size = os.path.getsize(path)
+    libc = ctypes.CDLL(None, use_errno=True)
+    libc.mmap.restype = ctypes.c_void_p
+    libc.mmap.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long]
+    libc.munmap.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        addr = libc.mmap(None, size, _mmap.PROT_READ, _mmap.MAP_PRIVATE, fd, 0)
+    finally:
+        os.close(fd)
+    if addr in (None, ctypes.c_void_p(-1).value):
+        raise OSError(ctypes.get_errno(), 'mmap failed', path)
+    buf = (ctypes.c_ubyte * size).from_address(addr)
+    arr = np.frombuffer(buf, dtype=np.uint8)
+    arr.flags.writeable = False
+    weakref.finalize(buf, libc.munmap, addr, size)            # (views keep `buf` alive through arr.base)
+    return arr
+
+
 def _mapped_arrays(path):
     """{member: array} of an UNCOMPRESSED .npz (what np.savez writes) without reading it: a stored zip member is the
-    bytes of its .npy file at a fixed offset, so every numeric array becomes a read-only np.memmap of the shard file -
-    no copy, no CRC pass (np.load spends 15 ms per 128-sample shard on zlib.crc32 alone; 40 % of the loader thread).
+    bytes of its .npy file at a fixed offset, so every numeric array becomes a read-only VIEW of ONE mapping of the shard
+    file - no copy, no CRC pass (np.load spends 15 ms per 128-sample shard on zlib.crc32 alone; 40 % of the loader thread).
+    One mapping per shard that pins no descriptor (_map_file): a np.memmap keeps a duplicated file descriptor until its
+    last view dies, and the reader's instances hold views of image / face_embeds / obj_embeds - three descriptors per live
+    shard exhausted the default limit of 1024 on a pass over a few hundred shards (EMFILE inside the loader thread).
     -> None when a member is compressed or of a dtype that cannot be mapped (strings are read normally)."""
     import struct
     import zipfile
     out = {}
+    whole = None
     with zipfile.ZipFile(path) as zf, open(path, 'rb') as f:
         for info in zf.infolist():
             name = info.filename[:-4] if info.filename.endswith('.npy') else info.filename
@@ -83,7 +113,12 @@ def _mapped_arrays(path):
                 with zf.open(info) as m:
                     out[name] = np.lib.format.read_array(m, allow_pickle=False)
                 continue
-            out[name] = np.memmap(path, dtype=dtype, mode='r', offset=f.tell(), shape=shape)
+            if whole is None:
+                whole = _map_file(path)                                    # one mapping per shard, no descriptor kept
+            start, nbytes = f.tell(), int(np.prod(shape)) * dtype.itemsize
+            out[name] = np.ndarray(shape, dtype=dtype, buffer=whole, offset=start) if start + nbytes <= whole.size else None
+            if out[name] is None:
+                return None
     return out
 
 

@@ -338,12 +338,28 @@ def finish_flush():
     jobs, _FINISH['jobs'] = _FINISH['jobs'], []
     if not jobs:
         return
+    # the kernel accumulates with a plain read-modify-write (one block per destination column range): two jobs of ONE
+    # launch that share a destination (a tied LayerNorm, gradient accumulation over several passes) would race, so a
+    # job whose destination is already in this launch goes into the next one (launches are ordered on the stream)
+    seen, later, now = set(), [], []
+    for j in jobs:
+        keys = {t.data_ptr() for t in (j[1], j[3]) if t is not None}
+        if keys & seen:
+            later.append(j)
+        else:
+            seen |= keys
+            now.append(j)
+    if later:
+        _FINISH['jobs'] = later
+    jobs = now
     n = len(jobs)
     call('tell_colsum_multi', n, _ptr_array([j[0] for j in jobs]), (ctypes.c_long * n)(*[j[0].stride(0) for j in jobs]),
          _int_array([j[0].shape[0] for j in jobs]), _int_array([j[0].shape[1] for j in jobs]),
          _int_array([j[2] for j in jobs]),
          (ctypes.c_void_p * n)(*[j[1].data_ptr() if j[1] is not None else None for j in jobs]),
          (ctypes.c_void_p * n)(*[j[3].data_ptr() if j[3] is not None else None for j in jobs]))
+    if later:
+        finish_flush()
 
 
 def colsum_into(x2, out, scale=1.0, m_dev=None):
@@ -1662,7 +1678,7 @@ def adaptive_log_probs(x2, cutoffs, emb0, class_proj, tails, want_full=False, to
     n_tails = len(tails) // 2
     from . import decode
     if (not want_full and decode.ENABLED and N <= decode.MAX_ROWS and x2.dtype == torch.bfloat16 and
-            E % 1024 == 0 and n_tails >= 1 and all(tails[2 * i].shape[0] % 8 == 0 for i in range(n_tails))):
+            E % 1024 == 0 and 1 <= n_tails <= 3 and all(tails[2 * i].shape[0] % 8 == 0 for i in range(n_tails))):
         return decode.head_step(x2, cutoffs, emb0, class_proj, tails, topk)
     w_head = _cached(emb0, ('whead', class_proj._version, class_proj.data_ptr()), lambda: torch.cat(
         [weight(emb0), weight(class_proj)], dim=0).contiguous())
