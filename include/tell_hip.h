@@ -10,11 +10,12 @@
  *
  * Conventions
  *   - plain pointers + sizes, no torch types; caller owns all memory; the library
- *     allocates nothing.  Its only state: a thread-local error string, three
- *     REGISTERED device pointers that kernels read while a hipGraph is recorded /
+ *     allocates nothing.  Its only state: a thread-local error string, five
+ *     REGISTERED device pointers: two that kernels read while a hipGraph is recorded /
  *     replayed (tell_set_rng_step_ptr, tell_set_pos_step_ptr: the dropout step and
- *     decode position counters), the registered tile-counter buffer of the persistent
- *     GEMM launches (tell_gemm_set_tile_queue) and a thread-local one-shot hook that arms
+ *     decode position counters), the tile-counter buffer of the persistent GEMM launches
+ *     (tell_gemm_set_tile_queue), the mask scratch of the long-sequence self-attention
+ *     (tell_attn_set_mask_scratch) and a thread-local one-shot hook that arms
  *     the next tell_gemm_nt launch with a span stamp (tell_gemm_ts_next);
  *   - every call is asynchronous on `stream` (pass torch's current stream);
  *   - return 0 on success, <0 on error (tell_last_error() explains);
@@ -348,6 +349,12 @@ int tell_attn_fwd(const void* q, const void* k, const void* v, void* out, float*
                   const void* bias_k, const void* bias_v, int B, int H, int Tq, int S, int D, long q_st,
                   long q_sb, long k_ss, long k_sb, long v_ss, long v_sb, long o_st, long o_sb, int has_zero,
                   float p, uint32_t seed, uint32_t salt, int dtype, tell_stream_t stream);
+/* register `bytes` of device scratch (caller-owned, alive while attention is launched; NULL unregisters) for the long-sequence
+ * self-attention forward (fairseq self-attention as called at transformer_faces_objects.py:352-353, D = 64, S % 64 == 0,
+ * Tq % 32 == 0, bf16, p > 0): tell_attn_fwd then first writes the dropout keep decisions of multi_head.py:463 as bit masks
+ * (B*H*Tq*S/8 bytes: 16.8 MB at B = 32, H = 16, S = 512; the same counter hash, so the same mask) with one launch and the
+ * attention kernel applies them with one instruction per probability instead of hashing in place.  Thread-local. */
+int tell_attn_set_mask_scratch(void* ptr, long bytes, tell_stream_t stream);
 /* dbias_k / dbias_v: fp32 [B, H*D] per-sample partials of the bias_k / bias_v gradients (the caller sums over B), each
    with row stride H*D - or, when dbias_v == dbias_k + H*D, the two column halves of one [B, 2*H*D] buffer. */
 int tell_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,

@@ -270,6 +270,44 @@ def test_gemm_q4_kernel(env):
     assert r.stdout.count('gemm_nt_q4_kernel') >= 9, r.stdout[-3000:]
 
 
+@pytest.mark.parametrize('B,H,S,masked', [(2, 4, 256, False), (3, 2, 512, True), (32, 16, 512, True)])
+def test_self_attention_dropout_lane_masks_equal_the_in_kernel_hash(B, H, S, masked):
+    """Long-sequence self-attention forward (fairseq self-attention, called at transformer_faces_objects.py:352-353) with
+    attention dropout: the decisions taken from attn_dropmask_kernel's lane masks (registered scratch; opt-in, TELL_ATTN_BITS=1:
+    measured slower than hashing in place, csrc/attention.hip) against the same kernel hashing in place: the SAME mask, so outputs and log-sum-exps are bit-identical; and
+    against dropout off, a tenth of the probabilities is gone (the two differ)."""
+    from tell_amd import hip
+    D, E = 64, H * 64
+    g = torch.Generator().manual_seed(B + H + S)
+    q = torch.randn(S, B, E, generator=g).bfloat16().to(DEV)
+    k = torch.randn(S, B, E, generator=g).bfloat16().to(DEV)
+    v = torch.randn(S, B, E, generator=g).bfloat16().to(DEV)
+    mask = torch.zeros(B, S, dtype=torch.uint8)
+    if masked:
+        for b in range(B):
+            mask[b, S - 17 * (b % 5):] = 1
+    mask = mask.to(DEV)
+
+    def run(p):
+        out = torch.empty_like(q)
+        lse = torch.empty(B * H, S, device=DEV)
+        hip.call('tell_attn_fwd', q, k, v, out, lse, mask, None, None, B, H, S, S, D, q.stride(0), q.stride(1), k.stride(0),
+                 k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1), 0, p, 11, 5, hip.dt(q))
+        torch.cuda.synchronize()
+        return out, lse
+    assert not os.environ.get('TELL_ATTN_BITS')
+    hashed = run(0.1)
+    os.environ['TELL_ATTN_BITS'] = '1'
+    try:
+        bits = run(0.1)
+        assert torch.equal(run(0.1)[0], bits[0])              # the scratch is rewritten by every call: repeatable
+    finally:
+        del os.environ['TELL_ATTN_BITS']
+    assert torch.equal(bits[0], hashed[0]) and torch.equal(bits[1], hashed[1])
+    plain = run(0.0)
+    assert not torch.equal(bits[0], plain[0])
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_lstm_cell_and_dot_attention_vs_torch(dtype):
     """csrc/lstm.hip against torch on CPU: nn.LSTMCell semantics from the two gate pre-activations, and the

@@ -6,6 +6,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tell_amd
 from tell_amd import hip
+hip.require_gpu()        # (registers the attention mask scratch)
 REP = 10
 
 
@@ -39,7 +40,7 @@ def case(name, B, H, T, S, D, p, bias, backward):
                  k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1), has_zero, p, 1, 2, hip.dt(q))
     tf = timed(fwd)
     fl = 4.0 * T * (S + 2 * has_zero) * D * B * H
-    line = '%-22s T=%3d S=%3d p=%.1f | fwd %6.1f us %5.0f TF' % (name, T, S, p, tf, fl / tf * 1e-6)
+    line = '%-30s T=%3d S=%3d p=%.1f | fwd %6.1f us %5.0f TF' % (name, T, S, p, tf, fl / tf * 1e-6)
     if backward:
         dout = torch.randn_like(q); dq = torch.empty_like(q); dk = torch.empty_like(k); dv = torch.empty_like(v)
         dbk = torch.empty(B, E, device='cuda') if bias else None
@@ -55,6 +56,9 @@ def case(name, B, H, T, S, D, p, bias, backward):
 
 
 case('roberta self', 32, 16, 512, 512, 64, 0.1, False, False)
+os.environ['TELL_ATTN_BITS'] = '1'      # opt-in: keep decisions as lane masks from attn_dropmask_kernel (its launch is inside the timed call)
+case('roberta self (lane masks)', 32, 16, 512, 512, 64, 0.1, False, False)
+del os.environ['TELL_ATTN_BITS']
 case('roberta self (no drop)', 32, 16, 512, 512, 64, 0.0, False, False)
 for name, S in (('decoder article', 512), ('decoder image', 49), ('decoder faces', 4), ('decoder objects', 64)):
     case(name, 32, 16, 32, S, 64, 0.1, True, True)

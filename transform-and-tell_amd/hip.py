@@ -8,6 +8,8 @@ import ctypes
 import os
 import re
 
+import threading
+
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -71,6 +73,7 @@ def lib():
 
 
 _tile_queue = {}
+_attn_buf, _attn_scratch = {}, {}
 
 
 def require_gpu():
@@ -83,6 +86,12 @@ def require_gpu():
         # 4 MB: 8 counters per launch; launches recorded into hipGraphs keep theirs (first half: 65536 launches' worth)
         _tile_queue[dev] = torch.zeros(1 << 20, dtype=torch.int32, device='cuda')
         lib().tell_gemm_set_tile_queue(_tile_queue[dev].data_ptr(), 1 << 20, None)
+    key = (dev, threading.get_ident())    # (thread-local on the library side: the loader / encoder threads launch too)
+    if key not in _attn_scratch:          # dropout lane masks of the long-sequence self-attention (csrc/attention.hip)
+        if dev not in _attn_buf:
+            _attn_buf[dev] = torch.empty(32 << 20, dtype=torch.uint8, device='cuda')      # B*H*Tq*S/8 = 16.8 MB at configs[2]
+        _attn_scratch[key] = True
+        lib().tell_attn_set_mask_scratch(_attn_buf[dev].data_ptr(), 32 << 20, None)
 
 
 def dt(t):
