@@ -376,7 +376,7 @@ def test_roberta_large_at_bench_size_matches_oracle():
                 bias = torch.zeros(n, dtype=torch.float32, device=DEV)
                 name = hip.query('tell_gemm_nt_plan', a, a.stride(0), w, w.stride(0), out, out.stride(0), B * S, n,
                                  a.shape[1], hip.dt(a), hip.dt(out), bias, 1, 0, None, 1.0, 0, None)
-                assert name.startswith(('gemm_nt_q4_kernel', 'gemm_nt_pp2_kernel', 'gemm_nt_pp_kernel')), (n, name)
+                assert name.startswith(('gemm_nt_q4_kernel', 'gemm_nt_q4e_kernel', 'gemm_nt_pp2_kernel', 'gemm_nt_pp_kernel')), (n, name)
             del x, h, out
         out = hipm.extract_features(ids.to(DEV), return_all_hiddens=True)
         assert out.shape == ref.shape
