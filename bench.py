@@ -139,6 +139,50 @@ def cpu_baseline(model_name='faces_objects', sample_b=4, gen_b=8, budget_s=30.0)
             'legs': legs, 'wall_s': round(time.time() - t_all, 1)}
 
 
+def dp_selftest(args):
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, TELL_DP_SELFTEST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1',
+               LOCAL_RANK='0')
+    cmd = [sys.executable, os.path.abspath(__file__), '--steps', '10', '--warmup', '4', '--no-cpu-baseline', '--no-secondary',
+           '--no-generation', '--no-loader', '--no-roofline', '--no-dp-selftest']
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')][-1]
+        j = json.loads(line)
+        return {'value': j['value'], 'unit': j['unit'], 'ms_per_step': j['ms_per_step'], 'steps': j['steps'], 'warmup': j['warmup'],
+                'dp': j.get('dp'), 'note': 'configs[2] step with TELL_DP_SELFTEST=1: 1-rank RCCL group, token-count / non-finite '
+                'flag / gradient all-reduce (bf16 wire), BertAdam reading the wire buffer; separate process'}
+    except Exception as e:                                   # the headline line must not depend on this leg
+        return {'error': repr(e)[:300]}
+
+
+def hog_child(n):
+    """bench.py --cu-hog: hold n CUs with back-to-back 50 ms tell_cu_hog launches until the parent closes our stdin."""
+    import threading
+    import tell_amd
+    from tell_amd import hip
+    torch.cuda.set_device(0)
+    hip.require_gpu()
+    done = threading.Event()
+    threading.Thread(target=lambda: (sys.stdin.read(), done.set()), daemon=True).start()
+    ticks = 50 * hip.lib().tell_wall_clock_khz()
+    for _ in range(4):
+        hip.call('tell_cu_hog', n, ticks, None)
+    print('ready', flush=True)
+    t_end = time.time() + 120
+    while not done.is_set() and time.time() < t_end:
+        hip.call('tell_cu_hog', n, ticks, None)
+        hip.call('tell_cu_hog', n, ticks, None)
+        torch.cuda.current_stream().synchronize()       # (two launches deep: the CUs are re-taken within microseconds)
+        hip.call('tell_cu_hog', n, ticks, None)
+    torch.cuda.synchronize()
+
+
 def relaunch(args):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run."""
     import socket
@@ -210,8 +254,19 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
     sync()
     if want_prof:
         prof.reset_records()
-    if world > 1:
+    if trainer.dp:
         trainer.dp_timing = []
+    hog = None
+    if getattr(args, 'cu_hog', 0) > 0:
+        # contention rehearsal: N workgroups that hold one CU each for the whole timed region (what RCCL's channel kernels
+        # do during the gradient exchange), launched by a CHILD PROCESS: its context has hardware queues of its own.  (As a
+        # fourth stream of this process the resident kernel shared a hardware queue with one of the step's streams -
+        # ROCm multiplexes streams onto GPU_MAX_HW_QUEUES = 4 queues, FIFO each - and the step simply waited for it:
+        # 220 ms per step for any N.  An RCCL communicator of this process takes a queue the same way: streams.py.)
+        import subprocess
+        hog = subprocess.Popen([sys.executable, os.path.abspath(__file__), '--hog-child', str(int(args.cu_hog))],
+                               stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+        assert hog.stdout.readline().strip() == 'ready', 'cu-hog child did not start'
     dec_ev = []
     t0 = time.perf_counter()
     loss = None
@@ -228,6 +283,9 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
     issued = time.perf_counter() - t0           # host finished issuing; the rest of `elapsed` is GPU backlog
     sync()
     elapsed = time.perf_counter() - t0
+    if hog is not None:
+        hog.stdin.close()
+        hog.wait(timeout=60)
     graph_replays = trainer.step_graph.replays if trainer.step_graph is not None else 0
     prof_concurrent = prof.summary() if want_prof else {}
     if want_prof and not args.serial:
@@ -244,12 +302,16 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
            'step_graph_replays': graph_replays, 'skipped_steps': trainer.skipped_steps(),
            'resnet_hipgraph': sorted({e['state'] for e in getattr(model.__dict__.get('_resnet_graph'),
                                                                   'entries', {}).values()})}
-    if world > 1:
+    if hog is not None:
+        res['cu_hog'] = {'cus_held': int(args.cu_hog), 'note': 'N workgroups with 64 KB of LDS each held one CU for the whole '
+                         'timed region (tell_cu_hog launched back to back by a child process): rehearsal of RCCL channel kernels next to the 256x256 GEMMs'}
+    if trainer.dp:
         # the gradient exchange of every timed step on this rank (HIP events on the update stream), max over ranks
         times = trainer.dp_times()
         tt = torch.tensor([sum(a for a, _ in times) / max(len(times), 1), sum(b for _, b in times) / max(len(times), 1)],
                           dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         res['dp'] = {'allreduce_ms': round(float(tt[0]), 3), 'exposed_allreduce_ms': round(float(tt[1]), 3),
                      'wire_dtype': str(trainer.allreduce_dtype).replace('torch.', ''),
                      'gradient_mbytes': round(trainer.flat.total * (2 if trainer.allreduce_dtype == torch.bfloat16 else 4)
@@ -462,6 +524,11 @@ def loader_bench(args, dev, n_batches=12, warm=4, variable=False):
             sg = trainer.step_graph
             extra = {'step_graph_replays': sg.replays if sg is not None else 0, 'steps_total': n_done,
                      'shape_buckets': list(trainer.shape_buckets or ()), 'epochs': epochs}
+            if sg is not None:                         # capture policy at work: signatures, captures kept, evictions, pool size
+                ready = sum(1 for v in sg.entries.values() if v.get('state') == 'ready')
+                extra.update(step_signatures_seen=len(sg.entries), step_graphs_kept=ready, step_graph_evictions=sg.cache.evictions,
+                             step_graph_failed=sum(1 for v in sg.entries.values() if v.get('state') == 'failed'),
+                             hbm_reserved_gb=round(torch.cuda.memory_reserved() / 2 ** 30, 2))
             if len(marks) >= 3:                        # steady state: the last epoch (every bucket signature captured)
                 (n1, t1), (n2, t2) = marks[-2], marks[-1]
                 extra['first_epochs_value'] = round(B * timed / elapsed, 2)
@@ -571,6 +638,8 @@ def main():
     ap.add_argument('--no-secondary', action='store_true', help='skip the configs[1] block')
     ap.add_argument('--cpu-sample', type=int, default=4)
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-dp-selftest', action='store_true', help='skip the 1-rank RCCL leg of the default line')
+    ap.add_argument('--cu-hog', type=int, default=0, help='hold N CUs with idle resident workgroups during the timed region (DP contention rehearsal)')
     ap.add_argument('--no-pipeline', action='store_true',
                     help='do not launch the next batch\'s frozen encoders underneath the current decoder step')
     ap.add_argument('--serial', action='store_true',
@@ -584,7 +653,10 @@ def main():
     ap.add_argument('--beam', type=int, default=4, help='beam size of --generate (1 = greedy, what the reference does)')
     ap.add_argument('--roofline-steps', type=int, default=3,
                     help='extra single-stream steps after the timed region that time the GEMM kernels in isolation')
+    ap.add_argument('--hog-child', type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.hog_child:
+        return hog_child(args.hog_child)
     if args.batch is None:
         args.batch = 32 if args.model == 'faces_objects' else 16
     args.warmup = max(args.warmup, 0)
@@ -681,6 +753,12 @@ def main():
             tell_amd.ops.clear_weight_cache()
             torch.cuda.empty_cache()
             result['loader_variable_lengths'] = loader_bench(args, dev, n_batches=22, warm=2, variable=True)
+        if world == 1 and not args.no_dp_selftest and not args.serial and args.model == 'faces_objects' and \
+                os.environ.get('TELL_DP_SELFTEST') is None and not args.cu_hog:
+            # the data-parallel code path's own cost at N = 1: the same step with a 1-rank RCCL group and every
+            # collective, cast and the wire-reading BertAdam of the DP schedule, in its own process (an RCCL communicator
+            # takes a hardware queue; the headline above runs without one)
+            result['dp_selftest'] = dp_selftest(args)
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.model, args.cpu_sample)
         print(json.dumps(result))

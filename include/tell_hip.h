@@ -58,6 +58,10 @@ int tell_set_pos_step_ptr(const void* counter, tell_stream_t stream);
 uint32_t tell_drop_threshold_host(float p);
 /* measurement aid (bench.py roofline): rate of the device wall clock in kHz (100 000 on MI355X) */
 int tell_wall_clock_khz(void);
+/* measurement aid (bench.py --cu-hog, the single-GPU rehearsal of what RCCL's channel kernels do to a step whose dominant
+ * GEMM needs whole compute units - SURVEY 8e): n workgroups that each hold one CU (64 KB of LDS) for `ticks` of the device
+ * wall clock (capped at 4 s), or until *stop (device int32, may be NULL) becomes non-zero, and do nothing else */
+int tell_cu_hog(int n_workgroups, long ticks, int* stop, tell_stream_t stream);
 /* arm the NEXT tell_gemm_nt launch of this thread: its direct-to-LDS / ping-pong kernel records its execution span
  * into ts[0] (first workgroup in) / ts[1] (last workgroup out), device wall-clock ticks; ts is uint64[3], zero before
  * the first use (ts[2] counts workgroup arrivals: every launch of the same grid re-opens the span by itself) */

@@ -43,3 +43,26 @@ extern "C" int tell_wall_clock_khz(void) {
   if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
   return khz;
 }
+
+// Contention rehearsal (bench.py --cu-hog N): n workgroups that do nothing but HOLD a compute unit each for `ticks` of the
+// device wall clock (64 KB of LDS: no 256x256 GEMM workgroup - 133 KB - fits beside one; the dispatcher places one per CU
+// while free CUs exist).  What RCCL's channel kernels will do to a step whose dominant kernel needs whole CUs, measurable on
+// one GPU.  Bounded: a launch never spins longer than 4 s.
+__global__ __launch_bounds__(64) void cu_hog_kernel(unsigned long long ticks, int* stop) {
+  __shared__ int hog[16384];
+  hog[threadIdx.x] = (int)threadIdx.x;
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) {
+    if (stop && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;     // (L2: another stream sets it)
+    __builtin_amdgcn_s_sleep(64);
+  }
+  if (stop && hog[(threadIdx.x * 7) & 16383] == -12345) *stop = 2;
+}
+extern "C" int tell_cu_hog(int n_workgroups, long ticks, int* stop, hipStream_t stream) {
+  TELL_REQUIRE(n_workgroups >= 0 && n_workgroups <= 256 && ticks >= 0, "cu_hog: 0..256 workgroups");
+  if (n_workgroups == 0) return TELL_OK;
+  const int khz = tell_wall_clock_khz();
+  const long cap = 4000L * (khz > 0 ? khz : 100000);
+  hipLaunchKernelGGL(cu_hog_kernel, dim3(n_workgroups), dim3(64), 0, stream, (unsigned long long)(ticks < cap ? ticks : cap), stop);
+  return tell_check_launch("cu_hog");
+}

@@ -88,11 +88,20 @@ class StepGraph:
         sig, small, big, by_ptr = plan
         e = self.cache.touch(sig)
         if e['state'] == 'seen':
-            loss = eager_step(batch, enc)
-            if self.cache.due(e):
+            if self.cache.due(e) and e['hits'] >= 2:
+                # this signature has run eagerly before (every cache a capture relies on exists): record the graph NOW and
+                # train this batch with its first replay - a new signature costs one eager step + one capture pass, not two
+                # eager steps + a capture (variable-length data: 12 signatures in the first epochs, 55 ms per eager step)
                 self.cache.make_room()
                 self._capture(e, batch, small, big, by_ptr, enc)
-            return loss
+                if e['state'] != 'ready':
+                    return eager_step(batch, enc)
+            else:
+                loss = eager_step(batch, enc)
+                if self.cache.due(e):
+                    self.cache.make_room()
+                    self._capture(e, batch, small, big, by_ptr, enc)
+                return loss
         if e['state'] != 'ready':
             return None
         tr = self.tr

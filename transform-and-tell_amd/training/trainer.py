@@ -65,6 +65,13 @@ class Trainer:
                                                  torch.device(device).type == 'cuda' and
                                                  os.environ.get('TELL_ALLREDUCE_FP32') != '1') else torch.float32
         self.allreduce_dtype, self._wire = allreduce_dtype, None
+        if self.dp and self.world > 1:
+            # RCCL's channel kernels will hold compute units while the next batch's encoders run: the 256x256 GEMMs
+            # (csrc/gemm_q4.hip, one workgroup per CU) then take their tiles from per-XCD counters, so that a workgroup
+            # whose CU is taken gets fewer tiles instead of finishing a static share late.  MEASURED on one GPU with N
+            # CUs held by idle workgroups (bench.py --cu-hog N, profiles/r04_cu_hog.txt): configs[2] 1565 -> 1423 samples/s
+            # with static tile lists for N = 8 / 16 / 32, -> 1498-1514 with the counters (1570 with no CU held).
+            os.environ.setdefault('TELL_Q4_DYNAMIC', '1')
         if self.dp:
             # every rank draws its own dropout masks: the counter-hash seed is process-global with the same default on
             # all ranks; the rank is mixed in where the seed is READ (runtime.seed), not written into the global seed
