@@ -428,7 +428,7 @@ def loader_bench(args, dev, n_batches=12, warm=4, variable=False):
     33-token captions, 4 faces, 64 objects, batch 32).
     variable=True: article / caption lengths, face and object counts drawn as SURVEY 8d describes real data
     (L ~ U{128..512}, T+1 ~ U{9..41}, faces U{0..4}, objects U{0..64}); the BucketIterator sorts by length with padding
-    noise, so batches differ in shape: the trainer pads to its shape buckets (64 article tokens, 8 caption tokens) and
+    noise, so batches differ in shape: the trainer pads to its shape buckets (128 article tokens, 16 caption tokens: Trainer(shape_buckets=(128, 16))) and
     captures a step graph per bucket signature at its second sighting - this leg times that policy."""
     import queue
     import shutil

@@ -173,6 +173,11 @@ int tell_wn_weight_multi(int n, const void* const* g, const void* const* v, void
 int tell_wn_backward_multi(int n, const void* const* dW, const void* const* g, const void* const* v,
                            const void* const* norms, const int* rows, const int* cols, void* const* dg,
                            void* const* dv, tell_stream_t stream);
+/* store (host int[n], may be NULL): tensor j's dg / dv are written (beta = 0) instead of accumulated - for gradients
+ * whose only producer in a step is this launch and that tell_bertadam_step2 was told not to zero (keep_grad). */
+int tell_wn_backward_multi2(int n, const void* const* dW, const void* const* g, const void* const* v,
+                            const void* const* norms, const int* rows, const int* cols, void* const* dg,
+                            void* const* dv, const int* store, tell_stream_t stream);
 
 /* ---- elementwise ------------------------------------------------------------ */
 /* nn.GLU, decoder_faces_objects.py:194-195,259-261: h = [a | gate] */
@@ -422,6 +427,16 @@ int tell_bertadam_step(float* param, float* grad, float* m, float* v, const int*
                        const float* lr_dev, float b1, float b2, float eps, float wd, float max_norm,
                        float grad_scale, void* shadow_bf16, int zero_grad, int* skip, const void* grad_wire_bf16,
                        int* step_dev, float lr_base, float warmup, float t_total, tell_stream_t stream);
+/* The same step with keep_grad (device int32[n_tensors], may be NULL): tensors with keep_grad[t] != 0 are NOT zeroed by
+ * zero_grad - their single weight-gradient product of the next backward pass stores over them (accumulate = 0), which
+ * saves the 4 B / parameter zero write here and the 4 B / parameter read there.  The host side (training/optimizers.py,
+ * ops.wgrad_target) decides per tensor from who wrote what in an observed first step. */
+int tell_bertadam_step2(float* param, float* grad, float* m, float* v, const int* chunk_tensor,
+                        const long* chunk_begin, long n_chunks, int n_tensors, float* partial, float* norms,
+                        const float* lr_dev, float b1, float b2, float eps, float wd, float max_norm,
+                        float grad_scale, void* shadow_bf16, int zero_grad, int* skip, const void* grad_wire_bf16,
+                        int* step_dev, float lr_base, float warmup, float t_total, const int* keep_grad,
+                        tell_stream_t stream);
 /* step_dev (device int32, may be NULL): the count of updates APPLIED so far.  When given, the library first writes
  * *lr_dev = lr_base * warmup_linear(*step_dev / t_total, warmup) (t_total <= 0: lr_base) and the update kernel
  * increments *step_dev only when the step is not skipped - a skipped batch costs no tick of the schedule, exactly as in

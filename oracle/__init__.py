@@ -24,5 +24,5 @@ Pinning:
     (pytorch_pretrained_bert, absent here): restated from their published
     architecture / update rule - **parity unpinned** for those three (RoBERTa is
     cross-checked structurally against `transformers.RobertaModel` in the
-    authoring container, see tests/test_oracle_roberta.py).
+    authoring container, see tests/test_oracle_encoders.py).
 """

@@ -886,13 +886,13 @@ def test_skinny_gemm_split_k(monkeypatch, M, N, K, act):
     assert (y1 != y0).float().mean() < 0.02           # the two differ only where the fp32 sum rounds the other way
 
 
-def test_long_reduction_few_columns_split_k(monkeypatch):
-    """gemm_nn with few output columns and a very long reduction (adaptive-softmax tails with a reduced dimension:
-    dh[rows, 64] = dlogits[rows, 30265] . W) runs as K slices of one grouped launch + the fold; zero padding columns of
-    the left operand beyond K and a ragged last slice included."""
+@pytest.mark.parametrize('M,N,K', [(256, 64, 8200 + 57), (1024, 1024, 2 * 8192 + 1001)])
+def test_long_reduction_few_columns_split_k(monkeypatch, M, N, K):
+    """gemm_nn with few output columns and a very long reduction (adaptive-softmax tails: dh[rows, 64] =
+    dlogits[rows, 30265] . W with a reduced dimension, [rows, 1024] with adaptive_softmax_factor 1) runs as K slices of
+    one grouped launch + the fold; zero padding columns of the left operand beyond K and a ragged last slice included."""
     from tell_amd import ops
     torch.manual_seed(23)
-    M, N, K = 256, 64, 8200 + 57
     a = torch.zeros(M, ops._round_up(K, 8), device=DEV).bfloat16()
     a[:200, :K] = torch.randn(200, K, device=DEV).bfloat16()
     w = (torch.randn(K, N, device=DEV) * 0.05).bfloat16()

@@ -59,11 +59,16 @@ def test_step_graph_equals_eager(kind, dtype):
         lb = tb.train_one_batch(_clone(batches[s % 2]))
         tol = 1e-6 if dtype == torch.float32 else 1e-3
         assert abs(float(la) - float(lb)) <= tol * abs(float(la)), (s, float(la), float(lb))
-    assert tb.step_graph.replays == 5 and [e['state'] for e in tb.step_graph.entries.values()] == ['ready']
+    # (a signature is captured at its second sighting and that batch already trains through the first replay)
+    assert tb.step_graph.replays == 6 and [e['state'] for e in tb.step_graph.entries.values()] == ['ready']
     assert tb.optimizer.step_count == ta.optimizer.step_count == 7
     num = float((ta.flat.flat - tb.flat.flat).norm())
     assert num <= (1e-6 if dtype == torch.float32 else 2e-3) * float(ta.flat.flat.norm()), num
-    assert float(tb.flat.grad.abs().max()) == 0.0
+    # the update zeroes every gradient but those its single dense producer stores over in the next pass (ops.py
+    # 'Gradient stores'): weight matrices of the projections and GehringLinears
+    kept = [p for p in tb.flat.params if getattr(p, '_tell_grad_store', False)]
+    assert kept and all(p.dim() >= 1 for p in kept) and tb.flat.stored_numel == sum(p.numel() for p in kept)
+    assert all(float(p.grad.abs().max()) == 0.0 for p in tb.flat.params if not getattr(p, '_tell_grad_store', False))
     assert b.n_batches == a.n_batches == 7
 
 
@@ -82,7 +87,7 @@ def test_step_graph_draws_fresh_dropout_masks():
     batch = _dev(synthetic_batch(B=4, article_len=24, caption_len=12, faces_objects=True, vocab=600,
                                  cutoffs=(100, 300), seed=7))
     losses = [float(tr.train_one_batch(_clone(batch))) for _ in range(7)]
-    assert tr.step_graph.replays == 5            # (a shape is captured at its second sighting)
+    assert tr.step_graph.replays == 6            # (captured at the second sighting, which is also the first replay)
     assert len({round(x, 5) for x in losses[2:]}) >= 4, losses
     assert max(losses) - min(losses) < 0.2 * abs(losses[0]), losses        # same weights: only the masks differ
 
@@ -114,7 +119,9 @@ def test_non_finite_step_is_skipped_on_device(graph):
     loss = tr.train_one_batch(_clone(bad))
     assert not torch.isfinite(loss)
     assert torch.equal(tr.flat.flat, w0) and torch.equal(tr.flat.m, m0)
-    assert float(tr.flat.grad.abs().max()) == 0.0 and tr.skipped_steps() == 1
+    # (gradients whose producer stores over them in the next pass are not cleared: ops.py 'Gradient stores')
+    assert all(float(p.grad.abs().nan_to_num(1.0).max()) == 0.0 for p in tr.flat.params
+               if not getattr(p, '_tell_grad_store', False)) and tr.skipped_steps() == 1
     loss = tr.train_one_batch(_clone(good))
     assert torch.isfinite(loss) and not torch.equal(tr.flat.flat, w0) and tr.skipped_steps() == 1
     assert bool(torch.isfinite(tr.flat.flat).all())

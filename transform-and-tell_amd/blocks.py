@@ -298,16 +298,8 @@ class KVAllFn(Function):
                 b_param = m.in_proj_bias
                 gb = ops.grad_buffer(b_param)[E:3 * E] if b_param.requires_grad else None
                 if wk.requires_grad:
-                    def rows_of(p, r):
-                        g = ops.grad_buffer(p)
-                        g = g.view(g.shape[0], -1)
-                        return g if r is None else g[r[0]:r[1]]
-                    gk, gv = rows_of(wk, rk), rows_of(wv, rv)
-                    if ops._adjacent(gk, gv):
-                        ops.gemm_tn(d2, s2, out=ops._stacked(gk, gv), accumulate=True, asum=gb)
-                    else:
-                        ops.gemm_tn(d2[:, :E], s2, out=gk, accumulate=True, asum=None if gb is None else gb[:E])
-                        ops.gemm_tn(d2[:, E:], s2, out=gv, accumulate=True, asum=None if gb is None else gb[E:])
+                    (gk, acc_k), (gv, acc_v) = ops.wgrad_target(wk, rk), ops.wgrad_target(wv, rv)
+                    ops.kv_wgrad(d2, s2, gk, acc_k, gv, acc_v, gb, E)
                 elif gb is not None:
                     ops.colsum_into(d2, gb)
             if not ctx.need_dx[ci]:

@@ -189,7 +189,7 @@ extern "C" int tell_wn_weight(const float* g, const float* v, int rows, int cols
 __device__ __forceinline__ void wn_backward_row(const float* __restrict__ dW, const float* __restrict__ g,
                                                 const float* __restrict__ v, const float* __restrict__ norms,
                                                 int row, int cols, float* __restrict__ dg, float* __restrict__ dv,
-                                                int lane) {
+                                                int lane, const bool store = false) {
   const float* vr = v + (long)row * cols;
   const float* dr = dW + (long)row * cols;
   float* o = dv + (long)row * cols;
@@ -205,16 +205,19 @@ __device__ __forceinline__ void wn_backward_row(const float* __restrict__ dW, co
   }
   dot = wave_sum(dot);
   const float nrm = norms[row], gs = g[row] / nrm, k = dot / (nrm * nrm);
-  if (lane == 0) dg[row] += dot / nrm;             // accumulate into the (zeroed) grad buffers
+  // accumulate into the (zeroed) grad buffers - or, `store` (wave-uniform): this launch is the only writer of dg / dv in
+  // the step and the optimizer left them alone (tell_bertadam_step2 keep_grad): no read of the old value
+  if (lane == 0) dg[row] = (store ? 0.f : dg[row]) + dot / nrm;
   if (vec) {
     for (int c = lane; c < cols / 4; c += 64) {
       const float4 d = reinterpret_cast<const float4*>(dr)[c], x = reinterpret_cast<const float4*>(vr)[c];
-      float4 a = reinterpret_cast<float4*>(o)[c];
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!store) a = reinterpret_cast<float4*>(o)[c];
       a.x += gs * (d.x - x.x * k); a.y += gs * (d.y - x.y * k); a.z += gs * (d.z - x.z * k); a.w += gs * (d.w - x.w * k);
       reinterpret_cast<float4*>(o)[c] = a;
     }
   } else {
-    for (int c = lane; c < cols; c += 64) o[c] += gs * (dr[c] - vr[c] * k);
+    for (int c = lane; c < cols; c += 64) o[c] = (store ? 0.f : o[c]) + gs * (dr[c] - vr[c] * k);
   }
 }
 __global__ __launch_bounds__(256) void wn_backward_kernel(const float* __restrict__ dW,
@@ -249,6 +252,7 @@ struct WNMulti {
   int cols[WN_MULTI_MAX];
   int row_start[WN_MULTI_MAX + 1];
   int n;
+  unsigned store;                      // backward: bit i = tensor i's dg / dv are stored, not accumulated
 };
 template <typename OutT, bool BWD>
 __global__ __launch_bounds__(256) void wn_multi_kernel(WNMulti m) {
@@ -257,17 +261,19 @@ __global__ __launch_bounds__(256) void wn_multi_kernel(WNMulti m) {
   int i = 0;
   while (i + 1 < m.n && row >= m.row_start[i + 1]) ++i;       // wave-uniform
   const int r = row - m.row_start[i];
-  if constexpr (BWD) wn_backward_row(m.a[i], m.g[i], m.v[i], m.norms[i], r, m.cols[i], m.dg[i], static_cast<float*>(m.w[i]), lane);
+  if constexpr (BWD) wn_backward_row(m.a[i], m.g[i], m.v[i], m.norms[i], r, m.cols[i], m.dg[i], static_cast<float*>(m.w[i]), lane, (m.store >> i) & 1u);
   else wn_weight_row<OutT>(m.g[i], m.v[i], r, m.cols[i], static_cast<OutT*>(m.w[i]), m.norms[i], lane);
 }
 template <bool BWD>
 static int wn_multi_launch(int n, const void* const* a, const void* const* g, const void* const* v, void* const* w,
                            void* const* norms, void* const* dg, const int* rows, const int* cols, int out_dtype,
-                           hipStream_t stream) {
+                           hipStream_t stream, const int* store = nullptr) {
+  static_assert(WN_MULTI_MAX <= 32, "WNMulti::store is one bit per tensor");
   for (int base = 0; base < n; base += WN_MULTI_MAX) {
     WNMulti m;
     m.n = n - base < WN_MULTI_MAX ? n - base : WN_MULTI_MAX;
     m.row_start[0] = 0;
+    m.store = 0u;
     for (int i = 0; i < m.n; ++i) {
       const int j = base + i;
       TELL_REQUIRE(rows[j] > 0 && cols[j] > 0, "wn_multi: empty tensor");
@@ -280,6 +286,7 @@ static int wn_multi_launch(int n, const void* const* a, const void* const* g, co
       m.dg[i] = BWD ? static_cast<float*>(dg[j]) : nullptr;
       m.cols[i] = cols[j];
       m.row_start[i + 1] = m.row_start[i] + rows[j];
+      if (BWD && store && store[j]) m.store |= 1u << i;
     }
     const dim3 grid((m.row_start[m.n] + 3) / 4);
     if (BWD) hipLaunchKernelGGL((wn_multi_kernel<float, true>), grid, dim3(256), 0, stream, m);
@@ -300,6 +307,14 @@ extern "C" int tell_wn_backward_multi(int n, const void* const* dW, const void* 
                                       void* const* dv, hipStream_t stream) {
   if (n <= 0) return TELL_OK;
   return wn_multi_launch<true>(n, dW, g, v, dv, const_cast<void* const*>(norms), dg, rows, cols, TELL_F32, stream);
+}
+// store: host int[n] or NULL - tensor j's dg / dv are WRITTEN (beta = 0) instead of accumulated: for gradients that have
+// this launch as their only writer in a step and that the optimizer does not zero (tell_bertadam_step2 keep_grad)
+extern "C" int tell_wn_backward_multi2(int n, const void* const* dW, const void* const* g, const void* const* v,
+                                       const void* const* norms, const int* rows, const int* cols, void* const* dg,
+                                       void* const* dv, const int* store, hipStream_t stream) {
+  if (n <= 0) return TELL_OK;
+  return wn_multi_launch<true>(n, dW, g, v, dv, const_cast<void* const*>(norms), dg, rows, cols, TELL_F32, stream, store);
 }
 
 // ---------------------------------------------------------------- GLU  (h = [a | gate], y = a * sigmoid(gate))

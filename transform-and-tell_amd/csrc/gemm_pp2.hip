@@ -387,5 +387,9 @@ extern "C" int tell_gemm_nt_dropout_residual(const void* A, long lda, const void
   a.bias_mode = bias ? 1 : 0; a.act = 5; a.alpha = 1.f;
   a.res = res; a.ld_res = ld_res; a.drop_thr = p > 0.f ? tell_drop_threshold(p) : 0u; a.drop_inv_keep = 1.f / (1.f - p);
   a.drop_seed = seed; a.drop_salt = salt; a.drop_step = g_tell_rng_step;
+  // round 4: the four-wave kernel (gemm_q4.hip) carries the same epilogue form (one rounding: bf16(res + dropout(.)) from
+  // fp32, where this file's staged epilogue rounds the dropped product first); TELL_GEMM_Q4=0 keeps the ping-pong kernel
+  const int q4_env = getenv("TELL_GEMM_Q4") ? atoi(getenv("TELL_GEMM_Q4")) : 1;
+  if (q4_env && K % 128 == 0 && K >= 128 && K / 64 < 65536 && 512L * lda < (1L << 31) && 512L * ldb < (1L << 31)) return launch_gemm_q4(a, stream, n_cu);
   return launch_gemm_pp2(a, stream, n_cu);
 }

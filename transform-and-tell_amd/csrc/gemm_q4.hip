@@ -108,10 +108,26 @@ __device__ __forceinline__ void q4_store(const GemmArgs& p, int m0, int n0, int 
     for (int i = 0; i < 4; ++i) bm[i] = p.bias[m0 + 128 * w_r + 8 * (r >> 1) + 2 * i + (r & 1)] * alpha;
   }
   uint16_t* C = static_cast<uint16_t*>(p.C);
+  // ACT 5: C = res + dropout_p(result) - the transformer sub-layer residual (fairseq: x = residual + dropout(out_proj(.)) /
+  // dropout(fc2(.))); the mask is the one tell_layernorm_fwd would draw for (seed, salt): element m N + n, common.h quad hash.
+  // A store group is two aligned quads of one row; the residual pieces of fragment row I + 1 are fetched while row I is worked on.
+  const uint16_t* R = static_cast<const uint16_t*>(p.res);
+  uint32_t dsalt = 0;
+  if constexpr (ACT == 5) dsalt = tell_step_salt(p.drop_salt, p.drop_step);
+  u32x4 rres[2][8];
+  auto fetch_res = [&](auto ic) __attribute__((always_inline)) {
+    constexpr int I = decltype(ic)::value;
+    const int m = m0 + 128 * w_r + 8 * (r >> 1) + 2 * I + (r & 1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      rres[I & 1][q] = *reinterpret_cast<const u32x4*>(R + (long)m * p.ld_res + nb + 16 * (q & 1) + 32 * (q >> 1));
+  };
+  if constexpr (ACT == 5) fetch_res(std::integral_constant<int, 0>{});
   q4_static_for<4>([&](auto ic) __attribute__((always_inline)) {
     constexpr int I = decltype(ic)::value;
     const int m = m0 + 128 * w_r + 8 * (r >> 1) + 2 * I + (r & 1);
     uint16_t* crow = C + (long)m * p.ldc + nb;
+    if constexpr (ACT == 5 && I < 3) fetch_res(std::integral_constant<int, I + 1>{});
     q4_static_for<8>([&](auto qc) __attribute__((always_inline)) {
       constexpr int Q = decltype(qc)::value;
       constexpr int G8 = 16 * (Q & 1) + 32 * (Q >> 1);
@@ -128,6 +144,24 @@ __device__ __forceinline__ void q4_store(const GemmArgs& p, int m0, int n0, int 
       }
       if constexpr (ACT == 1) v = __builtin_elementwise_max(v, f32x8_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
       else if constexpr (ACT == 2) v = q4_gelu8(v);
+      else if constexpr (ACT == 5) {
+        if (p.drop_thr) {                                  // block-uniform
+          const uint64_t quad = ((uint64_t)m * (uint64_t)p.N + (uint64_t)(nb + G8)) >> 2;
+#pragma unroll
+          for (int hq = 0; hq < 2; ++hq) {
+            bool k0, k1, k2, k3;
+            tell_keep4_bits(tell_quad_x(p.drop_seed, quad + hq), tell_quad_y(dsalt, quad + hq), p.drop_thr, k0, k1, k2, k3);
+            v[4 * hq] = k0 ? v[4 * hq] * p.drop_inv_keep : 0.f; v[4 * hq + 1] = k1 ? v[4 * hq + 1] * p.drop_inv_keep : 0.f;
+            v[4 * hq + 2] = k2 ? v[4 * hq + 2] * p.drop_inv_keep : 0.f; v[4 * hq + 3] = k3 ? v[4 * hq + 3] * p.drop_inv_keep : 0.f;
+          }
+        }
+        const u32x4 rr = rres[I & 1][Q];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v[2 * k] += __uint_as_float(rr[k] << 16);
+          v[2 * k + 1] += __uint_as_float(rr[k] & 0xffff0000u);
+        }
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = pack2_bf16(v[2 * k], v[2 * k + 1]);
       if (ABL != 2 || o[0] == 0x12345678u) *reinterpret_cast<u32x4*>(crow + G8) = o;
@@ -160,7 +194,7 @@ __device__ __forceinline__ void q4_epilogue(const GemmArgs& p, int m0, int n0, i
 
 // VAR: schedule variant of the K loop (tools/gen_q4_loop.py VARIANTS); ABL: timing probes with wrong results (1: no
 // epilogue at all, 2: epilogue arithmetic without the global stores)
-template <int VAR, int ABL>
+template <int VAR, int ABL, bool RES = false>
 __global__ __launch_bounds__(256) void gemm_nt_q4_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * Q4_BUF + 64];
   gemm_ts_enter(p);
@@ -274,7 +308,8 @@ __global__ __launch_bounds__(256) void gemm_nt_q4_kernel(GemmArgs p) {
       if constexpr (VAR == 1) Q4_RUN_MAIN(Q4_MAIN_ASM_1);
       else if constexpr (VAR == 2) Q4_RUN_MAIN(Q4_MAIN_ASM_2);
       else Q4_RUN_MAIN(Q4_MAIN_ASM_0);
-      if constexpr (ABL != 1) q4_epilogue<ABL>(p, m0, n0, w_r, w_c, lane);
+      if constexpr (RES) q4_store<5, false, 0>(p, m0, n0, w_r, w_c, lane);
+      else if constexpr (ABL != 1) q4_epilogue<ABL>(p, m0, n0, w_r, w_c, lane);
     }
     if (!has_next) break;
     vb = nvb; m0 = m1; n0 = n1;
@@ -302,7 +337,8 @@ int launch_gemm_q4(const GemmArgs& a_in, hipStream_t stream, int n_cu) {
   // (read per launch: tools/probes/q4_variants.py switches them inside one process)
   const int var = getenv("TELL_Q4_VAR") ? atoi(getenv("TELL_Q4_VAR")) : 0;
   const int abl = getenv("TELL_Q4_ABL") ? atoi(getenv("TELL_Q4_ABL")) : 0;   // timing probes (1, 2: wrong results; 3: stamps into aux)
-  if (abl == 3) hipLaunchKernelGGL((gemm_nt_q4_kernel<0, 3>), dim3(grid), dim3(256), 0, stream, a);
+  if (a.act == 5) hipLaunchKernelGGL((gemm_nt_q4_kernel<0, 0, true>), dim3(grid), dim3(256), 0, stream, a);
+  else if (abl == 3) hipLaunchKernelGGL((gemm_nt_q4_kernel<0, 3>), dim3(grid), dim3(256), 0, stream, a);
   else if (abl == 1) hipLaunchKernelGGL((gemm_nt_q4_kernel<0, 1>), dim3(grid), dim3(256), 0, stream, a);
   else if (abl == 2) hipLaunchKernelGGL((gemm_nt_q4_kernel<0, 2>), dim3(grid), dim3(256), 0, stream, a);
   else if (var == 1) hipLaunchKernelGGL((gemm_nt_q4_kernel<1, 0>), dim3(grid), dim3(256), 0, stream, a);

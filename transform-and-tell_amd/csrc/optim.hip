@@ -93,20 +93,25 @@ __global__ __launch_bounds__(256) void bertadam_update_kernel(float* __restrict_
                                                               float grad_scale, uint16_t* __restrict__ shadow,
                                                               int zero_grad, int* __restrict__ skip,
                                                               const uint16_t* __restrict__ wire,
-                                                              int* __restrict__ step_dev) {
+                                                              int* __restrict__ step_dev,
+                                                              const int* __restrict__ keep_grad) {
   const float lr = *lr_dev;
+  // keep_grad[t] != 0: tensor t's gradient is rewritten whole (beta = 0 stores) by its single producer in the next
+  // backward pass - not zeroed here (4 B / parameter less to write, and the producer does not read it back)
   if (skip && skip[0] != 0) {      // non-finite loss or gradient: leave p, m, v and the shadow alone, only clear the gradient
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skip + 1, 1);          // running count of skipped steps
     if (zero_grad)
       for (long c = blockIdx.x; c < n_chunks; c += gridDim.x)
-        reinterpret_cast<float4*>(grad)[c * OPT_CHUNK / 4 + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!keep_grad || !keep_grad[chunk_tensor[c]])
+          reinterpret_cast<float4*>(grad)[c * OPT_CHUNK / 4 + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
     return;
   }
   if (step_dev && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(step_dev, 1);   // (nobody reads it inside this launch)
   for (long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     float coef = grad_scale;
+    const int tensor = chunk_tensor[c];
     if (max_norm > 0.f) {
-      const float cc = max_norm / (norms[chunk_tensor[c]] + 1e-6f);
+      const float cc = max_norm / (norms[tensor] + 1e-6f);
       if (cc < 1.f) coef *= cc;
     }
     const long o = c * OPT_CHUNK / 4 + threadIdx.x;
@@ -130,20 +135,21 @@ __global__ __launch_bounds__(256) void bertadam_update_kernel(float* __restrict_
       s.y = (uint32_t)f2bf(p.z) | ((uint32_t)f2bf(p.w) << 16);
       reinterpret_cast<uint2*>(shadow)[o] = s;
     }
-    if (zero_grad) reinterpret_cast<float4*>(grad)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (zero_grad && !(keep_grad && keep_grad[tensor])) reinterpret_cast<float4*>(grad)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
 extern "C" int tell_opt_chunk(void) { return OPT_CHUNK; }
 
 // workspace `partial`: n_chunks floats; `norms`: n_tensors floats
-extern "C" int tell_bertadam_step(float* param, float* grad, float* m, float* v,
-                                  const int* chunk_tensor, const long* chunk_begin, long n_chunks,
-                                  int n_tensors, float* partial, float* norms, const float* lr_dev,
-                                  float b1, float b2, float eps, float wd, float max_norm,
-                                  float grad_scale, void* shadow_bf16, int zero_grad, int* skip,
-                                  const void* grad_wire_bf16, int* step_dev, float lr_base, float warmup, float t_total,
-                                  hipStream_t stream) {
+// keep_grad: device int32[n_tensors] or NULL - tensors whose gradient the zeroing leaves alone (see the kernel)
+extern "C" int tell_bertadam_step2(float* param, float* grad, float* m, float* v,
+                                   const int* chunk_tensor, const long* chunk_begin, long n_chunks,
+                                   int n_tensors, float* partial, float* norms, const float* lr_dev,
+                                   float b1, float b2, float eps, float wd, float max_norm,
+                                   float grad_scale, void* shadow_bf16, int zero_grad, int* skip,
+                                   const void* grad_wire_bf16, int* step_dev, float lr_base, float warmup, float t_total,
+                                   const int* keep_grad, hipStream_t stream) {
   if (n_chunks <= 0) return TELL_OK;
   if (step_dev)      // device-side schedule: this step's learning rate from the count of updates applied so far
     hipLaunchKernelGGL(lr_schedule_kernel, dim3(1), dim3(1), 0, stream, step_dev, lr_base, warmup, t_total,
@@ -156,8 +162,19 @@ extern "C" int tell_bertadam_step(float* param, float* grad, float* m, float* v,
     hipLaunchKernelGGL(sqsum_chunks_kernel, dim3(g), dim3(256), 0, stream, grad, wire, n_chunks, grad_scale, partial);
     hipLaunchKernelGGL(tensor_norms_kernel, dim3(n_tensors), dim3(256), 0, stream, partial, chunk_begin, n_tensors, norms, skip);
   }
-  hipLaunchKernelGGL(bertadam_update_kernel, dim3(g), dim3(256), 0, stream, param, grad, m, v, chunk_tensor, norms, n_chunks, lr_dev, b1, b2, eps, wd, max_norm, grad_scale, (uint16_t*)shadow_bf16, zero_grad, skip, wire, step_dev);
+  hipLaunchKernelGGL(bertadam_update_kernel, dim3(g), dim3(256), 0, stream, param, grad, m, v, chunk_tensor, norms, n_chunks, lr_dev, b1, b2, eps, wd, max_norm, grad_scale, (uint16_t*)shadow_bf16, zero_grad, skip, wire, step_dev, keep_grad);
   return tell_check_launch("bertadam_step");
+}
+extern "C" int tell_bertadam_step(float* param, float* grad, float* m, float* v,
+                                  const int* chunk_tensor, const long* chunk_begin, long n_chunks,
+                                  int n_tensors, float* partial, float* norms, const float* lr_dev,
+                                  float b1, float b2, float eps, float wd, float max_norm,
+                                  float grad_scale, void* shadow_bf16, int zero_grad, int* skip,
+                                  const void* grad_wire_bf16, int* step_dev, float lr_base, float warmup, float t_total,
+                                  hipStream_t stream) {
+  return tell_bertadam_step2(param, grad, m, v, chunk_tensor, chunk_begin, n_chunks, n_tensors, partial, norms, lr_dev, b1, b2,
+                             eps, wd, max_norm, grad_scale, shadow_bf16, zero_grad, skip, grad_wire_bf16, step_dev, lr_base,
+                             warmup, t_total, nullptr, stream);
 }
 
 // fill n floats with a value (grad zeroing without a memset node per tensor)

@@ -40,8 +40,14 @@ def as2dc(x):
     return x.reshape(-1, x.shape[-1]).contiguous()
 
 
-def grad_buffer(p):
-    """fp32 gradient accumulator of a parameter (== p.grad)."""
+_GRAD_STORE = {'on': False, 'observe': None}          # (see 'Gradient stores' below)
+
+
+def grad_buffer(p, _dense_writer=False):
+    """fp32 gradient accumulator of a parameter (== p.grad).  While the trainer observes a step (see _GRAD_STORE) every
+    caller but the dense weight-gradient sites counts as an ACCUMULATING writer: such a parameter keeps zero + accumulate."""
+    if not _dense_writer and _GRAD_STORE['observe'] is not None:
+        _GRAD_STORE['observe'].setdefault(id(p), (p, []))[1].append(None)
     if p.grad is None:
         g = getattr(p, '_tell_grad', None)
         if g is None or g.shape != p.shape or g.device != p.device:
@@ -57,6 +63,53 @@ def grad_buffer(p):
 # raw kernels
 # --------------------------------------------------------------------------- #
 _SPLITK = os.environ.get('TELL_GEMM_SKINNY_SPLITK', '1') != '0'          # A/B aid
+
+
+# Gradient stores (round 4).  The flat gradient buffer starts every step zeroed and the backward kernels accumulate into
+# it - for a weight whose gradient is ONE dense product per step that is 4 B / parameter of zeros read back by the product
+# and 4 B / parameter of zeros written by the optimizer.  The trainer OBSERVES its first eager step (who writes which
+# rows of which parameter through wgrad_target / note_grad_write); parameters written exactly once, whole, get
+# `_tell_grad_store`: from then on their product stores (accumulate = 0) and BertAdam leaves their gradient alone
+# (tell_bertadam_step2 keep_grad).  Everything else - tied tables, biases, LayerNorm parameters, scatter-added
+# embeddings - keeps the zero + accumulate convention.
+
+
+def grad_store_on():
+    return _GRAD_STORE['on']
+
+
+def grad_store_mode(on):
+    _GRAD_STORE['on'] = bool(on)
+
+
+def grad_store_observe(start):
+    """start=True: begin recording gradient writes; start=False: stop and return {id(p): (p, [(r0, r1), ...])}."""
+    if start:
+        _GRAD_STORE['observe'] = {}
+        return None
+    seen, _GRAD_STORE['observe'] = _GRAD_STORE['observe'], None
+    return seen or {}
+
+
+def note_grad_write(p, rows=None):
+    """A backward product is about to write rows [r0, r1) (default: all) of p's gradient, densely."""
+    obs = _GRAD_STORE['observe']
+    if obs is not None:
+        n = p.shape[0]
+        obs.setdefault(id(p), (p, []))[1].append((0, n) if rows is None else (int(rows[0]), int(rows[1])))
+
+
+def grad_stored(p):
+    """True: p's gradient is stored by its single producer this step (no accumulate, not zeroed by the optimizer)."""
+    return _GRAD_STORE['on'] and getattr(p, '_tell_grad_store', False)
+
+
+def wgrad_target(p, rows=None):
+    """-> (rows of p's flat gradient as [rows, fan_in], accumulate flag) for a dense weight-gradient product."""
+    gw = grad_buffer(p, True)
+    gw2 = gw.view(gw.shape[0], -1)
+    note_grad_write(p, rows)
+    return (gw2 if rows is None else gw2[rows[0]:rows[1]]), not grad_stored(p)
 
 
 def gemm(a, b, out=None, out_dtype=None, bias=None, bias_mode=0, act=0, aux=None, alpha=1.0,
@@ -224,15 +277,18 @@ def gemm_nn(a, b_kn, b_t=None, out=None, out_dtype=None, alpha=1.0, act=0, aux=N
     K, N = b_kn.shape                  # `a` may carry zero padding columns beyond K (never garbage: 0 * NaN)
     assert a.shape[1] >= K
     big = ((M + 127) // 128) * ((N + 127) // 128) >= 256 and K % 64 == 0     # direct-to-LDS NT kernel territory
-    if (_SPLITK and K >= 8192 and N <= 256 and N % 4 == 0 and _kmajor_ok(b_kn) and a.dtype == torch.bfloat16 and
+    if (_SPLITK and K >= 8192 and N <= 1024 and M <= 1024 and N % 4 == 0 and _kmajor_ok(b_kn) and a.dtype == torch.bfloat16 and
             a.stride(1) == 1 and a.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and a.shape[1] >= _round_up(K, 8) and
             act == 0 and aux is None and not accumulate and (out is None or out.stride(0) % 4 == 0)):
         # few output columns from a very long reduction (the adaptive-softmax tails' dh = dlogits . W: [1024, 64] from
         # K = 30265): 16-64 output tiles walking hundreds of K tiles each (162 us).  K slices as one grouped launch
         # of fp32 partial tiles + the fold.  (Rows past *m_dev are computed too: they are zeros in, zeros out.)
+        # With adaptive_softmax_factor 1 (the bench configuration) the tails keep the model width: [1024, 1024] from
+        # K = 15000 / 30265 is 256 tiles of 64x64 walking 235 / 473 K tiles (97 / 158 us); wider slices keep the fp32
+        # partials at 8-16 MB.
         if out is None:
             out = torch.empty(M, N, dtype=out_dtype or a.dtype, device=a.device)
-        ks = 2048
+        ks = 2048 if N <= 256 else 8192
         splits = (K + ks - 1) // ks
         partial = torch.empty(splits, M, N, dtype=torch.float32, device=a.device)
         gemm_grouped([dict(a=a[:, i * ks:min(_round_up(K, 8), (i + 1) * ks)], b=b_kn[i * ks:min(K, (i + 1) * ks)],
@@ -493,18 +549,22 @@ def wn_drop():
 
 def wn_flush():
     items, _WN_PENDING['items'] = _WN_PENDING['items'], []
-    if not items:
-        return
-    if len(items) == 1:
-        dW, g, v, norms = items[0]
-        call('tell_wn_backward', dW, g.detach(), v.detach(), norms, v.shape[0], v.shape[1], grad_buffer(g),
-             grad_buffer(v))
-        return
-    call('tell_wn_backward_multi', len(items), _ptr_array([i[0] for i in items]),
+    if items:
+        _wn_backward(items)
+
+
+def _wn_backward(items):
+    """dW -> dg, dv of [(dW, g, v, norms)] in one launch."""
+    for _, g, v, _ in items:
+        note_grad_write(g)
+        note_grad_write(v)
+    # dg / dv of a GehringLinear used once per step are stored, not accumulated (see _GRAD_STORE)
+    store = [int(grad_stored(g) and grad_stored(v)) for _, g, v, _ in items]
+    call('tell_wn_backward_multi2', len(items), _ptr_array([i[0] for i in items]),
          _ptr_array([i[1].detach() for i in items]), _ptr_array([i[2].detach() for i in items]),
          _ptr_array([i[3] for i in items]), _int_array([i[2].shape[0] for i in items]),
-         _int_array([i[2].shape[1] for i in items]), _ptr_array([grad_buffer(i[1]) for i in items]),
-         _ptr_array([grad_buffer(i[2]) for i in items]))
+         _int_array([i[2].shape[1] for i in items]), _ptr_array([grad_buffer(i[1], True) for i in items]),
+         _ptr_array([grad_buffer(i[2], True) for i in items]), _int_array(store))
 
 
 def wn_weight_t(g, v):
@@ -651,12 +711,11 @@ class LinearFn(Function):
         if w_param.requires_grad or gb is not None:
             def job(gb=gb):
                 if w_param.requires_grad:
-                    gw = grad_buffer(w_param)
-                    gw2 = gw.view(gw.shape[0], -1)[r0:r1]
+                    gw2, acc = wgrad_target(w_param, rows)
                     if x_t is not None:              # fp32 parity mode: the caller shared one transpose of x
-                        gemm(transpose(dy2)[0], x_t, out=gw2, alpha=alpha, accumulate=True)
+                        gemm(transpose(dy2)[0], x_t, out=gw2, alpha=alpha, accumulate=acc)
                     else:                            # the bias gradient rides on the wgrad GEMM's A tiles
-                        gemm_tn(dy2, x2, out=gw2, alpha=alpha, accumulate=True, asum=gb, asum_scale=alpha)
+                        gemm_tn(dy2, x2, out=gw2, alpha=alpha, accumulate=acc, asum=gb, asum_scale=alpha)
                         gb = None
                 if gb is not None:
                     colsum_into(dy2, gb, scale=alpha)
@@ -713,9 +772,8 @@ class GroupedLinearFn(Function):
                 gb = grad_buffer(b_param)
                 gb = gb if b_rows is None else gb[b_rows[0]:b_rows[1]]
             if w_param.requires_grad:
-                gw = grad_buffer(w_param)
-                gemm_tn(dy2, x2, out=gw.view(gw.shape[0], -1)[r0:r1], alpha=alpha, accumulate=True, asum=gb,
-                        asum_scale=alpha)
+                gw2, acc = wgrad_target(w_param, rows)
+                gemm_tn(dy2, x2, out=gw2, alpha=alpha, accumulate=acc, asum=gb, asum_scale=alpha)
             elif gb is not None:
                 colsum_into(dy2, gb, scale=alpha)
             if need_dx:
@@ -783,18 +841,10 @@ class KVLinearFn(Function):
         dy2 = as2d(dy)
         gb = grad_buffer(b_param)[E:3 * E] if b_param.requires_grad else None
         if wk.requires_grad:
-            def rows_of(p, r):
-                g = grad_buffer(p)
-                g = g.view(g.shape[0], -1)
-                return g if r is None else g[r[0]:r[1]]
-            gk, gv = rows_of(wk, rk), rows_of(wv, rv)
+            (gk, acc_k), (gv, acc_v) = wgrad_target(wk, rk), wgrad_target(wv, rv)
 
             def job(gb=gb):
-                if _adjacent(gk, gv):
-                    gemm_tn(dy2, x2, out=_stacked(gk, gv), accumulate=True, asum=gb)
-                else:
-                    gemm_tn(dy2[:, :E], x2, out=gk, accumulate=True, asum=None if gb is None else gb[:E])
-                    gemm_tn(dy2[:, E:], x2, out=gv, accumulate=True, asum=None if gb is None else gb[E:])
+                kv_wgrad(dy2, x2, gk, acc_k, gv, acc_v, gb, E)
             wgrad_job(job, dy2, x2)
         elif gb is not None:
             colsum_into(dy2, gb)
@@ -806,6 +856,16 @@ class KVLinearFn(Function):
             dx = gemm_nn(dy2, w, b_t=lambda: _cached(wk, ('kv_t', rk, id(wv), wv._version), lambda: transpose(w)[0]))
             dx = dx.reshape(xshape) if dx.is_contiguous() else dx.contiguous().view(xshape)
         return dx, None, None, None, None, None, None, None
+
+
+def kv_wgrad(dy2, x2, gk, acc_k, gv, acc_v, gb, E):
+    """Weight gradients of a stacked K / V projection: one product when the two gradient row blocks are neighbours in
+    the flat buffer (and agree on accumulate / store), else two."""
+    if _adjacent(gk, gv) and acc_k == acc_v:
+        gemm_tn(dy2, x2, out=_stacked(gk, gv), accumulate=acc_k, asum=gb)
+    else:
+        gemm_tn(dy2[:, :E], x2, out=gk, accumulate=acc_k, asum=None if gb is None else gb[:E])
+        gemm_tn(dy2[:, E:], x2, out=gv, accumulate=acc_v, asum=None if gb is None else gb[E:])
 
 
 def kv_linear(x, wk, rk, wv, rv, b_param, E):
@@ -844,8 +904,7 @@ class WNLinearFn(Function):
                     if _WN_PENDING['defer']:
                         _WN_PENDING['items'].append((dW, g, v, norms))
                     else:
-                        call('tell_wn_backward', dW, g.detach(), v.detach(), norms, v.shape[0], v.shape[1],
-                             grad_buffer(g), grad_buffer(v))
+                        _wn_backward([(dW, g, v, norms)])
                 if gb is not None:
                     colsum_into(dy2, gb)
             wgrad_job(job, dy2, x2)
@@ -866,8 +925,7 @@ def wn_wgrad(dy2, x2, g, v, b, norms):
         if _WN_PENDING['defer']:
             _WN_PENDING['items'].append((dW, g, v, norms))
         else:
-            call('tell_wn_backward', dW, g.detach(), v.detach(), norms, v.shape[0], v.shape[1], grad_buffer(g),
-                 grad_buffer(v))
+            _wn_backward([(dW, g, v, norms)])
     elif gb is not None:
         colsum_into(dy2, gb)
 
@@ -880,8 +938,8 @@ def linear_wgrad(dy2, x2, w_param, rows=None, b_param=None, b_rows=None, alpha=1
         gb = grad_buffer(b_param)
         gb = gb if b_rows is None else gb[b_rows[0]:b_rows[1]]
     if w_param.requires_grad:
-        gw = grad_buffer(w_param)
-        gemm_tn(dy2, x2, out=gw.view(gw.shape[0], -1)[r0:r1], alpha=alpha, accumulate=True, asum=gb, asum_scale=alpha)
+        gw2, acc = wgrad_target(w_param, rows)
+        gemm_tn(dy2, x2, out=gw2, alpha=alpha, accumulate=acc, asum=gb, asum_scale=alpha)
     elif gb is not None:
         colsum_into(dy2, gb, scale=alpha)
 

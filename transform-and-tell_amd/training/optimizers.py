@@ -64,6 +64,10 @@ class FlatParams:
             for p, o in zip(self.params, offs):
                 p._tell_shadow = self.shadow[o:o + p.numel()].view(p.shape)
             self.refresh_shadow()
+        # tensors whose gradient the optimizer's zeroing leaves alone (their single dense producer stores over it:
+        # ops.py 'Gradient stores'); all zero until the trainer has observed a step (set_grad_store)
+        self.keep_grad = torch.zeros(max(len(self.params), 1), dtype=torch.int32, device=device)
+        self.stored_numel = 0
         self.partial = torch.empty(max(self.n_chunks, 1), dtype=torch.float32, device=device)
         self.norms = torch.zeros(len(self.params), dtype=torch.float32, device=device)
         rt.bump_weights_epoch()
@@ -78,6 +82,27 @@ class FlatParams:
 
     def zero_grad(self):
         hip.call('tell_fill_f32', self.grad, self.total, 0.0)
+
+    def set_grad_store(self, seen):
+        """seen: ops.grad_store_observe(False) of one whole backward pass - {id(p): (p, [(r0, r1) | None, ...])}, a None
+        entry being an accumulating writer.  A parameter whose gradient rows were written exactly once each, by dense
+        products only, is marked `_tell_grad_store` (and kept out of the optimizer's zeroing).  -> elements marked."""
+        flags = []
+        for p in self.params:
+            e = seen.get(id(p))
+            ok = e is not None and e[0] is p and len(e[1]) > 0 and all(w is not None for w in e[1])
+            if ok:
+                pos = 0
+                for r0, r1 in sorted(e[1]):
+                    ok = ok and r0 == pos
+                    pos = r1
+                ok = ok and pos == p.shape[0]
+            p._tell_grad_store = bool(ok)
+            flags.append(int(ok))
+        if flags:
+            self.keep_grad.copy_(torch.tensor(flags, dtype=torch.int32))
+        self.stored_numel = sum(p.numel() for p, f in zip(self.params, flags) if f)
+        return self.stored_numel
 
     def numel(self):
         return sum(p.numel() for p in self.params)
@@ -125,10 +150,12 @@ class BertAdam:
         """grad_wire: optional bf16 copy of the whole flat gradient (the data-parallel exchange's wire buffer after the
         all-reduce): the kernels read it in place of flat.grad - no pass that widens it back first."""
         f = self.flat
-        hip.call('tell_bertadam_step', f.flat, f.grad, f.m, f.v, f.chunk_tensor, f.chunk_begin, f.n_chunks,
+        from .. import ops
+        keep = f.keep_grad if (zero_grad and ops.grad_store_on()) else None
+        hip.call('tell_bertadam_step2', f.flat, f.grad, f.m, f.v, f.chunk_tensor, f.chunk_begin, f.n_chunks,
                  len(f.params), f.partial, f.norms, self.lr_dev, self.b1, self.b2, self.e, self.weight_decay,
                  self.max_grad_norm, float(grad_scale), f.shadow, int(zero_grad), skip, grad_wire,
-                 self.step_dev, float(self.lr), float(self.warmup), float(self.t_total))
+                 self.step_dev, float(self.lr), float(self.warmup), float(self.t_total), keep)
 
     def advance(self):
         """Host part after the kernels.  The host cannot see a device-side skip without a synchronisation, so it bumps

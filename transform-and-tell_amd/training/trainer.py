@@ -90,6 +90,11 @@ class Trainer:
         self.async_update = async_update and torch.device(device).type == 'cuda'
         self.update_stream = streams.get('update', device) if self.async_update else None
         self.flat.zero_grad()
+        # gradient stores (ops.py): the first eager backward pass is observed, parameters with one dense whole-tensor
+        # gradient write per step are then stored by their producer and left alone by BertAdam's zeroing.
+        # TELL_GRAD_STORE=0: everything keeps zero + accumulate.
+        self._store = 'want' if (torch.device(device).type == 'cuda' and
+                                 os.environ.get('TELL_GRAD_STORE', '1') != '0') else 'off'
         self.model.register_state_dict_pre_hook(lambda *a, **k: self.finish_update())
         # DP: the gradients of a decoder layer are final when backward leaves the layer (ops.grad_ready_marker); their
         # slice of the flat buffer is handed to RCCL right then (cast to the wire dtype on the backward stream, the
@@ -220,9 +225,20 @@ class Trainer:
                 out[key] = grow(t, 1, rows, float('nan'))
         return batch if out is None else out
 
+    def _grad_store_begin(self):
+        """Select this step's gradient convention.  Store mode needs an update after every backward pass (micro-batch
+        accumulation - defer_update - adds into the buffer); leaving it, the stored gradients of the last step are
+        still in the buffer and have to go."""
+        want = self._store == 'ready' and not self.defer_update
+        if want != ops.grad_store_on():
+            if not want:
+                self.flat.zero_grad()
+            ops.grad_store_mode(want)
+
     def _train_one_batch(self, batch, next_batch=None):
         if not self.model.training:              # (recursing through ~650 modules costs 2.5 ms of host time)
             self.model.train()                   # (:214 zero_grad: done right after the previous update)
+        self._grad_store_begin()
         batch = self._bucketed(batch)
         if next_batch is not None:
             next_batch = self._bucketed(next_batch)
@@ -255,12 +271,17 @@ class Trainer:
         ops.wn_defer(not self._ranges)
         ops.wgrad_group_defer(not self._ranges)                          # ... and so do the weight-gradient GEMMs
         ops.finish_defer(not self._ranges)                               # ... and the small column-sum finishers
+        observe = self._store == 'want' and not self._capturing
+        if observe:
+            ops.grad_store_observe(True)
         try:
             scaled.backward()                                            # :229-231
         except BaseException:
             ops.wn_drop()
             ops.wgrad_group_drop()
             ops.finish_drop()
+            if observe:
+                ops.grad_store_observe(False)
             raise
         finally:
             self._in_backward = False
@@ -271,6 +292,14 @@ class Trainer:
         ops.wgrad_group_flush()
         ops.wn_flush()
         ops.finish_flush()
+        if observe:
+            # the gradients in the buffer are complete and were accumulated onto zeros: the convention can change right
+            # here - this step's update already leaves the marked tensors alone, the next pass stores over them.  (Every
+            # graph is captured after this point: the convention a signature is captured with follows from defer_update,
+            # which is part of the signature.)
+            self.flat.set_grad_store(ops.grad_store_observe(False))
+            self._store = 'ready'
+            ops.grad_store_mode(not self.defer_update)
 
     def skipped_steps(self):
         """Number of optimisation steps the device-side NaN / Inf check turned into no-ops so far (one host sync)."""
