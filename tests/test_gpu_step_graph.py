@@ -72,6 +72,62 @@ def test_step_graph_equals_eager(kind, dtype):
     assert b.n_batches == a.n_batches == 7
 
 
+@pytest.mark.parametrize('graph', [False, True])
+def test_gradient_stores_equal_zero_and_accumulate(graph, monkeypatch):
+    """ops.py 'Gradient stores': after the observed first step the weight matrices with one dense gradient product per
+    step are STORED by that product and skipped by BertAdam's zeroing (tell_bertadam_step2 keep_grad,
+    tell_wn_backward_multi2 store flags).  0 + x = x: a trainer with TELL_GRAD_STORE=0 (zero + accumulate everywhere) must
+    produce the same weights, eager and through graph replays, and leaving the convention (micro-batch accumulation,
+    defer_update) must start from a clean buffer."""
+    import tell_amd
+    from tell_amd.build import build_model
+    from tell_amd.data import synthetic_batch
+    from tell_amd.training import Trainer
+    tell_amd.set_compute_dtype(torch.float32)
+    torch.manual_seed(0)
+    a = build_model('faces_objects', _Res(True), _Rob(1024), n_bert_layers=3, **KW)
+    _no_dropout(a)
+    for m in a.modules():
+        if isinstance(getattr(m, 'dropout', None), float):
+            m.dropout = 0.0
+    b = copy.deepcopy(a)
+    ocfg = dict(lr=5e-3, warmup=0.5, t_total=12, b1=0.9, b2=0.98, e=1e-6, weight_decay=1e-5, max_grad_norm=0.1)
+    monkeypatch.setenv('TELL_GRAD_STORE', '0')
+    ta = Trainer(a, dict(ocfg), device=DEV)
+    monkeypatch.setenv('TELL_GRAD_STORE', '1')
+    tb = Trainer(b, dict(ocfg), device=DEV)
+    if not graph:
+        ta.step_graph = tb.step_graph = None
+    batch = _dev(synthetic_batch(B=3, article_len=20, caption_len=9, faces_objects=True, vocab=600, cutoffs=(100, 300),
+                                 seed=61))
+    for s in range(6):
+        la, lb = ta.train_one_batch(_clone(batch)), tb.train_one_batch(_clone(batch))
+        assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(la)), (s, float(la), float(lb))
+    assert ta._store == 'off' and ta.flat.stored_numel == 0 and float(ta.flat.grad.abs().max()) == 0.0
+    assert tb._store == 'ready' and tb.flat.stored_numel > 0.3 * tb.flat.numel()      # weight matrices are most of the decoder
+    names = dict(zip(tb.flat.names, tb.flat.params))
+    stored = {n for n, p in names.items() if getattr(p, '_tell_grad_store', False)}
+    assert any(n.endswith('weight_v') for n in stored) and any('in_proj_weight' in n or 'q_proj' in n for n in stored)
+    # tied tables, biases and LayerNorm parameters have accumulating writers: never stored
+    assert not any(n.endswith('bias') or 'layer_norm' in n.lower() or 'embed' in n for n in stored), sorted(stored)[:20]
+    num = float((ta.flat.flat - tb.flat.flat).norm())
+    assert num <= 1e-6 * float(ta.flat.flat.norm()), num
+    if graph:
+        assert tb.step_graph.replays == 5
+    # leaving the convention: the stored gradients of the last step are still in the buffer and must not be added to
+    ta.defer_update = tb.defer_update = True
+    for _ in range(2):                               # two micro-batches accumulate
+        ta.train_one_batch(_clone(batch))
+        tb.train_one_batch(_clone(batch))
+    ga, gb = ta.flat.grad, tb.flat.grad
+    assert float(ga.abs().max()) > 0 and float((ga - gb).norm()) <= 1e-6 * float(ga.norm())
+    ta.defer_update = tb.defer_update = False
+    ta.flat.zero_grad(); tb.flat.zero_grad()
+    la, lb = ta.train_one_batch(_clone(batch)), tb.train_one_batch(_clone(batch))      # and back into it
+    assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(la))
+    assert float((ta.flat.flat - tb.flat.flat).norm()) <= 1e-6 * float(ta.flat.flat.norm())
+
+
 def test_step_graph_draws_fresh_dropout_masks():
     """lr = 0 keeps the weights fixed: replaying the same batch must still give different losses, because every replay
     adds the graph's device step counter to the dropout salts."""

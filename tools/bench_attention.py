@@ -2,7 +2,7 @@
 attention dropout 0.1 as the reference leaves the hub model in train mode) forward, and the decoder's four context
 attentions forward + backward (T = 32 queries; article 512 keys, image 49, faces 4, objects 64).  Reports device time
 per launch (10 launches per hipGraph) and the MFMA rate on 4 T S D flops per (b, h) forward."""
-import os, sys, torch
+import os, statistics, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tell_amd
 from tell_amd import hip
@@ -11,18 +11,24 @@ REP = 10
 
 
 def timed(fn):
+    """Median of 5 timed batches of 5 x 10 launches, after 2 untimed ones (an idle GPU's clocks settle over tens of
+    milliseconds of load: the first kernel measured from cold read 10-15 % slow)."""
     fn(); torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g), hip.bound_stream():
         for _ in range(REP):
             fn()
     g.replay(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
-        g.replay()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / (10 * REP)
+    ts = []
+    for r in range(7):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            g.replay()
+        e1.record(); torch.cuda.synchronize()
+        if r >= 2:
+            ts.append(e0.elapsed_time(e1) * 1e3 / (5 * REP))
+    return statistics.median(ts)
 
 
 def case(name, B, H, T, S, D, p, bias, backward):

@@ -19,3 +19,12 @@ for b in 1 4; do python bench.py --generate --beam $b 2>/dev/null | tail -1 > gp
 python bench.py 2> gpurun_out/r04_bench.err | tail -1 > gpurun_out/r04_bench.json
 python tools/bench_dynconv.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_dynconv.txt
 bash tools/pmc_kernel.sh gemm_nt_q4 gpurun_out/r04_pmc_gemm_mfma.txt SQ_BUSY_CYCLES,SQ_ACTIVE_INST_ANY,SQ_ACTIVE_INST_VALU,SQ_ACTIVE_INST_LDS,SQ_INST_CYCLES_VMEM,SQ_VALU_MFMA_BUSY_CYCLES,SQ_WAVE_CYCLES,SQ_WAIT_ANY -- python tools/bench_roberta_gemms.py > /dev/null
+LDSC=SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE,SQ_INSTS_LDS,SQ_INST_CYCLES_VMEM,SQ_WAVE_CYCLES,SQ_WAIT_INST_LDS,SQ_VALU_MFMA_BUSY_CYCLES,SQ_BUSY_CYCLES
+TELL_GEMM_Q4=0 bash tools/pmc_kernel.sh gemm_nt_pp2 gpurun_out/r04_pmc_gemm_lds_pp2.txt $LDSC -- python tools/bench_roberta_gemms.py > /dev/null
+TELL_GEMM_Q4E=0 bash tools/pmc_kernel.sh gemm_nt_q4 gpurun_out/r04_pmc_gemm_lds_q4.txt $LDSC -- python tools/bench_roberta_gemms.py > /dev/null
+{ echo "# LDS counters of the dominant GEMM over RoBERTa's projection shapes (python tools/bench_roberta_gemms.py), rocprofv3 --pmc, per-dispatch averages"
+  echo "# round 3 ping-pong kernel (TELL_GEMM_Q4=0):"; cat gpurun_out/r04_pmc_gemm_lds_pp2.txt
+  echo; echo "# round 4 four-wave kernel (TELL_GEMM_Q4E=0 so that every launch is gemm_nt_q4_kernel):"; cat gpurun_out/r04_pmc_gemm_lds_q4.txt; } > gpurun_out/r04_pmc_gemm_lds.txt
+bash tools/pmc_generate_traffic.sh 1 gpurun_out/r04_pmc_generate_greedy_traffic.json > /dev/null 2>&1
+bash tools/pmc_generate_traffic.sh 4 gpurun_out/r04_pmc_generate_beam4_traffic.json > /dev/null 2>&1
+python tools/probes/q4_variants.py 5 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_q4_variants.txt

@@ -270,19 +270,22 @@ def _launch_wgrad_group(items):
                   for a, b, out, alpha, acc, asum, asum_scale in items])
 
 
-def gemm_nn(a, b_kn, b_t=None, out=None, out_dtype=None, alpha=1.0, act=0, aux=None, m_dev=None, accumulate=False):
+def gemm_nn(a, b_kn, b_t=None, out=None, out_dtype=None, alpha=1.0, act=0, aux=None, m_dev=None, accumulate=False,
+            zero_rows=False):
     """out[M,N] = act(alpha * a[M,K] @ b_kn[K,N]) (+ out) (dgrad: a = dY, b_kn = the weight as stored [N_out, K_in]).
-    `b_t`: callable returning b_kn^T [N, K] for the fallback path."""
+    `b_t`: callable returning b_kn^T [N, K] for the fallback path.  m_dev: device row count - rows past it are left
+    untouched; zero_rows=True: the caller guarantees that those rows of `a` are zero and may be written (as zeros)."""
     M = a.shape[0]
     K, N = b_kn.shape                  # `a` may carry zero padding columns beyond K (never garbage: 0 * NaN)
     assert a.shape[1] >= K
     big = ((M + 127) // 128) * ((N + 127) // 128) >= 256 and K % 64 == 0     # direct-to-LDS NT kernel territory
     if (_SPLITK and K >= 8192 and N <= 1024 and M <= 1024 and N % 4 == 0 and _kmajor_ok(b_kn) and a.dtype == torch.bfloat16 and
             a.stride(1) == 1 and a.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and a.shape[1] >= _round_up(K, 8) and
-            act == 0 and aux is None and not accumulate and (out is None or out.stride(0) % 4 == 0)):
+            act == 0 and aux is None and not accumulate and (out is None or out.stride(0) % 4 == 0) and
+            (m_dev is None or zero_rows)):
         # few output columns from a very long reduction (the adaptive-softmax tails' dh = dlogits . W: [1024, 64] from
         # K = 30265): 16-64 output tiles walking hundreds of K tiles each (162 us).  K slices as one grouped launch
-        # of fp32 partial tiles + the fold.  (Rows past *m_dev are computed too: they are zeros in, zeros out.)
+        # of fp32 partial tiles + the fold.  (Rows past *m_dev are computed too - zero_rows: zeros in, zeros out.)
         # With adaptive_softmax_factor 1 (the bench configuration) the tails keep the model width: [1024, 1024] from
         # K = 15000 / 30265 is 256 tiles of 64x64 walking 235 / 473 K tiles (97 / 158 us); wider slices keep the fp32
         # partials at 8-16 MB.
@@ -1685,7 +1688,7 @@ class AdaptiveLossFn(Function):
             call('tell_ce_bwd', logits, logits.stride(0), N, V, part['local'][band], None, cnt, int(pad_idx),
                  lse_t, gscale, dlt, dlt.stride(0), hip.dt(dtype))
             dh = zs[2 + 2 * i]
-            gemm_nn(dlt, weight(emb), b_t=lambda emb=emb: weight_t(emb), out=dh, m_dev=cnt)
+            gemm_nn(dlt, weight(emb), b_t=lambda emb=emb: weight_t(emb), out=dh, m_dev=cnt, zero_rows=True)
             if emb.requires_grad:                                  # rows >= count of dlt are zero
                 gemm_tn(dlt[:, :V], h, out=grad_buffer(emb), accumulate=True)
             if proj.requires_grad:

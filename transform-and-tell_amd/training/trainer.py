@@ -93,6 +93,7 @@ class Trainer:
         # gradient stores (ops.py): the first eager backward pass is observed, parameters with one dense whole-tensor
         # gradient write per step are then stored by their producer and left alone by BertAdam's zeroing.
         # TELL_GRAD_STORE=0: everything keeps zero + accumulate.
+        self._stored_last = False                # the buffer holds gradients that the last update did not zero
         self._store = 'want' if (torch.device(device).type == 'cuda' and
                                  os.environ.get('TELL_GRAD_STORE', '1') != '0') else 'off'
         self.model.register_state_dict_pre_hook(lambda *a, **k: self.finish_update())
@@ -230,12 +231,18 @@ class Trainer:
         accumulation - defer_update - adds into the buffer); leaving it, the stored gradients of the last step are
         still in the buffer and have to go."""
         want = self._store == 'ready' and not self.defer_update
-        if want != ops.grad_store_on():
-            if not want:
-                self.flat.zero_grad()
-            ops.grad_store_mode(want)
+        if self._stored_last and not want:       # (this trainer's own history: the switch in ops.py is process-wide)
+            self.flat.zero_grad()
+        self._stored_last = want
+        ops.grad_store_mode(want)
 
     def _train_one_batch(self, batch, next_batch=None):
+        try:
+            return self._train_one_batch_body(batch, next_batch)
+        finally:
+            ops.grad_store_mode(False)           # outside a trainer step every backward pass accumulates
+
+    def _train_one_batch_body(self, batch, next_batch=None):
         if not self.model.training:              # (recursing through ~650 modules costs 2.5 ms of host time)
             self.model.train()                   # (:214 zero_grad: done right after the previous update)
         self._grad_store_begin()
@@ -299,7 +306,8 @@ class Trainer:
             # which is part of the signature.)
             self.flat.set_grad_store(ops.grad_store_observe(False))
             self._store = 'ready'
-            ops.grad_store_mode(not self.defer_update)
+            self._stored_last = not self.defer_update
+            ops.grad_store_mode(self._stored_last)
 
     def skipped_steps(self):
         """Number of optimisation steps the device-side NaN / Inf check turned into no-ops so far (one host sync)."""
