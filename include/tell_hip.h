@@ -349,6 +349,14 @@ int tell_dynconv_fwd(const void* x, const void* logits, void* y, float* taps, in
 int tell_dynconv_bwd(const void* x, const void* dy, const float* taps, void* dx, int dx_accumulate,
                      void* dlogits, int T, int B, int H, int K, int R, float p, uint32_t seed, uint32_t salt,
                      int dtype, tell_stream_t stream);
+/* The core of the decoder's conv block as one launch (decoder_faces_objects.py:259-261 GLU + dynamic.py:300-336):
+ * h1 [T*B, 2E] bf16 = linear1's output (a | gate), w_tap [H*K, E] bf16 = DynamicConv.weight_linear (no bias) ->
+ * gl = GLU(h1) [T*B, E], y [T*B, E], taps [T*B*H, K] fp32 (softmax of the tap logits, before DropConnect: what
+ * tell_dynconv_bwd reads).  Replaces tell_glu_fwd + the tap-logit tell_gemm_nt + tell_dynconv_fwd; the logits stay
+ * fp32 on the chip.  Returns 1 (nothing launched) for shapes it does not take: bf16 only, T <= 32, K <= 32, head
+ * width 64, E = 1024. */
+int tell_dynconv_block_fwd(const void* h1, const void* w_tap, void* gl, void* y, float* taps, int T, int B, int H,
+                           int K, float p, uint32_t seed, uint32_t salt, tell_stream_t stream);
 
 /* ---- MultiHeadAttention core, tell/modules/attention/multi_head.py:376-475
  * element (b,h,t,d) of q at q + t*q_st + b*q_sb + h*D + d (k, v, out likewise);

@@ -551,6 +551,45 @@ def test_dynamic_conv_full_size_dropconnect(dtype, T, K):
     close(ld.grad, lc.grad, dtype, scale=2)
 
 
+@pytest.mark.parametrize('T,B,K,p', [(32, 32, 31, 0.1), (32, 16, 3, 0.0), (17, 8, 15, 0.1), (5, 4, 31, 0.1), (32, 3, 7, 0.1)])
+def test_dynconv_block_fused_forward(T, B, K, p):
+    """tell_dynconv_block_fwd: GLU + tap logits + tap softmax + DropConnect + K-tap sum of the decoder's conv block
+    (decoder_faces_objects.py:259-261, dynamic.py:300-336) in one launch.  gl must be what tell_glu_fwd writes, bit for
+    bit; taps and y are checked against the oracle fed with that gl, fp32 logits (the kernel never rounds them) and the
+    DropConnect mask of the RNG restatement; shapes it does not take are declined, not approximated."""
+    from tell_amd import hip, rng
+    from oracle import functional as OF
+    E, H = 1024, 16
+    g = torch.Generator().manual_seed(T * 100 + K)
+    h1 = torch.randn(T * B, 2 * E, generator=g).bfloat16().to(DEV)
+    wt = (torch.randn(H * K, E, generator=g) * 0.05).bfloat16().to(DEV)
+    gl = torch.full((T * B, E), 7.0, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty_like(gl)
+    taps = torch.empty(T * B * H, K, device=DEV)
+    assert hip.call_rc('tell_dynconv_block_fwd', h1, wt, gl, y, taps, T, B, H, K, p, 9, 101) == 0
+    gl_ref = torch.empty_like(gl)
+    hip.call('tell_glu_fwd', h1, gl_ref, T * B, E, hip.BF16)
+    assert torch.equal(gl, gl_ref)
+    x = gl.float().cpu().view(T, B, E)
+    logits = (gl.float() @ wt.float().t()).cpu().view(T, B, H * K)
+    mask = torch.from_numpy(rng.keep_mask(9, 101, T * B * H * K, p)).view(T, B, H, K) if p > 0 else None
+    w_ref = torch.softmax(logits.view(T, B, H, K), dim=-1)
+    assert (taps.cpu().view(T, B, H, K) - w_ref).abs().max() < 2e-5
+    ref = OF.dynamic_conv_apply(x, OF.dynamic_conv_taps(logits, H, K, mask, p))
+    close(y.view(T, B, E), ref, torch.bfloat16)
+    # the three-launch path on the same inputs (its logits pass through bf16): same mask, same numbers to that rounding
+    lg16 = (gl @ wt.t())
+    y3, taps3 = torch.empty_like(gl), torch.empty_like(taps)
+    hip.call('tell_dynconv_fwd', gl, lg16, y3, taps3, T, B, H, K, 64, p, 9, 101, hip.BF16)
+    assert (taps3 - taps).abs().max() < 2e-2 and (y3.float() - y.float()).norm() <= 1e-2 * y.float().norm()
+    if p > 0:                                              # dropped taps are the same taps: zeros in y line up
+        assert ((y3 == 0) == (y == 0)).float().mean() > 0.999
+    # declined: longer captions, wider kernels, other widths
+    assert hip.call_rc('tell_dynconv_block_fwd', h1, wt, gl, y, taps, 33, 1, H, K, p, 9, 101) == 1
+    assert hip.call_rc('tell_dynconv_block_fwd', h1, wt, gl, y, taps, T, B, 8, K, p, 9, 101) == 1
+    assert hip.call_rc('tell_dynconv_block_fwd', h1, wt, gl, y, taps, T, B, H, 33, p, 9, 101) == 1
+
+
 # ------------------------------------------------------------------ attention
 def _attn_case(dtype, T, B, E, H, S, kdim, use_mask, p, seed, has_bias=True):
     import tell_amd

@@ -37,3 +37,26 @@ for K in (3, 7, 15, 31):
     bb = T * B * ((3 * C + H * K) * 2 + H * K * 4)        # x, dy read, dx written, dlogits written, fp32 taps read
     print('  K=%2d  fwd %5.1f us  %5.2f TB/s (%4.1f %% of 8 TB/s) | bwd %5.1f us  %5.2f TB/s (%4.1f %%)  [%.1f / %.1f MB]'
           % (K, tf, bf / tf * 1e-6, bf / tf * 1e-6 / 8 * 100, tb, bb / tb * 1e-6, bb / tb * 1e-6 / 8 * 100, bf / 1e6, bb / 1e6))
+
+# ---- the conv-block core as one launch (tell_dynconv_block_fwd: GLU + tap logits + softmax + DropConnect + K-tap sum)
+# against the three launches it replaces; achieved bandwidth on the FUSED algorithmic bytes: h1 [T*B, 2C] and W_tap
+# [H*K, C] read, gl and y [T*B, C] and the fp32 taps [T*B*H, K] written
+from tell_amd import ops
+hip.require_gpu()
+print('conv-block core, fused launch vs glu + tap-logit GEMM + dynconv forward (same shapes):')
+for K in (3, 7, 15, 31):
+    h1 = torch.randn(T * B, 2 * C, device='cuda').bfloat16(); wt = (torch.randn(H * K, C, device='cuda') * 0.05).bfloat16()
+    gl = torch.empty(T * B, C, device='cuda', dtype=torch.bfloat16); y = torch.empty_like(gl)
+    taps = torch.empty(T * B * H, K, device='cuda')
+    lg = torch.empty(T * B, H * K, device='cuda', dtype=torch.bfloat16)
+
+    def three():
+        hip.call('tell_glu_fwd', h1, gl, T * B, C, 1)
+        ops.gemm(gl, wt, out=lg)
+        hip.call('tell_dynconv_fwd', gl, lg, y, taps, T, B, H, K, C // H, p, 1, 2, 1)
+    assert hip.call_rc('tell_dynconv_block_fwd', h1, wt, gl, y, taps, T, B, H, K, p, 1, 2) == 0
+    tfu = timed(lambda: hip.call('tell_dynconv_block_fwd', h1, wt, gl, y, taps, T, B, H, K, p, 1, 2))
+    t3 = timed(three)
+    by = T * B * 2 * C * 2 + H * K * C * 2 + 2 * T * B * C * 2 + T * B * H * K * 4
+    print('  K=%2d  fused %5.1f us  %5.2f TB/s (%4.1f %% of 8 TB/s on %.1f MB)  |  three launches %5.1f us'
+          % (K, tfu, by / tfu * 1e-6, by / tfu * 1e-6 / 8 * 100, by / 1e6, t3))

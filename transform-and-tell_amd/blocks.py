@@ -143,12 +143,18 @@ class ConvBlockFn(Function):
         w2, n2 = ops.wn_weight(l2.weight_g, l2.weight_v)
         h1 = ops.gemm(x0, w1, bias=l1.bias.detach(), bias_mode=1)                       # [rows, 2E]
         gl = torch.empty(x2.shape[0], E, dtype=x2.dtype, device=x2.device)
-        call('tell_glu_fwd', h1, gl, h1.shape[0], E, hip.dt(h1))
         wt = ops.weight(conv.weight_linear.weight)                                      # [H*K, E]
-        logits = ops.gemm(gl, wt)
         c = torch.empty_like(gl)
         taps = torch.empty(T * B * H, K, dtype=torch.float32, device=x2.device)
-        call('tell_dynconv_fwd', gl, logits, c, taps, T, B, H, K, E // H, float(p_w), rt.seed(), salts[1], hip.dt(gl))
+        # GLU + tap logits + tap softmax + DropConnect + K-tap sum as ONE launch (csrc/dynconv.hip); it declines
+        # (returns 1) shapes it does not take - fp32 parity mode, T > 32, other widths - and the three launches run
+        fused = (x2.dtype == torch.bfloat16 and E == H * 64 and h1.is_contiguous() and wt.is_contiguous() and
+                 hip.call_rc('tell_dynconv_block_fwd', h1, wt, gl, c, taps, T, B, H, K, float(p_w), rt.seed(),
+                             salts[1]) == 0)
+        if not fused:
+            call('tell_glu_fwd', h1, gl, h1.shape[0], E, hip.dt(h1))
+            logits = ops.gemm(gl, wt)
+            call('tell_dynconv_fwd', gl, logits, c, taps, T, B, H, K, E // H, float(p_w), rt.seed(), salts[1], hip.dt(gl))
         y2 = ops.gemm(c, w2, bias=l2.bias.detach(), bias_mode=1)
         out, mean, rstd = _ln_fwd(y2, x2, layer.conv_layer_norm, p, salts[2])
         ctx.save_for_backward(x2, x0, h1, gl, taps, c, y2, mean, rstd, w1, n1, w2, n2, wt)

@@ -46,6 +46,12 @@ __device__ __forceinline__ uint16_t f2bf(float f) {  // round-to-nearest-even, N
   return (uint16_t)(u >> 16);
 }
 
+// nn.GLU on one element, a * sigmoid(g) - every kernel that applies it (glu_fwd_kernel, the generation step's linear1
+// epilogue, the fused conv-block core) uses this one expression, so they agree bit for bit
+// (v_rcp_f32 instead of an IEEE division: 1 ulp of fp32 on a value that is stored as bf16 or enters a bf16 GEMM; the
+// division was 10 of the ~25 instructions per element and the fused conv-block core applies GLU 8x redundantly)
+__device__ __forceinline__ float tell_glu(float a, float g) { return a * __builtin_amdgcn_rcpf(1.f + __expf(-g)); }
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static constexpr int VEC = 4;  // elements per 16-byte chunk

@@ -111,7 +111,7 @@ __device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& p, int prob, i
   if (act == 1) v = fmaxf(v, 0.f);
   if (act == 2) {
     if (bias) g += bias[N + n];
-    v = v / (1.f + __expf(-g));
+    v = tell_glu(v, g);
   }
   v *= p.scale;
   if (p.res) v += __uint_as_float((uint32_t)p.res[(long)m * p.ld_res + n] << 16);

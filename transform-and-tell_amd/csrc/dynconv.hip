@@ -302,3 +302,228 @@ extern "C" int tell_dynconv_bwd(const void* x, const void* dy, const float* taps
   }
   return tell_check_launch("dynconv_bwd");
 }
+
+// ---------------------------------------------------------------- fused conv-block core (round 4)
+// decoder_faces_objects.py:259-261 + dynamic.py:285-336 as ONE launch:  gl = GLU(h1);  tap logits = gl . W_tap^T;
+// taps = softmax_K;  y = DropConnect(taps) (*) gl.   The unfused path is three launches (tell_glu_fwd, the tap-logit
+// GEMM, tell_dynconv_fwd) that write and re-read gl (2 x 2 MB) and the logits (1 MB) and each pay ~5-13 us of launch +
+// one memory round trip for ~1 us of work.  Here one workgroup owns (b, a group of DCB_HG heads): it stages the WHOLE
+// GLU output of its batch column - [T <= 32, E] bf16, 66 KB of LDS; the tap logits of a head reduce over all E channels -
+// from h1 (the 8 workgroups of a batch column repeat that read, 128 KB each, through the L2 of the one XCD they share), computes the [32, HG*K <= 64] tap
+// logits with v_mfma_f32_32x32x16_bf16 - the four waves split E, B fragments come straight from W_tap in global memory
+// (as the generation step's skinny kernel does), partial tiles meet in LDS - and then runs the softmax / DropConnect /
+// K-tap sum of the LDS kernel above on its heads' 64-channel columns of the staged tile.  Written: gl (its own
+// channels; backward needs it), y, the softmax taps (fp32, what tell_dynconv_bwd reads).  The logits never leave the
+// chip and stay fp32 (the unfused path rounds them to bf16 between the GEMM and the softmax).
+// Algorithmic bytes at T = B = 32, E = 1024, K = 31: h1 4.2 MB + W_tap 1 MB read, gl 2.1 + y 2.1 + taps 2.0 MB written.
+#define DCB_HG 2
+#define DCB_T 32
+typedef __attribute__((ext_vector_type(4))) unsigned int dcb_u32x4;
+template <int E>
+__global__ __launch_bounds__(256) void dynconv_block_fwd_kernel(const uint16_t* __restrict__ h1,
+                                                                const uint16_t* __restrict__ wtap,
+                                                                uint16_t* __restrict__ gl, uint16_t* __restrict__ y,
+                                                                float* __restrict__ taps, int Tn, int B, int H, int K,
+                                                                uint32_t thr, float inv_keep, uint32_t seed, uint32_t salt,
+                                                                const uint32_t* __restrict__ step, int abl) {
+  constexpr int GS = E + 8;                                  // LDS row stride (elements): 16 bytes of skew per row
+  constexpr int CPR = E / 8;                                 // 16-byte chunks per row
+  constexpr int NP = 64, PS = NP + 1;                        // tap columns of a head group (padded), partial-tile row stride
+  extern __shared__ __attribute__((aligned(16))) unsigned char dcb_sm[];
+  uint16_t* gs = reinterpret_cast<uint16_t*>(dcb_sm);                        // [32][GS] bf16
+  float* part = reinterpret_cast<float*>(dcb_sm + (size_t)DCB_T * GS * 2);   // [4][32][PS]
+  salt = tell_step_salt(salt, step);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // workgroup -> (b, head group): the `groups` workgroups of one batch column share its h1 rows, so they sit on ONE XCD
+  // (blockIdx & 7) and the column comes out of HBM once, not once per XCD's L2
+  const int groups = H / DCB_HG;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int b = (slot / groups) * 8 + xcd, h0 = (slot % groups) * DCB_HG;
+  if (b >= B) return;
+  const int c_lo = h0 * DC_R, c_hi = c_lo + DCB_HG * DC_R;
+  // ---- B fragments of this wave's first tap block: in flight while the GLU tile is staged
+  const int kw = wave * (E / 4);                                             // this wave reduces channels [kw, kw + E/4)
+  const int n_rows = H * K;
+  const int n0 = h0 * K;
+  auto wrow = [&](int nb) -> const uint16_t* {
+    int n = n0 + nb * 32 + (lane & 31);
+    n = n < n_rows ? n : n_rows - 1;                                         // (columns past the group are never read back)
+    return wtap + (long)n * E + kw + 8 * (lane >> 5);
+  };
+  constexpr int KS = E / 4 / 16;                                             // k steps of 16 per wave
+  dcb_u32x4 bf0[KS], bf1[KS];
+  {
+    const uint16_t* w0 = wrow(0);
+    const uint16_t* w1 = wrow(1);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) bf0[s] = *reinterpret_cast<const dcb_u32x4*>(w0 + 16 * s);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) bf1[s] = *reinterpret_cast<const dcb_u32x4*>(w1 + 16 * s);
+  }
+  // ---- GLU of the batch column into LDS (rows >= Tn: zeros), own channels to HBM.  Chunk i = tid + 256 j is row
+  // 2 j + (tid >> 7), 16-byte piece tid & 127 (E = 1024): 16 pieces per thread, loaded 8 at a time (16 loads in flight -
+  // issued one piece per loop trip the 16 round trips through L2 were most of the kernel)
+  static_assert(CPR == 128 && DCB_T * CPR == 16 * 256, "thread -> chunk mapping below");
+  {
+    const int ch = tid & 127, tr = tid >> 7;
+    const bool own = ch * 8 >= c_lo && ch * 8 < c_hi;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      uint4 va[8], vg[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int t = 2 * (8 * half + j) + tr;
+        const uint16_t* src = h1 + ((long)(t < Tn ? t : 0) * B + b) * (2 * E) + ch * 8;
+        va[j] = *reinterpret_cast<const uint4*>(src);
+        vg[j] = *reinterpret_cast<const uint4*>(src + E);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int t = 2 * (8 * half + j) + tr;
+        float a[8], g[8], r[8];
+        unpack16(va[j], a, (const uint16_t*)nullptr);
+        unpack16(vg[j], g, (const uint16_t*)nullptr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (abl & 1) ? a[e] : tell_glu(a[e], g[e]);           // (glu_fwd_kernel's arithmetic)
+        uint4 o = pack16(r, (const uint16_t*)nullptr);
+        if (t >= Tn) o = make_uint4(0u, 0u, 0u, 0u);
+        else if (own) *reinterpret_cast<uint4*>(gl + ((long)t * B + b) * E + ch * 8) = o;
+        *reinterpret_cast<uint4*>(gs + t * GS + ch * 8) = o;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- tap logits: D[t][n] partial over this wave's channels; lane holds column n = lane & 31, rows acc_row(r)
+  if (!(abl & 2)) {
+    const uint16_t* arow = gs + (lane & 31) * GS + kw + 8 * (lane >> 5);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(arow + 16 * s);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bf0[s]), acc0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(arow + 16 * s);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bf1[s]), acc1, 0, 0, 0);
+    }
+    float* pw = part + wave * (DCB_T * PS);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      pw[t * PS + (lane & 31)] = acc0[r];
+      pw[t * PS + 32 + (lane & 31)] = acc1[r];
+    }
+  }
+  __syncthreads();
+  // ---- softmax over the taps + DropConnect: four threads per (head, row), eight taps each, folded with quad DPP moves
+  // (the stand-alone kernels reduce a row with 12 dependent ds_bpermute shuffles - hidden there by twelve waves per CU,
+  // 11 us here at one wave per SIMD).  The dropped, boundary-zeroed taps go to LDS for the tap sums below.
+  float* wds = part + 4 * DCB_T * PS;                                         // [2 heads x 32 rows][32 taps]
+  {
+    const int r = tid >> 2, q = tid & 3, hl_ = r >> 5, t = r & 31;
+    const long wid = ((long)(t < Tn ? t : 0) * B + b) * H + h0 + hl_;
+    float lg[8], mx = -INFINITY;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int k = q + 4 * jj, n = hl_ * K + (k < K ? k : 0);
+      const float v = part[t * PS + n] + part[(DCB_T + t) * PS + n] + part[(2 * DCB_T + t) * PS + n] + part[(3 * DCB_T + t) * PS + n];
+      lg[jj] = k < K ? v : -INFINITY;
+      mx = fmaxf(mx, lg[jj]);
+    }
+    mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mx), 0xB1, 0xf, 0xf, true)));   // lane ^ 1
+    mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mx), 0x4E, 0xf, 0xf, true)));   // lane ^ 2
+    float sm = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      lg[jj] = (q + 4 * jj) < K ? __expf(lg[jj] - mx) : 0.f;
+      sm += lg[jj];
+    }
+    sm += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sm), 0xB1, 0xf, 0xf, true));
+    sm += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sm), 0x4E, 0xf, 0xf, true));
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int k = q + 4 * jj;
+      float v = 0.f;
+      if (k < K && t < Tn) {
+        const float w = lg[jj] / sm;
+        taps[wid * K + k] = w;
+        v = w;
+        if (thr) v *= tell_keep(seed, salt, (uint64_t)(wid * K + k), thr, inv_keep);
+        if (k < K - 1 - t) v = 0.f;                                           // taps that reach before t = 0
+      }
+      wds[r * 32 + k] = v;
+    }
+  }
+  __syncthreads();
+  // ---- K-tap sums.  A wave owns one head and 16 consecutive rows, four rows at a time: row t0 + i at tap k reads
+  // x[t0 + i - (K-1) + k] - a four-row window that slides by ONE row per tap, so a tap step is one LDS read, four
+  // v_readlane and four FMAs with four independent chains in flight.  Taps that would reach before t = 0 were zeroed
+  // above instead of skipped; their (clamped) reads hit row 0, which those rows also see through a live tap.
+  static_assert(DCB_HG == 2, "wave -> (head, row block) mapping below");
+  const int C = E;
+  const int hl = wave & 1, h = h0 + hl;
+  const uint16_t* xcol = gs + h * DC_R + lane;
+  auto ldx = [&](int r) -> float {
+    r = r < 0 ? 0 : (r > DCB_T - 1 ? DCB_T - 1 : r);
+    return bf2f(xcol[r * GS]);
+  };
+  if (!(abl & 4))
+  for (int t0 = (wave >> 1) * 16; t0 < (wave >> 1) * 16 + 16 && t0 < Tn; t0 += 4) {
+    float wd[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wd[i] = wds[(hl * 32 + t0 + i) * 32 + (lane & 31)];       // (lanes 32 .. 63 are never selected)
+    const int base = t0 - (K - 1);
+    float x0 = ldx(base), x1 = ldx(base + 1), x2 = ldx(base + 2), x3 = ldx(base + 3);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    // taps in blocks of 8 (lanes K .. 63 of wd hold zeros, so running to the next multiple of 8 adds zeros): the block's
+    // eight new rows are read together - fetched one per tap step, each read's latency sat in front of the next step
+    for (int kb = 0; kb < K; kb += 8) {
+      float xn[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xn[j] = ldx(base + kb + 4 + j);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a0 += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wd[0]), kb + j)) * x0;
+        a1 += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wd[1]), kb + j)) * x1;
+        a2 += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wd[2]), kb + j)) * x2;
+        a3 += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wd[3]), kb + j)) * x3;
+        x0 = x1; x1 = x2; x2 = x3; x3 = xn[j];
+      }
+    }
+    const float av[4] = {a0, a1, a2, a3};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (t0 + i < Tn) y[((long)(t0 + i) * B + b) * C + (long)h * DC_R + lane] = f2bf(av[i]);
+  }
+}
+
+// h1 [T*B, 2E] bf16 (linear1's output, a | gate), w_tap [H*K, E] bf16 (DynamicConv weight_linear, no bias) ->
+// gl [T*B, E], y [T*B, E] bf16, taps [T*B*H, K] fp32.  -> TELL_OK, or 1 when the shape is not one this kernel takes
+// (T <= 32, K <= 32, head width 64, E = 1024, even head count): the caller then runs the three separate launches.
+extern "C" int tell_dynconv_block_fwd(const void* h1, const void* w_tap, void* gl, void* y, float* taps, int T, int B,
+                                      int H, int K, float p, uint32_t seed, uint32_t salt, hipStream_t stream) {
+  if ((long)T * B * H <= 0) return TELL_OK;
+  TELL_REQUIRE(p >= 0.f && p < 1.f, "dynconv_block: p must be in [0,1)");
+  static const bool off = getenv("TELL_DYNCONV_BLOCK") && atoi(getenv("TELL_DYNCONV_BLOCK")) == 0;      // A/B switch
+  const int E = H * DC_R;
+  if (off || T > DCB_T || K < 1 || K > DC_KMAX || DCB_HG * K > 64 || E != 1024 || H % DCB_HG || !taps ||
+      ((((uintptr_t)h1 | (uintptr_t)w_tap | (uintptr_t)gl | (uintptr_t)y) & 15) != 0))
+    return 1;
+  const uint32_t thr = p > 0.f ? tell_drop_threshold(p) : 0u;
+  const float ik = 1.f / (1.f - p);
+  const size_t smem = (size_t)DCB_T * (1024 + 8) * 2 + (size_t)4 * DCB_T * 65 * sizeof(float) + (size_t)DCB_HG * DCB_T * 32 * sizeof(float);
+  static const bool attr = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dynconv_block_fwd_kernel<1024>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+    return true;
+  }();
+  (void)attr;
+  static const int abl = getenv("TELL_DCB_ABL") ? atoi(getenv("TELL_DCB_ABL")) : 0;      // timing probe (wrong results)
+  hipLaunchKernelGGL((dynconv_block_fwd_kernel<1024>), dim3((B + 7) / 8 * 8 * (H / DCB_HG)), dim3(256), smem, stream,
+                     (const uint16_t*)h1, (const uint16_t*)w_tap, (uint16_t*)gl, (uint16_t*)y, taps, T, B, H, K, thr, ik, seed,
+                     salt, g_tell_rng_step, abl);
+  return tell_check_launch("dynconv_block_fwd");
+}

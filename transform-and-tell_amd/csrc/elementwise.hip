@@ -325,7 +325,7 @@ __global__ void glu_fwd_kernel(const T* __restrict__ h, T* __restrict__ y, long 
   for (; i < n; i += stride) {
     long r = i / C; int c = (int)(i % C);
     float a = Elem<T>::ld(h + r * 2 * C + c), g = Elem<T>::ld(h + r * 2 * C + C + c);
-    Elem<T>::st(y + i, a / (1.f + __expf(-g)));
+    Elem<T>::st(y + i, tell_glu(a, g));
   }
 }
 template <typename T>
