@@ -268,6 +268,11 @@ def test_gemm_q4_kernel(env):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'ALL OK' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count('gemm_nt_q4_kernel') >= 9, r.stdout[-3000:]
+    if not env:                                # variable-length shapes: 192 / 384 tiles (75 % of 1 / 2 rounds) are taken by q4
+        # (qkv, N = 3072, has whole rounds of 256x192 tiles at those row counts and keeps that kernel)
+        for shape in ('M=12288 N=1024 K=1024', 'M=12288 N=1024 K=4096', 'M=12288 N=2048 K=1024'):
+            line = [ln for ln in r.stdout.splitlines() if shape in ln]
+            assert line and line[0].startswith('gemm_nt_q4_kernel'), (shape, line)
 
 
 @pytest.mark.parametrize('B,H,S,masked', [(2, 4, 256, False), (3, 2, 512, True), (32, 16, 512, True)])

@@ -9,7 +9,9 @@ from tell_amd import hip, ops
 hip.require_gpu()
 ok = True
 SHAPES = ((16384, 1024, 128), (16384, 2048, 256), (16384, 3072, 384), (16384, 4096, 1024), (16384, 1024, 4096),
-          (8192, 8192, 128), (4096, 4096, 256), (16384, 2048, 640), (16384 + 256 * 8, 1024, 256), (16384, 3072, 1024), (16384, 2048, 2048))
+          (8192, 8192, 128), (4096, 4096, 256), (16384, 2048, 640), (16384 + 256 * 8, 1024, 256), (16384, 3072, 1024), (16384, 2048, 2048),
+          # variable-length batches (B x L = 12288 / 8192 rows): partial rounds at least 70 % full stay on q4 by default
+          (12288, 1024, 1024), (12288, 1024, 4096), (12288, 2048, 1024), (8192, 3072, 1024), (12288, 3072, 1024))
 for M, N, K in SHAPES:
     g = torch.Generator(device='cuda').manual_seed(M + N + K)
     a = torch.randn(M, K, device='cuda', generator=g).bfloat16()

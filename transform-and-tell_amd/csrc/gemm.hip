@@ -1548,7 +1548,19 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
           TELL_GEMM_LAUNCH(gemm_label("gemm_nt_w4_kernel", -1, sizeof(OutT) == 2, 256, 256), (gemm_nt_w4_kernel<OutT>), dim3((unsigned)tiles(256, 256)), dim3(256));
           return g_gemm_plan ? TELL_OK : tell_check_launch("gemm_nt_w4");
         }
-        if (full && !no_pp && ((force == 0 && tiles(256, 256) % n_cu == 0) || (force == 8 && tiles(256, 256) >= n_cu))) {
+        // four waves x 128x128 (gemm_q4.hip): what it needs beyond `full`
+        const int q4_env = getenv("TELL_GEMM_Q4") ? atoi(getenv("TELL_GEMM_Q4")) : 1;   // (per launch: A/B inside one process)
+        const bool q4_takes = q4_env && (force == 0 || force == 8) && a.K % 128 == 0 && a.K >= 128 && a.K / 64 < 65536 && a.lda % 8 == 0 &&
+                              a.ldb % 8 == 0 && !a.conv_zero && a.act <= 2 && (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 &&
+                              (reinterpret_cast<uintptr_t>(a.B) & 15) == 0 && 256L * a.lda * 2 < (1L << 31) && 256L * a.ldb * 2 < (1L << 31);
+        // Partial rounds (variable-length batches: B x L = 12288 / 8192 / 4096 rows): the 256x256 ping-pong kernel lost
+        // them to 128x128 tiles, q4 does not as long as the rounds it runs are at least 70 % full - at 12288 rows fc2 has
+        // 192 tiles = 75 % of one round and still runs in the time of the full 16384-row launch (990 against 830 TFLOP/s
+        // effective), qkv is 2.25 rounds in 3.  TELL_Q4_PARTIAL=0: whole rounds only.
+        static const bool q4_partial_env = !(getenv("TELL_Q4_PARTIAL") && atoi(getenv("TELL_Q4_PARTIAL")) == 0);
+        const long t256 = tiles(256, 256);
+        const bool q4_partial = q4_partial_env && q4_takes && force == 0 && t256 * 10 >= ((t256 + n_cu - 1) / n_cu) * n_cu * 7;
+        if (full && !no_pp && ((force == 0 && (t256 % n_cu == 0 || q4_partial)) || (force == 8 && t256 >= n_cu))) {
           // persistent form (tile queue registered, more than one tile per CU): one workgroup per CU pulls tiles
           // MEASURED (MI355X, same box A/B, configs[2]): 1406 / 1420 samples/s without, 1415 / 1404 with; alone qkv 130.2 ->
           // 125.6 us, the other shapes unchanged.  Holding the CU does not buy back the in-step slowdown - the other
@@ -1560,10 +1572,7 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
           // four waves x 128x128, hand-placed K loop (gemm_q4.hip) - the default since round 4.  MEASURED (MI355X, interleaved
           // inside one process, M = 16384): RoBERTa layer GEMMs 419-422 us (ping-pong) -> 364-365 us: qkv 968 -> 1124 TFLOP/s,
           // out 922 -> 993, fc1 + GELU 855 -> 1036, fc2 1197 -> 1313 (tools/probes/q4_variants.py).  TELL_GEMM_Q4=0: ping-pong.
-          const int q4_env = getenv("TELL_GEMM_Q4") ? atoi(getenv("TELL_GEMM_Q4")) : 1;   // (per launch: A/B inside one process)
-          if (q4_env && (force == 0 || force == 8) && a.K % 128 == 0 && a.K >= 128 && a.K / 64 < 65536 && a.lda % 8 == 0 && a.ldb % 8 == 0 && !a.conv_zero &&
-              a.act <= 2 && (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0 &&
-              256L * a.lda * 2 < (1L << 31) && 256L * a.ldb * 2 < (1L << 31)) {
+          if (q4_takes) {
             // epilogue inside the next tile's K loop (gemm_q4e.hip): per-column bias, K >= 576.  TELL_GEMM_Q4E=0: plain q4
             const int q4e_env = getenv("TELL_GEMM_Q4E") ? atoi(getenv("TELL_GEMM_Q4E")) : 1;
             // MEASURED (static tile lists, M = 16384): qkv (3 tiles per workgroup) 90.2 -> 86.6 us; one tile per workgroup (out,
