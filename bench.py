@@ -450,6 +450,8 @@ def loader_bench(args, dev, n_batches=12, warm=4, variable=False):
             samples = []
             for i in range(sh, min(sh + 128, total)):
                 L, T = (g.randint(128, 513), g.randint(9, 42)) if variable else (512, 33)
+                if variable == 'wide':                  # captions of 5..98 tokens, articles of 32..512: 4 x 7 bucket pairs
+                    L, T = g.randint(32, 513), g.randint(5, 99)
                 F, O = (g.randint(0, 5), g.randint(0, 65)) if variable else (4, 64)
                 cap = np.r_[0, g.randint(4, 50265, T - 2), 2]
                 samples.append({'context_ids': np.r_[0, g.randint(4, 50265, L - 2), 2], 'caption_ids': cap,
@@ -526,7 +528,7 @@ def loader_bench(args, dev, n_batches=12, warm=4, variable=False):
                      'shape_buckets': list(trainer.shape_buckets or ()), 'epochs': epochs}
             if sg is not None:                         # capture policy at work: signatures, captures kept, evictions, pool size
                 ready = sum(1 for v in sg.entries.values() if v.get('state') == 'ready')
-                extra.update(step_signatures_seen=len(sg.entries), step_graphs_kept=ready, step_graph_evictions=sg.cache.evictions,
+                extra.update(step_signatures_seen=len(sg.entries), step_graphs_kept=ready, step_graph_evictions=sg.cache.evictions, step_graph_freezes=sg.cache.freezes,
                              step_graph_failed=sum(1 for v in sg.entries.values() if v.get('state') == 'failed'),
                              hbm_reserved_gb=round(torch.cuda.memory_reserved() / 2 ** 30, 2))
             if len(marks) >= 3:                        # steady state: the last epoch (every bucket signature captured)
@@ -648,6 +650,7 @@ def main():
                          'rocprofv3 kernel summaries')
     ap.add_argument('--generate', action='store_true', help='BASELINE configs[4]: caption generation throughput')
     ap.add_argument('--no-generation', action='store_true', help='skip the configs[4] generation block of the default line')
+    ap.add_argument('--no-many-signatures', action='store_true', help='skip the many-signature variable-length leg')
     ap.add_argument('--no-loader', action='store_true',
                     help='skip the data-plane leg (shards on tmpfs -> reader -> iterator -> collate -> training step)')
     ap.add_argument('--beam', type=int, default=4, help='beam size of --generate (1 = greedy, what the reference does)')
@@ -753,6 +756,14 @@ def main():
             tell_amd.ops.clear_weight_cache()
             torch.cuda.empty_cache()
             result['loader_variable_lengths'] = loader_bench(args, dev, n_batches=22, warm=2, variable=True)
+            if not args.no_many_signatures:
+                # the capture policy under MANY shape signatures (captions of 5..98 tokens -> 7 caption buckets x 4 article
+                # buckets x 2 encoder-slot parities), shuffled every epoch: signatures seen, graphs kept, evictions, freezes
+                # of the thrash guard, reserved HBM; value = the last of 3 epochs, first_epochs_value = all of them
+                gc.collect()
+                tell_amd.ops.clear_weight_cache()
+                torch.cuda.empty_cache()
+                result['loader_many_signatures'] = loader_bench(args, dev, n_batches=38, warm=2, variable='wide')
         if world == 1 and not args.no_dp_selftest and not args.serial and args.model == 'faces_objects' and \
                 os.environ.get('TELL_DP_SELFTEST') is None and not args.cu_hog:
             # the data-parallel code path's own cost at N = 1: the same step with a 1-rank RCCL group and every

@@ -185,3 +185,38 @@ def test_reference_expt_configs_instantiate_unmodified():
     from tell_amd.training.trainer import TrainerBase
     assert TrainerBase.by_name(params['trainer']['type']).__name__ == 'CallbackApexTrainer'
     assert isinstance(model, Registrable)
+
+
+def test_signature_cache_lru_and_thrash_guard():
+    """graphs.SignatureCache: least recently used READY entries are evicted down to the capacity; a rotation of more
+    signatures than the capacity (every miss an eviction) freezes the set after THRASH_EVICTIONS evictions within
+    THRASH_WINDOW sightings - make_room() then says "do not capture" - and thaws THRASH_FREEZE sightings later."""
+    from tell_amd import graphs
+    c = graphs.SignatureCache(4, capture_after=1)
+
+    def sight(sig):
+        e = c.touch(sig)
+        if e['state'] == 'seen' and c.due(e):
+            if c.make_room():
+                e['state'] = 'ready'
+                return 'captured'
+            return 'eager'
+        return 'replayed' if e['state'] == 'ready' else 'eager'
+    assert [sight(i) for i in range(4)] == ['captured'] * 4 and c.evictions == 0
+    assert [sight(i) for i in range(4)] == ['replayed'] * 4
+    assert sight(10) == 'captured' and c.evictions == 1 and 0 not in c.entries          # LRU victim: signature 0
+    assert sight(1) == 'replayed'
+    # 12 signatures in rotation over 4 slots: every sighting misses
+    seen = [sight(100 + (i % 12)) for i in range(40)]
+    # (one eviction of the window is already spent above)
+    assert c.freezes == 1 and seen.count('captured') == graphs.THRASH_EVICTIONS - 1 and 'eager' in seen[-10:]
+    kept = [k for k, v in c.entries.items() if v['state'] == 'ready']
+    assert len(kept) == 4
+    ev = c.evictions
+    assert [sight(k) for k in kept] == ['replayed'] * 4                                   # the frozen set keeps replaying
+    i = 0
+    while c.clock < c.frozen_until - 1:                                                   # ... others stay eager, nothing is evicted
+        assert sight(1000 + i % 7) == 'eager'
+        i += 1
+    assert i > graphs.THRASH_FREEZE // 2 and c.evictions == ev
+    assert sight(2000) == 'captured' and c.evictions == ev + 1                            # thawed: the LRU gets another chance

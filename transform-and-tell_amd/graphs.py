@@ -43,6 +43,7 @@ MAX_SIGNATURES = 8      # every captured signature keeps its activations in a pr
 # pool per shape for nothing.  Fixed-shape runs (bench.py) pass capture_after=1.
 CAPTURE_AFTER = max(1, int(os.environ.get('TELL_GRAPH_AFTER', '2')))
 MAX_ENTRIES = 256       # bookkeeping entries (sighting counters) kept per cache; the oldest are forgotten beyond that
+THRASH_WINDOW, THRASH_EVICTIONS, THRASH_FREEZE = 64, 8, 256          # (see SignatureCache)
 
 
 class SignatureCache:
@@ -57,6 +58,15 @@ class SignatureCache:
         self.max_ready = max(1, int(max_ready))
         self.capture_after = CAPTURE_AFTER if capture_after is None else max(1, int(capture_after))
         self.evictions = 0
+        # thrash guard: more distinct signatures in rotation than max_ready makes an LRU evict a graph at almost every
+        # miss - each eviction is a device synchronisation, a destroyed pool and an ~80 ms capture pass for a graph that
+        # is gone again before it has paid that back (worse than never capturing).  More than THRASH_EVICTIONS evictions
+        # within THRASH_WINDOW sightings freeze the set for THRASH_FREEZE sightings: what is captured keeps replaying,
+        # everything else runs eagerly; then the LRU gets another chance (the mix of shapes may have changed).
+        self.clock = 0
+        self.recent_evictions = []
+        self.frozen_until = -1
+        self.freezes = 0
 
     def touch(self, sig):
         """-> the entry of sig (created on first sight), counted as one more sighting and made most recently used."""
@@ -64,6 +74,7 @@ class SignatureCache:
         if e is None:
             e = self.entries[sig] = {'state': 'seen', 'hits': 0}
         e['hits'] += 1
+        self.clock += 1
         self.entries.move_to_end(sig)
         return e
 
@@ -71,17 +82,29 @@ class SignatureCache:
         return e['state'] == 'seen' and e['hits'] >= self.capture_after
 
     def make_room(self):
-        """Call right before a capture (never inside one: destroying a graph while capturing is illegal)."""
+        """Call right before a capture (never inside one: destroying a graph while capturing is illegal).
+        -> True: there is room for one more capture; False: the set is full and frozen (thrash guard) - do not capture."""
         ready = [k for k, v in self.entries.items() if v['state'] == 'ready']
-        if len(ready) >= self.max_ready and torch.cuda.is_available():
-            torch.cuda.synchronize()                # the victim's last replay may still be running (evictions are rare)
+        if len(ready) >= self.max_ready:
+            if self.clock < self.frozen_until:
+                return False
+            self.recent_evictions = [c for c in self.recent_evictions if c > self.clock - THRASH_WINDOW]
+            if len(self.recent_evictions) >= THRASH_EVICTIONS:
+                self.frozen_until = self.clock + THRASH_FREEZE
+                self.freezes += 1
+                self.recent_evictions = []
+                return False
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()            # the victim's last replay may still be running
         while len(ready) >= self.max_ready:
             k = ready.pop(0)
             self.entries.pop(k).clear()             # drops the graph, its static buffers and its pool
             self.evictions += 1
+            self.recent_evictions.append(self.clock)
         if len(self.entries) > MAX_ENTRIES:
             for k in [k for k, v in self.entries.items() if v['state'] != 'ready'][:len(self.entries) - MAX_ENTRIES]:
                 del self.entries[k]
+        return True
 
     def clear(self):
         self.entries.clear()
@@ -124,8 +147,7 @@ class GraphedCall:
         e = self.cache.touch(sig)
         if e['state'] == 'seen':
             out = self.fn(x)                            # eager: also builds the weight caches the capture relies on
-            if self.cache.due(e):
-                self.cache.make_room()
+            if self.cache.due(e) and self.cache.make_room():
                 self._capture(e, x)                     # records, does not execute: this call pays for it,
             return out                                  # not a later (timed) one
         if e['state'] != 'ready':

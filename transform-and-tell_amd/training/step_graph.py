@@ -35,13 +35,15 @@ COPY_LIMIT = 256 << 20          # encoder outputs that are not graph-owned are c
 class StepGraph:
     """Captured decoder steps, one per shape signature.  Real batches vary in shape (the iterator pads to the per-batch
     maximum): the trainer pads them to a small set of buckets first (Trainer.shape_buckets), a signature is only
-    captured at its `capture_after`-th sighting, at most 2 * graphs.MAX_SIGNATURES captures are kept (least recently
+    captured at its `capture_after`-th sighting, at most 4 * graphs.MAX_SIGNATURES = 32 captures are kept (least recently
     used evicted, which releases their activation pools) and the sighting counters themselves are bounded
     (graphs.SignatureCache)."""
 
     def __init__(self, trainer, capture_after=None):
         self.tr = trainer
-        self.cache = graphs.SignatureCache(2 * graphs.MAX_SIGNATURES, capture_after)
+        # ~3 GB of private activation pool per captured signature at B = 32 (bench leg: 6 graphs, 23.6 GB reserved in all):
+        # 32 graphs are ~100 of the 288 GB.  Beyond that the cache's thrash guard (graphs.SignatureCache) decides.
+        self.cache = graphs.SignatureCache(int(os.environ.get('TELL_STEP_GRAPHS_MAX', 4 * graphs.MAX_SIGNATURES)), capture_after)
         self.entries = self.cache.entries
         self.replays = 0
 
@@ -92,14 +94,13 @@ class StepGraph:
                 # this signature has run eagerly before (every cache a capture relies on exists): record the graph NOW and
                 # train this batch with its first replay - a new signature costs one eager step + one capture pass, not two
                 # eager steps + a capture (variable-length data: 12 signatures in the first epochs, 55 ms per eager step)
-                self.cache.make_room()
-                self._capture(e, batch, small, big, by_ptr, enc)
+                if self.cache.make_room():              # (False: full and frozen by the thrash guard - stay eager)
+                    self._capture(e, batch, small, big, by_ptr, enc)
                 if e['state'] != 'ready':
                     return eager_step(batch, enc)
             else:
                 loss = eager_step(batch, enc)
-                if self.cache.due(e):
-                    self.cache.make_room()
+                if self.cache.due(e) and self.cache.make_room():
                     self._capture(e, batch, small, big, by_ptr, enc)
                 return loss
         if e['state'] != 'ready':
