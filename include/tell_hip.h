@@ -461,7 +461,12 @@ int tell_loss_flag(const float* loss, int* skip, tell_stream_t stream);
 int tell_image_normalize(const uint8_t* x, float* y, int B, int H, int W, float m0, float m1, float m2, float s0,
                          float s1, float s2, tell_stream_t stream);
 int tell_nchw_to_nhwc(const float* x, void* y, int B, int C, int H, int W, int out_dtype, tell_stream_t stream);
-/* conv (1x1 / 3x3, stride 1 / 2, Cin = 64 * 2^n) as an IMPLICIT GEMM on the matrix cores + the statistics of the
+/* fp32 NCHW (C <= 4) -> bf16 NHWC with FOUR channels per pixel (missing ones zero): the input of the implicit 7x7 stem
+ * (resnet.py:92-96) - tell_conv_bn_stats / tell_conv_bn_act / tell_conv_bias_act called with Cin = 4, KH = KW = 7,
+ * stride 2, pad 3 and w [Cout, 256] laid out as 8 kernel rows (the 8th zero) x 8 window columns (the FIRST zero: the
+ * window of output column ow starts at input column 2 ow - 4) x 4 channels (the 4th zero); W must be even. */
+int tell_nchw_to_nhwc4(const float* x, void* y, int B, int C, int H, int W, tell_stream_t stream);
+/* conv (1x1 / 3x3, stride 1 / 2, Cin = 64 * 2^n; or the 7x7 stem, see tell_nchw_to_nhwc4) as an IMPLICIT GEMM on the matrix cores + the statistics of the
  * train-mode BatchNorm behind it (resnet.py:92-108: torchvision Bottleneck conv -> bn; BN in batch-stat mode per
  * callback_apex_trainer.py:259): no im2col matrix, no statistics pass over the activation.  x [B,H,W,Cin] bf16,
  * w [Cout, KH*KW*Cin] bf16, y [B*OH*OW, Cout] bf16 raw conv output; mean / invstd [Cout] (+ running stats update), or

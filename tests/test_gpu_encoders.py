@@ -199,6 +199,58 @@ def _device_kernel_names(fn):
     return {e.name for e in prof.events()}
 
 
+@pytest.mark.parametrize('train', [True, False])
+@pytest.mark.parametrize('B,H,W', [(2, 224, 224), (32, 224, 224), (3, 64, 96)])
+def test_resnet_stem_implicit_7x7_gather(B, H, W, train):
+    """conv1 (7x7, stride 2, padding 3) -> bn1 -> ReLU (resnet.py:94-97) as an implicit GEMM over NHWC4 pixels
+    (tell_nchw_to_nhwc4 + the stem gather of gemm_nt_glds_kernel: a K tile = two kernel rows of an 8-pixel window) against
+    torch's convolution + batch norm of the same bf16-rounded image and weights in fp32, train mode (batch statistics,
+    running-statistics update) and eval mode (BatchNorm folded into the weights); the im2col path it replaces must agree
+    too, and no im2col kernel may run."""
+    import tell_amd
+    from tell_amd.models import resnet as R
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(B + H)
+    m = R.ResNetFeatureExtractor(layers=(1, 1, 1, 1)).to(DEV)
+    m.bn1.weight.data.uniform_(0.5, 1.5); m.bn1.bias.data.uniform_(-0.3, 0.3)
+    m.bn1.running_mean.uniform_(-0.2, 0.2); m.bn1.running_var.uniform_(0.5, 1.5)
+    img = torch.randn(B, 3, H, W, device=DEV)
+    rm0, rv0 = m.bn1.running_mean.clone(), m.bn1.running_var.clone()
+
+    def stem(implicit):
+        m.bn1.running_mean.copy_(rm0); m.bn1.running_var.copy_(rv0)
+        R._STATS_EPOCH[0] += 1
+        if implicit:
+            x4 = torch.empty(B * H * W, 4, dtype=torch.bfloat16, device=DEV)
+            tell_amd.hip.call('tell_nchw_to_nhwc4', img, x4, B, 3, H, W)
+            assert torch.equal(x4.view(B, H, W, 4)[..., :3], img.permute(0, 2, 3, 1).bfloat16()) and (x4[:, 3] == 0).all()
+            y, OH, OW = R.stem_bn_act(x4, B, H, W, m.conv1, m.bn1, train)
+        else:
+            x = img.permute(0, 2, 3, 1).reshape(B * H * W, 3).bfloat16().contiguous()
+            y, OH, OW = R.conv_bn_act(x, B, H, W, m.conv1, m.bn1, True, None, train)
+        return y.float().view(B, OH, OW, -1), m.bn1.running_mean.clone(), m.bn1.running_var.clone()
+    names = _device_kernel_names(lambda: stem(True))
+    assert not any('im2col' in n for n in names) and any('gemm_nt_glds_kernel' in n for n in names), names
+    y1, rm1, rv1 = stem(True)
+    y0, rm2, rv2 = stem(False)
+    xr = img.bfloat16().float()
+    wr = m.conv1.weight.detach().bfloat16().float()
+    if train:
+        c = torch.nn.functional.conv2d(xr, wr, stride=2, padding=3)
+        ref = torch.relu(torch.nn.functional.batch_norm(c, rm0.clone(), rv0.clone(), m.bn1.weight, m.bn1.bias, True, 0.1, 1e-5))
+    else:
+        scale = m.bn1.weight * torch.rsqrt(rv0 + 1e-5)
+        ref = torch.relu(torch.nn.functional.conv2d(xr, (wr * scale[:, None, None, None]).bfloat16().float(), stride=2, padding=3)
+                         + (m.bn1.bias - rm0 * scale)[None, :, None, None])
+    ref = ref.permute(0, 2, 3, 1)
+    assert rel(y1, ref) < 8e-3, rel(y1, ref)
+    assert rel(y1, y0) < 8e-3, rel(y1, y0)
+    if train:
+        assert rel(rm1, rm2) < 2e-3 and rel(rv1, rv2) < 2e-3
+    else:
+        assert torch.equal(rm1, rm0) and torch.equal(rv1, rv0)
+
+
 @pytest.mark.parametrize('stage', [1, 2, 3])
 def test_resnet152_first_blocks_at_bench_batch_match_oracle(stage):
     """ResNet-152 AT THE BENCH BATCH (B = 32; resnet.py:92-108 as configs[2] runs it): the first bottleneck of layer1 /

@@ -30,6 +30,33 @@ extern "C" int tell_nchw_to_nhwc(const float* x, void* y, int B, int C, int H, i
   return tell_check_launch("nchw_to_nhwc");
 }
 
+// fp32 NCHW image (C <= 4) -> bf16 NHWC4 pixels (8 bytes each, missing channels zero): the input layout of the implicit
+// 7x7 stem gather (gemm.hip).  One thread per pixel: plane reads coalesce across the wave, one 8-byte store.
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int B, int C,
+                                                            long HW) {
+  const long n = (long)B * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / HW, hw = i - b * HW;
+    const float* src = x + b * C * HW + hw;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < C) v[c] = src[(long)c * HW];
+    uint2 o;
+    o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    reinterpret_cast<uint2*>(y)[i] = o;
+  }
+}
+extern "C" int tell_nchw_to_nhwc4(const float* x, void* y, int B, int C, int H, int W, hipStream_t stream) {
+  const long n = (long)B * H * W;
+  if (n <= 0) return TELL_OK;
+  TELL_REQUIRE(C >= 1 && C <= 4 && ((uintptr_t)y & 7) == 0, "nchw_to_nhwc4: 1..4 channels, 8-byte aligned output");
+  const int g = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+  hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(g), dim3(256), 0, stream, x, (uint16_t*)y, B, C, (long)H * W);
+  return tell_check_launch("nchw_to_nhwc4");
+}
+
 // col[m][(kh*KW + kw)*Cin + c] = x[b, oh*s - pad + kh, ow*s - pad + kw, c]  (0 outside / K padding)
 template <typename T>
 __global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ x, T* __restrict__ col, int B, int H,

@@ -505,9 +505,19 @@ __device__ __forceinline__ void gemm_nt_glds_body(const GemmArgs& p, const int b
     row = row < M ? row : M - 1;
     if (conv) {
       const int ow = row % p.conv_OW, t = row / p.conv_OW, oh = t % p.conv_OH, b = t / p.conv_OH;
-      cv_ih[j] = oh * p.conv_stride - p.conv_pad;
-      cv_iw[j] = ow * p.conv_stride - p.conv_pad;
-      asrc[j] = A + ((long)b * p.conv_H * p.conv_W << (6 + p.conv_cshift)) + (l16 & 7) * 8;   // image base + chunk
+      if (p.conv_cshift < 0) {
+        // 7x7 / stride 2 / pad 3 stem over NHWC4 pixels (3 channels + a zero one = 8 bytes): a K tile is TWO kernel rows
+        // of 8 pixels x 4 channels; the window starts at input column 2 ow - 4 (one column left of the first tap, whose
+        // weight is zero) so that every 16-byte chunk = an aligned pixel pair, wholly inside the image or wholly outside
+        // (W even).  This lane's chunk (l16 & 7): kernel row (chunk >> 2) of the tile's two, pixel pair chunk & 3.
+        cv_ih[j] = oh * 2 - 3 + ((l16 & 7) >> 2);
+        cv_iw[j] = ow * 2 - 4 + ((l16 & 7) & 3) * 2;
+        asrc[j] = A + ((long)b * p.conv_H * p.conv_W << 2);
+      } else {
+        cv_ih[j] = oh * p.conv_stride - p.conv_pad;
+        cv_iw[j] = ow * p.conv_stride - p.conv_pad;
+        asrc[j] = A + ((long)b * p.conv_H * p.conv_W << (6 + p.conv_cshift)) + (l16 & 7) * 8;   // image base + chunk
+      }
     } else {
       cv_ih[j] = cv_iw[j] = 0;
       asrc[j] = A + (long)row * p.lda + (l16 & 7) * 8;
@@ -525,7 +535,16 @@ __device__ __forceinline__ void gemm_nt_glds_body(const GemmArgs& p, const int b
   auto issue = [&](int kt, int stage, int q) __attribute__((always_inline)) {
     unsigned char* sa = smem + stage * STAGE + (wave * IA) * 1024;
     unsigned char* sb = smem + stage * STAGE + A_BYTES + (wave * IB) * 1024;
-    if (conv) {
+    if (conv && p.conv_cshift < 0) {                      // stem: kernel rows 2 kt, 2 kt + 1 (row 7: zero weights)
+#pragma unroll
+      for (int j = 0; j < IA; ++j)
+        if (q < 0 || j * 4 / IA == q) {
+          const int ih = cv_ih[j] + 2 * kt, iw = cv_iw[j];
+          const bool in = (unsigned)ih < (unsigned)p.conv_H && (unsigned)iw < (unsigned)p.conv_W;
+          const uint16_t* src = in ? asrc[j] + ((long)(ih * p.conv_W + iw) << 2) : zero_src;
+          __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(sa + j * 1024), 16, 0, 0);
+        }
+    } else if (conv) {
       // K tile kt = channels [c0, c0 + 64) of tap (kh, kw): scalar
       const int tap = kt >> p.conv_cshift, c0 = (kt & ((1 << p.conv_cshift) - 1)) << 6;
       const int kh = tap / p.conv_KW, kw = tap - kh * p.conv_KW;
@@ -1938,13 +1957,21 @@ static int conv_launch(const void* X, const void* Wt, void* Y, int B, int H, int
   const long Ml = (long)B * OH * OW;
   TELL_REQUIRE(Ml > 0 && Ml < (1L << 31) && Cout > 0, "conv_bn_stats: bad dimension");
   int cshift = 0;
-  while ((64 << cshift) < Cin) ++cshift;
-  TELL_REQUIRE((64 << cshift) == Cin, "conv_bn_stats: Cin must be 64 * 2^n");
-  TELL_REQUIRE(KH == KW && (KH == 1 || KH == 3) && (stride == 1 || stride == 2), "conv_bn_stats: 1x1 / 3x3, stride 1 / 2");
+  // the ResNet stem (resnet.py:92-96: 7x7, stride 2, padding 3) over NHWC4 input - X: [B, H, W, 4] (3 channels + zero),
+  // Wt: [Cout, 256] = 8 kernel rows (the 8th zero) x 8 window columns (the first zero) x 4 channels (the 4th zero)
+  const bool stem = Cin == 4 && KH == 7 && KW == 7 && stride == 2 && pad == 3;
+  if (stem) {
+    TELL_REQUIRE(W % 2 == 0, "conv_bn_stats: the 7x7 stem gather needs an even image width");
+    cshift = -1;
+  } else {
+    while ((64 << cshift) < Cin) ++cshift;
+    TELL_REQUIRE((64 << cshift) == Cin, "conv_bn_stats: Cin must be 64 * 2^n (or the 4-channel 7x7 stem)");
+    TELL_REQUIRE(KH == KW && (KH == 1 || KH == 3) && (stride == 1 || stride == 2), "conv_bn_stats: 1x1 / 3x3, stride 1 / 2");
+  }
   TELL_REQUIRE(Cout % 8 == 0, "conv_bn_stats: Cout must be a multiple of 8");
   TELL_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)Wt & 15) == 0 && ((uintptr_t)Y & 15) == 0 &&
                ((uintptr_t)zero_page & 15) == 0 && zero_page != nullptr, "conv_bn_stats: 16-byte alignment");
-  const int M = (int)Ml, N = Cout, K = KH * KW * Cin;
+  const int M = (int)Ml, N = Cout, K = stem ? 256 : KH * KW * Cin;
   GemmArgs a;
   a.A = X; a.B = Wt; a.C = Y; a.bias = bias; a.aux = aux; a.m_dev = nullptr;
   a.lda = Cin; a.ldb = K; a.ldc = N; a.M = M; a.N = N; a.K = K;

@@ -7,6 +7,8 @@ callback_apex_trainer.py:259) and running statistics in eval.  Parameter / buffe
 torchvision's so that the reference's `resnet.*` checkpoint entries load.
 Returns the region features as [B, 49, 2048] (== permute(0,2,3,1).view(B,49,2048),
 transformer_faces_objects.py:335-341)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -49,6 +51,26 @@ class _Conv(nn.Module):
             wp[:, :K] = w
             return ops.cast(wp, rt.compute_dtype())
         return ops._cached(self.weight, ('convw',), make)
+
+    def stem_weight(self, bn=None):
+        """The 7x7 / stride 2 / padding 3 stem (resnet.py:92-96) for the implicit gather over NHWC4 pixels
+        (csrc/gemm.hip, tell_nchw_to_nhwc4): [Cout, 256] = 8 kernel rows (the 8th zero) x 8 window columns (the first
+        zero - the window of output column ow starts at input column 2 ow - 4) x 4 channels (the 4th zero).
+        bn given: eval mode, BatchNorm folded in -> (weight, fp32 bias)."""
+        def lay(w):                                   # w: [Cout, 3, 7, 7] fp32
+            wk = torch.zeros(self.cout, 8, 8, 4, dtype=torch.float32, device=w.device)
+            wk[:, :7, 1:, :3] = w.permute(0, 2, 3, 1)
+            return ops.cast(wk.reshape(self.cout, 256), rt.compute_dtype())
+        if bn is None:
+            return ops._cached(self.weight, ('stemw',), lambda: lay(self.weight.detach().float()))
+
+        def make():
+            scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+            bias = (bn.bias.detach().float() - bn.running_mean.float() * scale).contiguous()
+            return lay(self.weight.detach().float() * scale[:, None, None, None]), bias
+        key = ('stemfold', _STATS_EPOCH[0], bn.weight._version, bn.bias._version, bn.running_mean._version,
+               bn.running_var._version, bn.weight.data_ptr(), bn.running_var.data_ptr())
+        return ops._cached(self.weight, key, make)
 
     def folded(self, bn):
         """Eval mode (running statistics, resnet.py:92-108 under model.eval()): the BatchNorm behind this convolution
@@ -203,6 +225,25 @@ def conv_bn_implicit(x, B, H, W, conv, bn, relu, residual, training, slot=0):
     return bn_apply(y, mean, invstd, bn, relu, residual), OH, OW
 
 
+_STEM_IMPLICIT = os.environ.get('TELL_STEM_IMPLICIT', '1') != '0'          # A/B aid: 0 = im2col rows + plain GEMM
+
+
+def stem_bn_act(x4, B, H, W, conv, bn, training):
+    """conv1 (7x7, stride 2, padding 3) -> bn1 -> ReLU (resnet.py:94-97) on NHWC4 pixels x4 [B*H*W, 4]: the implicit
+    gather of conv_bn_implicit with the stem's own window layout.  -> ([B*OH*OW, Cout], OH, OW)."""
+    OH, OW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    M, C = B * OH * OW, conv.cout
+    y = torch.empty(M, C, dtype=x4.dtype, device=x4.device)
+    if training:
+        ws, _ = _stat_buffers(x4.device, 2 * ((M + 63) // 64) * C + 2 * C + 256 * C, C)
+        call('tell_conv_bn_act', x4, conv.stem_weight(), y, B, H, W, 4, 7, 7, 2, 3, OH, OW, C, bn.eps, bn.momentum,
+             bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, None, 1, ws, _zero_page(x4.device))
+    else:
+        wf, bias = conv.stem_weight(bn)
+        call('tell_conv_bias_act', x4, wf, y, B, H, W, 4, 7, 7, 2, 3, OH, OW, C, bias, None, 1, _zero_page(x4.device))
+    return y, OH, OW
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -271,12 +312,20 @@ class ResNetFeatureExtractor(nn.Module):
         hip.require_gpu()
         dtype = rt.compute_dtype()
         B, C, H, W = image.shape
-        x = torch.empty(B * H * W, C, dtype=dtype, device=image.device)
-        call('tell_nchw_to_nhwc', image.float().contiguous(), x, B, C, H, W, hip.dt(dtype))
         tr = self.training
         if tr:
             _STATS_EPOCH[0] += 1                   # this pass rewrites every running_mean / running_var
-        x, H, W = conv_bn_act(x, B, H, W, self.conv1, self.bn1, True, None, tr)        # :94-97
+        c1 = self.conv1
+        if (_STEM_IMPLICIT and dtype == torch.bfloat16 and C <= 4 and W % 2 == 0 and (c1.k, c1.stride, c1.padding) == (7, 2, 3)
+                and c1.cout % 8 == 0):
+            # implicit 7x7 gather over NHWC4 pixels: no im2col matrix (B x 112 x 112 x 152 bf16 = 122 MB at B = 32)
+            x = torch.empty(B * H * W, 4, dtype=dtype, device=image.device)
+            call('tell_nchw_to_nhwc4', image.float().contiguous(), x, B, C, H, W)
+            x, H, W = stem_bn_act(x, B, H, W, c1, self.bn1, tr)                        # :94-97
+        else:
+            x = torch.empty(B * H * W, C, dtype=dtype, device=image.device)
+            call('tell_nchw_to_nhwc', image.float().contiguous(), x, B, C, H, W, hip.dt(dtype))
+            x, H, W = conv_bn_act(x, B, H, W, c1, self.bn1, True, None, tr)            # :94-97
         OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
         y = torch.empty(B * OH * OW, x.shape[1], dtype=dtype, device=x.device)
         call('tell_maxpool3x3s2', x, y, B, H, W, x.shape[1], OH, OW, hip.dt(dtype))    # :98
