@@ -1142,17 +1142,51 @@ __global__ __launch_bounds__(256, 3) void attn_self_fwd_kernel(AttnArgs p) {
   if (lane < 32 && p.lse) p.lse[(long)bh * p.Tq + t] = l_run > 0.f ? m_run + __logf(l_run) : INFINITY;
 }
 
+// MFMA operand fragments out of a K-MAJOR tile (tile[k][m], row stride ld, bf16) by gfx950's LDS transpose read: the lane
+// of row m = m0 + (lane & 31) gets k = ks + 8 (lane >> 5) .. + 7 - the same k order as a row-major operand read by
+// mma32, so the two can meet in one MFMA.  (csrc/gemm.hip gemm_tx_body has the addressing rule.)
+__device__ __forceinline__ bf16x8 attn_km_frag(const uint16_t* tile, int ld, int m0, int ks, int lane) {
+  const uint16_t* p = tile + (ks + 8 * (lane >> 5) + ((lane & 15) >> 2)) * ld + m0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  return attn_tr_frag(p, p + 4 * ld);
+}
+// acc[m][n] += sum_k a_km[k][m0 + m] * b[n][k]  (k < 32)
+__device__ __forceinline__ f32x16 mma32_kmA(f32x16 acc, const uint16_t* a_km, int ald, int m0, const uint16_t* b, int bs, int lane) {
+#pragma unroll
+  for (int ks = 0; ks < 32; ks += 16) {
+    const bf16x8 av = attn_km_frag(a_km, ald, m0, ks, lane);
+    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(b + (lane & 31) * bs + ks + ((lane >> 5) << 3));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+  }
+  return acc;
+}
+// acc[m][n] += sum_k a[m][k] * b_km[k][n0 + n]  (k < 32)
+__device__ __forceinline__ f32x16 mma32_kmB(f32x16 acc, const uint16_t* a, int as, const uint16_t* b_km, int bld, int n0, int lane) {
+#pragma unroll
+  for (int ks = 0; ks < 32; ks += 16) {
+    const bf16x8 av = *reinterpret_cast<const bf16x8*>(a + (lane & 31) * as + ks + ((lane >> 5) << 3));
+    const bf16x8 bv = attn_km_frag(b_km, bld, n0, ks, lane);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
 // ------------------------------------------------------------------ backward
 // One workgroup per (b,h); its NW waves split the key tiles.  Query blocks of 32 are
 // the outer loop (Q-side tiles shared by the waves); dQ is reduced across waves in LDS;
 // each key tile is owned by exactly one wave, so dK/dV need no atomics.
+// bf16 with 64-wide heads (round 4): the transposed copies Qt / dOt / Kt - written two bytes at a time, 30 KB of the 108 KB
+// a four-wave workgroup held - are gone: dV^T, dK^T and dQ take their K-major operands out of the ROW-major Q / dO / K
+// tiles by ds_read_b64_tr_b16 (attn_km_frag).  77 KB of LDS and <= 256 registers: TWO workgroups per CU, so the 512
+// (b, h) workgroups of the article attention are resident at once and each SIMD has a second wave to run while one waits
+// (this kernel is a chain of LDS round trips and barriers: 102 us for 134 MB at one wave per SIMD).
 template <typename T, int D, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && D == 64 && NW == 4) ? 2 : 1) void attn_bwd_kernel(AttnArgs p) {
   const uint32_t salt_eff = tell_step_salt(p.salt, p.step);   // hoisted: one scalar load per kernel
   using C_ = ACfg<T, D>;
   constexpr int DS = C_::DS, SS = C_::SS, DP = C_::DP, DF = C_::DF;
-  constexpr int SHARED_ELEMS = 2 * 32 * DS + 2 * DP * SS;       // Qs, dOs, Qt, dOt
-  constexpr int WAVE_ELEMS = 2 * 32 * DS + DP * SS + 3 * 32 * SS;  // Ks, Vs, Kt, PdT, dST, dS
+  constexpr bool TR = sizeof(T) == 2 && D == 64;                // K-major operands by transpose reads: no Qt / dOt / Kt
+  constexpr int SHARED_ELEMS = 2 * 32 * DS + (TR ? 0 : 2 * DP * SS);       // Qs, dOs, (Qt, dOt)
+  constexpr int WAVE_ELEMS = 2 * 32 * DS + (TR ? 0 : DP * SS) + 3 * 32 * SS;  // Ks, Vs, (Kt), PdT, dST, dS
   static_assert(WAVE_ELEMS * sizeof(T) >= 16 * DF * 64 * sizeof(float), "dQ combine buffer must fit");
   __shared__ __attribute__((aligned(16))) T smem[SHARED_ELEMS + NW * WAVE_ELEMS];
   __shared__ float lse_s[32], delta_s[32];
@@ -1168,12 +1202,12 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(AttnArgs p) {
 
   T* Qs = smem;
   T* dOs = Qs + 32 * DS;
-  T* Qt = dOs + 32 * DS;
-  T* dOt = Qt + DP * SS;
+  T* Qt = dOs + 32 * DS;                             // (TR: no transposed copies - the names alias the wave areas, unused)
+  T* dOt = Qt + (TR ? 0 : DP * SS);
   T* Ks = smem + SHARED_ELEMS + wave * WAVE_ELEMS;
   T* Vs = Ks + 32 * DS;
   T* Kt = Vs + 32 * DS;
-  T* PdT = Kt + DP * SS;
+  T* PdT = Kt + (TR ? 0 : DP * SS);
   T* dST = PdT + 32 * SS;
   T* dSs = dST + 32 * SS;
   const T* qg = static_cast<const T*>(p.q);
@@ -1247,12 +1281,14 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(AttnArgs p) {
           q1[0] = __uint_as_float(vq.x); q1[1] = __uint_as_float(vq.y); q1[2] = __uint_as_float(vq.z); q1[3] = __uint_as_float(vq.w);
           q2[0] = __uint_as_float(vdo.x); q2[1] = __uint_as_float(vdo.y); q2[2] = __uint_as_float(vdo.z); q2[3] = __uint_as_float(vdo.w);
         }
-        const T* eq = reinterpret_cast<const T*>(&vq);
-        const T* ed = reinterpret_cast<const T*>(&vdo);
+        if constexpr (!TR) {
+          const T* eq = reinterpret_cast<const T*>(&vq);
+          const T* ed = reinterpret_cast<const T*>(&vdo);
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-          Qt[(ch * VEC + k) * SS + row] = eq[k];
-          dOt[(ch * VEC + k) * SS + row] = ed[k];
+          for (int k = 0; k < VEC; ++k) {
+            Qt[(ch * VEC + k) * SS + row] = eq[k];
+            dOt[(ch * VEC + k) * SS + row] = ed[k];
+          }
         }
       }
     }
@@ -1269,7 +1305,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(AttnArgs p) {
       const int s0 = kt * 32;
       __syncthreads();
       if (tv) {
-        store32<T, D>(rk, Ks, DS, Kt, SS, lane);
+        store32<T, D>(rk, Ks, DS, TR ? (T*)nullptr : Kt, SS, lane);
         store32<T, D>(rv, Vs, DS, (T*)nullptr, 0, lane);
         if (kt + NW < nkt) fetch(kt + NW);
         if (lane < 32) {
@@ -1340,9 +1376,15 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(AttnArgs p) {
           f32x16 dv, dk;
 #pragma unroll
           for (int r = 0; r < 16; ++r) { dv[r] = 0.f; dk[r] = 0.f; }
-          dv = mma32<T, 32>(dv, dOt + f * 32 * SS, SS, PdT, SS, lane);
-          dk = mma32<T, 32>(dk, Qt + f * 32 * SS, SS, dST, SS, lane);
-          dq[f] = mma32<T, 32>(dq[f], dSs, SS, Kt + f * 32 * SS, SS, lane);  // dQ[q][d]
+          if constexpr (TR) {
+            dv = mma32_kmA(dv, dOs, DS, f * 32, PdT, SS, lane);               // dO is [q][d]: k = q, m = d
+            dk = mma32_kmA(dk, Qs, DS, f * 32, dST, SS, lane);
+            dq[f] = mma32_kmB(dq[f], dSs, SS, Ks, DS, f * 32, lane);          // K is [key][d]: k = key, n = d
+          } else {
+            dv = mma32<T, 32>(dv, dOt + f * 32 * SS, SS, PdT, SS, lane);
+            dk = mma32<T, 32>(dk, Qt + f * 32 * SS, SS, dST, SS, lane);
+            dq[f] = mma32<T, 32>(dq[f], dSs, SS, Kt + f * 32 * SS, SS, lane);  // dQ[q][d]
+          }
           const int s = s0 + (lane & 31);
           const bool real = s < p.S, isb = s == p.S && p.has_bias;
           T* pk = static_cast<T*>(p.dk) + (real ? s * p.k_ss + b * p.k_sb : 0) + (long)h * D;
