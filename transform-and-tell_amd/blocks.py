@@ -217,6 +217,7 @@ def _kv_weight(m):
 
 
 _KV_PP = os.environ.get('TELL_KV_PP', '1') != '0'          # A/B aid
+_KV_PITCH_PAD = int(os.environ.get('TELL_KV_PITCH_PAD', '256'))      # elements; 0 = packed rows (A/B aid)
 
 
 class KVAllFn(Function):
@@ -256,8 +257,14 @@ class KVAllFn(Function):
             s2 = srcs[ci].reshape(-1, srcs[ci].shape[-1])
             E2 = 2 * jobs[js[0]][0].embed_dim
             if ctxs[ci].requires_grad and len(js) > 1:              # side by side: one buffer, one gradient buffer
-                buf = torch.empty(s2.shape[0], len(js) * E2, dtype=s2.dtype, device=s2.device)
-                cat[ci] = (buf, torch.empty_like(buf), js)
+                # Row pitch n * 2E + 256 elements, NOT n * 2E: with 4 layers of 2E = 2048 bf16 a row is exactly 16 KB, and
+                # an attention workgroup (b, h) walks 512 keys that are one row apart each - every 128-byte piece it
+                # reads or writes then lands on the same few HBM channels.  MEASURED (tools/probes/attn_cold.py, cold
+                # caches as in the step): article attention backward 103 -> 55 us, forward 43 -> 29 us with the pad.
+                W = len(js) * E2
+                buf = torch.empty(s2.shape[0], W + _KV_PITCH_PAD, dtype=s2.dtype, device=s2.device)[:, :W]
+                dbuf = torch.empty(s2.shape[0], W + _KV_PITCH_PAD, dtype=s2.dtype, device=s2.device)[:, :W]
+                cat[ci] = (buf, dbuf, js)
             for k, j in enumerate(js):
                 w, bias, wmeta = _kv_weight(jobs[j][0])
                 y = cat[ci][0][:, k * E2:(k + 1) * E2] if ci in cat else \
