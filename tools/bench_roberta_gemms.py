@@ -34,8 +34,10 @@ def time_graph(g, reps=5):
 ROUNDS = 7
 cases = []
 for name, N, K, act in (('qkv', 3072, 1024, 0), ('out', 1024, 1024, 0), ('fc1+gelu', 4096, 1024, 2), ('fc2', 1024, 4096, 0)):
-    a = torch.randn(M, K, device='cuda').bfloat16(); w = torch.randn(N, K, device='cuda').bfloat16()
-    bias = torch.randn(N, device='cuda'); y = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+    # (PITCH_PAD_A / _W / _C: extra elements per row of the activation / weight / output - probes for power-of-two row pitches)
+    pa, pw, pc = (int(os.environ.get('PITCH_PAD_' + k, '0')) for k in 'AWC')
+    a = torch.randn(M, K + pa, device='cuda').bfloat16()[:, :K]; w = torch.randn(N, K + pw, device='cuda').bfloat16()[:, :K]
+    bias = torch.randn(N, device='cuda'); y = torch.empty(M, N + pc, device='cuda', dtype=torch.bfloat16)[:, :N]
     args = (a, a.stride(0), w, w.stride(0), y, y.stride(0), M, N, K, 1, 1, bias, 1, act, None, 1.0, 0, None)
     kname = hip.query('tell_gemm_nt_plan', *args)
     g = graph_of(lambda a=a, w=w, y=y, bias=bias, act=act: ops.gemm(a, w, out=y, bias=bias, bias_mode=1, act=act))

@@ -218,6 +218,7 @@ def _kv_weight(m):
 
 _KV_PP = os.environ.get('TELL_KV_PP', '1') != '0'          # A/B aid
 _KV_PITCH_PAD = int(os.environ.get('TELL_KV_PITCH_PAD', '256'))      # elements; 0 = packed rows (A/B aid)
+_KV_PITCH_PAD1 = int(os.environ.get('TELL_KV_PITCH_PAD1', '0'))    # the same for the single-layer buffers of the small contexts
 
 
 class KVAllFn(Function):
@@ -268,7 +269,7 @@ class KVAllFn(Function):
             for k, j in enumerate(js):
                 w, bias, wmeta = _kv_weight(jobs[j][0])
                 y = cat[ci][0][:, k * E2:(k + 1) * E2] if ci in cat else \
-                    torch.empty(s2.shape[0], E2, dtype=s2.dtype, device=s2.device)
+                    torch.empty(s2.shape[0], E2 + _KV_PITCH_PAD1, dtype=s2.dtype, device=s2.device)[:, :E2]
                 probs.append(dict(a=s2, b=w, out=y, form='nt', bias=bias))
                 outs[j] = as_sbe(y, ci, E2)
                 meta[j] = (w, wmeta, s2)
