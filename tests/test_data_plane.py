@@ -362,3 +362,63 @@ def test_compute_metrics_over_a_generations_file(tmp_path):
     assert m['Entity all - recall'] == {'count': 1, 'total': 2, 'percentage': 0.5}
     assert m['Entity GPE - precision'] == {'count': 0, 'total': 1, 'percentage': 0.0}
     assert abs(m['Generation TTR'] - 0.6) < 1e-12 and 'Generation Flesch Reading Ease' not in m
+
+
+def test_shard_builder_restates_the_reference_reader_field_logic(tmp_path):
+    """data/build_shards.py against nytimes_faces_ner_matched.py:104-190 on two hand-made article documents: one sample
+    per image position; empty captions and unreadable images dropped; context = headline, FIRST paragraph, then the
+    paragraphs around the image (document order before, then after) until 510 BPE tokens; PERSON names of the caption
+    counted for the reader's face trimming; objects by image hash (missing document -> empty); and the shards it writes
+    are what the reader serves."""
+    from PIL import Image
+    from tell_amd.data import DatasetReader, RobertaTokenIndexer
+    from tell_amd.data.bpe import RobertaBPE
+    from tell_amd.data.build_shards import article_samples, build_shards
+    _write_vocab(str(tmp_path))
+    idx = RobertaTokenIndexer(max_len=512, bpe=RobertaBPE(str(tmp_path)))
+    img_dir = tmp_path / 'images'
+    os.makedirs(img_dir)
+    g = np.random.RandomState(0)
+    pix = {}
+    for h in ('h1', 'h2', 'h4'):
+        pix[h] = g.randint(0, 256, (224, 224, 3)).astype(np.uint8)
+        Image.fromarray(pix[h]).save(str(img_dir / ('%s.png' % h)))
+        os.rename(str(img_dir / ('%s.png' % h)), str(img_dir / ('%s.jpg' % h)))          # lossless pixels under the .jpg name
+    par = lambda t, ents=(): {'type': 'paragraph', 'text': t, 'named_entities': [{'text': e, 'label': l} for e, l in ents]}  # noqa: E731
+    cap = lambda t, h, ents=(), faces=0: dict({'type': 'caption', 'text': t, 'hash': h,  # noqa: E731
+                                               'named_entities': [{'text': e, 'label': l} for e, l in ents]},
+                                              **({'facenet_details': {'embeddings': g.randn(faces, 512).tolist()}} if faces else {}))
+    a1 = {'_id': 'a1', 'web_url': 'u1', 'headline': {'main': ' hello the '}, 'image_positions': [1, 4, 5, 6],
+          'parsed_section': [par('p0', [('Milan', 'GPE')]), cap('the Milan', 'h1', [('Ann', 'PERSON'), ('Bo', 'PERSON'), ('X', 'ORG')], faces=3),
+                             par('p2'), par('p3', [('Zed', 'PERSON')]), cap('hello', 'h2'), cap('   ', 'h3'), cap('the', 'missing')]}
+    long_par = 'the ' * 300                                                                   # 300 tokens each
+    a2 = {'_id': 'a2', 'web_url': 'u2', 'headline': {}, 'image_positions': [3],
+          'parsed_section': [par('first'), par(long_par + 'A'), par(long_par + 'B'), cap('hello the', 'h4', faces=1),
+                             par(long_par + 'C'), par(long_par + 'D')]}
+    n_tok = lambda t: len(idx.bpe.bpe.encode(t))                                              # noqa: E731
+    s1 = list(article_samples(a1, n_tok))
+    assert [s[0] for s in s1] == [1, 4, 6]                                                    # position 5: empty caption
+    pos, caption, paragraphs, named, section = s1[0]
+    assert caption == 'the Milan' and paragraphs == ['hello the', 'p0', 'p2', 'p3'] and named == ['Milan', 'Zed']
+    assert s1[1][2] == ['hello the', 'p0', 'p2', 'p3']                                        # before the image, document order
+    s2 = list(article_samples(a2, n_tok))
+    # first paragraph, then nearest-first around position 3: (B, C) = 600+ tokens >= 510 -> stop before A and D
+    assert [p[-1] for p in s2[0][2]] == ['t', 'B', 'C'] and s2[0][2][0] == 'first'
+    objects = {'h1': {'object_features': np.abs(g.randn(70, 2048)).tolist()}, 'h2': {'object_features': []}}
+    written, skipped = build_shards([a2, a1], str(img_dir), str(tmp_path / 'shards'), 'train', idx, objects=objects,
+                                    shard_size=2, shuffle_seed=None)
+    assert (written, skipped) == (3, 1)                                                       # the 'missing' image is dropped
+    assert sorted(os.listdir(tmp_path / 'shards')) == ['train-00000.npz', 'train-00001.npz']
+    reader = DatasetReader.by_name('nytimes_faces_ner_matched')(shard_dir=str(tmp_path / 'shards'), use_objects=True,
+                                                                use_caption_names=True, seed=0)
+    got = {inst['metadata']['image_path'].split('/')[-1]: inst for inst in reader._read('train')}
+    assert sorted(got) == ['h1.jpg', 'h2.jpg', 'h4.jpg']
+    i1 = got['h1.jpg']
+    assert np.array_equal(np.asarray(i1['image']), pix['h1'])
+    assert i1['face_embeds'].shape == (2, 512)                                                # 3 faces stored, 2 PERSON names
+    assert i1['obj_embeds'].shape == (64, 2048)                                               # capped at the model's 64
+    assert list(i1['caption']['roberta'])[0] == 0 and list(i1['caption']['roberta'])[-1] == 2
+    assert i1['metadata']['context'] == 'hello the\np0\np2\np3' and i1['metadata']['names'] == ['Milan', 'Zed']
+    assert got['h2.jpg']['face_embeds'].shape == (1, 0) and got['h2.jpg']['obj_embeds'].shape[0] in (0, 1)
+    assert got['h4.jpg']['obj_embeds'].shape[0] in (0, 1)                                     # no objects document: the empty array
+    assert len(got['h4.jpg']['context']['roberta']) == 512                                    # indexer truncation (max_len)
