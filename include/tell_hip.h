@@ -129,6 +129,9 @@ int tell_gemm_bf16(const void* A, long lda, int trans_a, const void* B, long ldb
    bias fp32 [N] or NULL; act 0 none / 1 relu / 2 gelu(erf); N and ldc multiples of 4. */
 int tell_splitk_reduce(const float* partial, int splits, long split_stride, int M, int N, const float* bias, int act,
                        float alpha, void* out, long ldc, int out_dtype, tell_stream_t stream);
+/* the same with a device-side row count: rows >= *m_dev (may be NULL) are neither read nor written */
+int tell_splitk_reduce2(const float* partial, int splits, long split_stride, int M, int N, const float* bias, int act,
+                       float alpha, void* out, long ldc, int out_dtype, const int* m_dev, tell_stream_t stream);
 
 typedef struct tell_gemm_problem {
   const void* A; long lda;
@@ -144,7 +147,11 @@ typedef struct tell_gemm_problem {
   int act;
   float* asum;            /* fp32 [M] or NULL */
   float asum_scale;
-  int reserved;
+  const int* lim_dev;     /* device int32 or NULL: the number of VALID ROWS of the batch dimension - rows of A (and C) in the
+                           * nt / nn forms (M: tiles past it are skipped, their C rows stay untouched), the reduction
+                           * length in the tn form (K: rows past it of both K-major operands are not read).  The adaptive
+                           * softmax's tails work on fixed-capacity buffers with a device-side count (adaptive.py:61-76
+                           * without the mask.any() / nonzero() host syncs). */
 } tell_gemm_problem;
 int tell_gemm_grouped(int n, const tell_gemm_problem* problems, tell_stream_t stream);
 

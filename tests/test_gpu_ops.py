@@ -950,6 +950,35 @@ def test_long_reduction_few_columns_split_k(monkeypatch, M, N, K):
     assert (y1[200:] == 0).all()
 
 
+@pytest.mark.parametrize('cnt', [0, 37, 300, 1024])
+def test_count_limited_products_of_the_softmax_tails(cnt):
+    """The adaptive softmax's tails work on fixed-capacity buffers with a DEVICE-side row count (adaptive.py:61-76 without
+    the mask.any() / nonzero() syncs).  tell_gemm_grouped's lim_dev: the K-major weight-gradient form stops READING at
+    the count (rows past it hold garbage here and must not matter), the K-sliced input-gradient form skips the row tiles
+    past it and tell_splitk_reduce2 leaves those output rows untouched."""
+    from tell_amd import ops
+    torch.manual_seed(cnt)
+    cap, V, E = 1024, 2 * 8192 + 1000, 1024
+    n = torch.tensor([cnt], dtype=torch.int32, device=DEV)
+    # ---- weight gradient: dW[V', E] = dl[:cnt]^T h[:cnt]
+    Vs = 1536
+    dl = torch.randn(cap, Vs, device=DEV).bfloat16(); h = torch.randn(cap, E, device=DEV).bfloat16()
+    out = torch.ones(Vs, E, device=DEV)
+    ops.gemm_tn(dl, h, out=out, accumulate=True, k_dev=n)
+    ref = 1.0 + dl[:cnt].float().t() @ h[:cnt].float()
+    close(out, ref.cpu(), torch.bfloat16, scale=math.sqrt(max(cnt, 1)))
+    # ---- input gradient of a tail with the model width: dh[:cnt] = dl[:cnt] . W   (K = V, sliced)
+    a = torch.zeros(cap, ops._round_up(V, 8), device=DEV).bfloat16()
+    a[:cnt, :V] = torch.randn(cnt, V, device=DEV).bfloat16()
+    w = (torch.randn(V, E, device=DEV) * 0.05).bfloat16()
+    dh = torch.full((cap, E), 3.0, device=DEV).bfloat16()
+    ops.gemm_nn(a, w, out=dh, m_dev=n, zero_rows=True)
+    ref2 = a[:cnt, :V].float() @ w.float()
+    if cnt:
+        close(dh[:cnt], ref2.cpu(), torch.bfloat16, scale=math.sqrt(V) * 0.05)
+    assert (dh[cnt:] == 3).all()                           # row tiles past the count: skipped by the slices AND by the fold
+
+
 @pytest.mark.parametrize('L', [3, 25])
 def test_weigh_bert_mix_forward_and_logit_gradient(L):
     """sum_l softmax(w)[l] * H[l] (transformer_faces_objects.py:355-364): output and the gradient of the L mixing logits

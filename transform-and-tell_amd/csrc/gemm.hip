@@ -1236,9 +1236,11 @@ __device__ __forceinline__ void gemm_tx_body(const GemmArgs& p, const int block,
   const int N = p.N;
   // split K (gridDim.y > 1): this workgroup reduces rows [kb, K) of its slice only and adds its partial tile to the
   // fp32 output with float atomics (p.atomic_out)
-  const int kper = ((p.K + BK - 1) / BK + n_splits - 1) / n_splits * BK;
+  int Kall = p.K;
+  if (p.k_dev) { const int kd = *p.k_dev; Kall = kd < Kall ? kd : Kall; }      // device-side reduction length (block-uniform)
+  const int kper = ((Kall + BK - 1) / BK + n_splits - 1) / n_splits * BK;
   const int kb = split * kper;
-  const int K = p.K < kb + kper ? p.K : kb + kper;
+  const int K = Kall < kb + kper ? Kall : kb + kper;
   if (kb >= K) return;
   const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
   int tile_id;
@@ -1399,7 +1401,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tx_kernel(Gemm
 // Several workgroups per CU then hide each other's load latency.
 #define GROUP_MAX 24
 struct GroupProblem {
-  const void* A; const void* B; void* C; float* asum; const float* bias;
+  const void* A; const void* B; void* C; float* asum; const float* bias; const int* m_dev; const int* k_dev;
   long lda, ldb, ldc;
   int M, N, K, accumulate, bias_mode, act;
   float alpha, asum_scale;
@@ -1416,7 +1418,7 @@ __device__ __forceinline__ int group_find(const GemmGroup& g, int b) {
 }
 __device__ __forceinline__ GemmArgs group_args(const GroupProblem& q) {
   GemmArgs p;
-  p.A = q.A; p.B = q.B; p.C = q.C; p.bias = q.bias; p.aux = nullptr; p.m_dev = nullptr;
+  p.A = q.A; p.B = q.B; p.C = q.C; p.bias = q.bias; p.aux = nullptr; p.m_dev = q.m_dev; p.k_dev = q.k_dev;
   p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc; p.M = q.M; p.N = q.N; p.K = q.K;
   p.bias_mode = q.bias_mode; p.act = q.act; p.accumulate = q.accumulate; p.alpha = q.alpha;
   p.asum = q.asum; p.asum_scale = q.asum_scale; p.ts = nullptr; p.atomic_out = 0; p.conv_zero = nullptr; p.queue = nullptr;
@@ -1776,6 +1778,7 @@ static int launch_group(Kern kern, int bm, int bn, const tell_gemm_problem* pr, 
       t.A = q.A; t.B = q.B; t.C = q.C; t.asum = q.asum; t.bias = q.bias; t.lda = q.lda; t.ldb = q.ldb; t.ldc = q.ldc;
       t.M = q.M; t.N = q.N; t.K = q.K; t.accumulate = q.accumulate; t.bias_mode = q.bias_mode; t.act = q.act;
       t.alpha = q.alpha; t.asum_scale = q.asum_scale;
+      t.m_dev = q.trans_a ? nullptr : q.lim_dev; t.k_dev = q.trans_a ? q.lim_dev : nullptr;
       const long tiles = (long)((q.M + bm - 1) / bm) * ((q.N + bn - 1) / bn);
       g.start[i + 1] = g.start[i] + (int)((tiles + 7) / 8 * 8);
     }
@@ -1874,7 +1877,8 @@ extern "C" int tell_gemm_grouped(int n, const tell_gemm_problem* pr, hipStream_t
 template <typename OutT, int ACT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int splits, long split_stride,
                                                             int M, int N, const float* __restrict__ bias, float alpha,
-                                                            OutT* __restrict__ out, long ldc) {
+                                                            OutT* __restrict__ out, long ldc, const int* __restrict__ m_dev) {
+  if (m_dev) { const int md = *m_dev; M = md < M ? md : M; }
   const int nq = N >> 2;                                     // quads per row (N % 4 == 0)
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)M * nq; i += (long)gridDim.x * blockDim.x) {
     const int m = (int)(i / nq), n = (int)(i % nq) * 4;
@@ -1892,19 +1896,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 // partial: [splits][M][N] fp32 (slice s at partial + s * split_stride); bias: fp32 [N] or NULL; act 0 / 1 (relu) / 2 (gelu)
-extern "C" int tell_splitk_reduce(const float* partial, int splits, long split_stride, int M, int N, const float* bias,
-                                  int act, float alpha, void* out, long ldc, int out_dtype, hipStream_t stream) {
+extern "C" int tell_splitk_reduce2(const float* partial, int splits, long split_stride, int M, int N, const float* bias,
+                                   int act, float alpha, void* out, long ldc, int out_dtype, const int* m_dev,
+                                   hipStream_t stream) {
   if (M <= 0 || N <= 0) return TELL_OK;
   TELL_REQUIRE(splits >= 1 && N % 4 == 0 && ldc % 4 == 0 && act >= 0 && act <= 2, "splitk_reduce: bad arguments");
   TELL_REQUIRE((((uintptr_t)partial | (uintptr_t)out | (uintptr_t)bias) & 15) == 0 && split_stride % 4 == 0,
                "splitk_reduce: buffers must be 16-byte aligned");
   long g = ((long)M * (N / 4) + 255) / 256;
   if (g > 2048) g = 2048;
-#define SKR(OutT, ACT) hipLaunchKernelGGL((splitk_reduce_kernel<OutT, ACT>), dim3((unsigned)g), dim3(256), 0, stream, partial, splits, split_stride, M, N, bias, alpha, (OutT*)out, ldc)
+#define SKR(OutT, ACT) hipLaunchKernelGGL((splitk_reduce_kernel<OutT, ACT>), dim3((unsigned)g), dim3(256), 0, stream, partial, splits, split_stride, M, N, bias, alpha, (OutT*)out, ldc, m_dev)
   if (out_dtype == TELL_BF16) { if (act == 0) SKR(uint16_t, 0); else if (act == 1) SKR(uint16_t, 1); else SKR(uint16_t, 2); }
   else { if (act == 0) SKR(float, 0); else if (act == 1) SKR(float, 1); else SKR(float, 2); }
 #undef SKR
   return tell_check_launch("splitk_reduce");
+}
+extern "C" int tell_splitk_reduce(const float* partial, int splits, long split_stride, int M, int N, const float* bias,
+                                  int act, float alpha, void* out, long ldc, int out_dtype, hipStream_t stream) {
+  return tell_splitk_reduce2(partial, splits, split_stride, M, N, bias, act, alpha, out, ldc, out_dtype, nullptr, stream);
 }
 
 int tell_bn_finish_launch(const float* pmean, const float* pm2, long M, int C, int n_chunks, int rows_per_chunk,

@@ -10,6 +10,7 @@ struct GemmArgs {
   const float* bias;      // fp32, length N (mode 1) or M (mode 2)
   const void* aux;        // act 3: relu-mask source, act 4: residual added before the relu (same layout/dtype as C)
   const int* m_dev;       // optional device-side effective M (rows >= *m_dev are skipped)
+  const int* k_dev = nullptr;   // optional device-side effective K of the K-major forms (rows >= *k_dev of both operands are not read; only the grouped launches set it)
   long lda, ldb, ldc;
   int M, N, K;
   int bias_mode;          // 0 none, 1 per column n, 2 per row m

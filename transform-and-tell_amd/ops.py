@@ -63,6 +63,7 @@ def grad_buffer(p, _dense_writer=False):
 # raw kernels
 # --------------------------------------------------------------------------- #
 _SPLITK = os.environ.get('TELL_GEMM_SKINNY_SPLITK', '1') != '0'          # A/B aid
+_COUNT_LIMIT = os.environ.get('TELL_COUNT_LIMIT', '1') != '0'            # A/B aid: 0 = count-limited buffers are worked on whole
 
 
 # Gradient stores (round 4).  The flat gradient buffer starts every step zeroed and the backward kernels accumulate into
@@ -171,20 +172,28 @@ def _kmajor_ok(t):
 
 
 def gemm_tn(a_km, b_kn, out=None, out_dtype=None, accumulate=False, alpha=1.0, m_dev=None, asum=None,
-            asum_scale=1.0):
+            asum_scale=1.0, k_dev=None):
     """out[M,N] = alpha * sum_k a_km[k,m] * b_kn[k,n] (+ out): both operands K-major, as the forward pass left
     them (wgrad: a_km = dY [T,N_out], b_kn = X [T,K_in]).  bf16 operands go to the LDS-transpose-read kernel;
     anything else (fp32 parity mode, unaligned strides) takes explicit transposes + the NT kernel.
-    asum: optional fp32 [M] accumulator, asum += asum_scale * column sums of a_km (the bias gradient)."""
+    asum: optional fp32 [M] accumulator, asum += asum_scale * column sums of a_km (the bias gradient).
+    k_dev: optional device int32 - only the first *k_dev rows of the two operands carry data (the rest are zeros: the
+    count-limited buffers of the adaptive softmax); the K-major kernels stop reading there."""
     K, M = a_km.shape
     N = b_kn.shape[1]
+    if not _COUNT_LIMIT:
+        k_dev = None
     if _kmajor_ok(a_km) and _kmajor_ok(b_kn) and m_dev is None:
         if out is None:
             out = torch.empty(M, N, dtype=out_dtype or a_km.dtype, device=a_km.device)
         assert out.stride(1) == 1
         if _WGRAD_GROUP['defer'] and K > 0:
             # queued: the pass's weight-gradient GEMMs run together once it is over (wgrad_group_flush)
-            _WGRAD_GROUP['items'].append((a_km, b_kn, out, float(alpha), int(accumulate), asum, float(asum_scale)))
+            _WGRAD_GROUP['items'].append((a_km, b_kn, out, float(alpha), int(accumulate), asum, float(asum_scale), k_dev))
+            return out
+        if k_dev is not None:
+            gemm_grouped([dict(a=a_km, b=b_kn, out=out, form='tn', alpha=alpha, accumulate=accumulate, asum=asum,
+                               asum_scale=asum_scale, lim_dev=k_dev)])
             return out
         call('tell_gemm_bf16', a_km, a_km.stride(0), 1, b_kn, b_kn.stride(0), 1, out, out.stride(0), M, N, K,
              hip.dt(out), None, 0, 0, None, float(alpha), int(accumulate), None, asum, float(asum_scale))
@@ -203,13 +212,14 @@ class _GemmProblem(ctypes.Structure):
                 ('K', ctypes.c_int), ('trans_a', ctypes.c_int), ('trans_b', ctypes.c_int),
                 ('out_dtype', ctypes.c_int), ('accumulate', ctypes.c_int), ('alpha', ctypes.c_float),
                 ('bias', ctypes.c_void_p), ('bias_mode', ctypes.c_int), ('act', ctypes.c_int),
-                ('asum', ctypes.c_void_p), ('asum_scale', ctypes.c_float), ('reserved', ctypes.c_int)]
+                ('asum', ctypes.c_void_p), ('asum_scale', ctypes.c_float), ('lim_dev', ctypes.c_void_p)]
 
 
 def gemm_grouped(problems):
     """Independent bf16 products in a few launches (tell_gemm_grouped).  problems: dicts with a, b, out (tensors),
     form ('nt': a [M,K], b [N,K]; 'nn': b stored [K,N]; 'tn': a stored [K,M] as well) and optionally alpha,
-    accumulate, bias (fp32 [N], 'nt' only), act, asum, asum_scale."""
+    accumulate, bias (fp32 [N], 'nt' only), act, asum, asum_scale, lim_dev (device int32 tensor: the number of valid rows
+    of the batch dimension - output rows of 'nt' / 'nn', reduction rows of 'tn')."""
     if not problems:
         return
     arr = (_GemmProblem * len(problems))()
@@ -229,6 +239,8 @@ def gemm_grouped(problems):
             int(pr.get('act', 0))
         asum = pr.get('asum')
         q.asum, q.asum_scale = (asum.data_ptr() if asum is not None else None), float(pr.get('asum_scale', 1.0))
+        lim = pr.get('lim_dev')                  # device int32: valid rows of the batch dimension (M of nt / nn, K of tn)
+        q.lim_dev = lim.data_ptr() if lim is not None else None
     call('tell_gemm_grouped', len(problems), arr)
 
 
@@ -266,8 +278,8 @@ def wgrad_group_flush():
 
 
 def _launch_wgrad_group(items):
-    gemm_grouped([dict(a=a, b=b, out=out, form='tn', alpha=alpha, accumulate=acc, asum=asum, asum_scale=asum_scale)
-                  for a, b, out, alpha, acc, asum, asum_scale in items])
+    gemm_grouped([dict(a=a, b=b, out=out, form='tn', alpha=alpha, accumulate=acc, asum=asum, asum_scale=asum_scale, lim_dev=kd)
+                  for a, b, out, alpha, acc, asum, asum_scale, kd in items])
 
 
 def gemm_nn(a, b_kn, b_t=None, out=None, out_dtype=None, alpha=1.0, act=0, aux=None, m_dev=None, accumulate=False,
@@ -294,10 +306,12 @@ def gemm_nn(a, b_kn, b_t=None, out=None, out_dtype=None, alpha=1.0, act=0, aux=N
         ks = 2048 if N <= 256 else 8192
         splits = (K + ks - 1) // ks
         partial = torch.empty(splits, M, N, dtype=torch.float32, device=a.device)
+        # (m_dev: workgroups of row tiles past the count leave at once, the fold skips those rows - they stay the zeros the
+        #  caller's buffer holds.  With real captions the tails see a few dozen rows of the 1024-row capacity.)
         gemm_grouped([dict(a=a[:, i * ks:min(_round_up(K, 8), (i + 1) * ks)], b=b_kn[i * ks:min(K, (i + 1) * ks)],
-                           out=partial[i], form='nn') for i in range(splits)])
-        call('tell_splitk_reduce', partial, splits, partial.stride(0), M, N, None, 0, float(alpha), out, out.stride(0),
-             hip.dt(out))
+                           out=partial[i], form='nn', lim_dev=m_dev if _COUNT_LIMIT else None) for i in range(splits)])
+        call('tell_splitk_reduce2', partial, splits, partial.stride(0), M, N, None, 0, float(alpha), out, out.stride(0),
+             hip.dt(out), m_dev if _COUNT_LIMIT else None)
         return out
     if (_kmajor_ok(b_kn) and a.dtype == torch.bfloat16 and a.stride(1) == 1 and a.stride(0) % 8 == 0 and
             (K % 8 == 0 or a.shape[1] >= _round_up(K, 8)) and a.data_ptr() % 16 == 0 and
@@ -1564,7 +1578,7 @@ class AdaptiveEmbedFn(Function):
             cnt = part['count'][b:b + 1]
             dy = dband[b * N:(b + 1) * N]                      # rows >= count are zero
             if proj.requires_grad:
-                gemm_tn(dy, rows_saved[b], out=grad_buffer(proj), accumulate=True)
+                gemm_tn(dy, rows_saved[b], out=grad_buffer(proj), accumulate=True, k_dev=cnt)
             if emb.requires_grad:
                 drows = gemm_nn(dy, weight(proj), b_t=lambda: weight_t(proj), m_dev=cnt)[:, :dim]
                 if not drows.is_contiguous():
@@ -1689,10 +1703,10 @@ class AdaptiveLossFn(Function):
                  lse_t, gscale, dlt, dlt.stride(0), hip.dt(dtype))
             dh = zs[2 + 2 * i]
             gemm_nn(dlt, weight(emb), b_t=lambda emb=emb: weight_t(emb), out=dh, m_dev=cnt, zero_rows=True)
-            if emb.requires_grad:                                  # rows >= count of dlt are zero
-                gemm_tn(dlt[:, :V], h, out=grad_buffer(emb), accumulate=True)
+            if emb.requires_grad:                                  # rows >= count of dlt are zero: not read (k_dev)
+                gemm_tn(dlt[:, :V], h, out=grad_buffer(emb), accumulate=True, k_dev=cnt)
             if proj.requires_grad:
-                gemm_tn(dh, xg, out=grad_buffer(proj), accumulate=True)
+                gemm_tn(dh, xg, out=grad_buffer(proj), accumulate=True, k_dev=cnt)
             dxg = gemm_nn(dh, weight(proj), b_t=lambda proj=proj: weight_t(proj), m_dev=cnt)
             if not dxg.is_contiguous():
                 dxg = dxg.contiguous()
