@@ -10,12 +10,11 @@
  *
  * Conventions
  *   - plain pointers + sizes, no torch types; caller owns all memory; the library
- *     allocates nothing.  Its only state: a thread-local error string, five
+ *     allocates nothing.  Its only state: a thread-local error string, four
  *     REGISTERED device pointers: two that kernels read while a hipGraph is recorded /
  *     replayed (tell_set_rng_step_ptr, tell_set_pos_step_ptr: the dropout step and
- *     decode position counters), the tile-counter buffer of the persistent GEMM launches
- *     (tell_gemm_set_tile_queue), the mask scratch of the long-sequence self-attention
- *     (tell_attn_set_mask_scratch) and a thread-local one-shot hook that arms
+ *     decode position counters), the per-device tile-counter buffer of the resident GEMM
+ *     launches (tell_gemm_set_tile_queue) and a thread-local one-shot hook that arms
  *     the next tell_gemm_nt launch with a span stamp (tell_gemm_ts_next);
  *   - every call is asynchronous on `stream` (pass torch's current stream);
  *   - return 0 on success, <0 on error (tell_last_error() explains);
@@ -66,13 +65,23 @@ int tell_cu_hog(int n_workgroups, long ticks, int* stop, tell_stream_t stream);
  * into ts[0] (first workgroup in) / ts[1] (last workgroup out), device wall-clock ticks; ts is uint64[3], zero before
  * the first use (ts[2] counts workgroup arrivals: every launch of the same grid re-opens the span by itself) */
 int tell_gemm_ts_next(void* ts, tell_stream_t stream);
-/* register the tile counters of the RESIDENT 256x256 GEMM launches (gemm_nt_pp2_kernel): `counters` = n zero-initialised
- * int32 on the device, owned by the caller and alive for as long as GEMMs are launched (NULL / 0 unregisters: resident
- * launches then walk static tile lists).  A launch with more tiles than workgroups takes 8 counters (one per XCD) as its
- * work queues and leaves them zero.  Launches recorded into a hipGraph keep theirs for good and come out of the first half
- * of the buffer, each slot handed out once (when the half is used up, later captures use static lists); eager launches
- * walk a ring over the second half.  The host mirror registers 2^20 counters. */
+/* register the tile counters of the RESIDENT 256x256 GEMM launches (gemm_nt_pp2 / q4 / q4e kernels) FOR THE CALLING THREAD'S
+ * CURRENT DEVICE: `counters` = n zero-initialised int32 on that device, owned by the caller and alive for as long as GEMMs
+ * are launched there (NULL / 0 unregisters: resident launches then walk static tile lists).  The buffer is cut into slots
+ * of 8 counters (one per XCD); a launch with more tiles than workgroups takes one slot as its work queues and leaves it
+ * zero.  Launches recorded into a hipGraph keep their slot while the graph lives and take it from the first half of the
+ * buffer (released slots first, then fresh ones; when the half is used up, later captures use static lists); eager
+ * launches walk a ring over the second half.  Hand-out is thread-safe.  The host mirror registers 2^20 counters per device. */
 int tell_gemm_set_tile_queue(void* counters, int n, tell_stream_t stream);
+/* bookkeeping of the slots captured launches keep (host-only calls, no stream): _log_begin arms a thread-local record of the
+ * slot numbers the calling thread's captured launches take from now on; _log_end returns how many were taken (copying at
+ * most `cap` of them to `out`) and disarms it; _release gives slots back to the current device's free list (call it when
+ * the graph that recorded them is destroyed); _stats: out[0] = slots, out[1] = fresh captured slots handed out so far,
+ * out[2] = free-list length. */
+int tell_gemm_tile_queue_log_begin(void);
+int tell_gemm_tile_queue_log_end(int* out, int cap);
+int tell_gemm_tile_queue_release(const int* slots, int n);
+int tell_gemm_tile_queue_stats(int* out);
 
 /* ---- exact-erf GELU as its own launch (bf16; y may be x) ----------------------
  * the activation between fc1 and fc2 of fairseq's TransformerSentenceEncoderLayer (activation_fn = gelu) when it is kept
@@ -373,12 +382,6 @@ int tell_attn_fwd(const void* q, const void* k, const void* v, void* out, float*
                   const void* bias_k, const void* bias_v, int B, int H, int Tq, int S, int D, long q_st,
                   long q_sb, long k_ss, long k_sb, long v_ss, long v_sb, long o_st, long o_sb, int has_zero,
                   float p, uint32_t seed, uint32_t salt, int dtype, tell_stream_t stream);
-/* register `bytes` of device scratch (caller-owned, alive while attention is launched; NULL unregisters) for the long-sequence
- * self-attention forward (fairseq self-attention as called at transformer_faces_objects.py:352-353, D = 64, S % 64 == 0,
- * Tq % 32 == 0, bf16, p > 0): tell_attn_fwd then first writes the dropout keep decisions of multi_head.py:463 as bit masks
- * (B*H*Tq*S/8 bytes: 16.8 MB at B = 32, H = 16, S = 512; the same counter hash, so the same mask) with one launch and the
- * attention kernel applies them with one instruction per probability instead of hashing in place.  Thread-local. */
-int tell_attn_set_mask_scratch(void* ptr, long bytes, tell_stream_t stream);
 /* dbias_k / dbias_v: fp32 [B, H*D] per-sample partials of the bias_k / bias_v gradients (the caller sums over B), each
    with row stride H*D - or, when dbias_v == dbias_k + H*D, the two column halves of one [B, 2*H*D] buffer. */
 int tell_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,

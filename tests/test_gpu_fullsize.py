@@ -508,21 +508,28 @@ class _StandInResnet(torch.nn.Module):
         return f.permute(0, 2, 3, 1).reshape(f.shape[0], 49, 2048).to(tell_amd.compute_dtype()).contiguous()
 
 
-@pytest.mark.parametrize('kind,batch', [('faces_objects', 32), ('flattened', 16)])
-def test_bench_shape_step_through_the_step_graph_matches_oracle(kind, batch):
+@pytest.mark.parametrize('kind,batch,dyn', [('faces_objects', 32, False), ('flattened', 16, False), ('faces_objects', 32, True)],
+                         ids=['faces_objects-32', 'flattened-16', 'faces_objects-32-tile-queue'])
+def test_bench_shape_step_through_the_step_graph_matches_oracle(kind, batch, dyn, monkeypatch):
     """BASELINE configs[2] (4 contexts, B = 32) and configs[1] (2 contexts, B = 16) at full decoder size, 512-token
     articles, 33-token captions, bf16: one optimisation step's decoder half - loss and EVERY gradient tensor (decoder
     and the RoBERTa layer-mix weights) - as the captured step graph REPLAYS it (training/step_graph.py), against the
     CPU oracle on the same batch; reference: decoder_faces_objects.py:255-365, transformer_faces_objects.py:67-140.
     Bounds as in the B = 4 test: each gradient within BF16_VS_AUTOCAST x the error the oracle itself shows under CPU
     bf16 autocast on this batch.  (The encoders are table look-ups here; their own bench-size parity lives in
-    test_gpu_encoders.py.)"""
+    test_gpu_encoders.py.)
+    tile-queue: the same step with TELL_Q4_DYNAMIC=1 - per-XCD tile counters in the resident GEMMs (the article K|V
+    projection here), the DEFAULT under data parallelism (training/trainer.py) - captured into the graph: its slots come
+    out of the per-device queue (csrc/gemm.hip) and go back when the graph entry is dropped."""
     import tell_amd
     from oracle.build import build_model as obuild
     from tell_amd.build import build_model
     from tell_amd.data import synthetic_batch
     from tell_amd.training import Trainer
     fo = kind == 'faces_objects'
+    if dyn:
+        monkeypatch.setenv('TELL_Q4_DYNAMIC', '1')
+    held0 = tell_amd.hip.tile_queue_stats() if torch.cuda.is_available() else None
     tell_amd.set_compute_dtype(torch.bfloat16)
     torch.manual_seed(0)
     gpu = build_model(kind, _StandInResnet(True), _StandInRoberta(), n_bert_layers=3)
@@ -573,3 +580,14 @@ def test_bench_shape_step_through_the_step_graph_matches_oracle(kind, batch):
         kind, batch, abs(loss - float(ref['loss'])) / abs(float(ref['loss'])), len(report), report[len(report) // 2][0],
         ', '.join('%s %.2e (autocast %.2e)' % (k.replace('decoder.', ''), r, yard[k]) for r, k in report[:4])))
     assert worst <= BF16_CEIL, report[:6]
+    if dyn:
+        slots = list(e['tile_slots'].slots)
+        del e
+        assert slots, 'the captured step took no tile-counter slot: the dynamic path did not run'
+        n, fresh, free = tell_amd.hip.tile_queue_stats()
+        assert fresh - free >= len(slots) and n == (1 << 20) // 8
+        tr.step_graph.reset()                                              # dropping the graph gives its slots back
+        import gc
+        gc.collect()
+        n2, fresh2, free2 = tell_amd.hip.tile_queue_stats()
+        assert fresh2 == fresh and free2 == free + len(slots), (held0, (n, fresh, free), (n2, fresh2, free2))

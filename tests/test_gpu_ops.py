@@ -231,12 +231,11 @@ def test_gemm_dropout_residual_epilogue(M, N, K, p):
     assert hip.call_rc('tell_gemm_nt_dropout_residual', ad, K, bd, K, biasd, rd, N, out, N, 256, N, K, p, 17, 23) == 1
 
 
-@pytest.mark.parametrize('env', [{'TELL_GEMM_PP2': '0'}, {'TELL_GEMM_PP2': '1'}, {'TELL_GEMM_DUO': '2'},
-                                 {'TELL_GEMM_DUO': '2', 'TELL_DUO_REG': '1'}, {'TELL_GEMM_PP2': '2', 'TELL_PP2_DYNAMIC': '1'},
+@pytest.mark.parametrize('env', [{'TELL_GEMM_PP2': '0'}, {'TELL_GEMM_PP2': '1'}, {'TELL_GEMM_PP2': '2', 'TELL_PP2_DYNAMIC': '1'},
                                  {'TELL_GEMM_PP2': '2', 'TELL_PP2_DYNAMIC': '0'}],
-                         ids=['pp', 'pp2-multi-round', 'duo', 'duo-reg', 'pp2-tile-queue', 'pp2-static'])
+                         ids=['pp', 'pp2-multi-round', 'pp2-tile-queue', 'pp2-static'])
 def test_gemm_kernel_variants_behind_switches(env):
-    """The GEMM kernels that are not the default choice (one-workgroup-per-tile ping-pong, the 256x128 two-per-CU forms)
+    """The GEMM kernels that are not the default choice (the ping-pong family: fallback for K % 128 != 0)
     stay correct: the switches are read once per process, so each runs tools/probes/gemm_variant_check.py in its own."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -245,7 +244,7 @@ def test_gemm_kernel_variants_behind_switches(env):
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'probes', 'gemm_variant_check.py')], env=e,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'ALL OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-    want = 'gemm_nt_duo_kernel' if 'TELL_GEMM_DUO' in env else ('gemm_nt_pp_kernel' if env['TELL_GEMM_PP2'] == '0' else 'gemm_nt_pp2_kernel')
+    want = 'gemm_nt_pp_kernel' if env['TELL_GEMM_PP2'] == '0' else 'gemm_nt_pp2_kernel'
     assert want in r.stdout, r.stdout[-2000:]
 
 
@@ -273,44 +272,6 @@ def test_gemm_q4_kernel(env):
         for shape in ('M=12288 N=1024 K=1024', 'M=12288 N=1024 K=4096', 'M=12288 N=2048 K=1024'):
             line = [ln for ln in r.stdout.splitlines() if shape in ln]
             assert line and line[0].startswith('gemm_nt_q4_kernel'), (shape, line)
-
-
-@pytest.mark.parametrize('B,H,S,masked', [(2, 4, 256, False), (3, 2, 512, True), (32, 16, 512, True)])
-def test_self_attention_dropout_lane_masks_equal_the_in_kernel_hash(B, H, S, masked):
-    """Long-sequence self-attention forward (fairseq self-attention, called at transformer_faces_objects.py:352-353) with
-    attention dropout: the decisions taken from attn_dropmask_kernel's lane masks (registered scratch; opt-in, TELL_ATTN_BITS=1:
-    measured slower than hashing in place, csrc/attention.hip) against the same kernel hashing in place: the SAME mask, so outputs and log-sum-exps are bit-identical; and
-    against dropout off, a tenth of the probabilities is gone (the two differ)."""
-    from tell_amd import hip
-    D, E = 64, H * 64
-    g = torch.Generator().manual_seed(B + H + S)
-    q = torch.randn(S, B, E, generator=g).bfloat16().to(DEV)
-    k = torch.randn(S, B, E, generator=g).bfloat16().to(DEV)
-    v = torch.randn(S, B, E, generator=g).bfloat16().to(DEV)
-    mask = torch.zeros(B, S, dtype=torch.uint8)
-    if masked:
-        for b in range(B):
-            mask[b, S - 17 * (b % 5):] = 1
-    mask = mask.to(DEV)
-
-    def run(p):
-        out = torch.empty_like(q)
-        lse = torch.empty(B * H, S, device=DEV)
-        hip.call('tell_attn_fwd', q, k, v, out, lse, mask, None, None, B, H, S, S, D, q.stride(0), q.stride(1), k.stride(0),
-                 k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1), 0, p, 11, 5, hip.dt(q))
-        torch.cuda.synchronize()
-        return out, lse
-    assert not os.environ.get('TELL_ATTN_BITS')
-    hashed = run(0.1)
-    os.environ['TELL_ATTN_BITS'] = '1'
-    try:
-        bits = run(0.1)
-        assert torch.equal(run(0.1)[0], bits[0])              # the scratch is rewritten by every call: repeatable
-    finally:
-        del os.environ['TELL_ATTN_BITS']
-    assert torch.equal(bits[0], hashed[0]) and torch.equal(bits[1], hashed[1])
-    plain = run(0.0)
-    assert not torch.equal(bits[0], plain[0])
 
 
 @pytest.mark.parametrize('dtype', DTYPES)

@@ -128,6 +128,57 @@ def test_gradient_stores_equal_zero_and_accumulate(graph, monkeypatch):
     assert float((ta.flat.flat - tb.flat.flat).norm()) <= 1e-6 * float(ta.flat.flat.norm())
 
 
+@pytest.mark.parametrize('graph', [False, True])
+def test_gradient_stores_survive_an_all_empty_context_and_a_mixed_accumulation(graph, monkeypatch):
+    """Two ways a stored gradient could go stale (round-4 advisor findings): (1) a batch in which NO sample has a face
+    hands the model an empty faces context, the K / V projections of that context are skipped and rows [E,3E) of its
+    in_proj_weight get no gradient write - such a step must run zero + accumulate, or the previous step's rows would be
+    applied again; (2) micro-batches with defer_update=True followed by a LAST pass with defer_update=False: that pass
+    must add to the accumulated gradients, not store over part of them.  Reference: the same trainer with
+    TELL_GRAD_STORE=0."""
+    import tell_amd
+    from tell_amd.build import build_model
+    from tell_amd.data import synthetic_batch
+    from tell_amd.training import Trainer
+    tell_amd.set_compute_dtype(torch.float32)
+    torch.manual_seed(0)
+    a = build_model('faces_objects', _Res(True), _Rob(1024), n_bert_layers=3, **KW)
+    _no_dropout(a)
+    for m in a.modules():
+        if isinstance(getattr(m, 'dropout', None), float):
+            m.dropout = 0.0
+    b = copy.deepcopy(a)
+    ocfg = dict(lr=5e-3, warmup=0.5, t_total=20, b1=0.9, b2=0.98, e=1e-6, weight_decay=1e-5, max_grad_norm=0.1)
+    monkeypatch.setenv('TELL_GRAD_STORE', '0')
+    ta = Trainer(a, dict(ocfg), device=DEV)
+    monkeypatch.setenv('TELL_GRAD_STORE', '1')
+    tb = Trainer(b, dict(ocfg), device=DEV)
+    if not graph:
+        ta.step_graph = tb.step_graph = None
+    full = _dev(synthetic_batch(B=3, article_len=20, caption_len=9, faces_objects=True, vocab=600, cutoffs=(100, 300), seed=62))
+    empty = _clone(full)
+    empty['face_embeds'] = torch.empty(3, 1, 0, device=DEV)                 # collate's empty field: nobody has a face
+    seq = [full, full, full, empty, full, empty, empty, full, full]
+    for s, bt in enumerate(seq):
+        la, lb = ta.train_one_batch(_clone(bt)), tb.train_one_batch(_clone(bt))
+        assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(la)), (s, float(la), float(lb))
+        num = float((ta.flat.flat - tb.flat.flat).norm())
+        assert num <= 1e-6 * float(ta.flat.flat.norm()), (s, num)
+    assert tb._store == 'ready' and tb.flat.stored_numel > 0
+    # (2) accumulate two micro-batches, the second one ending the accumulation with the update
+    for t in (ta, tb):
+        t.defer_update = True
+        t.train_one_batch(_clone(full))
+        t.defer_update = False
+        t.train_one_batch(_clone(full))
+    num = float((ta.flat.flat - tb.flat.flat).norm())
+    assert num <= 1e-6 * float(ta.flat.flat.norm()), num
+    la, lb = ta.train_one_batch(_clone(full)), tb.train_one_batch(_clone(full))        # and store mode is back
+    assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(la))
+    assert float((ta.flat.flat - tb.flat.flat).norm()) <= 1e-6 * float(ta.flat.flat.norm())
+    assert not tb.flat.accum_pending
+
+
 def test_step_graph_draws_fresh_dropout_masks():
     """lr = 0 keeps the weights fixed: replaying the same batch must still give different losses, because every replay
     adds the graph's device step counter to the dropout salts."""

@@ -62,9 +62,6 @@ def case(name, B, H, T, S, D, p, bias, backward):
 
 
 case('roberta self', 32, 16, 512, 512, 64, 0.1, False, False)
-os.environ['TELL_ATTN_BITS'] = '1'      # opt-in: keep decisions as lane masks from attn_dropmask_kernel (its launch is inside the timed call)
-case('roberta self (lane masks)', 32, 16, 512, 512, 64, 0.1, False, False)
-del os.environ['TELL_ATTN_BITS']
 case('roberta self (no drop)', 32, 16, 512, 512, 64, 0.0, False, False)
 for name, S in (('decoder article', 512), ('decoder image', 49), ('decoder faces', 4), ('decoder objects', 64)):
     case(name, 32, 16, 32, S, 64, 0.1, True, True)

@@ -32,12 +32,10 @@ S_CLOBBER = list(range(36, 100))
 # operands (and the barrier) sits BEHIND the drain, which does not need them; no_imm: timing probe (wrong results) without the
 # drain's 8 immediate stores.  PROBES are instantiated with s_memtime stamps for tools/probes/q4_variants.py (TELL_Q4E_VAR).
 PROD = dict(nsb=12, pos=(53, 61), width=4, late_wait=True, no_imm=False)      # measured best of PROBES (tools/probes/q4_variants.py)
-PROBES = (dict(nsb=8, pos=(53, 56, 59), width=4, late_wait=False, no_imm=False),
-          dict(nsb=12, pos=(53, 61), width=4, late_wait=False, no_imm=False),
-          dict(nsb=12, pos=(53, 55, 57, 59), width=2, late_wait=False, no_imm=False),
-          dict(nsb=12, pos=(53, 61), width=4, late_wait=True, no_imm=False),
-          dict(nsb=12, pos=(53, 61), width=4, late_wait=True, no_imm=True),
-          dict(nsb=12, pos=(55, 58, 61, 0), width=2, late_wait=True, no_imm=False))
+# The production configuration with stamps (TELL_Q4E_VAR=0).  Round 4 compared six configurations here (nsb 8 / 12, store
+# positions, dwordx2 pairs, the late wait, no immediate stores: profiles/r04_q4_variants.txt has their numbers); the losing
+# five were removed from the shipped library in round 5 - put their dicts back here to re-measure them.
+PROBES = (dict(PROD),)
 
 # operands of the main statement
 OP = dict(XRD=0, WRD=1, XVO=2, WVO=3, COFF=4, BRD=5, BVO=6, XCUR=7, WCUR=8, XNEXT=9, WNEXT=10, LDA32=11, LDB32=12, NKF=13,

@@ -1,7 +1,6 @@
 """GEMM kernel variants behind environment switches, against an fp32 product of the same bf16 operands:
   (default)            gemm_nt_pp2_kernel  - resident 256x256 ping-pong workgroups, next tile prefetched under the epilogue
   TELL_GEMM_PP2=0      gemm_nt_pp_kernel   - one workgroup per tile
-  TELL_GEMM_DUO=2      gemm_nt_duo_kernel  - 256x128 tiles, two workgroups per CU (TELL_DUO_REG=1: register-staged ring)
 K-tile counts 1, 2, 3, 5 (, 16, 32) walk prologue / steady state / tail of the counted-vmcnt pipelines, several tiles per
 resident workgroup; every epilogue form; repeated launches bit-identical.  tests/test_gpu_ops.py runs it per switch."""
 import math, os, sys, torch
@@ -10,9 +9,7 @@ import tell_amd
 from tell_amd import hip, ops
 hip.require_gpu()        # (registers the tile-counter buffer of the resident GEMM launches)
 ok = True
-SHAPES = ((4096, 4096, 64), (4096, 4096, 96), (4096, 4096, 128), (8192, 2048, 160), (16384, 1024, 1024), (16384, 3072, 1024))
-if not os.environ.get('TELL_GEMM_DUO'):
-    SHAPES = ((16384, 4096, 64), (16384, 4096, 128), (16384, 4096, 192), (16384, 4096, 320), (8192, 8192, 256), (16384, 3072, 1024), (16384, 1024, 1024))
+SHAPES = ((16384, 4096, 64), (16384, 4096, 128), (16384, 4096, 192), (16384, 4096, 320), (8192, 8192, 256), (16384, 3072, 1024), (16384, 1024, 1024))
 for M, N, K in SHAPES:
     g = torch.Generator(device='cuda').manual_seed(M + N + K)
     a = torch.randn(M, K, device='cuda', generator=g).bfloat16()

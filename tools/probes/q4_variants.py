@@ -95,7 +95,7 @@ os.environ['TELL_Q4_ABL'] = '0'
 
 # ---- gemm_nt_q4e_kernel probes (TELL_Q4E_VAR = index into PROBES of tools/gen_q4e_loop.py; act 0 shapes only): time + stamps
 # t0 -> [setup (+ wait)] ta -> [drain of the previous tile (+ wait)] td -> [K loop with the deferred stores] tb -> t1
-NPROBE = int(os.environ.get('Q4E_PROBES', '6'))
+NPROBE = int(os.environ.get('Q4E_PROBES', '1'))
 pg = {}
 for v in range(NPROBE):
     setenv({'TELL_GEMM_Q4': '1', 'TELL_GEMM_Q4E': '1', 'TELL_Q4E_VAR': str(v), 'TELL_Q4_DYNAMIC': os.environ.get('Q4E_DYN', '1')})

@@ -142,7 +142,6 @@ struct AttnArgs {
   int has_bias, has_zero;
   uint32_t thr; float inv_keep; uint32_t seed, salt;
   const uint32_t* step;      // replayable dropout (common.h tell_step_salt); NULL in eager mode
-  const unsigned long long* drop_bits;   // self-attention forward: keep decisions as lane masks (attn_dropmask_kernel), or NULL
   // backward only
   const void *dout, *o;           // same layout as out
   void *dq, *dk, *dv;             // same layouts as q, k, v
@@ -845,11 +844,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_reg_kernel(AttnArgs p) {
 // without - the 14 us the no-staging ablation removes are the tile loads themselves, not the register round trip.
 typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* attn_glb_ptr_t;
-// BITS (round 4): the keep decisions do not come out of the counter hash here - 45 % of this kernel's VALU work sat in it
-// (r03_pmc_attention.txt) - but out of p.drop_bits, which attn_dropmask_kernel filled from the SAME hash just before this
-// launch: per (b h, 32-query block, 64-key tile) 32 lane masks of 64 bits, one per accumulator register of the score tile,
-// fetched with scalar loads and applied with one v_cndmask_b32 per probability (144 -> 32 VALU issues per tile and wave).
-template <bool DROP, int ABL = 0, bool DMA = false, bool BITS = false>
+template <bool DROP, int ABL = 0, bool DMA = false>
 __global__ __launch_bounds__(256, 3) void attn_self_fwd_kernel(AttnArgs p) {
   const uint32_t salt_eff = tell_step_salt(p.salt, p.step);
   using T = uint16_t;
@@ -981,21 +976,6 @@ __global__ __launch_bounds__(256, 3) void attn_self_fwd_kernel(AttnArgs p) {
     if (active) {
       const T* Kb = &Ks[BUF][k_off];
       const T* Vb = &Vs[BUF][v_off];
-      unsigned long long mbits[32];
-      if constexpr (DROP && BITS) {                        // this tile's 32 lane masks: scalar loads, waited for behind the exps
-        const int qb_u = __builtin_amdgcn_readfirstlane(qb);
-        const unsigned long long* mw = p.drop_bits + ((((long)bh * QB + qb_u) * nkt + kt) << 5);
-#define ATTN_SLOAD8(O)                                                                                                   \
-        asm volatile("s_load_dwordx2 %0, %8, %9\n\ts_load_dwordx2 %1, %8, %10\n\ts_load_dwordx2 %2, %8, %11\n\t"               \
-                     "s_load_dwordx2 %3, %8, %12\n\ts_load_dwordx2 %4, %8, %13\n\ts_load_dwordx2 %5, %8, %14\n\t"              \
-                     "s_load_dwordx2 %6, %8, %15\n\ts_load_dwordx2 %7, %8, %16"                                             \
-                     : "=&s"(mbits[O]), "=&s"(mbits[O + 1]), "=&s"(mbits[O + 2]), "=&s"(mbits[O + 3]), "=&s"(mbits[O + 4]),  \
-                       "=&s"(mbits[O + 5]), "=&s"(mbits[O + 6]), "=&s"(mbits[O + 7])                                      \
-                     : "s"(mw), "i"(8 * (O)), "i"(8 * (O) + 8), "i"(8 * (O) + 16), "i"(8 * (O) + 24), "i"(8 * (O) + 32),     \
-                       "i"(8 * (O) + 40), "i"(8 * (O) + 48), "i"(8 * (O) + 56))
-        ATTN_SLOAD8(0); ATTN_SLOAD8(8); ATTN_SLOAD8(16); ATTN_SLOAD8(24);
-#undef ATTN_SLOAD8
-      }
       f32x16 st[2];
 #pragma unroll
       for (int f = 0; f < 2; ++f)
@@ -1053,22 +1033,7 @@ __global__ __launch_bounds__(256, 3) void attn_self_fwd_kernel(AttnArgs p) {
           st[f][r + 1] = pv[1];
         }
       float ls = ls2[0] + ls2[1];
-      if constexpr (DROP && BITS) {
-        unsigned long long m[32];                          // (scalar loads issued at the top of the tile, below)
-#pragma unroll
-        for (int e = 0; e < 32; ++e) m[e] = mbits[e];
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+s"(m[0]), "+s"(m[1]), "+s"(m[2]), "+s"(m[3]), "+s"(m[4]), "+s"(m[5]), "+s"(m[6]), "+s"(m[7]),
-                       "+s"(m[8]), "+s"(m[9]), "+s"(m[10]), "+s"(m[11]), "+s"(m[12]), "+s"(m[13]), "+s"(m[14]), "+s"(m[15]));
-        asm volatile(""
-                     : "+s"(m[16]), "+s"(m[17]), "+s"(m[18]), "+s"(m[19]), "+s"(m[20]), "+s"(m[21]), "+s"(m[22]), "+s"(m[23]),
-                       "+s"(m[24]), "+s"(m[25]), "+s"(m[26]), "+s"(m[27]), "+s"(m[28]), "+s"(m[29]), "+s"(m[30]), "+s"(m[31]));
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            asm volatile("v_cndmask_b32 %0, 0, %1, %2" : "=v"(st[f][r]) : "v"(st[f][r]), "s"(m[f * 16 + r]));
-      } else if constexpr (DROP) {
+      if constexpr (DROP) {
         const uint64_t base = row_base + (uint64_t)kt * KT;
         if (tell_keep_row_ok(base >> 2, 16)) {
           const TellKeepRow row = tell_keep_row(p.seed, salt_eff, base >> 2);    // S % 64 == 0: base is a multiple of 4
@@ -1510,43 +1475,7 @@ static int fill_args(AttnArgs& a, const void* q, const void* k, const void* v, v
   a.o_st = o_st; a.o_sb = o_sb; a.B = B; a.H = H; a.Tq = Tq; a.S = S;
   a.has_bias = bias_k ? 1 : 0; a.has_zero = has_zero;
   a.thr = p > 0.f ? tell_drop_threshold(p) : 0u; a.inv_keep = 1.f / (1.f - p); a.seed = seed; a.salt = salt; a.step = g_tell_rng_step;
-  a.drop_bits = nullptr;
   a.dout = nullptr; a.o = nullptr; a.dq = a.dk = a.dv = nullptr; a.dbias_k = a.dbias_v = nullptr; a.dbias_ld = 0;
-  return TELL_OK;
-}
-
-// Keep decisions of the self-attention dropout as lane masks (see attn_self_fwd_kernel BITS): wave (b h, qb, kt), lane (qi =
-// lane & 31, hh = lane >> 5) owns query t = 32 qb + qi and, for mask e = 16 f + r, key 64 kt + 32 f + 8 (r >> 2) + 4 hh + (r & 3)
-// - the score tile's register layout.  The decisions are common.h's quad hash of element (b h, t, key): exactly what the
-// kernel computed in place before (tests that rebuild the masks from tell_amd/rng.py see no difference).
-__global__ __launch_bounds__(256) void attn_dropmask_kernel(unsigned long long* __restrict__ bits, int Tq, int S, uint32_t thr,
-                                                            uint32_t seed, uint32_t salt, const uint32_t* step) {
-  const uint32_t salt_eff = tell_step_salt(salt, step);
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hh = lane >> 5, qi = lane & 31;
-  const int nkt = S >> 6, QB = Tq >> 5;
-  const int kt = blockIdx.x * 4 + wave, qb = blockIdx.y, bh = blockIdx.z;
-  if (kt >= nkt) return;
-  const int t = qb * 32 + qi;
-  const uint64_t base = ((uint64_t)bh * Tq + t) * (uint64_t)S + (uint64_t)kt * 64 + 4 * hh;      // a multiple of 4
-  unsigned long long mine = 0ull;
-#pragma unroll
-  for (int m = 0; m < 8; ++m) {                              // quad m: keys 8 m + 4 hh + {0..3} of the tile -> (f, r) = (m >> 2, 4 (m & 3) + ..)
-    const uint64_t quad = (base >> 2) + 2 * m;
-    bool k[4];
-    tell_keep4_bits(tell_quad_x(seed, quad), tell_quad_y(salt_eff, quad), thr, k[0], k[1], k[2], k[3]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned long long b = __ballot(k[j]);
-      if (lane == 4 * m + j) mine = b;                       // e = 16 (m >> 2) + 4 (m & 3) + j = 4 m + j
-    }
-  }
-  if (lane < 32) bits[((((long)bh * QB + qb) * nkt + kt) << 5) + lane] = mine;
-}
-static thread_local unsigned long long* g_attn_bits = nullptr;
-static thread_local long g_attn_bits_bytes = 0;
-extern "C" int tell_attn_set_mask_scratch(void* ptr, long bytes, hipStream_t) {
-  g_attn_bits = static_cast<unsigned long long*>(ptr);
-  g_attn_bits_bytes = ptr ? bytes : 0;
   return TELL_OK;
 }
 
@@ -1571,21 +1500,9 @@ extern "C" int tell_attn_fwd(const void* q, const void* k, const void* v, void* 
         if (a.thr) hipLaunchKernelGGL((attn_self_fwd_kernel<true, 0, true>), grid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((attn_self_fwd_kernel<false, 0, true>), grid, dim3(256), 0, stream, a);
       } else if (a.thr) {
-        // dropout decisions as lane masks from their own launch (registered scratch, tell_attn_set_mask_scratch): OPT-IN
-        // (TELL_ATTN_BITS=1).  MEASURED (MI355X, B = 32, H = 16, S = 512, p = 0.1, same process): hash in place 78.2 us; mask
-        // launch + this kernel 126.6 us (bit-identical output); no dropout 62.7.  The 15 us the hash costs in place are
-        // VALU work that overlaps other waves' MFMA / exp; as its own launch the same hashes (+ 32 ballots per tile) are a
-        // chip-wide VALU-bound 45 us.  configs[2]: 1576 -> 1512 samples/s.  Only a cheaper hash would shorten this kernel.
-        const bool bits_env = getenv("TELL_ATTN_BITS") && atoi(getenv("TELL_ATTN_BITS")) == 1;      // (per call: A/B inside one process)
-        const long need = (long)B * H * (Tq / 32) * (S / 64) * 32 * 8;
-        if (bits_env && g_attn_bits && Tq % 32 == 0 && need <= g_attn_bits_bytes) {
-          hipLaunchKernelGGL(attn_dropmask_kernel, dim3((S / 64 + 3) / 4, Tq / 32, B * H), dim3(256), 0, stream, g_attn_bits, Tq, S,
-                             a.thr, a.seed, a.salt, a.step);
-          a.drop_bits = g_attn_bits;
-          hipLaunchKernelGGL((attn_self_fwd_kernel<true, 0, false, true>), grid, dim3(256), 0, stream, a);
-        } else {
-          hipLaunchKernelGGL((attn_self_fwd_kernel<true>), grid, dim3(256), 0, stream, a);
-        }
+        // (round 4 measured the keep decisions as lane masks from their own launch: 126.6 us against 78.2 us hashing in
+        //  place - tools/probes/rejected/README; removed from the library in round 5)
+        hipLaunchKernelGGL((attn_self_fwd_kernel<true>), grid, dim3(256), 0, stream, a);
       } else hipLaunchKernelGGL((attn_self_fwd_kernel<false>), grid, dim3(256), 0, stream, a);
       return tell_check_launch("attn_self_fwd");
     }

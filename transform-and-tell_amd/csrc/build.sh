@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=${1:-libtell_hip.so}
-SRCS="api gemm gemm_duo gemm_pp2 gemm_q4 gemm_q4e elementwise layernorm dynconv attention adaptive optim conv encoders lstm multi decode"
+SRCS="api gemm gemm_pp2 gemm_q4 gemm_q4e elementwise layernorm dynconv attention adaptive optim conv encoders lstm multi decode"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value"
 mkdir -p _obj
 pids=""

@@ -18,6 +18,9 @@
 // 33-dword stride; K-major tiles: +64 B skew for the transpose reads) or, for the lane-linear direct-to-LDS
 // image, swizzled on the source address.
 #include "common.h"
+#include <atomic>
+#include <mutex>
+#include <vector>
 #include "../../include/tell_hip.h"    // tell_gemm_tn_problem (and every prototype: a drifted definition fails to compile)
 #include <type_traits>
 #include <stdlib.h>
@@ -871,181 +874,6 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
   gemm_ts_exit(p);
 }
 
-// ------------------------------------------------------------- 256x256, four waves of 128x128 (bf16, full tiles only)
-// The ping-pong kernel above gives each of its 8 waves a 128x64 piece of the tile: per 32 k of the block that is
-// 8 x (128 + 64) x 64 B = 96 KB of fragment reads next to 32 KB of staging writes - 128 KB against the LDS port's
-// 128 B/clk over the 1031 clk the MFMAs of those 32 k take: the port is saturated, and no schedule gets past
-// ~1250 TFLOP/s in the main loop.  Here FOUR waves own 128x128 each (2 x 2; 256 accumulator registers per lane, which
-// is what the unified 512-register file of a one-wave-per-SIMD kernel is for): 4 x 256 x 64 B = 64 KB of fragment
-// reads per 32 k, 96 KB in all = 74 % of the port.  One wave per SIMD has no partner to hide behind, so the stream is
-// software-pipelined by hand:
-//   * the fragments of k-step s+1 are read (8 ds_read_b128) under the 16 MFMAs of step s, register double-buffered;
-//   * operands are REGISTER-staged (16 global_load_dwordx4 + 16 ds_write_b128 per lane and K tile): an LDS-DMA piece
-//     costs the issuing wave ~60 clk, and with 16 pieces per wave and tile and nobody else on the SIMD that is a
-//     quarter of the tile's MFMA time; a plain load or LDS write is one issue slot.  Tile t+2 is loaded during
-//     k-steps 1-2 of tile t and written to its stage during k-steps 0-1 of tile t+1 (~1500 clk later);
-//   * one barrier per K tile, after the first 4 MFMAs of the tile's last k-step: every wave has issued all its reads of
-//     the tile and finished its writes of the next, whose first fragments are then read under the remaining 12 MFMAs.
-// LDS image and swizzle are those of the ping-pong kernel (rows in pairs per 256-byte line, 16-byte chunks XORed with
-// the pair index): A rows 0-255 at 0, B rows 0-255 at 32 KB, two stages.
-// STATUS: opt-in (TELL_GEMM_W4=1), results bit-identical to the ping-pong kernel's tolerance class, NOT faster yet.
-// MI355X, M = 16384: fc2 (K = 4096) 1174 TFLOP/s against 1188 for ping-pong, fc1 (K = 1024) 751 against 809.
-// Ablations of this kernel at fc2 (wrong results, timing only): no operand staging at all 1749; staging writes kept but
-// no global loads 1320; no fragment reads 1317; no barrier 1198.  The MFMA + fragment-read stream itself therefore runs
-// at 70 % of the 2.5 PFLOP/s peak - the 128x128 wave tile does what it was chosen for - and what is lost is lost to
-// STAGING with nobody else on the SIMD: a ds_write_b128 occupies the issuing wave's store path for ~13 clk (79 B/clk
-// per CU), 16 of them plus 16 loads per tile and lane; the LDS-DMA alternative costs ~60 clk of issue per 1-KiB piece
-// (first version of this kernel: 757 / 1149).  And the epilogue takes 17.8 us per tile here against ~10 for the eight
-// waves of the ping-pong kernel (four waves issue the 128 KB of stores), which decides the K = 1024 shapes.  What
-// hipBLASLt's MT256x256x64 kernel reaches on these shapes (1115-1500 TFLOP/s, tools/gemm_vs_blaslt.py) says the
-// combination exists; finding a staging scheme that costs < 10 % beside one wave per SIMD is the open problem.
-template <typename OutT>
-__global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmArgs p) {
-  constexpr int BM = 256, BN = 256, BK = 64;
-  constexpr int OPER = 256 * 128, TILE = 2 * OPER;        // bytes: one operand image (256 rows x 64 k), one K tile
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * TILE];
-  gemm_ts_enter(p);
-  const int tid = threadIdx.x, lane = tid & 63, lh = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int M = p.M, N = p.N, K = p.K;
-  const int tiles_n = N / BN, tiles_m = M / BM;
-  int tile_id;
-  {
-    const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  }
-  int tm, tn;
-  {
-    constexpr int GROUP_M = 8;
-    const int per_group = GROUP_M * tiles_n;
-    const int g = tile_id / per_group, first_m = g * GROUP_M;
-    const int gm = tiles_m - first_m < GROUP_M ? tiles_m - first_m : GROUP_M;
-    const int in_g = tile_id - g * per_group;
-    tm = first_m + in_g % gm;
-    tn = in_g / gm;
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
-  // staging: thread -> (row tid/8 + 32 j, 16-byte chunk tid%8), j = 0..7, of each operand
-  const int srow = tid >> 3, sch = tid & 7;
-  const uint16_t* ag = static_cast<const uint16_t*>(p.A) + (long)(m0 + srow) * p.lda + sch * 8;
-  const uint16_t* bg = static_cast<const uint16_t*>(p.B) + (long)(n0 + srow) * p.ldb + sch * 8;
-  const long a_step = 32 * p.lda, b_step = 32 * p.ldb;
-  // LDS slot of (row r, chunk c): (r >> 1) * 256 + ((((r & 1) << 3) | c) ^ ((r >> 1) & 15)) * 16; row + 32 j -> + 4096 j
-  const int w_off = (srow >> 1) * 256 + (((((srow & 1) << 3) | sch) ^ ((srow >> 1) & 15)) << 4);
-  // fragment address of 32-row block 0 at k-step ks inside an operand image; block i is 4096 bytes further on
-  int f_off[4];
-  {
-    const int r = lane & 31;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      f_off[ks] = (r >> 1) * 256 + (((((r & 1) << 3) | (ks * 2 + lh)) ^ ((r >> 1) & 15)) << 4);
-  }
-  const int a_img = wr * (OPER / 2), b_img = OPER + wc * (OPER / 2);
-  u32x4 sa[8], sb[8];
-  bf16x8 fa[2][4], fb[2][4];
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-#define W4_GLOAD_A(TT) { _Pragma("unroll") for (int j = 0; j < 8; ++j) sa[j] = *reinterpret_cast<const u32x4*>(ag + j * a_step + (long)(TT) * BK); }
-#define W4_GLOAD_B(TT) { _Pragma("unroll") for (int j = 0; j < 8; ++j) sb[j] = *reinterpret_cast<const u32x4*>(bg + j * b_step + (long)(TT) * BK); }
-#define W4_STORE_A(TT) { unsigned char* d_ = smem + ((TT) & 1) * TILE + w_off; \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(d_ + j * 4096) = sa[j]; }
-#define W4_STORE_B(TT) { unsigned char* d_ = smem + ((TT) & 1) * TILE + OPER + w_off; \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(d_ + j * 4096) = sb[j]; }
-#define W4_READ(TT, KS, BUF)                                                                       \
-  {                                                                                                \
-    const unsigned char* base_ = smem + ((TT) & 1) * TILE + f_off[KS];                             \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
-      fa[BUF][i] = *reinterpret_cast<const bf16x8*>(base_ + a_img + i * 4096);                     \
-      fb[BUF][i] = *reinterpret_cast<const bf16x8*>(base_ + b_img + i * 4096);                     \
-    }                                                                                              \
-  }
-#define W4_MMA_ROWS(BUF, I0, I1)                                                                   \
-  {                                                                                                \
-    _Pragma("unroll") for (int i = I0; i < I1; ++i)                                                \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[BUF][j], fa[BUF][i], acc[i][j], 0, 0, 0); \
-  }
-  // scheduling shapes: per pair of MFMAs one fragment read and (R) one staging write / (V) one global load
-#define W4_SHAPE(DSW, VM)                                                                          \
-  {                                                                                                \
-    _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                             \
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                           \
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                           \
-      if (DSW) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                  \
-      if (VM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                   \
-    }                                                                                              \
-  }
-  const int nk = K / BK;
-  // one K tile: NEXT = tile t+1 exists (its operands sit in sa / sb), LOAD = tile t+2 exists
-  auto tile = [&](int t, auto next_c, auto load_c) __attribute__((always_inline)) {
-    constexpr bool NEXT = decltype(next_c)::value, LOAD = decltype(load_c)::value;
-    __builtin_amdgcn_sched_barrier(0);
-    W4_READ(t, 1, 1)
-    if constexpr (NEXT) W4_STORE_A(t + 1)
-    W4_MMA_ROWS(0, 0, 4)
-    W4_SHAPE(NEXT, false)
-    __builtin_amdgcn_sched_barrier(0);
-    W4_READ(t, 2, 0)
-    if constexpr (NEXT) W4_STORE_B(t + 1)
-    if constexpr (LOAD) W4_GLOAD_A(t + 2)
-    W4_MMA_ROWS(1, 0, 4)
-    W4_SHAPE(NEXT, LOAD)
-    __builtin_amdgcn_sched_barrier(0);
-    W4_READ(t, 3, 1)
-    if constexpr (LOAD) W4_GLOAD_B(t + 2)
-    W4_MMA_ROWS(0, 0, 4)
-    W4_SHAPE(false, LOAD)
-    __builtin_amdgcn_sched_barrier(0);
-    W4_MMA_ROWS(1, 0, 1)
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();       // all reads of tile t issued, all writes of tile t+1 done - by every wave
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (NEXT) W4_READ(t + 1, 0, 0)
-    W4_MMA_ROWS(1, 1, 4)
-    if constexpr (NEXT) {
-#pragma unroll
-      for (int g_ = 0; g_ < 8; ++g_) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      }
-    }
-  };
-  using Yes = std::integral_constant<bool, true>;
-  using No = std::integral_constant<bool, false>;
-  W4_GLOAD_A(0)
-  W4_GLOAD_B(0)
-  W4_STORE_A(0)
-  W4_STORE_B(0)
-  if (nk > 1) {
-    W4_GLOAD_A(1)
-    W4_GLOAD_B(1)
-  }
-  __syncthreads();
-  W4_READ(0, 0, 0)
-  int t = 0;
-  for (; t + 2 < nk; ++t) tile(t, Yes{}, Yes{});
-  if (t + 1 < nk) { tile(t, Yes{}, No{}); ++t; }
-  tile(t, No{}, No{});
-#undef W4_GLOAD_A
-#undef W4_GLOAD_B
-#undef W4_STORE_A
-#undef W4_STORE_B
-#undef W4_READ
-#undef W4_MMA_ROWS
-#undef W4_SHAPE
-  __builtin_amdgcn_sched_barrier(0);
-  // (the barrier inside the last tile came after every wave's last fragment read: the tile buffers are free)
-  glds_store_tile<BM, BN, 128, 128, 4, 4, BN, 256, 0>(acc, p, m0, n0, wr, wc, lane, tid,
-                                                      reinterpret_cast<uint16_t*>(smem));
-  gemm_ts_exit(p);
-}
-
 // ------------------------------------------------------------- register-staged kernel (any dtype, any K)
 template <typename T, typename OutT, int BM, int BN, int WAVES_M, int WAVES_N, int PF>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 4 * (BM * BN >= 256 * 128 ? 1 : 2))
@@ -1489,34 +1317,96 @@ static int launch_gemm_tx(const GemmArgs& a_in, hipStream_t stream) {
 // Which kernel a call runs is decided here and only here: every launch goes through TELL_GEMM_LAUNCH, which records a
 // readable label; tell_gemm_nt_plan() runs the same decision with the launch suppressed (bench.py's roofline block
 // names kernels by asking, not by mirroring the heuristics).
-// Tile counters of the persistent ping-pong launches: a caller-owned, zero-initialised int32 buffer registered once
-// (tell_gemm_set_tile_queue).  Every persistent launch takes the next slot; a launch leaves its slot zero again, so a
-// slot can be reused by any later launch that does not run concurrently with it - with thousands of slots that only
-// requires that no two launches 2^16 apart (in host issue / capture order) are in flight at once.
-static int* g_tile_queue = nullptr;
-static unsigned g_tile_queue_n = 0, g_tile_queue_next = 0, g_tile_queue_captured = 0;
+// Tile counters of the resident 256x256 GEMM launches (gemm_pp2.hip, gemm_q4.hip, gemm_q4e.hip: one counter per XCD): a
+// caller-owned, zero-initialised int32 buffer PER DEVICE (tell_gemm_set_tile_queue registers it for the calling thread's
+// current device), cut into slots of 8 counters.  A launch leaves its counters zero, so a slot may be reused by any
+// launch that cannot overlap it in time.  Launches recorded into a hipGraph keep their slot for the graph's lifetime and
+// replay concurrently with whatever the other streams run: they take slots from the FIRST half of the buffer - first
+// from the free list (slots a destroyed graph gave back, tell_gemm_tile_queue_release), then fresh ones - and, while the
+// capturing thread has a log armed (tell_gemm_tile_queue_log_begin / _end), the slot numbers are recorded so that the
+// graph's owner can release them when it drops the graph.  Eager launches walk a ring over the second half (thousands
+// of launches deep).  Hand-out is atomic / mutex-protected: the loader, encoder and training threads of one process (and
+// the processes of a data-parallel job, each with its own device) launch concurrently - under data parallelism the
+// per-XCD counters are the DEFAULT path (training/trainer.py), so this state must not be "last registration wins".
+namespace {
+constexpr int TQ_MAX_DEV = 64, TQ_WORDS = 8;
+struct TileQueueDev {
+  int* base = nullptr;
+  unsigned slots = 0;                       // 8-counter slots in the buffer; [0, slots / 2) captured, [slots / 2, slots) eager ring
+  std::atomic<unsigned> ring{0};
+  std::mutex mu;                            // guards fresh / free_list
+  unsigned fresh = 0;
+  std::vector<unsigned> free_list;
+};
+TileQueueDev g_tq[TQ_MAX_DEV];
+thread_local std::vector<int>* t_tq_log = nullptr;
+thread_local std::vector<int> t_tq_log_store;
+inline TileQueueDev* tq_current() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return (d >= 0 && d < TQ_MAX_DEV) ? &g_tq[d] : nullptr;
+}
+}  // namespace
 extern "C" int tell_gemm_set_tile_queue(void* counters, int n, hipStream_t) {
-  g_tile_queue = static_cast<int*>(counters);
-  g_tile_queue_captured = 0;
-  g_tile_queue_n = n > 0 ? (unsigned)n : 0u;
-  if (!g_tile_queue_n) g_tile_queue = nullptr;
+  TileQueueDev* q = tq_current();
+  TELL_REQUIRE(q != nullptr, "gemm_set_tile_queue: no current device");
+  std::lock_guard<std::mutex> lock(q->mu);
+  q->base = (counters && n >= 4 * TQ_WORDS) ? static_cast<int*>(counters) : nullptr;
+  q->slots = q->base ? (unsigned)n / TQ_WORDS : 0u;
+  q->fresh = 0;
+  q->free_list.clear();
+  q->ring.store(0);
   return TELL_OK;
 }
-// `words` consecutive zeroed counters for one launch (gemm_pp2.hip: one per XCD), or NULL (-> static tile lists) when no
-// buffer is registered / the capture half is used up.  A launch leaves its counters zero, so a slot may be reused by any
-// launch that cannot overlap it in time.  Launches recorded into a hipGraph keep their slot for the graph's lifetime and
-// replay concurrently with whatever the other streams run, so they take slots from the FIRST half of the buffer, each
-// handed out once; eager launches walk a ring over the second half (thousands of launches deep).
+extern "C" int tell_gemm_tile_queue_log_begin(void) {
+  t_tq_log_store.clear();
+  t_tq_log = &t_tq_log_store;
+  return TELL_OK;
+}
+// -> number of slots the calling thread's captured launches took since _log_begin (at most `cap` of them copied to `out`)
+extern "C" int tell_gemm_tile_queue_log_end(int* out, int cap) {
+  const int n = t_tq_log ? (int)t_tq_log->size() : 0;
+  for (int i = 0; i < n && i < cap; ++i) out[i] = (*t_tq_log)[i];
+  t_tq_log = nullptr;
+  return n;
+}
+extern "C" int tell_gemm_tile_queue_release(const int* slots, int n) {
+  TileQueueDev* q = tq_current();
+  if (!q || n <= 0) return TELL_OK;
+  std::lock_guard<std::mutex> lock(q->mu);
+  for (int i = 0; i < n; ++i)
+    if (slots[i] >= 0 && (unsigned)slots[i] < q->slots / 2) q->free_list.push_back((unsigned)slots[i]);
+  return TELL_OK;
+}
+// state of the calling thread's device: out[0] slots, out[1] fresh captured slots handed out, out[2] free-list length
+extern "C" int tell_gemm_tile_queue_stats(int* out) {
+  TileQueueDev* q = tq_current();
+  out[0] = out[1] = out[2] = 0;
+  if (!q) return TELL_OK;
+  std::lock_guard<std::mutex> lock(q->mu);
+  out[0] = (int)q->slots; out[1] = (int)q->fresh; out[2] = (int)q->free_list.size();
+  return TELL_OK;
+}
+// `words` (<= 8) consecutive zeroed counters for one launch, or NULL (-> static tile lists) when no buffer is registered
+// for the device / the capture half is used up
 int* gemm_tile_queue_slot(int words, hipStream_t stream) {
-  if (!g_tile_queue || g_tile_queue_n < (unsigned)words * 4) return nullptr;
-  const unsigned half = g_tile_queue_n / (unsigned)words / 2;
+  TileQueueDev* q = tq_current();
+  if (!q || !q->base || words > TQ_WORDS) return nullptr;
+  const unsigned half = q->slots / 2;
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   if (st != hipStreamCaptureStatusNone) {
-    if (g_tile_queue_captured >= half) return nullptr;
-    return g_tile_queue + (size_t)(g_tile_queue_captured++) * words;
+    unsigned slot;
+    {
+      std::lock_guard<std::mutex> lock(q->mu);
+      if (!q->free_list.empty()) { slot = q->free_list.back(); q->free_list.pop_back(); }
+      else if (q->fresh < half) slot = q->fresh++;
+      else return nullptr;
+    }
+    if (t_tq_log) t_tq_log->push_back((int)slot);
+    return q->base + (size_t)slot * TQ_WORDS;
   }
-  return g_tile_queue + (size_t)(half + g_tile_queue_next++ % half) * words;
+  return q->base + (size_t)(half + q->ring.fetch_add(1) % half) * TQ_WORDS;
 }
 static thread_local char g_gemm_label[96] = "";
 static thread_local bool g_gemm_plan = false;
@@ -1553,22 +1443,6 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
                           (a.bias_mode != 1 || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
         // ping-pong 256x256: whole rounds of full tiles (fc1 of RoBERTa: 878 vs 838 TFLOP/s, 4096^3: 1171 vs 1022,
         // 8192^3: 1333 vs 1164); partial rounds lose to the smaller tiles below.  TELL_GEMM_TILE=8 forces it.
-        // 256x128 tiles, two co-resident workgroups per CU (gemm_duo.hip): prologue and epilogue of one under the main loop
-        // of the other - the K <= 2048 shapes, where those are 40 % of a 256x256 tile's life.  TELL_GEMM_DUO=0 / 2: never / always.
-        static const int duo_env = getenv("TELL_GEMM_DUO") ? atoi(getenv("TELL_GEMM_DUO")) : 0;
-        const bool duo_ok = a.M % 256 == 0 && a.N % 128 == 0 && a.K % 32 == 0 && a.K >= 64 && !a.accumulate && a.act != 3 && a.act != 4 &&
-                            !a.m_dev && !a.stat_mean && !a.conv_zero && (a.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0 &&
-                            (a.bias_mode != 1 || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) && (a.lda & 7) == 0 && (a.ldb & 7) == 0 &&
-                            (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0;
-        if (duo_ok && force == 0 && (duo_env == 2 || (duo_env == 1 && a.K <= 2048)) && tiles(256, 128) >= 2 * n_cu) {
-          if (g_gemm_plan) { (void)gemm_label("gemm_nt_duo_kernel", -1, 1, 256, 128); return TELL_OK; }
-          return launch_gemm_duo(a, stream);
-        }
-        static const bool use_w4 = getenv("TELL_GEMM_W4") && atoi(getenv("TELL_GEMM_W4")) == 1;
-        if (use_w4 && full && !no_pp && ((force == 0 && tiles(256, 256) % n_cu == 0) || (force == 8 && tiles(256, 256) >= n_cu))) {
-          TELL_GEMM_LAUNCH(gemm_label("gemm_nt_w4_kernel", -1, sizeof(OutT) == 2, 256, 256), (gemm_nt_w4_kernel<OutT>), dim3((unsigned)tiles(256, 256)), dim3(256));
-          return g_gemm_plan ? TELL_OK : tell_check_launch("gemm_nt_w4");
-        }
         // four waves x 128x128 (gemm_q4.hip): what it needs beyond `full`
         const int q4_env = getenv("TELL_GEMM_Q4") ? atoi(getenv("TELL_GEMM_Q4")) : 1;   // (per launch: A/B inside one process)
         const bool q4_takes = q4_env && (force == 0 || force == 8) && a.K % 128 == 0 && a.K >= 128 && a.K / 64 < 65536 && a.lda % 8 == 0 &&
@@ -1805,6 +1679,9 @@ extern "C" int tell_gemm_grouped(int n, const tell_gemm_problem* pr, hipStream_t
     TELL_REQUIRE(!(q.trans_a && !q.trans_b), "gemm_grouped: A K-major with B row-major is not a form of the step");
     TELL_REQUIRE(q.act == 0 || q.act == 1, "gemm_grouped: act must be 0 (none) or 1 (relu)");
     TELL_REQUIRE(q.asum == nullptr || q.trans_a, "gemm_grouped: fused column sums need a K-major A");
+    // a count-limited REDUCTION (K-major A with lim_dev) that finds *lim_dev == 0 returns without touching C: right when
+    // the product is added to C, an uninitialised output when it is meant to replace it
+    TELL_REQUIRE(!(q.trans_a && q.lim_dev) || q.accumulate, "gemm_grouped: a count-limited K-major product must accumulate");
     const bool aligned = q.lda % 8 == 0 && q.ldb % 8 == 0 && (((uintptr_t)q.A | (uintptr_t)q.B) & 15) == 0;
     int form = q.trans_a ? 2 : q.trans_b ? 1 : 0;
     if (form > 0) TELL_REQUIRE(aligned, "gemm_grouped: K-major operands need 16-byte aligned rows");

@@ -1,4 +1,4 @@
-// Shared by the GEMM translation units (gemm.hip, gemm_duo.hip): argument block, epilogue arithmetic, execution-span stamps.
+// Shared by the GEMM translation units (gemm.hip, gemm_pp2.hip, gemm_q4.hip, gemm_q4e.hip): argument block, epilogue arithmetic, execution-span stamps.
 #pragma once
 #include "common.h"
 #include <stdlib.h>
@@ -22,7 +22,6 @@ struct GemmArgs {
   unsigned long long* ts; // measurement aid: ts[0] = min over workgroups of the wall clock at entry, ts[1] = max at exit
   int atomic_out;         // fp32 output shared by several workgroups (split K): accumulate with hardware float atomics
   int* queue;             // persistent ping-pong kernel: the launch's tile counter (zero between launches), or NULL
-  int stagger;            // duo kernel: start delay of the second resident workgroup of a CU (x 8128 clocks)
   // pp2 kernel, act 5: C = aux2[m,n] + dropout(result): the transformer sub-layer residual (fairseq: x = residual +
   // dropout(out_proj(.)) / dropout(fc2(.))) in the epilogue - the mask is the one tell_layernorm_fwd would draw for the
   // same (seed, salt): element index m * N + n, csrc/common.h quad hash
@@ -123,8 +122,6 @@ __device__ __forceinline__ void gemm_ts_exit(const GemmArgs& p) {
   }
 }
 
-// gemm_duo.hip: 256x128 tiles, two co-resident workgroups per CU (bf16 in / out, full tiles only)
-int launch_gemm_duo(const GemmArgs& a, hipStream_t stream);
 // gemm_pp2.hip: the 256x256 ping-pong kernel as resident workgroups that prefetch the next output tile under the epilogue
 int launch_gemm_pp2(const GemmArgs& a, hipStream_t stream, int n_cu);
 // gemm_q4.hip: 256x256 tiles, four waves of 128x128, hand-placed K loop (round 4)

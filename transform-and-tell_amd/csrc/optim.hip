@@ -10,6 +10,8 @@
 #include "common.h"
 
 #define OPT_CHUNK 1024
+#define TELL_ADAM_DEFAULT 0       // (set from the same-box A/B of tools/probes/stream_probe.hip and the step)
+#include <stdlib.h>
 
 // partial[c] = sum of squares of (grad * grad_scale) over chunk c
 // (wire != NULL: the gradient of this step is the bf16 buffer the data-parallel exchange left - read it as it is
@@ -22,16 +24,26 @@ __device__ __forceinline__ float4 load_grad4(const float* __restrict__ grad, con
   }
   return reinterpret_cast<const float4*>(grad)[o];
 }
+// U chunks per block iteration, every load of the iteration in flight before the first reduction (one chunk per iteration
+// left a block with a single 16-byte load outstanding per thread between two barriers)
+template <int U>
 __global__ __launch_bounds__(256) void sqsum_chunks_kernel(const float* __restrict__ grad, const uint16_t* __restrict__ wire,
                                                            long n_chunks, float grad_scale, float* __restrict__ partial) {
-  __shared__ float red[4];
-  for (long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-    const float4 g = load_grad4(grad, wire, c * OPT_CHUNK / 4 + threadIdx.x);
-    float s = (g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w) * grad_scale * grad_scale;
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __shared__ float red[U][4];
+  for (long c0 = (long)blockIdx.x * U; c0 < n_chunks; c0 += (long)gridDim.x * U) {
+    float4 g[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      g[u] = c0 + u < n_chunks ? load_grad4(grad, wire, (c0 + u) * OPT_CHUNK / 4 + threadIdx.x) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float s = (g[u].x * g[u].x + g[u].y * g[u].y + g[u].z * g[u].z + g[u].w * g[u].w) * grad_scale * grad_scale;
+      s = wave_sum(s);
+      if ((threadIdx.x & 63) == 0) red[u][threadIdx.x >> 6] = s;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) partial[c] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x < U && c0 + threadIdx.x < n_chunks)
+      partial[c0 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
     __syncthreads();
   }
 }
@@ -83,6 +95,10 @@ __global__ void lr_schedule_kernel(const int* __restrict__ step, float lr, float
 }
 // One pass over the flat buffers: BertAdam update of the fp32 masters, the bf16 working copy the next forward
 // reads (shadow; no per-tensor cast kernels), and the zeroing of the gradient for the next step.
+// U: chunks per block iteration (all 4 U loads of a thread in flight before the first use); NT: the streams nobody reads
+// again soon (master, m, v, the zeroed gradient) go out with non-temporal stores and come in with non-temporal loads -
+// the bf16 shadow, which the next forward pass reads, keeps the default policy.
+template <int U, bool NT>
 __global__ __launch_bounds__(256) void bertadam_update_kernel(float* __restrict__ param,
                                                               float* __restrict__ grad,
                                                               float* __restrict__ m, float* __restrict__ v,
@@ -95,6 +111,7 @@ __global__ __launch_bounds__(256) void bertadam_update_kernel(float* __restrict_
                                                               const uint16_t* __restrict__ wire,
                                                               int* __restrict__ step_dev,
                                                               const int* __restrict__ keep_grad) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
   const float lr = *lr_dev;
   // keep_grad[t] != 0: tensor t's gradient is rewritten whole (beta = 0 stores) by its single producer in the next
   // backward pass - not zeroed here (4 B / parameter less to write, and the producer does not read it back)
@@ -107,35 +124,55 @@ __global__ __launch_bounds__(256) void bertadam_update_kernel(float* __restrict_
     return;
   }
   if (step_dev && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(step_dev, 1);   // (nobody reads it inside this launch)
-  for (long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-    float coef = grad_scale;
-    const int tensor = chunk_tensor[c];
-    if (max_norm > 0.f) {
-      const float cc = max_norm / (norms[tensor] + 1e-6f);
-      if (cc < 1.f) coef *= cc;
+  auto ldf = [](const float* base, long o) __attribute__((always_inline)) {
+    const f4* q = reinterpret_cast<const f4*>(base) + o;
+    return NT ? __builtin_nontemporal_load(q) : *q;
+  };
+  auto stf = [](float* base, long o, f4 val) __attribute__((always_inline)) {
+    f4* q = reinterpret_cast<f4*>(base) + o;
+    if (NT) __builtin_nontemporal_store(val, q); else *q = val;
+  };
+  for (long c0 = (long)blockIdx.x * U; c0 < n_chunks; c0 += (long)gridDim.x * U) {
+    f4 g[U], p[U], mm[U], vv[U];
+    float coef[U];
+    int tensor[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long c = c0 + u < n_chunks ? c0 + u : n_chunks - 1;               // (clamped: the tail repeats the last chunk's loads)
+      const long o = c * OPT_CHUNK / 4 + threadIdx.x;
+      if (wire) { const float4 w = load_grad4(grad, wire, o); g[u] = f4{w.x, w.y, w.z, w.w}; }
+      else g[u] = ldf(grad, o);
+      p[u] = ldf(param, o); mm[u] = ldf(m, o); vv[u] = ldf(v, o);
+      tensor[u] = chunk_tensor[c];
     }
-    const long o = c * OPT_CHUNK / 4 + threadIdx.x;
-    float4 g = load_grad4(grad, wire, o);
-    float4 p = reinterpret_cast<float4*>(param)[o];
-    float4 mm = reinterpret_cast<float4*>(m)[o];
-    float4 vv = reinterpret_cast<float4*>(v)[o];
-#define UPD(f)                                                   \
-    { const float gg = g.f * coef;                               \
-      mm.f = b1 * mm.f + (1.f - b1) * gg;                        \
-      vv.f = b2 * vv.f + (1.f - b2) * gg * gg;                   \
-      p.f -= lr * (mm.f / (sqrtf(vv.f) + eps) + wd * p.f); }
-    UPD(x) UPD(y) UPD(z) UPD(w)
-#undef UPD
-    reinterpret_cast<float4*>(param)[o] = p;
-    reinterpret_cast<float4*>(m)[o] = mm;
-    reinterpret_cast<float4*>(v)[o] = vv;
-    if (shadow) {
-      uint2 s;
-      s.x = (uint32_t)f2bf(p.x) | ((uint32_t)f2bf(p.y) << 16);
-      s.y = (uint32_t)f2bf(p.z) | ((uint32_t)f2bf(p.w) << 16);
-      reinterpret_cast<uint2*>(shadow)[o] = s;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      coef[u] = grad_scale;
+      if (max_norm > 0.f) {
+        const float cc = max_norm / (norms[tensor[u]] + 1e-6f);
+        if (cc < 1.f) coef[u] *= cc;
+      }
     }
-    if (zero_grad && !(keep_grad && keep_grad[tensor])) reinterpret_cast<float4*>(grad)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (c0 + u >= n_chunks) break;
+      const long o = (c0 + u) * OPT_CHUNK / 4 + threadIdx.x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gg = g[u][k] * coef[u];
+        mm[u][k] = b1 * mm[u][k] + (1.f - b1) * gg;
+        vv[u][k] = b2 * vv[u][k] + (1.f - b2) * gg * gg;
+        p[u][k] -= lr * (mm[u][k] / (sqrtf(vv[u][k]) + eps) + wd * p[u][k]);
+      }
+      stf(param, o, p[u]); stf(m, o, mm[u]); stf(v, o, vv[u]);
+      if (shadow) {
+        uint2 sw;
+        sw.x = (uint32_t)f2bf(p[u][0]) | ((uint32_t)f2bf(p[u][1]) << 16);
+        sw.y = (uint32_t)f2bf(p[u][2]) | ((uint32_t)f2bf(p[u][3]) << 16);
+        reinterpret_cast<uint2*>(shadow)[o] = sw;
+      }
+      if (zero_grad && !(keep_grad && keep_grad[tensor[u]])) stf(grad, o, f4{0.f, 0.f, 0.f, 0.f});
+    }
   }
 }
 
@@ -157,12 +194,29 @@ extern "C" int tell_bertadam_step2(float* param, float* grad, float* m, float* v
   TELL_REQUIRE(((uintptr_t)grad_wire_bf16 & 7) == 0, "bertadam: the bf16 gradient must be 8-byte aligned");
   const uint16_t* wire = static_cast<const uint16_t*>(grad_wire_bf16);
   TELL_REQUIRE(((uintptr_t)param & 15) == 0 && ((uintptr_t)grad & 15) == 0, "bertadam: buffers must be 16-byte aligned");
-  int g = n_chunks < 4096 ? (int)n_chunks : 4096;
+  // TELL_ADAM_VAR (A/B aid, read once): 0 = one chunk per iteration, default cache policy (the round-4 kernel's shape);
+  // 1 = U 2; 2 = U 4; 3 = U 2 + non-temporal; 4 = U 4 + non-temporal.  tools/probes/stream_probe.hip has the same shapes
+  // on bare buffers.
+  static const int var = getenv("TELL_ADAM_VAR") ? atoi(getenv("TELL_ADAM_VAR")) : TELL_ADAM_DEFAULT;
+  static const int grid_env = getenv("TELL_ADAM_GRID") ? atoi(getenv("TELL_ADAM_GRID")) : 4096;
+  const int U = (var == 1 || var == 3) ? 2 : (var == 2 || var == 4) ? 4 : 1;
+  const long iters = (n_chunks + U - 1) / U;
+  int g = iters < grid_env ? (int)iters : grid_env;
   if (max_norm > 0.f) {
-    hipLaunchKernelGGL(sqsum_chunks_kernel, dim3(g), dim3(256), 0, stream, grad, wire, n_chunks, grad_scale, partial);
+    const long it4 = (n_chunks + 3) / 4;
+    const int gs = it4 < 4096 ? (int)it4 : 4096;
+    hipLaunchKernelGGL((sqsum_chunks_kernel<4>), dim3(gs), dim3(256), 0, stream, grad, wire, n_chunks, grad_scale, partial);
     hipLaunchKernelGGL(tensor_norms_kernel, dim3(n_tensors), dim3(256), 0, stream, partial, chunk_begin, n_tensors, norms, skip);
   }
-  hipLaunchKernelGGL(bertadam_update_kernel, dim3(g), dim3(256), 0, stream, param, grad, m, v, chunk_tensor, norms, n_chunks, lr_dev, b1, b2, eps, wd, max_norm, grad_scale, (uint16_t*)shadow_bf16, zero_grad, skip, wire, step_dev, keep_grad);
+#define TELL_ADAM_LAUNCH(UU, NTT) hipLaunchKernelGGL((bertadam_update_kernel<UU, NTT>), dim3(g), dim3(256), 0, stream, param, grad, m, v, chunk_tensor, norms, n_chunks, lr_dev, b1, b2, eps, wd, max_norm, grad_scale, (uint16_t*)shadow_bf16, zero_grad, skip, wire, step_dev, keep_grad)
+  switch (var) {
+    case 1: TELL_ADAM_LAUNCH(2, false); break;
+    case 2: TELL_ADAM_LAUNCH(4, false); break;
+    case 3: TELL_ADAM_LAUNCH(2, true); break;
+    case 4: TELL_ADAM_LAUNCH(4, true); break;
+    default: TELL_ADAM_LAUNCH(1, false); break;
+  }
+#undef TELL_ADAM_LAUNCH
   return tell_check_launch("bertadam_step");
 }
 extern "C" int tell_bertadam_step(float* param, float* grad, float* m, float* v,

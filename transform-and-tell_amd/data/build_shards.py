@@ -27,46 +27,51 @@ def _named(section, labels):
     return {ner['text'] for ner in section.get('named_entities', ()) if ner['label'] in labels}
 
 
-def article_samples(article, n_tokens):
-    """The (position, caption, paragraphs, named entities, caption section) tuples of one article document (:104-172).
+def _outward(pos, first, n):
+    """Section indices around the image at `pos`, one ring per step: (pos - r, pos + r) for r = 1, 2, ... until both sides
+    have left the article body (indices <= first on the left, >= n on the right).  The reference walks two cursors
+    (:130-158); this is the same visiting order as a generator."""
+    r = 1
+    while True:
+        yield pos - r, pos + r
+        if pos - r - 1 <= first and pos + r + 1 >= n:
+            return
+        r += 1
+
+
+def article_samples(article, n_tokens, budget=510):
+    """The (position, caption, paragraphs, named entities, caption section) tuples of one article document (:104-172):
+    context = headline + the article's first paragraph + the paragraphs nearest to the image, taken ring by ring
+    (one to the left, one to the right) until `budget` BPE tokens are reached - the test is made once per RING, and the
+    first paragraph is not counted (both as the reference has it).
     n_tokens(text) -> number of BPE tokens (the reference counts with fairseq's roberta.bpe, :252-260)."""
     sections = article['parsed_section']
+    labels = ('PERSON', 'ORG', 'GPE')
+    is_par = [sec['type'] == 'paragraph' for sec in sections]
+    # index of the first paragraph; an article without one behaves like the reference's fall-through (its loop
+    # variable ends on the last section)
+    first = is_par.index(True) if True in is_par else len(sections) - 1
+    title = article.get('headline', {}).get('main', '').strip() if 'main' in article.get('headline', {}) else ''
     for pos in article['image_positions']:
-        title = ''
-        if 'main' in article.get('headline', {}):
-            title = article['headline']['main'].strip()
-        paragraphs, named, n_words = [], set(), 0
-        if title:
-            paragraphs.append(title)
-            # (:115-116 calls set.union without keeping the result: the headline's entities are NOT collected)
-            n_words += n_tokens(title)
         caption = sections[pos]['text'].strip()
         if not caption:
             continue
-        before, after = [], []
-        i, j = pos - 1, pos + 1
-        k = 0
-        for k, section in enumerate(sections):                 # the first paragraph of the article (:136-140)
-            if section['type'] == 'paragraph':
-                paragraphs.append(section['text'])
-                named |= _named(section, ('PERSON', 'ORG', 'GPE'))
+        head = [title] if title else []
+        # (:115-116 calls set.union without keeping the result: the headline's entities are NOT collected)
+        spent = n_tokens(title) if title else 0
+        picked = [first] if True in is_par else []
+        for ring in _outward(pos, first, len(sections)):
+            for idx in ring:
+                if first < idx < len(sections) and is_par[idx]:
+                    picked.append(idx)
+                    spent += n_tokens(sections[idx]['text'])
+            if spent >= budget:
                 break
-        while True:                                            # :142-158
-            if i > k and sections[i]['type'] == 'paragraph':
-                text = sections[i]['text']
-                before.insert(0, text)
-                named |= _named(sections[i], ('PERSON', 'ORG', 'GPE'))
-                n_words += n_tokens(text)
-            i -= 1
-            if k < j < len(sections) and sections[j]['type'] == 'paragraph':
-                text = sections[j]['text']
-                after.append(text)
-                named |= _named(sections[j], ('PERSON', 'ORG', 'GPE'))
-                n_words += n_tokens(text)
-            j += 1
-            if n_words >= 510 or (i <= k and j >= len(sections)):
-                break
-        yield pos, caption, paragraphs + before + after, sorted(named), sections[pos]
+        picked.sort()                                            # [first] + left side + right side, each in article order
+        named = set()
+        for idx in picked:
+            named |= _named(sections[idx], labels)
+        yield pos, caption, head + [sections[idx]['text'] for idx in picked], sorted(named), sections[pos]
 
 
 def load_image(path):

@@ -174,18 +174,20 @@ class GraphedCall:
                 static_in = x.clone()
                 counter = torch.zeros(1, dtype=torch.int32, device=x.device) if self.rng else None
                 g = torch.cuda.CUDAGraph()
-                try:
+                held = hip.tile_slots()                 # tile-counter slots of the captured resident GEMMs: back to the
+                try:                                    # free list when this entry is evicted (held.__del__)
                     if counter is not None:
                         hip.call('tell_set_rng_step_ptr', counter)
                     # thread_local: calls made by OTHER threads while we capture (the RCCL watchdog of a data-parallel
                     # run polls events) must not invalidate the capture; everything captured is issued from this thread
-                    with no_gc(), torch.cuda.graph(g, capture_error_mode='thread_local'):
+                    with no_gc(), held, torch.cuda.graph(g, capture_error_mode='thread_local'):
                         with hip.bound_stream():        # launches must go to the CAPTURING stream
                             static_out = self.fn(static_in)
                 finally:
                     if counter is not None:
                         hip.call('tell_set_rng_step_ptr', None)
-                slots.append({'graph': g, 'static_in': static_in, 'static_out': static_out, 'counter': counter})
+                slots.append({'graph': g, 'static_in': static_in, 'static_out': static_out, 'counter': counter,
+                              'tile_slots': held})
             e.update(state='ready', slots=slots, turn=0, replays=1)
         except Exception as exc:                        # noqa: BLE001 - any capture problem -> eager for good
             e['state'] = 'failed'

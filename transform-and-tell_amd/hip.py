@@ -73,7 +73,6 @@ def lib():
 
 
 _tile_queue = {}
-_attn_buf, _attn_scratch = {}, {}
 
 
 def require_gpu():
@@ -83,15 +82,55 @@ def require_gpu():
     lib()
     dev = torch.cuda.current_device()
     if dev not in _tile_queue:            # work-queue counters of the persistent 256x256 GEMM launches (csrc/gemm.hip)
-        # 4 MB: 8 counters per launch; launches recorded into hipGraphs keep theirs (first half: 65536 launches' worth)
+        # 4 MB per device: 8 counters per launch; launches recorded into hipGraphs keep theirs (first half: 65536 launches'
+        # worth) until the graph's owner gives them back (tile_slots below)
         _tile_queue[dev] = torch.zeros(1 << 20, dtype=torch.int32, device='cuda')
         lib().tell_gemm_set_tile_queue(_tile_queue[dev].data_ptr(), 1 << 20, None)
-    key = (dev, threading.get_ident())    # (thread-local on the library side: the loader / encoder threads launch too)
-    if key not in _attn_scratch:          # dropout lane masks of the long-sequence self-attention (csrc/attention.hip)
-        if dev not in _attn_buf:
-            _attn_buf[dev] = torch.empty(32 << 20, dtype=torch.uint8, device='cuda')      # B*H*Tq*S/8 = 16.8 MB at configs[2]
-        _attn_scratch[key] = True
-        lib().tell_attn_set_mask_scratch(_attn_buf[dev].data_ptr(), 32 << 20, None)
+
+
+class tile_slots:
+    """`with hip.tile_slots() as held:` around a stream capture: records which tile-counter slots the captured resident
+    GEMM launches took (csrc/gemm.hip) - keep `held` next to the CUDAGraph object; when it is dropped (graph evicted,
+    cache cleared) the slots go back to the device's free list.  A graph that is destroyed without this simply leaks its
+    slots (65536 per device; later captures then walk static tile lists)."""
+
+    def __init__(self):
+        self.slots, self.device = None, None
+
+    def __enter__(self):
+        self.device = torch.cuda.current_device()
+        lib().tell_gemm_tile_queue_log_begin()
+        return self
+
+    def __exit__(self, *exc):
+        cap = 4096
+        buf = (ctypes.c_int * cap)()
+        n = lib().tell_gemm_tile_queue_log_end(buf, cap)
+        self.slots = list(buf[:min(n, cap)])
+        return False
+
+    def release(self):
+        if self.slots and _lib is not None:
+            try:
+                arr = (ctypes.c_int * len(self.slots))(*self.slots)
+                if torch.cuda.current_device() == self.device:
+                    _lib.tell_gemm_tile_queue_release(arr, len(self.slots))
+                else:
+                    with torch.cuda.device(self.device):
+                        _lib.tell_gemm_tile_queue_release(arr, len(self.slots))
+            except Exception:              # noqa: BLE001 - interpreter shutdown
+                pass
+        self.slots = None
+
+    def __del__(self):
+        self.release()
+
+
+def tile_queue_stats():
+    """(slots, fresh captured slots handed out, free-list length) of the current device's tile-counter buffer."""
+    out = (ctypes.c_int * 3)()
+    lib().tell_gemm_tile_queue_stats(out)
+    return tuple(out)
 
 
 def dt(t):

@@ -68,6 +68,9 @@ class FlatParams:
         # ops.py 'Gradient stores'); all zero until the trainer has observed a step (set_grad_store)
         self.keep_grad = torch.zeros(max(len(self.params), 1), dtype=torch.int32, device=device)
         self.stored_numel = 0
+        # True while the buffer holds gradients of defer_update passes that no update has consumed (trainer.py
+        # _grad_store_begin: the pass that ends the accumulation must add to them, not store over part of them)
+        self.accum_pending = False
         self.partial = torch.empty(max(self.n_chunks, 1), dtype=torch.float32, device=device)
         self.norms = torch.zeros(len(self.params), dtype=torch.float32, device=device)
         rt.bump_weights_epoch()
@@ -82,6 +85,7 @@ class FlatParams:
 
     def zero_grad(self):
         hip.call('tell_fill_f32', self.grad, self.total, 0.0)
+        self.accum_pending = False
 
     def set_grad_store(self, seen):
         """seen: ops.grad_store_observe(False) of one whole backward pass - {id(p): (p, [(r0, r1) | None, ...])}, a None
@@ -99,6 +103,14 @@ class FlatParams:
                 ok = ok and pos == p.shape[0]
             p._tell_grad_store = bool(ok)
             flags.append(int(ok))
+        # the (g, v) pair of a GehringLinear is written by ONE launch with ONE store bit (ops._wn_backward): mark jointly
+        index = {n: i for i, n in enumerate(self.names)}
+        for n, ia in index.items():
+            if n.endswith('.weight_g') and n[:-1] + 'v' in index:
+                ib = index[n[:-1] + 'v']
+                if flags[ia] != flags[ib]:
+                    flags[ia] = flags[ib] = 0
+                    self.params[ia]._tell_grad_store = self.params[ib]._tell_grad_store = False
         if flags:
             self.keep_grad.copy_(torch.tensor(flags, dtype=torch.int32))
         self.stored_numel = sum(p.numel() for p, f in zip(self.params, flags) if f)
@@ -152,6 +164,8 @@ class BertAdam:
         f = self.flat
         from .. import ops
         keep = f.keep_grad if (zero_grad and ops.grad_store_on()) else None
+        if zero_grad:
+            f.accum_pending = False
         hip.call('tell_bertadam_step2', f.flat, f.grad, f.m, f.v, f.chunk_tensor, f.chunk_begin, f.n_chunks,
                  len(f.params), f.partial, f.norms, self.lr_dev, self.b1, self.b2, self.e, self.weight_decay,
                  self.max_grad_norm, float(grad_scale), f.shadow, int(zero_grad), skip, grad_wire,

@@ -75,7 +75,8 @@ class StepGraph:
                 small[k] = batch[k]
         sig = (tuple((k, tuple(v.shape), v.dtype) for k, v in small.items()),
                tuple((tuple(t.shape), t.dtype, t.data_ptr() if by_ptr else 0) for t in big),
-               by_ptr, rt.compute_dtype(), tr.dp, ops._WGRAD['enabled'], tr.defer_update)
+               by_ptr, rt.compute_dtype(), tr.dp, ops._WGRAD['enabled'], tr.defer_update,
+               ops.grad_store_on())          # (the gradient convention - stores or zero + accumulate - is baked into the launches)
         return sig, small, big, by_ptr
 
     # ------------------------------------------------------------------ one step
@@ -125,6 +126,7 @@ class StepGraph:
             tr._update(n_local=e['sample_size'])
         elif not tr.defer_update:
             tr.optimizer.advance()
+            tr.flat.accum_pending = False               # (the captured update consumed and cleared the gradients)
         return e['loss'].clone()
 
     # ------------------------------------------------------------------ capture
@@ -139,11 +141,12 @@ class StepGraph:
         counter = torch.zeros(1, dtype=torch.int32, device=dev)
         saved = (model.n_samples, model.n_batches, tr.optimizer.step_count)
         g = torch.cuda.CUDAGraph()
+        held = hip.tile_slots()                 # (csrc/gemm.hip tile counters: released when this entry is dropped)
         tr._capturing = True
         try:
             ops.drop_trainable_cache()          # working weights of trainable parameters are rebuilt inside the graph
             hip.call('tell_set_rng_step_ptr', counter)
-            with graphs.no_gc(), torch.cuda.graph(g, capture_error_mode='thread_local'):
+            with graphs.no_gc(), held, torch.cuda.graph(g, capture_error_mode='thread_local'):
                 with hip.bound_stream():
                     encs = EncodedBatch()
                     encs.stack, encs.x_image = st_big
@@ -157,7 +160,7 @@ class StepGraph:
                     if not tr.dp and not tr.defer_update:
                         tr.optimizer.launch(grad_scale=1.0, zero_grad=True, skip=tr.skip)
             e.update(state='ready', graph=g, small=st_small, big=st_big, counter=counter, replays=1,
-                     loss=loss.detach(), sample_size=out['sample_size'])
+                     loss=loss.detach(), sample_size=out['sample_size'], tile_slots=held)
         except Exception as exc:                # noqa: BLE001 - any capture problem -> this signature stays eager
             e['state'] = 'failed'
             e['error'] = repr(exc)

@@ -226,15 +226,37 @@ class Trainer:
                 out[key] = grow(t, 1, rows, float('nan'))
         return batch if out is None else out
 
-    def _grad_store_begin(self):
+    @staticmethod
+    def _store_safe(batch):
+        """Store mode rests on every marked tensor being rewritten WHOLE by this step's backward pass.  The one
+        data-dependent exception: a batch in which no sample has a face / an object hands the model an EMPTY context
+        ([B,1,0], collate's empty field), for which the K / V projections of that context are skipped (blocks.py
+        kv_project_all, modules/attention.py project_kv; multi_head.py:349-374) - rows [E,3E) of its in_proj_weight
+        then get no gradient write, and a stored buffer would still hold the previous step's rows.  Such a step runs
+        with the zero + accumulate convention (shape test on the host: no synchronisation)."""
+        for key in ('face_embeds', 'obj_embeds'):
+            t = batch.get(key) if isinstance(batch, dict) else None
+            if torch.is_tensor(t) and t.dim() == 3 and (t.shape[1] == 0 or t.shape[2] == 0):
+                return False
+        return True
+
+    def _grad_store_begin(self, batch=None):
         """Select this step's gradient convention.  Store mode needs an update after every backward pass (micro-batch
-        accumulation - defer_update - adds into the buffer); leaving it, the stored gradients of the last step are
-        still in the buffer and have to go."""
-        want = self._store == 'ready' and not self.defer_update
+        accumulation - defer_update - adds into the buffer) and a batch whose backward pass writes every marked tensor
+        (_store_safe); leaving it, the stored gradients of the last step are still in the buffer and have to go.  While
+        the buffer holds accumulated gradients that no update has consumed yet (a defer_update pass came before), the
+        pass that ends the accumulation must ADD to them too: store mode stays off until an update / zero_grad has
+        cleared the buffer (flat.accum_pending)."""
+        want = (self._store == 'ready' and not self.defer_update and not self.flat.accum_pending and
+                (batch is None or self._store_safe(batch)))
         if self._stored_last and not want:       # (this trainer's own history: the switch in ops.py is process-wide)
+            pending = self.flat.accum_pending
             self.flat.zero_grad()
+            self.flat.accum_pending = pending
         self._stored_last = want
         ops.grad_store_mode(want)
+        if self.defer_update:
+            self.flat.accum_pending = True
 
     def _train_one_batch(self, batch, next_batch=None):
         try:
@@ -245,8 +267,8 @@ class Trainer:
     def _train_one_batch_body(self, batch, next_batch=None):
         if not self.model.training:              # (recursing through ~650 modules costs 2.5 ms of host time)
             self.model.train()                   # (:214 zero_grad: done right after the previous update)
-        self._grad_store_begin()
         batch = self._bucketed(batch)
+        self._grad_store_begin(batch)
         if next_batch is not None:
             next_batch = self._bucketed(next_batch)
         enc = None
