@@ -48,6 +48,50 @@ def _cpu_model():
         return 'unknown'
 
 
+def measure_gemm_traffic(kernel, batch):
+    """HBM bytes per launch of the dominant GEMM kernel, MEASURED in this run: two rocprofv3 passes (--pmc FETCH_SIZE,
+    --pmc WRITE_SIZE; counters in their own runs with --kernel-trace only, as MI355X_MICROARCH.md prescribes) over
+    tools/pmc_gemm_mix.py - that kernel's launches of one step and nothing else - averaged with the step's launch mix;
+    FETCH_SIZE x2 on gfx950 (64 B counted per 128 B request).  -> (bytes, note) or (None, None) when rocprofv3 is not on
+    PATH / a pass fails (the caller then falls back to the committed profile and says so)."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which('rocprofv3')
+    if exe is None:
+        return None, None
+    script = os.path.join(ROOT, 'tools', 'pmc_gemm_mix.py')
+    per_group = {}
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = tempfile.mkdtemp(prefix='tell_pmc_', dir='/tmp')
+            env = dict(os.environ, TMPDIR='/tmp')
+            r = subprocess.run([exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '-o', 'p', '--',
+                                sys.executable, script, str(batch)], cwd='/tmp', env=env, capture_output=True, text=True,
+                               timeout=240)
+            groups = [ln.split() for ln in r.stdout.splitlines() if ln.startswith('MIX ')]
+            files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+            if r.returncode != 0 or not groups or not files:
+                return None, None
+            rows = [row for row in csv.DictReader(open(files[0]))
+                    if row['Counter_Name'] == counter and 'gemm_nt_q4_kernel' in row['Kernel_Name']]
+            key = 'Dispatch_Id' if rows and 'Dispatch_Id' in rows[0] else 'Correlation_Id'
+            rows.sort(key=lambda row: int(row[key]))
+            if len(rows) != 3 * len(groups):
+                return None, None
+            for gi, grp in enumerate(groups):
+                vals = [float(row['Counter_Value']) for row in rows[3 * gi:3 * gi + 3]]
+                per_group.setdefault(grp[1], {'per_step': int(grp[5])})[counter] = sum(vals[1:]) / 2.0       # (first launch: cold)
+            shutil.rmtree(d, ignore_errors=True)
+    except Exception:                                    # noqa: BLE001 - measurement aid: never fail the bench line
+        return None, None
+    tot = sum(v['per_step'] for v in per_group.values())
+    kb = sum(v['per_step'] * (2.0 * v['FETCH_SIZE'] + v['WRITE_SIZE']) for v in per_group.values()) / tot
+    note = ('bytes/launch MEASURED IN THIS RUN: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) '
+            'over tools/pmc_gemm_mix.py, FETCH_SIZE x2 (gfx950), averaged with the step\'s launch mix ' +
+            ', '.join('%s x%d: %.1f MB' % (k, v['per_step'], (2.0 * v['FETCH_SIZE'] + v['WRITE_SIZE']) / 1024.0)
+                      for k, v in per_group.items()))
+    return int(kb * 1024), note
+
+
 def cpu_baseline(model_name='faces_objects', sample_b=4, gen_b=8, budget_s=30.0):
     """The oracle (CPU restatement of the reference, fp32; kind "port") timed on bounded samples of the same workload,
     SURVEY.md 8d: (a) the full optimisation step of the benchmarked model (weigh_bert as benchmarked), (b) the
@@ -376,7 +420,9 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
         achieved = d['work'] / (d['total_ms'] * 1e-3) / 1e12
         peak = 2500.0 if 'bf16' in name.split(',')[0] else 157.3
         traffic, tnote = None, None
-        for fn in ('r04_pmc_gemm_traffic.json', 'r03_pmc_gemm_traffic.json', 'r01_pmc_gemm_traffic.json'):
+        if not args.no_pmc and model_name == 'faces_objects' and name.startswith('gemm_nt_q4_kernel') and rank == 0:
+            traffic, tnote = measure_gemm_traffic(name, args.batch or 32)
+        for fn in (() if traffic else ('r04_pmc_gemm_traffic.json', 'r03_pmc_gemm_traffic.json', 'r01_pmc_gemm_traffic.json')):
             pmc = os.path.join(ROOT, 'profiles', fn)
             if os.path.exists(pmc):      # HBM bytes per launch of this kernel from the committed PMC passes
                 j = json.load(open(pmc))
@@ -640,6 +686,7 @@ def main():
     ap.add_argument('--no-secondary', action='store_true', help='skip the configs[1] block')
     ap.add_argument('--cpu-sample', type=int, default=4)
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-pmc', action='store_true', help='do not run the two rocprofv3 --pmc passes that measure roofline.traffic')
     ap.add_argument('--no-dp-selftest', action='store_true', help='skip the 1-rank RCCL leg of the default line')
     ap.add_argument('--cu-hog', type=int, default=0, help='hold N CUs with idle resident workgroups during the timed region (DP contention rehearsal)')
     ap.add_argument('--no-pipeline', action='store_true',

@@ -1140,6 +1140,34 @@ def test_generation_step_linears_layernorm_and_dynconv_step(M):
     side = torch.empty(M, 24, **bf)
     decode._skinny([x], E, [wo], None, [lo], 1024, M, 1024, E, out2=side, out2_from=1000, out_f32=True)
     assert rel(lo, x.float() @ wo.float().t()) < 1e-5 and torch.equal(side, lo[:, 1000:].bfloat16())
+    # ---- the LayerNorms FOLDED into their consumers (round 5): bf16 pre-norm rows in, weights scaled by gamma, the row
+    # statistics gathered from the kernel's own operands, corrected in the epilogue; against LayerNorm in fp32 of the
+    # rows the kernel saw (their bf16 rounding is the producer's side copy)
+    raw_bf, raw4_bf = raw.bfloat16(), raw4.bfloat16()
+    xnb = lnf(raw_bf.float(), ln)
+    w, b = W(2 * E, E), Bv(2 * E)
+    wf, sv, cv = decode._folded(torch.nn.Parameter(torch.zeros(1, device=DEV)), w, [ln], E)
+    st2 = torch.zeros(M, 2, **f32)
+    decode._skinny([raw_bf], E, [wf], [b], [out], E, M, E, E, pro=3, gammas=[sv], betas=[cv], eps=ln.eps, stats_out=st2, act=2)
+    assert rel(out, Fn.glu(xnb @ w.float().t() + b, dim=-1)) < 6e-3
+    torch.testing.assert_close(st2[:, 0], raw_bf.float().mean(1), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(st2[:, 1], (raw_bf.float().var(1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4, atol=1e-6)
+    fq = [decode._folded(torch.nn.Parameter(torch.zeros(1, device=DEV)), wq[i], [ln], E) for i in range(4)]
+    decode._skinny([raw_bf] * 4, E, [f[0] for f in fq], bq, [q4[i] for i in range(4)], E, M, E, E, pro=3,
+                   gammas=[f[1] for f in fq], betas=[f[2] for f in fq], eps=ln.eps, stats_out=st2, scale=0.125)
+    for i in range(4):
+        assert rel(q4[i], (xnb @ wq[i].float().t() + bq[i]) * 0.125) < 6e-3, i
+    # four problems' fp32 outputs side by side with their bf16 copies side by side (out2 per problem)
+    side4 = torch.empty(M, 4 * E, **bf)
+    decode._skinny([q4[i] for i in range(4)], E, wq, bq, [r6[:, i * E:(i + 1) * E] for i in range(4)], 4 * E, M, E, E,
+                   res_raw=raw, res_stats=st, res_ln=ln, out2=side4, out_f32=True)
+    assert torch.equal(side4, r6.bfloat16())
+    for nseg in (4, 2, 1):                                   # context_fc behind n = 4 / 2 / 1 LayerNorms of 1024 columns
+        wcn, rn = wc[:, :nseg * E].contiguous(), raw4_bf[:, :nseg * E].contiguous()
+        wcf, sc, cc = decode._folded(torch.nn.Parameter(torch.zeros(1, device=DEV)), wcn, lns[:nseg], E)
+        decode._skinny([rn], nseg * E, [wcf], [bc], [out], E, M, E, nseg * E, pro=4, gammas=[sc], betas=[cc], seg=E, eps=1e-5)
+        catb = torch.cat([lnf(rn[:, i * E:(i + 1) * E].float(), lns[i]) for i in range(nseg)], 1)
+        assert rel(out, catb @ wcn.float().t() + bc) < 6e-3, nseg
     # LayerNorm of fp32 rows to bf16
     y = torch.empty(M, E, **bf)
     ops.call('tell_layernorm_rows', raw, E, ln.weight, ln.bias, ln.eps, y, E, None, M, E)

@@ -171,11 +171,13 @@ def test_gradient_stores_survive_an_all_empty_context_and_a_mixed_accumulation(g
         t.train_one_batch(_clone(full))
         t.defer_update = False
         t.train_one_batch(_clone(full))
+    # (two accumulated passes double the atomically ordered embedding-row sums whose rounding Adam's normalisation
+    #  amplifies: measured 2.7e-6; a gradient stored over - or applied twice - moves the stored matrices by O(lr) = 1e-3)
     num = float((ta.flat.flat - tb.flat.flat).norm())
-    assert num <= 1e-6 * float(ta.flat.flat.norm()), num
+    assert num <= 1e-5 * float(ta.flat.flat.norm()), num
     la, lb = ta.train_one_batch(_clone(full)), tb.train_one_batch(_clone(full))        # and store mode is back
-    assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(la))
-    assert float((ta.flat.flat - tb.flat.flat).norm()) <= 1e-6 * float(ta.flat.flat.norm())
+    assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(la))
+    assert float((ta.flat.flat - tb.flat.flat).norm()) <= 2e-5 * float(ta.flat.flat.norm())
     assert not tb.flat.accum_pending
 
 

@@ -1,5 +1,6 @@
-"""Device time of tell_conv_bn_stats on the ResNet-152 bottleneck shapes at B = 32, each captured as 10 launches in one
-hipGraph: with / without the BatchNorm statistics + in-kernel finish, per tile shape (TELL_CONV_TILE)."""
+"""Device time of the implicit-GEMM convolution (tell_conv_bn_stats without the finish) on the ResNet-152 bottleneck shapes at
+B = 32, each captured as 10 launches in one hipGraph, per tile shape and LDS ring depth (TELL_CONV_TILE x TELL_GEMM_RING), and
+of the default choice with and without the BatchNorm launch behind it."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tell_amd
@@ -30,7 +31,10 @@ shapes = [('l1 conv1', 56, 256, 1, 1, 64), ('l1 conv2', 56, 64, 3, 1, 64), ('l1 
           ('l3 conv1', 14, 1024, 1, 1, 256), ('l3 conv2', 14, 256, 3, 1, 256), ('l3 conv3', 14, 256, 1, 1, 1024),
           ('l4 conv1', 7, 2048, 1, 1, 512), ('l4 conv2', 7, 512, 3, 1, 512), ('l4 conv3', 7, 512, 1, 1, 2048),
           ('l3 ds', 28, 512, 1, 2, 1024), ('l3 conv2 s2', 28, 256, 3, 2, 256)]
-print('%-12s %7s %5s %5s | per tile 128x128 | 128x64 | 64x64: us conv + statistics + finish / conv only, TFLOP/s | BN apply' % ('shape', 'M', 'N', 'K'))
+COMBOS = [('1', '2'), ('2', '2'), ('3', '2'), ('3', '4')]      # (tile, LDS stages) - the instantiated ones; round 5 also measured
+# 128x128 x 4, 128x64 x 4 / 6, 64x64 x 8 stages (profiles/r05_conv_shapes.txt): none won, removed from the library
+print('%-12s %7s %5s %5s | us conv + statistics epilogue (no finish) per (tile, stages): 1 = 128x128, 2 = 128x64, 3 = 64x64 | default choice' % ('shape', 'M', 'N', 'K'))
+print('%-12s %7s %5s %5s | %s | default' % ('', '', '', '', ' '.join('%7s' % ('%s/%s' % c) for c in COMBOS)))
 for name, H, Cin, k, s, Cout in shapes:
     p = k // 2
     OH = (H + 2 * p - k) // s + 1
@@ -38,15 +42,19 @@ for name, H, Cin, k, s, Cout in shapes:
     x = torch.randn(B, H, H, Cin, device='cuda').bfloat16()
     w = (torch.randn(Cout, K, device='cuda') * 0.05).bfloat16()
     y = torch.empty(M, Cout, dtype=torch.bfloat16, device='cuda')
-    mean = torch.empty(Cout, device='cuda'); invstd = torch.empty(Cout, device='cuda')
+    gamma = torch.ones(Cout, device='cuda'); beta = torch.zeros(Cout, device='cuda')
     rm = torch.zeros(Cout, device='cuda'); rv = torch.ones(Cout, device='cuda')
     out = []
-    for tile in ('1', '2', '3'):
+
+    def conv_only():      # statistics epilogue on (workspace given), the finish launch not issued: mean = None keeps it a plain launch
+        hip.call('tell_conv_bn_stats', x, w, y, B, H, H, Cin, k, k, s, p, OH, OH, Cout, 1e-5, 0.1, None, None, None, None, None, zero)
+    for tile, ring in COMBOS:
         os.environ['TELL_CONV_TILE'] = tile
-        t1 = timed(lambda: hip.call('tell_conv_bn_stats', x, w, y, B, H, H, Cin, k, k, s, p, OH, OH, Cout, 1e-5, 0.1, mean,
-                                    invstd, rm, rv, ws, zero))
-        t0 = timed(lambda: hip.call('tell_conv_bn_stats', x, w, y, B, H, H, Cin, k, k, s, p, OH, OH, Cout, 1e-5, 0.1, None,
-                                    None, None, None, None, zero))
-        out.append('%5.1f/%5.1f %4.0f' % (t1, t0, 2.0 * M * Cout * K * 1e-6 / t1))
-    ta = timed(lambda: hip.call('tell_bn_apply', y, mean, invstd, rm, rv, None, y, M, Cout, 1, 1))
-    print('%-12s %7d %5d %5d | %s | apply %5.1f' % (name, M, Cout, K, ' | '.join(out), ta), flush=True)
+        os.environ['TELL_GEMM_RING'] = ring
+        out.append('%7.1f' % timed(conv_only))
+    del os.environ['TELL_CONV_TILE'], os.environ['TELL_GEMM_RING']
+    td = timed(conv_only)
+    tf = timed(lambda: hip.call('tell_conv_bn_act', x, w, y, B, H, H, Cin, k, k, s, p, OH, OH, Cout, 1e-5, 0.1, gamma, beta, rm, rv,
+                                None, 1, ws, zero))
+    print('%-12s %7d %5d %5d | %s | %6.1f us = %4.0f TFLOP/s; conv + BN + ReLU %6.1f us' % (
+        name, M, Cout, K, ' '.join(out), td, 2.0 * M * Cout * K * 1e-6 / td, tf), flush=True)

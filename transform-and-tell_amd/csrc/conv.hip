@@ -444,6 +444,18 @@ extern "C" int tell_bn_apply(const void* x, const float* mean, const float* invs
 // n_chunks x 512 bytes of L2 reads per workgroup - used for n_chunks <= 128 (layer3 / layer4 of the trunk at B = 32:
 // 25-98 chunks), where that is a fraction of the slab itself; beyond, the combine stays a launch of its own.
 // The workgroups of the first row slab also write the running statistics (momentum update, unbiased variance).
+// Round 5: the launch is a chain of memory round trips, not bandwidth (6.4 MB in 11 us at layer3's [6272, 256]): chunk
+// means -> barrier -> chunk M2 -> barrier -> rows pass 1 -> rows pass 2, each ~1.5 us because everything it reads was
+// written by the convolution's workgroups on OTHER XCDs (nothing is in this XCD's L2).  Now ONE trip: the workgroup's
+// rows of y (and of the residual) - up to 4 passes of 32 rows - are requested FIRST, then every chunk statistic of the
+// thread (<= 32 chunks x 2 values, all in flight together), and the combine is a single shifted pass
+//   d_k = mean_k - c,  S = sum n_k d_k,  Q = sum (M2_k + n_k d_k^2),  mean = c + S / n,  M2 = Q - S^2 / n
+// with c = the first chunk's mean (each thread loads it itself): exact algebra, and the subtraction only ever sees the
+// spread of the chunk means around one of them - no cancellation against the mean itself (the two-pass form it replaces
+// needed the global mean before the second pass could start).  Folded over the 4 chunk strides in a fixed order.
+// MEASURED (MI355X, same box, ResNet-152 train B = 32): 4.76 -> 4.63 ms; layer3 conv1 + BN + ReLU 19.0 -> 17.4 us, conv2
+// 35.0 -> 33.2, layer4 conv1 20.8 -> 18.9 (tools/bench_conv.py).
+#define BNFA_PASSES 4
 __global__ __launch_bounds__(256) void bn_finish_apply_kernel(const float* __restrict__ pmean, const float* __restrict__ pm2,
                                                               long M, int C, int n_chunks, int rows_per_chunk, float eps,
                                                               float momentum, const float* __restrict__ gamma,
@@ -451,33 +463,50 @@ __global__ __launch_bounds__(256) void bn_finish_apply_kernel(const float* __res
                                                               float* __restrict__ running_var,
                                                               const uint16_t* __restrict__ residual, uint16_t* __restrict__ y,
                                                               int relu, int rows_per_block) {
-  __shared__ float smu[4][64], sm2[4][64], s_mean[64], s_scale[64], s_beta[64];
+  __shared__ float ss[4][64], sq[4][64], s_mean[64], s_scale[64], s_beta[64];
   const int tid = threadIdx.x, cl = tid & 63, g = tid >> 6;
   const int c = blockIdx.x * 64 + cl;
-  // Combine of the chunks in two passes of INDEPENDENT loads (the sequential Chan update - a division and a dependent
-  // load per chunk - cost 7 us of serial round trips per workgroup): the global mean from the chunk means, then
-  // M2 = sum_k (M2_k + n_k (mean_k - mean)^2), both folded over the 4 chunk strides in a fixed order (deterministic).
+  // ---- 1. this thread's rows: 8 channels (16 bytes) x one row per pass
+  const int o = tid & 7, rl = tid >> 3;
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  const long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  const long col = (long)blockIdx.x * 64 + o * 8;
+  u32x4_t yv[BNFA_PASSES], rv[BNFA_PASSES];
+#pragma unroll
+  for (int ps = 0; ps < BNFA_PASSES; ++ps) {
+    const long r = r0 + rl + 32 * ps;
+    const long rc = r < r1 ? r : r1 - 1;                       // (clamped: in-bounds, never stored)
+    yv[ps] = *reinterpret_cast<const u32x4_t*>(y + rc * C + col);
+    if (residual) rv[ps] = *reinterpret_cast<const u32x4_t*>(residual + rc * C + col);
+  }
+  // ---- 2. chunk statistics of channel c, chunks g, g + 4, ...
   const float n_last = (float)(M - (long)(n_chunks - 1) * rows_per_chunk), n_full = (float)rows_per_chunk;
-  {
-    float acc = 0.f;
-#pragma unroll 8
-    for (int k = g; k < n_chunks; k += 4) acc += (k == n_chunks - 1 ? n_last : n_full) * pmean[(long)k * C + c];
-    smu[g][cl] = acc;
+  const float shift = pmean[c];                               // chunk 0's mean
+  float mk[32], qk[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const int k = g + 4 * j, kk = k < n_chunks ? k : n_chunks - 1;
+    mk[j] = pmean[(long)kk * C + c];
+    qk[j] = pm2[(long)kk * C + c];
   }
-  __syncthreads();
-  const float mu = ((smu[0][cl] + smu[1][cl]) + (smu[2][cl] + smu[3][cl])) / (float)M;
-  {
-    float acc = 0.f;
-#pragma unroll 8
-    for (int k = g; k < n_chunks; k += 4) {
-      const float d = pmean[(long)k * C + c] - mu;
-      acc += pm2[(long)k * C + c] + (k == n_chunks - 1 ? n_last : n_full) * d * d;
-    }
-    sm2[g][cl] = acc;
+  float S = 0.f, Q = 0.f;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const int k = g + 4 * j;
+    const float nk = k >= n_chunks ? 0.f : (k == n_chunks - 1 ? n_last : n_full);
+    const float d = mk[j] - shift;
+    S += nk * d;
+    Q += (k < n_chunks ? qk[j] : 0.f) + nk * d * d;
   }
+  ss[g][cl] = S; sq[g][cl] = Q;
   __syncthreads();
   if (tid < 64) {
-    const float m2 = (sm2[0][cl] + sm2[1][cl]) + (sm2[2][cl] + sm2[3][cl]), n = (float)M;
+    const float St = (ss[0][cl] + ss[1][cl]) + (ss[2][cl] + ss[3][cl]);
+    const float Qt = (sq[0][cl] + sq[1][cl]) + (sq[2][cl] + sq[3][cl]);
+    const float n = (float)M;
+    const float mu = shift + St / n;
+    float m2 = Qt - St * St / n;
+    m2 = m2 > 0.f ? m2 : 0.f;
     const float var = m2 / n;
     s_mean[cl] = mu;
     s_scale[cl] = rsqrtf(var + eps) * gamma[c];
@@ -488,17 +517,21 @@ __global__ __launch_bounds__(256) void bn_finish_apply_kernel(const float* __res
     }
   }
   __syncthreads();
-  const int o = tid & 7, rl = tid >> 3;                       // 8 channels (16 bytes) per thread, 32 rows per pass
   float mean8[8], scale8[8], beta8[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { mean8[k] = s_mean[o * 8 + k]; scale8[k] = s_scale[o * 8 + k]; beta8[k] = s_beta[o * 8 + k]; }
-  const long r0 = (long)blockIdx.y * rows_per_block;
-  const long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
-  const long col = (long)blockIdx.x * 64 + o * 8;
-  for (long r = r0 + rl; r < r1; r += 32) {
+  // ---- 3. normalise the rows already in registers
+#pragma unroll
+  for (int ps = 0; ps < BNFA_PASSES; ++ps) {
+    const long r = r0 + rl + 32 * ps;
+    if (r >= r1) break;
     float v[8], rs[8];
-    unpack16(*reinterpret_cast<const uint4*>(y + r * C + col), v, (const uint16_t*)nullptr);
-    if (residual) unpack16(*reinterpret_cast<const uint4*>(residual + r * C + col), rs, (const uint16_t*)nullptr);
+    const uint4 yw = make_uint4(yv[ps][0], yv[ps][1], yv[ps][2], yv[ps][3]);
+    unpack16(yw, v, (const uint16_t*)nullptr);
+    if (residual) {
+      const uint4 rw = make_uint4(rv[ps][0], rv[ps][1], rv[ps][2], rv[ps][3]);
+      unpack16(rw, rs, (const uint16_t*)nullptr);
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       float t = (v[k] - mean8[k]) * scale8[k] + beta8[k];
@@ -562,11 +595,12 @@ int tell_bn_finish_apply_launch(const float* pmean, const float* pm2, long M, in
     if (rc) return rc;
     pmean = qmean; pm2 = qm2; n_chunks = G; rows_per_chunk *= S;
   }
-  // ~512-1024 workgroups, at least 32 rows (one pass) each
+  // ~768 workgroups of 32 .. 128 rows (1 .. 4 passes of 32, all requested up front) x 64 channels
   static const long wgs = getenv("TELL_BN_WGS") ? atol(getenv("TELL_BN_WGS")) : 768;   // tuning aid
   long per = (M * slabs + wgs - 1) / wgs;
   per = (per + 31) / 32 * 32;
   if (per < 32) per = 32;
+  if (per > 32 * BNFA_PASSES) per = 32 * BNFA_PASSES;
   const unsigned gy = (unsigned)((M + per - 1) / per);
   hipLaunchKernelGGL(bn_finish_apply_kernel, dim3(slabs, gy), dim3(256), 0, stream, pmean, pm2, M, C, n_chunks,
                      rows_per_chunk, eps, momentum, gamma, beta, running_mean, running_var, (const uint16_t*)residual,

@@ -46,6 +46,13 @@ struct SkinnyArgs {
   int cn;                                  // mfma kernel: columns per workgroup (4 / 8 / 16)
   float eps, scale;
   int M, N, K, seg, out_f32;
+  // FOLDED LayerNorm (pro 3 / 4): `in` holds the bf16 PRE-norm rows, w the weights scaled by gamma along K; the kernel
+  // gathers the row statistics from its own A fragments and the epilogue applies
+  //   LN(x) . W^T = rstd (x . W'^T) - rstd mean s + c,   W' = W gamma,  s[n] = sum_k W'[n][k],  c[n] = sum_k W[n][k] beta[k]
+  // per segment of `seg` columns (the context block's n LayerNorms feeding context_fc: s is [K / seg][N], c their sum)
+  const float* fold_s[SK_MAXP];
+  const float* fold_c[SK_MAXP];
+  long out2_prob;                          // out2 column offset per problem (n_prob outputs side by side), elements
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 sk_bf16x2;
@@ -118,20 +125,24 @@ __device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& p, int prob, i
   if (p.res_raw)
     v += (p.res_raw[(long)m * p.ld_res_raw + n] - p.res_stats[m * 2]) * p.res_stats[m * 2 + 1] * p.res_gamma[n] + p.res_beta[n];
   if (p.res_f32) v += p.res_f32[(long)m * p.ld_res_f32 + n];
-  if (p.out2 && n >= p.out2_from) p.out2[(long)m * p.ld_out2 + n - p.out2_from] = f2bf(v);
+  if (p.out2 && n >= p.out2_from) p.out2[(long)m * p.ld_out2 + prob * p.out2_prob + n - p.out2_from] = f2bf(v);
   if (p.out_f32) static_cast<float*>(p.out[prob])[(long)m * p.ld_out + n] = v;
   else static_cast<uint16_t*>(p.out[prob])[(long)m * p.ld_out + n] = f2bf(v);
 }
 
-template <int RT, int ACT, int U>
-__global__ __launch_bounds__(256) void skinny_mfma_kernel(SkinnyArgs p) {
-  constexpr int NB = ACT == 2 ? 2 : 1, MT = RT * 16, CW = 16 * NB;
+// NW: waves of the workgroup = slices of the reduction.  (Round 5 measured NW = 8 for K = 4096 - context_fc, fc2: two
+// batches of loads per wave instead of four - same box: greedy step 494.5 -> 507.3 us, beam 4 822 -> 834; only 4 is built.)
+template <int RT, int ACT, int U, bool FOLD = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
+  constexpr int NB = ACT == 2 ? 2 : 1, MT = RT * 16, CW = 16 * NB, NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
-  float* red = reinterpret_cast<float*>(sk_smem);                      // [4 waves][MT][CW]
+  float* red = reinterpret_cast<float*>(sk_smem);                      // [NW waves][MT][CW]
+  float* wst = red + NW * MT * CW;                                     // FOLD: [NW waves][MT][2] sum, sum of squares of the wave's k range
+  float* rst = wst + NW * MT * 2;                                      // FOLD: [MT][4 segments][2] mean, rstd
   const int tid = threadIdx.x, prob = blockIdx.y, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const int cn = p.cn, n0 = blockIdx.x * cn, m0 = blockIdx.z * MT, M = p.M, N = p.N, K = p.K;
-  const int kw = K / 4, nbatch = kw / (32 * U), kbeg = wave * kw;
+  const int kw = K / NW, nbatch = kw / (32 * U), kbeg = wave * kw;
   const uint16_t* X = static_cast<const uint16_t*>(p.in[prob]);
   const uint16_t* W = p.w[prob];
   const uint16_t* ap[RT];
@@ -162,7 +173,24 @@ __global__ __launch_bounds__(256) void skinny_mfma_kernel(SkinnyArgs p) {
       for (int rt = 0; rt < RT; ++rt) fa[u][rt] = *reinterpret_cast<const sk_u4*>(ap[rt] + k + u * 32);
     }
   };
+  float fs1[RT], fs2[RT];                                              // FOLD: this lane's part of the row sums
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) fs1[rt] = fs2[rt] = 0.f;
   auto compute = [&](const sk_u4 (&fa)[U][RT], const sk_u4 (&fb)[U][NB]) __attribute__((always_inline)) {
+    if constexpr (FOLD) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const sk_u4 aw = fa[u][rt];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(aw[e] << 16), hi = __uint_as_float(aw[e] & 0xffff0000u);
+            fs1[rt] += lo + hi;
+            fs2[rt] = fmaf(lo, lo, fmaf(hi, hi, fs2[rt]));
+          }
+        }
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -192,37 +220,94 @@ __global__ __launch_bounds__(256) void skinny_mfma_kernel(SkinnyArgs p) {
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[((long)wave * MT + rt * 16 + lg * 4 + r) * CW + nb * 16 + lr] = acc[rt][nb][r];
+  if constexpr (FOLD) {
+    // row (rt, lr): the four k-groups of the fragment layout sit in lanes lr, 16 + lr, 32 + lr, 48 + lr
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      float a = fs1[rt], b = fs2[rt];
+      a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+      a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+      if (lg == 0) { wst[((long)wave * MT + rt * 16 + lr) * 2] = a; wst[((long)wave * MT + rt * 16 + lr) * 2 + 1] = b; }
+    }
+  }
   __syncthreads();
-  for (int o = tid; o < MT * 16; o += 256) {
+  const int nseg = FOLD ? K / p.seg : 1, wps = NW / nseg;              // segments of the row, waves per segment
+  if constexpr (FOLD) {
+    for (int o = tid; o < MT * nseg; o += NT) {
+      const int r = o / nseg, sg = o - r * nseg;
+      float a = 0.f, b = 0.f;
+      for (int w = sg * wps; w < (sg + 1) * wps; ++w) { a += wst[((long)w * MT + r) * 2]; b += wst[((long)w * MT + r) * 2 + 1]; }
+      const float mu = a / (float)p.seg;
+      float var = b / (float)p.seg - mu * mu;
+      var = var > 0.f ? var : 0.f;
+      const float rs = rsqrtf(var + p.eps);
+      rst[(r * 4 + sg) * 2] = mu; rst[(r * 4 + sg) * 2 + 1] = rs;
+      if (p.stats_out && nseg == 1 && blockIdx.x == 0 && prob == 0 && m0 + r < M) {
+        p.stats_out[(m0 + r) * 2] = mu; p.stats_out[(m0 + r) * 2 + 1] = rs;
+      }
+    }
+    __syncthreads();
+  }
+  for (int o = tid; o < MT * 16; o += NT) {
     const int r = o >> 4, c = o & 15, m = m0 + r, n = n0 + c;
     if (c >= cn || m >= M || n >= N) continue;
-    const float v = (red[((long)0 * MT + r) * CW + c] + red[((long)1 * MT + r) * CW + c]) +
-                    (red[((long)2 * MT + r) * CW + c] + red[((long)3 * MT + r) * CW + c]);
-    float g = 0.f;
-    if constexpr (ACT == 2)
-      g = (red[((long)0 * MT + r) * CW + 16 + c] + red[((long)1 * MT + r) * CW + 16 + c]) +
-          (red[((long)2 * MT + r) * CW + 16 + c] + red[((long)3 * MT + r) * CW + 16 + c]);
+    float v, g = 0.f;
+    if constexpr (FOLD) {
+      const float* fsv = p.fold_s[prob];
+      const long NS = (long)N * NB;                                    // columns of one segment's s vector
+      v = p.fold_c[prob][n];
+      if constexpr (ACT == 2) g = p.fold_c[prob][N + n];
+      for (int sg = 0; sg < nseg; ++sg) {
+        const float mu = rst[(r * 4 + sg) * 2], rs = rst[(r * 4 + sg) * 2 + 1];
+        float dv = 0.f, dg = 0.f;
+        for (int w = sg * wps; w < (sg + 1) * wps; ++w) {
+          dv += red[((long)w * MT + r) * CW + c];
+          if constexpr (ACT == 2) dg += red[((long)w * MT + r) * CW + 16 + c];
+        }
+        v += rs * (dv - mu * fsv[sg * NS + n]);
+        if constexpr (ACT == 2) g += rs * (dg - mu * fsv[sg * NS + N + n]);
+      }
+    } else {
+      v = (red[((long)0 * MT + r) * CW + c] + red[((long)1 * MT + r) * CW + c]) +
+          (red[((long)2 * MT + r) * CW + c] + red[((long)3 * MT + r) * CW + c]);
+      if constexpr (NW == 8)
+        v += (red[((long)4 * MT + r) * CW + c] + red[((long)5 * MT + r) * CW + c]) +
+             (red[((long)6 * MT + r) * CW + c] + red[((long)7 * MT + r) * CW + c]);
+      if constexpr (ACT == 2) {
+        g = (red[((long)0 * MT + r) * CW + 16 + c] + red[((long)1 * MT + r) * CW + 16 + c]) +
+            (red[((long)2 * MT + r) * CW + 16 + c] + red[((long)3 * MT + r) * CW + 16 + c]);
+        if constexpr (NW == 8)
+          g += (red[((long)4 * MT + r) * CW + 16 + c] + red[((long)5 * MT + r) * CW + 16 + c]) +
+               (red[((long)6 * MT + r) * CW + 16 + c] + red[((long)7 * MT + r) * CW + 16 + c]);
+      }
+    }
     skinny_epilogue(p, prob, m, n, v, g, ACT);
   }
 }
-template <int RT, int ACT, int U>
+template <int RT, int ACT, int U, bool FOLD = false, int NW = 4>
 static int skinny_mfma_launch(SkinnyArgs a, int n_prob, hipStream_t stream) {
   constexpr int MT = RT * 16;
-  constexpr size_t smem = (size_t)4 * MT * 16 * (ACT == 2 ? 2 : 1) * 4;
+  constexpr size_t smem = (size_t)NW * MT * 16 * (ACT == 2 ? 2 : 1) * 4 + (FOLD ? (size_t)(NW * MT * 2 + MT * 8) * 4 : 0);
   const int groups = (a.M + MT - 1) / MT;
   const long tiles = (long)((a.N + 15) / 16) * n_prob * groups;
   a.cn = tiles >= 192 ? 16 : (tiles >= 96 ? 8 : 4);          // at least ~256 workgroups where the layer has the columns
-  auto kern = skinny_mfma_kernel<RT, ACT, U>;
+  auto kern = skinny_mfma_kernel<RT, ACT, U, FOLD, NW>;
   static bool attr_done = false;
   if (!attr_done && smem > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((a.N + a.cn - 1) / a.cn, n_prob, groups), dim3(256), smem, stream, a);
+  hipLaunchKernelGGL(kern, dim3((a.N + a.cn - 1) / a.cn, n_prob, groups), dim3(64 * NW), smem, stream, a);
   return tell_check_launch("skinny_linear (mfma)");
 }
 template <int RT, int U>
-static int skinny_mfma_dispatch(const SkinnyArgs& a, int n_prob, int act, hipStream_t stream) {
+static int skinny_mfma_dispatch(const SkinnyArgs& a, int n_prob, int act, hipStream_t stream, bool fold = false) {
+  if (fold) {                                                         // (query projections, context_fc: act 0; linear1: GLU)
+    if (act == 0) return skinny_mfma_launch<RT, 0, U, true>(a, n_prob, stream);
+    if (act == 2) return skinny_mfma_launch<RT, 2, U, true>(a, n_prob, stream);
+    tell_set_error("skinny_linear: the folded LayerNorm prologue comes with act 0 or 2");
+    return TELL_ERR_ARG;
+  }
   if (act == 0) return skinny_mfma_launch<RT, 0, U>(a, n_prob, stream);
   if (act == 1) return skinny_mfma_launch<RT, 1, U>(a, n_prob, stream);
   return skinny_mfma_launch<RT, 2, U>(a, n_prob, stream);
@@ -301,7 +386,14 @@ extern "C" int tell_skinny_linear(int n_prob, const void* const* in, long ld_in,
                                   void* const* out, long ld_out, int out_f32, int M, int N, int K, hipStream_t stream) {
   TELL_REQUIRE(n_prob >= 1 && n_prob <= SK_MAXP && M >= 1 && M <= 1024 && N >= 1 && K >= 256, "skinny_linear: bad shape");
   TELL_REQUIRE(K % 256 == 0 && ldw % 8 == 0 && ld_in % 8 == 0, "skinny_linear: K % 256, 16-byte rows");
-  TELL_REQUIRE(pro >= 0 && pro <= 2 && act >= 0 && act <= 2, "skinny_linear: bad mode");
+  TELL_REQUIRE(pro >= 0 && pro <= 4 && act >= 0 && act <= 2, "skinny_linear: bad mode");
+  const bool fold = pro >= 3;
+  if (fold) {
+    TELL_REQUIRE(gamma && beta, "skinny_linear: the folded prologue needs the s / c vectors");
+    if (pro == 3) seg = K;
+    TELL_REQUIRE(seg > 0 && K % seg == 0 && (K / seg == 1 || K / seg == 2 || K / seg == 4), "skinny_linear: folded LayerNorm over 1, 2 or 4 segments");
+    TELL_REQUIRE(pro == 3 || n_prob == 1, "skinny_linear: segmented fold: one problem");
+  }
   TELL_REQUIRE(pro != 2 || (seg > 0 && seg % 256 == 0 && K % seg == 0 && K / seg <= SK_MAXP), "skinny_linear: bad segments");
   TELL_REQUIRE(!res_raw || (res_stats && res_gamma && res_beta), "skinny_linear: res_raw needs statistics and affine");
   SkinnyArgs a;
@@ -311,6 +403,13 @@ extern "C" int tell_skinny_linear(int n_prob, const void* const* in, long ld_in,
     a.out[i] = out[j];
     a.gamma[i] = a.beta[i] = nullptr;
   }
+  for (int i = 0; i < SK_MAXP; ++i) {
+    const int j = i < n_prob ? i : 0;
+    a.fold_s[i] = fold ? static_cast<const float*>(gamma[j]) : nullptr;
+    a.fold_c[i] = fold ? static_cast<const float*>(beta[j]) : nullptr;
+    if (fold) TELL_REQUIRE(a.fold_s[i] && a.fold_c[i], "skinny_linear: folded prologue without s / c");
+  }
+  a.out2_prob = N;
   const int nseg = pro == 2 ? K / seg : (pro == 1 ? 1 : 0);
   for (int s = 0; s < nseg; ++s) {
     TELL_REQUIRE(gamma && beta && gamma[s] && beta[s], "skinny_linear: LayerNorm prologue without gamma / beta");
@@ -321,7 +420,7 @@ extern "C" int tell_skinny_linear(int n_prob, const void* const* in, long ld_in,
   a.res_gamma = res_gamma; a.res_beta = res_beta; a.res_f32 = res_f32; a.ld_res_f32 = ld_res_f32;
   a.out2 = static_cast<uint16_t*>(out2); a.ld_out2 = ld_out2; a.out2_from = out2_from; a.eps = eps; a.scale = scale; a.M = M; a.N = N; a.K = K;
   a.seg = seg > 0 ? seg : K; a.out_f32 = out_f32; a.cn = 16;
-  if (pro != 0) {
+  if (pro == 1 || pro == 2) {
     TELL_REQUIRE((pro == 1 ? K : seg) % 1024 == 0 && (pro == 1 ? K : seg) <= 4096, "skinny_linear: LayerNorm over 1024 .. 4096 columns");
     TELL_REQUIRE(ws, "skinny_linear: the LayerNorm prologue needs ws [M,K] bf16");
     for (int i = 1; i < n_prob; ++i) TELL_REQUIRE(in[i] == in[0], "skinny_linear: separate prologue: one shared input");
@@ -337,8 +436,8 @@ extern "C" int tell_skinny_linear(int n_prob, const void* const* in, long ld_in,
   // fragments of a column tile are loaded once for 128 rows instead of four times
   static const int rt_env = getenv("TELL_SK_ROWS") ? atoi(getenv("TELL_SK_ROWS")) : 0;          // A/B aid: 32 / 128
   const bool tall = rt_env ? rt_env == 128 : (M > 64 && (long)((N + 15) / 16) * n_prob * ((M + 127) / 128) >= 192);
-  if (tall) return skinny_mfma_dispatch<8, 2>(a, n_prob, act, stream);
-  return K % 1024 == 0 ? skinny_mfma_dispatch<2, 8>(a, n_prob, act, stream) : skinny_mfma_dispatch<2, 2>(a, n_prob, act, stream);
+  if (tall) return skinny_mfma_dispatch<8, 2>(a, n_prob, act, stream, fold);
+  return K % 1024 == 0 ? skinny_mfma_dispatch<2, 8>(a, n_prob, act, stream, fold) : skinny_mfma_dispatch<2, 2>(a, n_prob, act, stream, fold);
 }
 
 // ------------------------------------------------------------------ DynamicConv step (T = 1, fixed K-1 row buffer)
@@ -472,16 +571,20 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecArgs g) {
   const uint8_t* mk = p.mask ? p.mask + (long)bs * S : nullptr;
   const int ST = S + (p.bias_k ? 1 : 0) + p.has_zero;
   const int S8 = (S + 7) & ~7;
-  for (int s0 = wave * 8; s0 < S8; s0 += 128) {            // 4 key groups per trip: their loads fly together
-    uint4 kr[4];
+  // AD_G key groups (of 32 keys: 8 per wave) per trip - their loads fly together.  (Round 5 measured 8 groups per trip
+  // and the first trip of values requested ahead of the softmax: greedy step 492.7 -> 494.5 us, beam 4 743 -> 822 us -
+  // at 4 hypotheses per workgroup the 200 registers it takes halve the occupancy; 4 groups stay.)
+  constexpr int AD_G = 4;
+  for (int s0 = wave * 8; s0 < S8; s0 += 32 * AD_G) {
+    uint4 kr[AD_G];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < AD_G; ++u) {
       const int s = s0 + u * 32 + ks;
       kr[u] = make_uint4(0u, 0u, 0u, 0u);
       if (s < S) kr[u] = *reinterpret_cast<const uint4*>(kb + (long)s * p.k_ss);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < AD_G; ++u) {
       const int s = s0 + u * 32 + ks;
       float kf[8];
       unpack16(kr[u], kf, (const uint16_t*)nullptr);
@@ -545,16 +648,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecArgs g) {
   for (int i = 0; i < NQ; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[i][e] = 0.f;
-  for (int s0 = wave * 8; s0 < S8; s0 += 128) {
-    uint4 vr[4];
+  for (int s0 = wave * 8; s0 < S8; s0 += 32 * AD_G) {
+    uint4 vr[AD_G];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < AD_G; ++u) {
       const int s = s0 + u * 32 + ks;
       vr[u] = make_uint4(0u, 0u, 0u, 0u);
       if (s < S) vr[u] = *reinterpret_cast<const uint4*>(vb + (long)s * p.v_ss);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < AD_G; ++u) {
       const int s = s0 + u * 32 + ks;
       float vf[8];
       unpack16(vr[u], vf, (const uint16_t*)nullptr);

@@ -1279,8 +1279,12 @@ __global__ __launch_bounds__(256) void gemm_nt_group_kernel(GemmGroup g) {
 // layer4 conv1 24.5 -> 18.4 us, conv2 53.3 -> 38.3; ResNet-152 5.78 -> 5.50 ms) - and LOSES where many workgroups per
 // CU already hide each other's latency (layer1 conv3, K = 64: 43 -> 61 us; layer3 conv3, K = 256: 18.0 -> 24.1).
 // TELL_GEMM_RING = 2 / 3 / 4 forces a depth everywhere (A/B aid).
+static int ring_env() {                     // (read per call: tools/bench_conv.py / bench_decoder_gemms.py switch it inside one process)
+  const char* e = getenv("TELL_GEMM_RING");
+  return e ? atoi(e) : 0;
+}
 static int small_ring_stages(long tiles64, int K) {
-  static const int v = getenv("TELL_GEMM_RING") ? atoi(getenv("TELL_GEMM_RING")) : 0;
+  const int v = ring_env();
   if (v) return v;
   return (tiles64 <= 512 && K >= 512) ? 4 : 2;
 }
@@ -1525,6 +1529,8 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
   // wins (11.8 us against 20 us per launch).  TELL_GEMM_SMALL=0 restores the register-staged kernel everywhere (A/B).
   if constexpr (sizeof(T) == 2) {
     static const bool small_glds = !(getenv("TELL_GEMM_SMALL") && atoi(getenv("TELL_GEMM_SMALL")) == 0);
+    // (Round 5: an 8-stage ring for the decoder's one-round 1024 x 1024 GEMMs - 7 K tiles in flight, one workgroup per CU -
+    //  measured neutral: K = 1024 7.8 -> 8.4 us, K = 4096 23.5 -> 22.4 us, decoder half 6.955 -> 6.953 ms; not kept.)
     // (K = 4096: 35.6 us against 23.7 us for the register-staged kernel below)
     if (small_glds && a.M >= 512 && a.K <= 2048 && a.K % 64 == 0 && !a.stat_mean &&
         (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0 &&
@@ -1879,15 +1885,26 @@ static int conv_launch(const void* X, const void* Wt, void* Y, int B, int H, int
   // 50-800 tiles of 128x128, the small tile fills the chip and hides the short K loops behind its neighbours); 128x64
   // ties once there are thousands of tiles
   int pick = (tiles(64, 64) >= 6000 && N % 64 == 0) ? 2 : 3;
-  if (force) pick = force;
+  // (Round 5: 128x64 tiles for layer2 at B = 32 - 196 row chunks, which a two-round form of the fused BatchNorm finish +
+  //  apply launch could merge per workgroup, instead of 392 chunks and two BatchNorm launches - measured: the trunk got
+  //  SLOWER, 4.63 -> 4.80 ms; the 200 KB of chunk statistics per workgroup cost more than the launch they save.)
+  // (Round 5 measured DEEPER rings where one round of workgroups covers the output - 64x64 with 8 stages, 128x64 with 6,
+  //  128x128 with 4, one workgroup per CU - on every bottleneck shape, profiles/r05_conv_shapes.txt: none wins; layer3
+  //  conv2 25.0 (2 stages) / 25.2 (4) / 38.3 us (8).  These launches are not chains of DMA round trips any more: at 32
+  //  flop per staged byte a 64x64 tile is bound by what a CU's LDS-DMA path delivers from L2, ~40-45 GB/s per CU, and
+  //  several small workgroups per CU pull more than one deep one.  ResNet-152: 4.71 -> 5.08 ms with the deep choice.)
+  int ns = 0;                                                      // forced ring depth (TELL_CONV_TILE + TELL_GEMM_RING)
+  if (force) { pick = force; ns = ring_env(); }
 #define CONV_LAUNCH(BM_, BN_, CV, NS_)                                                                              \
   hipLaunchKernelGGL((gemm_nt_glds_kernel<uint16_t, BM_, BN_, 2, 2, CV, NS_>), dim3((unsigned)tiles(BM_, BN_)), dim3(256), 0, stream, a)
+#define CONV_LAUNCH2(BM_, BN_, NS_) do { if (cv) CONV_LAUNCH(BM_, BN_, true, NS_); else CONV_LAUNCH(BM_, BN_, false, NS_); } while (0)
   const bool cv = a.conv_zero != nullptr;
-  const bool ring = small_ring_stages(tiles(64, 64), K) >= 3;
-  if (pick == 1) { if (cv) CONV_LAUNCH(128, 128, true, 2); else CONV_LAUNCH(128, 128, false, 2); }
-  else if (pick == 2) { if (cv) CONV_LAUNCH(128, 64, true, 2); else CONV_LAUNCH(128, 64, false, 2); }
-  else if (ring) { if (cv) CONV_LAUNCH(64, 64, true, 4); else CONV_LAUNCH(64, 64, false, 4); }
-  else { if (cv) CONV_LAUNCH(64, 64, true, 2); else CONV_LAUNCH(64, 64, false, 2); }
+  const bool ring = ns ? ns >= 3 : small_ring_stages(tiles(64, 64), K) >= 3;
+  if (pick == 1) CONV_LAUNCH2(128, 128, 2);
+  else if (pick == 2) CONV_LAUNCH2(128, 64, 2);
+  else if (ring) CONV_LAUNCH2(64, 64, 4);
+  else CONV_LAUNCH2(64, 64, 2);
+#undef CONV_LAUNCH2
 #undef CONV_LAUNCH
   *bm_out = pick == 3 ? 64 : 128;
   return tell_check_launch("conv_bn_stats");

@@ -3,6 +3,10 @@
 // One wave per row, fp32 statistics, two-pass variance.  Rows are re-read from
 // L1/L2 (a 1024-wide bf16 row is 2 KB), so HBM traffic is one read + one write.
 #include "common.h"
+#include <stdlib.h>
+// MEASURED (MI355X, tools/bench_layernorm.py, [16384, 1024] bf16 + residual): one row per wave 20.8 us with dropout / 20.7
+// without; two rows per wave, loads up front 19.9 / 18.1; the same with non-temporal loads 22.4 / 21.0.
+#define TELL_LN_DEFAULT 1
 
 template <typename T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, long ld_x,
@@ -90,6 +94,86 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x
   }
 }
 
+// RPW rows per wave, every 16-byte load of the wave's rows (x and the residual) requested before the first use; NT: the
+// two inputs are dead after this launch in the encoder's chain (x = a GEMM output, res = the previous sub-layer's output)
+// and come in with non-temporal loads.  Same arithmetic, same reduction order per row as ln_fwd_vec_kernel: bit-identical.
+template <typename T, int NCH, int RPW, bool NT>
+__global__ __launch_bounds__(256) void ln_fwd_vec_rows_kernel(const T* __restrict__ x, long ld_x,
+                                                              const T* __restrict__ res, long ld_r,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, T* __restrict__ y,
+                                                              long ld_y, float* __restrict__ mean,
+                                                              float* __restrict__ rstd, int rows, float eps,
+                                                              uint32_t thr, float inv_keep, uint32_t seed, uint32_t salt,
+    const uint32_t* __restrict__ step) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+  salt = tell_step_salt(salt, step);
+  constexpr int VEC = Elem<T>::VEC, C = 64 * VEC * NCH;
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+  if (row0 >= rows) return;
+  u4 xv[RPW][NCH], rv[RPW][NCH];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int row = row0 + r < rows ? row0 + r : rows - 1;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c0 = (lane + 64 * i) * VEC;
+      const u4* px = reinterpret_cast<const u4*>(x + (long)row * ld_x + c0);
+      xv[r][i] = NT ? __builtin_nontemporal_load(px) : *px;
+      if (res) {
+        const u4* pr = reinterpret_cast<const u4*>(res + (long)row * ld_r + c0);
+        rv[r][i] = NT ? __builtin_nontemporal_load(pr) : *pr;
+      }
+    }
+  }
+  float gm[NCH][VEC], bt[NCH][VEC];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { gm[i][k] = gamma[(lane + 64 * i) * VEC + k]; bt[i][k] = beta[(lane + 64 * i) * VEC + k]; }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int row = row0 + r;
+    if (row >= rows) break;
+    float v[NCH][VEC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c0 = (lane + 64 * i) * VEC;
+      unpack16(make_uint4(xv[r][i][0], xv[r][i][1], xv[r][i][2], xv[r][i][3]), v[i], (const T*)nullptr);
+      if (thr) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v[i][k] *= tell_keep(seed, salt, (uint64_t)row * C + c0 + k, thr, inv_keep);
+      }
+      if (res) {
+        float q[VEC];
+        unpack16(make_uint4(rv[r][i][0], rv[r][i][1], rv[r][i][2], rv[r][i][3]), q, (const T*)nullptr);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v[i][k] += q[k];
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) s += v[i][k];
+    }
+    const float mu = wave_sum(s) / C;
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) { const float d = v[i][k] - mu; q2 += d * d; }
+    const float rs = rsqrtf(wave_sum(q2) / C + eps);
+    if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c0 = (lane + 64 * i) * VEC;
+      float o[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) o[k] = (v[i][k] - mu) * rs * gm[i][k] + bt[i][k];
+      *reinterpret_cast<uint4*>(y + (long)row * ld_y + c0) = pack16(o, (const T*)nullptr);
+    }
+  }
+}
+
 extern "C" int tell_layernorm_fwd(const void* x, long ld_x, const void* res, long ld_r,
                                   const float* gamma, const float* beta, void* y, long ld_y,
                                   float* mean, float* rstd, int rows, int C, float eps, float p,
@@ -104,6 +188,20 @@ extern "C" int tell_layernorm_fwd(const void* x, long ld_x, const void* res, lon
                        ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)res & 15) == 0;
 #define LNV(T, NCH) hipLaunchKernelGGL((ln_fwd_vec_kernel<T, NCH>), grid, dim3(256), 0, stream, (const T*)x, ld_x, \
     (const T*)res, ld_r, gamma, beta, (T*)y, ld_y, mean, rstd, rows, eps, thr, ik, seed, salt, g_tell_rng_step)
+  // TELL_LN_VAR (A/B aid, read per call): 0 = one row per wave; 1 = two rows per wave, loads up front.
+  // bf16, C = 1024, >= 4096 rows (the encoder's [B x 512, 1024] rows).
+  {
+    const char* ve = getenv("TELL_LN_VAR");
+    const int var = ve ? atoi(ve) : TELL_LN_DEFAULT;
+    if (var && aligned && dtype == TELL_BF16 && C == 1024 && rows >= 4096) {
+      dim3 g2((rows + 7) / 8);
+#define LNR(NTT) hipLaunchKernelGGL((ln_fwd_vec_rows_kernel<uint16_t, 2, 2, NTT>), g2, dim3(256), 0, stream, (const uint16_t*)x, ld_x, \
+    (const uint16_t*)res, ld_r, gamma, beta, (uint16_t*)y, ld_y, mean, rstd, rows, eps, thr, ik, seed, salt, g_tell_rng_step)
+      LNR(false);          // (the non-temporal form lost: see TELL_LN_DEFAULT)
+#undef LNR
+      return tell_check_launch("layernorm_fwd_rows");
+    }
+  }
   if (aligned && C % (64 * vec) == 0 && C / (64 * vec) <= 4 && C / (64 * vec) != 3) {
     const int nch = C / (64 * vec);
     if (dtype == TELL_BF16) { if (nch == 1) LNV(uint16_t, 1); else if (nch == 2) LNV(uint16_t, 2); else LNV(uint16_t, 4); }

@@ -10,7 +10,11 @@
 #include "common.h"
 
 #define OPT_CHUNK 1024
-#define TELL_ADAM_DEFAULT 0       // (set from the same-box A/B of tools/probes/stream_probe.hip and the step)
+// MEASURED (MI355X, same box, round 5): on bare buffers of the decoder's size (tools/probes/stream_probe.hip, 176 M
+// parameters, 34 B each) one chunk per iteration 1108 us = 5.66 TB/s, four chunks per iteration 1032 us, four chunks + non-
+// temporal loads / stores 1003 us = 6.26 TB/s (a float4 copy on that box: 5.3-5.7 TB/s); decoder half of the step alone
+// (tools/decoder_profile.py, TELL_ADAM_VAR = 0..4): 6.93 / 6.82 / 6.75 / 6.80 / 6.73 ms.
+#define TELL_ADAM_DEFAULT 4
 #include <stdlib.h>
 
 // partial[c] = sum of squares of (grad * grad_scale) over chunk c

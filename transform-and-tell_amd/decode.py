@@ -21,6 +21,31 @@ ENABLED = os.environ.get('TELL_DECODE_FUSED', '1') != '0'       # A/B aid: 0 = t
 MAX_ROWS = int(os.environ.get('TELL_DECODE_ROWS', '128'))
 
 
+# LayerNorms of the step FOLDED into their consumers (round 5): the producer of a pre-norm `residual + branch` leaves it in
+# fp32 (the residual of the next sub-layer is rebuilt from it) AND in bf16; the consuming linear runs on the bf16 raw rows
+# with weights pre-scaled by gamma, gathers the row statistics from its own MFMA operands and corrects in its epilogue
+# (csrc/decode.hip FOLD): 12 LayerNorm launches per step become one (the head's input).  TELL_DECODE_FOLD=0: round-4 form.
+FOLD = os.environ.get('TELL_DECODE_FOLD', '1') != '0'
+
+
+def _folded(w_param_key, w, lns, seg):
+    """(W' bf16 [N, K], s fp32 [K / seg][N], c fp32 [N]) of `LN_seg(x) . W^T` for consecutive column segments of width seg:
+    W'[n][k] = W[n][k] gamma_seg[k], s[seg][n] = sum_k W'[n][k] over the segment (of the ROUNDED W': what the matrix cores
+    multiply), c[n] = sum_k W[n][k] beta[k].  Cached with the weight's cache entry (dropped when the weights change)."""
+    def make():
+        wf = w.float()
+        K = wf.shape[1]
+        g = torch.cat([ln.weight.detach().float() for ln in lns])
+        b = torch.cat([ln.bias.detach().float() for ln in lns])
+        assert g.numel() == K and K % seg == 0
+        wp = (wf * g[None, :]).to(torch.bfloat16).contiguous()
+        s_vec = wp.float().view(wf.shape[0], K // seg, seg).sum(2).t().contiguous()          # [K / seg][N]
+        c_vec = (wf @ b).contiguous()
+        return wp, s_vec, c_vec
+    key = ('ln_fold', seg) + tuple((ln.weight._version, ln.bias._version, ln.weight.data_ptr()) for ln in lns) + (w.data_ptr(),)
+    return ops._cached(w_param_key, key, make)
+
+
 def _ptrs(items):
     return (ctypes.c_void_p * len(items))(*[(t.data_ptr() if torch.is_tensor(t) else (t or 0)) for t in items])
 
@@ -62,7 +87,7 @@ def _skinny(ins, ld_in, ws, biases, outs, ld_out, M, N, K, pro=0, gammas=None, b
             res_f32=None, out2=None, out2_from=0, out_f32=False):
     n = len(ins)
     work = None
-    if pro:                                                              # LayerNorm rows as their own launch
+    if pro in (1, 2):                                                    # LayerNorm rows as their own launch
         work = torch.empty(M, K, dtype=torch.bfloat16, device=ws[0].device)
     call('tell_skinny_linear', n, _ptrs(ins), ld_in, pro, _ptrs(gammas) if gammas else None,
          _ptrs(betas) if betas else None, seg, eps, stats_out, work, _ptrs(ws), ws[0].stride(0),
@@ -162,6 +187,7 @@ def decoder_step(dec, X, contexts, state, kv_cache):
     dev = X.device
     x_bf = X.reshape(M, E)
     raw_in, st_in, ln_in = None, None, None           # from layer 1 on: fp32 pre-norm rows of the previous layer
+    raw_in_bf = None                                  # ... and their bf16 copy (FOLD: the operand of the next linear1)
     f32 = dict(dtype=torch.float32, device=dev)
     bf = dict(dtype=torch.bfloat16, device=dev)
     for li, layer in enumerate(dec.layers):
@@ -170,11 +196,18 @@ def decoder_step(dec, X, contexts, state, kv_cache):
         names = layer.context_names
         n = len(names)
         mods = [layer.context_attns[nm] for nm in names]
+        fold = FOLD and n in (1, 2, 4)
+        last = li + 1 == len(dec.layers)
         # ---- conv block (:256-266): linear1 + GLU | tap projection, softmax, K-tap sum, buffer shift | linear2 + res
         w1, _ = ops.wn_weight(layer.linear1.weight_g, layer.linear1.weight_v)
         g = torch.empty(M, C, **bf)
         if raw_in is None:
             _skinny([x_bf], E, [w1], [layer.linear1.bias], [g], C, M, C, E, act=2)
+        elif raw_in_bf is not None:
+            st_in = torch.empty(M, 2, **f32)
+            w1f, s1, c1 = _folded(layer.linear1.weight_v, w1, [ln_in], E)
+            _skinny([raw_in_bf], E, [w1f], [layer.linear1.bias], [g], C, M, C, E, pro=3, gammas=[s1], betas=[c1],
+                    eps=ln_in.eps, stats_out=st_in, act=2)
         else:
             st_in = torch.empty(M, 2, **f32)
             _skinny([raw_in], E, [w1], [layer.linear1.bias], [g], C, M, C, E, pro=1, gammas=[ln_in.weight],
@@ -185,11 +218,12 @@ def decoder_step(dec, X, contexts, state, kv_cache):
         call('tell_dynconv_step', g, hist, ops.weight(conv.weight_linear.weight), c, M, C, H, K)
         w2, _ = ops.wn_weight(layer.linear2.weight_g, layer.linear2.weight_v)
         raw3 = torch.empty(M, E, **f32)
+        raw3_bf = torch.empty(M, E, **bf) if fold else None
         if raw_in is None:
-            _skinny([c], C, [w2], [layer.linear2.bias], [raw3], E, M, E, C, res=x_bf, ld_res=E, out_f32=True)
+            _skinny([c], C, [w2], [layer.linear2.bias], [raw3], E, M, E, C, res=x_bf, ld_res=E, out2=raw3_bf, out_f32=True)
         else:
             _skinny([c], C, [w2], [layer.linear2.bias], [raw3], E, M, E, C, res_raw=raw_in, res_stats=st_in,
-                    res_ln=ln_in, out_f32=True)
+                    res_ln=ln_in, out2=raw3_bf, out_f32=True)
         # ---- context block (:271-355): n query projections of LN(raw3) | n attentions | n output projections + LN(raw3)
         ln3 = layer.conv_layer_norm
         st3 = torch.empty(M, 2, **f32)
@@ -199,8 +233,13 @@ def decoder_step(dec, X, contexts, state, kv_cache):
             wp, rows = m._wrows(0)
             wq.append(ops.weight(wp, rows))
             bq.append(m.in_proj_bias.detach()[0:E])
-        _skinny([raw3] * n, E, wq, bq, [q_all[i] for i in range(n)], E, M, E, E, pro=1, gammas=[ln3.weight],
-                betas=[ln3.bias], eps=ln3.eps, stats_out=st3, scale=mods[0].scaling)
+        if fold:
+            fq = [_folded(m._wrows(0)[0], w_, [ln3], E) for m, w_ in zip(mods, wq)]
+            _skinny([raw3_bf] * n, E, [f[0] for f in fq], bq, [q_all[i] for i in range(n)], E, M, E, E, pro=3,
+                    gammas=[f[1] for f in fq], betas=[f[2] for f in fq], eps=ln3.eps, stats_out=st3, scale=mods[0].scaling)
+        else:
+            _skinny([raw3] * n, E, wq, bq, [q_all[i] for i in range(n)], E, M, E, E, pro=1, gammas=[ln3.weight],
+                    betas=[ln3.bias], eps=ln3.eps, stats_out=st3, scale=mods[0].scaling)
         a_all = torch.empty(n, M, E, **bf)
         ks, vs, k_ss, k_sb, v_ss, v_sb, masks, S, bk, bv = [], [], [], [], [], [], [], [], [], []
         beams = 1
@@ -225,14 +264,20 @@ def decoder_step(dec, X, contexts, state, kv_cache):
              _longs(k_sb), _ptrs(vs), _longs(v_ss), _longs(v_sb), _ptrs(masks), _ptrs(bk), _ptrs(bv), 1, _ints(S),
              _ptrs([a_all[i] for i in range(n)]), _longs([E] * n), M, mods[0].num_heads, beams)
         raw6 = torch.empty(M, n * E, **f32)
+        raw6_bf = torch.empty(M, n * E, **bf) if fold else None     # (problem i's copy lands at columns i E ..: out2_prob)
         _skinny([a_all[i] for i in range(n)], E, [ops.weight(m.out_proj.weight) for m in mods],
                 [m.out_proj.bias for m in mods], [raw6[:, i * E:(i + 1) * E] for i in range(n)], n * E, M, E, E,
-                res_raw=raw3, res_stats=st3, res_ln=ln3, out_f32=True)
+                res_raw=raw3, res_stats=st3, res_ln=ln3, out2=raw6_bf, out_f32=True)
         lns = [layer.context_attn_lns[nm] for nm in names]
         wc, _ = ops.wn_weight(layer.context_fc.weight_g, layer.context_fc.weight_v)
         x2 = torch.empty(M, E, **bf)
-        _skinny([raw6], n * E, [wc], [layer.context_fc.bias], [x2], E, M, E, n * E, pro=2,
-                gammas=[ln.weight for ln in lns], betas=[ln.bias for ln in lns], seg=E, eps=lns[0].eps)
+        if fold:
+            wcf, sc, cc = _folded(layer.context_fc.weight_v, wc, lns, E)
+            _skinny([raw6_bf], n * E, [wcf], [layer.context_fc.bias], [x2], E, M, E, n * E, pro=4, gammas=[sc], betas=[cc],
+                    seg=E, eps=lns[0].eps)
+        else:
+            _skinny([raw6], n * E, [wc], [layer.context_fc.bias], [x2], E, M, E, n * E, pro=2,
+                    gammas=[ln.weight for ln in lns], betas=[ln.bias for ln in lns], seg=E, eps=lns[0].eps)
         # ---- FFN (:357-364)
         F = layer.fc1.out_features
         wf1, _ = ops.wn_weight(layer.fc1.weight_g, layer.fc1.weight_v)
@@ -240,8 +285,10 @@ def decoder_step(dec, X, contexts, state, kv_cache):
         hmid = torch.empty(M, F, **bf)
         _skinny([x2], E, [wf1], [layer.fc1.bias], [hmid], F, M, F, E, act=1)
         raw9 = torch.empty(M, E, **f32)
-        _skinny([hmid], F, [wf2], [layer.fc2.bias], [raw9], E, M, E, F, res=x2, ld_res=E, out_f32=True)
-        raw_in, ln_in = raw9, layer.final_layer_norm
+        nxt_fold = FOLD and not last and len(dec.layers[li + 1].context_names) in (1, 2, 4)
+        raw9_bf = torch.empty(M, E, **bf) if nxt_fold else None
+        _skinny([hmid], F, [wf2], [layer.fc2.bias], [raw9], E, M, E, F, res=x2, ld_res=E, out2=raw9_bf, out_f32=True)
+        raw_in, ln_in, raw_in_bf = raw9, layer.final_layer_norm, raw9_bf
     y = torch.empty(M, E, **bf)
     call('tell_layernorm_rows', raw_in, E, ln_in.weight, ln_in.bias, ln_in.eps, y, E, None, M, E)
     return y.view(1, M, E)

@@ -46,6 +46,13 @@ class StepGraph:
         self.cache = graphs.SignatureCache(int(os.environ.get('TELL_STEP_GRAPHS_MAX', 4 * graphs.MAX_SIGNATURES)), capture_after)
         self.entries = self.cache.entries
         self.replays = 0
+        # ONE memory pool for every captured signature of this trainer (round 5).  A private pool per graph pinned 3.9 GB per
+        # signature (66.5 GB for the 17 signatures of bench.py's many-signature leg) although the graphs never run at
+        # the same time: replays are serial on the training stream, a graph's intermediates are dead when its replay
+        # ends, and what outlives it (loss, token count) is read before the next replay starts.  With a shared pool a new
+        # capture reuses the blocks the earlier captures' intermediates returned.  TELL_STEP_POOL=0: private pools (A/B).
+        self.shared_pool = os.environ.get('TELL_STEP_POOL', '1') != '0'
+        self.pool = None
 
     def reset(self):
         self.cache.clear()
@@ -76,7 +83,10 @@ class StepGraph:
         sig = (tuple((k, tuple(v.shape), v.dtype) for k, v in small.items()),
                tuple((tuple(t.shape), t.dtype, t.data_ptr() if by_ptr else 0) for t in big),
                by_ptr, rt.compute_dtype(), tr.dp, ops._WGRAD['enabled'], tr.defer_update,
-               ops.grad_store_on())          # (the gradient convention - stores or zero + accumulate - is baked into the launches)
+               # the gradient convention - stores or zero + accumulate - is baked into the launches; the trainer's ONE
+               # observing step runs zero + accumulate but is followed by captures in store mode: it counts as a sighting
+               # of the store-mode signature
+               ops.grad_store_on() or (tr._store == 'want' and not tr.defer_update))
         return sig, small, big, by_ptr
 
     # ------------------------------------------------------------------ one step
@@ -146,7 +156,10 @@ class StepGraph:
         try:
             ops.drop_trainable_cache()          # working weights of trainable parameters are rebuilt inside the graph
             hip.call('tell_set_rng_step_ptr', counter)
-            with graphs.no_gc(), held, torch.cuda.graph(g, capture_error_mode='thread_local'):
+            if self.shared_pool and self.pool is None:
+                self.pool = torch.cuda.graph_pool_handle()
+            with graphs.no_gc(), held, torch.cuda.graph(g, pool=self.pool if self.shared_pool else None,
+                                                        capture_error_mode='thread_local'):
                 with hip.bound_stream():
                     encs = EncodedBatch()
                     encs.stack, encs.x_image = st_big
