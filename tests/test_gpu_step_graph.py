@@ -166,18 +166,24 @@ def test_gradient_stores_survive_an_all_empty_context_and_a_mixed_accumulation(g
         assert num <= 1e-6 * float(ta.flat.flat.norm()), (s, num)
     assert tb._store == 'ready' and tb.flat.stored_numel > 0
     # (2) accumulate two micro-batches, the second one ending the accumulation with the update
+    # (two DIFFERENT micro-batches: Adam's update is nearly invariant to the gradient's scale, so g + g against g would
+    #  hide a stored-over sum; g1 + g2 against g2 does not)
+    other = _dev(synthetic_batch(B=3, article_len=20, caption_len=9, faces_objects=True, vocab=600, cutoffs=(100, 300), seed=63))
+    before = tb.flat.flat.clone()
     for t in (ta, tb):
         t.defer_update = True
         t.train_one_batch(_clone(full))
         t.defer_update = False
-        t.train_one_batch(_clone(full))
-    # (two accumulated passes double the atomically ordered embedding-row sums whose rounding Adam's normalisation
-    #  amplifies: measured 2.7e-6; a gradient stored over - or applied twice - moves the stored matrices by O(lr) = 1e-3)
+        t.train_one_batch(_clone(other))
+    # (the accumulated passes double the atomically ordered embedding-row sums whose rounding Adam's normalisation
+    #  amplifies: measured 3e-6 of the weights' norm; the step itself moves them by 1e-3 of it, and a gradient stored
+    #  over - or applied twice - changes that step by a comparable amount)
+    moved = float((tb.flat.flat - before).norm())
     num = float((ta.flat.flat - tb.flat.flat).norm())
-    assert num <= 1e-5 * float(ta.flat.flat.norm()), num
+    assert num <= 2e-2 * moved, (num, moved)
     la, lb = ta.train_one_batch(_clone(full)), tb.train_one_batch(_clone(full))        # and store mode is back
-    assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(la))
-    assert float((ta.flat.flat - tb.flat.flat).norm()) <= 2e-5 * float(ta.flat.flat.norm())
+    assert abs(float(la) - float(lb)) <= 1e-4 * abs(float(la))
+    assert float((ta.flat.flat - tb.flat.flat).norm()) <= 4e-2 * moved
     assert not tb.flat.accum_pending
 
 

@@ -1711,6 +1711,8 @@ extern "C" int tell_gemm_grouped(int n, const tell_gemm_problem* pr, hipStream_t
     if (tile_env == 128) big = q.M >= 128 && q.N >= 128;
     int b = (form_of[i] * 2 + f32) * 2 + (big ? 1 : 0);
     static const bool wide_env = !(getenv("TELL_GROUP_WIDE") && atoi(getenv("TELL_GROUP_WIDE")) == 0);   // A/B aid
+    // (round 5: 256x128 tiles for the K = 1024 / 2048 weight gradients too - same box, decoder half 6.74 / 6.75 / 6.74 ms
+    //  for a threshold of 4096 / 1024 / 2048: the four 128x128 launches, 0.70 ms, become 0.70 ms of wide launches)
     if (wide_env && form_of[i] == 2 && f32 && q.K >= 4096 && q.M >= 256 && q.N >= 128) b = WIDE;
     ids[b * n + cnt[b]++] = i;
   }

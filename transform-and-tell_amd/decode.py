@@ -26,6 +26,7 @@ MAX_ROWS = int(os.environ.get('TELL_DECODE_ROWS', '128'))
 # with weights pre-scaled by gamma, gathers the row statistics from its own MFMA operands and corrects in its epilogue
 # (csrc/decode.hip FOLD): 12 LayerNorm launches per step become one (the head's input).  TELL_DECODE_FOLD=0: round-4 form.
 FOLD = os.environ.get('TELL_DECODE_FOLD', '1') != '0'
+HEAD_GROUPED = os.environ.get('TELL_HEAD_GROUPED', '1') != '0'      # A/B aid: the two tail-table products as one launch
 
 
 def _folded(w_param_key, w, lns, seg):
@@ -157,6 +158,7 @@ def head_step(x2, cutoffs, emb0, class_proj, tails, topk=0):
     _skinny([x2], x2.stride(0), [w_all], None, [head], ld, N, n_all, E, out2=h, out2_from=n_head, out_f32=True)
     tl, lds, ns = [None] * 3, [0] * 3, [0] * 3
     off = 0
+    big = []                                                 # the large tail tables: ONE grouped launch (round 5)
     for i in range(n_tails):
         emb = ops.weight(tails[2 * i + 1])
         n_i = emb.shape[0]
@@ -164,9 +166,15 @@ def head_step(x2, cutoffs, emb0, class_proj, tails, topk=0):
         tl[i] = torch.empty(N, lds[i], dtype=torch.float32, device=dev)
         if n_i * hdims[i] <= 4096 * 1024 and hdims[i] % 256 == 0:
             _skinny([h[:, off:off + hdims[i]]], h.stride(0), [emb], None, [tl[i]], lds[i], N, n_i, hdims[i], out_f32=True)
+        elif HEAD_GROUPED and hdims[i] % 64 == 0 and off % 8 == 0:
+            big.append(dict(a=h[:, off:off + hdims[i]], b=emb, out=tl[i][:, :n_i], form='nt'))
         else:       # tens of MB of table: the MFMA GEMM's 64-column tiles re-read the rows 4x less often per weight byte
             ops.gemm(h[:, off:off + hdims[i]], emb, out=tl[i][:, :n_i])
         off += hdims[i]
+    if len(big) == 1:
+        ops.gemm(big[0]['a'], big[0]['b'], out=big[0]['out'])
+    elif big:       # two dependent launches of 235 / 473 column tiles (12 + 16 us) -> one launch of 708
+        ops.gemm_grouped(big)
     if topk:
         tokens = torch.empty(N, topk, dtype=torch.int32, device=dev)
         lps = torch.empty(N, topk, dtype=torch.float32, device=dev)
