@@ -111,9 +111,35 @@ __device__ __forceinline__ float sk_wave_sum(float v) {
 // L2 - 25 us per launch against 6.)
 // U: k-steps of 32 per batch of loads (two batches are in flight).
 typedef __attribute__((ext_vector_type(8))) __bf16 sk_bf16x8;
-__device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& p, int prob, int m, int n, float v, float g, int act) {
+// what an output element's epilogue reads from memory: requested BEFORE the reduction (round 5).  Fetched behind it, the
+// bias / residual / LayerNorm-rebuild operands were one more dependent memory round trip at the tail of every launch of
+// the step's chain (~35 launches).
+struct SkPre { float b0, b1, res, raw, mean, rstd, gam, bet, r32; };
+__device__ __forceinline__ SkPre skinny_preload(const SkinnyArgs& p, int prob, int m, int n, int act) {
+  SkPre q = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float* bias = p.bias[prob];
+  if (bias) { q.b0 = bias[n]; if (act == 2) q.b1 = bias[p.N + n]; }
+  if (p.res) q.res = __uint_as_float((uint32_t)p.res[(long)m * p.ld_res + n] << 16);
+  if (p.res_raw) {
+    q.raw = p.res_raw[(long)m * p.ld_res_raw + n]; q.mean = p.res_stats[m * 2]; q.rstd = p.res_stats[m * 2 + 1];
+    q.gam = p.res_gamma[n]; q.bet = p.res_beta[n];
+  }
+  if (p.res_f32) q.r32 = p.res_f32[(long)m * p.ld_res_f32 + n];
+  return q;
+}
+__device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& p, int prob, int m, int n, float v, float g, int act,
+                                                const SkPre* pre = nullptr) {
   const int N = p.N;
   const float* bias = p.bias[prob];
+  if (pre) {
+    v += pre->b0;
+    if (act == 1) v = fmaxf(v, 0.f);
+    if (act == 2) v = tell_glu(v, g + pre->b1);
+    v *= p.scale;
+    v += pre->res;
+    if (p.res_raw) v += (pre->raw - pre->mean) * pre->rstd * pre->gam + pre->bet;
+    v += pre->r32;
+  } else {
   if (bias) v += bias[n];
   if (act == 1) v = fmaxf(v, 0.f);
   if (act == 2) {
@@ -125,6 +151,7 @@ __device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& p, int prob, i
   if (p.res_raw)
     v += (p.res_raw[(long)m * p.ld_res_raw + n] - p.res_stats[m * 2]) * p.res_stats[m * 2 + 1] * p.res_gamma[n] + p.res_beta[n];
   if (p.res_f32) v += p.res_f32[(long)m * p.ld_res_f32 + n];
+  }
   if (p.out2 && n >= p.out2_from) p.out2[(long)m * p.ld_out2 + prob * p.out2_prob + n - p.out2_from] = f2bf(v);
   if (p.out_f32) static_cast<float*>(p.out[prob])[(long)m * p.ld_out + n] = v;
   else static_cast<uint16_t*>(p.out[prob])[(long)m * p.ld_out + n] = f2bf(v);
@@ -175,22 +202,23 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
       for (int rt = 0; rt < RT; ++rt) fa[u][rt] = *reinterpret_cast<const sk_u4*>(ap[rt] + k + u * 32);
     }
   };
-  float fs1[RT], fs2[RT];                                              // FOLD: this lane's part of the row sums
+  // FOLD: the row statistics come off the matrix cores too.  X . 1 (B = a fragment of bf16 ones) leaves sum_k x[m][k] in
+  // every column of row m; X . X^T (the A fragment passed as B as well: both operands use the same k placement) leaves
+  // sum_k x[m][k]^2 on the diagonal.  Two more 16x16x32 MFMAs per A fragment on a pipe that has one to do, instead of 24
+  // VALU operations per fragment (first version: 3 us of arithmetic in front of context_fc's 4096-column rows).
+  c4 fsum[RT], fsq[RT];
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) fs1[rt] = fs2[rt] = 0.f;
+  for (int rt = 0; rt < RT; ++rt) { fsum[rt] = c4{0.f, 0.f, 0.f, 0.f}; fsq[rt] = c4{0.f, 0.f, 0.f, 0.f}; }
+  const sk_u4 ones4 = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
   auto compute = [&](const sk_u4 (&fa)[U][RT], const sk_u4 (&fb)[U][NB]) __attribute__((always_inline)) {
     if constexpr (FOLD) {
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-          const sk_u4 aw = fa[u][rt];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float lo = __uint_as_float(aw[e] << 16), hi = __uint_as_float(aw[e] & 0xffff0000u);
-            fs1[rt] += lo + hi;
-            fs2[rt] = fmaf(lo, lo, fmaf(hi, hi, fs2[rt]));
-          }
+          const sk_bf16x8 av = __builtin_bit_cast(sk_bf16x8, fa[u][rt]);
+          fsum[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(sk_bf16x8, ones4), fsum[rt], 0, 0, 0);
+          fsq[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, av, fsq[rt], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -207,6 +235,30 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
       }
   };
   load(fa0, fb0, 0);
+  // FOLD: the epilogue's s / c values of this thread's column (o & 15 == tid & 15 for every o it handles) are requested
+  // now - behind the reduction they were a dependent global round trip at the very end of the launch
+  float pre_s[4][NB], pre_c[NB];
+  if constexpr (FOLD) {
+    const int n_pre = n0 + (tid & 15) < N ? n0 + (tid & 15) : N - 1;
+    const int nsg = K / p.seg;
+#pragma unroll
+    for (int e = 0; e < NB; ++e) {
+      pre_c[e] = p.fold_c[prob][e * N + n_pre];
+#pragma unroll
+      for (int sg = 0; sg < 4; ++sg) pre_s[sg][e] = sg < nsg ? p.fold_s[prob][(long)sg * N * NB + e * N + n_pre] : 0.f;
+    }
+  }
+  constexpr int EPI = MT * 16 / NT;                                    // output elements per thread
+  constexpr bool PRE = EPI <= 8;
+  SkPre pre[PRE ? EPI : 1];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int e = 0; e < EPI; ++e) {
+      const int o = tid + e * NT, r = o >> 4, c = o & 15;
+      const int m = m0 + r < M ? m0 + r : M - 1, n = n0 + c < N ? n0 + c : N - 1;
+      pre[e] = skinny_preload(p, prob, m, n, ACT);
+    }
+  }
   int b = 0;
   for (; b + 1 < nbatch; b += 2) {
     load(fa1, fb1, b + 1);
@@ -223,13 +275,19 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[((long)wave * MT + rt * 16 + lg * 4 + r) * CW + nb * 16 + lr] = acc[rt][nb][r];
   if constexpr (FOLD) {
-    // row (rt, lr): the four k-groups of the fragment layout sit in lanes lr, 16 + lr, 32 + lr, 48 + lr
+    // C layout: column = lane & 15, row = (lane >> 4) * 4 + register.  Row sums: any column (column 0: lanes 0, 16, 32,
+    // 48 hold rows lg * 4 + r); sums of squares: the diagonal (row == column: the lane with (lr >> 2) == lg, register lr & 3)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      float a = fs1[rt], b = fs2[rt];
-      a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
-      a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
-      if (lg == 0) { wst[((long)wave * MT + rt * 16 + lr) * 2] = a; wst[((long)wave * MT + rt * 16 + lr) * 2 + 1] = b; }
+      if (lr == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wst[((long)wave * MT + rt * 16 + lg * 4 + r) * 2] = fsum[rt][r];
+      }
+      if ((lr >> 2) == lg) {
+        const int r = lr & 3;
+        const float q = r == 0 ? fsq[rt][0] : r == 1 ? fsq[rt][1] : r == 2 ? fsq[rt][2] : fsq[rt][3];
+        wst[((long)wave * MT + rt * 16 + lr) * 2 + 1] = q;
+      }
     }
   }
   __syncthreads();
@@ -250,24 +308,26 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
     }
     __syncthreads();
   }
-  for (int o = tid; o < MT * 16; o += NT) {
+#pragma unroll
+  for (int e = 0; e < EPI; ++e) {
+    const int o = tid + e * NT;
     const int r = o >> 4, c = o & 15, m = m0 + r, n = n0 + c;
     if (c >= cn || m >= M || n >= N) continue;
     float v, g = 0.f;
     if constexpr (FOLD) {
-      const float* fsv = p.fold_s[prob];
-      const long NS = (long)N * NB;                                    // columns of one segment's s vector
-      v = p.fold_c[prob][n];
-      if constexpr (ACT == 2) g = p.fold_c[prob][N + n];
-      for (int sg = 0; sg < nseg; ++sg) {
+      v = pre_c[0];
+      if constexpr (ACT == 2) g = pre_c[NB - 1];
+#pragma unroll
+      for (int sg = 0; sg < 4; ++sg) {
+        if (sg >= nseg) break;
         const float mu = rst[(r * 4 + sg) * 2], rs = rst[(r * 4 + sg) * 2 + 1];
         float dv = 0.f, dg = 0.f;
         for (int w = sg * wps; w < (sg + 1) * wps; ++w) {
           dv += red[((long)w * MT + r) * CW + c];
           if constexpr (ACT == 2) dg += red[((long)w * MT + r) * CW + 16 + c];
         }
-        v += rs * (dv - mu * fsv[sg * NS + n]);
-        if constexpr (ACT == 2) g += rs * (dg - mu * fsv[sg * NS + N + n]);
+        v += rs * (dv - mu * pre_s[sg][0]);
+        if constexpr (ACT == 2) g += rs * (dg - mu * pre_s[sg][NB - 1]);
       }
     } else {
       v = (red[((long)0 * MT + r) * CW + c] + red[((long)1 * MT + r) * CW + c]) +
@@ -283,7 +343,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
                (red[((long)6 * MT + r) * CW + 16 + c] + red[((long)7 * MT + r) * CW + 16 + c]);
       }
     }
-    skinny_epilogue(p, prob, m, n, v, g, ACT);
+    skinny_epilogue(p, prob, m, n, v, g, ACT, PRE ? &pre[e] : nullptr);
   }
 }
 template <int RT, int ACT, int U, bool FOLD = false, int NW = 4>
@@ -568,6 +628,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecArgs g) {
   for (int i = 0; i < NQ; ++i)
     unpack16(*reinterpret_cast<const uint4*>(p.q + (long)(b0 + (i < nq ? i : 0)) * p.q_sb + h * 64 + dc * 8), q[i],
              (const uint16_t*)nullptr);
+  // (round 5: a head-major cache [B, H, S, 64] - one contiguous block per workgroup instead of S pieces of 128 bytes a row
+  //  of E apart - measured on one layer's four contexts at B = 32: 16.2 -> 15.8 us; the layout is not what costs)
   const uint16_t* kb = p.k + (long)bs * p.k_sb + h * 64 + dc * 8;
   const uint16_t* vb = p.v + (long)bs * p.v_sb + h * 64 + dc * 8;
   const uint8_t* mk = p.mask ? p.mask + (long)bs * S : nullptr;

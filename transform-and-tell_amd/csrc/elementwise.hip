@@ -141,6 +141,37 @@ __device__ __forceinline__ void wn_weight_row(const float* __restrict__ g, const
   const float* vr = v + (long)row * cols;
   OutT* wr = w + (long)row * cols;
   float s = 0.f;
+  typedef __attribute__((ext_vector_type(4))) float f4v;
+  if ((cols & 255) == 0 && cols <= 4096) {
+    // the row lives in registers (<= 16 float4 per lane): ONE pass over v with every load in flight before the first use
+    // (round 5: the two-pass form read the row, reduced, and read it again - 3.4 TB/s on the 372 MB of the decoder's 20
+    // GehringLinears)
+    const int nv = cols >> 8;
+    f4v x[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < nv) x[j] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(vr) + lane + 64 * j);
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < nv) s += x[j][0] * x[j][0] + x[j][1] * x[j][1] + x[j][2] * x[j][2] + x[j][3] * x[j][3];
+    s = wave_sum(s);
+    const float nrm = sqrtf(s), sc = g[row] / nrm;
+    if (lane == 0) norms[row] = nrm;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < nv) {
+        const int c = lane + 64 * j;
+        if constexpr (sizeof(OutT) == 2) {
+          uint2 o;
+          o.x = (uint32_t)f2bf(x[j][0] * sc) | ((uint32_t)f2bf(x[j][1] * sc) << 16);
+          o.y = (uint32_t)f2bf(x[j][2] * sc) | ((uint32_t)f2bf(x[j][3] * sc) << 16);
+          reinterpret_cast<uint2*>(wr)[c] = o;
+        } else {
+          reinterpret_cast<float4*>(wr)[c] = make_float4(x[j][0] * sc, x[j][1] * sc, x[j][2] * sc, x[j][3] * sc);
+        }
+      }
+    return;
+  }
   if ((cols & 3) == 0) {
     const float4* v4 = reinterpret_cast<const float4*>(vr);
     for (int c = lane; c < cols / 4; c += 64) { const float4 x = v4[c]; s += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w; }
@@ -195,6 +226,36 @@ __device__ __forceinline__ void wn_backward_row(const float* __restrict__ dW, co
   float* o = dv + (long)row * cols;
   const bool vec = (cols & 3) == 0 && (((uintptr_t)dW | (uintptr_t)v | (uintptr_t)dv) & 15) == 0;
   float dot = 0.f;
+  if (vec && (cols & 255) == 0 && cols <= 4096) {
+    // dW and v rows in registers (<= 2 x 16 float4 per lane): one pass, every load in flight before the dot product
+    // (round 5; the two-pass form read both rows twice).  dW is dead after this launch: non-temporal.
+    typedef __attribute__((ext_vector_type(4))) float f4v;
+    const int nv = cols >> 8;
+    f4v d[16], x[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < nv) {
+        d[j] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(dr) + lane + 64 * j);
+        x[j] = reinterpret_cast<const f4v*>(vr)[lane + 64 * j];
+      }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < nv) dot += d[j][0] * x[j][0] + d[j][1] * x[j][1] + d[j][2] * x[j][2] + d[j][3] * x[j][3];
+    dot = wave_sum(dot);
+    const float nrm = norms[row], gs = g[row] / nrm, k = dot / (nrm * nrm);
+    if (lane == 0) dg[row] = (store ? 0.f : dg[row]) + dot / nrm;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < nv) {
+        const int c = lane + 64 * j;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!store) a = reinterpret_cast<float4*>(o)[c];
+        a.x += gs * (d[j][0] - x[j][0] * k); a.y += gs * (d[j][1] - x[j][1] * k);
+        a.z += gs * (d[j][2] - x[j][2] * k); a.w += gs * (d[j][3] - x[j][3] * k);
+        reinterpret_cast<float4*>(o)[c] = a;
+      }
+    return;
+  }
   if (vec) {
     for (int c = lane; c < cols / 4; c += 64) {
       const float4 d = reinterpret_cast<const float4*>(dr)[c], x = reinterpret_cast<const float4*>(vr)[c];
