@@ -66,7 +66,7 @@ def measure_gemm_traffic(kernel, batch):
             env = dict(os.environ, TMPDIR='/tmp')
             r = subprocess.run([exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '-o', 'p', '--',
                                 sys.executable, script, str(batch)], cwd='/tmp', env=env, capture_output=True, text=True,
-                               timeout=240)
+                               timeout=120)
             groups = [ln.split() for ln in r.stdout.splitlines() if ln.startswith('MIX ')]
             files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
             if r.returncode != 0 or not groups or not files:
@@ -434,6 +434,11 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
         conc = prof_concurrent.get(name) if not args.serial else None
         iso = {'achieved': round(achieved, 2), 'frac': round(achieved / peak, 4), 'avg_launch_us': round(d['avg_us'], 2),
                'timed_launches': d['timed']}
+        if d['timed']:       # the same figure WITHOUT the event-overhead subtraction (the conservative reading)
+            raw_ms = d['total_ms'] + d['timed'] * prof.overhead_us() * 1e-3
+            raw_tf = d['work'] / (raw_ms * 1e-3) / 1e12
+            iso['frac_without_overhead_subtraction'] = round(raw_tf / peak, 4)
+            iso['avg_launch_us_without_overhead_subtraction'] = round(d['avg_us'] + prof.overhead_us(), 2)
         if conc:        # headline = the kernel INSIDE the timed region (three streams share the CUs there)
             c_tf = conc['work'] / (conc['total_ms'] * 1e-3) / 1e12
             head = {'achieved': round(c_tf, 2), 'frac': round(c_tf / peak, 4), 'avg_launch_us': round(conc['avg_us'], 2),
