@@ -279,6 +279,11 @@ int tell_dropout_add(const void* x, const void* add, void* out, long n, float p,
  *
  * tell_skinny_linear: out[p] = (act(prologue(in[p]) . w[p]^T + bias[p])) * scale + residual, n_prob <= 4 problems of one
  * shape per launch (HOST arrays of n_prob pointers), bf16 weights [N (2N with GLU), K], M <= 1024, K % 256 == 0.
+ *   pro 3 / 4 (round 5): the LayerNorm FOLDED into the product - in = the bf16 PRE-norm rows, w = the weights scaled by the
+ *   LayerNorm's gamma along K, gamma[p] / beta[p] carry problem p's fp32 vectors s [K / seg][N (2N)] and c [N (2N)] with
+ *   s[g][n] = sum_k w[n][k] over segment g, c[n] = sum_k W[n][k] beta[k]; the kernel gathers mean / rstd of its rows (per
+ *   `seg` columns for pro 4: K / seg in {1, 2, 4}, one problem) from its own operands and applies
+ *   LN(x) . W^T = rstd (x . w^T) - rstd mean s + c in the epilogue; stats_out (pro 3) receives (mean, rstd); act 0 or 2.
  *   pro 0: in bf16 [M,K].  pro 1: in fp32 [M,K] (a pre-norm `residual + branch`), LayerNorm(gamma[0], beta[0], eps) first;
  *   stats_out (optional, [M][2] fp32) receives (mean, rstd) per row.  pro 2: one LayerNorm per `seg` columns of in
  *   (gamma[s], beta[s], K / seg <= 4): the four LayerNorms that end the context block feeding context_fc.  pro 1 / 2 are
@@ -288,7 +293,7 @@ int tell_dropout_add(const void* x, const void* add, void* out, long n, float p,
  *   residual: res (bf16 [M,N]), LayerNorm(res_raw) rebuilt from res_stats ([M][2]), res_gamma, res_beta, res_f32 (fp32
  *   [M,N]); each may be NULL.
  *   out bf16 or (out_f32) fp32 [M,N]; out2 (optional, bf16): columns n >= out2_from of the result once more, at
- *   out2[m][n - out2_from] (the softmax head: cluster logits in fp32 and the tails' projected inputs in bf16 from one
+ *   out2[m][p * N + n - out2_from] for problem p (the softmax head: cluster logits in fp32 and the tails' projected inputs in bf16 from one
  *   launch). */
 int tell_skinny_linear(int n_prob, const void* const* in, long ld_in, int pro, const void* const* gamma,
                        const void* const* beta, int seg, float eps, float* stats_out, void* ws, const void* const* w,
