@@ -614,19 +614,38 @@ def generate_bench(args, dev, world, rank, dist):
     def clone(b):
         return {k: (dict(v) if isinstance(v, dict) else v.clone()) for k, v in b.items()}
     out = None
+    pipelined = not getattr(args, 'gen_serial', False)
+
+    def run(n):
+        """n batches: pipelined = the test-set loop of commands/evaluate.py (model.generate_stream: encoders of batch
+        N+1 on their own streams underneath the decode loop of batch N); serial = one generate() after the other"""
+        last = None
+        if pipelined:
+            for _, last in model.generate_stream((clone(batches[i % 2]) for i in range(n)), beam_size=beam):
+                pass
+        else:
+            for i in range(n):
+                last = model.generate(**clone(batches[i % 2]), beam_size=beam)
+        return last
     with tell_amd.hip.bound_stream():
-        for i in range(args.warmup):
-            out = model.generate(**clone(batches[i % 2]), beam_size=beam)
+        out = run(args.warmup)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            out = model.generate(**clone(batches[i % 2]), beam_size=beam)
+        out = run(args.steps)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        serial_elapsed = None
+        if pipelined:                              # the round-4 flow beside it: encoders, then the decode loop, per batch
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                out = model.generate(**clone(batches[i % 2]), beam_size=beam)
+            torch.cuda.synchronize()
+            serial_elapsed = time.perf_counter() - t1
         # decode loop alone (contexts already encoded): HIP events on its stream -> time per decode step
         with torch.no_grad():
             cap_ids, _, contexts = model._forward(**{k: v for k, v in clone(batches[0]).items() if k != 'metadata'})
@@ -667,12 +686,15 @@ def generate_bench(args, dev, world, rank, dist):
                   'caption generation throughput (img+article->caption), greedy',
         'value': round(world * B * args.steps / elapsed, 2), 'unit': 'captions/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 2),
+        'serial_value': round(world * B * args.steps / serial_elapsed, 2) if serial_elapsed else None,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
         'data': 'synthetic (random pixels, random BPE ids; random-init weights)',
         'config': {'workload': 'BASELINE configs[4]: caption generation, full faces+objects model '
                                '(expt/nytimes/9_transformer_objects), %s, %d captions per batch per GPU, up to 100 '
-                               'steps, encoders included; replicas only (each rank decodes its own images)'
-                               % ('beam %d' % beam if beam > 1 else 'greedy (sampling_topk 1, as the reference)', B),
+                               'steps, encoders included%s; replicas only (each rank decodes its own images)'
+                               % ('beam %d' % beam if beam > 1 else 'greedy (sampling_topk 1, as the reference)', B,
+                                  ' (batch N+1 encoded underneath the decode loop of batch N: generate_stream)'
+                                  if pipelined else ''),
                    'global_batch': world * B, 'article_len': 512, 'decode_steps': int(n_steps),
                    'parallelism': 'replicas x%d' % world},
         'roofline': {'bound': 'hbm', 'kernel': 'captured decode step (one hipGraph replay per generated token)',
@@ -712,6 +734,8 @@ def main():
     ap.add_argument('--no-loader', action='store_true',
                     help='skip the data-plane leg (shards on tmpfs -> reader -> iterator -> collate -> training step)')
     ap.add_argument('--beam', type=int, default=4, help='beam size of --generate (1 = greedy, what the reference does)')
+    ap.add_argument('--gen-serial', action='store_true', help='--generate: encoders, then the decode loop, batch after '
+                    'batch (the round-4 flow) instead of the pipelined test-set loop')
     ap.add_argument('--roofline-steps', type=int, default=3,
                     help='extra single-stream steps after the timed region that time the GEMM kernels in isolation')
     ap.add_argument('--hog-child', type=int, default=0, help=argparse.SUPPRESS)
@@ -791,12 +815,16 @@ def main():
             tell_amd.ops.clear_weight_cache()
             torch.cuda.empty_cache()
             result['generation'] = {}
-            for beam in (4, 1):
+            # (the reference's validation_iterator has batch_size 16; the batch is the iterator's knob, not the model's:
+            #  32 = the figure every round has reported, 128 = the size this GPU's 288 GB are for)
+            for beam, gb in ((4, 32), (1, 32), (4, 128), (1, 128)):
                 ga = argparse.Namespace(**vars(args))
-                ga.batch, ga.beam, ga.steps, ga.warmup = 32, beam, 3, 2
+                ga.batch, ga.beam, ga.steps, ga.warmup = gb, beam, (4 if gb == 32 else 3), 2
                 g = generate_bench(ga, dev, world, rank, dist)
-                result['generation']['beam%d' % beam if beam > 1 else 'greedy'] = {
+                key = ('beam%d' % beam if beam > 1 else 'greedy') + ('' if gb == 32 else '_b%d' % gb)
+                result['generation'][key] = {
                     'workload': g['config']['workload'], 'value': g['value'], 'unit': g['unit'],
+                    'serial_value': g['serial_value'],
                     'ms_per_batch': g['ms_per_step'], 'steps': g['steps'], 'warmup': g['warmup'],
                     'decode_steps': g['config']['decode_steps'], 'roofline': g['roofline']}
                 gc.collect()

@@ -80,3 +80,31 @@ def test_shards_to_training_steps_and_evaluation_tail(tmp_path):
     assert model.evaluate_mode is True
     with pytest.raises(AssertionError):            # the reference refuses to append to an existing generations file
         evaluate(model, reader._read('test'), it, DEV, out_dir, eval_suffix='_t')
+
+
+@pytest.mark.parametrize('beam', [1, 3])
+def test_generate_stream_equals_batch_by_batch_generation(beam):
+    """The pipelined test-set loop (encoders of batch N+1 on their own streams underneath the decode loop of batch N)
+    yields, batch for batch, the ids and log-probabilities of `generate` called on that batch alone - bit for bit: the
+    encoders read nothing the decode loop writes, and a batch's encoder outputs live in their own buffer set."""
+    import tell_amd
+    from tell_amd.build import build_model
+    from tell_amd.data import synthetic_batch
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(0)
+        model = build_model('faces_objects', _Res(True), _Rob(1024), n_bert_layers=3, **KW).to(DEV).eval()
+        batches = [synthetic_batch(4, 24 + 8 * (i % 2), 9, True, seed=11 + i, device=DEV, vocab=600, cutoffs=(100, 300)) for i in range(5)]
+
+        def clone(b):
+            return {k: (dict(v) if isinstance(v, dict) else v.clone()) for k, v in b.items()}
+        alone = [model.generate(**clone(b), beam_size=beam) for b in batches]
+        torch.cuda.synchronize()
+        seen = 0
+        for i, (b, out) in enumerate(model.generate_stream((clone(b) for b in batches), beam_size=beam)):
+            assert torch.equal(out['gen_ids'], alone[i]['gen_ids'])
+            assert torch.equal(out['log_probs'], alone[i]['log_probs'])
+            seen += 1
+        assert seen == len(batches)
+    finally:
+        tell_amd.set_compute_dtype(torch.float32)

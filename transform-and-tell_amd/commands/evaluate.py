@@ -64,8 +64,12 @@ def evaluate(model, instances, data_iterator, cuda_device, serialization_dir, ev
         model.evaluate_mode = True
         model.eval_beam_size = beam_size
         loss_count, total_loss, total_weight = 0, 0.0, 0.0
-        for batch in data_iterator(instances, num_epochs=1, shuffle=False, device=device):
-            output_dict = model(**batch)
+        batches = data_iterator(instances, num_epochs=1, shuffle=False, device=device)
+        if hasattr(model, 'generate_stream'):         # encoders of batch N+1 underneath the decode loop of batch N
+            outputs = (out for _, out in model.generate_stream(batches, forward=True))
+        else:
+            outputs = (model(**batch) for batch in batches)
+        for output_dict in outputs:
             loss = output_dict.get('loss')
             write_to_json(output_dict, serialization_dir, eval_suffix, annotate)
             if loss is not None:

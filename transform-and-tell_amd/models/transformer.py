@@ -312,10 +312,47 @@ class CaptionModel(Model):
         return ' '.join(str(int(i)) for i in ids if int(i) != 2)
 
     def generate(self, context, image, caption, face_embeds=None, obj_embeds=None, metadata=None, names=None,
-                 attn_idx=None, beam_size=1):
-        caption_ids, _, contexts = self._forward(context, image, caption, face_embeds, obj_embeds)
+                 attn_idx=None, beam_size=1, encoded=None):
+        """encoded: optional EncodedBatch of THIS batch produced earlier by `encode(..., ahead=True)`."""
+        caption_ids, _, contexts = self._forward(context, image, caption, face_embeds, obj_embeds, encoded)
         log_probs, gen_ids, attns = self._generate(caption_ids, contexts, attn_idx, beam_size=beam_size)
         return {'gen_ids': gen_ids, 'log_probs': log_probs, 'attns': attns}
+
+    def generate_stream(self, batches, beam_size=1, forward=False):
+        """Captions for a sequence of batches (the test-set loop of tell/commands/evaluate.py:118-160) with the frozen
+        encoders of batch N+1 launched on their own streams BEFORE the decode loop of batch N is issued - the trainer's
+        schedule applied to generation.  Numerics are those of `generate` / `forward` batch by batch: the encoders read
+        nothing the decode loop writes, and consecutive batches' encoder outputs live in different buffer sets.
+
+        MEASURED (MI355X, full model, 32 captions x 100 steps): 534 -> 544 captions/s greedy, 375 -> 381 beam 4 - not the
+        25 % the two legs' sum promises.  A decode step is ~44 dependent launches of 5-20 us whose workgroups fill the
+        chip for one round each; every one of them queues behind a wave of 100-us GEMM workgroups of the encoders, so
+        the two mostly take turns.  Giving the decode chain compute units of its own (hipExtStreamCreateWithCUMask
+        streams - hipGraph replays launched on them DO keep the mask, tools/probes/cumask_probe.hip) was built and
+        measured: 64 / 128 CUs for the chain -> 260 / 416 captions/s - the chain's kernels are one round of
+        latency-bound workgroups on 256 CUs and become two / four rounds on fewer (profiles/r05_cu_partition.txt); not
+        kept.  What moves generation throughput is the batch (the iterator's knob): 544 / 747 / 939 captions/s greedy at
+        32 / 64 / 128 captions per batch.
+
+        batches: any iterable of batch dicts (keys of `forward`); forward=True yields `self(**batch)` (evaluate mode:
+        loss + generation + metrics) instead of `generate(**batch)`.  Yields (batch, output_dict) in order."""
+        it = iter(batches)
+        cur = next(it, None)
+        enc = None
+        while cur is not None:
+            nxt = next(it, None)
+            ahead = None
+            can = hasattr(self, 'encode') and torch.is_tensor(cur.get('image')) and cur['image'].is_cuda
+            if can and enc is None:
+                enc = self.encode(cur['context'], cur['image'])
+            if can and nxt is not None:
+                ahead = self.encode(nxt['context'], nxt['image'], ahead=True)
+            if enc is not None and enc.stale():
+                enc = self.encode(cur['context'], cur['image'])
+            extra = {'encoded': enc} if enc is not None else {}
+            out = self(**cur, **extra) if forward else self.generate(**cur, beam_size=beam_size, **extra)
+            yield cur, out
+            cur, enc = nxt, ahead
 
     # ---- :399-494 -----------------------------------------------------------------
     fast_generation = True      # projected-K/V cache + static batch; False = the reference's control flow
