@@ -128,4 +128,6 @@ int launch_gemm_pp2(const GemmArgs& a, hipStream_t stream, int n_cu);
 int launch_gemm_q4(const GemmArgs& a, hipStream_t stream, int n_cu);
 // gemm_q4e.hip: the same K loop with the previous tile's epilogue inside it (-> 1: not a call it takes)
 int launch_gemm_q4e(const GemmArgs& a, hipStream_t stream, int n_cu);
+// gemm_s64.hip: 64x64 tiles with the one-wave-per-SIMD K loop (plain NT GEMM or implicit convolution; -> 1: not a call it takes)
+int launch_gemm_s64(const GemmArgs& a, hipStream_t stream, int out_f32);
 int* gemm_tile_queue_slot(int words, hipStream_t stream);    // gemm.hip: `words` zeroed tile counters for one launch, or NULL
