@@ -35,10 +35,15 @@
 
 namespace {
 typedef __attribute__((address_space(3))) void* s64_lds_ptr_t;
-constexpr int S_STAGE = 16384, S_HALF = 8192, S_NS = 4;
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for_tail(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for_tail<I + 1, N>(f); }
+}
+constexpr int S_STAGE = 16384, S_HALF = 8192;
 constexpr unsigned S_OOB = 0x80000000u;            // >= num_records: the buffer unit returns zeros
 
-template <typename OutT, bool CONV>
+// S_NS: stages of the ring (S_NS - 1 K tiles in flight); 4 = 64 KB of LDS, two workgroups per CU
+template <typename OutT, bool CONV, int S_NS>
 __global__ __launch_bounds__(256) void gemm_nt_s64_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[S_NS * S_STAGE];
   gemm_ts_enter(p);
@@ -143,12 +148,13 @@ __global__ __launch_bounds__(256) void gemm_nt_s64_kernel(GemmArgs p) {
     ++nt;
   };
 
-  issue(0); issue(1); issue(2);
+#pragma unroll
+  for (int st = 0; st < S_NS - 1; ++st) issue(st);
 
   // one K tile, stage ST (compile time: every ds_read is `launch-constant VGPR + immediate`)
   auto step = [&](auto st_tag) __attribute__((always_inline)) {
     constexpr int ST = decltype(st_tag)::value;
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // this wave's pieces of the tile have landed (2 younger tiles in flight)
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((S_NS - 2) * 4) : "memory");   // this wave's pieces of the tile have landed (S_NS - 2 younger tiles in flight)
     __builtin_amdgcn_s_barrier();                        // everyone's have, and everyone is done with the stage issued into below
     asm volatile("" ::: "memory");
     const unsigned char* ts = smem + ST * S_STAGE;
@@ -158,25 +164,36 @@ __global__ __launch_bounds__(256) void gemm_nt_s64_kernel(GemmArgs p) {
       fa[ks] = *reinterpret_cast<const bf16x8*>(ts + a_fo[ks]);
       fb[ks] = *reinterpret_cast<const bf16x8*>(ts + b_fo[ks]);
     }
-    issue((ST + 3) & 3);
+    issue((ST + S_NS - 1) % S_NS);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)                        // (the order of the general body: bit-identical sums)
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks], fa[ks], acc[0][0], 0, 0, 0);
   };
   int kt = 0;
-  for (; kt + 4 <= nk; kt += 4) {
-    step(std::integral_constant<int, 0>{});
-    step(std::integral_constant<int, 1>{});
-    step(std::integral_constant<int, 2>{});
-    step(std::integral_constant<int, 3>{});
+  if constexpr (S_NS == 4) {
+    for (; kt + 4 <= nk; kt += 4) {
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{});
+    }
+  } else {
+    for (; kt + 8 <= nk; kt += 8) {
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{});
+      step(std::integral_constant<int, 4>{});
+      step(std::integral_constant<int, 5>{});
+      step(std::integral_constant<int, 6>{});
+      step(std::integral_constant<int, 7>{});
+    }
   }
-  if (kt < nk) { step(std::integral_constant<int, 0>{}); ++kt; }
-  if (kt < nk) { step(std::integral_constant<int, 1>{}); ++kt; }
-  if (kt < nk) { step(std::integral_constant<int, 2>{}); ++kt; }
+  static_for_tail<0, S_NS - 1>([&](auto tag) { if (kt < nk) { step(tag); ++kt; } });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the trailing num_records = 0 loads still write their zeros)
   __syncthreads();                                       // every wave is done with the stages: they become the staging area
 
-  gemm_nt_glds_epilogue<OutT, 64, 64, 2, 2, CONV, S_NS>(acc, p, smem, m0, n0, tm, wm, wn, lane, tid, M, N);
+  gemm_nt_glds_epilogue<OutT, 64, 64, 2, 2, CONV, 4>(acc, p, smem, m0, n0, tm, wm, wn, lane, tid, M, N);
 }
 }  // namespace
 
@@ -195,8 +212,10 @@ static int launch_s64(const GemmArgs& a, hipStream_t stream) {
   const long tiles = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
   if (tiles > (1L << 30)) return 1;
   const dim3 grid((unsigned)tiles), block(256);
-  if (conv) hipLaunchKernelGGL((gemm_nt_s64_kernel<OutT, true>), grid, block, 0, stream, a);
-  else hipLaunchKernelGGL((gemm_nt_s64_kernel<OutT, false>), grid, block, 0, stream, a);
+  // (an 8-stage instantiation - 128 KB, seven K tiles in flight - for launches of at most one workgroup per CU, the decoder's
+  //  1024 x 1024 outputs whose weights come from HBM: decoder half 6.655 -> 6.650 ms, 15.1 -> 15.2 us per launch; not kept)
+  if (conv) hipLaunchKernelGGL((gemm_nt_s64_kernel<OutT, true, 4>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((gemm_nt_s64_kernel<OutT, false, 4>), grid, block, 0, stream, a);
   return tell_check_launch("gemm_nt_s64");
 }
 int launch_gemm_s64(const GemmArgs& a, hipStream_t stream, int out_f32) {
