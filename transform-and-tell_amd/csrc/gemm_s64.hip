@@ -26,6 +26,8 @@
 // (1152) 20.5 -> 17.0, layer3 conv1 (1024) 9.1 -> 8.2; decoder q / out / linear2 (1024^3) 7.8 -> 5.7, tap logits 7.9 ->
 // 5.7.  Short reductions lose (K = 128 / 256: 13.5 -> 18.9, 10.4 -> 13.0 - 64 KB of LDS is two workgroups per CU where
 // the 2-stage body fits five, and there the launch is prologue + epilogue): the callers take this kernel from K = 1024.
+// (A 2-stage instantiation - 32 KB, five workgroups per CU - for K < 1024 ties the general body there: K = 256 10.0 against
+// 10.1 us, 128: 13.4 / 13.1, 512: 9.7 / 9.2, 576: 16.3 / 20.3; ResNet-152 4.32 against 4.30 ms with it; not kept.)
 // (A variant in which the waves split the K TILE instead of the output tile - four independent accumulators, half the
 // fragment reads, partial tiles folded through LDS - measured the same or slower, 14.7 / 17.2 / 10.2 us on the first
 // three shapes, and changes the summation order; not kept.)
