@@ -188,6 +188,53 @@ def head_step(x2, cutoffs, emb0, class_proj, tails, topk=0):
     return token, token_lp, None
 
 
+def attn_decode_usable(mods, kv_layer, names, q):
+    """tell_attn_decode takes: bf16, one query position per row, 64-wide heads, the learned bias row + the zero row,
+    at most 4 contexts of at most 2048 cached keys."""
+    if not (q.is_cuda and q.dtype == torch.bfloat16 and 1 <= len(mods) <= 4):
+        return False
+    for m, nm in zip(mods, names):
+        k = kv_layer[nm][0]
+        if m.head_dim != 64 or m.bias_k is None or not m.add_zero_attn or k.shape[0] > 2048 or k.dtype != torch.bfloat16:
+            return False
+        if k.shape[0] > 0 and (k.stride(2) != 1 or kv_layer[nm][1].stride(2) != 1 or q.shape[-2] % k.shape[1] != 0):
+            return False
+    return True
+
+
+def attn_decode_all(mods, names, qs, kv_layer, contexts, M, E):
+    """The n one-query context attentions of a layer against the projected K / V cache as ONE launch (multi_head.py:376-475
+    at Tq = 1): qs[i] [M, E] bf16 (projected, scaled) -> [n, M, E] bf16.  The `beams` hypotheses of a sample (rows
+    b * beams + j) share its cache: beams = M // (cached batch)."""
+    n = len(mods)
+    dev = qs[0].device
+    a_all = torch.empty(n, M, E, dtype=torch.bfloat16, device=dev)
+    ks, vs, k_ss, k_sb, v_ss, v_sb, masks, S, bk, bv = [], [], [], [], [], [], [], [], [], []
+    beams = 1
+    for i, (nm, m) in enumerate(zip(names, mods)):
+        k, v = kv_layer[nm]
+        if k.shape[0] == 0:                                     # empty context: bias and zero rows only
+            ks.append(qs[i]); vs.append(qs[i]); masks.append(None)
+            k_ss.append(0); k_sb.append(0); v_ss.append(0); v_sb.append(0); S.append(0)
+        else:
+            assert k.stride(2) == 1 and v.stride(2) == 1 and M % k.shape[1] == 0
+            beams = M // k.shape[1]
+            ks.append(k); vs.append(v)
+            k_ss.append(k.stride(0)); k_sb.append(k.stride(1)); v_ss.append(v.stride(0)); v_sb.append(v.stride(1))
+            S.append(k.shape[0])
+            mk = contexts.get(nm + '_mask')
+            if mk is not None and mk.dtype != torch.uint8:
+                mk = mk.to(torch.uint8)
+            masks.append(mk.contiguous() if mk is not None else None)
+        bk.append(ops._bias_row(m.bias_k, torch.bfloat16))
+        bv.append(ops._bias_row(m.bias_v, torch.bfloat16))
+    q_sb = [int(q.stride(-2)) for q in qs]
+    call('tell_attn_decode', n, _ptrs(qs), _longs(q_sb), _ptrs(ks), _longs(k_ss), _longs(k_sb), _ptrs(vs), _longs(v_ss),
+         _longs(v_sb), _ptrs(masks), _ptrs(bk), _ptrs(bv), 1, _ints(S), _ptrs([a_all[i] for i in range(n)]), _longs([E] * n),
+         M, mods[0].num_heads, beams)
+    return a_all
+
+
 def decoder_step(dec, X, contexts, state, kv_cache):
     """X [1, M, E] bf16 (embedded tokens of this step) -> [1, M, E] bf16 after all layers; the DynamicConv input
     buffers in `state` are shifted in place."""
@@ -248,29 +295,7 @@ def decoder_step(dec, X, contexts, state, kv_cache):
         else:
             _skinny([raw3] * n, E, wq, bq, [q_all[i] for i in range(n)], E, M, E, E, pro=1, gammas=[ln3.weight],
                     betas=[ln3.bias], eps=ln3.eps, stats_out=st3, scale=mods[0].scaling)
-        a_all = torch.empty(n, M, E, **bf)
-        ks, vs, k_ss, k_sb, v_ss, v_sb, masks, S, bk, bv = [], [], [], [], [], [], [], [], [], []
-        beams = 1
-        for i, (nm, m) in enumerate(zip(names, mods)):
-            k, v = kv_cache[li][nm]
-            if k.shape[0] == 0:                                     # empty context: bias and zero rows only
-                ks.append(q_all[i]); vs.append(q_all[i]); masks.append(None)
-                k_ss.append(0); k_sb.append(0); v_ss.append(0); v_sb.append(0); S.append(0)
-            else:
-                assert k.stride(2) == 1 and v.stride(2) == 1 and M % k.shape[1] == 0
-                beams = M // k.shape[1]
-                ks.append(k); vs.append(v)
-                k_ss.append(k.stride(0)); k_sb.append(k.stride(1)); v_ss.append(v.stride(0)); v_sb.append(v.stride(1))
-                S.append(k.shape[0])
-                mk = contexts.get(nm + '_mask')
-                if mk is not None and mk.dtype != torch.uint8:
-                    mk = mk.to(torch.uint8)
-                masks.append(mk.contiguous() if mk is not None else None)
-            bk.append(ops._bias_row(m.bias_k, torch.bfloat16))
-            bv.append(ops._bias_row(m.bias_v, torch.bfloat16))
-        call('tell_attn_decode', n, _ptrs([q_all[i] for i in range(n)]), _longs([E] * n), _ptrs(ks), _longs(k_ss),
-             _longs(k_sb), _ptrs(vs), _longs(v_ss), _longs(v_sb), _ptrs(masks), _ptrs(bk), _ptrs(bv), 1, _ints(S),
-             _ptrs([a_all[i] for i in range(n)]), _longs([E] * n), M, mods[0].num_heads, beams)
+        a_all = attn_decode_all(mods, names, [q_all[i] for i in range(n)], kv_cache[li], contexts, M, E)
         raw6 = torch.empty(M, n * E, **f32)
         raw6_bf = torch.empty(M, n * E, **bf) if fold else None     # (problem i's copy lands at columns i E ..: out2_prob)
         _skinny([a_all[i] for i in range(n)], E, [ops.weight(m.out_proj.weight) for m in mods],

@@ -117,9 +117,20 @@ class DynamicConvDecoderLayer(DecoderLayer):
             # time is the kernel's fixed latency, not its work.)
             mods = [self.context_attns[n] for n in self.context_names]
             qs = ops.grouped_linear([handles[i] for i in range(nctx)], [m.q_spec() for m in mods])
-            cores = [m.core(q, contexts[n], contexts[n + '_mask'], None if kv is None else kv[n],
-                            None if kv_packed is None else kv_packed.get(n))
-                     for m, q, n in zip(mods, qs, self.context_names)]
+            cores = None
+            if kv is not None and not tr and X.shape[0] == 1 and torch.is_tensor(qs[0]) and qs[0].is_contiguous():
+                # one generated token against the projected K / V cache, layer-by-layer step (more rows than the fused
+                # step of decode.py takes): the n attention cores as ONE launch of the decode kernel instead of n launches
+                # of the training kernel with one real query row each (+ a strided copy per context under beam search)
+                from .. import decode as _dec
+                q2 = [q.reshape(q.shape[1], q.shape[2]) for q in qs]
+                if _dec.attn_decode_usable(mods, kv, self.context_names, q2[0]):
+                    a_all = _dec.attn_decode_all(mods, self.context_names, q2, kv, contexts, q2[0].shape[0], q2[0].shape[1])
+                    cores = [a_all[i].unsqueeze(0) for i in range(nctx)]
+            if cores is None:
+                cores = [m.core(q, contexts[n], contexts[n + '_mask'], None if kv is None else kv[n],
+                                None if kv_packed is None else kv_packed.get(n))
+                         for m, q, n in zip(mods, qs, self.context_names)]
             outs = ops.grouped_linear(cores, [m.out_spec() for m in mods])
         for i, name in enumerate(() if grouped else self.context_names):  # :271-352
             a, w = self.context_attns[name](
