@@ -638,6 +638,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecArgs g) {
   // AD_G key groups (of 32 keys: 8 per wave) per trip - their loads fly together.  (Round 5 measured 8 groups per trip
   // and the first trip of values requested ahead of the softmax: greedy step 492.7 -> 494.5 us, beam 4 743 -> 822 us -
   // at 4 hypotheses per workgroup the 200 registers it takes halve the occupancy; 4 groups stay.)
+  // (Round 5, second half: the score rows as dynamic LDS sized by the launch's longest context - 8 KB instead of 33 KB at four
+  //  hypotheses and S = 512 - measured: greedy step 457.8 -> 457.3 us, beam 4 708.6 -> 714.7, 512 rows 1384 -> 1397 us; the
+  //  LDS is not what bounds the resident workgroups; static arrays stay.)
   constexpr int AD_G = 4;
   for (int s0 = wave * 8; s0 < S8; s0 += 32 * AD_G) {
     uint4 kr[AD_G];
