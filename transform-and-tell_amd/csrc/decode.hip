@@ -640,7 +640,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecArgs g) {
   // at 4 hypotheses per workgroup the 200 registers it takes halve the occupancy; 4 groups stay.)
   // (Round 5, second half: the score rows as dynamic LDS sized by the launch's longest context - 8 KB instead of 33 KB at four
   //  hypotheses and S = 512 - measured: greedy step 457.8 -> 457.3 us, beam 4 708.6 -> 714.7, 512 rows 1384 -> 1397 us; the
-  //  LDS is not what bounds the resident workgroups; static arrays stay.)
+  //  LDS is not what bounds the resident workgroups; static arrays stay.  What does: 68 / 88 / 128 VGPRs at 1 / 2 / 4 hypotheses =
+  //  7 / 5 / 4 workgroups per CU - the four-hypothesis form reads the cache at 2.7 TB/s where the one-hypothesis form reaches
+  //  4.6; capping it at 96 / 80 registers (amdgpu_waves_per_eu 5 / 6) spills 42 / 78 of them.)
   constexpr int AD_G = 4;
   for (int s0 = wave * 8; s0 < S8; s0 += 32 * AD_G) {
     uint4 kr[AD_G];
