@@ -471,6 +471,57 @@ def test_fused_decode_step_matches_layer_by_layer_step_and_fp32(kind, beams):
         assert torch.equal(r, r[:, :1].expand_as(r))
 
 
+def test_layer_by_layer_decode_step_above_128_rows_matches_fp32():
+    """More than 128 rows (batch x beam) take the layer-by-layer step (decode.MAX_ROWS): the training GEMM kernels for the
+    linears, and - since round 5 - the decode kernels for the DynamicConv step (tell_dynconv_step) and the n context
+    attentions (one tell_attn_decode launch).  192 rows = 4 samples x 48 hypotheses against the fp32 full-sequence decoder,
+    teacher-forced; the hypotheses of a sample see identical tokens and must agree bit for bit."""
+    import tell_amd
+    from tell_amd import decode
+    from tell_amd.build import build_decoder
+    kind, beams, STEPS = 'faces_objects', 48, 6
+    o = _oracle(kind)
+    ctx, ids, _ = o['inputs']
+    seq = ids[:, :STEPS].to(DEV)
+    tell_amd.set_compute_dtype(torch.float32)
+    dec32 = build_decoder(kind)
+    dec32.load_state_dict(o['sd'])
+    dec32.to(DEV).eval()
+    with torch.no_grad():
+        want = dec32({'roberta': seq}, _to_dev(ctx, torch.float32))[0].float()            # [B, STEPS, E]
+    del dec32
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    dec = build_decoder(kind)
+    dec.load_state_dict(o['sd'])
+    dec.to(DEV).eval()
+    dctx = _to_dev(ctx, torch.bfloat16)
+    names = []
+    with torch.no_grad():
+        kv = dec.project_contexts(dctx)
+        state = dec.static_incremental_state(B * beams, DEV, torch.bfloat16)
+        assert not decode.usable(dec, torch.empty(1, B * beams, 1024, dtype=torch.bfloat16, device=DEV), state, kv)
+        xs = []
+        for i in range(STEPS):
+            cur = seq[:, i:i + 1].repeat_interleave(beams, dim=0).contiguous()
+            if i == 1:                                      # which kernels a step launches (torch.profiler / roctracer)
+                from torch.profiler import ProfilerActivity, profile
+                with profile(activities=[ProfilerActivity.CUDA]) as pf:
+                    xs.append(dec({'roberta': cur}, dctx, incremental_state=state, kv_cache=kv)[0][:, 0].float())
+                    torch.cuda.synchronize()
+                names = [e.name for e in pf.events()]
+            else:
+                xs.append(dec({'roberta': cur}, dctx, incremental_state=state, kv_cache=kv)[0][:, 0].float())
+        out = torch.stack(xs, 1)                                                           # [B*beams, STEPS, E]
+    w = want.repeat_interleave(beams, dim=0)
+    err = _rel(out, w)
+    print('\ndecode step at %d rows (layer by layer + decode kernels) vs fp32: %.3e' % (B * beams, err))
+    assert err < BF16_OUT, err
+    r = out.view(B, beams, STEPS, -1)
+    assert torch.equal(r, r[:, :1].expand_as(r))
+    joined = ' '.join(names)
+    assert 'dynconv_step_kernel' in joined and 'attn_decode_kernel' in joined, joined
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # The shapes bench.py times, through the captured step graph.
 # B = 4 above runs the per-token GEMMs at M = 128 rows (register-staged 64x64 kernel); at B = 32 / 16 they have
