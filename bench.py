@@ -544,6 +544,8 @@ def loader_bench(args, dev, n_batches=12, warm=4, variable=False):
         th.start()
         host_ms, issue_ms, n_done, t_start = [], [], 0, None
         marks = []                                     # (steps done, wall clock) at every epoch end (variable leg)
+        tok = [0, 0]                                   # padded article / caption tokens of the steps done so far
+        tok_marks, tok_start = [], (0, 0)
 
         def fetch():
             while True:
@@ -551,6 +553,7 @@ def loader_bench(args, dev, n_batches=12, warm=4, variable=False):
                 if isinstance(g_, str):                # epoch boundary
                     torch.cuda.synchronize()
                     marks.append((n_done + 1, time.perf_counter()))
+                    tok_marks.append((tok[0] + int(cur['context']['roberta'].numel()), tok[1] + int(cur['caption']['roberta'].numel())))
                     continue
                 return g_
         cur = to_device(fetch(), dev)
@@ -561,12 +564,16 @@ def loader_bench(args, dev, n_batches=12, warm=4, variable=False):
                 nxt = to_device(group, dev) if group is not None else None
                 host_ms.append(1e3 * (time.perf_counter() - h0))
                 h1 = time.perf_counter()
+                n_art, n_cap = int(cur['context']['roberta'].numel()), int(cur['caption']['roberta'].numel())
                 trainer.train_one_batch(cur, next_batch=nxt)
                 issue_ms.append(1e3 * (time.perf_counter() - h1))
                 n_done += 1
+                tok[0] += n_art
+                tok[1] += n_cap
                 if n_done == warm:
                     torch.cuda.synchronize()
                     t_start = time.perf_counter()
+                    tok_start = (tok[0], tok[1])
                 cur = nxt
             torch.cuda.synchronize()
         elapsed = time.perf_counter() - t_start
@@ -586,6 +593,13 @@ def loader_bench(args, dev, n_batches=12, warm=4, variable=False):
                 (n1, t1), (n2, t2) = marks[-2], marks[-1]
                 extra['first_epochs_value'] = round(B * timed / elapsed, 2)
                 timed, elapsed = n2 - n1, t2 - t1
+                tok_start, tok = tok_marks[-2], list(tok_marks[-1])
+        # the WORK behind `value`: padded tokens per second through RoBERTa (article) and through the decoder (caption) - a
+        # variable-length leg is comparable with the fixed-shape one through these, not through samples/s
+        extra['article_tokens_per_s'] = round((tok[0] - tok_start[0]) / elapsed)
+        extra['caption_tokens_per_s'] = round((tok[1] - tok_start[1]) / elapsed)
+        extra['mean_article_len'] = round((tok[0] - tok_start[0]) / max(B * timed, 1), 1)
+        extra['mean_caption_len'] = round((tok[1] - tok_start[1]) / max(B * timed, 1), 1)
         return {**extra, 'value': round(B * timed / elapsed, 2), 'unit': 'samples/s', 'ms_per_step': round(1e3 * elapsed / timed, 3),
                 'batches': timed, 'host_ms_per_batch_on_the_training_thread': round(host[len(host) // 2], 2),
                 'step_issue_ms': round(sorted(issue_ms[-timed:])[timed // 2], 2),
