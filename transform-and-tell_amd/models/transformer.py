@@ -345,7 +345,7 @@ class CaptionModel(Model):
             can = hasattr(self, 'encode') and torch.is_tensor(cur.get('image')) and cur['image'].is_cuda
             if can and enc is None:
                 enc = self.encode(cur['context'], cur['image'])
-            if can and nxt is not None:
+            if can and nxt is not None and torch.is_tensor(nxt.get('image')) and nxt['image'].is_cuda:
                 ahead = self.encode(nxt['context'], nxt['image'], ahead=True)
             if enc is not None and enc.stale():
                 enc = self.encode(cur['context'], cur['image'])
