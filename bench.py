@@ -604,6 +604,10 @@ def loader_bench(args, dev, n_batches=12, warm=4, variable=False):
                 'batches': timed, 'host_ms_per_batch_on_the_training_thread': round(host[len(host) // 2], 2),
                 'step_issue_ms': round(sorted(issue_ms[-timed:])[timed // 2], 2),
                 'shard_mbytes': round(shard_mb, 1), 'shard_write_s': round(write_s, 1),
+                'window_note': 'the timed window starts at a synchronisation point, where the encoders of its first batch have '
+                               'already run (they are launched one step ahead), and the last batch has no successor to '
+                               'encode: %d decoder passes, %d encoder passes - this leg reads about 1/%d high against the '
+                               'headline, whose window holds as many encoder passes as steps' % (timed, timed - 1, timed),
                 'pipeline': 'npz shards on tmpfs -> nytimes_faces_ner_matched reader -> collate_host into pinned tensors '
                             '(background thread, one batch ahead) -> async H2D + tell_image_normalize -> '
                             'Trainer.train_one_batch(next_batch=...)'}
