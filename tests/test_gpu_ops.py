@@ -274,6 +274,66 @@ def test_gemm_q4_kernel(env):
             assert line and line[0].startswith('gemm_nt_q4_kernel'), (shape, line)
 
 
+def test_gemm_s64_kernel_is_bit_identical_to_the_general_body(monkeypatch):
+    """gemm_nt_s64_kernel (csrc/gemm_s64.hip: the 64x64 direct-to-LDS tile with a K loop written for one wave per SIMD;
+    taken from K = 1024 by the small-GEMM branch of tell_gemm_nt and by the implicit convolutions) against the general body
+    it replaces (TELL_GEMM_S64=0, read per launch): same tiles, same MFMA order -> the same bits.  Plain products with bias /
+    ReLU / ragged M and N / fp32 output / an accumulating epilogue, and the implicit 3x3 convolutions of ResNet layer3 /
+    layer4 (stride 1 and 2, padding ring = out-of-range buffer offsets) with their BatchNorm-statistics epilogue."""
+    from tell_amd import hip, ops
+    g = torch.Generator().manual_seed(11)
+
+    def both(fn):
+        monkeypatch.setenv('TELL_GEMM_S64', '0')
+        a = fn()
+        monkeypatch.setenv('TELL_GEMM_S64', '1')
+        b = fn()
+        torch.cuda.synchronize()
+        return a, b
+    for M, N, K, kw in ((1024, 1024, 1024, {}), (1024, 496, 1024, {}), (1000, 1000, 4096, dict(act=1)),
+                        (1536, 1024, 2048, dict(out_dtype=torch.float32)), (520, 72, 1088, {})):
+        x = (torch.randn(M, K, generator=g) * 0.5).bfloat16().to(DEV)
+        w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().to(DEV)
+        bias = torch.randn(N, generator=g).to(DEV)
+        out = torch.empty(M, N, dtype=kw.get('out_dtype', torch.bfloat16), device=DEV)
+        name = hip.query('tell_gemm_nt_plan', x, x.stride(0), w, w.stride(0), out, out.stride(0), M, N, K, hip.BF16,
+                         hip.dt(out), bias, 1, 0, None, 1.0, 0, None)
+        assert name.startswith('gemm_nt_s64_kernel'), (M, N, K, name)
+        a, b = both(lambda: ops.gemm(x, w, bias=bias, bias_mode=1, act=kw.get('act', 0),
+                                     **({'out_dtype': kw['out_dtype']} if 'out_dtype' in kw else {})).clone())
+        assert torch.equal(a, b), (M, N, K)
+        ref = torch.nn.functional.linear(x.float(), w.float(), bias)
+        if kw.get('act'):
+            ref = torch.relu(ref)
+        assert ((b.float() - ref).norm() / ref.norm()).item() < 6e-3
+    zero = torch.zeros(256, dtype=torch.uint8, device=DEV)
+    B = 4
+    for H, Cin, k, s, Cout in ((14, 256, 3, 1, 256), (28, 256, 3, 2, 256), (7, 512, 3, 1, 512), (14, 1024, 1, 1, 256)):
+        p = k // 2
+        OH = (H + 2 * p - k) // s + 1
+        M = B * OH * OH
+        x = torch.randn(B, H, H, Cin, generator=g).bfloat16().to(DEV)
+        w = (torch.randn(Cout, k * k * Cin, generator=g) * 0.05).bfloat16().to(DEV)
+        ws = torch.zeros(1 << 22, dtype=torch.float32, device=DEV)
+        gamma, beta = torch.rand(Cout, generator=g).to(DEV) + 0.5, torch.randn(Cout, generator=g).to(DEV)
+
+        def conv():
+            y = torch.empty(M, Cout, dtype=torch.bfloat16, device=DEV)
+            hip.call('tell_conv_bn_stats', x, w, y, B, H, H, Cin, k, k, s, p, OH, OH, Cout, 1e-5, 0.1, None, None, None, None,
+                     None, zero)                                                   # the convolution alone
+            z = torch.empty(M, Cout, dtype=torch.bfloat16, device=DEV)
+            rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+            hip.call('tell_conv_bn_act', x, w, z, B, H, H, Cin, k, k, s, p, OH, OH, Cout, 1e-5, 0.1, gamma, beta, rm, rv, None,
+                     1, ws, zero)                                                  # + statistics epilogue, BatchNorm, ReLU
+            return y, torch.cat([z.float().reshape(-1), rm, rv])
+        (ya, wa), (yb, wb) = both(conv)
+        assert torch.equal(ya, yb) and torch.equal(wa, wb), (H, Cin, k, s)
+        xr = x.float().permute(0, 3, 1, 2)
+        wr = w.float().view(Cout, k, k, Cin).permute(0, 3, 1, 2)
+        ref = torch.nn.functional.conv2d(xr, wr, stride=s, padding=p).permute(0, 2, 3, 1).reshape(M, Cout)
+        assert ((yb.float() - ref).norm() / ref.norm()).item() < 6e-3
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_lstm_cell_and_dot_attention_vs_torch(dtype):
     """csrc/lstm.hip against torch on CPU: nn.LSTMCell semantics from the two gate pre-activations, and the
