@@ -97,11 +97,6 @@ __global__ __launch_bounds__(256) void gemm_nt_s64_kernel(GemmArgs p) {
     rn = rn < N ? rn : N - 1;
     b_off[j] = (unsigned)rn * (unsigned)(p.ldb * 2) + (l16 & 7) * 16;
   }
-  const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)S_OOB, 0x00020000);
-  const __amdgpu_buffer_rsrc_t srd_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)S_OOB, 0x00020000);
-  const __amdgpu_buffer_rsrc_t nil_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t nil_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, 0, 0x00020000);
-
   // ---- fragment read offsets inside a stage: row r, 16-byte k-chunk c: (r>>1)*256 + ((((r&1)<<3)|c) ^ ((r>>1)&15))*16
   int a_fo[4], b_fo[4];                                        // one per 16-deep k-substep
   {
@@ -127,8 +122,10 @@ __global__ __launch_bounds__(256) void gemm_nt_s64_kernel(GemmArgs p) {
     const bool more = nt < nk;
     unsigned char* sa = smem + stage * S_STAGE + wave * 2048;
     unsigned char* sb = sa + S_HALF;
-    const __amdgpu_buffer_rsrc_t ra = more ? srd_a : nil_a;
-    const __amdgpu_buffer_rsrc_t rb = more ? srd_b : nil_b;
+    // (one scalar select - the num_records word - instead of two whole descriptors)
+    const int nrec = more ? (int)S_OOB : 0;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, nrec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, nrec, 0x00020000);
     if constexpr (CONV) {
       const int delta = (((tap_kh * p.conv_W + tap_kw) << (6 + p.conv_cshift)) + tap_c0) * 2;      // bytes, uniform
 #pragma unroll
