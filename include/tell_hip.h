@@ -10,12 +10,15 @@
  *
  * Conventions
  *   - plain pointers + sizes, no torch types; caller owns all memory; the library
- *     allocates nothing.  Its only state: a thread-local error string, four
- *     REGISTERED device pointers: two that kernels read while a hipGraph is recorded /
- *     replayed (tell_set_rng_step_ptr, tell_set_pos_step_ptr: the dropout step and
- *     decode position counters), the per-device tile-counter buffer of the resident GEMM
- *     launches (tell_gemm_set_tile_queue) and a thread-local one-shot hook that arms
- *     the next tell_gemm_nt launch with a span stamp (tell_gemm_ts_next);
+ *     allocates nothing.  Its state, all of it set through this header: a thread-local
+ *     error string; four REGISTERED device pointers - two that kernels read while a
+ *     hipGraph is recorded / replayed (tell_set_rng_step_ptr, tell_set_pos_step_ptr: the
+ *     dropout step and decode position counters), the per-device tile-counter buffer of
+ *     the resident GEMM launches (tell_gemm_set_tile_queue) and a thread-local one-shot
+ *     hook that arms the next tell_gemm_nt launch with a span stamp (tell_gemm_ts_next);
+ *     and the table of named integer OPTIONS below (tell_set_option), which is the only
+ *     way to steer a launcher's choice of kernel.  The library reads NO environment
+ *     variable;
  *   - every call is asynchronous on `stream` (pass torch's current stream);
  *   - return 0 on success, <0 on error (tell_last_error() explains);
  *   - `dtype`: TELL_F32 = 0 (exact-f32 parity mode, f32 MFMA), TELL_BF16 = 1;
@@ -41,6 +44,18 @@ typedef struct ihipStream_t* tell_stream_t; /* hipStream_t */
 
 /* ---- library ------------------------------------------------------------ */
 int tell_abi_version(void);
+/* Named run-time options (csrc/options.h lists keys and defaults: "gemm_q4", "q4_dynamic", "gemm_s64", "conv_tile", ...).
+ * Each is one process-global integer read by the launchers when a launch is ISSUED (a launch recorded into a hipGraph
+ * keeps the choice it was recorded with).  Every option selects between kernels that compute the SAME result (to the
+ * rounding the parity tests state); the wrong-result timing ablations of tools/probes/ exist only in the probe build
+ * (-DTELL_PROBES, libtell_hip_probes.so; tell_probe_build() = 1) - in the shipped library their keys are unknown.
+ * tell_set_option -> 0, or -1 for an unknown key (tell_last_error names it); tell_get_option -> the value, or LONG_MIN
+ * for an unknown key; tell_option_key(i) / tell_option_default(i) enumerate the table (NULL / LONG_MIN past its end). */
+int tell_set_option(const char* key, long value);
+long tell_get_option(const char* key);
+const char* tell_option_key(int index);
+long tell_option_default(int index);
+int tell_probe_build(void);
 int tell_device_count(void);
 const char* tell_last_error(void);
 void tell_set_error(const char* msg);

@@ -15,6 +15,23 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+@pytest.fixture(autouse=True)
+def _restore_library_options():
+    """A test that steers a launcher with tell_amd.hip.set_option leaves the defaults (or what TELL_<KEY> asked for at load
+    time) behind it."""
+    hip = sys.modules.get('tell_amd.hip')
+    before = None
+    if hip is not None and getattr(hip, '_lib', None) is not None:
+        before = {k: hip.get_option(k) for k in hip.option_keys()}
+    yield
+    hip = sys.modules.get('tell_amd.hip')
+    if hip is not None and getattr(hip, '_lib', None) is not None:
+        want = before if before is not None else hip.loaded_options()
+        for k, v in want.items():
+            if hip.get_option(k) != v:
+                hip.set_option(k, v)
+
+
 @pytest.fixture(scope='session')
 def golden():
     import seeded

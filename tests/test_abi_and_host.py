@@ -2,6 +2,7 @@
 host-side logic (schedules, flat-buffer layout, RNG restatement, config shim, registries)."""
 import ctypes
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -18,13 +19,62 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in protos if not hasattr(lib, n)]
     assert not missing, missing
     bound = tell_amd.hip.lib()                       # binds restype/argtypes for all of them
-    assert bound.tell_abi_version() == 1
+    assert bound.tell_abi_version() == 2
     assert bound.tell_opt_chunk() == 1024
     assert bound.tell_last_error() is not None
     for must in ['tell_gemm_nt', 'tell_attn_fwd', 'tell_attn_bwd', 'tell_dynconv_fwd', 'tell_dynconv_bwd',
                  'tell_layernorm_fwd', 'tell_ce_fwd', 'tell_adaptive_partition', 'tell_bertadam_step',
                  'tell_adaptive_logprob_argmax', 'tell_im2col', 'tell_bn_stats']:
         assert must in protos
+
+
+def test_library_options_are_explicit_and_the_ablations_are_not_in_the_shipped_library():
+    """include/tell_hip.h tell_set_option: the launchers' choices are named integers set through the ABI; the library reads
+    no environment variable (no getenv import, no TELL_* string), and the wrong-result timing ablations of tools/probes/
+    (csrc/options.h TELL_PROBE_LIST) are unknown keys in the shipped build - setting them is an error, not a switch."""
+    import re
+    import subprocess
+    import tell_amd
+    hip = tell_amd.hip
+    lib = hip.lib()
+    assert lib.tell_probe_build() == 0
+    keys = hip.option_keys()
+    assert len(keys) == len(set(keys)) >= 30 and {'gemm_q4', 'q4_dynamic', 'gemm_s64', 'conv_tile', 'dynconv_block'} <= set(keys)
+    # the table in the library is the table in csrc/options.h (keys and defaults)
+    src = open(os.path.join(ROOT, 'transform-and-tell_amd', 'csrc', 'options.h')).read()
+    shipped = src[src.index('#define TELL_OPTION_LIST'):src.index('#define TELL_PROBE_LIST')]
+    probes = src[src.index('#define TELL_PROBE_LIST'):src.index('enum TellOpt')]
+    decl = re.findall(r'X\(\w+, "(\w+)", (-?\d+)\)', shipped)
+    assert [k for k, _ in decl] == keys
+    assert {k: int(d) for k, d in decl} == hip.option_defaults()
+    probe_keys = [k for k, _ in re.findall(r'X\(\w+, "(\w+)", (-?\d+)\)', probes)]
+    assert {'q4_abl', 'pp2_abl', 'dcb_abl'} <= set(probe_keys)
+    for k in probe_keys + ['no_such_option']:
+        assert lib.tell_set_option(k.encode(), 1) == -1 and k.encode() in lib.tell_last_error()
+        assert lib.tell_get_option(k.encode()) == -(1 << 63)
+        with pytest.raises(KeyError):
+            hip.set_option(k, 1)
+    # round trip, context manager, the TELL_<KEY> spelling of the A/B scripts
+    before = hip.get_option('gemm_s64')
+    with hip.options(gemm_s64=2, conv_tile=3):
+        assert hip.get_option('gemm_s64') == 2 and hip.get_option('conv_tile') == 3
+    assert hip.get_option('gemm_s64') == before and hip.get_option('conv_tile') == hip.loaded_options()['conv_tile']
+    hip.apply_env({'TELL_GEMM_RING': '4', 'TELL_STEP_GRAPH': '0'})          # (the second is a host-side switch: ignored)
+    assert hip.get_option('gemm_ring') == 4
+    hip.apply_env({'TELL_GEMM_RING': None})
+    assert hip.get_option('gemm_ring') == hip.loaded_options()['gemm_ring']
+    # a fresh process translates TELL_<KEY> once, at load time
+    code = ('import sys; sys.path.insert(0, %r); import tell_amd; h = tell_amd.hip; h.lib(); '
+            'print(h.get_option("gemm_q4"), h.get_option("q4_dynamic"))' % ROOT)
+    env = dict(os.environ, TELL_GEMM_Q4='0', TELL_Q4_DYNAMIC='1', TELL_Q4_ABL='1')
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.split() == ['0', '1'], out.stdout + out.stderr
+    # the binary: no TELL_* string (<= 10 allowed: error texts), no getenv among the imported symbols
+    blob = open(hip.LIB_PATH, 'rb').read()
+    assert blob.count(b'TELL_') <= 10
+    nm = subprocess.run(['nm', '-D', '--undefined-only', hip.LIB_PATH], capture_output=True, text=True)
+    if nm.returncode == 0:
+        assert not [ln for ln in nm.stdout.splitlines() if re.search(r'\bgetenv\b', ln)], nm.stdout
 
 
 def test_product_fails_loudly_without_gpu():

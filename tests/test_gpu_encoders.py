@@ -317,7 +317,7 @@ def test_implicit_conv_path_equals_im2col_path_bf16(train, tile, monkeypatch):
     of any tile."""
     import tell_amd
     from tell_amd.models import resnet as R
-    monkeypatch.setenv('TELL_CONV_TILE', tile)       # 0: the launcher's own choice
+    tell_amd.hip.set_option('conv_tile', int(tile))       # 0: the launcher's own choice (conftest restores it)
     tell_amd.set_compute_dtype(torch.bfloat16)
     torch.manual_seed(2)
     a = R.ResNetFeatureExtractor((2, 1, 2, 1), width=64)

@@ -579,7 +579,7 @@ def test_bench_shape_step_through_the_step_graph_matches_oracle(kind, batch, dyn
     from tell_amd.training import Trainer
     fo = kind == 'faces_objects'
     if dyn:
-        monkeypatch.setenv('TELL_Q4_DYNAMIC', '1')
+        tell_amd.hip.set_option('q4_dynamic', 1)
     held0 = tell_amd.hip.tile_queue_stats() if torch.cuda.is_available() else None
     tell_amd.set_compute_dtype(torch.bfloat16)
     torch.manual_seed(0)

@@ -167,7 +167,7 @@ def test_gemm_pingpong_kernel(M, N, K):
                          x.shape[1], hip.BF16, hip.BF16, None, 0, 0, None, 1.0, 0, None)
     # (K a multiple of 128: the four-wave kernel of round 4, csrc/gemm_q4.hip; TELL_GEMM_Q4=0 / TELL_GEMM_PP2=0 select the others)
     assert plan(ad, bd, out) in ('gemm_nt_q4_kernel<bf16,256,256>', 'gemm_nt_pp2_kernel<bf16,256,256>', 'gemm_nt_pp_kernel<bf16,256,256>')
-    if K % 128 == 0 and not os.environ.get('TELL_GEMM_Q4'):
+    if K % 128 == 0 and hip.get_option('gemm_q4') == 1:
         assert plan(ad, bd, out) == 'gemm_nt_q4_kernel<bf16,256,256>'
     assert plan(ad[:M - 8], bd, out_small).startswith('gemm_nt_glds_kernel<bf16,')
 
@@ -250,8 +250,11 @@ def test_gemm_kernel_variants_behind_switches(env):
 
 @pytest.mark.parametrize('env', [{}, {'TELL_GEMM_TILE': '8'}, {'TELL_Q4_DYNAMIC': '1'}, {'TELL_GEMM_Q4E': '2'},
                                  {'TELL_GEMM_Q4E': '2', 'TELL_Q4_DYNAMIC': '1'}, {'TELL_GEMM_Q4E': '0', 'TELL_Q4_VAR': '1'},
-                                 {'TELL_GEMM_Q4E': '0', 'TELL_Q4_VAR': '2'}],
-                         ids=['default', 'partial-rounds', 'tile-queue', 'q4e-everywhere', 'q4e-tile-queue', 'schedule-1', 'schedule-2'])
+                                 {'TELL_GEMM_Q4E': '0', 'TELL_Q4_VAR': '2'},
+                                 # the wrong-result timing ablations are not in the shipped library: their names change nothing
+                                 {'TELL_Q4_ABL': '1', 'TELL_PP2_ABL': '1', 'TELL_DCB_ABL': '2', 'TELL_Q4E_VAR': '0'}],
+                         ids=['default', 'partial-rounds', 'tile-queue', 'q4e-everywhere', 'q4e-tile-queue', 'schedule-1', 'schedule-2',
+                              'ablation-names-inert'])
 def test_gemm_q4_kernel(env):
     """gemm_nt_q4_kernel (csrc/gemm_q4.hip: four waves of 128x128, hand-placed K loop - the default for whole rounds of
     256x256 bf16 tiles with K % 128 == 0) through tools/probes/q4_check.py: 2 to 64 K tiles (first / steady-state / last
@@ -277,17 +280,17 @@ def test_gemm_q4_kernel(env):
 def test_gemm_s64_kernel_is_bit_identical_to_the_general_body(monkeypatch):
     """gemm_nt_s64_kernel (csrc/gemm_s64.hip: the 64x64 direct-to-LDS tile with a K loop written for one wave per SIMD;
     taken from K = 1024 by the small-GEMM branch of tell_gemm_nt and by the implicit convolutions) against the general body
-    it replaces (TELL_GEMM_S64=0, read per launch): same tiles, same MFMA order -> the same bits.  Plain products with bias /
+    it replaces (option gemm_s64 = 0, read per launch): same tiles, same MFMA order -> the same bits.  Plain products with bias /
     ReLU / ragged M and N / fp32 output / an accumulating epilogue, and the implicit 3x3 convolutions of ResNet layer3 /
     layer4 (stride 1 and 2, padding ring = out-of-range buffer offsets) with their BatchNorm-statistics epilogue."""
     from tell_amd import hip, ops
     g = torch.Generator().manual_seed(11)
 
     def both(fn):
-        monkeypatch.setenv('TELL_GEMM_S64', '0')
-        a = fn()
-        monkeypatch.setenv('TELL_GEMM_S64', '1')
-        b = fn()
+        with hip.options(gemm_s64=0):
+            a = fn()
+        with hip.options(gemm_s64=1):
+            b = fn()
         torch.cuda.synchronize()
         return a, b
     for M, N, K, kw in ((1024, 1024, 1024, {}), (1024, 496, 1024, {}), (1000, 1000, 4096, dict(act=1)),

@@ -49,20 +49,19 @@ for name, H, Cin, k, s, Cout in shapes:
     def conv_only():      # statistics epilogue on (workspace given), the finish launch not issued: mean = None keeps it a plain launch
         hip.call('tell_conv_bn_stats', x, w, y, B, H, H, Cin, k, k, s, p, OH, OH, Cout, 1e-5, 0.1, None, None, None, None, None, zero)
     for tile, ring in COMBOS:
-        os.environ['TELL_CONV_TILE'] = tile
-        os.environ['TELL_GEMM_RING'] = ring
+        hip.apply_env({'TELL_CONV_TILE': tile, 'TELL_GEMM_RING': ring})
         out.append('%7.1f' % timed(conv_only))
-    del os.environ['TELL_CONV_TILE'], os.environ['TELL_GEMM_RING']
+    hip.apply_env({'TELL_CONV_TILE': None, 'TELL_GEMM_RING': None})
     conv_only(); torch.cuda.synchronize(); y_ref = y.clone()
     for mode in ('0', '2'):                   # gemm_s64.hip: 0 = never (the general body), 2 = always (default: from K = 1024)
-        os.environ['TELL_GEMM_S64'] = mode
+        hip.apply_env({'TELL_GEMM_S64': mode})
         t_s = timed(conv_only)
         y.zero_(); conv_only(); torch.cuda.synchronize()
         same = bool((y.float() - y_ref.float()).abs().max() <= 0.02 * y_ref.float().abs().max())
         tf_s = timed(lambda: hip.call('tell_conv_bn_act', x, w, y, B, H, H, Cin, k, k, s, p, OH, OH, Cout, 1e-5, 0.1, gamma, beta, rm,
                                       rv, None, 1, ws, zero))
         out.append('| s64/%s %6.1f (%s) +BN %6.1f' % (mode, t_s, 'ok' if same else 'DIFF', tf_s))
-    del os.environ['TELL_GEMM_S64']
+    hip.apply_env({'TELL_GEMM_S64': None})
     td = timed(conv_only)
     tf = timed(lambda: hip.call('tell_conv_bn_act', x, w, y, B, H, H, Cin, k, k, s, p, OH, OH, Cout, 1e-5, 0.1, gamma, beta, rm, rv,
                                 None, 1, ws, zero))

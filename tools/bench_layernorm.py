@@ -29,7 +29,7 @@ for rows in (16384, 1024):
     mean = torch.empty(rows, device='cuda'); rstd = torch.empty(rows, device='cuda')
     for p in (0.1, 0.0):
         for var in ('0', '1', '2'):
-            os.environ['TELL_LN_VAR'] = var
+            hip.apply_env({'TELL_LN_VAR': var})
             t = timed(lambda: hip.call('tell_layernorm_fwd', x, C, r, C, g, b, y, C, mean, rstd, rows, C, 1e-5, p, 1, 2, hip.BF16))
             print('rows %5d p=%.1f  TELL_LN_VAR=%s  %6.1f us  %5.2f TB/s' % (rows, p, var, t, 3 * rows * C * 2 / t * 1e-6))
-    del os.environ['TELL_LN_VAR']
+    hip.apply_env({'TELL_LN_VAR': None})

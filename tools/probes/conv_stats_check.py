@@ -12,7 +12,7 @@ cases = [(2, 14, 14, 256, 3, 1, 256), (32, 14, 14, 256, 3, 1, 256), (32, 14, 14,
 for rep in range(3):
     for (B, H, W, Cin, k, s, Cout) in cases:
         for tile in ('1', '2', '3'):
-            os.environ['TELL_CONV_TILE'] = tile
+            hip.apply_env({'TELL_CONV_TILE': tile})
             p = k // 2
             OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
             x = (torch.randn(B, H, W, Cin, device='cuda') + 0.3 * rep).bfloat16()

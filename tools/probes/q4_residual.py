@@ -34,7 +34,7 @@ for name, N, K in (('out', 1024, 1024), ('fc2', 1024, 4096)):
     for cname, env in (('plain q4', {'TELL_GEMM_Q4': '1'}), ('res q4', {'TELL_GEMM_Q4': '1'}), ('res pp2', {'TELL_GEMM_Q4': '0'})):
         if len(sys.argv) > 1 and cname not in sys.argv[1:]:
             continue
-        os.environ.update(env)
+        hip.apply_env(env)
         if cname == 'plain q4':
             fn = lambda a=a, w=w, bias=bias, y=y: ops.gemm(a, w, out=y, bias=bias, bias_mode=1)
         else:

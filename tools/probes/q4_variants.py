@@ -1,8 +1,11 @@
 """gemm_nt_q4_kernel: schedule variants / ablations / the ping-pong kernel INTERLEAVED inside one process (same box, same
 thermal state: separate processes differ by +-5 % on this pool), and the kernel's own s_memtime stamps per output tile.
   python tools/probes/q4_variants.py [rounds]
-Configurations are environment settings the library reads per launch (csrc/gemm_q4.hip, csrc/gemm.hip)."""
+Configurations are library options (tell_set_option, given here in their TELL_<KEY> spelling) read per launch (csrc/gemm_q4.hip, csrc/gemm.hip)."""
 import os, statistics, sys, torch
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the ablations (TELL_Q4_ABL, TELL_Q4E_VAR) exist only in the probe build: PROBES=1 transform-and-tell_amd/csrc/build.sh
+os.environ.setdefault('TELL_LIB', os.path.join(_ROOT, 'transform-and-tell_amd', 'csrc', 'libtell_hip_probes.so'))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import tell_amd
 from tell_amd import hip, ops
@@ -20,8 +23,7 @@ if os.environ.get('Q4_ABLS', '1') != '0':
 
 
 def setenv(env):
-    for k, v in env.items():
-        os.environ[k] = v
+    hip.apply_env(env)
 
 
 def graph_of(fn):
@@ -91,7 +93,7 @@ for name, N, K, act in SHAPES:
     live = d[:, 0, 0] != 0
     span = (d[live, nt - 1, 4].max() - d[live, 0, 0].min())
     print('%-9s %d tiles per workgroup, first-in to last-out %8.0f clk\n   ' % (name, nt, span) + '\n   '.join(out))
-os.environ['TELL_Q4_ABL'] = '0'
+hip.apply_env({'TELL_Q4_ABL': '0'})
 
 # ---- gemm_nt_q4e_kernel probes (TELL_Q4E_VAR = index into PROBES of tools/gen_q4e_loop.py; act 0 shapes only): time + stamps
 # t0 -> [setup (+ wait)] ta -> [drain of the previous tile (+ wait)] td -> [K loop with the deferred stores] tb -> t1
@@ -109,7 +111,7 @@ for r in range(ROUNDS):
         pt[k].append(time_graph(g_))
 print('\nq4e probes: median us per launch;  stamps in shader clocks, mean over workgroups, of the middle tile (qkv) / the only tile')
 for v in range(NPROBE):
-    os.environ['TELL_Q4E_VAR'] = str(v)
+    hip.apply_env({'TELL_Q4E_VAR': str(v)})
     row = 'probe %d  ' % v
     for name, N, K, act in SHAPES:
         if act != 0:
@@ -126,4 +128,4 @@ for v in range(NPROBE):
         gap = (d[:, t + 1, 0] - d[:, t, 4]).mean() if t + 1 < nt else float('nan')
         row += '%s %6.1f us [top %4.0f drain %5.0f loop %6.0f = %4.0f/Kt gap %5.0f]  ' % (name, statistics.median(pt[(v, name)]), top, drain, loop, loop / (K // 64), gap)
     print(row)
-del os.environ['TELL_Q4E_VAR']
+hip.apply_env({'TELL_Q4E_VAR': None})

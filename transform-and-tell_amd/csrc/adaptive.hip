@@ -8,6 +8,7 @@
 // fixed-capacity buffer with a device-side row count (gemm_nt's m_dev), so the
 // whole step has no data-dependent launch and no host synchronisation.
 #include "common.h"
+#include "options.h"
 
 #define MAX_BANDS 4
 
@@ -583,7 +584,7 @@ extern "C" int tell_adaptive_logprob_topk(const float* head, long ld_head, int c
                        (n_tails < 1 || (ld0 % 4 == 0 && ((uintptr_t)tail0 % 16) == 0)) &&
                        (n_tails < 2 || (ld1 % 4 == 0 && ((uintptr_t)tail1 % 16) == 0)) &&
                        (n_tails < 3 || (ld2 % 4 == 0 && ((uintptr_t)tail2 % 16) == 0));
-  static const bool regs_env = !(getenv("TELL_ARGMAX_REGS") && atoi(getenv("TELL_ARGMAX_REGS")) == 0);      // A/B aid
+  const bool regs_env = tell_opt(OPT_ARGMAX_REGS) != 0;      // A/B aid
   if (regs_env && aligned && p.head_n <= 2 * 4096 && (n_tails < 1 || n0 <= 4 * 4096) && (n_tails < 2 || n1 <= 8 * 4096) &&
       (n_tails < 3 || n2 <= 2 * 4096)) {
     if (k <= 4) hipLaunchKernelGGL((logprob_regs_kernel<4>), dim3(rows), dim3(1024), 0, stream, p, k, tokens, lps);
@@ -612,7 +613,7 @@ extern "C" int tell_adaptive_logprob_argmax(const float* head, long ld_head, int
                        (n_tails < 1 || (ld0 % 4 == 0 && ((uintptr_t)tail0 % 16) == 0)) &&
                        (n_tails < 2 || (ld1 % 4 == 0 && ((uintptr_t)tail1 % 16) == 0)) &&
                        (n_tails < 3 || (ld2 % 4 == 0 && ((uintptr_t)tail2 % 16) == 0));
-  static const bool regs_env = !(getenv("TELL_ARGMAX_REGS") && atoi(getenv("TELL_ARGMAX_REGS")) == 0);      // A/B aid
+  const bool regs_env = tell_opt(OPT_ARGMAX_REGS) != 0;      // A/B aid
   if (!log_probs && regs_env && aligned && p.head_n <= 2 * 4096 && (n_tails < 1 || n0 <= 4 * 4096) &&
       (n_tails < 2 || n1 <= 8 * 4096) && (n_tails < 3 || n2 <= 2 * 4096)) {
     hipLaunchKernelGGL((logprob_regs_kernel<1>), dim3(rows), dim3(1024), 0, stream, p, 1, (int*)nullptr, (float*)nullptr);

@@ -1,5 +1,7 @@
 // Error reporting + misc entry points of libtell_hip.so.
 #include "common.h"
+#include "options.h"
+#include <limits.h>
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -9,7 +11,63 @@ extern "C" void tell_set_error(const char* msg) {
   g_err[sizeof(g_err) - 1] = 0;
 }
 extern "C" const char* tell_last_error(void) { return g_err; }
-extern "C" int tell_abi_version(void) { return 1; }
+extern "C" int tell_abi_version(void) { return 2; }
+
+// ---- run-time options (options.h): the library's only tunable state, set explicitly - no environment variable is read
+#define TELL_X(e, k, d) {d},
+std::atomic<long> g_tell_opt[TELL_OPT_COUNT] = {
+  TELL_OPTION_LIST(TELL_X)
+#ifdef TELL_PROBES
+  TELL_PROBE_LIST(TELL_X)
+#endif
+};
+#undef TELL_X
+#define TELL_X(e, k, d) k,
+static const char* const g_opt_keys[TELL_OPT_COUNT] = {
+  TELL_OPTION_LIST(TELL_X)
+#ifdef TELL_PROBES
+  TELL_PROBE_LIST(TELL_X)
+#endif
+};
+#undef TELL_X
+#define TELL_X(e, k, d) d,
+static const long g_opt_defaults[TELL_OPT_COUNT] = {
+  TELL_OPTION_LIST(TELL_X)
+#ifdef TELL_PROBES
+  TELL_PROBE_LIST(TELL_X)
+#endif
+};
+#undef TELL_X
+static int opt_index(const char* key) {
+  if (!key) return -1;
+  for (int i = 0; i < TELL_OPT_COUNT; ++i)
+    if (strcmp(key, g_opt_keys[i]) == 0) return i;
+  return -1;
+}
+extern "C" int tell_set_option(const char* key, long value) {
+  const int i = opt_index(key);
+  if (i < 0) {
+    char msg[160];
+    snprintf(msg, sizeof(msg), "set_option: unknown option '%.64s'", key ? key : "(null)");
+    tell_set_error(msg);
+    return TELL_ERR_ARG;
+  }
+  g_tell_opt[i].store(value, std::memory_order_relaxed);
+  return TELL_OK;
+}
+extern "C" long tell_get_option(const char* key) {
+  const int i = opt_index(key);
+  return i < 0 ? LONG_MIN : g_tell_opt[i].load(std::memory_order_relaxed);
+}
+extern "C" const char* tell_option_key(int index) { return index >= 0 && index < TELL_OPT_COUNT ? g_opt_keys[index] : nullptr; }
+extern "C" long tell_option_default(int index) { return index >= 0 && index < TELL_OPT_COUNT ? g_opt_defaults[index] : LONG_MIN; }
+extern "C" int tell_probe_build(void) {
+#ifdef TELL_PROBES
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 // number of visible HIP devices (0 on a CPU-only box); never throws
 extern "C" int tell_device_count(void) {

@@ -15,6 +15,7 @@
 // (S^T[key][q] = K.Q^T) so that each lane owns one query column: the softmax
 // row-reduction is 16 in-register values + one cross-half wavefront shuffle.
 #include "common.h"
+#include "options.h"
 #include <type_traits>
 
 template <typename T, int D> struct ACfg {
@@ -1491,11 +1492,11 @@ extern "C" int tell_attn_fwd(const void* q, const void* k, const void* v, void* 
   const int QB = (Tq + 31) / 32;
   if (D == 64 && QB >= 4) {            // long sequences: shared 64-key tiles
     dim3 grid((QB + 3) / 4, B * H);
-    static const int old_path = getenv("TELL_ATTN_TILE64") ? atoi(getenv("TELL_ATTN_TILE64")) : 0;   // A/B aid
-    static const bool self_env = !(getenv("TELL_ATTN_SELF") && atoi(getenv("TELL_ATTN_SELF")) == 0);      // A/B aid
+    const int old_path = (int)tell_opt(OPT_ATTN_TILE64);   // A/B aid
+    const bool self_env = tell_opt(OPT_ATTN_SELF) != 0;      // A/B aid
     if (dtype == TELL_BF16 && !old_path && self_env && !a.has_bias && !a.has_zero && S % 64 == 0 &&
         (long)63 * k_ss + 64 < (1L << 31) && (long)63 * v_ss + 64 < (1L << 31)) {
-      static const bool dma_env = getenv("TELL_ATTN_DMA") && atoi(getenv("TELL_ATTN_DMA")) == 1;      // A/B aid
+      const bool dma_env = tell_opt(OPT_ATTN_DMA) == 1;      // A/B aid
       if (dma_env) {
         if (a.thr) hipLaunchKernelGGL((attn_self_fwd_kernel<true, 0, true>), grid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((attn_self_fwd_kernel<false, 0, true>), grid, dim3(256), 0, stream, a);
@@ -1507,7 +1508,7 @@ extern "C" int tell_attn_fwd(const void* q, const void* k, const void* v, void* 
       return tell_check_launch("attn_self_fwd");
     }
     if (dtype == TELL_BF16 && !old_path) {
-      static const int occ = getenv("TELL_ATTN_OCC") ? atoi(getenv("TELL_ATTN_OCC")) : 2;     // A/B aid
+      const int occ = (int)tell_opt(OPT_ATTN_OCC);     // A/B aid
       if (occ == 3) {
         if (a.thr) hipLaunchKernelGGL((attn_fwd_reg_kernel<true, 3>), grid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((attn_fwd_reg_kernel<false, 3>), grid, dim3(256), 0, stream, a);

@@ -5,6 +5,7 @@
 // weights stored [Cout, KH, KW, Cin].  BatchNorm runs with BATCH statistics in
 // training (callback_apex_trainer.py:259 puts the frozen trunk in train mode).
 #include "common.h"
+#include "options.h"
 #include <stdlib.h>
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;   // native 16-byte vector (stays in VGPRs)
 
@@ -596,7 +597,7 @@ int tell_bn_finish_apply_launch(const float* pmean, const float* pm2, long M, in
     pmean = qmean; pm2 = qm2; n_chunks = G; rows_per_chunk *= S;
   }
   // ~768 workgroups of 32 .. 128 rows (1 .. 4 passes of 32, all requested up front) x 64 channels
-  static const long wgs = getenv("TELL_BN_WGS") ? atol(getenv("TELL_BN_WGS")) : 768;   // tuning aid
+  const long wgs = tell_opt(OPT_BN_WGS) > 0 ? tell_opt(OPT_BN_WGS) : 768;   // tuning aid
   long per = (M * slabs + wgs - 1) / wgs;
   per = (per + 31) / 32 * 32;
   if (per < 32) per = 32;

@@ -26,6 +26,7 @@
 // workgroup: 256 workgroups re-reading 64-256 KB of rows each made it L2-bound (10-30 us per launch at 32-128 rows);
 // the register-direct MFMA form measures 5-8 us at 32 rows and 5-17 us at 128.
 #include "common.h"
+#include "options.h"
 #include "../../include/tell_hip.h"
 
 #define SK_MAXP 4
@@ -498,7 +499,7 @@ extern "C" int tell_skinny_linear(int n_prob, const void* const* in, long ld_in,
   // fragments of a column tile are loaded once for 128 rows instead of four times
   // (64 rows per workgroup - RT = 4, U = 4 - where 128 is taken: beam 4 711 -> 705 us, 128 greedy rows 866 -> 853; everywhere
   //  above 64 rows: 784 / 926 us.  Not instantiated.)
-  static const int rt_env = getenv("TELL_SK_ROWS") ? atoi(getenv("TELL_SK_ROWS")) : 0;          // A/B aid: 32 / 128
+  const int rt_env = (int)tell_opt(OPT_SK_ROWS);          // A/B aid: 32 / 128
   const bool tall = rt_env ? rt_env == 128 : (M > 64 && (long)((N + 15) / 16) * n_prob * ((M + 127) / 128) >= 192);
   if (tall) return skinny_mfma_dispatch<8, 2>(a, n_prob, act, stream, fold);
   return K % 1024 == 0 ? skinny_mfma_dispatch<2, 8>(a, n_prob, act, stream, fold) : skinny_mfma_dispatch<2, 2>(a, n_prob, act, stream, fold);

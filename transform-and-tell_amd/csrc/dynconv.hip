@@ -7,6 +7,7 @@
 // rows; HBM-bound: AI = 2K / ((2 + H*K/C) * sizeof) flop/byte).
 // Softmax over the taps is done with wavefront shuffles (lane k holds tap k).
 #include "common.h"
+#include "options.h"
 #include <stdlib.h>
 
 template <typename T>
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(256) void dynconv_bwd_lds_kernel(const T* __restric
 
 static inline bool dc_lds_ok(const void* x, const void* y, int T, int R, int K, int dtype) {
   const int vec = dtype == TELL_BF16 ? 8 : 4;
-  static const bool off = getenv("TELL_DYNCONV_LDS") && atoi(getenv("TELL_DYNCONV_LDS")) == 0;     // A/B switch
+  const bool off = tell_opt(OPT_DYNCONV_LDS) == 0;     // A/B switch
   return !off && R == DC_R && T <= DC_TMAX && K <= DC_KMAX && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && (DC_R % vec) == 0;
 }
 
@@ -507,7 +508,7 @@ extern "C" int tell_dynconv_block_fwd(const void* h1, const void* w_tap, void* g
                                       int H, int K, float p, uint32_t seed, uint32_t salt, hipStream_t stream) {
   if ((long)T * B * H <= 0) return TELL_OK;
   TELL_REQUIRE(p >= 0.f && p < 1.f, "dynconv_block: p must be in [0,1)");
-  static const bool off = getenv("TELL_DYNCONV_BLOCK") && atoi(getenv("TELL_DYNCONV_BLOCK")) == 0;      // A/B switch
+  const bool off = tell_opt(OPT_DYNCONV_BLOCK) == 0;      // A/B switch
   const int E = H * DC_R;
   if (off || T > DCB_T || K < 1 || K > DC_KMAX || DCB_HG * K > 64 || E != 1024 || H % DCB_HG || !taps ||
       ((((uintptr_t)h1 | (uintptr_t)w_tap | (uintptr_t)gl | (uintptr_t)y) & 15) != 0))
@@ -521,7 +522,7 @@ extern "C" int tell_dynconv_block_fwd(const void* h1, const void* w_tap, void* g
     return true;
   }();
   (void)attr;
-  static const int abl = getenv("TELL_DCB_ABL") ? atoi(getenv("TELL_DCB_ABL")) : 0;      // timing probe (wrong results)
+  const int abl = (int)tell_probe(PROBE_DCB_ABL);      // timing probe (wrong results): probe build only
   hipLaunchKernelGGL((dynconv_block_fwd_kernel<1024>), dim3((B + 7) / 8 * 8 * (H / DCB_HG)), dim3(256), smem, stream,
                      (const uint16_t*)h1, (const uint16_t*)w_tap, (uint16_t*)gl, (uint16_t*)y, taps, T, B, H, K, thr, ik, seed,
                      salt, g_tell_rng_step, abl);

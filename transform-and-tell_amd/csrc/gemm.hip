@@ -18,6 +18,7 @@
 // 33-dword stride; K-major tiles: +64 B skew for the transpose reads) or, for the lane-linear direct-to-LDS
 // image, swizzled on the source address.
 #include "common.h"
+#include "options.h"
 #include <atomic>
 #include <mutex>
 #include <vector>
@@ -856,10 +857,7 @@ __global__ __launch_bounds__(256) void gemm_nt_group_kernel(GemmGroup g) {
 // layer4 conv1 24.5 -> 18.4 us, conv2 53.3 -> 38.3; ResNet-152 5.78 -> 5.50 ms) - and LOSES where many workgroups per
 // CU already hide each other's latency (layer1 conv3, K = 64: 43 -> 61 us; layer3 conv3, K = 256: 18.0 -> 24.1).
 // TELL_GEMM_RING = 2 / 3 / 4 forces a depth everywhere (A/B aid).
-static int ring_env() {                     // (read per call: tools/bench_conv.py / bench_decoder_gemms.py switch it inside one process)
-  const char* e = getenv("TELL_GEMM_RING");
-  return e ? atoi(e) : 0;
-}
+static int ring_env() { return (int)tell_opt(OPT_GEMM_RING); }   // (read per call: tools/bench_conv.py switches it inside one process)
 static int small_ring_stages(long tiles64, int K) {
   const int v = ring_env();
   if (v) return v;
@@ -870,7 +868,7 @@ template <typename OutT, bool TA, bool TB>
 static int launch_gemm_tx(const GemmArgs& a_in, hipStream_t stream) {
   GemmArgs a = a_in;
   auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
-  static const int split_env = getenv("TELL_GEMM_SPLITK") ? atoi(getenv("TELL_GEMM_SPLITK")) : -1;   // tuning aid: 0 = off
+  const int split_env = (int)tell_opt(OPT_GEMM_SPLITK);   // tuning aid: <= 0 = off
   if constexpr (std::is_same<OutT, float>::value) {
     // Opt-in (TELL_GEMM_SPLITK=n): long reductions into a small fp32 output that is accumulated anyway (weight gradients
     // of the context K/V projections: K = S*B = 16384 rows into [2048, 1024]) split over gridDim.y, partial tiles added
@@ -1008,7 +1006,7 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
   auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
   if constexpr (sizeof(T) == 2) {
     if (a.K % 64 == 0 && tiles(128, 128) >= 256) {       // direct-to-LDS path
-      static const int force_env = getenv("TELL_GEMM_TILE") ? atoi(getenv("TELL_GEMM_TILE")) : 0;   // tuning aid
+      const int force_env = (int)tell_opt(OPT_GEMM_TILE);   // tuning aid
       const bool no_pp = force_env == 7;                  // 7: the default choice without the ping-pong kernel (A/B)
       const int force = no_pp ? 0 : force_env;
       static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); (void)hipGetDeviceProperties(&pr, d); return pr.multiProcessorCount; }();
@@ -1025,7 +1023,7 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
         // ping-pong 256x256: whole rounds of full tiles (fc1 of RoBERTa: 878 vs 838 TFLOP/s, 4096^3: 1171 vs 1022,
         // 8192^3: 1333 vs 1164); partial rounds lose to the smaller tiles below.  TELL_GEMM_TILE=8 forces it.
         // four waves x 128x128 (gemm_q4.hip): what it needs beyond `full`
-        const int q4_env = getenv("TELL_GEMM_Q4") ? atoi(getenv("TELL_GEMM_Q4")) : 1;   // (per launch: A/B inside one process)
+        const int q4_env = (int)tell_opt(OPT_GEMM_Q4);   // (per launch: A/B inside one process)
         const bool q4_takes = q4_env && (force == 0 || force == 8) && a.K % 128 == 0 && a.K >= 128 && a.K / 64 < 65536 && a.lda % 8 == 0 &&
                               a.ldb % 8 == 0 && !a.conv_zero && a.act <= 2 && (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 &&
                               (reinterpret_cast<uintptr_t>(a.B) & 15) == 0 && 256L * a.lda * 2 < (1L << 31) && 256L * a.ldb * 2 < (1L << 31);
@@ -1033,7 +1031,7 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
         // them to 128x128 tiles, q4 does not as long as the rounds it runs are at least 70 % full - at 12288 rows fc2 has
         // 192 tiles = 75 % of one round and still runs in the time of the full 16384-row launch (990 against 830 TFLOP/s
         // effective), qkv is 2.25 rounds in 3.  TELL_Q4_PARTIAL=0: whole rounds only.
-        static const bool q4_partial_env = !(getenv("TELL_Q4_PARTIAL") && atoi(getenv("TELL_Q4_PARTIAL")) == 0);
+        const bool q4_partial_env = tell_opt(OPT_Q4_PARTIAL) != 0;
         const long t256 = tiles(256, 256);
         const bool q4_partial = q4_partial_env && q4_takes && force == 0 && t256 * 10 >= ((t256 + n_cu - 1) / n_cu) * n_cu * 7;
         if (full && !no_pp && ((force == 0 && (t256 % n_cu == 0 || q4_partial)) || (force == 8 && t256 >= n_cu))) {
@@ -1050,13 +1048,13 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
           // out 922 -> 993, fc1 + GELU 855 -> 1036, fc2 1197 -> 1313 (tools/probes/q4_variants.py).  TELL_GEMM_Q4=0: ping-pong.
           if (q4_takes) {
             // epilogue inside the next tile's K loop (gemm_q4e.hip): per-column bias, K >= 576.  TELL_GEMM_Q4E=0: plain q4
-            const int q4e_env = getenv("TELL_GEMM_Q4E") ? atoi(getenv("TELL_GEMM_Q4E")) : 1;
+            const int q4e_env = (int)tell_opt(OPT_GEMM_Q4E);
             // MEASURED (static tile lists, M = 16384): qkv (3 tiles per workgroup) 90.2 -> 86.6 us; one tile per workgroup (out,
             // fc2) has no next K loop to hide anything in; with GELU the in-asm drain is slower than hipcc's (fc1 130.5 -> 135.0):
             // taken for act 0 / 1 with at least two tiles per workgroup (TELL_GEMM_Q4E=2: wherever it applies)
             const bool q4e_ok = q4e_env && a.bias_mode == 1 && a.K / 64 >= 13 && 512L * a.ldc < (1L << 31) && tiles(256, 256) % n_cu == 0 &&
                                 (q4e_env == 2 || (a.act != 2 && tiles(256, 256) >= 2L * n_cu)) &&
-                                !(getenv("TELL_Q4_ABL") && atoi(getenv("TELL_Q4_ABL")));
+                                !tell_probe(PROBE_Q4_ABL);
             if (g_gemm_plan) { (void)gemm_label(q4e_ok ? "gemm_nt_q4e_kernel" : "gemm_nt_q4_kernel", -1, 1, 256, 256); return TELL_OK; }
             if (q4e_ok) {
               const int rc = launch_gemm_q4e(a, stream, n_cu);
@@ -1064,12 +1062,12 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
             }
             return launch_gemm_q4(a, stream, n_cu);
           }
-          static const int pp2_env = getenv("TELL_GEMM_PP2") ? atoi(getenv("TELL_GEMM_PP2")) : 2;
+          const int pp2_env = (int)tell_opt(OPT_GEMM_PP2);
           if (pp2_env && force == 0 && tiles(256, 256) >= (pp2_env == 2 ? 1 : 2) * (long)n_cu && a.lda % 8 == 0 && a.ldb % 8 == 0 && !a.conv_zero) {
             if (g_gemm_plan) { (void)gemm_label("gemm_nt_pp2_kernel", -1, 1, 256, 256); return TELL_OK; }
             return launch_gemm_pp2(a, stream, n_cu);
           }
-          static const bool persist_env = getenv("TELL_GEMM_PERSIST") && atoi(getenv("TELL_GEMM_PERSIST")) == 1;
+          const bool persist_env = tell_opt(OPT_GEMM_PERSIST) == 1;
           int* pq = (persist_env && !g_gemm_plan && tiles(256, 256) > n_cu) ? gemm_tile_queue_slot(1, stream) : nullptr;
           if (pq) {
             GemmArgs ap = a;
@@ -1107,13 +1105,13 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
   if constexpr (sizeof(T) == 2) {
     // fewer than 256 tiles of 128x128 and a reduction of 1024 or more: gemm_s64.hip (q / out / linear2 of the decoder 7.8 ->
     // 5.7 us, tap logits 7.9 -> 5.7; bit-identical sums).  TELL_GEMM_S64=0: the kernels below (A/B; read per launch)
-    const int s64_env = getenv("TELL_GEMM_S64") ? atoi(getenv("TELL_GEMM_S64")) : 1;
+    const int s64_env = (int)tell_opt(OPT_GEMM_S64);
     if (a.M >= 512 && a.K % 64 == 0 && !a.stat_mean && !a.conv_zero && (s64_env == 2 || (s64_env == 1 && a.K >= 1024))) {
       if (g_gemm_plan) { *bm_used = 64; (void)gemm_label("gemm_nt_s64_kernel", -1, sizeof(OutT) == 2, 64, 64); return TELL_OK; }
       const int rc = launch_gemm_s64(a, stream, sizeof(OutT) == 4);
       if (rc <= 0) { *bm_used = 64; return rc; }
     }
-    static const bool small_glds = !(getenv("TELL_GEMM_SMALL") && atoi(getenv("TELL_GEMM_SMALL")) == 0);
+    const bool small_glds = tell_opt(OPT_GEMM_SMALL) != 0;
     // (Round 5: an 8-stage ring for the decoder's one-round 1024 x 1024 GEMMs - 7 K tiles in flight, one workgroup per CU -
     //  measured neutral: K = 1024 7.8 -> 8.4 us, K = 4096 23.5 -> 22.4 us, decoder half 6.955 -> 6.953 ms; not kept.)
     // (K = 4096: 35.6 us against 23.7 us for the register-staged kernel below)
@@ -1257,7 +1255,7 @@ extern "C" int tell_gemm_bf16(const void* A, long lda, int trans_a, const void* 
                               float a_colsum_scale, hipStream_t stream);
 extern "C" int tell_gemm_grouped(int n, const tell_gemm_problem* pr, hipStream_t stream) {
   if (n <= 0) return TELL_OK;
-  static const int tile_env = getenv("TELL_GROUP_TILE") ? atoi(getenv("TELL_GROUP_TILE")) : 0;   // A/B aid: 64 / 128
+  const int tile_env = (int)tell_opt(OPT_GROUP_TILE);   // A/B aid: 64 / 128
   enum { FORMS = 3, BUCKETS = FORMS * 2 * 2 + 1, WIDE = FORMS * 2 * 2 };   // form x (bf16, f32) x (64, 128) + long fp32 TN
   int* ids = (int*)alloca(sizeof(int) * BUCKETS * n);
   int* form_of = (int*)alloca(sizeof(int) * n);
@@ -1295,7 +1293,7 @@ extern "C" int tell_gemm_grouped(int n, const tell_gemm_problem* pr, hipStream_t
     if (tile_env == 64) big = false;
     if (tile_env == 128) big = q.M >= 128 && q.N >= 128;
     int b = (form_of[i] * 2 + f32) * 2 + (big ? 1 : 0);
-    static const bool wide_env = !(getenv("TELL_GROUP_WIDE") && atoi(getenv("TELL_GROUP_WIDE")) == 0);   // A/B aid
+    const bool wide_env = tell_opt(OPT_GROUP_WIDE) != 0;   // A/B aid
     // (round 5: 256x128 tiles for the K = 1024 / 2048 weight gradients too - same box, decoder half 6.74 / 6.75 / 6.74 ms
     //  for a threshold of 4096 / 1024 / 2048: the four 128x128 launches, 0.70 ms, become 0.70 ms of wide launches)
     if (wide_env && form_of[i] == 2 && f32 && q.K >= 4096 && q.M >= 256 && q.N >= 128) b = WIDE;
@@ -1303,7 +1301,7 @@ extern "C" int tell_gemm_grouped(int n, const tell_gemm_problem* pr, hipStream_t
   }
   // inside a bucket: longest reductions first - a launch lasts until its last workgroup is done, and a 16384-row
   // reduction dispatched behind twenty 1024-row problems would start when the others are already finishing
-  static const bool sort_env = !(getenv("TELL_GROUP_SORT") && atoi(getenv("TELL_GROUP_SORT")) == 0);   // A/B aid
+  const bool sort_env = tell_opt(OPT_GROUP_SORT) != 0;   // A/B aid
   for (int b = 0; b < BUCKETS && sort_env; ++b) {
     int* v = ids + b * n;
     for (int i = 1; i < cnt[b]; ++i) {                 // insertion sort (stable, n <= ~100)
@@ -1465,8 +1463,7 @@ static int conv_launch(const void* X, const void* Wt, void* Y, int B, int H, int
     a.stat_m2 = stats_ws + (((long)M + 63) / 64) * N;
   }
   auto tiles = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
-  const char* fe = getenv("TELL_CONV_TILE");                       // tuning / test aid: 1 / 2 / 3 forces a tile shape
-  const int force = fe ? atoi(fe) : 0;
+  const int force = (int)tell_opt(OPT_CONV_TILE);                  // tuning / test aid: 1 / 2 / 3 forces a tile shape
   // 64x64 tiles (4 waves, 32 KB of LDS, 5 workgroups per CU) win on every bottleneck shape of the trunk at B = 32
   // (tools/bench_conv.py: layer3 conv1 15.1 us against 20.4 / 22.3 with 128x64 / 128x128 - these GEMMs are only
   // 50-800 tiles of 128x128, the small tile fills the chip and hides the short K loops behind its neighbours); 128x64
@@ -1489,7 +1486,7 @@ static int conv_launch(const void* X, const void* Wt, void* Y, int B, int H, int
   const bool ring = ns ? ns >= 3 : small_ring_stages(tiles(64, 64), K) >= 3;
   // 64x64 tiles, K >= 1024: the one-wave-per-SIMD K loop of gemm_s64.hip (layer3 conv2 25.0 -> 14.4 us, layer4 conv2 37.5 ->
   // 17.8; shorter reductions stay on the 2-stage body, measured there).  TELL_GEMM_S64=0: the general body (A/B; read per launch)
-  const int s64_env = getenv("TELL_GEMM_S64") ? atoi(getenv("TELL_GEMM_S64")) : 1;
+  const int s64_env = (int)tell_opt(OPT_GEMM_S64);
   if (pick == 3 && !stem && (s64_env == 2 || (s64_env == 1 && K >= 1024))) {
     const int rc = launch_gemm_s64(a, stream, 0);
     if (rc <= 0) { *bm_out = 64; return rc; }
@@ -1551,10 +1548,10 @@ extern "C" int tell_conv_bn_act(const void* X, const void* Wt, void* Y, int B, i
   const float* pmean = workspace;
   const float* pm2 = workspace + chunks64 * Cout;
   const int n_chunks = (int)((M + bm - 1) / bm);
-  static const bool fuse = !(getenv("TELL_BN_FUSE") && atoi(getenv("TELL_BN_FUSE")) == 0);                 // A/B aid
+  const bool fuse = tell_opt(OPT_BN_FUSE) != 0;                 // A/B aid
   if (fuse) {
     // (opt-in: ResNet alone 4.97 -> 4.93 ms, the training step unchanged - 1443 / 1437 against 1434 / 1432 samples/s)
-    static const bool comb = getenv("TELL_BN_COMBINE") && atoi(getenv("TELL_BN_COMBINE")) == 1;
+    const bool comb = tell_opt(OPT_BN_COMBINE) == 1;
     rc = tell_bn_finish_apply_launch(pmean, pm2, M, Cout, n_chunks, bm, eps, momentum, gamma, beta, running_mean, running_var,
                                      residual, Y, relu, comb ? workspace + 2 * chunks64 * Cout + 2 * Cout : nullptr, stream);
     if (rc <= 0) return rc;

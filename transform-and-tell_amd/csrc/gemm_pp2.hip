@@ -16,6 +16,7 @@
 // other, so after an epilogue the only safe wait for the prefetched tiles is vmcnt(0) - the start of the next tile
 // waits for the last store acknowledgement (~1 us) where a fresh workgroup waited for its first operand round trip.
 #include "gemm_common.h"
+#include "options.h"
 #include <type_traits>
 
 typedef __attribute__((address_space(3))) void* pp2_lds_ptr_t;
@@ -347,20 +348,22 @@ int launch_gemm_pp2(const GemmArgs& a, hipStream_t stream, int n_cu) {
   const int n_tiles = (a.M / BM) * (a.N / BN);
   // TELL_PP2_GRID: resident workgroups per launch (default: one per CU) - a tuning aid for how many CUs the step's other
   // two streams are left with while a GEMM runs
-  static const int grid_env = getenv("TELL_PP2_GRID") ? atoi(getenv("TELL_PP2_GRID")) : 0;
+  const int grid_env = (int)tell_opt(OPT_PP2_GRID);
   const int cap = grid_env > 0 && grid_env < n_cu ? grid_env : n_cu;
   const unsigned grid = (unsigned)(n_tiles < cap ? n_tiles : cap);
-  static const int abl = getenv("TELL_PP2_ABL") ? atoi(getenv("TELL_PP2_ABL")) : 0;   // timing probes (wrong results): 1 no epilogue, 2 no global stores
+  // timing probes (wrong results; probe build only): 1 no epilogue, 2 no global stores
   // per-XCD tile counters (default on; TELL_PP2_DYNAMIC=0: static tile lists).  MEASURED (same box A/B, configs[2]): 1444 / 1450
   // samples/s static, 1456 / 1468 dynamic; the launch inside the step 160-164 -> 142-146 us (100 alone either way)
-  static const int dyn_env = getenv("TELL_PP2_DYNAMIC") ? atoi(getenv("TELL_PP2_DYNAMIC")) : 1;
+  const int dyn_env = (int)tell_opt(OPT_PP2_DYNAMIC);
   GemmArgs ad = a;
   ad.queue = nullptr;
   if (dyn_env && n_tiles > (int)grid && grid % 8 == 0 && n_tiles % 8 == 0) ad.queue = gemm_tile_queue_slot(8, stream);
   const GemmArgs& a2 = ad;
   if (a.act == 5) hipLaunchKernelGGL((gemm_nt_pp2_kernel<0, true>), dim3(grid), dim3(512), 0, stream, a2);
-  else if (abl == 1) hipLaunchKernelGGL((gemm_nt_pp2_kernel<1, false>), dim3(grid), dim3(512), 0, stream, a2);
-  else if (abl == 2) hipLaunchKernelGGL((gemm_nt_pp2_kernel<2, false>), dim3(grid), dim3(512), 0, stream, a2);
+#ifdef TELL_PROBES
+  else if (tell_probe(PROBE_PP2_ABL) == 1) hipLaunchKernelGGL((gemm_nt_pp2_kernel<1, false>), dim3(grid), dim3(512), 0, stream, a2);
+  else if (tell_probe(PROBE_PP2_ABL) == 2) hipLaunchKernelGGL((gemm_nt_pp2_kernel<2, false>), dim3(grid), dim3(512), 0, stream, a2);
+#endif
   else hipLaunchKernelGGL((gemm_nt_pp2_kernel<0, false>), dim3(grid), dim3(512), 0, stream, a2);
   return tell_check_launch("gemm_nt_pp2");
 }
@@ -389,7 +392,7 @@ extern "C" int tell_gemm_nt_dropout_residual(const void* A, long lda, const void
   a.drop_seed = seed; a.drop_salt = salt; a.drop_step = g_tell_rng_step;
   // round 4: the four-wave kernel (gemm_q4.hip) carries the same epilogue form (one rounding: bf16(res + dropout(.)) from
   // fp32, where this file's staged epilogue rounds the dropped product first); TELL_GEMM_Q4=0 keeps the ping-pong kernel
-  const int q4_env = getenv("TELL_GEMM_Q4") ? atoi(getenv("TELL_GEMM_Q4")) : 1;
+  const int q4_env = (int)tell_opt(OPT_GEMM_Q4);
   if (q4_env && K % 128 == 0 && K >= 128 && K / 64 < 65536 && 512L * lda < (1L << 31) && 512L * ldb < (1L << 31)) return launch_gemm_q4(a, stream, n_cu);
   return launch_gemm_pp2(a, stream, n_cu);
 }

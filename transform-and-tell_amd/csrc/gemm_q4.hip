@@ -16,6 +16,7 @@
 // PMC (profiles/r04_pmc_gemm_lds.txt, RoBERTa's four shapes): SQ_LDS_BANK_CONFLICT 590 k -> 0 per launch, SQ_LDS_IDX_ACTIVE
 // 10.9 M -> 6.3 M, matrix pipes busy 54 % -> 64 % of wave cycles.
 #include "gemm_common.h"
+#include "options.h"
 #include "gemm_q4_loop.inc"
 #include <utility>
 
@@ -329,18 +330,18 @@ int launch_gemm_q4(const GemmArgs& a_in, hipStream_t stream, int n_cu) {
   const int n_tiles = (a_in.M / QBM) * (a_in.N / QBN);
   const unsigned grid = (unsigned)(n_tiles < n_cu ? n_tiles : n_cu);
   // per-XCD tile counters for launches of more than one round (TELL_Q4_DYNAMIC=0: static tile lists)
-  const int dyn_env = getenv("TELL_Q4_DYNAMIC") ? atoi(getenv("TELL_Q4_DYNAMIC")) : 0;
+  const int dyn_env = (int)tell_opt(OPT_Q4_DYNAMIC);
   GemmArgs ad = a_in;
   ad.queue = nullptr;
   if (dyn_env && n_tiles > (int)grid && grid % 8 == 0 && n_tiles % 8 == 0) ad.queue = gemm_tile_queue_slot(8, stream);
   const GemmArgs& a = ad;
-  // (read per launch: tools/probes/q4_variants.py switches them inside one process)
-  const int var = getenv("TELL_Q4_VAR") ? atoi(getenv("TELL_Q4_VAR")) : 0;
-  const int abl = getenv("TELL_Q4_ABL") ? atoi(getenv("TELL_Q4_ABL")) : 0;   // timing probes (1, 2: wrong results; 3: stamps into aux)
+  const int var = (int)tell_opt(OPT_Q4_VAR);
   if (a.act == 5) hipLaunchKernelGGL((gemm_nt_q4_kernel<0, 0, true>), dim3(grid), dim3(256), 0, stream, a);
-  else if (abl == 3) hipLaunchKernelGGL((gemm_nt_q4_kernel<0, 3>), dim3(grid), dim3(256), 0, stream, a);
-  else if (abl == 1) hipLaunchKernelGGL((gemm_nt_q4_kernel<0, 1>), dim3(grid), dim3(256), 0, stream, a);
-  else if (abl == 2) hipLaunchKernelGGL((gemm_nt_q4_kernel<0, 2>), dim3(grid), dim3(256), 0, stream, a);
+#ifdef TELL_PROBES      // timing probes (1, 2: wrong results; 3: stamps into aux) - tools/probes/q4_variants.py, probe build only
+  else if (tell_probe(PROBE_Q4_ABL) == 3) hipLaunchKernelGGL((gemm_nt_q4_kernel<0, 3>), dim3(grid), dim3(256), 0, stream, a);
+  else if (tell_probe(PROBE_Q4_ABL) == 1) hipLaunchKernelGGL((gemm_nt_q4_kernel<0, 1>), dim3(grid), dim3(256), 0, stream, a);
+  else if (tell_probe(PROBE_Q4_ABL) == 2) hipLaunchKernelGGL((gemm_nt_q4_kernel<0, 2>), dim3(grid), dim3(256), 0, stream, a);
+#endif
   else if (var == 1) hipLaunchKernelGGL((gemm_nt_q4_kernel<1, 0>), dim3(grid), dim3(256), 0, stream, a);
   else if (var == 2) hipLaunchKernelGGL((gemm_nt_q4_kernel<2, 0>), dim3(grid), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((gemm_nt_q4_kernel<0, 0>), dim3(grid), dim3(256), 0, stream, a);

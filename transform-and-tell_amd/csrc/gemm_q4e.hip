@@ -12,6 +12,7 @@
 // by a final statement.  Everything between two statements that must survive lives in physical registers a[0:255]
 // (accumulators) and v[32:127] (pending stores): the C++ around the statements only computes addresses.
 #include "gemm_common.h"
+#include "options.h"
 #include "gemm_q4_loop.inc"
 #include "gemm_q4e_loop.inc"
 
@@ -181,14 +182,16 @@ int launch_gemm_q4e(const GemmArgs& a_in, hipStream_t stream, int n_cu) {
   if (a_in.bias_mode != 1 || a_in.act > 2 || a_in.K / EBK < Q4E_NSB + 1 || a_in.K / EBK < 13 || (long)a_in.ldc * 2 * 256 >= (1L << 31)) return 1;
   const int n_tiles = (a_in.M / EBM) * (a_in.N / EBN);
   const unsigned grid = (unsigned)(n_tiles < n_cu ? n_tiles : n_cu);
-  const int dyn_env = getenv("TELL_Q4_DYNAMIC") ? atoi(getenv("TELL_Q4_DYNAMIC")) : 0;
+  const int dyn_env = (int)tell_opt(OPT_Q4_DYNAMIC);
   GemmArgs a = a_in;
   a.queue = nullptr;
   if (dyn_env && n_tiles > (int)grid && grid % 8 == 0 && n_tiles % 8 == 0) a.queue = gemm_tile_queue_slot(8, stream);
-  const int probe = getenv("TELL_Q4E_VAR") ? atoi(getenv("TELL_Q4E_VAR")) : -1;       // (read per launch)
-  if (probe >= 0 && a.act == 0 && a.K / EBK >= 13) {
+#ifdef TELL_PROBES
+  if (tell_probe(PROBE_Q4E_VAR) >= 0 && a.act == 0 && a.K / EBK >= 13) {
     hipLaunchKernelGGL((gemm_nt_q4e_kernel<0, 0>), dim3(grid), dim3(256), 0, stream, a);      // the stamped statement
-  } else if (a.act == 2) hipLaunchKernelGGL((gemm_nt_q4e_kernel<2>), dim3(grid), dim3(256), 0, stream, a);
+  } else
+#endif
+  if (a.act == 2) hipLaunchKernelGGL((gemm_nt_q4e_kernel<2>), dim3(grid), dim3(256), 0, stream, a);
   else if (a.act == 1) hipLaunchKernelGGL((gemm_nt_q4e_kernel<1>), dim3(grid), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((gemm_nt_q4e_kernel<0>), dim3(grid), dim3(256), 0, stream, a);
   return tell_check_launch("gemm_nt_q4e");

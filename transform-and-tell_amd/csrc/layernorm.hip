@@ -3,6 +3,7 @@
 // One wave per row, fp32 statistics, two-pass variance.  Rows are re-read from
 // L1/L2 (a 1024-wide bf16 row is 2 KB), so HBM traffic is one read + one write.
 #include "common.h"
+#include "options.h"
 #include <stdlib.h>
 // MEASURED (MI355X, tools/bench_layernorm.py, [16384, 1024] bf16 + residual): one row per wave 20.8 us with dropout / 20.7
 // without; two rows per wave, loads up front 19.9 / 18.1; the same with non-temporal loads 22.4 / 21.0.
@@ -191,8 +192,7 @@ extern "C" int tell_layernorm_fwd(const void* x, long ld_x, const void* res, lon
   // TELL_LN_VAR (A/B aid, read per call): 0 = one row per wave; 1 = two rows per wave, loads up front.
   // bf16, C = 1024, >= 4096 rows (the encoder's [B x 512, 1024] rows).
   {
-    const char* ve = getenv("TELL_LN_VAR");
-    const int var = ve ? atoi(ve) : TELL_LN_DEFAULT;
+    const int var = tell_opt(OPT_LN_VAR) >= 0 ? (int)tell_opt(OPT_LN_VAR) : TELL_LN_DEFAULT;
     if (var && aligned && dtype == TELL_BF16 && C == 1024 && rows >= 4096) {
       dim3 g2((rows + 7) / 8);
 #define LNR(NTT) hipLaunchKernelGGL((ln_fwd_vec_rows_kernel<uint16_t, 2, 2, NTT>), g2, dim3(256), 0, stream, (const uint16_t*)x, ld_x, \

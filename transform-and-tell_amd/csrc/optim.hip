@@ -8,6 +8,7 @@
 // buffers (zero padded), so a chunk belongs to exactly one tensor.  HBM-bound:
 // 4 reads + 3 writes of fp32 per element.
 #include "common.h"
+#include "options.h"
 
 #define OPT_CHUNK 1024
 // MEASURED (MI355X, same box, round 5): on bare buffers of the decoder's size (tools/probes/stream_probe.hip, 176 M
@@ -201,8 +202,8 @@ extern "C" int tell_bertadam_step2(float* param, float* grad, float* m, float* v
   // TELL_ADAM_VAR (A/B aid, read once): 0 = one chunk per iteration, default cache policy (the round-4 kernel's shape);
   // 1 = U 2; 2 = U 4; 3 = U 2 + non-temporal; 4 = U 4 + non-temporal.  tools/probes/stream_probe.hip has the same shapes
   // on bare buffers.
-  static const int var = getenv("TELL_ADAM_VAR") ? atoi(getenv("TELL_ADAM_VAR")) : TELL_ADAM_DEFAULT;
-  static const int grid_env = getenv("TELL_ADAM_GRID") ? atoi(getenv("TELL_ADAM_GRID")) : 4096;
+  const int var = tell_opt(OPT_ADAM_VAR) >= 0 ? (int)tell_opt(OPT_ADAM_VAR) : TELL_ADAM_DEFAULT;
+  const int grid_env = tell_opt(OPT_ADAM_GRID) > 0 ? (int)tell_opt(OPT_ADAM_GRID) : 4096;
   const int U = (var == 1 || var == 3) ? 2 : (var == 2 || var == 4) ? 4 : 1;
   const long iters = (n_chunks + U - 1) / U;
   int g = iters < grid_env ? (int)iters : grid_env;

@@ -14,7 +14,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libtell_hip.so')
+# TELL_LIB: another build of the same ABI (tools/probes/ load csrc/libtell_hip_probes.so, the -DTELL_PROBES build)
+LIB_PATH = os.environ.get('TELL_LIB') or os.path.join(_HERE, 'csrc', 'libtell_hip.so')
 HEADER_PATH = os.path.join(_ROOT, 'include', 'tell_hip.h')
 
 F32, BF16 = 0, 1
@@ -69,7 +70,89 @@ def lib():
             fn = getattr(_lib, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = argtypes
+        _options_from_env()
     return _lib
+
+
+# ---- run-time options of the library (include/tell_hip.h tell_set_option; keys and defaults in csrc/options.h).
+# The library itself reads no environment variable.  For the A/B scripts under tools/ the host mirror translates
+# TELL_<KEY> (e.g. TELL_GEMM_Q4=0) into tell_set_option calls ONCE, when the library is loaded; inside a process use
+# set_option / `with hip.options(gemm_s64=0):`.
+def option_keys():
+    out, i = [], 0
+    while True:
+        k = lib().tell_option_key(i)
+        if k is None:
+            return out
+        out.append(k.decode())
+        i += 1
+
+
+def option_defaults():
+    return {k: lib().tell_option_default(i) for i, k in enumerate(option_keys())}
+
+
+def set_option(key, value):
+    if lib().tell_set_option(key.encode(), int(value)) != 0:
+        raise KeyError('tell_amd: %s' % _lib.tell_last_error().decode())
+
+
+def get_option(key):
+    v = lib().tell_get_option(key.encode())
+    if v == -(1 << 63):
+        raise KeyError('tell_amd: unknown option %r' % key)
+    return v
+
+
+class options:
+    """`with hip.options(gemm_s64=0, conv_tile=2):` - set for the block, previous values restored after it."""
+
+    def __init__(self, **kw):
+        self.kw, self.prev = kw, {}
+
+    def __enter__(self):
+        lib()
+        for k, v in self.kw.items():
+            self.prev[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            set_option(k, v)
+        return False
+
+
+def apply_env(env):
+    """{'TELL_GEMM_Q4': '0', ...} (the spelling the A/B scripts under tools/ use) -> set_option calls; a value of None
+    restores the option's load-time value.  Names that are not library options are ignored (host-side switches)."""
+    lib()
+    for name, v in env.items():
+        k = name[5:].lower() if name.startswith('TELL_') else name
+        if k in _loaded_options:
+            set_option(k, _loaded_options[k] if v is None else int(v))
+
+
+_loaded_options = {}
+
+
+def loaded_options():
+    """{key: value} as they stood right after the library was loaded (defaults + what TELL_<KEY> asked for)."""
+    lib()
+    return dict(_loaded_options)
+
+
+def _options_from_env():
+    i = 0
+    while True:
+        k = _lib.tell_option_key(i)
+        if k is None:
+            return
+        v = os.environ.get('TELL_' + k.decode().upper())
+        if v is not None and v.strip() != '':
+            _lib.tell_set_option(k, int(v))
+        _loaded_options[k.decode()] = _lib.tell_get_option(k)
+        i += 1
 
 
 _tile_queue = {}

@@ -71,7 +71,8 @@ class Trainer:
             # whose CU is taken gets fewer tiles instead of finishing a static share late.  MEASURED on one GPU with N
             # CUs held by idle workgroups (bench.py --cu-hog N, profiles/r04_cu_hog.txt): configs[2] 1565 -> 1423 samples/s
             # with static tile lists for N = 8 / 16 / 32, -> 1498-1514 with the counters (1570 with no CU held).
-            os.environ.setdefault('TELL_Q4_DYNAMIC', '1')
+            if 'TELL_Q4_DYNAMIC' not in os.environ:           # (an explicit choice at load time stands)
+                hip.set_option('q4_dynamic', 1)
         if self.dp:
             # every rank draws its own dropout masks: the counter-hash seed is process-global with the same default on
             # all ranks; the rank is mixed in where the seed is READ (runtime.seed), not written into the global seed
