@@ -253,11 +253,17 @@ int tell_loss_bits(const float* x, const int* n_valid, float* out, tell_stream_t
  * tk int32 / lp fp32 [B,K,K]: the K best continuations of every hypothesis (tell_adaptive_logprob_topk); per sample the
  * K best of cum[parent] + lp / temperature (a finished hypothesis continues with pad at no cost; lowest index wins a
  * tie); in place: cum fp32 [B,K], finished uint8 [B,K], seqs int64 [B,K,L] (column step + 1 written), lps fp32
- * [B,K,L-1] (column step); out: cur int64 [B*K] next input tokens, rows int64 [B*K] the row each survivor descends from. */
+ * [B,K,L-1] (column step); out: cur int64 [B*K] next input tokens, rows int64 [B*K] the row each survivor descends from.
+ * back (optional): the ancestor table int32 [n_back <= 31][B*K] of the DynamicConv rings (tell_dynconv_step), composed in
+ * place with this step's parents: new back[0][r] = rows[r], new back[j][r] = old back[j-1][rows[r]] - the reference's
+ * reorder_incremental_state (dynamic.py:338-342) without moving a row.  counter (optional): device int32 that a captured
+ * decode step reads as its position offset (tell_set_pos_step_ptr); set to `step`, the offset of step + 1. */
 int tell_beam_update(const int* tk, const float* lp, float* cum, uint8_t* finished, long* seqs, float* lps, long* cur,
-                     long* rows, int B, int K, int L, int step, int pad, int eos, float inv_temp, tell_stream_t stream);
+                     long* rows, int B, int K, int L, int step, int pad, int eos, float inv_temp, int* back, int n_back,
+                     int* counter, tell_stream_t stream);
 /* buf[i][p][r][:] <- buf[i][p][rows[r]][:] in place for n <= 8 bf16 buffers [planes[i], M, 1024] (HOST arrays); rows[r]
- * must lie inside r's group of K consecutive rows (dynamic.py:338-342 reorder_incremental_state, all layers at once). */
+ * must lie inside r's group of K consecutive rows (dynamic.py:338-342 reorder_incremental_state, all layers at once) - for
+ * input buffers kept in time order (the layer-by-layer fp32 step); the rings of tell_dynconv_step are never moved. */
 int tell_reorder_rows(int n, void* const* bufs, const int* planes, const long* rows, int M, int C, int K,
                       tell_stream_t stream);
 
@@ -328,10 +334,15 @@ int tell_layernorm_rows(const float* x, long ld_x, const float* gamma, const flo
 int tell_embed_gather_step(const long* ids, int M, int nb, const void* const* tables, const int* lo, const int* hi,
                            const int* dim, const int* off, void* cat, int ktot, const float* pos_table, int pos_rows,
                            int pos_pad, int start_pos, float* pos_out, int E, tell_stream_t stream);
-/* DynamicConv1dTBC with an input buffer, one step (dynamic.py:85-120, :285-336 at T = 1): x [M,C] bf16, hist [K-1][M][C]
- * bf16 (previous K-1 inputs, zero before the caption starts; shifted in place), wt [H*K, C] bf16 (weight_linear, no bias),
- * y [M,C] bf16.  C = H * 64, K <= 32. */
-int tell_dynconv_step(const void* x, void* hist, const void* wt, void* y, int M, int C, int H, int K, tell_stream_t stream);
+/* DynamicConv1dTBC with an input buffer, one step (dynamic.py:85-120, :285-336 at T = 1): x [M,C] bf16, wt [H*K, C] bf16
+ * (weight_linear, no bias), y [M,C] bf16.  C = H * 64, K <= 32.  hist [K][M][C] bf16 is a RING of K planes indexed by
+ * time: the input of step s lives in plane s mod K, in the slot its hypothesis had at step s; planes never written hold
+ * zeros (cleared by the caller per caption).  t = index of this step (+ the registered decode position counter while a
+ * hipGraph of the step is recorded, tell_set_pos_step_ptr); the step reads planes t-1 .. t-K+1 and writes x into plane
+ * t mod K.  back (optional): int32 [>= K-1][M], back[j-1][m] = slot, j steps ago, of the hypothesis now in slot m (beam
+ * search, maintained by tell_beam_update); NULL = m itself. */
+int tell_dynconv_step(const void* x, void* hist, const void* wt, void* y, int M, int C, int H, int K, int t,
+                      const int* back, tell_stream_t stream);
 /* MultiHeadAttention at Tq = 1 against n_ctx <= 4 static key / value caches in one launch (multi_head.py:330-352,
  * :376-475): HOST arrays of n_ctx entries; q[c] / out[c] [B, H*64] with row strides q_sb / o_sb, element (b,s,h,d) of
  * k[c] at k + s*k_ss + (b / beams)*k_sb + h*64 + d (the `beams` hypotheses of a sample - rows b*beams + j - share its
@@ -449,9 +460,10 @@ int tell_adaptive_logprob_argmax(const float* head, long ld_head, int c0, int n_
 /* per-token bookkeeping of the greedy decode loop (transformer_faces_objects.py:443-494) for all B rows in one launch:
    unfinished rows record tok / lp * inv_temp at step i, rows emitting eos are marked finished (done_step = i + 1),
    cur = tok for the next step.  tok int32 [B], lp fp32 [B], finished uint8 [B], ids int64 [B, ld_ids], lps fp32
-   [B, ld_lps], done_step int64 [B], cur int64 [B]. */
+   [B, ld_lps], done_step int64 [B], cur int64 [B].  counter (optional): device int32 that a captured decode step reads
+   as its position offset (tell_set_pos_step_ptr); set to i, the offset of step i + 1. */
 int tell_greedy_update(const int* tok, const float* lp, uint8_t* finished, long* ids, long ld_ids, float* lps,
-                       long ld_lps, long* done_step, long* cur, int B, int i, int eos, float inv_temp,
+                       long ld_lps, long* done_step, long* cur, int B, int i, int eos, float inv_temp, int* counter,
                        tell_stream_t stream);
 
 /* ---- BertAdam (config.yaml:126-149), flat fp32 buffers, tensors CHUNK-aligned */

@@ -1029,7 +1029,10 @@ def test_beam_bookkeeping_kernels_match_the_tensor_formulation():
     """tell_beam_update (candidate scores, top-K per sample, histories gathered by parent, next inputs, parent rows) and
     tell_reorder_rows (every layer's DynamicConv buffer rows follow their hypotheses, in place) against the elementwise /
     gather / topk formulation they replace in CaptionModel._generate_beam, over several steps with random head outputs,
-    finished hypotheses and an EOS token in play."""
+    finished hypotheses and an EOS token in play.  Round 6: the ANCESTOR TABLE of the DynamicConv rings, composed by the same
+    launch - rows pushed into a ring of planes that is never re-ordered, read back through the table, against a history
+    that is physically re-ordered by parent every step (the reference's reorder_incremental_state); and the decode position
+    counter the launch leaves for the next replay of a captured step."""
     from tell_amd import ops
     B, K, L, pad, eos, temp = 5, 4, 12, 1, 2, 0.7
     g = torch.Generator().manual_seed(3)
@@ -1045,6 +1048,12 @@ def test_beam_bookkeeping_kernels_match_the_tensor_formulation():
     bufs = [torch.randn(p, B * K, 1024, generator=g).to(DEV, torch.bfloat16) for p in (2, 6, 0, 14)]
     ref_bufs = [b.clone() for b in bufs]
     base = (torch.arange(B, device=DEV) * K).view(B, 1)
+    NB = 6                                                      # ancestor table: 6 steps back = a ring of 7 planes
+    k_back = torch.arange(B * K, dtype=torch.int32, device=DEV).repeat(NB, 1).contiguous()
+    m_back = k_back.clone()                                    # the tensor formulation (decoders.reorder_incremental_state)
+    ring = torch.zeros(NB + 1, B * K, 8, device=DEV)
+    moved = torch.zeros(NB, B * K, 8, device=DEV)               # most recent first, re-ordered physically
+    counter = torch.full((1,), -7, dtype=torch.int32, device=DEV)
     for i in range(L - 1):
         lp_raw = torch.log_softmax(torch.randn(B, K, 50, generator=g), -1).topk(K, dim=-1)
         tk = lp_raw.indices.to(DEV, torch.int32).contiguous()
@@ -1071,7 +1080,20 @@ def test_beam_bookkeeping_kernels_match_the_tensor_formulation():
         cum = top
         ref_bufs = [b.index_select(1, rows) for b in ref_bufs]
         # ---- kernels
-        ops.call('tell_beam_update', tk, lp_t, k_cum, k_fin, k_seqs, k_lps, k_cur, k_rows, B, K, L, i, pad, eos, 1.0 / temp)
+        xrow = torch.randn(B * K, 8, generator=g).to(DEV)           # what step i pushes: slot r of plane i mod (NB + 1)
+        ring[i % (NB + 1)] = xrow
+        moved = torch.cat([xrow[None], moved[:-1]], 0).index_select(1, rows)
+        ops.call('tell_beam_update', tk, lp_t, k_cum, k_fin, k_seqs, k_lps, k_cur, k_rows, B, K, L, i, pad, eos, 1.0 / temp,
+                 k_back, NB, counter)
+        assert int(counter) == i
+        nb = torch.empty_like(m_back)
+        nb[0] = rows.to(torch.int32)
+        nb[1:] = m_back[:-1].index_select(1, rows)
+        m_back = nb
+        assert torch.equal(k_back, m_back), i
+        for j in range(1, min(i + 1, NB) + 1):                      # step i + 1 reads the row of j steps before it
+            got = ring[(i + 1 - j) % (NB + 1)].gather(0, k_back[j - 1].long()[:, None].expand(-1, 8))
+            assert torch.equal(got, moved[j - 1]), (i, j)
         live = [b for b in bufs if b.shape[0] > 0]
         ops.call('tell_reorder_rows', len(live), ops._ptr_array(live), ops._int_array([b.shape[0] for b in live]), k_rows,
                  B * K, 1024, K)
@@ -1235,14 +1257,32 @@ def test_generation_step_linears_layernorm_and_dynconv_step(M):
     y = torch.empty(M, E, **bf)
     ops.call('tell_layernorm_rows', raw, E, ln.weight, ln.bias, ln.eps, y, E, None, M, E)
     assert rel(y, xn) < 4e-3
-    # DynamicConv step
-    for K in (3, 31):
+    # DynamicConv step on the ring of past inputs (K planes indexed by time; zero planes = before the caption starts):
+    # K + 3 consecutive steps from an empty ring (the ring wraps), greedy (no ancestor table); then one step whose rows find
+    # their past through a random ancestor table (beam search)
+    for K in (3, 7, 31):
         H = 16
         wt = W(H * K, E)
-        hist = R(K - 1, M, E).to(**bf)
-        h0 = hist.clone()
-        ops.call('tell_dynconv_step', x, hist, wt, out, M, E, H, K)
-        taps = torch.softmax((x.float() @ wt.float().t()).view(M, H, K), -1)
-        win = torch.cat([h0, x[None]], 0).float().view(K, M, H, 64)
-        assert rel(out, torch.einsum('mhk,kmhd->mhd', taps, win).reshape(M, E)) < 4e-3
-        assert torch.equal(hist, torch.cat([h0[1:], x[None]], 0))
+        ring = torch.zeros(K, M, E, **bf)
+        past = []                                            # inputs of the previous steps, most recent last
+        for t in range(K + 3):
+            xt = R(M, E).to(**bf)
+            ops.call('tell_dynconv_step', xt, ring, wt, out, M, E, H, K, t, None)
+            taps = torch.softmax((xt.float() @ wt.float().t()).view(M, H, K), -1)
+            hist = ([torch.zeros(M, E, **bf)] * (K - 1) + past)[-(K - 1):]
+            win = torch.stack(hist + [xt], 0).float().view(K, M, H, 64)
+            assert rel(out, torch.einsum('mhk,kmhd->mhd', taps, win).reshape(M, E)) < 4e-3, (K, t)
+            past.append(xt)
+            assert torch.equal(ring[t % K], xt), (K, t)
+        t = K + 3
+        before = ring.clone()
+        back = torch.randint(0, M, (K - 1, M), generator=g).to(DEV, torch.int32)
+        xt = R(M, E).to(**bf)
+        ops.call('tell_dynconv_step', xt, ring, wt, out, M, E, H, K, t, back)
+        taps = torch.softmax((xt.float() @ wt.float().t()).view(M, H, K), -1)
+        hist = [before[(t - j) % K].index_select(0, back[j - 1].long()) for j in range(K - 1, 0, -1)]
+        win = torch.stack(hist + [xt], 0).float().view(K, M, H, 64)
+        assert rel(out, torch.einsum('mhk,kmhd->mhd', taps, win).reshape(M, E)) < 4e-3, K
+        want_ring = before.clone()
+        want_ring[t % K] = xt
+        assert torch.equal(ring, want_ring), K               # exactly one plane written: the one the step does not read

@@ -76,10 +76,12 @@ cases = {
     'fc1+relu     pro0 N4096 K1024': lambda: decode._skinny([x], E, [w1], [b1], [h], F, M, F, E, act=1),
     'fc2+res      pro0 N1024 K4096': lambda: decode._skinny([x4], F, [w2], [b2], [o32], E, M, E, F, res=x, ld_res=E, out_f32=True),
 }
-for K in (3, 31):
-    hist = torch.zeros(max(K - 1, 0), M, E, **bf)
+back_tab = torch.arange(M, dtype=torch.int32, device='cuda').repeat(30, 1).contiguous()
+for K in (3, 7, 15, 31):
+    hist = torch.zeros(K, M, E, **bf)
     wt = W(16 * K, E)
-    cases['dynconv_step K=%d' % K] = (lambda hist=hist, wt=wt, K=K: ops.call('tell_dynconv_step', x, hist, wt, g, M, E, 16, K))
+    cases['dynconv_step K=%d' % K] = (lambda hist=hist, wt=wt, K=K: ops.call('tell_dynconv_step', x, hist, wt, g, M, E, 16, K, 5, None))
+    cases['dynconv_step K=%d + ancestor table' % K] = (lambda hist=hist, wt=wt, K=K: ops.call('tell_dynconv_step', x, hist, wt, g, M, E, 16, K, 5, back_tab))
 print('M = %d' % M)
 for name, fn in cases.items():
     print('%-34s %7.2f us' % (name, timeit(fn)))

@@ -80,11 +80,11 @@ print('fc2+res            %.2e' % rel(o, x4.float() @ w2.float().t() + b2 + x.fl
 for K in (3, 31):
     H = 16
     wt = W(H * K, E)
-    hist = torch.randn(K - 1, M, E, **bf)
+    hist = torch.randn(K, M, E, **bf)                # ring of K planes; step t = K - 1 reads planes K-2 .. 0, writes plane K-1
     h0 = hist.clone()
     y = torch.empty(M, E, **bf)
-    ops.call('tell_dynconv_step', x, hist, wt, y, M, E, H, K)
+    ops.call('tell_dynconv_step', x, hist, wt, y, M, E, H, K, K - 1, None)
     taps = torch.softmax((x.float() @ wt.float().t()).view(M, H, K), -1)
-    win = torch.cat([h0, x[None]], 0).float().view(K, M, H, 64)
+    win = torch.cat([h0[:K - 1], x[None]], 0).float().view(K, M, H, 64)
     want = torch.einsum('mhk,kmhd->mhd', taps, win).reshape(M, E)
-    print('dynconv K=%-2d       %.2e   hist shift ok: %s' % (K, rel(y, want), torch.equal(hist, torch.cat([h0[1:], x[None]], 0))))
+    print('dynconv K=%-2d       %.2e   ring plane ok: %s' % (K, rel(y, want), torch.equal(hist, torch.cat([h0[:K - 1], x[None]], 0))))

@@ -505,95 +505,184 @@ extern "C" int tell_skinny_linear(int n_prob, const void* const* in, long ld_in,
   return K % 1024 == 0 ? skinny_mfma_dispatch<2, 8>(a, n_prob, act, stream, fold) : skinny_mfma_dispatch<2, 2>(a, n_prob, act, stream, fold);
 }
 
-// ------------------------------------------------------------------ DynamicConv step (T = 1, fixed K-1 row buffer)
-// x [M, C] bf16 (the GLU output of this step), hist [K-1][M][C] bf16 (the previous K-1 inputs, zero rows before the
-// caption starts), wt [H*K, C] bf16 (weight_linear).  One wave per (row m, head h), lane = channel d of the head:
+// ------------------------------------------------------------------ DynamicConv step (T = 1, K-plane ring of past inputs)
+// x [M, C] bf16 (the GLU output of this step), wt [H*K, C] bf16 (weight_linear), hist [K planes][M][C] bf16.
 //   logits[k] = x[m,:] . wt[h*K + k,:]; taps = softmax_k(logits)            (dynamic.py:300-304, eval: no DropConnect)
-//   y[m, h*64 + d] = sum_k taps[k] * window[k][m, h*64 + d],  window = hist rows then x   (:306-336, causal)
-//   hist <- window[1:]                                                                   (:95-99)
-// One workgroup per (head, 4 rows): the head's K x C tap weights are staged in LDS once (all requests in flight
-// together), then one wave per row.
+//   y[m, h*64 + d] = sum_k taps[k] * window[k][m, h*64 + d],  window = the K-1 previous inputs, then x   (:306-336, causal)
+//   the input buffer takes x                                                              (:95-99)
+// Round 6 - nothing is moved any more.  Rounds 3-5 kept the buffer as K-1 rows in time order: every step SHIFTED it (K-2
+// planes re-written per layer) and beam search physically re-ordered its rows by parent (tell_reorder_rows: every plane
+// read and written again) - 27 of the 100 MB a beam-4 step wrote.  Now the buffer is a RING of K planes indexed by time
+// (the row of step s lives in plane s mod K: a step writes ONE plane - the one plane it does not read, hence K planes
+// for K-1 past rows) and a hypothesis finds its past through an ANCESTOR table: back[j-1][m] = the slot, j steps ago, of
+// the hypothesis that now sits in slot m (null: m itself - greedy decoding).  The reference's contract is only
+// reorder_incremental_state (dynamic.py:338-342): the beam bookkeeping launch composes the table with this step's parents
+// instead (tell_beam_update).  Planes that were never written hold zeros (the caller clears the ring per caption): the
+// taps that reach before the start of the caption multiply zeros, which is what the reference's narrowing does.
+// t = index of this step = t_host + *step_dev (step_dev: the registered decode position counter while a hipGraph of the
+// step is recorded - one captured launch then serves every position, like the embedder's sinusoid row).
+// One workgroup per (head, R rows).  The tap logits come off the matrix cores (rounds 3-5: K x C dot products per row on
+// the VALU against K x C weights staged through LDS, 64 KB per workgroup at K = 31, with a 64-lane sum per tap): the 4
+// waves split C, load their mfma_f32_16x16x32_bf16 fragments straight from memory (A: the R rows, B: the head's K <= 32
+// tap rows as two column tiles) and fold the partial tiles through LDS; every past row's load is issued before the first
+// MFMA; softmax by half-waves (lane = tap); then each thread sums its R / 4 channels over the K taps.
+// KB: taps the unrolled loops cover (4 / 8 / 16 / 32 >= K)
+template <int R, int NK, bool HAS_BACK, int KB>
 __global__ __launch_bounds__(256) void dynconv_step_kernel(const uint16_t* __restrict__ x, uint16_t* hist,
                                                            const uint16_t* __restrict__ wt, uint16_t* __restrict__ y,
-                                                           int M, int C, int H, int K) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char dc_smem[];
-  uint16_t* Wl = reinterpret_cast<uint16_t*>(dc_smem);                  // [K][C + 8]
+                                                           int M, int H, int K, int t_host,
+                                                           const uint32_t* __restrict__ step_dev,
+                                                           const int* __restrict__ back) {
+  constexpr int C = NK * 128, VEC = R / 4, TPR = 64 / VEC;             // channels per thread, threads per row
+  __shared__ float red[4][R][33];
+  __shared__ float prob[R][32];
   const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m = blockIdx.y * 4 + wave;
-  const int WS = C + 8, cpr = C / 8, total = K * cpr;
-  sk_u4 wreg[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int c = tid + i * 256;
-    if (c < total) wreg[i] = *reinterpret_cast<const sk_u4*>(wt + (long)(h * K + c / cpr) * C + (c % cpr) * 8);
-  }
+  const int lr = lane & 15, lg = lane >> 4;
+  const int m0 = blockIdx.y * R;
+  const int t = t_host + (step_dev ? (int)*step_dev : 0);
+  // ---- tap-sum role of this thread: row r, channels c0 .. c0 + VEC - 1 of the head
+  const int r = tid / TPR, c0 = (tid % TPR) * VEC, m = m0 + r;
   const bool live = m < M;
-  const uint16_t* xr = x + (long)(live ? m : 0) * C;
-  const int nx = C / 512;                                               // 16-byte pieces of the row per lane (<= 4)
-  sk_u4 xv[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-    if (j < nx) xv[j] = *reinterpret_cast<const sk_u4*>(xr + lane * 8 + j * 512);
-  const int ch = h * 64 + lane;
+  const int ch = h * 64 + c0;
+  // (plain 32-bit registers: lo = channels 0 / 0-1, hi = channels 2-3 when a thread owns four)
+  uint32_t hlo[KB - 1], hhi[KB - 1];
   const long plane = (long)M * C;
-  uint16_t hv[32];
+  auto fetch = [](const uint16_t* src, uint32_t& lo, uint32_t& hi) __attribute__((always_inline)) {
+    if constexpr (VEC == 1) lo = (uint32_t)*src;
+    else if constexpr (VEC == 2) lo = *reinterpret_cast<const uint32_t*>(src);
+    else { const uint2 w = *reinterpret_cast<const uint2*>(src); lo = w.x; hi = w.y; }
+  };
+  // (branch-free: a dead tap j >= K re-reads the row of tap K - 1 and gets weight 0 below, a dead row m >= M reads row M - 1
+  //  and stores nothing - 31 guarded loads made the register allocator spill every fragment around 31 branches)
+  const int mm = live ? m : M - 1;
+  int pl = (t - 1) % K;
+  pl = pl < 0 ? pl + K : pl;
+  const int* bk = back + mm;
+#pragma clang loop unroll(full)
+  for (int j = 1; j < KB; ++j) {
+    int slot = mm;
+    if constexpr (HAS_BACK) slot = *bk;
+    hhi[j - 1] = 0u;
+    fetch(hist + pl * plane + (long)slot * C + ch, hlo[j - 1], hhi[j - 1]);
+    const bool more = j + 1 < K;
+    pl = more ? (pl == 0 ? K - 1 : pl - 1) : pl;
+    if constexpr (HAS_BACK) bk = more ? bk + M : bk;
+  }
+  uint32_t clo = 0u, chi = 0u;
+  fetch(x + (long)mm * C + ch, clo, chi);
+  // ---- tap logits of the R rows: [16 (R live), C] . [32 (K live), C]^T, C split over the waves
+  {
+    const int ma = m0 + (lr < R ? lr : R - 1);
+    const uint16_t* ap = x + (long)(ma < M ? ma : M - 1) * C + wave * (C / 4) + lg * 8;
+    const uint16_t* bp[2];
 #pragma unroll
-  for (int k = 0; k < 32; ++k) hv[k] = (live && k < K - 1) ? hist[k * plane + (long)m * C + ch] : (uint16_t)0;
-  const uint16_t cur = xr[ch];
+    for (int ct = 0; ct < 2; ++ct) {
+      const int tap = ct * 16 + lr;
+      bp[ct] = wt + (long)(h * K + (tap < K ? tap : K - 1)) * C + wave * (C / 4) + lg * 8;
+    }
+    sk_u4 fa[NK], fb[2][NK];
+    constexpr bool two = KB > 16;                                        // (K <= 16: the second column tile has no live tap)
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int c = tid + i * 256;
-    if (c < total) *reinterpret_cast<sk_u4*>(Wl + (c / cpr) * WS + (c % cpr) * 8) = wreg[i];
+    for (int i = 0; i < NK; ++i) {
+      fb[0][i] = *reinterpret_cast<const sk_u4*>(bp[0] + i * 32);
+      fb[1][i] = sk_u4{0u, 0u, 0u, 0u};
+      if (two) fb[1][i] = *reinterpret_cast<const sk_u4*>(bp[1] + i * 32);
+      fa[i] = *reinterpret_cast<const sk_u4*>(ap + i * 32);
+    }
+    typedef float c4 __attribute__((ext_vector_type(4)));
+    c4 acc[2] = {c4{0.f, 0.f, 0.f, 0.f}, c4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sk_bf16x8, fa[i]), __builtin_bit_cast(sk_bf16x8, fb[0][i]),
+                                                       acc[0], 0, 0, 0);
+      if (two)
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sk_bf16x8, fa[i]), __builtin_bit_cast(sk_bf16x8, fb[1][i]),
+                                                         acc[1], 0, 0, 0);
+    }
+    // C layout: column (tap) = lane & 15, row = (lane >> 4) * 4 + register
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (lg * 4 + q < R) red[wave][lg * 4 + q][ct * 16 + lr] = acc[ct][q];
+  }
+  __syncthreads();
+  // ---- softmax over the taps: a half-wave per row, lane = tap
+  for (int o = tid; o < R * 32; o += 256) {
+    const int rr = o >> 5, k = o & 31;
+    float l = k < K ? (red[0][rr][k] + red[1][rr][k]) + (red[2][rr][k] + red[3][rr][k]) : -INFINITY;
+    float mx = l;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 32));
+    const float e = k < K ? __expf(l - mx) : 0.f;
+    float den = e;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) den += __shfl_xor(den, off, 32);
+    prob[rr][k] = e / den;
   }
   __syncthreads();
   if (!live) return;
-  float logit[32];
-  float mx = -INFINITY;
+  float out[VEC];
 #pragma unroll
-  for (int k = 0; k < 32; ++k) {
-    logit[k] = 0.f;
-    if (k < K) {
+  for (int v = 0; v < VEC; ++v) out[v] = 0.f;
+  auto elem = [](uint32_t lo, uint32_t hi, int v) __attribute__((always_inline)) -> float {
+    const uint32_t word = v < 2 ? lo : hi;
+    return __uint_as_float((VEC == 1 || (v & 1) == 0) ? (word << 16) : (word & 0xffff0000u));
+  };
+  // window[K - 1 - j] = the input j steps ago
+#pragma clang loop unroll(full)
+  for (int j = 1; j < KB; ++j) {
+    const float pk = j < K ? prob[r][j < K ? K - 1 - j : 0] : 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (j < nx) logit[k] = sk_dot8(xv[j], *reinterpret_cast<const sk_u4*>(Wl + k * WS + lane * 8 + j * 512), logit[k]);
-      logit[k] = sk_wave_sum(logit[k]);
-      mx = fmaxf(mx, logit[k]);
-    }
+    for (int v = 0; v < VEC; ++v) out[v] = fmaf(pk, elem(hlo[j - 1], hhi[j - 1], v), out[v]);
   }
-  float den = 0.f;
+  {
+    const float pk = prob[r][K - 1];
 #pragma unroll
-  for (int k = 0; k < 32; ++k)
-    if (k < K) { logit[k] = __expf(logit[k] - mx); den += logit[k]; }
-  const float inv = 1.f / den;
-  float out = 0.f;
-  // window[k] = hist[k] for k < K-1, x for k = K-1; the shifted window is written back
-#pragma unroll
-  for (int k = 0; k < 32; ++k)
-    if (k < K - 1) {
-      out += logit[k] * inv * __uint_as_float((uint32_t)hv[k] << 16);
-      if (k > 0) hist[(k - 1) * plane + (long)m * C + ch] = hv[k];
-    }
-  float last = 0.f;
-#pragma unroll
-  for (int k = 0; k < 32; ++k)
-    if (k == K - 1) last = logit[k];
-  out += last * inv * __uint_as_float((uint32_t)cur << 16);
-  if (K > 1) hist[(long)(K - 2) * plane + (long)m * C + ch] = cur;
-  y[(long)m * C + ch] = f2bf(out);
+    for (int v = 0; v < VEC; ++v) out[v] = fmaf(pk, elem(clo, chi, v), out[v]);
+  }
+  int pw = t % K;
+  pw = pw < 0 ? pw + K : pw;
+  uint16_t* hd = hist + pw * plane + (long)m * C + ch;
+  uint16_t* yd = y + (long)m * C + ch;
+  if constexpr (VEC == 1) {
+    *hd = (uint16_t)clo;
+    *yd = f2bf(out[0]);
+  } else if constexpr (VEC == 2) {
+    *reinterpret_cast<uint32_t*>(hd) = clo;
+    *reinterpret_cast<uint32_t*>(yd) = (uint32_t)f2bf(out[0]) | ((uint32_t)f2bf(out[1]) << 16);
+  } else {
+    *reinterpret_cast<uint2*>(hd) = make_uint2(clo, chi);
+    *reinterpret_cast<uint2*>(yd) = make_uint2((uint32_t)f2bf(out[0]) | ((uint32_t)f2bf(out[1]) << 16),
+                                               (uint32_t)f2bf(out[2]) | ((uint32_t)f2bf(out[3]) << 16));
+  }
 }
-extern "C" int tell_dynconv_step(const void* x, void* hist, const void* wt, void* y, int M, int C, int H, int K,
-                                 hipStream_t stream) {
-  TELL_REQUIRE(M > 0 && H > 0 && C == H * 64 && K >= 1 && K <= 32 && C % 512 == 0 && C <= 2048, "dynconv_step: head width 64, K <= 32");
-  const size_t smem = (size_t)K * (C + 8) * 2;
-  TELL_REQUIRE(K * (C / 8) <= 16 * 256 && smem <= 160 * 1024, "dynconv_step: tap weights of a head must fit LDS");
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dynconv_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
+template <int R>
+static int dynconv_step_launch(const uint16_t* x, uint16_t* hist, const uint16_t* wt, uint16_t* y, int M, int C, int H, int K,
+                               int t, const int* back, hipStream_t stream) {
+  const dim3 grid(H, (M + R - 1) / R), block(256);
+#define DCS2(NK_, KB_) do { if (back) hipLaunchKernelGGL((dynconv_step_kernel<R, NK_, true, KB_>), grid, block, 0, stream, x, hist, wt, y, M, H, K, t, g_tell_pos_step, back); \
+                     else hipLaunchKernelGGL((dynconv_step_kernel<R, NK_, false, KB_>), grid, block, 0, stream, x, hist, wt, y, M, H, K, t, g_tell_pos_step, back); } while (0)
+#define DCS(NK_) do { if (K <= 4) DCS2(NK_, 4); else if (K <= 8) DCS2(NK_, 8); else if (K <= 16) DCS2(NK_, 16); else DCS2(NK_, 32); } while (0)
+  switch (C / 128) {
+    case 4: DCS(4); break;
+    case 8: DCS(8); break;
+    default: DCS(16); break;
   }
-  hipLaunchKernelGGL(dynconv_step_kernel, dim3(H, (M + 3) / 4), dim3(256), smem, stream, (const uint16_t*)x, (uint16_t*)hist,
-                     (const uint16_t*)wt, (uint16_t*)y, M, C, H, K);
+#undef DCS
+#undef DCS2
   return tell_check_launch("dynconv_step");
+}
+extern "C" int tell_dynconv_step(const void* x, void* hist, const void* wt, void* y, int M, int C, int H, int K, int t,
+                                 const int* back, hipStream_t stream) {
+  TELL_REQUIRE(M > 0 && H > 0 && C == H * 64 && K >= 2 && K <= 32 && (C == 512 || C == 1024 || C == 2048), "dynconv_step: head width 64, 2 <= K <= 32, C = 512 / 1024 / 2048");
+  TELL_REQUIRE(t >= 0 || g_tell_pos_step, "dynconv_step: step index");
+  // rows per workgroup: enough workgroups to cover the chip at 32 rows (16 heads x 8), fewer re-reads of the head's tap
+  // weights where the rows are many
+  const uint16_t* xp = (const uint16_t*)x; uint16_t* hp = (uint16_t*)hist; const uint16_t* wp = (const uint16_t*)wt; uint16_t* yp = (uint16_t*)y;
+  if ((long)H * ((M + 3) / 4) <= 256) return dynconv_step_launch<4>(xp, hp, wp, yp, M, C, H, K, t, back, stream);
+  if ((long)H * ((M + 7) / 8) <= 512) return dynconv_step_launch<8>(xp, hp, wp, yp, M, C, H, K, t, back, stream);
+  return dynconv_step_launch<16>(xp, hp, wp, yp, M, C, H, K, t, back, stream);
 }
 
 // ------------------------------------------------------------------ one-query attention over up to 4 cached contexts
@@ -863,13 +952,19 @@ __global__ __launch_bounds__(64) void beam_update_kernel(const int* __restrict__
                                                          float* __restrict__ cum, uint8_t* __restrict__ finished,
                                                          long* __restrict__ seqs, float* __restrict__ lps,
                                                          long* __restrict__ cur, long* __restrict__ rows, int K, int L,
-                                                         int step, int pad, int eos, float inv_temp) {
+                                                         int step, int pad, int eos, float inv_temp, int* back, int n_back,
+                                                         int M, int* counter) {
   __shared__ long s_seq[8 * 256];
   __shared__ float s_lp[8 * 256];
   __shared__ int s_parent[8], s_tok[8];
   __shared__ float s_top[8], s_dlp[8];
   __shared__ uint8_t s_fin[8];
+  __shared__ int s_back[31 * 8];
   const int b = blockIdx.x, t = threadIdx.x;
+  // the ancestor table of the DynamicConv rings (dynconv_step_kernel): this sample's K columns, before the update
+  if (back)
+    for (int e = t; e < n_back * K; e += 64) s_back[e] = back[(long)(e / K) * M + b * K + e % K];
+  if (counter && b == 0 && t == 0) *counter = step;            // position offset of the NEXT replay of a captured step: (step + 1) - 1
   const int j = t / K, m = t % K;
   float score = -INFINITY;
   int token = pad;
@@ -918,16 +1013,27 @@ __global__ __launch_bounds__(64) void beam_update_kernel(const int* __restrict__
     cur[b * K + t] = s_tok[t];
     rows[b * K + t] = (long)b * K + s_parent[t];
   }
+  // slot r now holds a child of slot parent[r]: one step ago it sat there, j steps ago where the parent sat j - 1 steps ago
+  if (back)
+    for (int e = t; e < n_back * K; e += 64) {
+      const int j = e / K, r = e % K;
+      back[(long)j * M + b * K + r] = j == 0 ? b * K + s_parent[r] : s_back[(j - 1) * K + s_parent[r]];
+    }
 }
 // tk int32 / lp fp32 [B,K,K] (the K best continuations of every hypothesis, best first), cum fp32 [B,K], finished uint8
 // [B,K], seqs int64 [B,K,L], lps fp32 [B,K,L-1] - all updated in place -, cur int64 [B*K] (next input tokens), rows
 // int64 [B*K] (row each surviving hypothesis descends from).  K <= 8, L <= 256.
+// back (optional): the ancestor table int32 [n_back <= 31][B*K] of the DynamicConv rings (tell_dynconv_step), composed in
+// place with this step's parents - the reference's reorder_incremental_state (dynamic.py:338-342) without moving a row.
+// counter (optional): device int32 that the captured decode step reads as its position offset; set to `step` (= the
+// offset of step + 1 for a graph captured at step 1).
 extern "C" int tell_beam_update(const int* tk, const float* lp, float* cum, uint8_t* finished, long* seqs, float* lps,
                                 long* cur, long* rows, int B, int K, int L, int step, int pad, int eos, float inv_temp,
-                                hipStream_t stream) {
+                                int* back, int n_back, int* counter, hipStream_t stream) {
   TELL_REQUIRE(B > 0 && K >= 1 && K <= 8 && L >= 2 && L <= 256 && step >= 0 && step + 1 < L, "beam_update: K <= 8, L <= 256");
+  TELL_REQUIRE(!back || (n_back >= 1 && n_back <= 31), "beam_update: ancestor table of 1 .. 31 steps");
   hipLaunchKernelGGL(beam_update_kernel, dim3(B), dim3(64), 0, stream, tk, lp, cum, finished, seqs, lps, cur, rows, K, L,
-                     step, pad, eos, inv_temp);
+                     step, pad, eos, inv_temp, back, back ? n_back : 0, B * K, counter);
   return tell_check_launch("beam_update");
 }
 

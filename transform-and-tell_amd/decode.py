@@ -62,7 +62,8 @@ def _ints(vals):
 def usable(dec, X, incremental_state, kv_cache):
     """The fused step covers what the expt/ configs build: post-LN layers, GLU + DynamicConv with 64-wide heads,
     bf16, eval, a static (fixed-shape) incremental state and projected K/V."""
-    if not (ENABLED and kv_cache is not None and incremental_state is not None and incremental_state.get('_static')):
+    if not (ENABLED and kv_cache is not None and incremental_state is not None and incremental_state.get('_static') and
+            incremental_state.get('_ring')):
         return False
     if dec.training or not X.is_cuda or X.dtype != torch.bfloat16 or ops.rt.compute_dtype() != torch.bfloat16:
         return False
@@ -72,7 +73,7 @@ def usable(dec, X, incremental_state, kv_cache):
     for layer in dec.layers:
         conv = layer.conv
         if (layer.normalize_before or layer.need_attn or not layer.glu or type(conv).__name__ != 'DynamicConv1dTBC' or
-                layer.conv_dim != E or E % 512 or conv.num_heads * 64 != E or conv.kernel_size > 32 or
+                layer.conv_dim != E or E % 512 or conv.num_heads * 64 != E or not conv.ring_usable() or
                 conv.weight_linear.bias is not None or not 1 <= len(layer.context_names) <= 4 or
                 layer.fc1.out_features % 256):
             return False
@@ -269,8 +270,9 @@ def decoder_step(dec, X, contexts, state, kv_cache):
                     betas=[ln_in.bias], eps=ln_in.eps, stats_out=st_in, act=2)
         c = torch.empty(M, C, **bf)
         hist = state[conv._state_key]
-        assert hist.is_contiguous() and hist.shape[1] == M
-        call('tell_dynconv_step', g, hist, ops.weight(conv.weight_linear.weight), c, M, C, H, K)
+        assert hist.is_contiguous() and hist.shape[1] == M and hist.shape[0] == K
+        call('tell_dynconv_step', g, hist, ops.weight(conv.weight_linear.weight), c, M, C, H, K, int(state['_t_cur']),
+             state.get('_back'))
         w2, _ = ops.wn_weight(layer.linear2.weight_g, layer.linear2.weight_v)
         raw3 = torch.empty(M, E, **f32)
         raw3_bf = torch.empty(M, E, **bf) if fold else None

@@ -211,6 +211,10 @@ class _DynamicConvDecoderBase(Decoder):
         if self.training and torch.is_grad_enabled():
             ops.wn_prepare(self._wn_pairs())          # every weight-normalised working weight of the step in one launch
         X = self.embedder(prev_target, incremental_state=incremental_state)      # :98  [B,T,E] view
+        if incremental_state is not None and incremental_state.get('_ring'):
+            # index of this step for the DynamicConv rings (host part; a captured step adds the device counter)
+            incremental_state['_t_cur'] = incremental_state.get('_t', 0)
+            incremental_state['_t'] = incremental_state['_t_cur'] + 1
         X = X.transpose(0, 1)                                                      # :109 T x B x C (contiguous)
         X = ops.dropout(X, self.dropout, self.training)                            # :106
         contexts_t = None
@@ -274,17 +278,53 @@ class _DynamicConvDecoderBase(Decoder):
         out = self.adaptive_softmax.get_log_prob(net_output[0])
         return out if log_probs else out.exp()
 
-    def static_incremental_state(self, batch, device, dtype):
-        """Incremental state of fixed shape (every DynamicConv buffer K-1 zero rows) for the captured decode step."""
+    def static_incremental_state(self, batch, device, dtype, beam=False):
+        """Incremental state of fixed shape for the captured decode step.  Where every layer's convolution takes the step
+        kernel (bf16, 64-wide heads: csrc/decode.hip tell_dynconv_step) the input buffers are RINGS: K planes indexed by
+        time, never shifted, and - beam search - never re-ordered: `_back` [Kmax-1, batch] int32 says in which slot a
+        hypothesis' past rows lie (reorder_incremental_state composes it with the parents).  Otherwise (fp32 parity mode,
+        other convolution types) every buffer is K-1 zero rows in time order, shifted and re-ordered physically."""
         st = {'_static': True}
-        for layer in self.layers:
-            conv = layer.conv
-            st[conv._state_key] = torch.zeros(conv.kernel_size - 1, batch, conv.input_size, dtype=dtype, device=device)
+        convs = [layer.conv for layer in self.layers]
+        ring = (dtype == torch.bfloat16 and torch.device(device).type == 'cuda' and
+                all(hasattr(c, 'ring_usable') and c.ring_usable() for c in convs))
+        for conv in convs:
+            st[conv._state_key] = torch.zeros(conv.kernel_size - (0 if ring else 1), batch, conv.input_size, dtype=dtype,
+                                              device=device)
+        if ring:
+            st['_ring'] = True
+            if beam:
+                kmax = max(c.kernel_size for c in convs)
+                st['_back'] = torch.arange(batch, dtype=torch.int32, device=device).repeat(max(kmax - 1, 1), 1).contiguous()
         return st
+
+    @staticmethod
+    def reset_static_state(st):
+        """A new caption batch on the same buffers: empty history, step 0."""
+        for k, s in st.items():
+            if torch.is_tensor(s):
+                if k == '_back':
+                    s.copy_(torch.arange(s.shape[1], dtype=torch.int32, device=s.device).expand_as(s))
+                else:
+                    s.zero_()
+        st.pop('_t', None)
+        st.pop('_t_cur', None)
 
     def reorder_incremental_state(self, incremental_state, new_order):
         """Beam search: row r of the new state is row new_order[r] of the old one (dynamic.py:338-342)."""
         if incremental_state is None:
+            return
+        if incremental_state.get('_ring'):
+            # rings: nothing moves - slot r's past is where its parent's past was; one step ago it sat in the parent's slot
+            back = incremental_state.get('_back')
+            if back is None:
+                raise RuntimeError('ring-buffer decode state without an ancestor table: create it with beam=True')
+            order = new_order.to(torch.int32)
+            nb = torch.empty_like(back)
+            nb[0] = order
+            if back.shape[0] > 1:
+                nb[1:] = back[:-1].index_select(1, new_order)
+            back.copy_(nb)
             return
         for key in incremental_state:
             if 'Conv1dTBC' in key:

@@ -398,9 +398,10 @@ class CaptionModel(Model):
             fin8 = finished.to(torch.uint8)
             step.cur.copy_(cur)
         for i in range(gen_len if fused else 0):
-            tok, lp = step(i, None)
+            # (the bookkeeping launch of step i - 1 left the position offset of step i in the device counter: no fill launch)
+            tok, lp = step(i, None, counter_set=i > 0)
             ops.call('tell_greedy_update', tok.reshape(B), lp.reshape(B), fin8, ids, ids.stride(0), lps, lps.stride(0),
-                     done_step, step.cur, B, i, int(eos), 1.0 / float(self.sampling_temp))
+                     done_step, step.cur, B, i, int(eos), 1.0 / float(self.sampling_temp), step.counter)
             if (i + 1) % check_every == 0 and bool(fin8.all()):
                 break
         for i in range(0 if fused else gen_len):
@@ -462,7 +463,7 @@ class CaptionModel(Model):
                 # (key-padding masks as the uint8 the attention kernels read: converted once per caption batch)
                 'ctx': {k: torch.empty_like(v, dtype=torch.uint8 if v.dtype == torch.bool else v.dtype)
                         for k, v in contexts.items() if torch.is_tensor(v)},
-                'state': dec.static_incremental_state(B, dev, dtype),
+                'state': dec.static_incremental_state(B, dev, dtype, beam=bool(topk)),
             }
             po = dec.embedder.token_embedder_position            # the table must already cover the longest caption
             po.next_start(gen_len + 2, None)
@@ -472,9 +473,7 @@ class CaptionModel(Model):
                     s.copy_(t)
         for k, s in h['ctx'].items():
             s.copy_(contexts[k])
-        for k, s in h['state'].items():
-            if torch.is_tensor(s):
-                s.zero_()
+        dec.reset_static_state(h['state'])
         pos_key = dec.embedder.token_embedder_position._state_key
         h['state'].pop(pos_key, None)
 
@@ -484,7 +483,7 @@ class CaptionModel(Model):
             out = dec({self.index: h['cur']}, h['ctx'], incremental_state=h['state'], kv_cache=h['kv'])
             return head(out[0][:, -1:])
 
-        def step(i, cur):
+        def step(i, cur, counter_set=False):
             if cur is not None:                                   # (None: the caller already wrote step.cur)
                 h['cur'].copy_(cur)
             if h['graph'] is None and i != 1:
@@ -507,12 +506,16 @@ class CaptionModel(Model):
                     return run()
             if h['graph'] is False:
                 return run()
-            h['counter'].fill_(i - h['base'])                     # position offset of this step (may be -1)
+            if not counter_set:
+                h['counter'].fill_(i - h['base'])                 # position offset of this step (may be -1)
             h['graph'].replay()
             return h['out']
 
         def reorder(rows, group=0):                               # in place: the buffers are part of the graph
-            bufs = [s for s in h['state'].values() if torch.is_tensor(s) and s.shape[0] > 0]
+            if h['state'].get('_ring'):                           # rings: only the ancestor table changes
+                dec.reorder_incremental_state(h['state'], rows)
+                return
+            bufs = [s for k_, s in h['state'].items() if 'Conv1dTBC' in k_ and torch.is_tensor(s) and s.shape[0] > 0]
             if (group and 1 <= group <= 8 and bufs and all(s.dtype == torch.bfloat16 and s.is_contiguous() and
                                                            s.shape[2] == 1024 for s in bufs) and len(bufs) <= 8):
                 # rows[r] lies inside r's group of `group` hypotheses: every layer's buffer in ONE launch
@@ -523,6 +526,8 @@ class CaptionModel(Model):
                 s.copy_(s.index_select(1, rows))
         step.reorder = reorder
         step.cur = h['cur']
+        step.counter = h['counter']                               # (base 1: the offset of step i is i - 1)
+        step.back = h['state'].get('_back')                       # ancestor table of the DynamicConv rings, or None
         return step
 
     @torch.no_grad()
@@ -559,11 +564,15 @@ class CaptionModel(Model):
             fin8 = finished.to(torch.uint8).contiguous()
             rows = torch.empty(B * K, dtype=torch.long, device=dev)
             step.cur.copy_(cur)
+            ring = step.back is not None
             for i in range(gen_len):
-                tk, lp = step(i, None)
+                tk, lp = step(i, None, counter_set=i > 0)
+                # (ring buffers: the same launch composes the ancestor table with this step's parents - no row of any
+                #  layer's DynamicConv buffer is moved; time-ordered buffers: one launch re-orders every layer's rows)
                 ops.call('tell_beam_update', tk, lp, cum, fin8, seqs, lps, step.cur, rows, B, K, gen_len + 1, i, int(pad),
-                         int(eos), 1.0 / float(self.sampling_temp))
-                step.reorder(rows, K)
+                         int(eos), 1.0 / float(self.sampling_temp), step.back, step.back.shape[0] if ring else 0, step.counter)
+                if not ring:
+                    step.reorder(rows, K)
                 if (i + 1) % check_every == 0 and bool(fin8.all()):
                     n_steps = i + 1
                     break

@@ -36,14 +36,17 @@ class DynamicConv1dTBC(nn.Module):
             # the start multiply zero rows, which is what the reference's narrowing does (dynamic.py:306-311).
             prev = incremental_state[self._state_key]
             n_hist = prev.shape[0]
-            if self._step_kernel_usable(X, prev):
-                # one token: tap logits of the new row, tap softmax, K-tap sum over buffer + row and the buffer shift as
-                # ONE launch (tell_dynconv_step, the kernel of the fused decode step) - not the K-row concatenation, a
-                # tap-logit GEMM over all K rows and the training kernel for K outputs of which one is kept
+            if incremental_state.get('_ring'):
+                # one token: tap logits of the new row (matrix cores), tap softmax, K-tap sum over the ring of past rows +
+                # the row, and the row's store into the ring as ONE launch (tell_dynconv_step, the kernel of the fused decode
+                # step) - not the K-row concatenation, a tap-logit GEMM over all K rows and the training kernel for K outputs
+                # of which one is kept
+                if not self._step_kernel_usable(X, prev):
+                    raise RuntimeError('ring-buffer decode state with an input the step kernel does not take')
                 M, C = X.shape[1], X.shape[2]
                 y = torch.empty(1, M, C, dtype=X.dtype, device=X.device)
                 ops.call('tell_dynconv_step', X.reshape(M, C), prev, ops.weight(self.weight_linear.weight), y, M, C,
-                         self.num_heads, self.kernel_size)
+                         self.num_heads, self.kernel_size, int(incremental_state['_t_cur']), incremental_state.get('_back'))
                 return y
             X = torch.cat([prev, X], dim=0)
             if n_hist:
@@ -61,12 +64,17 @@ class DynamicConv1dTBC(nn.Module):
     def _logits(self, X):
         return self.weight_linear(X)
 
-    def _step_kernel_usable(self, X, prev):
+    def ring_usable(self):
+        """tell_dynconv_step takes this module (its limits, mirrored): taps predicted from the input without a bias, 64-wide
+        heads, 2 <= K <= 32, C = 512 / 1024 / 2048, bf16 compute."""
         C, H, K = self.input_size, self.num_heads, self.kernel_size
-        return (type(self) is DynamicConv1dTBC and not self.training and X.is_cuda and X.dtype == torch.bfloat16 and
-                X.shape[0] == 1 and X.is_contiguous() and prev.is_contiguous() and prev.dtype == torch.bfloat16 and
-                prev.shape[0] == K - 1 and K >= 2 and K <= 32 and C == H * 64 and C % 512 == 0 and C <= 2048 and
+        return (type(self) is DynamicConv1dTBC and 2 <= K <= 32 and C == H * 64 and C in (512, 1024, 2048) and
                 self.weight_linear.bias is None and ops.rt.compute_dtype() == torch.bfloat16)
+
+    def _step_kernel_usable(self, X, prev):
+        return (self.ring_usable() and not self.training and X.is_cuda and X.dtype == torch.bfloat16 and X.shape[0] == 1 and
+                X.is_contiguous() and prev.is_contiguous() and prev.dtype == torch.bfloat16 and
+                prev.shape[0] == self.kernel_size and prev.shape[1] == X.shape[1])
 
     def reorder_incremental_state(self, incremental_state, new_order):
         buf = incremental_state.get(self._state_key)
