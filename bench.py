@@ -48,6 +48,20 @@ def _cpu_model():
         return 'unknown'
 
 
+def _physical_cores():
+    """Physical cores of the host: distinct (physical id, core id) pairs of /proc/cpuinfo (None if it cannot be read)."""
+    try:
+        seen, phys = set(), None
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('physical id'):
+                phys = ln.split(':')[1].strip()
+            elif ln.startswith('core id'):
+                seen.add((phys, ln.split(':')[1].strip()))
+        return len(seen) or None
+    except OSError:
+        return None
+
+
 def measure_gemm_traffic(kernel, batch):
     """HBM bytes per launch of the dominant GEMM kernel, MEASURED in this run: two rocprofv3 passes (--pmc FETCH_SIZE,
     --pmc WRITE_SIZE; counters in their own runs with --kernel-trace only, as MI355X_MICROARCH.md prescribes) over
@@ -176,6 +190,9 @@ def cpu_baseline(model_name='faces_objects', sample_b=4, gen_b=8, budget_s=30.0)
                                      's_per_token_step': round(dt / steps, 3), 'batch': gen_b, 'threads': cores,
                                      'note': 'decoder only, %d steps timed, scaled to the 100-step cap' % steps}
     return {'value': legs['full_step']['samples_per_s'], 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
+            'threads_used': cores, 'host_logical_cpus': os.cpu_count(), 'host_physical_cores': _physical_cores(),
+            'cores_note': '`cores` = the threads the baseline ran on (its best configuration: torch stops scaling on this '
+                          'workload at 16-32 threads, tools/cpu_thread_sweep.py); the host has `host_physical_cores` cores',
             'cpu_model': _cpu_model(),
             'sample': 'fp32 CPU oracle (torch, %d threads): 2 warmed full optimisation steps of the %s model '
                       '(ResNet-152 + RoBERTa-large fwd, decoder fwd+loss+bwd, BertAdam) on %d samples; other legs '
@@ -267,6 +284,7 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
         torch.cuda.synchronize()
 
     wgrad_default = tell_amd.ops._WGRAD['enabled']
+    legs = []                                   # which parts of this function this rank ran (every rank must run the same)
 
     def set_serial(flag):
         """One stream for everything (flag) or the overlapped production schedule (not flag)."""
@@ -296,6 +314,11 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
     for i in range(args.warmup):
         trainer.train_one_batch(fresh(batches[i % 2]), next_batch=nxt(i))
     sync()
+    # clock settling: an idle MI355X needs a few hundred milliseconds of load before its clocks stop moving (the first
+    # 20-step window of a fresh process read 1-3 % off the later ones); untimed, like the warm-up
+    for i in range(getattr(args, 'burn_in', 0)):
+        trainer.train_one_batch(fresh(batches[(args.warmup + i) % 2]), next_batch=nxt(args.warmup + i))
+    sync()
     if want_prof:
         prof.reset_records()
     if trainer.dp:
@@ -311,22 +334,38 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
         hog = subprocess.Popen([sys.executable, os.path.abspath(__file__), '--hog-child', str(int(args.cu_hog))],
                                stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
         assert hog.stdout.readline().strip() == 'ready', 'cu-hog child did not start'
+    # The timed region is a WINDOW of exactly --steps steps bracketed by barrier + synchronize on both sides.  It is run
+    # `windows` times back to back and the MEDIAN window is the headline (`value`, `ms_per_step`); every window is in the
+    # line (`windows_ms_per_step`, `spread`): one 0.4 s window cannot resolve a 2 % change on this pool.
     dec_ev = []
-    t0 = time.perf_counter()
     loss = None
-    for i in range(args.steps):
-        k = args.warmup + i
-        if want_prof and not args.serial:                    # decoder half of the step, in situ (main stream)
-            e0 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-        loss = trainer.train_one_batch(fresh(batches[k % 2]), next_batch=nxt(k))
-        if want_prof and not args.serial:
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record()
-            dec_ev.append((e0, e1))
-    issued = time.perf_counter() - t0           # host finished issuing; the rest of `elapsed` is GPU backlog
-    sync()
-    elapsed = time.perf_counter() - t0
+    wins = []
+    k0 = args.warmup + getattr(args, 'burn_in', 0)
+    for w in range(max(1, getattr(args, 'windows', 1))):
+        dec_ev = []
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            k = k0 + w * args.steps + i
+            if want_prof and not args.serial:                    # decoder half of the step, in situ (main stream)
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+            loss = trainer.train_one_batch(fresh(batches[k % 2]), next_batch=nxt(k))
+            if want_prof and not args.serial:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                dec_ev.append((e0, e1))
+        issued_w = time.perf_counter() - t0       # host finished issuing; the rest of `elapsed` is GPU backlog
+        sync()
+        wins.append((time.perf_counter() - t0, issued_w))
+    legs.append('timed_region')
+    tw = torch.tensor([e for e, _ in wins], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)            # per window: the slowest rank
+    win_s = [float(x) for x in tw.tolist()]
+    order = sorted(range(len(win_s)), key=lambda j: win_s[j])
+    med = order[(len(order) - 1) // 2]                        # (lower median for an even count)
+    elapsed, issued = win_s[med], wins[med][1]
     if hog is not None:
         hog.stdin.close()
         hog.wait(timeout=60)
@@ -335,12 +374,11 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
     if want_prof and not args.serial:
         prof_concurrent.update(prof.graph_summary())       # launches replayed from graphs: the last replay of each graph
     prof.enable(False)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
     ms = 1e3 * elapsed / args.steps
     res = {'value': round(world * batch_size * args.steps / elapsed, 2), 'ms_per_step': round(ms, 3),
+           'windows': len(win_s), 'windows_ms_per_step': [round(1e3 * x / args.steps, 3) for x in win_s],
+           'first_window_value': round(world * batch_size * args.steps / win_s[0], 2),
+           'spread': round((max(win_s) - min(win_s)) / elapsed, 4), 'burn_in_steps': getattr(args, 'burn_in', 0),
            'host_issue_ms_per_step': round(1e3 * issued / args.steps, 3), 'final_loss_bits': round(float(loss), 4),
            'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
            'step_graph_replays': graph_replays, 'skipped_steps': trainer.skipped_steps(),
@@ -368,6 +406,7 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
     res['step_mfma'] = {'gflop_per_sample': gf['encoders'] + gf['decoder'], 'achieved': round(tf, 1),
                         'peak': 2500.0 * world, 'unit': 'TFLOP/s', 'frac': round(tf / (2500.0 * world), 4)}
     if not want_prof:
+        _rank_report(res, trainer, legs, world, rank, dist, dev)
         return res, trainer
     # (with several ranks EVERY rank runs the legs below - their steps contain the gradient exchange - rank 0 reports)
     # ---- decoder-only step (the number north_star sets its MFMA target on): the decoder half alone on an idle GPU
@@ -378,6 +417,7 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
         ins = sorted(a.elapsed_time(b) for a, b in dec_ev)
         dec['in_step_ms'] = round(ins[len(ins) // 2], 3)
     if not args.serial and world == 1:
+        legs.append('decoder_alone')
         encs = []
         for b in batches:                       # both buffer slots of the encoder graphs
             encs.append(trainer.model.encode(b['context'], b['image']))
@@ -403,6 +443,7 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
     # (in the overlapped schedule several streams share the CUs and every duration is inflated)
     prof_summary = prof_concurrent
     if not args.serial and args.roofline_steps > 0:
+        legs.append('roofline_leg')
         set_serial(True)
         trainer.train_one_batch(fresh(batches[0]))
         sync()
@@ -459,13 +500,40 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
             'launches_per_step': d['launches'] // nsteps, 'avg_launch_us': head['avg_launch_us'],
             'timed_launches': head['timed_launches'],
             'isolated': iso if conc else None,
+            # box-speed normaliser: samples/s per TFLOP/s that the dominant GEMM reaches ALONE on this box (boxes of the
+            # pool differ by +-3 % in both; their ratio is what a code change moves)
+            'value_per_isolated_tflops': round(res['value'] / world / max(iso['achieved'], 1e-9), 4),
             'timing': 'HIP events around every 3rd launch of each GEMM kernel (>= 2 GFLOP), on the launch stream; '
                       'event_overhead_us (bracket around a 1-element kernel minus its 1.5 us) is subtracted',
             'event_overhead_us': round(prof.overhead_us(), 2),
             'all_gemm_kernels': {k: {'avg_us': round(v['avg_us'], 2), 'launches_per_step': v['launches'] // nsteps,
                                      'tflops': round(v['work'] / (v['total_ms'] * 1e-3) / 1e12, 2)}
                                  for k, v in prof_summary.items()}}
+    _rank_report(res, trainer, legs, world, rank, dist, dev)
     return res, trainer
+
+
+def _rank_report(res, trainer, legs, world, rank, dist, dev):
+    """Data parallel only: which legs every rank ran (a rank that skips a leg whose steps contain the gradient exchange
+    deadlocks the others - round 3 found exactly that) and whether the replicas still hold bit-identical weights after all
+    of them (fp32 masters: an exact integer checksum of their bit patterns + their sum)."""
+    if world <= 1 or not getattr(trainer, 'dp', False):
+        return
+    tell = sys.modules['tell_amd']
+    tell.runtime.wait_weight_update()
+    torch.cuda.synchronize()
+    flat = trainer.flat.flat
+    bits = flat.view(torch.int32).to(torch.int64)
+    mine = {'rank': rank, 'legs': list(legs), 'weights_checksum': int(bits.sum().item()),
+            'weights_xor_fold': int((bits * torch.arange(1, bits.numel() + 1, device=dev, dtype=torch.int64) % 1000003).sum().item()),
+            'weights_sum': float(flat.double().sum().item())}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    same = all(e['weights_checksum'] == everyone[0]['weights_checksum'] and e['weights_xor_fold'] == everyone[0]['weights_xor_fold']
+               for e in everyone)
+    res.setdefault('dp', {}).update(
+        ranks=everyone, weights_identical_across_ranks=bool(same),
+        every_rank_ran_the_same_legs=all(e['legs'] == everyone[0]['legs'] for e in everyone))
 
 
 
@@ -730,6 +798,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--windows', type=int, default=5, help='timed windows of --steps steps each (barrier + synchronize around '
+                    'every one); the median window is the headline value')
+    ap.add_argument('--burn-in', dest='burn_in', type=int, default=40, help='untimed clock-settling steps after the warm-up')
     ap.add_argument('--batch', type=int, default=None, help='samples per GPU (configs[2]: 32, configs[1]: 16)')
     ap.add_argument('--model', default='faces_objects', choices=['flattened', 'faces_objects'])
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])

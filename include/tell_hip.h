@@ -94,6 +94,7 @@ int tell_gemm_set_tile_queue(void* counters, int n, tell_stream_t stream);
  * the graph that recorded them is destroyed); _stats: out[0] = slots, out[1] = fresh captured slots handed out so far,
  * out[2] = free-list length. */
 int tell_gemm_tile_queue_log_begin(void);
+int tell_gemm_tile_queue_log_count(void);   /* slots logged so far (the log stays open): sizes the buffer for _log_end */
 int tell_gemm_tile_queue_log_end(int* out, int cap);
 int tell_gemm_tile_queue_release(const int* slots, int n);
 int tell_gemm_tile_queue_stats(int* out);

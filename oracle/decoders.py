@@ -75,7 +75,7 @@ class DynamicConvDecoderLayer(nn.Module):
             h = x + _maybe_dropout(h, self.dropout, tr)
             outs.append(self._ln(self.context_attn_lns[name], h, False))
             if w is not None:
-                attns[name] = w.detach().numpy()
+                attns[name] = w.detach().float().numpy()
         x = self.context_fc(torch.cat(outs, dim=-1))                   # :354-355 (no residual)
 
         res = x                                                        # :357-364 FFN

@@ -164,9 +164,70 @@ def test_model_loss_and_greedy_generation_golden(golden, dtype, kind):
                 assert hs and all(h['graph'] not in (None, False) for h in hs), [h.get('error') for h in hs]
             close(gen['log_probs'], fx['out']['gen_log_probs'], dtype, atol=2e-4)
         else:
+            # bf16: a random-init model's arg-max has near-ties, and a free-running decode that takes one of them the other
+            # way never comes back - so the gate is a MEASURED yardstick, not a constant: the CPU oracle under
+            # torch.autocast(bfloat16) decodes the same batch (0.82 / 0.88 position-wise agreement with the fp32 reference
+            # on these fixtures: one of the four rows leaves it); the HIP path may lose at most one row's worth more.
             n = min(got.shape[1], ref_ids.shape[1])
             agree = (got[:, :n] == ref_ids[:, :n]).float().mean().item()
-            assert agree > 0.5, agree
+            yard = _autocast_yardstick(kind, fx)
+            assert agree >= yard['free_running'] - 1.0 / ref_ids.shape[0] - 1e-6, (fast, agree, yard)
+    if dtype == torch.bfloat16:
+        # ... and TEACHER-FORCED on the reference's own tokens (no divergence: every position is judged on its own): the
+        # arg-max of the HIP decoder against the reference token, non-padding positions, within 2 % of the same figure for
+        # the autocast oracle
+        ref = ref_ids.to(DEV)
+        with torch.no_grad():
+            b = batch()
+            _, _, ctx = model._forward(b['context'], b['image'], b['caption'], b.get('face_embeds'), b.get('obj_embeds'))
+            out = model.decoder({'roberta': ref[:, :-1].contiguous()}, ctx)
+            pred = model.decoder.get_normalized_probs(out, log_probs=True).argmax(-1).cpu()
+        valid = ref_ids[:, 1:] != 1
+        tf = (pred == ref_ids[:, 1:])[valid].float().mean().item()
+        yard = _autocast_yardstick(kind, fx)
+        print('\nbf16 greedy, %s: teacher-forced agreement %.4f (autocast oracle %.4f), free-running %.4f (%.4f)'
+              % (kind, tf, yard['teacher_forced'], agree, yard['free_running']))
+        assert tf >= yard['teacher_forced'] - 0.02, (tf, yard)
+
+
+_YARD = {}
+
+
+def _autocast_yardstick(kind, fx):
+    """The CPU oracle (fp32 restatement of the reference) under torch.autocast('cpu', bfloat16) on the fixture's batch:
+    position-wise agreement of its free-running greedy decode, and of its teacher-forced arg-max, with the fp32
+    reference's token ids - what bf16 arithmetic alone costs on this model."""
+    if kind in _YARD:
+        return _YARD[kind]
+    from oracle.build import build_model as obuild
+    from test_oracle_golden import _PoolResnet as OResnet, _TableRoberta as ORoberta
+    art_dim = 64 if kind == 'flattened' else 1024
+    cpu = obuild(kind, OResnet(), ORoberta(art_dim), article_dim=art_dim, **DEC_KW).eval()
+    own = cpu.state_dict()
+    cpu.load_state_dict({k: v for k, v in fx['sd'].items() if k in own}, strict=False)
+    ins, ref = fx['in'], fx['out']['gen_ids']
+
+    def batch():
+        b = dict(context={'roberta': ins['article_ids'].clone()}, image=ins['image'].clone(),
+                 caption={'roberta': ins['caption_ids'].clone()})
+        if kind == 'faces_objects':
+            f, o = ins['face_embeds'].clone(), ins['obj_embeds'].clone()
+            for i in range(f.shape[0]):
+                f[i, int(ins['n_faces'][i]):] = float('nan')
+                o[i, int(ins['n_objs'][i]):] = float('nan')
+            b.update(face_embeds=f, obj_embeds=o)
+        return b
+    with torch.no_grad(), torch.autocast('cpu', dtype=torch.bfloat16):
+        got = cpu.generate(**batch())['gen_ids']
+        b = batch()
+        _, _, ctx = cpu._forward(b['context'], b['image'], b['caption'], b.get('face_embeds'), b.get('obj_embeds'))
+        out = cpu.decoder({'roberta': ref[:, :-1]}, ctx)
+        pred = cpu.decoder.get_normalized_probs((out[0], None), log_probs=True).argmax(-1)
+    n = min(got.shape[1], ref.shape[1])
+    valid = ref[:, 1:] != 1
+    _YARD[kind] = dict(free_running=(got[:, :n] == ref[:, :n]).float().mean().item(),
+                       teacher_forced=(pred == ref[:, 1:])[valid].float().mean().item())
+    return _YARD[kind]
 
 
 @pytest.mark.parametrize('dtype', DTYPES)

@@ -228,8 +228,9 @@ def test_generation_head_as_skinny_launches_matches_gemm_head_bf16():
 
 def test_full_size_greedy_decode_bit_exact_fp32_and_bf16_agreement():
     """The 4-context decoder at full size: (a) fp32 cached / graphed greedy ids == the oracle's reference-flow greedy
-    ids, (b) the bf16 path under teacher forcing: fraction of positions whose arg-max equals the fp32 token (reported;
-    gate 0.9 - random-init logits are nearly flat, a trained model's margins are wider)."""
+    ids, (b) the bf16 path under teacher forcing: fraction of positions whose arg-max equals the fp32 token, gated against a
+    MEASURED yardstick - the oracle itself under torch.autocast(bfloat16) on the same tokens (random-init logits are nearly
+    flat: what bf16 costs here is a property of the model, not a constant)."""
     import tell_amd
     from tell_amd.build import build_decoder
     o = _oracle('faces_objects')
@@ -246,6 +247,17 @@ def test_full_size_greedy_decode_bit_exact_fp32_and_bf16_agreement():
     om.decoder, om.padding_idx, om.index, om.sampling_topk, om.sampling_temp = ref, 1, 'roberta', 1, 1.0
     with torch.no_grad():
         _, want, _ = om._generate(ids[:, :1], {k: v.clone() for k, v in ctx.items()}, gen_len=GEN, eos=2)
+    # the yardstick of the bf16 gates below: the SAME oracle under torch.autocast(bfloat16), teacher-forced on its own fp32
+    # tokens and free-running - what bf16 arithmetic alone costs on this random-init model
+    valid_w = (want[:, :-1] != 1) & (want[:, 1:] != 1)
+    with torch.no_grad(), torch.autocast('cpu', dtype=torch.bfloat16):
+        y_out = ref({'roberta': want[:, :-1]}, {k: v.clone() for k, v in ctx.items()})
+        y_tok = ref.get_normalized_probs((y_out[0], None), log_probs=True).argmax(-1)
+        _, y_gen, _ = om._generate(ids[:, :1], {k: v.clone() for k, v in ctx.items()}, gen_len=GEN, eos=2)
+    yard_tf = float((y_tok == want[:, 1:])[valid_w].float().mean())
+    ny = min(y_gen.shape[1], want.shape[1])
+    yard_free = float((y_gen[:, :ny] == want[:, :ny]).float().mean())
+    one_pos = 1.0 / max(int(valid_w.sum()), 1)
     results = {}
     for dtype in (torch.float32, torch.bfloat16):
         tell_amd.set_compute_dtype(dtype)
@@ -291,13 +303,15 @@ def test_full_size_greedy_decode_bit_exact_fp32_and_bf16_agreement():
     agree = {f: float((gen[f][0][:, :n] == want[:, :n]).float().mean()) for f in gen}
     print('\nbf16 captured greedy decode vs the fp32 oracle tokens: weight-streaming step %.3f, layer-by-layer %.3f'
           % (agree[True], agree[False]))
-    assert agree[True] >= 0.9 and agree[True] >= agree[False] - 0.1, agree
+    print('autocast oracle: free-running %.3f, teacher-forced %.3f' % (yard_free, yard_tf))
+    # (free-running: one flipped near-tie costs the rest of its row - at most one row of 4 more than the yardstick)
+    assert agree[True] >= yard_free - 0.25 - 1e-6 and agree[True] >= agree[False] - 0.1, (agree, yard_free)
     nb = min(gen[True][1].shape[1], gen[False][1].shape[1])
     assert float((gen[True][1][:, :nb] == gen[False][1][:, :nb]).float().mean()) >= 0.8
     print('\nfull-size greedy, teacher-forced arg-max agreement with the fp32 oracle tokens: fp32 %.3f  bf16 %.3f'
           % (results[torch.float32], results[torch.bfloat16]))
     assert results[torch.float32] == 1.0
-    assert results[torch.bfloat16] >= 0.9, results
+    assert results[torch.bfloat16] >= yard_tf - 2 * one_pos - 1e-6, (results, yard_tf)     # within two positions of the yardstick
 
 
 def _inputs_batch(batch, seed):

@@ -161,12 +161,12 @@ def test_gradient_stores_survive_an_all_empty_context_and_a_mixed_accumulation(g
     seq = [full, full, full, empty, full, empty, empty, full, full]
     for s, bt in enumerate(seq):
         la, lb = ta.train_one_batch(_clone(bt)), tb.train_one_batch(_clone(bt))
-        # (the two trainers differ by the ORDER of the atomic embedding-row sums, which depends on where the allocator put
-        #  their buffers - i.e. on which tests ran before: seen 1.1e-6 of the loss at step 8 in a full-suite run, 0 alone.
-        #  A gradient row applied twice or not at all moves the loss by 1e-3 and more.)
-        assert abs(float(la) - float(lb)) <= 5e-6 * abs(float(la)), (s, float(la), float(lb))
+        # (round 5 had to allow 5e-6 here: the embedding-row gradient sums were fp32 atomics whose order depended on
+        #  workgroup scheduling.  tell_embed_table_grad is a deterministic segmented sum now - back to 1e-6.  A gradient row
+        #  applied twice or not at all moves the loss by 1e-3 and more.)
+        assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(la)), (s, float(la), float(lb))
         num = float((ta.flat.flat - tb.flat.flat).norm())
-        assert num <= 5e-6 * float(ta.flat.flat.norm()), (s, num)
+        assert num <= 1e-6 * float(ta.flat.flat.norm()), (s, num)
     assert tb._store == 'ready' and tb.flat.stored_numel > 0
     # (2) accumulate two micro-batches, the second one ending the accumulation with the update
     # (two DIFFERENT micro-batches: Adam's update is nearly invariant to the gradient's scale, so g + g against g would

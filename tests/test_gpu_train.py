@@ -525,3 +525,38 @@ def test_pipelined_steps_with_graphed_encoders_equal_eager_fp32():
         graphs.ENABLED = was
         tb.finish_update()
         torch.cuda.synchronize()
+
+
+def test_bench_two_ranks_through_the_real_launcher():
+    """`python bench.py --gpus 2` end to end - the launcher (torch.distributed.run, rendezvous on 127.0.0.1), two ranks of
+    the configs[2] step with the gradient exchange in every leg, max-over-ranks timing, the per-rank report - rehearsed on
+    ONE GPU (TELL_BENCH_ONE_GPU=1: every rank computes on cuda:0; gradients over gloo, because RCCL refuses two ranks on
+    one device).  The first real 8-GPU run must not be the first run of this code path: every rank has to enter every leg
+    (a rank that skips one deadlocks the exchange - round 3), the line has to carry the exchange's cost, and the replicas
+    have to hold bit-identical weights at the end."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TELL_BENCH_ONE_GPU='1', TELL_DP_BACKEND='gloo', OMP_NUM_THREADS='4')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'TELL_DP_SELFTEST'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2', '--windows', '2',
+           '--burn-in', '0', '--roofline-steps', '1', '--no-pmc']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]     # rank 0 alone prints
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['steps'] == 3 and j['warmup'] == 2 and j['scaling'] == 'weak'
+    assert j['config']['global_batch'] == 64 and j['config']['parallelism'] == 'dp2'
+    assert j['windows'] == 2 and len(j['windows_ms_per_step']) == 2 and j['value'] > 0
+    # value = the whole job: both ranks' samples over the slowest rank's window
+    assert abs(j['value'] - 2 * 32 * 3 / (j['ms_per_step'] * 3e-3)) <= 0.01 * j['value']
+    dp = j['dp']
+    assert dp['allreduce_ms'] > 0 and dp['exposed_allreduce_ms'] >= 0 and dp['gradient_mbytes'] > 100
+    assert dp['every_rank_ran_the_same_legs'] and dp['weights_identical_across_ranks'], dp
+    assert [r['rank'] for r in dp['ranks']] == [0, 1]
+    assert dp['ranks'][0]['legs'] == ['timed_region', 'roofline_leg'], dp['ranks']
+    assert j['config']['skipped_steps'] == 0 and j['roofline']['frac'] > 0
+    assert 'cpu_baseline' not in j and 'generation' not in j          # single-GPU legs stay out of a multi-rank line

@@ -602,6 +602,7 @@ int tell_bn_finish_apply_launch(const float* pmean, const float* pm2, long M, in
   per = (per + 31) / 32 * 32;
   if (per < 32) per = 32;
   if (per > 32 * BNFA_PASSES) per = 32 * BNFA_PASSES;
+  if ((M + per - 1) / per > 65535) return 1;          // (grid.y limit: more than 65535 x 128 rows -> the two-launch path)
   const unsigned gy = (unsigned)((M + per - 1) / per);
   hipLaunchKernelGGL(bn_finish_apply_kernel, dim3(slabs, gy), dim3(256), 0, stream, pmean, pm2, M, C, n_chunks,
                      rows_per_chunk, eps, momentum, gamma, beta, running_mean, running_var, (const uint16_t*)residual,

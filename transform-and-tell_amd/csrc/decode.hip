@@ -198,6 +198,9 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
 #pragma unroll
       // (round 5: non-temporal loads for the weights here and for the cached K / V in attn_decode_kernel - each byte is read
       //  by one workgroup, once per step - measured: greedy step 486.6-487.5 us plain, 483.9-489.4 nt; not kept)
+      // (round 6 measured the B loads of the lanes past cn masked off instead of repeating column n0 - if the address unit's
+      //  time per wave instruction were what bounds the cn = 4 launches, that would have removed a quarter of it: context_fc
+      //  14.2 -> 15.5 us, fc2 11.3 -> 12.1, linear2 5.0 -> 5.6 at 32 rows (same box within 1 % on the unchanged shapes). Not kept.)
       for (int b = 0; b < NB; ++b) fb[u][b] = *reinterpret_cast<const sk_u4*>(bp[b] + k + u * 32);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) fa[u][rt] = *reinterpret_cast<const sk_u4*>(ap[rt] + k + u * 32);
@@ -715,11 +718,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecArgs g) {
   const int nq = g.beams - j0 < NQ ? g.beams - j0 : NQ;       // live hypotheses of this workgroup
   const int b0 = bs * g.beams + j0;                            // first row
   const int ks = lane >> 3, dc = lane & 7, S = p.S;
-  float q[NQ][8];
+  // Round 6: the arithmetic of both passes halved - at four hypotheses per workgroup the kernel was bound by its VALU work,
+  // not by the cache reads (2.7 TB/s against 4.6 with one hypothesis; per 16 bytes of K: 8 unpack + 32 FMA + 12 DPP adds).
+  // Scores: q stays PACKED bf16 and meets the packed key in four v_dot2_f32_bf16 per hypothesis (exact products, fp32 sum);
+  // values: the unpacked value pairs meet the probability in four v_pk_fma_f32 per hypothesis.
+  uint4 q[NQ];
 #pragma unroll
   for (int i = 0; i < NQ; ++i)
-    unpack16(*reinterpret_cast<const uint4*>(p.q + (long)(b0 + (i < nq ? i : 0)) * p.q_sb + h * 64 + dc * 8), q[i],
-             (const uint16_t*)nullptr);
+    q[i] = *reinterpret_cast<const uint4*>(p.q + (long)(b0 + (i < nq ? i : 0)) * p.q_sb + h * 64 + dc * 8);
   // (round 5: a head-major cache [B, H, S, 64] - one contiguous block per workgroup instead of S pieces of 128 bytes a row
   //  of E apart - measured on one layer's four contexts at B = 32: 16.2 -> 15.8 us; the layout is not what costs)
   const uint16_t* kb = p.k + (long)bs * p.k_sb + h * 64 + dc * 8;
@@ -747,14 +753,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecArgs g) {
 #pragma unroll
     for (int u = 0; u < AD_G; ++u) {
       const int s = s0 + u * 32 + ks;
-      float kf[8];
-      unpack16(kr[u], kf, (const uint16_t*)nullptr);
       const bool masked = s < S && mk && mk[s];
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
-        float d = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) d = fmaf(q[i][e], kf[e], d);
+        float d = sk_dot8(q[i], kr[u], 0.f);
         d += sk_dpp<0xB1>(d); d += sk_dpp<0x4E>(d); d += sk_dpp<0x141>(d);     // over the 8 lanes that share the key
         if (dc == 0 && s < S) sc[i][s] = masked ? -INFINITY : d;
       }
@@ -762,13 +764,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecArgs g) {
   }
   if (wave == 0) {
     if (p.bias_k) {
-      float kf[8];
-      unpack16(*reinterpret_cast<const uint4*>(p.bias_k + h * 64 + dc * 8), kf, (const uint16_t*)nullptr);
+      const uint4 kb4 = *reinterpret_cast<const uint4*>(p.bias_k + h * 64 + dc * 8);
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
-        float d = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) d = fmaf(q[i][e], kf[e], d);
+        float d = sk_dot8(q[i], kb4, 0.f);
         d += sk_dpp<0xB1>(d); d += sk_dpp<0x4E>(d); d += sk_dpp<0x141>(d);
         if (lane == 0) sc[i][S] = d;
       }
@@ -804,11 +803,18 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecArgs g) {
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < NQ; ++i) l[i] = (redw[i][0] + redw[i][1]) + (redw[i][2] + redw[i][3]);
-  float o[NQ][8];
+  typedef float ad_f2 __attribute__((ext_vector_type(2)));
+  ad_f2 o[NQ][4];
 #pragma unroll
   for (int i = 0; i < NQ; ++i)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[i][e] = 0.f;
+    for (int e = 0; e < 4; ++e) o[i][e] = ad_f2{0.f, 0.f};
+  auto unpack2 = [](const uint4& w, ad_f2 (&f)[4]) __attribute__((always_inline)) {
+    f[0] = ad_f2{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u)};
+    f[1] = ad_f2{__uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u)};
+    f[2] = ad_f2{__uint_as_float(w.z << 16), __uint_as_float(w.z & 0xffff0000u)};
+    f[3] = ad_f2{__uint_as_float(w.w << 16), __uint_as_float(w.w & 0xffff0000u)};
+  };
   for (int s0 = wave * 8; s0 < S8; s0 += 32 * AD_G) {
     uint4 vr[AD_G];
 #pragma unroll
@@ -820,37 +826,40 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecArgs g) {
 #pragma unroll
     for (int u = 0; u < AD_G; ++u) {
       const int s = s0 + u * 32 + ks;
-      float vf[8];
-      unpack16(vr[u], vf, (const uint16_t*)nullptr);
+      ad_f2 vf[4];
+      unpack2(vr[u], vf);
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
         const float pr = s < S ? sc[i][s] : 0.f;
+        const ad_f2 p2 = {pr, pr};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[i][e] = fmaf(pr, vf[e], o[i][e]);
+        for (int e = 0; e < 4; ++e) o[i][e] = __builtin_elementwise_fma(p2, vf[e], o[i][e]);
       }
     }
   }
   if (p.bias_v && wave == 0 && ks == 0) {
-    float vf[8];
-    unpack16(*reinterpret_cast<const uint4*>(p.bias_v + h * 64 + dc * 8), vf, (const uint16_t*)nullptr);
+    ad_f2 vf[4];
+    unpack2(*reinterpret_cast<const uint4*>(p.bias_v + h * 64 + dc * 8), vf);
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       const float pr = sc[i][S];
+      const ad_f2 p2 = {pr, pr};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[i][e] = fmaf(pr, vf[e], o[i][e]);
+      for (int e = 0; e < 4; ++e) o[i][e] = __builtin_elementwise_fma(p2, vf[e], o[i][e]);
     }
   }
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
+    float ov[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float v = o[i][e];
+      float v = (e & 1) ? o[i][e >> 1].y : o[i][e >> 1].x;
       v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-      o[i][e] = v;
+      ov[e] = v;
     }
     if (ks == 0) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) part[i][wave][dc * 8 + e] = o[i][e];
+      for (int e = 0; e < 8; ++e) part[i][wave][dc * 8 + e] = ov[e];
     }
   }
   __syncthreads();
@@ -995,17 +1004,18 @@ __global__ __launch_bounds__(64) void beam_update_kernel(const int* __restrict__
   }
   __syncthreads();
   // gather the surviving histories by parent (through LDS: the permutation is in place)
-  const int Lp = L - 1;
-  for (int e = t; e < K * L; e += 64) s_seq[e] = seqs[(long)b * K * L + e];
-  for (int e = t; e < K * Lp; e += 64) s_lp[e] = lps[(long)b * K * Lp + e];
+  // (round 6: only columns 0 .. step + 1 - everything behind them is still the initial padding in every row)
+  const int Lp = L - 1, nc = step + 2 < L ? step + 2 : L, ncp = step + 1 < Lp ? step + 1 : Lp;
+  for (int e = t; e < K * nc; e += 64) { const int r = e / nc, c = e % nc; s_seq[r * L + c] = seqs[(long)b * K * L + r * L + c]; }
+  for (int e = t; e < K * ncp; e += 64) { const int r = e / ncp, c = e % ncp; s_lp[r * Lp + c] = lps[(long)b * K * Lp + r * Lp + c]; }
   __syncthreads();
-  for (int e = t; e < K * L; e += 64) {
-    const int r = e / L, c = e % L;
-    seqs[(long)b * K * L + e] = c == step + 1 ? (long)s_tok[r] : s_seq[s_parent[r] * L + c];
+  for (int e = t; e < K * nc; e += 64) {
+    const int r = e / nc, c = e % nc;
+    seqs[(long)b * K * L + r * L + c] = c == step + 1 ? (long)s_tok[r] : s_seq[s_parent[r] * L + c];
   }
-  for (int e = t; e < K * Lp; e += 64) {
-    const int r = e / Lp, c = e % Lp;
-    lps[(long)b * K * Lp + e] = c == step ? s_dlp[r] : s_lp[s_parent[r] * Lp + c];
+  for (int e = t; e < K * ncp; e += 64) {
+    const int r = e / ncp, c = e % ncp;
+    lps[(long)b * K * Lp + r * Lp + c] = c == step ? s_dlp[r] : s_lp[s_parent[r] * Lp + c];
   }
   if (t < K) {
     cum[b * K + t] = s_top[t];

@@ -942,6 +942,9 @@ extern "C" int tell_gemm_tile_queue_log_begin(void) {
   t_tq_log = &t_tq_log_store;
   return TELL_OK;
 }
+// -> number of slots the calling thread's captured launches have taken since _log_begin (the log stays open): lets the
+// caller size the buffer it hands to _log_end
+extern "C" int tell_gemm_tile_queue_log_count(void) { return t_tq_log ? (int)t_tq_log->size() : 0; }
 // -> number of slots the calling thread's captured launches took since _log_begin (at most `cap` of them copied to `out`)
 extern "C" int tell_gemm_tile_queue_log_end(int* out, int cap) {
   const int n = t_tq_log ? (int)t_tq_log->size() : 0;
@@ -1106,7 +1109,8 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream, int* bm_used = nul
     // fewer than 256 tiles of 128x128 and a reduction of 1024 or more: gemm_s64.hip (q / out / linear2 of the decoder 7.8 ->
     // 5.7 us, tap logits 7.9 -> 5.7; bit-identical sums).  TELL_GEMM_S64=0: the kernels below (A/B; read per launch)
     const int s64_env = (int)tell_opt(OPT_GEMM_S64);
-    if (a.M >= 512 && a.K % 64 == 0 && !a.stat_mean && !a.conv_zero && (s64_env == 2 || (s64_env == 1 && a.K >= 1024))) {
+    if (a.M >= 512 && a.K % 64 == 0 && !a.stat_mean && !a.conv_zero && (s64_env == 2 || (s64_env == 1 && a.K >= 1024)) &&
+        gemm_s64_takes(a)) {
       if (g_gemm_plan) { *bm_used = 64; (void)gemm_label("gemm_nt_s64_kernel", -1, sizeof(OutT) == 2, 64, 64); return TELL_OK; }
       const int rc = launch_gemm_s64(a, stream, sizeof(OutT) == 4);
       if (rc <= 0) { *bm_used = 64; return rc; }

@@ -130,4 +130,5 @@ int launch_gemm_q4(const GemmArgs& a, hipStream_t stream, int n_cu);
 int launch_gemm_q4e(const GemmArgs& a, hipStream_t stream, int n_cu);
 // gemm_s64.hip: 64x64 tiles with the one-wave-per-SIMD K loop (plain NT GEMM or implicit convolution; -> 1: not a call it takes)
 int launch_gemm_s64(const GemmArgs& a, hipStream_t stream, int out_f32);
+bool gemm_s64_takes(const GemmArgs& a);          // the launch path's own eligibility test (also asked by tell_gemm_nt_plan)
 int* gemm_tile_queue_slot(int words, hipStream_t stream);    // gemm.hip: `words` zeroed tile counters for one launch, or NULL

@@ -196,20 +196,27 @@ __global__ __launch_bounds__(256) void gemm_nt_s64_kernel(GemmArgs p) {
 }
 }  // namespace
 
-// -> TELL_OK after launching, 1 when the problem is not one this kernel takes (the caller keeps its own path)
-template <typename OutT>
-static int launch_s64(const GemmArgs& a, hipStream_t stream) {
+// Is the problem one this kernel takes?  ONE test for the launch path and for tell_gemm_nt_plan (which used to name this
+// kernel for every K % 64 == 0 shape, also where the launch then declined and a glds / register kernel ran).
+bool gemm_s64_takes(const GemmArgs& a) {
   const bool conv = a.conv_zero != nullptr;
-  if (a.K % 64 || a.K < 64 || a.M <= 0 || a.N <= 0) return 1;
-  if (conv && a.conv_cshift < 0) return 1;                                         // the 7x7 stem gather stays where it is
+  if (a.K % 64 || a.K < 64 || a.M <= 0 || a.N <= 0) return false;
+  if (conv && a.conv_cshift < 0) return false;                                     // the 7x7 stem gather stays where it is
   // 32-bit byte offsets into either operand; an offset of 2^31 is the "padding pixel" marker
   const long a_bytes = conv ? ((long)a.M / ((long)a.conv_OH * a.conv_OW) + 1) * a.conv_H * a.conv_W * (128L << a.conv_cshift)
                             : (long)a.M * a.lda * 2;
   const long b_bytes = (long)a.N * a.ldb * 2;
-  if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31) || (a.lda & 7) || (a.ldb & 7)) return 1;
-  if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.B) & 15)) return 1;
+  if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31) || (a.lda & 7) || (a.ldb & 7)) return false;
+  if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.B) & 15)) return false;
+  return (long)((a.M + 63) / 64) * ((a.N + 63) / 64) <= (1L << 30);
+}
+
+// -> TELL_OK after launching, 1 when the problem is not one this kernel takes (the caller keeps its own path)
+template <typename OutT>
+static int launch_s64(const GemmArgs& a, hipStream_t stream) {
+  const bool conv = a.conv_zero != nullptr;
+  if (!gemm_s64_takes(a)) return 1;
   const long tiles = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
-  if (tiles > (1L << 30)) return 1;
   const dim3 grid((unsigned)tiles), block(256);
   // (an 8-stage instantiation - 128 KB, seven K tiles in flight - for launches of at most one workgroup per CU, the decoder's
   //  1024 x 1024 outputs whose weights come from HBM: decoder half 6.655 -> 6.650 ms, 15.1 -> 15.2 us per launch; not kept)

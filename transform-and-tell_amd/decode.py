@@ -9,6 +9,7 @@ path up to bf16 rounding points (pre-norm sums stay fp32 here); tests/test_gpu_f
 """
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -43,8 +44,21 @@ def _folded(w_param_key, w, lns, seg):
         s_vec = wp.float().view(wf.shape[0], K // seg, seg).sum(2).t().contiguous()          # [K / seg][N]
         c_vec = (wf @ b).contiguous()
         return wp, s_vec, c_vec
-    key = ('ln_fold', seg) + tuple((ln.weight._version, ln.bias._version, ln.weight.data_ptr()) for ln in lns) + (w.data_ptr(),)
-    return ops._cached(w_param_key, key, make)
+    # ONE entry per (weight parameter, consumer): overwritten in place when it goes stale.  (Round 5 keyed it on w.data_ptr()
+    # too - the working weight is re-allocated with every weights epoch, so every train-then-validate round left a dead
+    # gamma-scaled copy of every decoder linear behind.)  Stale = the weight's own stamp (ops._fresh: weights epoch, dtype,
+    # version, address) or the guard below: the LayerNorms' torch versions and - the optimizer kernel bypasses those - the
+    # weights epoch when a LayerNorm is trainable.
+    trainable = any(getattr(t, 'requires_grad', False) for ln in lns for t in (ln.weight, ln.bias))
+    guard = (ops.rt.weights_epoch() if trainable else -1,
+             tuple((ln.weight._version, ln.bias._version, ln.weight.data_ptr(), ln.bias.data_ptr()) for ln in lns))
+    key = ('ln_fold', seg, len(lns))
+    hit = ops._fresh(w_param_key, key)
+    if hit is not None and hit[1][0] == guard:
+        return hit[1][1]
+    val = make()
+    ops._wcache[(id(w_param_key), key)] = (ops._stamp(w_param_key), (guard, val), weakref.ref(w_param_key))
+    return val
 
 
 def _ptrs(items):

@@ -186,7 +186,7 @@ class tile_slots:
         return self
 
     def __exit__(self, *exc):
-        cap = 4096
+        cap = max(int(lib().tell_gemm_tile_queue_log_count()), 1)      # (every slot: a truncated list would leak the rest)
         buf = (ctypes.c_int * cap)()
         n = lib().tell_gemm_tile_queue_log_end(buf, cap)
         self.slots = list(buf[:min(n, cap)])

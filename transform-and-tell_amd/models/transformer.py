@@ -494,9 +494,12 @@ class CaptionModel(Model):
                     try:
                         ops.call('tell_set_rng_step_ptr', h['counter'])
                         ops.call('tell_set_pos_step_ptr', h['counter'])
-                        with graphs.no_gc(), torch.cuda.graph(g):
+                        # (the captured step's resident GEMM launches keep their tile-counter slots until this entry is
+                        #  dropped - `held` gives them back, like StepGraph / GraphedCall do)
+                        with graphs.no_gc(), ops.hip.tile_slots() as held, torch.cuda.graph(g):
                             with ops.hip.bound_stream():
                                 h['out'] = run()
+                        h['tile_slots'] = held
                     finally:
                         ops.call('tell_set_rng_step_ptr', None)
                         ops.call('tell_set_pos_step_ptr', None)
