@@ -12,6 +12,10 @@ from ..common.registrable import Registrable
 
 
 _OVERLAP = os.environ.get('TELL_ENCODER_OVERLAP', '1') != '0'
+# where the PREFETCHED ResNet pass of the next batch is enqueued: 'own' = its side stream (three streams share the chip),
+# 'main' = the training stream, in front of the decoder step of the current batch (two streams: RoBERTa against ResNet +
+# decoder back to back - 4.3 + 6.7 ms against 11.2 ms alone).  MEASURED in round 6: tools/step_timeline.py, DESIGN.md.
+_RESNET_STREAM = os.environ.get('TELL_RESNET_STREAM', 'own')
 def _side_stream(device, name='resnet'):
     return streams.get(name, device)
 
@@ -152,11 +156,13 @@ class CaptionModel(Model):
             # buffer, and the addresses the decoder step graph is keyed on depend on the parity alone (graphs.py)
             par = self.__dict__['_enc_parity'] = self.__dict__.get('_enc_parity', -1) + 1
             if ahead:
-                rs, is_ = _side_stream(image.device, 'roberta'), _side_stream(image.device, 'resnet')
+                rs = _side_stream(image.device, 'roberta')
+                is_ = main if _RESNET_STREAM == 'main' else _side_stream(image.device, 'resnet')
                 start = torch.cuda.Event()
                 start.record(main)
                 rs.wait_event(start)
-                is_.wait_event(start)
+                if is_ is not main:
+                    is_.wait_event(start)
                 with torch.cuda.stream(rs), ops.hip.bound_stream():
                     enc.article_mask = self._pad_mask(article_ids)                      # :347
                     enc.stack = self._run_roberta(article_ids, par)
