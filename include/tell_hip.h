@@ -316,14 +316,19 @@ int tell_dropout_add(const void* x, const void* add, void* out, long n, float p,
  *   [M,N]); each may be NULL.
  *   out bf16 or (out_f32) fp32 [M,N]; out2 (optional, bf16): columns n >= out2_from of the result once more, at
  *   out2[m][p * N + n - out2_from] for problem p (the softmax head: cluster logits in fp32 and the tails' projected inputs in bf16 from one
- *   launch). */
+ *   launch).
+ *   split_ws (optional, split_ws_bytes >= 64 KB + the partial tiles; 16-byte aligned, ZEROED ONCE when allocated and then
+ *   owned by the launches of ONE stream): lets a single-problem launch with few column tiles and a long reduction (N <=
+ *   1536, K >= 2048: context_fc, fc2) share the reduction of a tile between 2 / 4 workgroups that combine inside the launch
+ *   (write-through partial tiles, an agent-scope arrival counter per tile - never reset -, the last arrival sums the
+ *   slices in slice order: deterministic).  NULL = every workgroup owns its whole reduction.  Option "sk_split" = 0: never. */
 int tell_skinny_linear(int n_prob, const void* const* in, long ld_in, int pro, const void* const* gamma,
                        const void* const* beta, int seg, float eps, float* stats_out, void* ws, const void* const* w,
                        long ldw, const void* const* bias, int act, float scale, const void* res, long ld_res,
                        const float* res_raw, long ld_res_raw, const float* res_stats, const float* res_gamma,
                        const float* res_beta, const float* res_f32, long ld_res_f32, void* out2, long ld_out2,
-                       int out2_from, void* const* out, long ld_out, int out_f32, int M, int N, int K,
-                       tell_stream_t stream);
+                       int out2_from, void* const* out, long ld_out, int out_f32, int M, int N, int K, void* split_ws,
+                       long split_ws_bytes, tell_stream_t stream);
 /* y (bf16) = LayerNorm(x) of fp32 rows [M, C], C = 1024 .. 4096; stats_out (optional): (mean, rstd) per row [M][2]. */
 int tell_layernorm_rows(const float* x, long ld_x, const float* gamma, const float* beta, float eps, void* y, long ld_y,
                         float* stats_out, int M, int C, tell_stream_t stream);

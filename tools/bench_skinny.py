@@ -8,7 +8,7 @@ import torch
 
 sys.path.insert(0, '.')
 import tell_amd  # noqa: E402
-from tell_amd import decode, ops  # noqa: E402
+from tell_amd import hip, decode, ops  # noqa: E402
 
 tell_amd.hip.require_gpu()
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 32
@@ -76,6 +76,17 @@ cases = {
     'fc1+relu     pro0 N4096 K1024': lambda: decode._skinny([x], E, [w1], [b1], [h], F, M, F, E, act=1),
     'fc2+res      pro0 N1024 K4096': lambda: decode._skinny([x4], F, [w2], [b2], [o32], E, M, E, F, res=x, ld_res=E, out_f32=True),
 }
+raw4_bf = raw4.bfloat16()
+wcf, sc_f, cc_f = decode._folded(torch.nn.Parameter(torch.zeros(1, device='cuda')), wc, lns, E)
+cases['context_fc   pro4 N1024 K4096 (folded LN)'] = lambda: decode._skinny([raw4_bf], 4 * E, [wcf], [bc], [g], E, M, E, 4 * E, pro=4, gammas=[sc_f], betas=[cc_f], seg=E)
+for opt in (0, 2):
+    def with_opt(fn, opt=opt):
+        def run():
+            with hip.options(sk_split=opt):
+                fn()
+        return run
+    cases['fc2+res      (sk_split=%d)' % opt] = with_opt(cases['fc2+res      pro0 N1024 K4096'])
+    cases['context_fc   pro4 (sk_split=%d)' % opt] = with_opt(cases['context_fc   pro4 N1024 K4096 (folded LN)'])
 back_tab = torch.arange(M, dtype=torch.int32, device='cuda').repeat(30, 1).contiguous()
 for K in (3, 7, 15, 31):
     hist = torch.zeros(K, M, E, **bf)

@@ -54,6 +54,9 @@ struct SkinnyArgs {
   const float* fold_s[SK_MAXP];
   const float* fold_c[SK_MAXP];
   long out2_prob;                          // out2 column offset per problem (n_prob outputs side by side), elements
+  // in-launch split of the reduction over `ksplit` workgroups per output tile (round 6): fp32 partial tiles in `sk_slab`
+  // ([tile][slice][MT * 16 (* 2 with GLU)]), arrivals counted in sk_cnt[tile] (monotonic: never reset)
+  int ksplit; float* sk_slab; unsigned* sk_cnt;
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 sk_bf16x2;
@@ -160,7 +163,18 @@ __device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& p, int prob, i
 
 // NW: waves of the workgroup = slices of the reduction.  (Round 5 measured NW = 8 for K = 4096 - context_fc, fc2: two
 // batches of loads per wave instead of four - same box: greedy step 494.5 -> 507.3 us, beam 4 822 -> 834; only 4 is built.)
-template <int RT, int ACT, int U, bool FOLD = false, int NW = 4>
+// SPLIT (round 6): the reduction of an output tile shared by p.ksplit workgroups (blockIdx.z = row group * ksplit + slice).
+// The K = 4096 linears of the step (context_fc, fc2: N = 1024 = 64 column tiles) ran 256 workgroups of 4 columns x the WHOLE
+// reduction - every workgroup pulls all 32 x 4096 activation elements (256 KB) through its CU for 32 KB of weights, and
+// takes 11-14 us where the K = 1024 layers take 5.  Split four ways a workgroup owns 16 columns x 1024 of K: 64 KB of
+// activations, one batch of loads per wave.  The combine follows cdna_hip_programming.md 6 G16 / the split-K recipe:
+// partial tiles leave as write-through (sc1) stores, every wave drains them (s_waitcnt vmcnt(0)), one lane takes a ticket
+// from the tile's agent-scope counter, the workgroup that draws the last ticket of the launch reads all slabs back with
+// sc1 loads IN SLICE ORDER (deterministic sum whatever the arrival order) and runs the epilogue.  The counter is monotonic
+// (ticket % ksplit == ksplit - 1 marks the last arrival; every launch adds exactly ksplit): nothing to zero between
+// launches or graph replays.  With the folded LayerNorm a slice is exactly one segment (K / ksplit == seg): its row
+// statistics are complete inside the workgroup and its partial tile is already corrected.
+template <int RT, int ACT, int U, bool FOLD = false, int NW = 4, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
   constexpr int NB = ACT == 2 ? 2 : 1, MT = RT * 16, CW = 16 * NB, NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
@@ -169,8 +183,10 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
   float* rst = wst + NW * MT * 2;                                      // FOLD: [MT][4 segments][2] mean, rstd
   const int tid = threadIdx.x, prob = blockIdx.y, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
-  const int cn = p.cn, n0 = blockIdx.x * cn, m0 = blockIdx.z * MT, M = p.M, N = p.N, K = p.K;
-  const int kw = K / NW, nbatch = kw / (32 * U), kbeg = wave * kw;
+  const int ksplit = SPLIT ? p.ksplit : 1, slice = SPLIT ? (int)blockIdx.z % ksplit : 0;
+  const int cn = p.cn, n0 = blockIdx.x * cn, m0 = (SPLIT ? (int)blockIdx.z / ksplit : (int)blockIdx.z) * MT, M = p.M, N = p.N;
+  const int K = SPLIT ? p.K / ksplit : p.K;                            // this workgroup's share of the reduction
+  const int kw = K / NW, nbatch = kw / (32 * U), kbeg = slice * K + wave * kw;
   const uint16_t* X = static_cast<const uint16_t*>(p.in[prob]);
   const uint16_t* W = p.w[prob];
   const uint16_t* ap[RT];
@@ -244,12 +260,12 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
   float pre_s[4][NB], pre_c[NB];
   if constexpr (FOLD) {
     const int n_pre = n0 + (tid & 15) < N ? n0 + (tid & 15) : N - 1;
-    const int nsg = K / p.seg;
+    const int nsg = K / p.seg;                                          // (SPLIT: the slice covers segments slice * nsg ..)
 #pragma unroll
     for (int e = 0; e < NB; ++e) {
       pre_c[e] = p.fold_c[prob][e * N + n_pre];
 #pragma unroll
-      for (int sg = 0; sg < 4; ++sg) pre_s[sg][e] = sg < nsg ? p.fold_s[prob][(long)sg * N * NB + e * N + n_pre] : 0.f;
+      for (int sg = 0; sg < 4; ++sg) pre_s[sg][e] = sg < nsg ? p.fold_s[prob][(long)(sg + slice * nsg) * N * NB + e * N + n_pre] : 0.f;
     }
   }
   constexpr int EPI = MT * 16 / NT;                                    // output elements per thread
@@ -312,15 +328,16 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
     }
     __syncthreads();
   }
+  float sv[SPLIT ? EPI : 1], sg2[SPLIT && ACT == 2 ? EPI : 1];
 #pragma unroll
   for (int e = 0; e < EPI; ++e) {
     const int o = tid + e * NT;
     const int r = o >> 4, c = o & 15, m = m0 + r, n = n0 + c;
-    if (c >= cn || m >= M || n >= N) continue;
+    if constexpr (!SPLIT) { if (c >= cn || m >= M || n >= N) continue; }
     float v, g = 0.f;
     if constexpr (FOLD) {
-      v = pre_c[0];
-      if constexpr (ACT == 2) g = pre_c[NB - 1];
+      v = SPLIT ? 0.f : pre_c[0];                                      // (SPLIT: c is added once, by the combining workgroup)
+      if constexpr (ACT == 2) g = SPLIT ? 0.f : pre_c[NB - 1];
 #pragma unroll
       for (int sg = 0; sg < 4; ++sg) {
         if (sg >= nseg) break;
@@ -347,7 +364,41 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
                (red[((long)6 * MT + r) * CW + 16 + c] + red[((long)7 * MT + r) * CW + 16 + c]);
       }
     }
-    skinny_epilogue(p, prob, m, n, v, g, ACT, PRE ? &pre[e] : nullptr);
+    if constexpr (SPLIT) { sv[e] = v; if constexpr (ACT == 2) sg2[e] = g; }
+    else skinny_epilogue(p, prob, m, n, v, g, ACT, PRE ? &pre[e] : nullptr);
+  }
+  if constexpr (SPLIT) {
+    // ---- publish this slice's partial tile (write-through), take a ticket; the last arrival combines
+    const long tile = ((long)(blockIdx.z / ksplit) * gridDim.y + prob) * gridDim.x + blockIdx.x;
+    constexpr int SLAB = MT * 16 * NB;
+    float* slab = p.sk_slab + (tile * ksplit + slice) * SLAB;
+#pragma unroll
+    for (int e = 0; e < EPI; ++e) {
+      __hip_atomic_store(slab + tid + e * NT, sv[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (ACT == 2) __hip_atomic_store(slab + MT * 16 + tid + e * NT, sg2[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // EVERY storing wave drains its stores ...
+    __syncthreads();                                                    // ... before ONE lane announces the slice
+    int* flag = reinterpret_cast<int*>(sk_smem);                        // (red is dead: every wave passed the barrier above)
+    if (tid == 0) {
+      const unsigned t = __hip_atomic_fetch_add(p.sk_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = ((t % (unsigned)ksplit) == (unsigned)ksplit - 1u) ? 1 : 0;
+    }
+    __syncthreads();
+    if (*flag == 0) return;
+    const float* slabs = p.sk_slab + tile * ksplit * SLAB;
+#pragma unroll
+    for (int e = 0; e < EPI; ++e) {
+      const int o = tid + e * NT;
+      const int r = o >> 4, c = o & 15, m = m0 + r, n = n0 + c;
+      float v = FOLD ? pre_c[0] : 0.f, g = (FOLD && ACT == 2) ? pre_c[NB - 1] : 0.f;
+      for (int sl = 0; sl < ksplit; ++sl) {                              // slice order: the sum does not depend on who came last
+        v += __hip_atomic_load(slabs + (long)sl * SLAB + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (ACT == 2) g += __hip_atomic_load(slabs + (long)sl * SLAB + MT * 16 + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (c >= cn || m >= M || n >= N) continue;
+      skinny_epilogue(p, prob, m, n, v, g, ACT, PRE ? &pre[e] : nullptr);
+    }
   }
 }
 template <int RT, int ACT, int U, bool FOLD = false, int NW = 4>
@@ -366,6 +417,28 @@ static int skinny_mfma_launch(SkinnyArgs a, int n_prob, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3((a.N + a.cn - 1) / a.cn, n_prob, groups), dim3(64 * NW), smem, stream, a);
   return tell_check_launch("skinny_linear (mfma)");
 }
+// the split form: cn = 16, grid.z = row groups x ksplit
+template <int RT, int ACT, int U, bool FOLD>
+static int skinny_split_launch(SkinnyArgs a, hipStream_t stream) {
+  constexpr int MT = RT * 16;
+  constexpr size_t smem = (size_t)4 * MT * 16 * (ACT == 2 ? 2 : 1) * 4 + (FOLD ? (size_t)(4 * MT * 2 + MT * 8) * 4 : 0);
+  const int groups = (a.M + MT - 1) / MT;
+  auto kern = skinny_mfma_kernel<RT, ACT, U, FOLD, 4, true>;
+  static bool attr_done = false;
+  if (!attr_done && smem > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((a.N + a.cn - 1) / a.cn, 1, groups * a.ksplit), dim3(256), smem, stream, a);
+  return tell_check_launch("skinny_linear (mfma, split reduction)");
+}
+template <int RT, int U>
+static int skinny_split_dispatch(const SkinnyArgs& a, int act, hipStream_t stream, bool fold) {
+  if (fold) return skinny_split_launch<RT, 0, U, true>(a, stream);                 // (context_fc behind its LayerNorms)
+  if (act == 0) return skinny_split_launch<RT, 0, U, false>(a, stream);
+  return skinny_split_launch<RT, 1, U, false>(a, stream);
+}
+
 template <int RT, int U>
 static int skinny_mfma_dispatch(const SkinnyArgs& a, int n_prob, int act, hipStream_t stream, bool fold = false) {
   if (fold) {                                                         // (query projections, context_fc: act 0; linear1: GLU)
@@ -449,7 +522,8 @@ extern "C" int tell_skinny_linear(int n_prob, const void* const* in, long ld_in,
                                   const void* res, long ld_res, const float* res_raw, long ld_res_raw,
                                   const float* res_stats, const float* res_gamma, const float* res_beta,
                                   const float* res_f32, long ld_res_f32, void* out2, long ld_out2, int out2_from,
-                                  void* const* out, long ld_out, int out_f32, int M, int N, int K, hipStream_t stream) {
+                                  void* const* out, long ld_out, int out_f32, int M, int N, int K, void* split_ws,
+                                  long split_ws_bytes, hipStream_t stream) {
   TELL_REQUIRE(n_prob >= 1 && n_prob <= SK_MAXP && M >= 1 && M <= 1024 && N >= 1 && K >= 256, "skinny_linear: bad shape");
   TELL_REQUIRE(K % 256 == 0 && ldw % 8 == 0 && ld_in % 8 == 0, "skinny_linear: K % 256, 16-byte rows");
   TELL_REQUIRE(pro >= 0 && pro <= 4 && act >= 0 && act <= 2, "skinny_linear: bad mode");
@@ -486,6 +560,7 @@ extern "C" int tell_skinny_linear(int n_prob, const void* const* in, long ld_in,
   a.res_gamma = res_gamma; a.res_beta = res_beta; a.res_f32 = res_f32; a.ld_res_f32 = ld_res_f32;
   a.out2 = static_cast<uint16_t*>(out2); a.ld_out2 = ld_out2; a.out2_from = out2_from; a.eps = eps; a.scale = scale; a.M = M; a.N = N; a.K = K;
   a.seg = seg > 0 ? seg : K; a.out_f32 = out_f32; a.cn = 16;
+  a.ksplit = 1; a.sk_slab = nullptr; a.sk_cnt = nullptr;
   if (pro == 1 || pro == 2) {
     TELL_REQUIRE((pro == 1 ? K : seg) % 1024 == 0 && (pro == 1 ? K : seg) <= 4096, "skinny_linear: LayerNorm over 1024 .. 4096 columns");
     TELL_REQUIRE(ws, "skinny_linear: the LayerNorm prologue needs ws [M,K] bf16");
@@ -502,6 +577,33 @@ extern "C" int tell_skinny_linear(int n_prob, const void* const* in, long ld_in,
   // fragments of a column tile are loaded once for 128 rows instead of four times
   // (64 rows per workgroup - RT = 4, U = 4 - where 128 is taken: beam 4 711 -> 705 us, 128 greedy rows 866 -> 853; everywhere
   //  above 64 rows: 784 / 926 us.  Not instantiated.)
+  // ---- the reduction shared by several workgroups per tile (skinny_mfma_kernel SPLIT): one problem, few column tiles, a
+  // long reduction - context_fc / fc2 of the step (N = 1024, K = 4096).  Needs the caller's workspace: the first 64 KB
+  // are arrival counters (zero once, at allocation; never reset), the rest holds the partial tiles.
+  // MEASURED (MI355X, hot operands, fc2 shape): 32 rows 11.3 -> 9.5 us with 4 slices x 16 columns; 128 rows as ONE 128-row
+  // group per tile 13.1 -> 22.4 us (the activation bytes per workgroup do not shrink there - 128 rows x 1024 = the 32 rows
+  // x 4096 of the unsplit form - and the partial tiles are 8 KB each); 64 rows as two 32-row groups: fc2 12.1 -> 12.2, the
+  // folded context_fc 13.3 -> 18.6 us (512 workgroups, two per CU, 1 MB of partial tiles).  Taken up to 32 rows: fc2 11.4
+  // -> 9.4 us, context_fc behind its folded LayerNorms 12.7 -> 10.6 us; greedy step 433 -> 418 us same box.
+  // option sk_split: 1 = K / 1024 slices x 16 columns; 2 = 2 slices x 8 columns (A/B aid).
+  const long sk_opt = tell_opt(OPT_SK_SPLIT);
+  if (split_ws && sk_opt && n_prob == 1 && M <= 32 && act != 2 && !stats_out && (pro == 0 || pro == 4) &&
+      K >= 2048 && K % 1024 == 0 && (N + 15) / 16 <= 96) {
+    int ks = K >= 4096 ? 4 : 2;
+    a.cn = 16;
+    if (sk_opt == 2) { ks = 2; a.cn = 8; }
+    const int mt = 32, groups = (M + mt - 1) / mt;
+    const long tiles = (long)((N + a.cn - 1) / a.cn) * groups;
+    const long need = 65536 + tiles * ks * mt * 16 * 4;
+    if ((K / ks) % 1024 == 0 && (pro != 4 || (K / ks) % a.seg == 0) && tiles <= 8192 && need <= split_ws_bytes &&
+        (reinterpret_cast<uintptr_t>(split_ws) & 15) == 0) {
+      a.ksplit = ks;
+      a.sk_cnt = static_cast<unsigned*>(split_ws) + (ks == 2 ? 8192 : 0);
+      a.sk_slab = reinterpret_cast<float*>(static_cast<char*>(split_ws) + 65536);
+      return skinny_split_dispatch<2, 8>(a, act, stream, fold);
+    }
+    a.cn = 16;
+  }
   const int rt_env = (int)tell_opt(OPT_SK_ROWS);          // A/B aid: 32 / 128
   const bool tall = rt_env ? rt_env == 128 : (M > 64 && (long)((N + 15) / 16) * n_prob * ((M + 127) / 128) >= 192);
   if (tall) return skinny_mfma_dispatch<8, 2>(a, n_prob, act, stream, fold);

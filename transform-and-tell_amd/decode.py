@@ -98,6 +98,24 @@ def usable(dec, X, incremental_state, kv_cache):
     return True
 
 
+_SPLIT_WS = {}
+
+
+def split_workspace(device):
+    """Workspace of the skinny linears that share a reduction between workgroups (tell_skinny_linear split_ws): 64 KB of
+    arrival counters - zeroed HERE, once; the kernels keep them consistent - and 16 MB for partial tiles.  One per device:
+    the launches that use it (the decode steps of this process) are ordered with respect to each other - one stream, or
+    replays of graphs captured from it; a caller that decodes on two streams at once gives each its own (pass split_ws to
+    tell_skinny_linear directly).  Created outside any stream capture (the eager warm step of a decode loop comes first)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    ws = _SPLIT_WS.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None                                   # (never allocate + zero inside a capture: no split for this graph)
+        ws = _SPLIT_WS[key] = torch.zeros((65536 + (16 << 20)) // 4, dtype=torch.int32, device=device)
+    return ws
+
+
 def _skinny(ins, ld_in, ws, biases, outs, ld_out, M, N, K, pro=0, gammas=None, betas=None, seg=0, eps=1e-5,
             stats_out=None, act=0, scale=1.0, res=None, ld_res=0, res_raw=None, res_stats=None, res_ln=None,
             res_f32=None, out2=None, out2_from=0, out_f32=False):
@@ -105,13 +123,15 @@ def _skinny(ins, ld_in, ws, biases, outs, ld_out, M, N, K, pro=0, gammas=None, b
     work = None
     if pro in (1, 2):                                                    # LayerNorm rows as their own launch
         work = torch.empty(M, K, dtype=torch.bfloat16, device=ws[0].device)
+    sws = split_workspace(ws[0].device) if (n == 1 and M <= 32 and K >= 2048 and N <= 1536) else None
     call('tell_skinny_linear', n, _ptrs(ins), ld_in, pro, _ptrs(gammas) if gammas else None,
          _ptrs(betas) if betas else None, seg, eps, stats_out, work, _ptrs(ws), ws[0].stride(0),
          _ptrs(biases) if biases is not None else None, act, scale, res, ld_res, res_raw,
          res_raw.stride(0) if res_raw is not None else 0, res_stats,
          res_ln.weight if res_ln is not None else None, res_ln.bias if res_ln is not None else None,
          res_f32, res_f32.stride(0) if res_f32 is not None else 0, out2,
-         out2.stride(0) if out2 is not None else 0, out2_from, _ptrs(outs), ld_out, 1 if out_f32 else 0, M, N, K)
+         out2.stride(0) if out2 is not None else 0, out2_from, _ptrs(outs), ld_out, 1 if out_f32 else 0, M, N, K,
+         sws, sws.numel() * 4 if sws is not None else 0)
 
 
 def embed_usable(embedder, ids, incremental_state):
