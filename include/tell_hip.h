@@ -355,9 +355,10 @@ int tell_dynconv_step(const void* x, void* hist, const void* wt, void* y, int M,
  * cache), mask[c] [B / beams, S[c]] uint8 or NULL, bias_k[c] / bias_v[c] [H*64] (:355-364) or NULL, has_zero: the zero
  * row (:416-421).  bf16, q pre-scaled, S <= 2048 (S = 0 allowed with a bias / zero row: the empty context :349-374). */
 int tell_attn_decode(int n_ctx, const void* const* q, const long* q_sb, const void* const* k, const long* k_ss,
-                     const long* k_sb, const void* const* v, const long* v_ss, const long* v_sb, const void* const* mask,
-                     const void* const* bias_k, const void* const* bias_v, int has_zero, const int* S, void* const* out,
-                     const long* o_sb, int B, int H, int beams, tell_stream_t stream);
+                     const long* k_sb, const long* k_sh, const void* const* v, const long* v_ss, const long* v_sb,
+                     const long* v_sh, const void* const* mask, const void* const* bias_k, const void* const* bias_v,
+                     int has_zero, const int* S, void* const* out, const long* o_sb, int B, int H, int beams,
+                     tell_stream_t stream);
 /* n LayerNorms over ONE residual in one launch each way - the end of a decoder layer's context block
    (decoder_faces_objects.py:283-352): y[:, i*C:(i+1)*C] = LayerNorm_i(res + dropout_p(x_i)), mean / rstd [n, rows].
    Backward: dx_i (entries may be NULL), dres = sum_i dz_i (may be NULL), dgamma_i / dbeta_i ACCUMULATED; partial is a

@@ -1142,14 +1142,30 @@ def test_one_query_attention_over_cached_contexts(beams):
     kk = [k if k.shape[0] else q[c] for c, k in enumerate(ks)]
     vv = [v if v.shape[0] else q[c] for c, v in enumerate(vs)]
     ops.call('tell_attn_decode', 4, P(q), Lg([E] * 4), P(kk), Lg([k.stride(0) if k.dim() == 3 else 0 for k in kk]),
-             Lg([k.stride(1) if k.dim() == 3 else 0 for k in kk]), P(vv),
-             Lg([v.stride(0) if v.dim() == 3 else 0 for v in vv]), Lg([v.stride(1) if v.dim() == 3 else 0 for v in vv]),
+             Lg([k.stride(1) if k.dim() == 3 else 0 for k in kk]), None, P(vv),
+             Lg([v.stride(0) if v.dim() == 3 else 0 for v in vv]), Lg([v.stride(1) if v.dim() == 3 else 0 for v in vv]), None,
              P([m if S else None for m, S in zip(masks, S_list)]),
              P([ops._bias_row(b, torch.bfloat16) for b in bk]), P([ops._bias_row(b, torch.bfloat16) for b in bv]), 1,
              (ctypes.c_int * 4)(*S_list), P(outs), Lg([E] * 4), M, H, beams)
     for c in range(4):
         rel = ((outs[c].float() - want[c].float()).norm() / want[c].float().norm()).item()
         assert rel < 1e-2, (S_list[c], rel)          # bf16 outputs; the MFMA kernel rounds probabilities to bf16, this one does not
+    # the generation loop's HEAD-MAJOR cache ([B, H, S, 64] seen as [S, B, H, 64]: explicit head strides): the same bits
+    from tell_amd import decode
+    hm = lambda t: (torch.empty(n, H, t.shape[0], 64, **bf).permute(2, 0, 1, 3).copy_(t.view(t.shape[0], n, H, 64))   # noqa: E731
+                    if t.shape[0] else t)
+
+    class _Mod:
+        def __init__(self, c):
+            self.head_dim, self.num_heads, self.bias_k, self.bias_v, self.add_zero_attn = 64, H, bk[c], bv[c], True
+    mods = [_Mod(c) for c in range(4)]
+    names = ['c%d' % c for c in range(4)]
+    kvl = {nm: (hm(ks[c]), hm(vs[c])) for c, nm in enumerate(names)}
+    ctx = {nm + '_mask': masks[c] for c, nm in enumerate(names) if S_list[c]}
+    assert decode.attn_decode_usable(mods, kvl, names, q[0])
+    got = decode.attn_decode_all(mods, names, q, kvl, ctx, M, E)
+    for c in range(4):
+        assert torch.equal(got[c], outs[c]), S_list[c]
 
 
 @pytest.mark.parametrize('M', [5, 32, 70, 128])

@@ -801,7 +801,7 @@ extern "C" int tell_dynconv_step(const void* x, void* hist, const void* wt, void
 struct AttnDecCtx {
   const uint16_t *q, *k, *v; uint16_t* out; const uint8_t* mask;
   const uint16_t *bias_k, *bias_v;      // [H*64] or null
-  long q_sb, k_ss, k_sb, v_ss, v_sb, o_sb;
+  long q_sb, k_ss, k_sb, k_sh, v_ss, v_sb, v_sh, o_sb;    // k_sh / v_sh: elements between the heads of a key (64: row-major [.., H*64])
   int S, has_zero;
 };
 struct AttnDecArgs { AttnDecCtx c[SK_MAXP]; int B, H, beams; };
@@ -830,8 +830,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecArgs g) {
     q[i] = *reinterpret_cast<const uint4*>(p.q + (long)(b0 + (i < nq ? i : 0)) * p.q_sb + h * 64 + dc * 8);
   // (round 5: a head-major cache [B, H, S, 64] - one contiguous block per workgroup instead of S pieces of 128 bytes a row
   //  of E apart - measured on one layer's four contexts at B = 32: 16.2 -> 15.8 us; the layout is not what costs)
-  const uint16_t* kb = p.k + (long)bs * p.k_sb + h * 64 + dc * 8;
-  const uint16_t* vb = p.v + (long)bs * p.v_sb + h * 64 + dc * 8;
+  const uint16_t* kb = p.k + (long)bs * p.k_sb + (long)h * p.k_sh + dc * 8;
+  const uint16_t* vb = p.v + (long)bs * p.v_sb + (long)h * p.v_sh + dc * 8;
   const uint8_t* mk = p.mask ? p.mask + (long)bs * S : nullptr;
   const int ST = S + (p.bias_k ? 1 : 0) + p.has_zero;
   const int S8 = (S + 7) & ~7;
@@ -974,13 +974,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecArgs g) {
 }
 
 // n_ctx <= 4 contexts of one decode step in one launch (host arrays of n_ctx entries).  bf16, head width 64, Tq = 1.
-// q[c] [B, H*64] (row stride q_sb[c]), k[c] / v[c]: element (b / beams, s, h, d) at k + s*k_ss + (b/beams)*k_sb + h*64 + d,
+// q[c] [B, H*64] (row stride q_sb[c]), k[c] / v[c]: element (b / beams, s, h, d) at k + s*k_ss + (b/beams)*k_sb + h*k_sh + d
+// (k_sh / v_sh NULL: 64 - heads side by side in a row of E; the generation loop keeps its cache HEAD-MAJOR, [B, H, S, 64]:
+// the S keys a workgroup walks are then one contiguous 64 KB block instead of 128-byte pieces a whole [B, 2E] row apart),
 // mask[c] [B / beams, S[c]] uint8 or null, bias_k[c] / bias_v[c] [H*64] or null, out[c] [B, H*64] (row stride o_sb[c]).
 extern "C" int tell_attn_decode(int n_ctx, const void* const* q, const long* q_sb, const void* const* k, const long* k_ss,
-                                const long* k_sb, const void* const* v, const long* v_ss, const long* v_sb,
-                                const void* const* mask, const void* const* bias_k, const void* const* bias_v,
-                                int has_zero, const int* S, void* const* out, const long* o_sb, int B, int H, int beams,
-                                hipStream_t stream) {
+                                const long* k_sb, const long* k_sh, const void* const* v, const long* v_ss, const long* v_sb,
+                                const long* v_sh, const void* const* mask, const void* const* bias_k,
+                                const void* const* bias_v, int has_zero, const int* S, void* const* out, const long* o_sb,
+                                int B, int H, int beams, hipStream_t stream) {
   TELL_REQUIRE(n_ctx >= 1 && n_ctx <= SK_MAXP && B > 0 && H > 0 && beams >= 1 && B % beams == 0, "attn_decode: 1-4 contexts");
   AttnDecArgs g;
   g.B = B; g.H = H; g.beams = beams;
@@ -993,6 +995,8 @@ extern "C" int tell_attn_decode(int n_ctx, const void* const* q, const long* q_s
     g.c[c].q = (const uint16_t*)q[j]; g.c[c].k = (const uint16_t*)k[j]; g.c[c].v = (const uint16_t*)v[j];
     g.c[c].out = (uint16_t*)out[j]; g.c[c].mask = mask ? (const uint8_t*)mask[j] : nullptr;
     g.c[c].q_sb = q_sb[j]; g.c[c].k_ss = k_ss[j]; g.c[c].k_sb = k_sb[j]; g.c[c].v_ss = v_ss[j]; g.c[c].v_sb = v_sb[j];
+    g.c[c].k_sh = k_sh ? k_sh[j] : 64; g.c[c].v_sh = v_sh ? v_sh[j] : 64;
+    TELL_REQUIRE(g.c[c].k_sh % 8 == 0 && g.c[c].v_sh % 8 == 0, "attn_decode: 16-byte aligned heads");
     g.c[c].o_sb = o_sb[j]; g.c[c].S = S[j]; g.c[c].has_zero = has_zero ? 1 : 0;
     g.c[c].bias_k = bias_k ? (const uint16_t*)bias_k[j] : nullptr; g.c[c].bias_v = bias_v ? (const uint16_t*)bias_v[j] : nullptr;
   }

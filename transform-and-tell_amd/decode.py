@@ -28,6 +28,8 @@ MAX_ROWS = int(os.environ.get('TELL_DECODE_ROWS', '128'))
 # (csrc/decode.hip FOLD): 12 LayerNorm launches per step become one (the head's input).  TELL_DECODE_FOLD=0: round-4 form.
 FOLD = os.environ.get('TELL_DECODE_FOLD', '1') != '0'
 HEAD_GROUPED = os.environ.get('TELL_HEAD_GROUPED', '1') != '0'      # A/B aid: the two tail-table products as one launch
+# the generation loop's projected K / V cache HEAD-MAJOR ([B, H, S, 64]: models/transformer.py _decode_stepper); 0 = [S, B, E]
+KV_HEAD_MAJOR = os.environ.get('TELL_KV_HEAD_MAJOR', '1') != '0'
 
 
 def _folded(w_param_key, w, lns, seg):
@@ -232,7 +234,9 @@ def attn_decode_usable(mods, kv_layer, names, q):
         k = kv_layer[nm][0]
         if m.head_dim != 64 or m.bias_k is None or not m.add_zero_attn or k.shape[0] > 2048 or k.dtype != torch.bfloat16:
             return False
-        if k.shape[0] > 0 and (k.stride(2) != 1 or kv_layer[nm][1].stride(2) != 1 or q.shape[-2] % k.shape[1] != 0):
+        if k.shape[0] > 0 and (k.stride(-1) != 1 or kv_layer[nm][1].stride(-1) != 1 or q.shape[-2] % k.shape[1] != 0):
+            return False
+        if k.dim() == 4 and (k.shape[3] != 64 or kv_layer[nm][1].dim() != 4):      # head-major cache [S, B, H, 64] views
             return False
     return True
 
@@ -245,17 +249,21 @@ def attn_decode_all(mods, names, qs, kv_layer, contexts, M, E):
     dev = qs[0].device
     a_all = torch.empty(n, M, E, dtype=torch.bfloat16, device=dev)
     ks, vs, k_ss, k_sb, v_ss, v_sb, masks, S, bk, bv = [], [], [], [], [], [], [], [], [], []
+    k_sh, v_sh = [], []
     beams = 1
     for i, (nm, m) in enumerate(zip(names, mods)):
         k, v = kv_layer[nm]
         if k.shape[0] == 0:                                     # empty context: bias and zero rows only
             ks.append(qs[i]); vs.append(qs[i]); masks.append(None)
             k_ss.append(0); k_sb.append(0); v_ss.append(0); v_sb.append(0); S.append(0)
+            k_sh.append(64); v_sh.append(64)
         else:
-            assert k.stride(2) == 1 and v.stride(2) == 1 and M % k.shape[1] == 0
+            assert k.stride(-1) == 1 and v.stride(-1) == 1 and M % k.shape[1] == 0
             beams = M // k.shape[1]
             ks.append(k); vs.append(v)
             k_ss.append(k.stride(0)); k_sb.append(k.stride(1)); v_ss.append(v.stride(0)); v_sb.append(v.stride(1))
+            # [S, B, E] (heads side by side in a row) or a head-major cache seen as [S, B, H, 64]
+            k_sh.append(k.stride(2) if k.dim() == 4 else 64); v_sh.append(v.stride(2) if v.dim() == 4 else 64)
             S.append(k.shape[0])
             mk = contexts.get(nm + '_mask')
             if mk is not None and mk.dtype != torch.uint8:
@@ -264,9 +272,9 @@ def attn_decode_all(mods, names, qs, kv_layer, contexts, M, E):
         bk.append(ops._bias_row(m.bias_k, torch.bfloat16))
         bv.append(ops._bias_row(m.bias_v, torch.bfloat16))
     q_sb = [int(q.stride(-2)) for q in qs]
-    call('tell_attn_decode', n, _ptrs(qs), _longs(q_sb), _ptrs(ks), _longs(k_ss), _longs(k_sb), _ptrs(vs), _longs(v_ss),
-         _longs(v_sb), _ptrs(masks), _ptrs(bk), _ptrs(bv), 1, _ints(S), _ptrs([a_all[i] for i in range(n)]), _longs([E] * n),
-         M, mods[0].num_heads, beams)
+    call('tell_attn_decode', n, _ptrs(qs), _longs(q_sb), _ptrs(ks), _longs(k_ss), _longs(k_sb), _longs(k_sh), _ptrs(vs),
+         _longs(v_ss), _longs(v_sb), _longs(v_sh), _ptrs(masks), _ptrs(bk), _ptrs(bv), 1, _ints(S),
+         _ptrs([a_all[i] for i in range(n)]), _longs([E] * n), M, mods[0].num_heads, beams)
     return a_all
 
 

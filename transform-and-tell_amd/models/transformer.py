@@ -465,7 +465,7 @@ class CaptionModel(Model):
             h = cache[sig] = {
                 'graph': None, 'counter': torch.zeros(1, dtype=torch.int32, device=dev),
                 'cur': torch.zeros(B, 1, dtype=torch.long, device=dev),
-                'kv': [{n: tuple(torch.empty_like(t) for t in pair) for n, pair in lk.items()} for lk in kv],
+                'kv': None,
                 # (key-padding masks as the uint8 the attention kernels read: converted once per caption batch)
                 'ctx': {k: torch.empty_like(v, dtype=torch.uint8 if v.dtype == torch.bool else v.dtype)
                         for k, v in contexts.items() if torch.is_tensor(v)},
@@ -473,10 +473,26 @@ class CaptionModel(Model):
             }
             po = dec.embedder.token_embedder_position            # the table must already cover the longest caption
             po.next_start(gen_len + 2, None)
+            # The static copy of the projected K / V.  Where the weight-streaming step takes this batch (decode.usable: all
+            # four attentions of a layer are one tell_attn_decode launch) the copy is HEAD-MAJOR - [B, H, S, 64], handed on
+            # as [S, B, H, 64] views: the keys a (sample, head) workgroup walks are one contiguous block instead of 128-byte
+            # pieces a whole [B, 2E] projection row (128 KB at B = 32) apart.  The re-layout rides on the copy into the
+            # static buffers that the captured step needs anyway, once per caption batch.
+            from .. import decode as _dec
+            probe = torch.empty(1, B, dec.embedder.get_output_dim(), dtype=dtype, device=dev)
+            hm = _dec.KV_HEAD_MAJOR and dtype == torch.bfloat16 and _dec.usable(dec, probe, h['state'], kv)
+
+            def static_like(t, mod):
+                if hm and t.shape[0] > 0 and t.dim() == 3 and t.shape[2] == mod.num_heads * 64:
+                    S_, Bc, H_ = t.shape[0], t.shape[1], mod.num_heads
+                    return torch.empty(Bc, H_, S_, 64, dtype=t.dtype, device=t.device).permute(2, 0, 1, 3)
+                return torch.empty_like(t)
+            h['kv'] = [{n: tuple(static_like(t, layer.context_attns[n]) for t in pair) for n, pair in lk.items()}
+                       for lk, layer in zip(kv, dec.layers)]
         for lk, ls in zip(kv, h['kv']):
             for n, pair in lk.items():
                 for t, s in zip(pair, ls[n]):
-                    s.copy_(t)
+                    s.copy_(t.view(s.shape) if s.dim() == 4 else t)
         for k, s in h['ctx'].items():
             s.copy_(contexts[k])
         dec.reset_static_state(h['state'])
