@@ -69,6 +69,10 @@ int tell_set_rng_step_ptr(const void* counter, tell_stream_t stream);
 /* the same mechanism for the position offset of the embedder (positional.py:170-173 keeps it in incremental_state):
  * while registered, tell_embed_finalize adds *counter to start_pos - one captured decode step serves every position */
 int tell_set_pos_step_ptr(const void* counter, tell_stream_t stream);
+/* in-graph bookkeeping of a captured decode step: `next` (device uint32, or NULL) holds the position offset of the NEXT
+ * step; tell_embed_gather_step - the step's first kernel - reads it and publishes it in the counter registered above,
+ * tell_greedy_update / tell_beam_update - its last - write the following offset back (their `counter` argument) */
+int tell_set_pos_next_ptr(void* next, tell_stream_t stream);
 uint32_t tell_drop_threshold_host(float p);
 /* measurement aid (bench.py roofline): rate of the device wall clock in kHz (100 000 on MI355X) */
 int tell_wall_clock_khz(void);
@@ -258,10 +262,11 @@ int tell_loss_bits(const float* x, const int* n_valid, float* out, tell_stream_t
  * back (optional): the ancestor table int32 [n_back <= 31][B*K] of the DynamicConv rings (tell_dynconv_step), composed in
  * place with this step's parents: new back[0][r] = rows[r], new back[j][r] = old back[j-1][rows[r]] - the reference's
  * reorder_incremental_state (dynamic.py:338-342) without moving a row.  counter (optional): device int32 that a captured
- * decode step reads as its position offset (tell_set_pos_step_ptr); set to `step`, the offset of step + 1. */
+ * decode step reads as its position offset (tell_set_pos_step_ptr); set to `step`, the offset of step + 1.  step_dev
+ * (optional): the launch is PART of a captured step - the step index is *step_dev + 1 instead of `step`. */
 int tell_beam_update(const int* tk, const float* lp, float* cum, uint8_t* finished, long* seqs, float* lps, long* cur,
                      long* rows, int B, int K, int L, int step, int pad, int eos, float inv_temp, int* back, int n_back,
-                     int* counter, tell_stream_t stream);
+                     int* counter, const int* step_dev, tell_stream_t stream);
 /* buf[i][p][r][:] <- buf[i][p][rows[r]][:] in place for n <= 8 bf16 buffers [planes[i], M, 1024] (HOST arrays); rows[r]
  * must lie inside r's group of K consecutive rows (dynamic.py:338-342 reorder_incremental_state, all layers at once) - for
  * input buffers kept in time order (the layer-by-layer fp32 step); the rings of tell_dynconv_step are never moved. */
@@ -468,10 +473,11 @@ int tell_adaptive_logprob_argmax(const float* head, long ld_head, int c0, int n_
    unfinished rows record tok / lp * inv_temp at step i, rows emitting eos are marked finished (done_step = i + 1),
    cur = tok for the next step.  tok int32 [B], lp fp32 [B], finished uint8 [B], ids int64 [B, ld_ids], lps fp32
    [B, ld_lps], done_step int64 [B], cur int64 [B].  counter (optional): device int32 that a captured decode step reads
-   as its position offset (tell_set_pos_step_ptr); set to i, the offset of step i + 1. */
+   as its position offset (tell_set_pos_step_ptr); set to i, the offset of step i + 1.  step_dev (optional): the launch is
+   PART of a captured step - the step index is *step_dev + 1 instead of i. */
 int tell_greedy_update(const int* tok, const float* lp, uint8_t* finished, long* ids, long ld_ids, float* lps,
                        long ld_lps, long* done_step, long* cur, int B, int i, int eos, float inv_temp, int* counter,
-                       tell_stream_t stream);
+                       const int* step_dev, tell_stream_t stream);
 
 /* ---- BertAdam (config.yaml:126-149), flat fp32 buffers, tensors CHUNK-aligned */
 int tell_opt_chunk(void);

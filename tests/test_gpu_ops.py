@@ -1084,7 +1084,7 @@ def test_beam_bookkeeping_kernels_match_the_tensor_formulation():
         ring[i % (NB + 1)] = xrow
         moved = torch.cat([xrow[None], moved[:-1]], 0).index_select(1, rows)
         ops.call('tell_beam_update', tk, lp_t, k_cum, k_fin, k_seqs, k_lps, k_cur, k_rows, B, K, L, i, pad, eos, 1.0 / temp,
-                 k_back, NB, counter)
+                 k_back, NB, counter, None)
         assert int(counter) == i
         nb = torch.empty_like(m_back)
         nb[0] = rows.to(torch.int32)

@@ -683,7 +683,9 @@ extern "C" int tell_adaptive_logprob_argmax(const float* head, long ld_head, int
 __global__ void greedy_update_kernel(const int* __restrict__ tok, const float* __restrict__ lp,
                                      uint8_t* __restrict__ finished, long* __restrict__ ids, long ld_ids,
                                      float* __restrict__ lps, long ld_lps, long* __restrict__ done_step,
-                                     long* __restrict__ cur, int B, int i, int eos, float inv_temp, int* counter) {
+                                     long* __restrict__ cur, int B, int i_host, int eos, float inv_temp, int* counter,
+                                     const int* step_dev) {
+  const int i = step_dev ? *step_dev + 1 : i_host;             // (in a captured step: the registered counter holds i - 1)
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (counter && b == 0) *counter = i;       // position offset of the NEXT replay of a step graph captured at step 1: (i + 1) - 1
   if (b >= B) return;
@@ -701,9 +703,9 @@ __global__ void greedy_update_kernel(const int* __restrict__ tok, const float* _
 // int32 a captured decode step reads as its position offset - set to i (saves the per-step fill launch in front of the graph)
 extern "C" int tell_greedy_update(const int* tok, const float* lp, uint8_t* finished, long* ids, long ld_ids, float* lps,
                                   long ld_lps, long* done_step, long* cur, int B, int i, int eos, float inv_temp, int* counter,
-                                  hipStream_t stream) {
+                                  const int* step_dev, hipStream_t stream) {
   if (B <= 0) return TELL_OK;
   hipLaunchKernelGGL(greedy_update_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, tok, lp, finished, ids, ld_ids, lps,
-                     ld_lps, done_step, cur, B, i, eos, inv_temp, counter);
+                     ld_lps, done_step, cur, B, i, eos, inv_temp, counter, step_dev);
   return tell_check_launch("greedy_update");
 }

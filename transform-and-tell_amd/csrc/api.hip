@@ -91,6 +91,16 @@ extern "C" int tell_set_pos_step_ptr(const void* counter, hipStream_t) {
   g_tell_pos_step = static_cast<const uint32_t*>(counter);
   return TELL_OK;
 }
+// Round 6: the per-token bookkeeping launch INSIDE the captured decode step.  A second registered word holds the offset of
+// the NEXT step: the step's first kernel (tell_embed_gather_step, every block) reads it and its block 0 copies it into the
+// counter above, which every later kernel of the step reads; the bookkeeping kernel - the step's last - reads the counter
+// (every block) and its block 0 writes the next offset into the second word.  Nobody writes a word while another block of
+// the same launch may still read it, and the host's part of a decode step shrinks to one graph replay.
+uint32_t* g_tell_pos_next = nullptr;
+extern "C" int tell_set_pos_next_ptr(void* next, hipStream_t) {
+  g_tell_pos_next = static_cast<uint32_t*>(next);
+  return TELL_OK;
+}
 extern "C" uint32_t tell_keep_field_host(uint32_t seed, uint32_t salt, uint64_t idx) { return tell_keep_field(seed, salt, idx); }
 extern "C" uint32_t tell_drop_threshold_host(float p) { return tell_drop_threshold(p); }
 

@@ -105,6 +105,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // leaves the salt untouched.
 extern const uint32_t* g_tell_rng_step;
 extern const uint32_t* g_tell_pos_step;      // position offset counter of a captured decode step (api.hip)
+extern uint32_t* g_tell_pos_next;            // ... and the word that holds the NEXT step's offset (in-graph bookkeeping), or null
 __device__ __forceinline__ uint32_t tell_step_salt(uint32_t salt, const uint32_t* step) {
   return step ? salt + *step * 0x632BE5ABu : salt;
 }

@@ -1020,8 +1020,13 @@ __global__ __launch_bounds__(256) void embed_gather_step_kernel(const long* __re
                                                                 uint16_t* __restrict__ cat,
                                                                 const float* __restrict__ pos_table,
                                                                 float* __restrict__ pos_out,
-                                                                const uint32_t* __restrict__ step) {
+                                                                const uint32_t* step, const uint32_t* next) {
   const int m = blockIdx.x, tid = threadIdx.x;
+  // in-graph bookkeeping (api.hip g_tell_pos_next): this step's offset is in `next`; block 0 publishes it as the counter
+  // the later kernels of the step read
+  const uint32_t* sp = next ? next : step;
+  const int sv = sp ? (int)*sp : 0;
+  if (next && m == 0 && tid == 0) *const_cast<uint32_t*>(step) = (uint32_t)sv;
   const long id = ids[m];
   int band = -1;
   for (int b = 0; b < p.nb; ++b)
@@ -1034,7 +1039,7 @@ __global__ __launch_bounds__(256) void embed_gather_step_kernel(const long* __re
     if (c >= c0 && c < c1) v = *reinterpret_cast<const uint4*>(src + (c - c0));
     *reinterpret_cast<uint4*>(dst + c) = v;
   }
-  int pos = id == p.pos_pad ? p.pos_pad : p.pos_pad + 1 + p.start_pos + (step ? (int)*step : 0);
+  int pos = id == p.pos_pad ? p.pos_pad : p.pos_pad + 1 + p.start_pos + sv;
   if (pos >= p.pos_rows) pos = p.pos_rows - 1;
   for (int c = tid * 4; c < p.E; c += 1024)
     *reinterpret_cast<float4*>(pos_out + (long)m * p.E + c) = *reinterpret_cast<const float4*>(pos_table + (long)pos * p.E + c);
@@ -1053,7 +1058,7 @@ extern "C" int tell_embed_gather_step(const long* ids, int M, int nb, const void
   }
   a.nb = nb; a.ktot = ktot; a.E = E; a.pos_rows = pos_rows; a.pos_pad = pos_pad; a.start_pos = start_pos;
   hipLaunchKernelGGL(embed_gather_step_kernel, dim3(M), dim3(256), 0, stream, ids, a, static_cast<uint16_t*>(cat), pos_table,
-                     pos_out, g_tell_pos_step);
+                     pos_out, g_tell_pos_step, g_tell_pos_step ? g_tell_pos_next : nullptr);
   return tell_check_launch("embed_gather_step");
 }
 
@@ -1067,8 +1072,9 @@ __global__ __launch_bounds__(64) void beam_update_kernel(const int* __restrict__
                                                          float* __restrict__ cum, uint8_t* __restrict__ finished,
                                                          long* __restrict__ seqs, float* __restrict__ lps,
                                                          long* __restrict__ cur, long* __restrict__ rows, int K, int L,
-                                                         int step, int pad, int eos, float inv_temp, int* back, int n_back,
-                                                         int M, int* counter) {
+                                                         int step_host, int pad, int eos, float inv_temp, int* back, int n_back,
+                                                         int M, int* counter, const int* step_dev) {
+  const int step = step_dev ? *step_dev + 1 : step_host;      // (in a captured step: the registered counter holds step - 1)
   __shared__ long s_seq[8 * 256];
   __shared__ float s_lp[8 * 256];
   __shared__ int s_parent[8], s_tok[8];
@@ -1145,11 +1151,11 @@ __global__ __launch_bounds__(64) void beam_update_kernel(const int* __restrict__
 // offset of step + 1 for a graph captured at step 1).
 extern "C" int tell_beam_update(const int* tk, const float* lp, float* cum, uint8_t* finished, long* seqs, float* lps,
                                 long* cur, long* rows, int B, int K, int L, int step, int pad, int eos, float inv_temp,
-                                int* back, int n_back, int* counter, hipStream_t stream) {
-  TELL_REQUIRE(B > 0 && K >= 1 && K <= 8 && L >= 2 && L <= 256 && step >= 0 && step + 1 < L, "beam_update: K <= 8, L <= 256");
+                                int* back, int n_back, int* counter, const int* step_dev, hipStream_t stream) {
+  TELL_REQUIRE(B > 0 && K >= 1 && K <= 8 && L >= 2 && L <= 256 && (step_dev || (step >= 0 && step + 1 < L)), "beam_update: K <= 8, L <= 256");
   TELL_REQUIRE(!back || (n_back >= 1 && n_back <= 31), "beam_update: ancestor table of 1 .. 31 steps");
   hipLaunchKernelGGL(beam_update_kernel, dim3(B), dim3(64), 0, stream, tk, lp, cum, finished, seqs, lps, cur, rows, K, L,
-                     step, pad, eos, inv_temp, back, back ? n_back : 0, B * K, counter);
+                     step, pad, eos, inv_temp, back, back ? n_back : 0, B * K, counter, step_dev);
   return tell_check_launch("beam_update");
 }
 

@@ -30,6 +30,9 @@ FOLD = os.environ.get('TELL_DECODE_FOLD', '1') != '0'
 HEAD_GROUPED = os.environ.get('TELL_HEAD_GROUPED', '1') != '0'      # A/B aid: the two tail-table products as one launch
 # the generation loop's projected K / V cache HEAD-MAJOR ([B, H, S, 64]: models/transformer.py _decode_stepper); 0 = [S, B, E]
 KV_HEAD_MAJOR = os.environ.get('TELL_KV_HEAD_MAJOR', '1') != '0'
+# the per-token bookkeeping launch (tell_greedy_update / tell_beam_update) as the LAST launch of the captured step: the host's
+# part of a decode step is one graph replay.  0 = a host-side launch behind every replay (A/B aid)
+IN_GRAPH_BOOK = os.environ.get('TELL_DECODE_BOOK_IN_GRAPH', '1') != '0'
 
 
 def _folded(w_param_key, w, lns, seg):

@@ -393,21 +393,39 @@ class CaptionModel(Model):
         step = self._decode_stepper(B, kv, contexts, gen_len)
         cur = caption_ids[:, 0:1].contiguous()
         finished = cur[:, 0] == eos
-        ids = torch.full((B, gen_len + 1), self.padding_idx, dtype=torch.long, device=dev)
-        ids[:, 0] = cur[:, 0]
-        lps = torch.zeros(B, gen_len, dtype=torch.float32, device=dev)
-        done_step = torch.full((B,), gen_len, dtype=torch.long, device=dev)   # steps this row took part in
-        done_step[finished] = 0
-        steps = gen_len
         fused = caption_ids.is_cuda and hasattr(step, 'cur')      # one bookkeeping launch per token (tell_greedy_update)
         if fused:
-            fin8 = finished.to(torch.uint8)
+            # the histories live in STATIC buffers of the stepper (the bookkeeping launch is part of the captured step)
+            bk = step.book('greedy', lambda: dict(
+                ids=torch.empty(B, gen_len + 1, dtype=torch.long, device=dev),
+                lps=torch.empty(B, gen_len, dtype=torch.float32, device=dev),
+                done_step=torch.empty(B, dtype=torch.long, device=dev), fin8=torch.empty(B, dtype=torch.uint8, device=dev)))
+            ids, lps, done_step, fin8 = bk['ids'], bk['lps'], bk['done_step'], bk['fin8']
+            ids.fill_(self.padding_idx)
+            lps.zero_()
+            done_step.fill_(gen_len)
+        else:
+            ids = torch.full((B, gen_len + 1), self.padding_idx, dtype=torch.long, device=dev)
+            lps = torch.zeros(B, gen_len, dtype=torch.float32, device=dev)
+            done_step = torch.full((B,), gen_len, dtype=torch.long, device=dev)   # steps this row took part in
+        ids[:, 0] = cur[:, 0]
+        done_step[finished] = 0
+        steps = gen_len
+        if fused:
+            fin8.copy_(finished)
             step.cur.copy_(cur)
+            inv_temp = 1.0 / float(self.sampling_temp)
+
+            def book(out, i, step_dev):
+                # the step's LAST launch: inside the captured step it takes the step index from the device counter
+                # (step_dev), eagerly from the host; either way it leaves the next step's position offset behind
+                tok, lp = out
+                ops.call('tell_greedy_update', tok.reshape(B), lp.reshape(B), fin8, ids, ids.stride(0), lps, lps.stride(0),
+                         done_step, step.cur, B, int(i), int(eos), inv_temp, step.counter_out, step_dev)
         for i in range(gen_len if fused else 0):
-            # (the bookkeeping launch of step i - 1 left the position offset of step i in the device counter: no fill launch)
-            tok, lp = step(i, None, counter_set=i > 0)
-            ops.call('tell_greedy_update', tok.reshape(B), lp.reshape(B), fin8, ids, ids.stride(0), lps, lps.stride(0),
-                     done_step, step.cur, B, i, int(eos), 1.0 / float(self.sampling_temp), step.counter)
+            # (the bookkeeping launch of step i - 1 left the position offset of step i in the device counter: no fill launch;
+            #  the host's part of a step is ONE graph replay)
+            step(i, None, counter_set=i > 0, post=book)
             if (i + 1) % check_every == 0 and bool(fin8.all()):
                 break
         for i in range(0 if fused else gen_len):
@@ -424,6 +442,8 @@ class CaptionModel(Model):
                 break
         steps = int(done_step.max())                                          # one sync at the end
         steps = max(steps, 1)
+        if fused:                                                             # (the static buffers belong to the stepper)
+            return lps[:, :steps].clone(), ids[:, :steps + 1].clone(), []
         return lps[:, :steps], ids[:, :steps + 1], []
 
     def _decode_stepper(self, B, kv, contexts, gen_len, topk=0):
@@ -448,7 +468,7 @@ class CaptionModel(Model):
             eager_step.reorder = lambda rows: dec.reorder_incremental_state(state, rows)
             return eager_step
         dev, dtype = kv[0][names[0]][0].device, kv[0][names[0]][0].dtype
-        sig = (B, dtype, topk, tuple((n, tuple(kv[0][n][0].shape), tuple(kv[0][n][1].shape)) for n in names),
+        sig = (B, dtype, topk, int(gen_len), tuple((n, tuple(kv[0][n][0].shape), tuple(kv[0][n][1].shape)) for n in names),
                dec.embedder.token_embedder_position.weights.data_ptr())
         cache = self.__dict__.setdefault('_decode_graphs', {})
         # A captured step bakes in the addresses of the working weights (weight-normalised copies, the concatenated
@@ -463,7 +483,9 @@ class CaptionModel(Model):
             if len(cache) >= graphs.MAX_SIGNATURES:
                 cache.pop(next(iter(cache)))
             h = cache[sig] = {
-                'graph': None, 'counter': torch.zeros(1, dtype=torch.int32, device=dev),
+                # counter[0]: the position offset the kernels of a replay read; counter[1]: the NEXT step's offset when
+                # the bookkeeping launch is part of the captured step (`ig`, below)
+                'graph': None, 'counter': torch.zeros(2, dtype=torch.int32, device=dev), 'book': {},
                 'cur': torch.zeros(B, 1, dtype=torch.long, device=dev),
                 'kv': None,
                 # (key-padding masks as the uint8 the attention kernels read: converted once per caption batch)
@@ -489,6 +511,9 @@ class CaptionModel(Model):
                 return torch.empty_like(t)
             h['kv'] = [{n: tuple(static_like(t, layer.context_attns[n]) for t in pair) for n, pair in lk.items()}
                        for lk, layer in zip(kv, dec.layers)]
+            # in-graph bookkeeping needs the step's first kernel to be tell_embed_gather_step (it publishes the counter)
+            h['ig'] = bool(_dec.IN_GRAPH_BOOK and dtype == torch.bfloat16 and _dec.usable(dec, probe, h['state'], kv) and
+                           _dec.embed_usable(dec.embedder, h['cur'], h['state']))
         for lk, ls in zip(kv, h['kv']):
             for n, pair in lk.items():
                 for t, s in zip(pair, ls[n]):
@@ -501,40 +526,67 @@ class CaptionModel(Model):
 
         head = (lambda x: dec.adaptive_softmax.topk(x, topk)) if topk else dec.adaptive_softmax.greedy
 
+        c_cur, c_next = h['counter'][0:1], h['counter'][1:2]
+        # where a bookkeeping launch leaves the next step's offset: the word the embedder's kernel reads (in-graph
+        # bookkeeping), or the counter itself
+        c_out = c_next if h['ig'] else c_cur
+
         def run():
             out = dec({self.index: h['cur']}, h['ctx'], incremental_state=h['state'], kv_cache=h['kv'])
             return head(out[0][:, -1:])
 
-        def step(i, cur, counter_set=False):
+        def eager(i, post):
+            res = run()
+            if post is not None:
+                post(res, i, None)
+            return res
+
+        def step(i, cur, counter_set=False, post=None):
+            """post(out, i, step_dev): the caller's per-token bookkeeping launch (over static buffers: step.book).  With
+            in-graph bookkeeping it is recorded as the LAST launch of the captured step."""
             if cur is not None:                                   # (None: the caller already wrote step.cur)
                 h['cur'].copy_(cur)
             if h['graph'] is None and i != 1:
-                return run()                                      # warm step(s) before the capture, or fallback
+                return eager(i, post)                             # warm step(s) before the capture, or fallback
             if h['graph'] is None:                                # i == 1: the host position state is 1 now
+                inside = post is not None and h['ig']
                 try:
                     g = torch.cuda.CUDAGraph()
                     try:
-                        ops.call('tell_set_rng_step_ptr', h['counter'])
-                        ops.call('tell_set_pos_step_ptr', h['counter'])
+                        ops.call('tell_set_rng_step_ptr', c_cur)
+                        ops.call('tell_set_pos_step_ptr', c_cur)
+                        if inside:
+                            ops.call('tell_set_pos_next_ptr', c_next)
                         # (the captured step's resident GEMM launches keep their tile-counter slots until this entry is
                         #  dropped - `held` gives them back, like StepGraph / GraphedCall do)
                         with graphs.no_gc(), ops.hip.tile_slots() as held, torch.cuda.graph(g):
                             with ops.hip.bound_stream():
                                 h['out'] = run()
+                                if inside:
+                                    post(h['out'], i, c_cur)
                         h['tile_slots'] = held
                     finally:
                         ops.call('tell_set_rng_step_ptr', None)
                         ops.call('tell_set_pos_step_ptr', None)
-                    h['graph'], h['base'] = g, 1
+                        ops.call('tell_set_pos_next_ptr', None)
+                    h['graph'], h['base'], h['graph_has_post'] = g, 1, inside
                 except Exception as exc:                          # noqa: BLE001 - stay eager for this signature
                     h['graph'], h['error'] = False, repr(exc)
-                    return run()
+                    return eager(i, post)
             if h['graph'] is False:
-                return run()
+                return eager(i, post)
             if not counter_set:
-                h['counter'].fill_(i - h['base'])                 # position offset of this step (may be -1)
+                # position offset of this step (may be -1): into the word the step's first kernel reads
+                (c_next if h.get('graph_has_post') else c_cur).fill_(i - h['base'])
             h['graph'].replay()
+            if post is not None and not h.get('graph_has_post'):
+                post(h['out'], i, None)
             return h['out']
+
+        def book(kind, make):
+            if kind not in h['book']:
+                h['book'][kind] = make()
+            return h['book'][kind]
 
         def reorder(rows, group=0):                               # in place: the buffers are part of the graph
             if h['state'].get('_ring'):                           # rings: only the ancestor table changes
@@ -551,7 +603,8 @@ class CaptionModel(Model):
                 s.copy_(s.index_select(1, rows))
         step.reorder = reorder
         step.cur = h['cur']
-        step.counter = h['counter']                               # (base 1: the offset of step i is i - 1)
+        step.book = book
+        step.counter_out = c_out                                  # (base 1: the offset of step i is i - 1)
         step.back = h['state'].get('_back')                       # ancestor table of the DynamicConv rings, or None
         return step
 
@@ -574,29 +627,45 @@ class CaptionModel(Model):
         kv = dec.project_contexts(contexts)
         step = self._decode_stepper(B * K, kv, ctx, gen_len, topk=K)
         cur = rep(caption_ids[:, 0:1], 0)
-        cum = torch.full((B, K), float('-inf'), dtype=torch.float32, device=dev)
-        cum[:, 0] = 0.0                                     # all K rows start identical: only hypothesis 0 counts
         finished = (cur[:, 0] == eos).view(B, K)
-        seqs = torch.full((B, K, gen_len + 1), pad, dtype=torch.long, device=dev)
-        seqs[:, :, 0] = cur.view(B, K)
-        lps = torch.zeros(B, K, gen_len, dtype=torch.float32, device=dev)
-        base = (torch.arange(B, device=dev) * K).view(B, 1)
-        n_steps = gen_len
         fused = caption_ids.is_cuda and hasattr(step, 'cur') and K <= 8 and gen_len + 1 <= 256
         if fused:
+            bk = step.book('beam', lambda: dict(
+                cum=torch.empty(B, K, dtype=torch.float32, device=dev), fin8=torch.empty(B, K, dtype=torch.uint8, device=dev),
+                seqs=torch.empty(B, K, gen_len + 1, dtype=torch.long, device=dev),
+                lps=torch.empty(B, K, gen_len, dtype=torch.float32, device=dev),
+                rows=torch.empty(B * K, dtype=torch.long, device=dev)))
+            cum, fin8, seqs, lps, rows = bk['cum'], bk['fin8'], bk['seqs'], bk['lps'], bk['rows']
+            cum.fill_(float('-inf'))
+            seqs.fill_(pad)
+            lps.zero_()
+        else:
+            cum = torch.full((B, K), float('-inf'), dtype=torch.float32, device=dev)
+            seqs = torch.full((B, K, gen_len + 1), pad, dtype=torch.long, device=dev)
+            lps = torch.zeros(B, K, gen_len, dtype=torch.float32, device=dev)
+        cum[:, 0] = 0.0                                     # all K rows start identical: only hypothesis 0 counts
+        seqs[:, :, 0] = cur.view(B, K)
+        base = (torch.arange(B, device=dev) * K).view(B, 1)
+        n_steps = gen_len
+        if fused:
             # one bookkeeping launch per token (tell_beam_update: candidate scores, top-K per sample, histories gathered
-            # by parent, next inputs) + one launch that moves every layer's DynamicConv buffer rows to their descendants
-            fin8 = finished.to(torch.uint8).contiguous()
-            rows = torch.empty(B * K, dtype=torch.long, device=dev)
+            # by parent, next inputs; ring buffers: it also composes the ancestor table with this step's parents - no row
+            # of any layer's DynamicConv buffer is moved) - the LAST launch of the captured step where the stepper allows
+            fin8.copy_(finished)
             step.cur.copy_(cur)
             ring = step.back is not None
+            inv_temp = 1.0 / float(self.sampling_temp)
+
+            def book(out, i, step_dev):
+                tk, lp = out
+                ops.call('tell_beam_update', tk, lp, cum, fin8, seqs, lps, step.cur, rows, B, K, gen_len + 1, int(i), int(pad),
+                         int(eos), inv_temp, step.back, step.back.shape[0] if ring else 0, step.counter_out, step_dev)
             for i in range(gen_len):
-                tk, lp = step(i, None, counter_set=i > 0)
-                # (ring buffers: the same launch composes the ancestor table with this step's parents - no row of any
-                #  layer's DynamicConv buffer is moved; time-ordered buffers: one launch re-orders every layer's rows)
-                ops.call('tell_beam_update', tk, lp, cum, fin8, seqs, lps, step.cur, rows, B, K, gen_len + 1, i, int(pad),
-                         int(eos), 1.0 / float(self.sampling_temp), step.back, step.back.shape[0] if ring else 0, step.counter)
+                # (time-ordered buffers - fp32 parity mode: the bookkeeping stays a host-side launch and one more launch
+                #  re-orders every layer's rows by parent)
+                out = step(i, None, counter_set=i > 0, post=book if ring else None)
                 if not ring:
+                    book(out, i, None)
                     step.reorder(rows, K)
                 if (i + 1) % check_every == 0 and bool(fin8.all()):
                     n_steps = i + 1
@@ -631,6 +700,8 @@ class CaptionModel(Model):
         best = seqs[:, 0]                                    # topk keeps hypotheses sorted by score
         steps = int((best[:, 1:] != pad).sum(1).max())       # one sync: length of the longest best caption
         steps = max(min(steps, n_steps), 1)
+        if fused:                                            # (the static buffers belong to the stepper)
+            return lps[:, 0, :steps].clone(), best[:, :steps + 1].clone(), []
         return lps[:, 0, :steps], best[:, :steps + 1], []
 
     @torch.no_grad()
