@@ -463,7 +463,7 @@ def measure(args, model_name, batch_size, dev, world, rank, dist, roofline=True)
         traffic, tnote = None, None
         if not args.no_pmc and model_name == 'faces_objects' and name.startswith('gemm_nt_q4_kernel') and rank == 0:
             traffic, tnote = measure_gemm_traffic(name, args.batch or 32)
-        for fn in (() if traffic else ('r05_pmc_gemm_traffic.json', 'r04_pmc_gemm_traffic.json', 'r03_pmc_gemm_traffic.json')):
+        for fn in (() if traffic else ('r06_pmc_gemm_traffic.json', 'r05_pmc_gemm_traffic.json', 'r04_pmc_gemm_traffic.json')):
             pmc = os.path.join(ROOT, 'profiles', fn)
             if os.path.exists(pmc):      # HBM bytes per launch of this kernel from the committed PMC passes
                 j = json.load(open(pmc))
@@ -757,7 +757,7 @@ def generate_bench(args, dev, world, rank, dist):
     tbs = (w_bytes + kv_bytes) / (step_us * 1e-6) / 1e12
     traffic, tnote = None, None
     pmc = None
-    for rnd in ('r05', 'r04'):                 # the newest committed PMC passes of the decode step
+    for rnd in ('r06', 'r05', 'r04'):          # the newest committed PMC passes of the decode step
         cand = os.path.join(ROOT, 'profiles', '%s_pmc_generate_%s_traffic.json' % (rnd, 'beam%d' % beam if beam > 1 else 'greedy'))
         if os.path.exists(cand):
             pmc = cand
