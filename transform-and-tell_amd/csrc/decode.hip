@@ -808,168 +808,194 @@ struct AttnDecArgs { AttnDecCtx c[SK_MAXP]; int B, H, beams; };
 
 // NQ: hypotheses of one sample served by a workgroup (beam search: the NQ rows b*beams + j read the SAME cached keys
 // and values - loaded once, used NQ times).
+// Round 6: ONE pass.  Rounds 3-5 walked the keys twice - scores into LDS (33 KB at four hypotheses), a block-wide softmax,
+// then the values - i.e. 2 x 4 dependent trips of loads per workgroup with barriers in between: a chain of ~8 memory round
+// trips for 128 KB of cache, 2.5 TB/s at four hypotheses per workgroup (3.8 with one) whatever the arithmetic cost (halving
+// the VALU work changed nothing).  Now every group of 8 lanes that shares a key keeps its OWN running (max, sum, output) over
+// the keys it sees - the flash-decoding split, across lanes instead of workgroups: a trip loads K AND V of its keys (8 loads
+// in flight per lane), no score ever leaves the registers, nothing synchronises until the end, where the 8 key slots of a wave
+// merge through shuffles and the 4 waves through LDS.  The learned bias_k / bias_v key and the zero key are two more keys of
+// wave 0's first slot.
 template <int NQ>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecArgs g) {
   const AttnDecCtx& p = g.c[blockIdx.y];
-  __shared__ float sc[NQ][AD_MAXS + 2];
-  __shared__ float redw[NQ][4];
-  __shared__ float part[NQ][4][64];
+  __shared__ float part_o[NQ][NQ <= 2 ? 4 : 32][64];           // per wave (NQ <= 2) / per (wave, key slot): output, (max, sum)
+  __shared__ float part_ml[NQ][NQ <= 2 ? 4 : 32][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int groups = (g.beams + NQ - 1) / NQ;                 // workgroups per (sample, head)
   const int h = blockIdx.x % g.H, bg = blockIdx.x / g.H, bs = bg / groups, j0 = (bg % groups) * NQ;
   const int nq = g.beams - j0 < NQ ? g.beams - j0 : NQ;       // live hypotheses of this workgroup
   const int b0 = bs * g.beams + j0;                            // first row
   const int ks = lane >> 3, dc = lane & 7, S = p.S;
-  // Round 6: the arithmetic of both passes halved - at four hypotheses per workgroup the kernel was bound by its VALU work,
-  // not by the cache reads (2.7 TB/s against 4.6 with one hypothesis; per 16 bytes of K: 8 unpack + 32 FMA + 12 DPP adds).
-  // Scores: q stays PACKED bf16 and meets the packed key in four v_dot2_f32_bf16 per hypothesis (exact products, fp32 sum);
-  // values: the unpacked value pairs meet the probability in four v_pk_fma_f32 per hypothesis.
   uint4 q[NQ];
 #pragma unroll
   for (int i = 0; i < NQ; ++i)
     q[i] = *reinterpret_cast<const uint4*>(p.q + (long)(b0 + (i < nq ? i : 0)) * p.q_sb + h * 64 + dc * 8);
-  // (round 5: a head-major cache [B, H, S, 64] - one contiguous block per workgroup instead of S pieces of 128 bytes a row
-  //  of E apart - measured on one layer's four contexts at B = 32: 16.2 -> 15.8 us; the layout is not what costs)
   const uint16_t* kb = p.k + (long)bs * p.k_sb + (long)h * p.k_sh + dc * 8;
   const uint16_t* vb = p.v + (long)bs * p.v_sb + (long)h * p.v_sh + dc * 8;
   const uint8_t* mk = p.mask ? p.mask + (long)bs * S : nullptr;
-  const int ST = S + (p.bias_k ? 1 : 0) + p.has_zero;
   const int S8 = (S + 7) & ~7;
-  // AD_G key groups (of 32 keys: 8 per wave) per trip - their loads fly together.  (Round 5 measured 8 groups per trip
-  // and the first trip of values requested ahead of the softmax: greedy step 492.7 -> 494.5 us, beam 4 743 -> 822 us -
-  // at 4 hypotheses per workgroup the 200 registers it takes halve the occupancy; 4 groups stay.)
-  // (Round 5, second half: the score rows as dynamic LDS sized by the launch's longest context - 8 KB instead of 33 KB at four
-  //  hypotheses and S = 512 - measured: greedy step 457.8 -> 457.3 us, beam 4 708.6 -> 714.7, 512 rows 1384 -> 1397 us; the
-  //  LDS is not what bounds the resident workgroups; static arrays stay.  What does: 68 / 88 / 128 VGPRs at 1 / 2 / 4 hypotheses =
-  //  7 / 5 / 4 workgroups per CU - the four-hypothesis form reads the cache at 2.7 TB/s where the one-hypothesis form reaches
-  //  4.6; capping it at 96 / 80 registers (amdgpu_waves_per_eu 5 / 6) spills 42 / 78 of them.)
-  constexpr int AD_G = 4;
-  for (int s0 = wave * 8; s0 < S8; s0 += 32 * AD_G) {
-    uint4 kr[AD_G];
-#pragma unroll
-    for (int u = 0; u < AD_G; ++u) {
-      const int s = s0 + u * 32 + ks;
-      kr[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (s < S) kr[u] = *reinterpret_cast<const uint4*>(kb + (long)s * p.k_ss);
-    }
-#pragma unroll
-    for (int u = 0; u < AD_G; ++u) {
-      const int s = s0 + u * 32 + ks;
-      const bool masked = s < S && mk && mk[s];
-#pragma unroll
-      for (int i = 0; i < NQ; ++i) {
-        float d = sk_dot8(q[i], kr[u], 0.f);
-        d += sk_dpp<0xB1>(d); d += sk_dpp<0x4E>(d); d += sk_dpp<0x141>(d);     // over the 8 lanes that share the key
-        if (dc == 0 && s < S) sc[i][s] = masked ? -INFINITY : d;
-      }
-    }
-  }
-  if (wave == 0) {
-    if (p.bias_k) {
-      const uint4 kb4 = *reinterpret_cast<const uint4*>(p.bias_k + h * 64 + dc * 8);
-#pragma unroll
-      for (int i = 0; i < NQ; ++i) {
-        float d = sk_dot8(q[i], kb4, 0.f);
-        d += sk_dpp<0xB1>(d); d += sk_dpp<0x4E>(d); d += sk_dpp<0x141>(d);
-        if (lane == 0) sc[i][S] = d;
-      }
-    }
-    if (p.has_zero && lane == 0) {
-#pragma unroll
-      for (int i = 0; i < NQ; ++i) sc[i][ST - 1] = 0.f;
-    }
-  }
-  __syncthreads();
-  float mx[NQ], l[NQ];
-#pragma unroll
-  for (int i = 0; i < NQ; ++i) {
-    float m = -INFINITY;
-    for (int s = tid; s < ST; s += 256) m = fmaxf(m, sc[i][s]);
-    m = wave_max(m);
-    if (lane == 0) redw[i][wave] = m;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < NQ; ++i) mx[i] = fmaxf(fmaxf(redw[i][0], redw[i][1]), fmaxf(redw[i][2], redw[i][3]));
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < NQ; ++i) {
-    float t = 0.f;
-    for (int s = tid; s < ST; s += 256) {
-      const float e = mx[i] == -INFINITY ? 0.f : __expf(sc[i][s] - mx[i]);
-      sc[i][s] = e; t += e;
-    }
-    t = sk_wave_sum(t);
-    if (lane == 0) redw[i][wave] = t;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < NQ; ++i) l[i] = (redw[i][0] + redw[i][1]) + (redw[i][2] + redw[i][3]);
   typedef float ad_f2 __attribute__((ext_vector_type(2)));
+  float m[NQ], l[NQ];
   ad_f2 o[NQ][4];
 #pragma unroll
-  for (int i = 0; i < NQ; ++i)
+  for (int i = 0; i < NQ; ++i) {
+    m[i] = -INFINITY; l[i] = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[i][e] = ad_f2{0.f, 0.f};
+  }
   auto unpack2 = [](const uint4& w, ad_f2 (&f)[4]) __attribute__((always_inline)) {
     f[0] = ad_f2{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u)};
     f[1] = ad_f2{__uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u)};
     f[2] = ad_f2{__uint_as_float(w.z << 16), __uint_as_float(w.z & 0xffff0000u)};
     f[3] = ad_f2{__uint_as_float(w.w << 16), __uint_as_float(w.w & 0xffff0000u)};
   };
-  for (int s0 = wave * 8; s0 < S8; s0 += 32 * AD_G) {
-    uint4 vr[AD_G];
+  // Scores are kept in the exp2 domain (d * log2 e: one multiply, then v_exp_f32 directly).  A TRIP of AD_G keys is absorbed
+  // at once: the running maximum moves once per trip (one rescale of the state for AD_G keys).  PMC on the first one-pass
+  // version (profiles/r06_pmc_attn_decode.txt): the kernel was INSTRUCTION-bound - 100 instructions per key and lane with one
+  // hypothesis, 200 with four (issue slots 78 % busy at beam 4), memory latency 770-1050 cycles per request and hidden.
+  constexpr float LOG2E = 1.4426950408889634f;
+  constexpr int AD_G = 4;
+  // act[u]: WAVE-uniform - key group u of the trip has any key at all (the short contexts - 4 faces, 49 regions - fill one
+  // or two of a trip's four groups: the others cost a scalar branch instead of ~100 instructions)
+  auto absorb = [&](const uint4 (&kr)[AD_G], const uint4 (&vr)[AD_G], const bool (&live)[AD_G], const bool (&act)[AD_G])
+      __attribute__((always_inline)) {
+    float sc[NQ][AD_G], mn[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) mn[i] = m[i];
 #pragma unroll
     for (int u = 0; u < AD_G; ++u) {
-      const int s = s0 + u * 32 + ks;
-      vr[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (s < S) vr[u] = *reinterpret_cast<const uint4*>(vb + (long)s * p.v_ss);
+      if (act[u]) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+          float d = sk_dot8(q[i], kr[u], 0.f);
+          d += sk_dpp<0xB1>(d); d += sk_dpp<0x4E>(d); d += sk_dpp<0x141>(d);   // over the 8 lanes that share the key
+          sc[i][u] = live[u] ? d * LOG2E : -INFINITY;
+          mn[i] = fmaxf(mn[i], sc[i][u]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) sc[i][u] = -INFINITY;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      // (mn = -inf: nothing live so far - keep the empty state; m = -inf, mn finite: exp2(-inf) = 0)
+      const float a = mn[i] == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(m[i] - mn[i]);
+      const ad_f2 a2 = {a, a};
+      l[i] *= a;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[i][e] *= a2;
+      m[i] = mn[i];
     }
 #pragma unroll
     for (int u = 0; u < AD_G; ++u) {
-      const int s = s0 + u * 32 + ks;
+      if (!act[u]) continue;
       ad_f2 vf[4];
       unpack2(vr[u], vf);
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
-        const float pr = s < S ? sc[i][s] : 0.f;
+        const float pr = sc[i][u] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(sc[i][u] - mn[i]);
+        l[i] += pr;
         const ad_f2 p2 = {pr, pr};
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[i][e] = __builtin_elementwise_fma(p2, vf[e], o[i][e]);
       }
     }
+  };
+  // a trip = AD_G key groups of 32 keys (8 per wave): the K and V loads of a trip (2 x AD_G per lane) fly together.
+  // Branch-free: a key past S re-reads key S - 1 and is not live.
+  const bool has_mask = mk != nullptr;
+  const uint8_t* mkp = has_mask ? mk : reinterpret_cast<const uint8_t*>(p.q);   // (no mask: any readable byte, ignored)
+  const int kss = (int)p.k_ss, vss = (int)p.v_ss;                               // (S * stride < 2^31: checked by the launcher)
+  for (int s0 = wave * 8; s0 < S8; s0 += 32 * AD_G) {
+    uint4 kr[AD_G], vr[AD_G];
+    bool live[AD_G], act[AD_G];
+#pragma unroll
+    for (int u = 0; u < AD_G; ++u) {
+      const int s = s0 + u * 32 + ks;
+      const int sc_ = s < S ? s : S - 1;
+      act[u] = s0 + u * 32 < S8;                                                // (s0 is a multiple of 8: wave-uniform)
+      kr[u] = make_uint4(0u, 0u, 0u, 0u); vr[u] = make_uint4(0u, 0u, 0u, 0u);
+      live[u] = false;
+      if (act[u]) {
+        kr[u] = *reinterpret_cast<const uint4*>(kb + sc_ * kss);
+        vr[u] = *reinterpret_cast<const uint4*>(vb + sc_ * vss);
+        const uint8_t mb = mkp[has_mask ? sc_ : 0];
+        live[u] = (s < S) & !(has_mask & (mb != 0));
+      }
+    }
+    absorb(kr, vr, live, act);
   }
-  if (p.bias_v && wave == 0 && ks == 0) {
-    ad_f2 vf[4];
-    unpack2(*reinterpret_cast<const uint4*>(p.bias_v + h * 64 + dc * 8), vf);
+  {  // the two virtual keys (multi_head.py:355-364, :416-421), never masked: wave 0, key slot 0
+    const bool mine = wave == 0 && ks == 0;
+    if (wave == 0) {
+      uint4 kr[AD_G], vr[AD_G];
+      bool live[AD_G], act[AD_G];
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      const float pr = sc[i][S];
-      const ad_f2 p2 = {pr, pr};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[i][e] = __builtin_elementwise_fma(p2, vf[e], o[i][e]);
+      for (int u = 0; u < AD_G; ++u) { kr[u] = make_uint4(0u, 0u, 0u, 0u); vr[u] = make_uint4(0u, 0u, 0u, 0u); live[u] = false; act[u] = u < 2; }
+      if (p.bias_k) {
+        kr[0] = *reinterpret_cast<const uint4*>(p.bias_k + h * 64 + dc * 8);
+        if (p.bias_v) vr[0] = *reinterpret_cast<const uint4*>(p.bias_v + h * 64 + dc * 8);
+        live[0] = mine;
+      }
+      live[1] = mine && p.has_zero != 0;                   // the zero key: score 0, value 0
+      absorb(kr, vr, live, act);
     }
   }
+  // ---- merge: every (wave, key slot) that saw a key parks its state in LDS; NQ x 64 threads fold the slots per output
+  // element.  (First version: three rounds of shuffles per wave - 30 ds_bpermute per hypothesis - then the 4 waves through LDS:
+  // ~600 instructions per wave, more than a short context's whole trip.)  Waves without keys (a 4-face context has one
+  // live wave) only pass the barrier.
+  const int n_waves = S8 > 24 ? 4 : (S8 > 16 ? 3 : (S8 > 8 ? 2 : 1));      // waves with at least one key (wave 0 always: virtual keys)
+  // One or two hypotheses per workgroup: only 64 / 128 threads fold, so the 8 key slots of a wave merge by shuffles first
+  // and one slot per wave goes through LDS (measured with one hypothesis: 17.2 us this way, 21.8 us with 32 slots in LDS;
+  // with four: 36.8 against 28.6 us the other way round).
+  constexpr bool WAVE_MERGE = NQ <= 2;
+  if (wave < n_waves) {
+    if constexpr (WAVE_MERGE) {
 #pragma unroll
-  for (int i = 0; i < NQ; ++i) {
-    float ov[8];
+      for (int i = 0; i < NQ; ++i) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float v = (e & 1) ? o[i][e >> 1].y : o[i][e >> 1].x;
-      v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-      ov[e] = v;
+        for (int off = 8; off < 64; off <<= 1) {
+          const float m2 = __shfl_xor(m[i], off), l2 = __shfl_xor(l[i], off);
+          const float mn = fmaxf(m[i], m2);
+          const float a = mn == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(m[i] - mn), b = mn == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(m2 - mn);
+          l[i] = l[i] * a + l2 * b;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float ox = __shfl_xor(o[i][e].x, off), oy = __shfl_xor(o[i][e].y, off);
+            o[i][e] = ad_f2{o[i][e].x * a + ox * b, o[i][e].y * a + oy * b};
+          }
+          m[i] = mn;
+        }
+      }
     }
-    if (ks == 0) {
+    if (!WAVE_MERGE || ks == 0) {
+      const int slot = WAVE_MERGE ? wave : wave * 8 + ks;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) part[i][wave][dc * 8 + e] = ov[e];
+      for (int i = 0; i < NQ; ++i) {
+        float* po = &part_o[i][slot][dc * 8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *reinterpret_cast<ad_f2*>(po + 2 * e) = o[i][e];
+        if (dc == 0) { part_ml[i][slot][0] = m[i]; part_ml[i][slot][1] = l[i]; }
+      }
     }
   }
   __syncthreads();
+  const int n_slots = WAVE_MERGE ? n_waves : n_waves * 8;
   for (int t = tid; t < NQ * 64; t += 256) {
     const int i = t >> 6, d = t & 63;
     if (i >= nq) continue;
-    const float v = (part[i][0][d] + part[i][1][d]) + (part[i][2][d] + part[i][3][d]);
-    p.out[(long)(b0 + i) * p.o_sb + h * 64 + d] = f2bf(l[i] > 0.f ? v / l[i] : 0.f);
+    float mn = -INFINITY;
+    for (int sl = 0; sl < n_slots; ++sl) mn = fmaxf(mn, part_ml[i][sl][0]);
+    float lt = 0.f, v = 0.f;
+    for (int sl = 0; sl < n_slots; ++sl) {
+      const float a = mn == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(part_ml[i][sl][0] - mn);
+      lt = fmaf(part_ml[i][sl][1], a, lt);
+      v = fmaf(part_o[i][sl][d], a, v);
+    }
+    p.out[(long)(b0 + i) * p.o_sb + h * 64 + d] = f2bf(lt > 0.f ? v / lt : 0.f);
   }
 }
 
@@ -992,6 +1018,8 @@ extern "C" int tell_attn_decode(int n_ctx, const void* const* q, const long* q_s
     TELL_REQUIRE(S[j] + (bias_k && bias_k[j] ? 1 : 0) + has_zero >= 1, "attn_decode: no keys");
     TELL_REQUIRE(q_sb[j] % 8 == 0 && k_ss[j] % 8 == 0 && k_sb[j] % 8 == 0 && v_ss[j] % 8 == 0 && v_sb[j] % 8 == 0,
                  "attn_decode: 16-byte aligned rows");
+    TELL_REQUIRE(S[j] == 0 || ((long)S[j] * k_ss[j] < (1L << 31) && (long)S[j] * v_ss[j] < (1L << 31) && k_ss[j] >= 0 && v_ss[j] >= 0),
+                 "attn_decode: key offsets of a (sample, head) must fit 31 bits");
     g.c[c].q = (const uint16_t*)q[j]; g.c[c].k = (const uint16_t*)k[j]; g.c[c].v = (const uint16_t*)v[j];
     g.c[c].out = (uint16_t*)out[j]; g.c[c].mask = mask ? (const uint8_t*)mask[j] : nullptr;
     g.c[c].q_sb = q_sb[j]; g.c[c].k_ss = k_ss[j]; g.c[c].k_sb = k_sb[j]; g.c[c].v_ss = v_ss[j]; g.c[c].v_sb = v_sb[j];
