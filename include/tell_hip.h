@@ -359,6 +359,17 @@ int tell_dynconv_step(const void* x, void* hist, const void* wt, void* y, int M,
  * k[c] at k + s*k_ss + (b / beams)*k_sb + h*64 + d (the `beams` hypotheses of a sample - rows b*beams + j - share its
  * cache), mask[c] [B / beams, S[c]] uint8 or NULL, bias_k[c] / bias_v[c] [H*64] (:355-364) or NULL, has_zero: the zero
  * row (:416-421).  bf16, q pre-scaled, S <= 2048 (S = 0 allowed with a bias / zero row: the empty context :349-374). */
+/* The same attention over a PACKED cache, on the matrix cores (the generation loop owns its cache's layout):
+ *   kc [B/beams, H, Sp, 64] bf16 keys, head-major; the learned bias_k row and the zero row (multi_head.py:355-364, :416-421)
+ *      are stored as keys S and S + 1, rows up to Sp (a multiple of 32) are zero;
+ *   vt [B/beams, H, 64, Sp] bf16 values TRANSPOSED, keys permuted inside every block of 32 (stored position 8 g + j holds key
+ *      4 g + j for j < 4, key 16 + 4 g + j - 4 for j >= 4: the keys whose scores an MFMA accumulator leaves in k-group g);
+ *   mask [B/beams, Sp] uint8, 1 = masked (context padding and every position past S + 1).
+ * q[c] bf16 [B, H*64] projected and scaled, out[c] bf16 [B, H*64]; head width 64; the beams hypotheses of a sample are
+ * columns of one MFMA (any beams).  HOST arrays of n_ctx <= 4 entries. */
+int tell_attn_decode_packed(int n_ctx, const void* const* q, const long* q_sb, const void* const* kc, const void* const* vt,
+                            const void* const* mask, const int* Sp, void* const* out, const long* o_sb, int B, int H,
+                            int beams, tell_stream_t stream);
 int tell_attn_decode(int n_ctx, const void* const* q, const long* q_sb, const void* const* k, const long* k_ss,
                      const long* k_sb, const long* k_sh, const void* const* v, const long* v_ss, const long* v_sb,
                      const long* v_sh, const void* const* mask, const void* const* bias_k, const void* const* bias_v,

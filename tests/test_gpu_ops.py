@@ -1166,6 +1166,21 @@ def test_one_query_attention_over_cached_contexts(beams):
     got = decode.attn_decode_all(mods, names, q, kvl, ctx, M, E)
     for c in range(4):
         assert torch.equal(got[c], outs[c]), S_list[c]
+    # ... and PACKED for the matrix cores (decode.PackedKV / tell_attn_decode_packed: keys head-major with the two virtual keys
+    # appended, values transposed and permuted inside blocks of 32 keys, probabilities rounded to bf16 for the second MFMA)
+    for m_, c in zip(mods, range(4)):
+        m_.bias_k, m_.bias_v = bk[c], bv[c]
+    pk = {}
+    for c, nm in enumerate(names):
+        pk[nm] = decode.PackedKV(mods[c], S_list[c], n, DEV)
+        pk[nm].fill(ks[c], vs[c], masks[c] if S_list[c] else None)
+        pk[nm].fill(ks[c], vs[c], masks[c] if S_list[c] else None)            # (refilling a cache is idempotent)
+    assert decode.attn_decode_usable(mods, pk, names, q[0])
+    got = decode.attn_decode_all(mods, names, q, pk, ctx, M, E)
+    for c in range(4):
+        rel = ((got[c].float() - want[c].float()).norm() / want[c].float().norm()).item()
+        assert rel < 1e-2, ('packed', S_list[c], rel)
+        assert bool(torch.isfinite(got[c].float()).all())
 
 
 @pytest.mark.parametrize('M', [5, 32, 70, 128])

@@ -1035,6 +1035,161 @@ extern "C" int tell_attn_decode(int n_ctx, const void* const* q, const long* q_s
   return tell_check_launch("attn_decode");
 }
 
+// ------------------------------------------------------------------ one-query attention over a PACKED cache, matrix cores
+// Round 6, second half.  PMC showed the VALU kernel above instruction-bound (52 instructions per key and lane with one
+// hypothesis, 122 with four, for 32 bytes of cache; memory latency 770-1050 cycles per request, hidden).  The generation loop
+// owns the layout of its cache, so it can store what the matrix cores want to read:
+//   kc   [Bs, H, Sp, 64]  keys, head-major; rows S and S + 1 are the learned bias_k row and the zero row (multi_head.py:355-364,
+//                         :416-421) - virtual keys are ordinary keys here; rows up to Sp (a multiple of 32) are zero
+//   vt   [Bs, H, 64, Sp]  values TRANSPOSED (a lane's 16 bytes = 8 keys of one dimension: the A operand of O^T = V^T P^T), keys
+//                         permuted inside every block of 32: stored position 8 g + j holds key 4 g + j (j < 4) or 16 + 4 g + j - 4
+//                         (j >= 4) - exactly the 8 keys whose scores the QK^T accumulators leave in the lane of k-group g, so
+//                         the probabilities go from the accumulator of one MFMA into the B operand of the next without
+//                         leaving their lane
+//   mask [Bs, Sp] uint8   1 = masked (padding of the context, and everything past S + 1)
+// Per 32 keys a wave issues 4 + 4 sixteen-byte loads per lane, 4 MFMAs for the scores (A = K tile, B = the hypotheses as
+// columns: up to 16 of them for the price of one), ~60 VALU instructions of online softmax in the exp2 domain on 8 scores per
+// lane, 4 MFMAs for P V: ~0.8 instructions per cache byte against 3.8.  Waves of a workgroup take blocks of 32 keys round
+// robin and merge through LDS.
+struct AttnPkCtx { const uint16_t *q, *kc, *vt; const uint8_t* mask; uint16_t* out; long q_sb, o_sb; int Sp; };
+struct AttnPkArgs { AttnPkCtx c[SK_MAXP]; int B, H, beams; };
+
+__global__ __launch_bounds__(256) void attn_decode_packed_kernel(AttnPkArgs g) {
+  const AttnPkCtx& p = g.c[blockIdx.y];
+  __shared__ float po[4][64][17];                              // per wave: O^T [d][hypothesis] (+1: bank spread)
+  __shared__ float pml[4][16][2];
+  typedef float c4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+  const int groups = (g.beams + 15) / 16;
+  const int h = blockIdx.x % g.H, bg = blockIdx.x / g.H, bs = bg / groups, j0 = (bg % groups) * 16;
+  const int nq = g.beams - j0 < 16 ? g.beams - j0 : 16;
+  const int b0 = bs * g.beams + j0;
+  const int Sp = p.Sp, nblk = Sp >> 5;
+  constexpr float LOG2E = 1.4426950408889634f;
+  sk_u4 qf[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    qf[c] = sk_u4{0u, 0u, 0u, 0u};
+    if (lr < nq) qf[c] = *reinterpret_cast<const sk_u4*>(p.q + (long)(b0 + lr) * p.q_sb + h * 64 + c * 32 + lg * 8);
+  }
+  const uint16_t* kbase = p.kc + (long)(bs * g.H + h) * Sp * 64 + (long)lr * 64 + lg * 8;
+  const uint16_t* vbase = p.vt + (long)(bs * g.H + h) * 64 * Sp + (long)lr * Sp + lg * 8;
+  const uint8_t* mbase = p.mask + (long)bs * Sp + lg * 4;
+  c4 acc_o[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) acc_o[rt] = c4{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;
+  // (Measured and not kept: PAIRS of adjacent blocks per wave and iteration - the 16-byte loads of a V^T row then cover whole
+  //  128-byte lines, 16 loads per lane in flight - 22.6-24.9 -> 24.5-26.1 us per launch at beam 4, 20.4 -> 21.5 with one hypothesis.)
+  sk_u4 kf[2][2], vf[4];
+  uint32_t mw[2];
+  auto load = [&](int blk) __attribute__((always_inline)) {
+    const uint16_t* kp = kbase + (long)blk * 32 * 64;
+    const uint16_t* vp = vbase + blk * 32;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      kf[t][0] = *reinterpret_cast<const sk_u4*>(kp + t * 16 * 64);
+      kf[t][1] = *reinterpret_cast<const sk_u4*>(kp + t * 16 * 64 + 32);
+      mw[t] = *reinterpret_cast<const uint32_t*>(mbase + blk * 32 + t * 16);
+    }
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) vf[rt] = *reinterpret_cast<const sk_u4*>(vp + (long)rt * 16 * Sp);
+  };
+  if (wave < nblk) load(wave);
+  for (int blk = wave; blk < nblk; blk += 4) {
+    c4 sc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      sc[t] = c4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sk_bf16x8, kf[t][c]), __builtin_bit_cast(sk_bf16x8, qf[c]),
+                                                        sc[t], 0, 0, 0);
+    }
+    const sk_u4 v0 = vf[0], v1 = vf[1], v2 = vf[2], v3 = vf[3];
+    const uint32_t m0 = mw[0], m1 = mw[1];
+    if (blk + 4 < nblk) load(blk + 4);                          // the next block of this wave flies under the softmax
+    // scores of this lane: keys 4 lg + r (tile 0) and 16 + 4 lg + r (tile 1) for hypothesis lr
+    float v[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] = ((m0 >> (8 * r)) & 0xffu) ? -INFINITY : sc[0][r] * LOG2E;
+      v[4 + r] = ((m1 >> (8 * r)) & 0xffu) ? -INFINITY : sc[1][r] * LOG2E;
+      mx = fmaxf(mx, fmaxf(v[r], v[4 + r]));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mn = fmaxf(m, mx);
+    const float a = mn == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(m - mn);
+    l *= a;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) acc_o[rt] *= a;
+    m = mn;
+    float pr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pr[j] = v[j] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(v[j] - mn);
+      l += pr[j];
+    }
+    sk_u4 pf;
+    pf.x = (uint32_t)f2bf(pr[0]) | ((uint32_t)f2bf(pr[1]) << 16);
+    pf.y = (uint32_t)f2bf(pr[2]) | ((uint32_t)f2bf(pr[3]) << 16);
+    pf.z = (uint32_t)f2bf(pr[4]) | ((uint32_t)f2bf(pr[5]) << 16);
+    pf.w = (uint32_t)f2bf(pr[6]) | ((uint32_t)f2bf(pr[7]) << 16);
+    acc_o[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sk_bf16x8, v0), __builtin_bit_cast(sk_bf16x8, pf), acc_o[0], 0, 0, 0);
+    acc_o[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sk_bf16x8, v1), __builtin_bit_cast(sk_bf16x8, pf), acc_o[1], 0, 0, 0);
+    acc_o[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sk_bf16x8, v2), __builtin_bit_cast(sk_bf16x8, pf), acc_o[2], 0, 0, 0);
+    acc_o[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sk_bf16x8, v3), __builtin_bit_cast(sk_bf16x8, pf), acc_o[3], 0, 0, 0);
+  }
+  // ---- the row sums over the 4 k-groups, then the waves through LDS
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+  const int n_waves = nblk < 4 ? nblk : 4;
+  if (wave < n_waves) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) po[wave][rt * 16 + lg * 4 + r][lr] = acc_o[rt][r];
+    if (lg == 0) { pml[wave][lr][0] = m; pml[wave][lr][1] = l; }
+  }
+  __syncthreads();
+  for (int t = tid; t < nq * 64; t += 256) {
+    const int qi = t >> 6, d = t & 63;
+    float mn = -INFINITY;
+    for (int w = 0; w < n_waves; ++w) mn = fmaxf(mn, pml[w][qi][0]);
+    float lt = 0.f, o = 0.f;
+    for (int w = 0; w < n_waves; ++w) {
+      const float a = mn == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(pml[w][qi][0] - mn);
+      lt = fmaf(pml[w][qi][1], a, lt);
+      o = fmaf(po[w][d][qi], a, o);
+    }
+    p.out[(long)(b0 + qi) * p.o_sb + h * 64 + d] = f2bf(lt > 0.f ? o / lt : 0.f);
+  }
+}
+// n_ctx <= 4 contexts of one decode step in one launch over packed caches (layouts above; HOST arrays of n_ctx entries):
+// q[c] bf16 [B, H*64] (row stride q_sb[c], already scaled), kc[c] / vt[c] / mask[c] for B / beams samples, Sp[c] % 32 == 0,
+// out[c] bf16 [B, H*64] (row stride o_sb[c]).  Head width 64.  The `beams` hypotheses of a sample are columns of one MFMA.
+extern "C" int tell_attn_decode_packed(int n_ctx, const void* const* q, const long* q_sb, const void* const* kc,
+                                       const void* const* vt, const void* const* mask, const int* Sp, void* const* out,
+                                       const long* o_sb, int B, int H, int beams, hipStream_t stream) {
+  TELL_REQUIRE(n_ctx >= 1 && n_ctx <= SK_MAXP && B > 0 && H > 0 && beams >= 1 && B % beams == 0, "attn_decode_packed: 1-4 contexts");
+  AttnPkArgs g;
+  g.B = B; g.H = H; g.beams = beams;
+  for (int c = 0; c < SK_MAXP; ++c) {
+    const int j = c < n_ctx ? c : 0;
+    TELL_REQUIRE(Sp[j] >= 32 && Sp[j] % 32 == 0 && q_sb[j] % 8 == 0 && mask[j] && kc[j] && vt[j], "attn_decode_packed: Sp % 32, masks");
+    TELL_REQUIRE(((reinterpret_cast<uintptr_t>(kc[j]) | reinterpret_cast<uintptr_t>(vt[j]) | reinterpret_cast<uintptr_t>(q[j])) & 15) == 0 &&
+                 (reinterpret_cast<uintptr_t>(mask[j]) & 3) == 0, "attn_decode_packed: 16-byte aligned caches");
+    g.c[c].q = (const uint16_t*)q[j]; g.c[c].kc = (const uint16_t*)kc[j]; g.c[c].vt = (const uint16_t*)vt[j];
+    g.c[c].mask = (const uint8_t*)mask[j]; g.c[c].out = (uint16_t*)out[j]; g.c[c].q_sb = q_sb[j]; g.c[c].o_sb = o_sb[j];
+    g.c[c].Sp = Sp[j];
+  }
+  const int samples = B / beams, groups = (beams + 15) / 16;
+  hipLaunchKernelGGL(attn_decode_packed_kernel, dim3(samples * groups * H, n_ctx), dim3(256), 0, stream, g);
+  return tell_check_launch("attn_decode_packed");
+}
+
 // ------------------------------------------------------------------ the step's token embedding, front half
 // adaptive.py:61-76 at T = 1: a token's embedding is proj_band . table_band[id - lo] with band-dependent width.  As ONE
 // skinny linear: row m of `cat` holds the token's table row in its band's column range (zeros elsewhere), the weight is

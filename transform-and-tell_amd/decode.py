@@ -30,6 +30,10 @@ FOLD = os.environ.get('TELL_DECODE_FOLD', '1') != '0'
 HEAD_GROUPED = os.environ.get('TELL_HEAD_GROUPED', '1') != '0'      # A/B aid: the two tail-table products as one launch
 # the generation loop's projected K / V cache HEAD-MAJOR ([B, H, S, 64]: models/transformer.py _decode_stepper); 0 = [S, B, E]
 KV_HEAD_MAJOR = os.environ.get('TELL_KV_HEAD_MAJOR', '1') != '0'
+# ... and, on top of it, PACKED for the matrix cores (PackedKV below; tell_attn_decode_packed); 0 = the VALU kernel on the
+# head-major cache
+KV_PACKED = os.environ.get('TELL_KV_PACKED', '1') != '0'
+ENABLED_LAYER_PACKED = os.environ.get('TELL_KV_PACKED_LAYERS', '1') != '0'
 # the per-token bookkeeping launch (tell_greedy_update / tell_beam_update) as the LAST launch of the captured step: the host's
 # part of a decode step is one graph replay.  0 = a host-side launch behind every replay (A/B aid)
 IN_GRAPH_BOOK = os.environ.get('TELL_DECODE_BOOK_IN_GRAPH', '1') != '0'
@@ -98,7 +102,9 @@ def usable(dec, X, incremental_state, kv_cache):
             return False
         for name in layer.context_names:
             m = layer.context_attns[name]
-            if m.head_dim != 64 or m.bias_k is None or not m.add_zero_attn or kv_cache[0][name][0].shape[0] > 2048:
+            ent = kv_cache[0][name]
+            n_keys = ent.shape[0] if isinstance(ent, PackedKV) else ent[0].shape[0]
+            if m.head_dim != 64 or m.bias_k is None or not m.add_zero_attn or n_keys > 2048:
                 return False
     return True
 
@@ -228,11 +234,62 @@ def head_step(x2, cutoffs, emb0, class_proj, tails, topk=0):
     return token, token_lp, None
 
 
+class PackedKV:
+    """Projected K / V of one (layer, context) in the layout tell_attn_decode_packed reads (csrc/decode.hip): kc [Bc, H, Sp, 64]
+    with the bias_k row and the zero row as keys S and S + 1, vt [Bc, H, 64, Sp] transposed with the keys of every block of 32
+    permuted for the matrix cores, mask [Bc, Sp] uint8 (1 = masked).  Built once per stepper (models/transformer.py), refilled
+    per caption batch by `fill`."""
+
+    def __init__(self, mod, S, Bc, device):
+        H = mod.num_heads
+        self.S, self.Bc, self.H = int(S), int(Bc), H
+        self.Sp = -(-(self.S + 2) // 32) * 32
+        bf = dict(dtype=torch.bfloat16, device=device)
+        self.kc = torch.zeros(Bc, H, self.Sp, 64, **bf)
+        self.vnat = torch.zeros(Bc, H, self.Sp, 64, **bf)               # staging: values in key order
+        self.vt = torch.zeros(Bc, H, 64, self.Sp, **bf)
+        self.mask = torch.ones(Bc, self.Sp, dtype=torch.uint8, device=device)
+        self.mask[:, self.S:self.S + 2] = 0                             # the two virtual keys are never masked
+        self.kc[:, :, self.S] = ops._bias_row(mod.bias_k, torch.bfloat16).view(H, 64)
+        self.vnat[:, :, self.S] = ops._bias_row(mod.bias_v, torch.bfloat16).view(H, 64)
+        self.shape = (self.S, Bc, H * 64)                               # (what the [S, B, E] tensors it replaces answer)
+
+    def fill(self, k, v, mask):
+        S, Bc, H, nb = self.S, self.Bc, self.H, self.Sp // 32
+        if S:
+            self.kc[:, :, :S].copy_(k.view(S, Bc, H, 64).permute(1, 2, 0, 3))
+            self.vnat[:, :, :S].copy_(v.view(S, Bc, H, 64).permute(1, 2, 0, 3))
+            if mask is not None:
+                self.mask[:, :S].copy_(mask)
+            else:
+                self.mask[:, :S].zero_()
+        # key (block, half, g, r) of the natural order -> stored position (block, g, half, r), dimension-major
+        self.vt.view(Bc, H, 64, nb, 4, 2, 4).copy_(self.vnat.view(Bc, H, nb, 2, 4, 4, 64).permute(0, 1, 6, 2, 4, 3, 5))
+
+
+def layer_path_takes_packed(dec):
+    """More rows than the weight-streaming step takes (MAX_ROWS): the layer-by-layer step hands the n context attentions of a
+    layer to attn_decode_all - and with it to a PackedKV cache - exactly when DynamicConvDecoderLayer.forward groups them:
+    post-LN layers with more than one context, no attention-weight export, bf16, the learned bias row + zero row, 64-wide heads."""
+    if dec.training or ops.rt.compute_dtype() != torch.bfloat16 or not ENABLED_LAYER_PACKED:
+        return False
+    for layer in dec.layers:
+        if layer.normalize_before or layer.need_attn or not 2 <= len(layer.context_names) <= 4:
+            return False
+        for name in layer.context_names:
+            m = layer.context_attns[name]
+            if m.head_dim != 64 or m.bias_k is None or not m.add_zero_attn:
+                return False
+    return True
+
+
 def attn_decode_usable(mods, kv_layer, names, q):
     """tell_attn_decode takes: bf16, one query position per row, 64-wide heads, the learned bias row + the zero row,
     at most 4 contexts of at most 2048 cached keys."""
     if not (q.is_cuda and q.dtype == torch.bfloat16 and 1 <= len(mods) <= 4):
         return False
+    if all(isinstance(kv_layer[nm], PackedKV) for nm in names):
+        return all(m.head_dim == 64 for m in mods)
     for m, nm in zip(mods, names):
         k = kv_layer[nm][0]
         if m.head_dim != 64 or m.bias_k is None or not m.add_zero_attn or k.shape[0] > 2048 or k.dtype != torch.bfloat16:
@@ -251,6 +308,12 @@ def attn_decode_all(mods, names, qs, kv_layer, contexts, M, E):
     n = len(mods)
     dev = qs[0].device
     a_all = torch.empty(n, M, E, dtype=torch.bfloat16, device=dev)
+    if isinstance(kv_layer[names[0]], PackedKV):
+        pk = [kv_layer[nm] for nm in names]
+        call('tell_attn_decode_packed', n, _ptrs(qs), _longs([int(q.stride(-2)) for q in qs]), _ptrs([c.kc for c in pk]),
+             _ptrs([c.vt for c in pk]), _ptrs([c.mask for c in pk]), _ints([c.Sp for c in pk]),
+             _ptrs([a_all[i] for i in range(n)]), _longs([E] * n), M, mods[0].num_heads, M // pk[0].Bc)
+        return a_all
     ks, vs, k_ss, k_sb, v_ss, v_sb, masks, S, bk, bv = [], [], [], [], [], [], [], [], [], []
     k_sh, v_sh = [], []
     beams = 1

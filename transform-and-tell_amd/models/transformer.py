@@ -509,13 +509,29 @@ class CaptionModel(Model):
                     S_, Bc, H_ = t.shape[0], t.shape[1], mod.num_heads
                     return torch.empty(Bc, H_, S_, 64, dtype=t.dtype, device=t.device).permute(2, 0, 1, 3)
                 return torch.empty_like(t)
-            h['kv'] = [{n: tuple(static_like(t, layer.context_attns[n]) for t in pair) for n, pair in lk.items()}
-                       for lk, layer in zip(kv, dec.layers)]
+            # (measured, B = 32: packed 28.6 -> 22.6-24.9 us per launch at beam 4; with ONE hypothesis per sample the VALU kernel on
+            #  the head-major cache is the faster one, 18.7 against 20.4 us - packed from two hypotheses per sample on)
+            n_cached = kv[0][names[0]][0].shape[1] if kv[0][names[0]][0].dim() == 3 else B
+            several = B >= 2 * max(int(n_cached), 1)
+            layer_pk = (B > _dec.MAX_ROWS and dtype == torch.bfloat16 and bool(h['state'].get('_ring')) and
+                        _dec.layer_path_takes_packed(dec))     # (the layer-by-layer step above MAX_ROWS rows)
+            if _dec.KV_PACKED and several and (hm or layer_pk):
+                # ... or PACKED for the matrix cores: keys head-major with the two virtual keys appended, values transposed
+                # and permuted (decode.PackedKV); one launch per layer reads all four contexts (tell_attn_decode_packed)
+                h['kv'] = [{n: _dec.PackedKV(layer.context_attns[n], pair[0].shape[0], pair[0].shape[1], dev)
+                            for n, pair in lk.items()} for lk, layer in zip(kv, dec.layers)]
+            else:
+                h['kv'] = [{n: tuple(static_like(t, layer.context_attns[n]) for t in pair) for n, pair in lk.items()}
+                           for lk, layer in zip(kv, dec.layers)]
             # in-graph bookkeeping needs the step's first kernel to be tell_embed_gather_step (it publishes the counter)
             h['ig'] = bool(_dec.IN_GRAPH_BOOK and dtype == torch.bfloat16 and _dec.usable(dec, probe, h['state'], kv) and
                            _dec.embed_usable(dec.embedder, h['cur'], h['state']))
         for lk, ls in zip(kv, h['kv']):
             for n, pair in lk.items():
+                if not isinstance(ls[n], tuple):                  # decode.PackedKV
+                    mk = contexts.get(n + '_mask')
+                    ls[n].fill(pair[0], pair[1], mk)
+                    continue
                 for t, s in zip(pair, ls[n]):
                     s.copy_(t.view(s.shape) if s.dim() == 4 else t)
         for k, s in h['ctx'].items():
