@@ -606,7 +606,16 @@ extern "C" int tell_skinny_linear(int n_prob, const void* const* in, long ld_in,
   }
   const int rt_env = (int)tell_opt(OPT_SK_ROWS);          // A/B aid: 32 / 128
   const bool tall = rt_env ? rt_env == 128 : (M > 64 && (long)((N + 15) / 16) * n_prob * ((M + 127) / 128) >= 192);
-  if (tall) return skinny_mfma_dispatch<8, 2>(a, n_prob, act, stream, fold);
+  if (tall) {
+    // option sk_tall_waves = 8: the 128-row workgroup as 8 waves x K / 8 (both batches of a wave's loads in flight at once,
+    // twice the waves per CU to hide them) instead of 4 x K / 4.  MEASURED (round 6): alone q-proj x4 15.6 -> 15.0 us, out-proj
+    // x4 12.3 -> 12.0, fc1 12.3 -> 11.7 - and the beam-4 step, where the weights are cold, 644 -> 672 us.  Default 4.
+    if (tell_opt(OPT_SK_TALL_WAVES) == 8 && K % 512 == 0 && act != 2) {
+      if (fold) return skinny_mfma_launch<8, 0, 2, true, 8>(a, n_prob, stream);
+      return act == 1 ? skinny_mfma_launch<8, 1, 2, false, 8>(a, n_prob, stream) : skinny_mfma_launch<8, 0, 2, false, 8>(a, n_prob, stream);
+    }
+    return skinny_mfma_dispatch<8, 2>(a, n_prob, act, stream, fold);
+  }
   return K % 1024 == 0 ? skinny_mfma_dispatch<2, 8>(a, n_prob, act, stream, fold) : skinny_mfma_dispatch<2, 2>(a, n_prob, act, stream, fold);
 }
 
@@ -1269,6 +1278,14 @@ __global__ __launch_bounds__(64) void beam_update_kernel(const int* __restrict__
   if (back)
     for (int e = t; e < n_back * K; e += 64) s_back[e] = back[(long)(e / K) * M + b * K + e % K];
   if (counter && b == 0 && t == 0) *counter = step;            // position offset of the NEXT replay of a captured step: (step + 1) - 1
+  // the histories of the sample's K hypotheses into LDS FIRST: they do not depend on the selection below, whose K rounds of
+  // shuffles then run under these loads (round 6: the launch was a chain of four dependent memory round trips + two loops with
+  // an integer division per element; 15 us at K = 4)
+  const int Lp = L - 1, nc = step + 2 < L ? step + 2 : L, ncp = step + 1 < Lp ? step + 1 : Lp;
+  for (int r = 0; r < K; ++r) {
+    for (int c = t; c < nc; c += 64) s_seq[r * L + c] = seqs[(long)b * K * L + r * L + c];
+    for (int c = t; c < ncp; c += 64) s_lp[r * Lp + c] = lps[(long)b * K * Lp + r * Lp + c];
+  }
   const int j = t / K, m = t % K;
   float score = -INFINITY;
   int token = pad;
@@ -1299,18 +1316,19 @@ __global__ __launch_bounds__(64) void beam_update_kernel(const int* __restrict__
   }
   __syncthreads();
   // gather the surviving histories by parent (through LDS: the permutation is in place)
-  // (round 6: only columns 0 .. step + 1 - everything behind them is still the initial padding in every row)
-  const int Lp = L - 1, nc = step + 2 < L ? step + 2 : L, ncp = step + 1 < Lp ? step + 1 : Lp;
-  for (int e = t; e < K * nc; e += 64) { const int r = e / nc, c = e % nc; s_seq[r * L + c] = seqs[(long)b * K * L + r * L + c]; }
-  for (int e = t; e < K * ncp; e += 64) { const int r = e / ncp, c = e % ncp; s_lp[r * Lp + c] = lps[(long)b * K * Lp + r * Lp + c]; }
-  __syncthreads();
-  for (int e = t; e < K * nc; e += 64) {
-    const int r = e / nc, c = e % nc;
-    seqs[(long)b * K * L + r * L + c] = c == step + 1 ? (long)s_tok[r] : s_seq[s_parent[r] * L + c];
+  // (only columns 0 .. step + 1 - everything behind them is still the initial padding in every row; a hypothesis that
+  //  descends from its own slot keeps its row: only the new column is written)
+  for (int r = 0; r < K; ++r) {
+    const int pr = s_parent[r];
+    if (pr != r) {
+      for (int c = t; c < nc; c += 64) seqs[(long)b * K * L + r * L + c] = s_seq[pr * L + c];
+      for (int c = t; c < ncp; c += 64) lps[(long)b * K * Lp + r * Lp + c] = s_lp[pr * Lp + c];
+    }
   }
-  for (int e = t; e < K * ncp; e += 64) {
-    const int r = e / ncp, c = e % ncp;
-    lps[(long)b * K * Lp + r * Lp + c] = c == step ? s_dlp[r] : s_lp[s_parent[r] * Lp + c];
+  __syncthreads();
+  if (t < K) {
+    seqs[(long)b * K * L + t * L + step + 1] = (long)s_tok[t];
+    if (step < Lp) lps[(long)b * K * Lp + t * Lp + step] = s_dlp[t];
   }
   if (t < K) {
     cum[b * K + t] = s_top[t];

@@ -49,7 +49,8 @@
   X(OPT_ADAM_VAR, "adam_var", -1)          /* -1: the built-in default shape */                                         \
   X(OPT_ADAM_GRID, "adam_grid", 4096)                                                                                   \
   X(OPT_SK_ROWS, "sk_rows", 0)             /* 32 / 128: rows per skinny-linear workgroup everywhere */            \
-  X(OPT_SK_SPLIT, "sk_split", 1)           /* 0: never share a skinny linear's reduction between workgroups */
+  X(OPT_SK_SPLIT, "sk_split", 1)           /* 0: never share a skinny linear's reduction between workgroups */            \
+  X(OPT_SK_TALL_WAVES, "sk_tall_waves", 4) /* 8: the 128-row skinny workgroup as 8 waves x K / 8 */
 
 // wrong-result timing probes: probe build only
 #define TELL_PROBE_LIST(X)                                                                                              \
