@@ -342,6 +342,12 @@ int tell_layernorm_rows(const float* x, long ld_x, const float* gamma, const flo
  * (fp32 [M,E]) = the sinusoid row of this step (pad -> row pos_pad; offset start_pos + the captured step's device
  * counter).  scale * (cat . [proj_0 | proj_1 | ..]^T) + pos_out - one tell_skinny_linear - is the embedding.
  * tables / lo / hi / dim / off: HOST arrays of nb <= 4 bands (ids lo_b .. hi_b - 1). */
+/* the step's embedding as a LOOKUP in a pre-projected table (generation: the weights do not move): table fp32 [V, E] =
+ * embed_scale * proj_band . table_band[v] for every token (adaptive.py:61-76, built once by the caller);
+ * out[m] = bf16(table[ids[m]] + sinusoid[position of this step]) (positional.py:167-211; pad -> row pos_pad).  First kernel
+ * of a captured decode step: reads / publishes the position counter like tell_embed_gather_step. */
+int tell_embed_lookup_step(const long* ids, int M, const float* table, int V, const float* pos_table, int pos_rows,
+                           int pos_pad, int start_pos, void* out, int E, tell_stream_t stream);
 int tell_embed_gather_step(const long* ids, int M, int nb, const void* const* tables, const int* lo, const int* hi,
                            const int* dim, const int* off, void* cat, int ktot, const float* pos_table, int pos_rows,
                            int pos_pad, int start_pos, float* pos_out, int E, tell_stream_t stream);

@@ -1254,6 +1254,44 @@ extern "C" int tell_embed_gather_step(const long* ids, int M, int nb, const void
   return tell_check_launch("embed_gather_step");
 }
 
+// The same front half against a PRE-PROJECTED table (round 6): during generation the weights do not move, so
+// scale * proj_band . table_band[v] is computed ONCE per vocabulary entry ([V, E] fp32, three GEMMs when a decode graph is
+// built) and the step's embedding is a lookup: out[m] = bf16(table[id[m]] + sinusoid[position]) - one 5 us launch instead of
+// the gather (5 us) + a skinny linear that streamed [proj_0 | proj_1 | proj_2] (6 MB, two thirds of it against zeros) in 12 us.
+// Same roles for the position counter as tell_embed_gather_step (first kernel of the captured step).
+__global__ __launch_bounds__(256) void embed_lookup_step_kernel(const long* __restrict__ ids, const float* __restrict__ table,
+                                                                int V, const float* __restrict__ pos_table, int pos_rows,
+                                                                int pos_pad, int start_pos, uint16_t* __restrict__ out, int E,
+                                                                const uint32_t* step, const uint32_t* next) {
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const uint32_t* sp = next ? next : step;
+  const int sv = sp ? (int)*sp : 0;
+  if (next && m == 0 && tid == 0) *const_cast<uint32_t*>(step) = (uint32_t)sv;
+  long id = ids[m];
+  int pos = id == pos_pad ? pos_pad : pos_pad + 1 + start_pos + sv;
+  if (pos >= pos_rows) pos = pos_rows - 1;
+  const bool known = id >= 0 && id < V;
+  const float* row = table + (known ? id : 0) * (long)E;
+  const float* prow = pos_table + (long)pos * E;
+  for (int c = tid * 4; c < E; c += 1024) {
+    float4 a = known ? *reinterpret_cast<const float4*>(row + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 b = *reinterpret_cast<const float4*>(prow + c);
+    uint2 o;
+    o.x = (uint32_t)f2bf(a.x + b.x) | ((uint32_t)f2bf(a.y + b.y) << 16);
+    o.y = (uint32_t)f2bf(a.z + b.z) | ((uint32_t)f2bf(a.w + b.w) << 16);
+    *reinterpret_cast<uint2*>(out + (long)m * E + c) = o;
+  }
+}
+// ids [M] int64; table fp32 [V, E] = scale * projected embedding of every token; out bf16 [M, E].  E % 4 == 0.
+extern "C" int tell_embed_lookup_step(const long* ids, int M, const float* table, int V, const float* pos_table, int pos_rows,
+                                      int pos_pad, int start_pos, void* out, int E, hipStream_t stream) {
+  TELL_REQUIRE(M > 0 && V > 0 && E % 4 == 0 && (reinterpret_cast<uintptr_t>(table) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(out) & 7) == 0, "embed_lookup_step: bad shape");
+  hipLaunchKernelGGL(embed_lookup_step_kernel, dim3(M), dim3(256), 0, stream, ids, table, V, pos_table, pos_rows, pos_pad,
+                     start_pos, static_cast<uint16_t*>(out), E, g_tell_pos_step, g_tell_pos_step ? g_tell_pos_next : nullptr);
+  return tell_check_launch("embed_lookup_step");
+}
+
 // ------------------------------------------------------------------ beam search: one step's bookkeeping
 // What the host loop does per token after the top-k head (scoring = sum of token log-probs, a finished
 // hypothesis has one continuation: pad at no cost): per sample the K best of the K x K candidates

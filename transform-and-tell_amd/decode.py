@@ -37,6 +37,8 @@ ENABLED_LAYER_PACKED = os.environ.get('TELL_KV_PACKED_LAYERS', '1') != '0'
 # the per-token bookkeeping launch (tell_greedy_update / tell_beam_update) as the LAST launch of the captured step: the host's
 # part of a decode step is one graph replay.  0 = a host-side launch behind every replay (A/B aid)
 IN_GRAPH_BOOK = os.environ.get('TELL_DECODE_BOOK_IN_GRAPH', '1') != '0'
+# the step's token embedding as a lookup in a pre-projected [V, E] fp32 table (embed_step); 0 = gather + skinny linear per step
+EMBED_TABLE = os.environ.get('TELL_DECODE_EMBED_TABLE', '1') != '0'
 
 
 def _folded(w_param_key, w, lns, seg):
@@ -159,6 +161,20 @@ def embed_step(embedder, ids, start):
     [proj_0 | proj_1 | ..] with the scale and the sinusoid row in its epilogue.  -> [1, M, E] bf16."""
     ad, po = embedder.token_embedder_adaptive, embedder.token_embedder_position
     M, E = ids.shape[0], ad.embed_size
+    if EMBED_TABLE and E % 4 == 0:
+        # generation: every token's projected, scaled embedding ONCE ([V, E] fp32: 206 MB at V = 50265 - what 288 GB are for),
+        # rebuilt when the weights change (ops._cached: weights epoch / versions); the step's embedding is then one lookup launch
+        prm = [t for s in ad.embeddings for t in (s[0].weight, s[1].weight)]
+
+        def full_table():
+            rows = [ops.gemm(ops.weight(s[0].weight), ops.weight(s[1].weight), out_dtype=torch.float32,
+                             alpha=float(ad.embed_scale)) for s in ad.embeddings]
+            return torch.cat(rows, 0).contiguous()
+        table = ops._cached(prm[0], ('embed_full_table',) + tuple((p._version, p.data_ptr()) for p in prm[1:]), full_table)
+        out = torch.empty(M, E, dtype=torch.bfloat16, device=ids.device)
+        call('tell_embed_lookup_step', ids.reshape(M), M, table, table.shape[0], po.weights, po.weights.shape[0],
+             int(po.padding_idx), int(start), out, E)
+        return out.view(1, M, E)
     dims = [s[0].weight.shape[1] for s in ad.embeddings]
     offs = [sum(dims[:i]) for i in range(len(dims))]
     ktot = -(-sum(dims) // 1024) * 1024
