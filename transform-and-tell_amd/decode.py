@@ -39,6 +39,8 @@ ENABLED_LAYER_PACKED = os.environ.get('TELL_KV_PACKED_LAYERS', '1') != '0'
 IN_GRAPH_BOOK = os.environ.get('TELL_DECODE_BOOK_IN_GRAPH', '1') != '0'
 # the step's token embedding as a lookup in a pre-projected [V, E] fp32 table (embed_step); 0 = gather + skinny linear per step
 EMBED_TABLE = os.environ.get('TELL_DECODE_EMBED_TABLE', '1') != '0'
+# the adaptive-softmax head of the step as ONE product against [emb_0; class_proj; table_1 . proj_1; table_2 . proj_2] (head_step)
+HEAD_COMPOSED = os.environ.get('TELL_HEAD_COMPOSED', '1') != '0'
 
 
 def _folded(w_param_key, w, lns, seg):
@@ -207,6 +209,47 @@ def head_step(x2, cutoffs, emb0, class_proj, tails, topk=0):
     dev = x2.device
     c0, n_tails = cutoffs[0], len(tails) // 2
     projs = [tails[2 * i] for i in range(n_tails)]
+    if HEAD_COMPOSED and 1 <= n_tails <= 3 and all(p.shape[1] == E for p in projs):
+        # Round 6: during generation the weights do not move, so a tail's projection and its table are ONE matrix,
+        # W_i = table_i . proj_i ([n_i, E]; softmax.py:207-214 computes (x . proj_i^T) . table_i^T = x . W_i^T), composed once per
+        # weights state in fp32 and rounded to bf16 like every other working weight.  Head rows, cluster rows and the composed
+        # tails are stacked into one [V + n_tails (+ padding to 16-byte segments), E] matrix: the head is ONE product (the
+        # grouped GEMM's 64x64 fp32 tiles, which stream 100 MB at 4 TB/s where the skinny form took 13 us for 14 MB) + the
+        # register-resident arg-max / top-k, instead of skinny linear + grouped GEMM + arg-max.
+        embs = [tails[2 * i + 1] for i in range(n_tails)]
+        prm = [emb0, class_proj] + projs + embs
+
+        def make_big():
+            segs, offs, off = [], [], 0
+
+            def push(t):
+                nonlocal off
+                offs.append(off)
+                pad = -t.shape[0] % 4
+                segs.append(t if not pad else torch.cat([t, t.new_zeros(pad, t.shape[1])], 0))
+                off += t.shape[0] + pad
+            push(torch.cat([ops.weight(emb0), ops.weight(class_proj)], 0))
+            for p_, e_ in zip(projs, embs):
+                push(ops.gemm(ops.weight(e_), ops.weight(p_).t().contiguous(), out_dtype=torch.float32).to(torch.bfloat16))
+            return torch.cat(segs, 0).contiguous(), offs
+        w_big, offs = ops._cached(emb0, ('whead_composed',) + tuple((p._version, p.data_ptr()) for p in prm[1:]), make_big)
+        LD = w_big.shape[0]
+        logits = torch.empty(N, LD, dtype=torch.float32, device=dev)
+        ops.gemm_grouped([dict(a=x2, b=w_big, out=logits, form='nt')])
+        ns = [e.shape[0] for e in embs] + [0] * (3 - n_tails)
+        tl = [logits[:, offs[1 + i]:] if i < n_tails else None for i in range(3)]
+        lds = [LD if i < n_tails else 0 for i in range(3)]
+        if topk:
+            tokens = torch.empty(N, topk, dtype=torch.int32, device=dev)
+            lps = torch.empty(N, topk, dtype=torch.float32, device=dev)
+            call('tell_adaptive_logprob_topk', logits, LD, c0, n_tails, tl[0], lds[0], ns[0], tl[1], lds[1], ns[1], tl[2], lds[2],
+                 ns[2], N, int(topk), tokens, lps)
+            return tokens, lps, None
+        token = torch.empty(N, dtype=torch.int32, device=dev)
+        token_lp = torch.empty(N, dtype=torch.float32, device=dev)
+        call('tell_adaptive_logprob_argmax', logits, LD, c0, n_tails, tl[0], lds[0], ns[0], tl[1], lds[1], ns[1], tl[2], lds[2],
+             ns[2], N, None, 0, token, token_lp)
+        return token, token_lp, None
     w_all = ops._cached(emb0, ('whead_all', class_proj._version, class_proj.data_ptr()) +
                         tuple((p._version, p.data_ptr()) for p in projs),
                         lambda: torch.cat([ops.weight(emb0), ops.weight(class_proj)] + [ops.weight(p) for p in projs],
