@@ -41,6 +41,9 @@ IN_GRAPH_BOOK = os.environ.get('TELL_DECODE_BOOK_IN_GRAPH', '1') != '0'
 EMBED_TABLE = os.environ.get('TELL_DECODE_EMBED_TABLE', '1') != '0'
 # the adaptive-softmax head of the step as ONE product against [emb_0; class_proj; table_1 . proj_1; table_2 . proj_2] (head_step)
 HEAD_COMPOSED = os.environ.get('TELL_HEAD_COMPOSED', '1') != '0'
+# the two precomputed forms (embedding lookup, composed head) do not care how many rows a step has: also on the layer-by-layer
+# path above MAX_ROWS (beam 4 at 128 captions per batch = 512 rows)
+MAX_ROWS_WIDE = 1024
 
 
 def _folded(w_param_key, w, lns, seg):
@@ -152,7 +155,7 @@ def _skinny(ins, ld_in, ws, biases, outs, ld_out, M, N, K, pro=0, gammas=None, b
 def embed_usable(embedder, ids, incremental_state):
     ad = embedder.token_embedder_adaptive
     return (ENABLED and incremental_state is not None and incremental_state.get('_static') and not embedder.training and
-            ids.is_cuda and ids.shape[1] == 1 and ids.shape[0] <= MAX_ROWS and
+            ids.is_cuda and ids.shape[1] == 1 and ids.shape[0] <= (MAX_ROWS_WIDE if EMBED_TABLE else MAX_ROWS) and
             ops.rt.compute_dtype() == torch.bfloat16 and len(ad.cutoff) <= 4 and ad.embed_size % 1024 == 0 and
             all(s[0].weight.shape[1] % 8 == 0 for s in ad.embeddings))
 

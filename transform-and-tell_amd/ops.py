@@ -1752,7 +1752,9 @@ def adaptive_log_probs(x2, cutoffs, emb0, class_proj, tails, want_full=False, to
     c0 = cutoffs[0]
     n_tails = len(tails) // 2
     from . import decode
-    if (not want_full and decode.ENABLED and N <= decode.MAX_ROWS and x2.dtype == torch.bfloat16 and
+    wide = decode.HEAD_COMPOSED and all(tails[2 * i].shape[1] == E for i in range(n_tails))    # (head_step's one-product form)
+    if (not want_full and decode.ENABLED and N <= (decode.MAX_ROWS_WIDE if wide else decode.MAX_ROWS) and
+            x2.dtype == torch.bfloat16 and
             E % 1024 == 0 and 1 <= n_tails <= 3 and all(tails[2 * i].shape[0] % 8 == 0 for i in range(n_tails))):
         return decode.head_step(x2, cutoffs, emb0, class_proj, tails, topk)
     w_head = _cached(emb0, ('whead', class_proj._version, class_proj.data_ptr()), lambda: torch.cat(
