@@ -14,6 +14,7 @@ import weakref
 import torch
 
 from . import ops
+from . import hip as hip_mod
 from .hip import call
 
 ENABLED = os.environ.get('TELL_DECODE_FUSED', '1') != '0'       # A/B aid: 0 = the layer-by-layer step
@@ -44,6 +45,7 @@ HEAD_COMPOSED = os.environ.get('TELL_HEAD_COMPOSED', '1') != '0'
 # the two precomputed forms (embedding lookup, composed head) do not care how many rows a step has: also on the layer-by-layer
 # path above MAX_ROWS (beam 4 at 128 captions per batch = 512 rows)
 MAX_ROWS_WIDE = 1024
+HEAD_TILE128 = os.environ.get('TELL_HEAD_TILE128', '1') != '0'
 
 
 def _folded(w_param_key, w, lns, seg):
@@ -238,7 +240,13 @@ def head_step(x2, cutoffs, emb0, class_proj, tails, topk=0):
         w_big, offs = ops._cached(emb0, ('whead_composed',) + tuple((p._version, p.data_ptr()) for p in prm[1:]), make_big)
         LD = w_big.shape[0]
         logits = torch.empty(N, LD, dtype=torch.float32, device=dev)
-        ops.gemm_grouped([dict(a=x2, b=w_big, out=logits, form='nt')])
+        if N >= 128 and HEAD_TILE128:
+            # 128 rows and more: 128-row tiles, so that the 100 MB table is streamed once, not once per 64-row tile (the
+            # launcher's own rule keeps 64x64 tiles below 512 tiles of 128x128; the choice is recorded with the captured launch)
+            with hip_mod.options(group_tile=128):
+                ops.gemm_grouped([dict(a=x2, b=w_big, out=logits, form='nt')])
+        else:
+            ops.gemm_grouped([dict(a=x2, b=w_big, out=logits, form='nt')])
         ns = [e.shape[0] for e in embs] + [0] * (3 - n_tails)
         tl = [logits[:, offs[1 + i]:] if i < n_tails else None for i in range(3)]
         lds = [LD if i < n_tails else 0 for i in range(3)]
