@@ -706,7 +706,10 @@ def generate_bench(args, dev, world, rank, dist):
         """n batches: pipelined = the test-set loop of commands/evaluate.py (model.generate_stream: encoders of batch
         N+1 on their own streams underneath the decode loop of batch N); serial = one generate() after the other"""
         last = None
-        if pipelined:
+        if getattr(args, 'lanes', 1) > 1:
+            for _, last in model.generate_lanes((clone(batches[i % 2]) for i in range(n)), beam_size=beam, lanes=args.lanes):
+                pass
+        elif pipelined:
             for _, last in model.generate_stream((clone(batches[i % 2]) for i in range(n)), beam_size=beam):
                 pass
         else:
@@ -779,6 +782,8 @@ def generate_bench(args, dev, world, rank, dist):
                                '(expt/nytimes/9_transformer_objects), %s, %d captions per batch per GPU, up to 100 '
                                'steps, encoders included%s; replicas only (each rank decodes its own images)'
                                % ('beam %d' % beam if beam > 1 else 'greedy (sampling_topk 1, as the reference)', B,
+                                  (' (%d decode loops in flight together on %d streams: generate_lanes)' % (args.lanes, args.lanes))
+                                  if getattr(args, 'lanes', 1) > 1 else
                                   ' (batch N+1 encoded underneath the decode loop of batch N: generate_stream)'
                                   if pipelined else ''),
                    'global_batch': world * B, 'article_len': 512, 'decode_steps': int(n_steps),
@@ -823,6 +828,7 @@ def main():
     ap.add_argument('--no-loader', action='store_true',
                     help='skip the data-plane leg (shards on tmpfs -> reader -> iterator -> collate -> training step)')
     ap.add_argument('--beam', type=int, default=4, help='beam size of --generate (1 = greedy, what the reference does)')
+    ap.add_argument('--lanes', type=int, default=1, help='--generate: decode loops in flight together (CaptionModel.generate_lanes)')
     ap.add_argument('--gen-serial', action='store_true', help='--generate: encoders, then the decode loop, batch after '
                     'batch (the round-4 flow) instead of the pipelined test-set loop')
     ap.add_argument('--roofline-steps', type=int, default=3,
@@ -906,14 +912,16 @@ def main():
             result['generation'] = {}
             # (the reference's validation_iterator has batch_size 16; the batch is the iterator's knob, not the model's:
             #  32 = the figure every round has reported, 128 = the size this GPU's 288 GB are for)
-            for beam, gb in ((4, 32), (1, 32), (4, 128), (1, 128)):
+            # (`_lanes2`: CaptionModel.generate_lanes - two caption batches decoded together on two streams, each with its own
+            #  captured step; the encoders of a pair run first)
+            for beam, gb, ln in ((4, 32, 1), (1, 32, 1), (4, 128, 1), (1, 128, 1), (4, 32, 2), (1, 32, 2), (4, 128, 2), (1, 128, 2)):
                 ga = argparse.Namespace(**vars(args))
-                ga.batch, ga.beam, ga.steps, ga.warmup = gb, beam, (4 if gb == 32 else 3), 2
+                ga.batch, ga.beam, ga.steps, ga.warmup, ga.lanes = gb, beam, (4 if gb == 32 else 3) * ln, 2 * ln, ln
                 g = generate_bench(ga, dev, world, rank, dist)
-                key = ('beam%d' % beam if beam > 1 else 'greedy') + ('' if gb == 32 else '_b%d' % gb)
+                key = ('beam%d' % beam if beam > 1 else 'greedy') + ('' if gb == 32 else '_b%d' % gb) + ('' if ln == 1 else '_lanes%d' % ln)
                 result['generation'][key] = {
                     'workload': g['config']['workload'], 'value': g['value'], 'unit': g['unit'],
-                    'serial_value': g['serial_value'],
+                    'serial_value': g['serial_value'], 'lanes': ln,
                     'ms_per_batch': g['ms_per_step'], 'steps': g['steps'], 'warmup': g['warmup'],
                     'decode_steps': g['config']['decode_steps'], 'roofline': g['roofline']}
                 gc.collect()

@@ -108,3 +108,35 @@ def test_generate_stream_equals_batch_by_batch_generation(beam):
         assert seen == len(batches)
     finally:
         tell_amd.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize('beam,lanes', [(1, 2), (4, 2), (1, 3)])
+def test_generate_lanes_equals_batch_by_batch_generation(beam, lanes):
+    """Several decode loops in flight together (CaptionModel.generate_lanes: one stream, one captured step, one set of static
+    buffers, counters and split-reduction workspace per lane; the host alternates the lanes' graph replays) yield, batch for
+    batch, the ids and log-probabilities of `generate` called on that batch alone - bit for bit, twice over (the second
+    pass replays every lane's captured step from its first token on), with an odd number of batches (a last group with
+    fewer batches than lanes) and two context shapes."""
+    import tell_amd
+    from tell_amd.build import build_model
+    from tell_amd.data import synthetic_batch
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(0)
+        model = build_model('faces_objects', _Res(True), _Rob(1024), n_bert_layers=3, **KW).to(DEV).eval()
+        batches = [synthetic_batch(4, 24 + 8 * (i % 2), 9, True, seed=31 + i, device=DEV, vocab=600, cutoffs=(100, 300)) for i in range(5)]
+
+        def clone(b):
+            return {k: (dict(v) if isinstance(v, dict) else v.clone()) for k, v in b.items()}
+        alone = [model.generate(**clone(b), beam_size=beam) for b in batches]
+        torch.cuda.synchronize()
+        for rep in range(2):
+            seen = 0
+            for i, (b, out) in enumerate(model.generate_lanes((clone(b) for b in batches), beam_size=beam, lanes=lanes)):
+                torch.cuda.synchronize()
+                assert torch.equal(out['gen_ids'], alone[i]['gen_ids']), (rep, i)
+                assert torch.equal(out['log_probs'], alone[i]['log_probs']), (rep, i)
+                seen += 1
+            assert seen == len(batches)
+    finally:
+        tell_amd.set_compute_dtype(torch.float32)

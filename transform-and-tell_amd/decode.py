@@ -119,6 +119,7 @@ def usable(dec, X, incremental_state, kv_cache):
 
 
 _SPLIT_WS = {}
+CUR_LANE = [0]          # which decode lane is being issued / recorded (models/transformer.py): lanes own their split workspace
 
 
 def split_workspace(device):
@@ -127,7 +128,7 @@ def split_workspace(device):
     the launches that use it (the decode steps of this process) are ordered with respect to each other - one stream, or
     replays of graphs captured from it; a caller that decodes on two streams at once gives each its own (pass split_ws to
     tell_skinny_linear directly).  Created outside any stream capture (the eager warm step of a decode loop comes first)."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), CUR_LANE[0])
     ws = _SPLIT_WS.get(key)
     if ws is None:
         if torch.cuda.is_current_stream_capturing():

@@ -324,6 +324,53 @@ class CaptionModel(Model):
         log_probs, gen_ids, attns = self._generate(caption_ids, contexts, attn_idx, beam_size=beam_size)
         return {'gen_ids': gen_ids, 'log_probs': log_probs, 'attns': attns}
 
+    @torch.no_grad()
+    def generate_lanes(self, batches, beam_size=1, lanes=2):
+        """Captions for a sequence of batches with `lanes` decode loops IN FLIGHT TOGETHER, each on its own stream with its
+        own captured step, static buffers and counters (_decode_stepper(lane=)): a decode step is a chain of ~40 dependent
+        launches that each fill the chip for a few microseconds and then wait on memory - at 12-27 % of the HBM roofline a second
+        chain fits beside the first.  The host alternates the lanes' graph replays (one replay per lane and token).  The
+        encoders of a group of batches run first (eval mode: no randomness, results identical to `generate`).
+        Yields (batch, output) in order."""
+        it = iter(batches)
+        main = torch.cuda.current_stream()
+        lane_streams = [streams.get('decode_lane_%d' % i) for i in range(lanes)]
+        while True:
+            group = []
+            for _ in range(lanes):
+                b = next(it, None)
+                if b is not None:
+                    group.append(b)
+            if not group:
+                return
+            gens, outs = [], [None] * len(group)
+            for ln, b in enumerate(group):
+                f = {k: v for k, v in b.items() if k in ('context', 'image', 'caption', 'face_embeds', 'obj_embeds')}
+                caption_ids, _, contexts = self._forward(**f)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                lane_streams[ln].wait_event(ev)
+                with torch.cuda.stream(lane_streams[ln]), ops.hip.bound_stream():
+                    g = (self._beam_steps(caption_ids, contexts, int(beam_size), lane=ln) if beam_size > 1 else
+                         self._greedy_steps(caption_ids, contexts, lane=ln))
+                gens.append(g)
+            live = list(range(len(group)))
+            while live:
+                for ln in list(live):
+                    with torch.cuda.stream(lane_streams[ln]), ops.hip.bound_stream():
+                        try:
+                            next(gens[ln])
+                        except StopIteration as done:
+                            lp, ids, attns = done.value
+                            outs[ln] = {'gen_ids': ids, 'log_probs': lp, 'attns': attns}
+                            live.remove(ln)
+            for ln in range(len(group)):
+                ev = torch.cuda.Event()
+                ev.record(lane_streams[ln])
+                main.wait_event(ev)
+            for b, o in zip(group, outs):
+                yield b, o
+
     def generate_stream(self, batches, beam_size=1, forward=False):
         """Captions for a sequence of batches (the test-set loop of tell/commands/evaluate.py:118-160) with the frozen
         encoders of batch N+1 launched on their own streams BEFORE the decode loop of batch N is issued - the trainer's
@@ -378,9 +425,22 @@ class CaptionModel(Model):
             return self._generate_cached(caption_ids, contexts, gen_len, eos)
         return self._generate_reference_flow(caption_ids, contexts, attn_idx, gen_len, eos)
 
+    @staticmethod
+    def _drive(gen):
+        """Run a decode generator (one `yield` per issued step) to its result."""
+        try:
+            while True:
+                next(gen)
+        except StopIteration as done:
+            return done.value
+
     @torch.no_grad()
-    def _generate_cached(self, caption_ids, contexts, gen_len=100, eos=2, check_every=8):
-        """Same greedy decode, restructured for the GPU: (1) context K/V projected once per caption,
+    def _generate_cached(self, caption_ids, contexts, gen_len=100, eos=2, check_every=8, lane=0):
+        return self._drive(self._greedy_steps(caption_ids, contexts, gen_len, eos, check_every, lane))
+
+    def _greedy_steps(self, caption_ids, contexts, gen_len=100, eos=2, check_every=8, lane=0):
+        """A generator: yields after every issued decode step (generate_lanes interleaves two of these on two streams), returns
+        (log_probs, ids, []).  Same greedy decode, restructured for the GPU: (1) context K/V projected once per caption,
         (2) the batch keeps its shape - finished rows are masked instead of compacted, so there is no
         per-step gather of the contexts and no per-step host synchronisation (the all-finished test
         runs every `check_every` steps), (3) fused arg-max over the adaptive softmax.  Rows are
@@ -390,7 +450,7 @@ class CaptionModel(Model):
         B = caption_ids.shape[0]
         dev = caption_ids.device
         kv = dec.project_contexts(contexts)
-        step = self._decode_stepper(B, kv, contexts, gen_len)
+        step = self._decode_stepper(B, kv, contexts, gen_len, lane=lane)
         cur = caption_ids[:, 0:1].contiguous()
         finished = cur[:, 0] == eos
         fused = caption_ids.is_cuda and hasattr(step, 'cur')      # one bookkeeping launch per token (tell_greedy_update)
@@ -426,10 +486,12 @@ class CaptionModel(Model):
             # (the bookkeeping launch of step i - 1 left the position offset of step i in the device counter: no fill launch;
             #  the host's part of a step is ONE graph replay)
             step(i, None, counter_set=i > 0, post=book)
+            yield i
             if (i + 1) % check_every == 0 and bool(fin8.all()):
                 break
         for i in range(0 if fused else gen_len):
             tok, lp = step(i, cur)
+            yield i
             tok = tok.long().view(B)
             lp = lp.view(B) / self.sampling_temp
             ids[:, i + 1] = torch.where(finished, ids[:, i + 1], tok)
@@ -446,7 +508,7 @@ class CaptionModel(Model):
             return lps[:, :steps].clone(), ids[:, :steps + 1].clone(), []
         return lps[:, :steps], ids[:, :steps + 1], []
 
-    def _decode_stepper(self, B, kv, contexts, gen_len, topk=0):
+    def _decode_stepper(self, B, kv, contexts, gen_len, topk=0, lane=0):
         """-> step(i, cur [B,1]) -> (token [B,1], log-prob [B,1]) - or, with topk=k, the k best (tokens [B,1,k],
         log-probs [B,1,k]) of every row - for the cached greedy / beam generators; step.reorder(rows) permutes the
         rows of the incremental state (beam search).
@@ -468,8 +530,10 @@ class CaptionModel(Model):
             eager_step.reorder = lambda rows: dec.reorder_incremental_state(state, rows)
             return eager_step
         dev, dtype = kv[0][names[0]][0].device, kv[0][names[0]][0].dtype
+        # lane: decode loops that are in flight TOGETHER (generate_lanes: two caption batches decoded on two streams) own
+        # their graphs, static buffers, counters and split-reduction workspace
         sig = (B, dtype, topk, int(gen_len), tuple((n, tuple(kv[0][n][0].shape), tuple(kv[0][n][1].shape)) for n in names),
-               dec.embedder.token_embedder_position.weights.data_ptr())
+               dec.embedder.token_embedder_position.weights.data_ptr(), int(lane))
         cache = self.__dict__.setdefault('_decode_graphs', {})
         # A captured step bakes in the addresses of the working weights (weight-normalised copies, the concatenated
         # softmax head) that ops._cached rebuilds - at NEW addresses - whenever the weights change (optimizer step,
@@ -548,8 +612,14 @@ class CaptionModel(Model):
         c_out = c_next if h['ig'] else c_cur
 
         def run():
-            out = dec({self.index: h['cur']}, h['ctx'], incremental_state=h['state'], kv_cache=h['kv'])
-            return head(out[0][:, -1:])
+            from .. import decode as _dec2
+            prev_lane = _dec2.CUR_LANE[0]
+            _dec2.CUR_LANE[0] = int(lane)
+            try:
+                out = dec({self.index: h['cur']}, h['ctx'], incremental_state=h['state'], kv_cache=h['kv'])
+                return head(out[0][:, -1:])
+            finally:
+                _dec2.CUR_LANE[0] = prev_lane
 
         def eager(i, post):
             res = run()
@@ -625,8 +695,11 @@ class CaptionModel(Model):
         return step
 
     @torch.no_grad()
-    def _generate_beam(self, caption_ids, contexts, beam_size, gen_len=100, eos=2, check_every=8):
-        """Beam search on the cached static-shape generator (SURVEY 8-f1 / BASELINE config 5; the reference itself
+    def _generate_beam(self, caption_ids, contexts, beam_size, gen_len=100, eos=2, check_every=8, lane=0):
+        return self._drive(self._beam_steps(caption_ids, contexts, beam_size, gen_len, eos, check_every, lane))
+
+    def _beam_steps(self, caption_ids, contexts, beam_size, gen_len=100, eos=2, check_every=8, lane=0):
+        """A generator like _greedy_steps.  Beam search on the cached static-shape generator (SURVEY 8-f1 / BASELINE config 5; the reference itself
         only samples top-1, transformer_faces_objects.py:443-464).  B*K rows (row = b*K + j) stay resident; the
         projected K/V of the static contexts are computed once per caption and replicated per beam; the DynamicConv
         input buffers are reordered by parent with the reference's `reorder_incremental_state` contract
@@ -641,7 +714,7 @@ class CaptionModel(Model):
         # sample as K query positions of that sample (modules/attention.py), nothing is replicated per beam
         ctx = {k_: v_ for k_, v_ in contexts.items() if torch.is_tensor(v_)}
         kv = dec.project_contexts(contexts)
-        step = self._decode_stepper(B * K, kv, ctx, gen_len, topk=K)
+        step = self._decode_stepper(B * K, kv, ctx, gen_len, topk=K, lane=lane)
         cur = rep(caption_ids[:, 0:1], 0)
         finished = (cur[:, 0] == eos).view(B, K)
         fused = caption_ids.is_cuda and hasattr(step, 'cur') and K <= 8 and gen_len + 1 <= 256
@@ -683,6 +756,7 @@ class CaptionModel(Model):
                 if not ring:
                     book(out, i, None)
                     step.reorder(rows, K)
+                yield i
                 if (i + 1) % check_every == 0 and bool(fin8.all()):
                     n_steps = i + 1
                     break
@@ -710,6 +784,7 @@ class CaptionModel(Model):
             cum = top
             step.reorder(rows)
             cur = tok.view(B * K, 1)
+            yield i
             if (i + 1) % check_every == 0 and bool(finished.all()):
                 n_steps = i + 1
                 break
