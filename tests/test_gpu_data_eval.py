@@ -140,3 +140,41 @@ def test_generate_lanes_equals_batch_by_batch_generation(beam, lanes):
             assert seen == len(batches)
     finally:
         tell_amd.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize('beam', [1, 3])
+def test_evaluate_forward_through_lanes_equals_forward_batch_by_batch(beam):
+    """What commands/evaluate.py drives: `generate_lanes(forward=True)` yields, batch for batch, the evaluate-mode output of
+    `forward` (the loss, the generated ids, the detokenised texts, the captions) and leaves the model's running metrics
+    (sample count, batch count, per-sample BLEU sums) exactly where batch-by-batch `forward` calls leave them."""
+    import tell_amd
+    from tell_amd.build import build_model
+    from tell_amd.data import synthetic_batch
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(0)
+        model = build_model('faces_objects', _Res(True), _Rob(1024), n_bert_layers=3, **KW).to(DEV).eval()
+        model.evaluate_mode = True
+        model.eval_beam_size = beam
+        batches = [synthetic_batch(4, 24 + 8 * (i % 2), 9, True, seed=51 + i, device=DEV, vocab=600, cutoffs=(100, 300)) for i in range(3)]
+        for i, b in enumerate(batches):
+            b['metadata'] = [{'caption': '7 8 9 %d 11' % (10 + j + i)} for j in range(4)]
+
+        def clone(b):
+            return {k: (dict(v) if isinstance(v, dict) else (list(v) if isinstance(v, list) else v.clone())) for k, v in b.items()}
+        with torch.no_grad():
+            alone = [model(**clone(b)) for b in batches]
+        torch.cuda.synchronize()
+        want = (model.n_samples, model.n_batches, dict(model.sample_history))
+        model.get_metrics(reset=True)
+        model.n_samples = model.n_batches = 0
+        seen = 0
+        for i, (b, out) in enumerate(model.generate_lanes((clone(b) for b in batches), lanes=2, forward=True)):
+            assert torch.equal(out['loss'], alone[i]['loss']), i
+            assert (out['gen_ids'] == alone[i]['gen_ids']).all() and out['gen_ids'].shape == alone[i]['gen_ids'].shape, i
+            assert out['generations'] == alone[i]['generations'] and out['captions'] == alone[i]['captions'], i
+            seen += 1
+        assert seen == len(batches)
+        assert (model.n_samples, model.n_batches, dict(model.sample_history)) == want
+    finally:
+        tell_amd.set_compute_dtype(torch.float32)

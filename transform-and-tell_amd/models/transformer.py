@@ -264,35 +264,43 @@ class CaptionModel(Model):
     def forward(self, context, image, caption, face_embeds=None, obj_embeds=None, metadata=None, names=None,
                 attn_idx=None, encoded=None):
         """encoded: optional EncodedBatch of THIS batch produced earlier by `encode(..., ahead=True)`."""
+        output_dict, caption_ids, contexts = self._forward_loss(context, image, caption, face_embeds, obj_embeds, encoded)
+        if not self.training and self.evaluate_mode:                       # :92-116
+            _, gen_ids, attns = self._generate(caption_ids, contexts, beam_size=getattr(self, 'eval_beam_size', 1))
+            self._forward_generated(output_dict, gen_ids, attns, metadata)
+        self.n_samples += caption_ids.shape[0]
+        self.n_batches += 1
+        return output_dict
+
+    def _forward_loss(self, context, image, caption, face_embeds=None, obj_embeds=None, encoded=None):
+        """:67-88 - encoders, teacher-forced decoder pass, loss in bits per token -> (output_dict, caption_ids, contexts)."""
         caption_ids, target_ids, contexts = self._forward(context, image, caption, face_embeds, obj_embeds, encoded)
         decoder_out = self.decoder(caption, contexts)
         loss_sum, sample_size = self.criterion(self.decoder.adaptive_softmax, decoder_out, target_ids)
         loss = ops.loss_bits(loss_sum, sample_size)                        # :85-88, bits per token
-        output_dict = {'loss': loss, 'sample_size': sample_size.reshape(())}
-        if not self.training and self.evaluate_mode:                       # :92-116
-            _, gen_ids, attns = self._generate(caption_ids, contexts, beam_size=getattr(self, 'eval_beam_size', 1))
-            ids_cpu = gen_ids.cpu()
-            output_dict['gen_ids'] = ids_cpu.numpy()
-            output_dict['attns'] = attns
-            gen_texts = [self.detokenize(x[x > 1]) for x in ids_cpu]        # :96 "we ignore <s> and <pad>"
-            output_dict['generations'] = gen_texts
-            if metadata is not None:
-                captions = [m.get('caption') or '' for m in metadata]
-                output_dict['captions'] = captions
-                output_dict['metadata'] = metadata
-                import re
-                from ..metrics import BleuScorer
-                gens = [re.sub(r'[^\w\s]', '', t) for t in gen_texts]       # :105-106 remove punctuation
-                refs = [re.sub(r'[^\w\s]', '', t) for t in captions]
-                for gen, ref in zip(gens, refs):                            # :108-116
-                    scorer = BleuScorer(n=4)
-                    scorer += (gen, [ref])
-                    score, _ = scorer.compute_score(option='closest')
-                    for k in range(4):
-                        self.sample_history['bleu-%d' % (k + 1)] += score[k] * 100
-        self.n_samples += caption_ids.shape[0]
-        self.n_batches += 1
-        return output_dict
+        return {'loss': loss, 'sample_size': sample_size.reshape(())}, caption_ids, contexts
+
+    def _forward_generated(self, output_dict, gen_ids, attns, metadata):
+        """:92-116 - what evaluate mode adds to the output once the captions are decoded: ids, text, per-sample BLEU."""
+        ids_cpu = gen_ids.cpu()
+        output_dict['gen_ids'] = ids_cpu.numpy()
+        output_dict['attns'] = attns
+        gen_texts = [self.detokenize(x[x > 1]) for x in ids_cpu]        # :96 "we ignore <s> and <pad>"
+        output_dict['generations'] = gen_texts
+        if metadata is not None:
+            captions = [m.get('caption') or '' for m in metadata]
+            output_dict['captions'] = captions
+            output_dict['metadata'] = metadata
+            import re
+            from ..metrics import BleuScorer
+            gens = [re.sub(r'[^\w\s]', '', t) for t in gen_texts]       # :105-106 remove punctuation
+            refs = [re.sub(r'[^\w\s]', '', t) for t in captions]
+            for gen, ref in zip(gens, refs):                            # :108-116
+                scorer = BleuScorer(n=4)
+                scorer += (gen, [ref])
+                score, _ = scorer.compute_score(option='closest')
+                for k in range(4):
+                    self.sample_history['bleu-%d' % (k + 1)] += score[k] * 100
 
     def detokenize(self, ids):
         """`self.roberta.decode(ids)` of the reference (:96): BPE ids -> text.  Uses the encoder's own `decode` when it
@@ -324,14 +332,25 @@ class CaptionModel(Model):
         log_probs, gen_ids, attns = self._generate(caption_ids, contexts, attn_idx, beam_size=beam_size)
         return {'gen_ids': gen_ids, 'log_probs': log_probs, 'attns': attns}
 
+    def lanes_usable(self):
+        """Whether `generate_lanes` has a decode loop to interleave: the K/V-cached static-batch generator on a GPU."""
+        return (self.fast_generation and hasattr(self.decoder, 'project_contexts')
+                and next(self.parameters()).is_cuda)
+
     @torch.no_grad()
-    def generate_lanes(self, batches, beam_size=1, lanes=2):
+    def generate_lanes(self, batches, beam_size=1, lanes=2, forward=False):
         """Captions for a sequence of batches with `lanes` decode loops IN FLIGHT TOGETHER, each on its own stream with its
         own captured step, static buffers and counters (_decode_stepper(lane=)): a decode step is a chain of ~40 dependent
         launches that each fill the chip for a few microseconds and then wait on memory - at 12-27 % of the HBM roofline a second
         chain fits beside the first.  The host alternates the lanes' graph replays (one replay per lane and token).  The
         encoders of a group of batches run first (eval mode: no randomness, results identical to `generate`).
-        Yields (batch, output) in order."""
+        Yields (batch, output) in order.  forward=True: the outputs of `forward` in evaluate mode (loss + captions + per-sample
+        BLEU bookkeeping: what commands/evaluate.py consumes) instead of `generate`'s; beam_size then is `eval_beam_size`."""
+        if forward:
+            beam_size = getattr(self, 'eval_beam_size', 1)
+            if self.training or not self.evaluate_mode or not self.lanes_usable():
+                yield from self.generate_stream(batches, forward=True)  # nothing to decode / no static-batch decode loop
+                return
         it = iter(batches)
         main = torch.cuda.current_stream()
         lane_streams = [streams.get('decode_lane_%d' % i) for i in range(lanes)]
@@ -343,10 +362,14 @@ class CaptionModel(Model):
                     group.append(b)
             if not group:
                 return
-            gens, outs = [], [None] * len(group)
+            gens, outs, heads = [], [None] * len(group), []
             for ln, b in enumerate(group):
                 f = {k: v for k, v in b.items() if k in ('context', 'image', 'caption', 'face_embeds', 'obj_embeds')}
-                caption_ids, _, contexts = self._forward(**f)
+                if forward:
+                    od, caption_ids, contexts = self._forward_loss(**f)
+                    heads.append((od, b.get('metadata'), caption_ids.shape[0]))
+                else:
+                    caption_ids, _, contexts = self._forward(**f)
                 ev = torch.cuda.Event()
                 ev.record(main)
                 lane_streams[ln].wait_event(ev)
@@ -368,7 +391,13 @@ class CaptionModel(Model):
                 ev = torch.cuda.Event()
                 ev.record(lane_streams[ln])
                 main.wait_event(ev)
-            for b, o in zip(group, outs):
+            for ln, (b, o) in enumerate(zip(group, outs)):
+                if forward:
+                    od, metadata, n = heads[ln]
+                    self._forward_generated(od, o['gen_ids'], o['attns'], metadata)
+                    self.n_samples += n
+                    self.n_batches += 1
+                    o = od
                 yield b, o
 
     def generate_stream(self, batches, beam_size=1, forward=False):
