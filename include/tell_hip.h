@@ -326,7 +326,8 @@ int tell_dropout_add(const void* x, const void* add, void* out, long n, float p,
  *   owned by the launches of ONE stream): lets a single-problem launch with few column tiles and a long reduction (N <=
  *   1536, K >= 2048: context_fc, fc2) share the reduction of a tile between 2 / 4 workgroups that combine inside the launch
  *   (write-through partial tiles, an agent-scope arrival counter per tile - never reset -, the last arrival sums the
- *   slices in slice order: deterministic).  NULL = every workgroup owns its whole reduction.  Option "sk_split" = 0: never. */
+ *   slices in slice order: deterministic).  NULL = every workgroup owns its whole reduction.  Taken only with option "sk_split"
+ *   = 1 (default 0: with the operands staged through LDS the unsplit form is as fast). */
 int tell_skinny_linear(int n_prob, const void* const* in, long ld_in, int pro, const void* const* gamma,
                        const void* const* beta, int seg, float eps, float* stats_out, void* ws, const void* const* w,
                        long ldw, const void* const* bias, int act, float scale, const void* res, long ld_res,

@@ -1319,6 +1319,82 @@ def test_generation_step_linears_layernorm_and_dynconv_step(M):
         assert torch.equal(ring, want_ring), K               # exactly one plane written: the one the step does not read
 
 
+@pytest.mark.parametrize('M', [5, 32, 70, 128])
+def test_skinny_linear_operands_staged_through_lds_bit_identical_to_direct_loads(M):
+    """The skinny linears' operands reach the matrix cores through LDS (whole cache lines per wave load, a wave-private XOR-
+    swizzled transposition; option sk_staged, csrc/decode.hip) - the k -> fragment-slot assignment and the order of the
+    accumulation are those of the direct form, so every form of the step (GLU, ReLU, four problems per launch, folded
+    LayerNorms over 1 / 4 segments, K = 1024 / 2048 / 4096, few-column tiles, the in-launch split reduction, ragged row
+    counts) must give the SAME BITS either way."""
+    import tell_amd
+    from tell_amd import decode, hip
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    E, F = 1024, 4096
+    g = torch.Generator().manual_seed(100 + M)
+    bf, f32 = dict(dtype=torch.bfloat16, device=DEV), dict(dtype=torch.float32, device=DEV)
+    R = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k)                         # noqa: E731
+
+    class LN:
+        def __init__(self):
+            self.weight, self.bias, self.eps = (torch.rand(E, generator=g) + 0.5).to(**f32), R(E, k=0.1).to(**f32), 1e-5
+    W = lambda n_, k_: R(n_, k_, k=0.03).to(**bf)                                             # noqa: E731
+    Bv = lambda n_: R(n_, k=0.1).to(**f32)                                                    # noqa: E731
+    x, x2, x4 = R(M, E).to(**bf), R(M, 2 * E).to(**bf), R(M, F).to(**bf)
+    raw_bf, raw4_bf = (R(M, E, k=2.0) + 0.3).to(**bf), (R(M, 4 * E, k=2.0) - 0.2).to(**bf)
+    ln, lns = LN(), [LN() for _ in range(4)]
+    w_l1, b_l1, w_l2, b_l2 = W(2 * E, E), Bv(2 * E), W(E, E), Bv(E)
+    wq, bq = [W(E, E) for _ in range(4)], [Bv(E) for _ in range(4)]
+    wc, bc, w1, b1, w2, b2, w22 = W(E, 4 * E), Bv(E), W(F, E), Bv(F), W(E, F), Bv(E), W(E, 2 * E)
+    P = lambda: torch.nn.Parameter(torch.zeros(1, device=DEV))                                # noqa: E731
+    wf1, s1, c1 = decode._folded(P(), w_l1, [ln], E)
+    fq = [decode._folded(P(), wq[i], [ln], E) for i in range(4)]
+    wcf, scf, ccf = decode._folded(P(), wc, lns, E)
+    ws = decode.split_workspace(torch.device(DEV))
+
+    def run():
+        outs = []
+        o = torch.zeros(M, E, **bf)
+        decode._skinny([x], E, [w_l1], [b_l1], [o], E, M, E, E, act=2)
+        outs.append(o)
+        o = torch.zeros(M, E, **bf)
+        st = torch.zeros(M, 2, **f32)
+        decode._skinny([raw_bf], E, [wf1], [b_l1], [o], E, M, E, E, pro=3, gammas=[s1], betas=[c1], eps=ln.eps, stats_out=st, act=2)
+        outs += [o, st]
+        o32 = torch.zeros(M, E, **f32)
+        decode._skinny([x], E, [w_l2], [b_l2], [o32], E, M, E, E, res=x, ld_res=E, out_f32=True)
+        outs.append(o32)
+        q4 = torch.zeros(4, M, E, **bf)
+        decode._skinny([raw_bf] * 4, E, [f[0] for f in fq], bq, [q4[i] for i in range(4)], E, M, E, E, pro=3,
+                       gammas=[f[1] for f in fq], betas=[f[2] for f in fq], eps=ln.eps, scale=0.125)
+        outs.append(q4)
+        r6 = torch.zeros(M, 4 * E, **f32)
+        decode._skinny([q4[i] for i in range(4)], E, wq, bq, [r6[:, i * E:(i + 1) * E] for i in range(4)], 4 * E, M, E, E,
+                       res_f32=o32, out_f32=True)
+        outs.append(r6)
+        for split in (0, 1):
+            with hip.options(sk_split=split):
+                o = torch.zeros(M, E, **bf)
+                decode._skinny([raw4_bf], 4 * E, [wcf], [bc], [o], E, M, E, 4 * E, pro=4, gammas=[scf], betas=[ccf], seg=E, eps=1e-5)
+                o32 = torch.zeros(M, E, **f32)
+                decode._skinny([x4], F, [w2], [b2], [o32], E, M, E, F, res=x, ld_res=E, out_f32=True)
+                o2 = torch.zeros(M, E, **f32)
+                decode._skinny([x2], 2 * E, [w22], [b2], [o2], E, M, E, 2 * E, out_f32=True)
+                outs += [o, o32, o2]
+        h = torch.zeros(M, F, **bf)
+        decode._skinny([x], E, [w1], [b1], [h], F, M, F, E, act=1)
+        outs.append(h)
+        torch.cuda.synchronize()
+        return outs
+    with hip.options(sk_staged=0):
+        direct = run()
+    with hip.options(sk_staged=1):
+        staged = run()
+    assert ws is not None
+    for i, (a, b) in enumerate(zip(direct, staged)):
+        assert torch.equal(a, b), i
+        assert bool(torch.isfinite(a.float()).all()) and float(a.float().abs().sum()) > 0, i
+
+
 @pytest.mark.parametrize('M', [7, 19, 32, 64])
 def test_skinny_linear_reduction_shared_between_workgroups(M):
     """tell_skinny_linear with split_ws (round 6): context_fc / fc2 of the generation step (N = 1024, K = 4096 / 2048) with
@@ -1331,6 +1407,7 @@ def test_skinny_linear_reduction_shared_between_workgroups(M):
     import tell_amd
     from tell_amd import decode, hip
     tell_amd.set_compute_dtype(torch.bfloat16)
+    hip.set_option('sk_split', 1)                 # (off by default since the operands are staged through LDS: no gain left)
     E = 1024
     g = torch.Generator().manual_seed(100 + M)
     bf, f32 = dict(dtype=torch.bfloat16, device=DEV), dict(dtype=torch.float32, device=DEV)
@@ -1376,7 +1453,8 @@ def test_skinny_linear_reduction_shared_between_workgroups(M):
             fc2(xs[0]); cfc(raws[0])
             torch.cuda.synchronize()
         names = ' '.join(e.name for e in pf.events())
-        split_ran = ', true>' in names or ',true>' in names                       # skinny_mfma_kernel<..., SPLIT = true>
+        import re
+        split_ran = re.search(r'skinny_mfma_kernel<\d+, ?\d+, ?\d+, ?(true|false), ?\d+, ?true', names) is not None   # <RT, ACT, U, FOLD, NW, SPLIT = true, ..>
         assert split_ran == (M <= 32), names          # (measured: a loss above 32 rows - csrc/decode.hip; those keep the unsplit form)
         # ---- alternate inputs under memory traffic on another stream
         side_stream = torch.cuda.Stream()

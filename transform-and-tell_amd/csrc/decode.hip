@@ -57,6 +57,11 @@ struct SkinnyArgs {
   // in-launch split of the reduction over `ksplit` workgroups per output tile (round 6): fp32 partial tiles in `sk_slab`
   // ([tile][slice][MT * 16 (* 2 with GLU)]), arrivals counted in sk_cnt[tile] (monotonic: never reset)
   int ksplit; float* sk_slab; unsigned* sk_cnt;
+#ifdef TELL_PROBES
+  // probe build: per-workgroup wall-clock stamps of ONE launch slot ([1 + workgroups][4] u64: entry 0 = the launch's shape;
+  // then start, end of the K loop, end, hardware id) - tools/probes/skinny_stamps.py
+  unsigned long long* stamp;
+#endif
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 sk_bf16x2;
@@ -123,7 +128,10 @@ __device__ __forceinline__ SkPre skinny_preload(const SkinnyArgs& p, int prob, i
   SkPre q = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const float* bias = p.bias[prob];
   if (bias) { q.b0 = bias[n]; if (act == 2) q.b1 = bias[p.N + n]; }
-  if (p.res) q.res = __uint_as_float((uint32_t)p.res[(long)m * p.ld_res + n] << 16);
+  // (the bf16 residual stays as the 16 bits the load delivers: shifting it into a float HERE made the compiler wait for
+  //  the load - and, loads returning in order, for the whole first batch of operand loads issued before it - in front of
+  //  the K loop; the epilogue shifts)
+  if (p.res) q.res = __uint_as_float((uint32_t)p.res[(long)m * p.ld_res + n]);
   if (p.res_raw) {
     q.raw = p.res_raw[(long)m * p.ld_res_raw + n]; q.mean = p.res_stats[m * 2]; q.rstd = p.res_stats[m * 2 + 1];
     q.gam = p.res_gamma[n]; q.bet = p.res_beta[n];
@@ -140,7 +148,11 @@ __device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& p, int prob, i
     if (act == 1) v = fmaxf(v, 0.f);
     if (act == 2) v = tell_glu(v, g + pre->b1);
     v *= p.scale;
-    v += pre->res;
+    {                                                                // (bf16 bits -> float; 0 stays 0.  The empty asm pins the
+      uint32_t rb = __float_as_uint(pre->res);                       //  shift HERE: the optimizer otherwise moves it back up to
+      asm volatile("" : "+v"(rb));                                   //  the load, and the wait with it)
+      v += __uint_as_float(rb << 16);
+    }
     if (p.res_raw) v += (pre->raw - pre->mean) * pre->rstd * pre->gam + pre->bet;
     v += pre->r32;
   } else {
@@ -174,7 +186,23 @@ __device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& p, int prob, i
 // (ticket % ksplit == ksplit - 1 marks the last arrival; every launch adds exactly ksplit): nothing to zero between
 // launches or graph replays.  With the folded LayerNorm a slice is exactly one segment (K / ksplit == seg): its row
 // statistics are complete inside the workgroup and its partial tile is already corrected.
-template <int RT, int ACT, int U, bool FOLD = false, int NW = 4, bool SPLIT = false>
+//
+// STAGED (round 6, second half): the operands reach the matrix cores through LDS.  Loading an MFMA fragment straight from a
+// row-major matrix makes every quarter-wave of a 16-byte load touch 16 ROWS x 16 bytes - the texture addresser spends a
+// lookup per row where a lookup can deliver 64 bytes, and that, not HBM, the L2 or latency, is what the K loop waited for:
+// per-workgroup wall-clock stamps (tools/probes/skinny_stamps.py, profiles/r06_skinny_stamps_*.txt) show all 256 workgroups
+// of a launch alive from its first to its last microsecond (dispatch ramp 0.2-0.3 us, launch-to-launch gap 1.5-2 us) with
+// 4 us (32 rows) / 9-11 us (128 rows) inside the K loop = 20-30 GB/s per CU; staggering the column tiles' walks through K
+// changed nothing (not an L2 hot spot: fc1 12.79 -> 12.83 us); the same loads issued as one contiguous KB per wave
+// instruction (wrong results, probe build) took the launches from 5.2-5.8 to 3.9-4.7 us at 32 rows and from 12.8-16.2 to
+// 7.1-10.9 us at 128.  So a wave now reads 8 rows x 128 bytes per instruction (whole cache lines: lane l = row l >> 3,
+// 16-byte chunk l & 7) into registers, U stages of 64 k in flight, drops a landed stage into ITS OWN slice of LDS
+// (ds_write_b128, chunk position XORed with the row's low 3 bits) and reads the fragments back in the instruction's layout
+// (ds_read_b128; the XOR makes both the 8-lane write groups and the 16-lane read groups of MI355X_MICROARCH.md's LDS table
+// conflict-free).  No barrier: a wave stages only what it consumes.  Activation rows and the tile's weight rows are the
+// same thing to the stage (R = MT + 16 NB rows).  The k -> fragment-slot assignment and the order of the accumulation are
+// those of the direct form: results are bit-identical.
+template <int RT, int ACT, int U, bool FOLD = false, int NW = 4, bool SPLIT = false, bool STAGED = false>
 __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
   constexpr int NB = ACT == 2 ? 2 : 1, MT = RT * 16, CW = 16 * NB, NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
@@ -183,6 +211,23 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
   float* rst = wst + NW * MT * 2;                                      // FOLD: [MT][4 segments][2] mean, rstd
   const int tid = threadIdx.x, prob = blockIdx.y, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
+#ifdef TELL_PROBES
+  unsigned long long st0 = 0, st1 = 0;
+  if (p.stamp) st0 = wall_clock64();
+  auto stamp_out = [&]() {
+    if (!p.stamp || tid != 0) return;
+    const long wg = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    unsigned long long* s = p.stamp + (1 + wg) * 4;
+    s[0] = st0; s[1] = st1; s[2] = wall_clock64(); s[3] = __builtin_amdgcn_s_getreg((31 << 11) | 4 /* HW_ID, 32 bits */) |
+                                                          ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20 /* XCC_ID, 4 bits */) << 32);
+    if (wg == 0) {
+      p.stamp[0] = gridDim.x | ((unsigned long long)gridDim.y << 16) | ((unsigned long long)gridDim.z << 32);
+      p.stamp[1] = (unsigned long long)p.M | ((unsigned long long)p.N << 20) | ((unsigned long long)p.K << 40);
+      p.stamp[2] = RT | (ACT << 8) | (U << 16) | ((int)FOLD << 24) | ((int)SPLIT << 25) | (NW << 26);
+      p.stamp[3] = p.cn;
+    }
+  };
+#endif
   const int ksplit = SPLIT ? p.ksplit : 1, slice = SPLIT ? (int)blockIdx.z % ksplit : 0;
   const int cn = p.cn, n0 = blockIdx.x * cn, m0 = (SPLIT ? (int)blockIdx.z / ksplit : (int)blockIdx.z) * MT, M = p.M, N = p.N;
   const int K = SPLIT ? p.K / ksplit : p.K;                            // this workgroup's share of the reduction
@@ -211,12 +256,12 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
     const int k = batch * 32 * U;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-#pragma unroll
       // (round 5: non-temporal loads for the weights here and for the cached K / V in attn_decode_kernel - each byte is read
       //  by one workgroup, once per step - measured: greedy step 486.6-487.5 us plain, 483.9-489.4 nt; not kept)
       // (round 6 measured the B loads of the lanes past cn masked off instead of repeating column n0 - if the address unit's
       //  time per wave instruction were what bounds the cn = 4 launches, that would have removed a quarter of it: context_fc
       //  14.2 -> 15.5 us, fc2 11.3 -> 12.1, linear2 5.0 -> 5.6 at 32 rows (same box within 1 % on the unchanged shapes). Not kept.)
+#pragma unroll
       for (int b = 0; b < NB; ++b) fb[u][b] = *reinterpret_cast<const sk_u4*>(bp[b] + k + u * 32);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) fa[u][rt] = *reinterpret_cast<const sk_u4*>(ap[rt] + k + u * 32);
@@ -230,10 +275,11 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) { fsum[rt] = c4{0.f, 0.f, 0.f, 0.f}; fsq[rt] = c4{0.f, 0.f, 0.f, 0.f}; }
   const sk_u4 ones4 = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-  auto compute = [&](const sk_u4 (&fa)[U][RT], const sk_u4 (&fb)[U][NB]) __attribute__((always_inline)) {
+  auto compute = [&](const auto& fa, const auto& fb) __attribute__((always_inline)) {
+    constexpr int UU = sizeof(fa) / sizeof(fa[0]);                      // k-steps of 32 held by the fragments
     if constexpr (FOLD) {
 #pragma unroll
-      for (int u = 0; u < U; ++u)
+      for (int u = 0; u < UU; ++u)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           const sk_bf16x8 av = __builtin_bit_cast(sk_bf16x8, fa[u][rt]);
@@ -242,7 +288,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
         }
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+    for (int u = 0; u < UU; ++u)
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const sk_u4 bw = fb[u][b];
@@ -254,7 +300,64 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
         }
       }
   };
-  load(fa0, fb0, 0);
+  // ---- STAGED: stage = 64 k of the wave's R rows = NL wave loads of 8 rows x 128 bytes
+  constexpr int R = MT + 16 * NB, NL = R / 8, SB = R * 128;
+  sk_u4 stg[STAGED ? U : 1][STAGED ? NL : 1];
+  const int ns = kw / 64;                                              // stages of this wave
+  const int lrow = lane >> 3, lch = lane & 7;
+  unsigned char* const sbuf = sk_smem + (STAGED ? (long)wave * SB : 0);   // ONE buffer: a wave's LDS instructions execute in order
+  const int woff = lrow * 128 + ((lch ^ lrow) << 4);                   // + i * 1024: where this lane's 16 bytes of load i go
+  const int roff0 = lr * 128 + ((lg ^ (lr & 7)) << 4);                 // + row tile * 2048: fragment of k-step 0 ...
+  const int roff1 = lr * 128 + (((4 + lg) ^ (lr & 7)) << 4);           //   ... and of k-step 1 of the stage
+  auto stage_load = [&](sk_u4 (&st)[STAGED ? NL : 1], int sidx) __attribute__((always_inline)) {
+    const int k = kbeg + sidx * 64 + lch * 8;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int row = i * 8 + lrow;
+      if (i * 8 < MT) {                                                // (MT is a multiple of 8: a load is all activations or all weights)
+        const int m = m0 + row;
+        st[i] = *reinterpret_cast<const sk_u4*>(X + (long)(m < M ? m : M - 1) * p.ld_in + k);
+      } else {
+        const int c = row - MT, cc = c & 15;
+        const int cq = n0 + (cc < cn ? cc : 0);
+        st[i] = *reinterpret_cast<const sk_u4*>(W + (long)((c >> 4) * N + (cq < N ? cq : N - 1)) * p.ldw + k);
+      }
+    }
+  };
+  auto stage_write = [&](const sk_u4 (&st)[STAGED ? NL : 1], int) __attribute__((always_inline)) {
+    unsigned char* const buf = sbuf;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) *reinterpret_cast<sk_u4*>(buf + i * 1024 + woff) = st[i];
+  };
+  auto stage_compute = [&](int) __attribute__((always_inline)) {
+    unsigned char* const buf = sbuf;
+    if constexpr (RT >= 8) {                                           // (register budget: one k-step's fragments at a time)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ro = ks ? roff1 : roff0;
+        sk_u4 ga[1][RT], gb[1][NB];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) ga[0][rt] = *reinterpret_cast<const sk_u4*>(buf + rt * 2048 + ro);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) gb[0][b] = *reinterpret_cast<const sk_u4*>(buf + (MT + b * 16) * 128 + ro);
+        compute(ga, gb);
+      }
+    } else {
+      sk_u4 ga[2][RT], gb[2][NB];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        ga[0][rt] = *reinterpret_cast<const sk_u4*>(buf + rt * 2048 + roff0);
+        ga[1][rt] = *reinterpret_cast<const sk_u4*>(buf + rt * 2048 + roff1);
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        gb[0][b] = *reinterpret_cast<const sk_u4*>(buf + (MT + b * 16) * 128 + roff0);
+        gb[1][b] = *reinterpret_cast<const sk_u4*>(buf + (MT + b * 16) * 128 + roff1);
+      }
+      compute(ga, gb);
+    }
+  };
+  if constexpr (!STAGED) load(fa0, fb0, 0);
   // FOLD: the epilogue's s / c values of this thread's column (o & 15 == tid & 15 for every o it handles) are requested
   // now - behind the reduction they were a dependent global round trip at the very end of the launch
   float pre_s[4][NB], pre_c[NB];
@@ -279,6 +382,31 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
       pre[e] = skinny_preload(p, prob, m, n, ACT);
     }
   }
+  // STAGED: the epilogue operands above were requested FIRST, the operand stages follow, every stage load unconditional
+  // (the launcher picks U so that the wave's stage count is a multiple of it): s_waitcnt vmcnt counts loads in issue
+  // order, and the compiler, which must assume the fewest younger loads any path may have issued, waits for far more
+  // than the stage it needs as soon as a stage load sits under a condition (first version: vmcnt(5) in front of stage 0 -
+  // the whole prologue drained before the first MFMA).
+  if constexpr (STAGED) {
+#pragma unroll
+    for (int d = 0; d < U; ++d) stage_load(stg[d], d);
+  }
+  if constexpr (STAGED) {
+    for (int s0 = U; s0 < ns; s0 += U) {                               // every group but the last: consume a stage, refill its registers
+#pragma unroll
+      for (int d = 0; d < U; ++d) {
+        stage_write(stg[d], d & 1);                                    // (the landed stage leaves its registers ...
+        stage_load(stg[d], s0 + d);                                    //  ... to the loads of the stage U further on)
+        stage_compute(d & 1);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < U; ++d) {                                      // the last U stages: nothing left to request
+      stage_write(stg[d], d & 1);
+      stage_compute(d & 1);
+    }
+    __syncthreads();                                                   // (the reduction buffer below lies over the stages)
+  } else {
   int b = 0;
   for (; b + 1 < nbatch; b += 2) {
     load(fa1, fb1, b + 1);
@@ -287,6 +415,15 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
     compute(fa1, fb1);
   }
   if (b < nbatch) compute(fa0, fb0);
+  }
+#ifdef TELL_PROBES
+  if (p.stamp) {                                                       // (the stamp waits for the accumulators: the K loop's loads have landed)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) asm volatile("" ::"v"(acc[rt][0]));
+    asm volatile("s_nop 4" ::: "memory");
+    st1 = wall_clock64();
+  }
+#endif
   // ---- fold the 4 waves' partial tiles, epilogue
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -312,22 +449,8 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
   }
   __syncthreads();
   const int nseg = FOLD ? K / p.seg : 1, wps = NW / nseg;              // segments of the row, waves per segment
-  if constexpr (FOLD) {
-    for (int o = tid; o < MT * nseg; o += NT) {
-      const int r = o / nseg, sg = o - r * nseg;
-      float a = 0.f, b = 0.f;
-      for (int w = sg * wps; w < (sg + 1) * wps; ++w) { a += wst[((long)w * MT + r) * 2]; b += wst[((long)w * MT + r) * 2 + 1]; }
-      const float mu = a / (float)p.seg;
-      float var = b / (float)p.seg - mu * mu;
-      var = var > 0.f ? var : 0.f;
-      const float rs = rsqrtf(var + p.eps);
-      rst[(r * 4 + sg) * 2] = mu; rst[(r * 4 + sg) * 2 + 1] = rs;
-      if (p.stats_out && nseg == 1 && blockIdx.x == 0 && prob == 0 && m0 + r < M) {
-        p.stats_out[(m0 + r) * 2] = mu; p.stats_out[(m0 + r) * 2 + 1] = rs;
-      }
-    }
-    __syncthreads();
-  }
+  (void)rst;
+  const int lw = __builtin_ctz(wps);                                   // log2 of the waves per segment
   float sv[SPLIT ? EPI : 1], sg2[SPLIT && ACT == 2 ? EPI : 1];
 #pragma unroll
   for (int e = 0; e < EPI; ++e) {
@@ -338,17 +461,32 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
     if constexpr (FOLD) {
       v = SPLIT ? 0.f : pre_c[0];                                      // (SPLIT: c is added once, by the combining workgroup)
       if constexpr (ACT == 2) g = SPLIT ? 0.f : pre_c[NB - 1];
+      // one unrolled walk over the waves: partial dot products and row statistics of a segment add up over its waves, the
+      // segment closes behind its last wave.  (Until round 6 the statistics were a stage of their own - 128 threads, a second
+      // barrier - and the walk two nested run-time loops: 2.2-3 us of epilogue where the plain form takes 0.7.)
+      float dv = 0.f, dg = 0.f, sa = 0.f, sb = 0.f;
 #pragma unroll
-      for (int sg = 0; sg < 4; ++sg) {
-        if (sg >= nseg) break;
-        const float mu = rst[(r * 4 + sg) * 2], rs = rst[(r * 4 + sg) * 2 + 1];
-        float dv = 0.f, dg = 0.f;
-        for (int w = sg * wps; w < (sg + 1) * wps; ++w) {
-          dv += red[((long)w * MT + r) * CW + c];
-          if constexpr (ACT == 2) dg += red[((long)w * MT + r) * CW + 16 + c];
+      for (int w = 0; w < NW; ++w) {
+        dv += red[((long)w * MT + r) * CW + c];
+        if constexpr (ACT == 2) dg += red[((long)w * MT + r) * CW + 16 + c];
+        sa += wst[((long)w * MT + r) * 2]; sb += wst[((long)w * MT + r) * 2 + 1];
+        if (((w + 1) & (wps - 1)) == 0) {
+          const int sg = w >> lw;
+          const float mu = sa / (float)p.seg;
+          float var = sb / (float)p.seg - mu * mu;
+          var = var > 0.f ? var : 0.f;
+          const float rs = rsqrtf(var + p.eps);
+          const float ps0 = sg == 0 ? pre_s[0][0] : sg == 1 ? pre_s[1][0] : sg == 2 ? pre_s[2][0] : pre_s[3][0];
+          v += rs * (dv - mu * ps0);
+          if constexpr (ACT == 2) {
+            const float ps1 = sg == 0 ? pre_s[0][NB - 1] : sg == 1 ? pre_s[1][NB - 1] : sg == 2 ? pre_s[2][NB - 1] : pre_s[3][NB - 1];
+            g += rs * (dg - mu * ps1);
+          }
+          if (p.stats_out && nseg == 1 && c == 0 && blockIdx.x == 0 && prob == 0 && m < M) {
+            p.stats_out[m * 2] = mu; p.stats_out[m * 2 + 1] = rs;
+          }
+          dv = dg = sa = sb = 0.f;
         }
-        v += rs * (dv - mu * pre_s[sg][0]);
-        if constexpr (ACT == 2) g += rs * (dg - mu * pre_s[sg][NB - 1]);
       }
     } else {
       v = (red[((long)0 * MT + r) * CW + c] + red[((long)1 * MT + r) * CW + c]) +
@@ -367,6 +505,9 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
     if constexpr (SPLIT) { sv[e] = v; if constexpr (ACT == 2) sg2[e] = g; }
     else skinny_epilogue(p, prob, m, n, v, g, ACT, PRE ? &pre[e] : nullptr);
   }
+#ifdef TELL_PROBES
+  if constexpr (!SPLIT) stamp_out();
+#endif
   if constexpr (SPLIT) {
     // ---- publish this slice's partial tile (write-through), take a ticket; the last arrival combines
     const long tile = ((long)(blockIdx.z / ksplit) * gridDim.y + prob) * gridDim.x + blockIdx.x;
@@ -385,7 +526,11 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
       *flag = ((t % (unsigned)ksplit) == (unsigned)ksplit - 1u) ? 1 : 0;
     }
     __syncthreads();
+#ifdef TELL_PROBES
+    if (*flag == 0) { stamp_out(); return; }
+#else
     if (*flag == 0) return;
+#endif
     const float* slabs = p.sk_slab + tile * ksplit * SLAB;
 #pragma unroll
     for (int e = 0; e < EPI; ++e) {
@@ -399,39 +544,96 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
       if (c >= cn || m >= M || n >= N) continue;
       skinny_epilogue(p, prob, m, n, v, g, ACT, PRE ? &pre[e] : nullptr);
     }
+#ifdef TELL_PROBES
+    stamp_out();
+#endif
   }
 }
-template <int RT, int ACT, int U, bool FOLD = false, int NW = 4>
+#ifdef TELL_PROBES
+// probe build: every skinny launch takes the next slot of the caller's stamp buffer (options sk_stamp_ptr = device address,
+// sk_stamp_slots; a slot = SK_STAMP_SLOT u64s); a captured launch keeps its slot, so a graph replay refreshes it.
+constexpr long SK_STAMP_SLOT = (1 + 2048) * 4;
+static unsigned long long* skinny_next_stamp() {
+  static long base_seen = 0, next = 0;
+  const long base = tell_opt(PROBE_SK_STAMP_PTR), slots = tell_opt(PROBE_SK_STAMP_SLOTS);
+  if (base != base_seen) { base_seen = base; next = 0; }
+  if (!base || next >= slots) return nullptr;
+  return reinterpret_cast<unsigned long long*>(base) + (next++) * SK_STAMP_SLOT;
+}
+#define SK_STAMP(a) (a).stamp = skinny_next_stamp()
+#else
+#define SK_STAMP(a)
+#endif
+// LDS of a launch: the reduction buffers; STAGED: or the waves' stage buffers, which they lie over
+template <int RT, int ACT, bool FOLD, int NW, bool STAGED>
+constexpr size_t skinny_smem() {
+  constexpr int MT = RT * 16, NB = ACT == 2 ? 2 : 1;
+  constexpr size_t red = (size_t)NW * MT * 16 * NB * 4 + (FOLD ? (size_t)(NW * MT * 2 + MT * 8) * 4 : 0);
+  constexpr size_t stages = STAGED ? (size_t)NW * (MT + 16 * NB) * 128 : 0;
+  return red > stages ? red : stages;
+}
+// the stages in flight of the STAGED form per row tiles (registers: stages x (MT + 16 NB) / 8 x 4)
+// (0: the launch keeps the direct form - the wave's stage count must be a multiple of the stages in flight)
+static inline int skinny_stage_count(const SkinnyArgs& a, int nw) {
+  return tell_opt(OPT_SK_STAGED) && a.K / a.ksplit % (64 * nw) == 0 ? a.K / a.ksplit / (64 * nw) : 0;
+}
+
+template <int RT, int ACT, int U, bool FOLD = false, int NW = 4, bool STAGED = false>
 static int skinny_mfma_launch(SkinnyArgs a, int n_prob, hipStream_t stream) {
+  if constexpr (!STAGED && (NW == 4)) {
+    const int ns = skinny_stage_count(a, NW);
+    if constexpr (RT >= 8) {
+      if (ns && ns % 2 == 0) return skinny_mfma_launch<RT, ACT, 2, FOLD, NW, true>(a, n_prob, stream);
+    } else {
+      // (128 rows = four row groups = 1024 workgroups, two resident per CU with these registers: a two-stage variant at
+      //  118 registers - four per CU, the whole grid resident at once - measured the same, beam-4 step 489.8 vs 488.4 us)
+      if (ns && ns % 8 == 0) return skinny_mfma_launch<RT, ACT, 8, FOLD, NW, true>(a, n_prob, stream);
+      if (ns && ns % 4 == 0) return skinny_mfma_launch<RT, ACT, 4, FOLD, NW, true>(a, n_prob, stream);
+    }
+  }
   constexpr int MT = RT * 16;
-  constexpr size_t smem = (size_t)NW * MT * 16 * (ACT == 2 ? 2 : 1) * 4 + (FOLD ? (size_t)(NW * MT * 2 + MT * 8) * 4 : 0);
+  constexpr size_t smem = skinny_smem<RT, ACT, FOLD, NW, STAGED>();
+  static_assert(smem <= 160 * 1024, "skinny_linear: LDS");
   const int groups = (a.M + MT - 1) / MT;
   const long tiles = (long)((a.N + 15) / 16) * n_prob * groups;
   a.cn = tiles >= 192 ? 16 : (tiles >= 96 ? 8 : 4);          // at least ~256 workgroups where the layer has the columns
-  auto kern = skinny_mfma_kernel<RT, ACT, U, FOLD, NW>;
+  auto kern = skinny_mfma_kernel<RT, ACT, U, FOLD, NW, false, STAGED>;
   static bool attr_done = false;
   if (!attr_done && smem > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
+  SK_STAMP(a);
   hipLaunchKernelGGL(kern, dim3((a.N + a.cn - 1) / a.cn, n_prob, groups), dim3(64 * NW), smem, stream, a);
   return tell_check_launch("skinny_linear (mfma)");
 }
 // the split form: cn = 16, grid.z = row groups x ksplit
-template <int RT, int ACT, int U, bool FOLD>
+template <int RT, int ACT, int U, bool FOLD, bool STAGED = false>
 static int skinny_split_launch(SkinnyArgs a, hipStream_t stream) {
+  if constexpr (!STAGED) {
+    const int ns = skinny_stage_count(a, 4);
+    if (ns && ns % 8 == 0) return skinny_split_launch<RT, ACT, 8, FOLD, true>(a, stream);
+    if (ns && ns % 4 == 0) return skinny_split_launch<RT, ACT, 4, FOLD, true>(a, stream);
+  }
   constexpr int MT = RT * 16;
-  constexpr size_t smem = (size_t)4 * MT * 16 * (ACT == 2 ? 2 : 1) * 4 + (FOLD ? (size_t)(4 * MT * 2 + MT * 8) * 4 : 0);
+  constexpr size_t smem = skinny_smem<RT, ACT, FOLD, 4, STAGED>();
   const int groups = (a.M + MT - 1) / MT;
-  auto kern = skinny_mfma_kernel<RT, ACT, U, FOLD, 4, true>;
+  auto kern = skinny_mfma_kernel<RT, ACT, U, FOLD, 4, true, STAGED>;
   static bool attr_done = false;
   if (!attr_done && smem > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
+  SK_STAMP(a);
   hipLaunchKernelGGL(kern, dim3((a.N + a.cn - 1) / a.cn, 1, groups * a.ksplit), dim3(256), smem, stream, a);
   return tell_check_launch("skinny_linear (mfma, split reduction)");
 }
+// (Warming the NEXT launch's weights from inside a launch - a dword per line of the successor's row blocks, read by the
+// workgroups whose dispatch index puts them on the XCD that will want them (workgroup i runs on XCD (i + 6) % 8, launch after
+// launch: tools/probes/skinny_stamps.py) - was built and measured, tools/probes/skinny_cold.py: a launch whose weights are
+// cold costs 0.9-1.9 us more than with them in its L2 (linear2 3.7 -> 4.7 us, fc1 3.7 -> 5.1, fc2 7.6 -> 9.2 at 32 rows),
+// but every launch warming its successor made the chain SLOWER: 4.65 -> 5.3, 5.1 -> 5.8, 9.1 -> 9.5 us per launch, greedy
+// step 378 -> 395 us, beam 4 531 -> 545; 64-byte instead of 128-byte strides the same.  Removed.)
 template <int RT, int U>
 static int skinny_split_dispatch(const SkinnyArgs& a, int act, hipStream_t stream, bool fold) {
   if (fold) return skinny_split_launch<RT, 0, U, true>(a, stream);                 // (context_fc behind its LayerNorms)
@@ -561,6 +763,7 @@ extern "C" int tell_skinny_linear(int n_prob, const void* const* in, long ld_in,
   a.out2 = static_cast<uint16_t*>(out2); a.ld_out2 = ld_out2; a.out2_from = out2_from; a.eps = eps; a.scale = scale; a.M = M; a.N = N; a.K = K;
   a.seg = seg > 0 ? seg : K; a.out_f32 = out_f32; a.cn = 16;
   a.ksplit = 1; a.sk_slab = nullptr; a.sk_cnt = nullptr;
+
   if (pro == 1 || pro == 2) {
     TELL_REQUIRE((pro == 1 ? K : seg) % 1024 == 0 && (pro == 1 ? K : seg) <= 4096, "skinny_linear: LayerNorm over 1024 .. 4096 columns");
     TELL_REQUIRE(ws, "skinny_linear: the LayerNorm prologue needs ws [M,K] bf16");
@@ -604,8 +807,13 @@ extern "C" int tell_skinny_linear(int n_prob, const void* const* in, long ld_in,
     }
     a.cn = 16;
   }
-  const int rt_env = (int)tell_opt(OPT_SK_ROWS);          // A/B aid: 32 / 128
-  const bool tall = rt_env ? rt_env == 128 : (M > 64 && (long)((N + 15) / 16) * n_prob * ((M + 127) / 128) >= 192);
+  // Rows per workgroup: 32.  (Rounds 3-5, direct fragment loads: 128-row workgroups wherever they alone filled the chip - the
+  // weight fragments of a column tile loaded once for 128 rows instead of four times.  With the operands staged through LDS
+  // the activation rows are cheap and the 128-row workgroup - 2 stages of 18 loads in flight, a 128 x 16 reduction through
+  // LDS, 8 outputs per thread - loses everywhere: beam-4 step 512.5 us with the old rule, 486.9 with 32 rows everywhere,
+  // 686.9 with 128 everywhere; 128 greedy rows 666 -> 642 us; 64-row workgroups (4 stages of 10 loads) above 32 rows: beam 4
+  // 491.8 -> 570.8 us, 128 greedy rows 643 -> 722 - not kept.  Option sk_rows = 128 keeps the tall form reachable.)
+  const bool tall = tell_opt(OPT_SK_ROWS) == 128 && M > 64;
   if (tall) {
     // option sk_tall_waves = 8: the 128-row workgroup as 8 waves x K / 8 (both batches of a wave's loads in flight at once,
     // twice the waves per CU to hide them) instead of 4 x K / 4.  MEASURED (round 6): alone q-proj x4 15.6 -> 15.0 us, out-proj

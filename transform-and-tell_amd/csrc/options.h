@@ -48,16 +48,19 @@
   X(OPT_ARGMAX_REGS, "argmax_regs", 1)                                                                                  \
   X(OPT_ADAM_VAR, "adam_var", -1)          /* -1: the built-in default shape */                                         \
   X(OPT_ADAM_GRID, "adam_grid", 4096)                                                                                   \
-  X(OPT_SK_ROWS, "sk_rows", 0)             /* 32 / 128: rows per skinny-linear workgroup everywhere */            \
-  X(OPT_SK_SPLIT, "sk_split", 1)           /* 0: never share a skinny linear's reduction between workgroups */            \
-  X(OPT_SK_TALL_WAVES, "sk_tall_waves", 4) /* 8: the 128-row skinny workgroup as 8 waves x K / 8 */
+  X(OPT_SK_ROWS, "sk_rows", 0)             /* 128: 128-row skinny-linear workgroups above 64 rows (default: 32 rows everywhere) */ \
+  X(OPT_SK_SPLIT, "sk_split", 0)           /* 1 / 2: share a long reduction of a skinny linear between 4 / 2 workgroups (split_ws) */ \
+  X(OPT_SK_TALL_WAVES, "sk_tall_waves", 4) /* 8: the 128-row skinny workgroup as 8 waves x K / 8 */                   \
+  X(OPT_SK_STAGED, "sk_staged", 1)         /* 0: the skinny linears load their MFMA fragments straight from memory */
 
 // wrong-result timing probes: probe build only
 #define TELL_PROBE_LIST(X)                                                                                              \
   X(PROBE_Q4_ABL, "q4_abl", 0)             /* 1 no epilogue, 2 no global stores, 3 s_memtime stamps into aux */        \
   X(PROBE_Q4E_VAR, "q4e_var", -1)          /* >= 0: the stamped statement */                                            \
   X(PROBE_PP2_ABL, "pp2_abl", 0)                                                                                        \
-  X(PROBE_DCB_ABL, "dcb_abl", 0)
+  X(PROBE_DCB_ABL, "dcb_abl", 0)                                                                                        \
+  X(PROBE_SK_STAMP_PTR, "sk_stamp_ptr", 0) /* device address of the skinny linears' per-workgroup time stamps */       \
+  X(PROBE_SK_STAMP_SLOTS, "sk_stamp_slots", 0)
 
 enum TellOpt {
 #define TELL_X(e, k, d) e,
