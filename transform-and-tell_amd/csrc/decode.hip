@@ -1256,13 +1256,18 @@ extern "C" int tell_attn_decode(int n_ctx, const void* const* q, const long* q_s
 // Round 6, second half.  PMC showed the VALU kernel above instruction-bound (52 instructions per key and lane with one
 // hypothesis, 122 with four, for 32 bytes of cache; memory latency 770-1050 cycles per request, hidden).  The generation loop
 // owns the layout of its cache, so it can store what the matrix cores want to read:
-//   kc   [Bs, H, Sp, 64]  keys, head-major; rows S and S + 1 are the learned bias_k row and the zero row (multi_head.py:355-364,
-//                         :416-421) - virtual keys are ordinary keys here; rows up to Sp (a multiple of 32) are zero
-//   vt   [Bs, H, 64, Sp]  values TRANSPOSED (a lane's 16 bytes = 8 keys of one dimension: the A operand of O^T = V^T P^T), keys
-//                         permuted inside every block of 32: stored position 8 g + j holds key 4 g + j (j < 4) or 16 + 4 g + j - 4
-//                         (j >= 4) - exactly the 8 keys whose scores the QK^T accumulators leave in the lane of k-group g, so
-//                         the probabilities go from the accumulator of one MFMA into the B operand of the next without
-//                         leaving their lane
+//   kc   [Bs, H, Sp / 16, 2, 64, 8]  keys; key rows S and S + 1 are the learned bias_k row and the zero row (multi_head.py:355-364,
+//                         :416-421) - virtual keys are ordinary keys here; keys up to Sp (a multiple of 32) are zero.  FRAGMENT
+//                         ORDER: per tile of 16 keys and half c of the head width, lane l's 16 bytes = elements c * 32 + (l >> 4) * 8
+//                         .. + 7 of key l & 15 - the A operand of the score MFMA, one contiguous KB per wave load
+//   vt   [Bs, H, Sp / 32, 4, 64, 8]  values TRANSPOSED (a lane's 16 bytes = 8 keys of one dimension: the A operand of O^T = V^T
+//                         P^T), fragment order as well: per block of 32 keys and tile rt of 16 dimensions, lane l holds dimension
+//                         rt * 16 + (l & 15) of the keys 4 g + j (j < 4) and 16 + 4 g + j - 4 (j >= 4), g = l >> 4 - exactly the 8 keys
+//                         whose scores the QK^T accumulators leave in the lane of k-group g, so the probabilities go from the
+//                         accumulator of one MFMA into the B operand of the next without leaving their lane
+//                         (first version: kc [Bs, H, Sp, 64] / vt [Bs, H, 64, Sp] row-major - every quarter-wave of a fragment
+//                         load then touches 16 rows x 16 bytes, the address unit delivers 16 bytes per lookup instead of 64:
+//                         the skinny linears' finding, tools/probes/skinny_stamps.py; 22.8 us per launch at beam 4)
 //   mask [Bs, Sp] uint8   1 = masked (padding of the context, and everything past S + 1)
 // Per 32 keys a wave issues 4 + 4 sixteen-byte loads per lane, 4 MFMAs for the scores (A = K tile, B = the hypotheses as
 // columns: up to 16 of them for the price of one), ~60 VALU instructions of online softmax in the exp2 domain on 8 scores per
@@ -1289,8 +1294,9 @@ __global__ __launch_bounds__(256) void attn_decode_packed_kernel(AttnPkArgs g) {
     qf[c] = sk_u4{0u, 0u, 0u, 0u};
     if (lr < nq) qf[c] = *reinterpret_cast<const sk_u4*>(p.q + (long)(b0 + lr) * p.q_sb + h * 64 + c * 32 + lg * 8);
   }
-  const uint16_t* kbase = p.kc + (long)(bs * g.H + h) * Sp * 64 + (long)lr * 64 + lg * 8;
-  const uint16_t* vbase = p.vt + (long)(bs * g.H + h) * 64 * Sp + (long)lr * Sp + lg * 8;
+  // both caches in fragment order (layouts above): every 16-byte wave load below is one contiguous KB
+  const uint16_t* kbase = p.kc + (long)(bs * g.H + h) * Sp * 64 + lane * 8;
+  const uint16_t* vbase = p.vt + (long)(bs * g.H + h) * 64 * Sp + lane * 8;
   const uint8_t* mbase = p.mask + (long)bs * Sp + lg * 4;
   c4 acc_o[4];
 #pragma unroll
@@ -1301,16 +1307,16 @@ __global__ __launch_bounds__(256) void attn_decode_packed_kernel(AttnPkArgs g) {
   sk_u4 kf[2][2], vf[4];
   uint32_t mw[2];
   auto load = [&](int blk) __attribute__((always_inline)) {
-    const uint16_t* kp = kbase + (long)blk * 32 * 64;
-    const uint16_t* vp = vbase + blk * 32;
+    const uint16_t* kp = kbase + (long)blk * 2048;
+    const uint16_t* vp = vbase + (long)blk * 2048;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      kf[t][0] = *reinterpret_cast<const sk_u4*>(kp + t * 16 * 64);
-      kf[t][1] = *reinterpret_cast<const sk_u4*>(kp + t * 16 * 64 + 32);
+      kf[t][0] = *reinterpret_cast<const sk_u4*>(kp + t * 1024);
+      kf[t][1] = *reinterpret_cast<const sk_u4*>(kp + t * 1024 + 512);
       mw[t] = *reinterpret_cast<const uint32_t*>(mbase + blk * 32 + t * 16);
     }
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) vf[rt] = *reinterpret_cast<const sk_u4*>(vp + (long)rt * 16 * Sp);
+    for (int rt = 0; rt < 4; ++rt) vf[rt] = *reinterpret_cast<const sk_u4*>(vp + rt * 512);
   };
   if (wave < nblk) load(wave);
   for (int blk = wave; blk < nblk; blk += 4) {

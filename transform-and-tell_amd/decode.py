@@ -35,6 +35,7 @@ KV_HEAD_MAJOR = os.environ.get('TELL_KV_HEAD_MAJOR', '1') != '0'
 # head-major cache
 KV_PACKED = os.environ.get('TELL_KV_PACKED', '1') != '0'
 ENABLED_LAYER_PACKED = os.environ.get('TELL_KV_PACKED_LAYERS', '1') != '0'
+PACKED_MIN_HYP = int(os.environ.get('TELL_PACKED_MIN_HYP', '2'))   # hypotheses per sample from which the packed cache is taken
 # the per-token bookkeeping launch (tell_greedy_update / tell_beam_update) as the LAST launch of the captured step: the host's
 # part of a decode step is one graph replay.  0 = a host-side launch behind every replay (A/B aid)
 IN_GRAPH_BOOK = os.environ.get('TELL_DECODE_BOOK_IN_GRAPH', '1') != '0'
@@ -306,36 +307,43 @@ def head_step(x2, cutoffs, emb0, class_proj, tails, topk=0):
 
 
 class PackedKV:
-    """Projected K / V of one (layer, context) in the layout tell_attn_decode_packed reads (csrc/decode.hip): kc [Bc, H, Sp, 64]
-    with the bias_k row and the zero row as keys S and S + 1, vt [Bc, H, 64, Sp] transposed with the keys of every block of 32
-    permuted for the matrix cores, mask [Bc, Sp] uint8 (1 = masked).  Built once per stepper (models/transformer.py), refilled
-    per caption batch by `fill`."""
+    """Projected K / V of one (layer, context) in the layout tell_attn_decode_packed reads (csrc/decode.hip): the bias_k / bias_v
+    row and the zero row are keys S and S + 1, the key axis is padded to Sp % 32 == 0, and both operands sit in MFMA FRAGMENT
+    ORDER - a wave-wide 16-byte load reads one contiguous KB: kc [Bc, H, Sp / 16 key tiles, 2 halves of the head width, 64
+    lanes, 8] (lane l = key l & 15 of the tile, elements half * 32 + (l >> 4) * 8 ..), vt [Bc, H, Sp / 32 blocks, 4 row tiles
+    of the head width, 64 lanes, 8] (lane l = dimension tile * 16 + (l & 15), the block's keys 4 g + r | 16 + 4 g + r of k-group
+    g = l >> 4 - the order the probabilities leave the score tiles in); mask [Bc, Sp] uint8 (1 = masked).  Built once per
+    stepper (models/transformer.py), refilled per caption batch by `fill` (one permuting copy per operand and caption batch -
+    against a hundred decode steps that read it)."""
 
     def __init__(self, mod, S, Bc, device):
         H = mod.num_heads
         self.S, self.Bc, self.H = int(S), int(Bc), H
         self.Sp = -(-(self.S + 2) // 32) * 32
         bf = dict(dtype=torch.bfloat16, device=device)
-        self.kc = torch.zeros(Bc, H, self.Sp, 64, **bf)
-        self.vnat = torch.zeros(Bc, H, self.Sp, 64, **bf)               # staging: values in key order
-        self.vt = torch.zeros(Bc, H, 64, self.Sp, **bf)
+        self.knat = torch.zeros(Bc, H, self.Sp, 64, **bf)               # staging: keys / values in key order
+        self.vnat = torch.zeros(Bc, H, self.Sp, 64, **bf)
+        self.kc = torch.zeros(Bc, H, self.Sp * 64, **bf)
+        self.vt = torch.zeros(Bc, H, 64 * self.Sp, **bf)
         self.mask = torch.ones(Bc, self.Sp, dtype=torch.uint8, device=device)
         self.mask[:, self.S:self.S + 2] = 0                             # the two virtual keys are never masked
-        self.kc[:, :, self.S] = ops._bias_row(mod.bias_k, torch.bfloat16).view(H, 64)
+        self.knat[:, :, self.S] = ops._bias_row(mod.bias_k, torch.bfloat16).view(H, 64)
         self.vnat[:, :, self.S] = ops._bias_row(mod.bias_v, torch.bfloat16).view(H, 64)
         self.shape = (self.S, Bc, H * 64)                               # (what the [S, B, E] tensors it replaces answer)
 
     def fill(self, k, v, mask):
         S, Bc, H, nb = self.S, self.Bc, self.H, self.Sp // 32
         if S:
-            self.kc[:, :, :S].copy_(k.view(S, Bc, H, 64).permute(1, 2, 0, 3))
+            self.knat[:, :, :S].copy_(k.view(S, Bc, H, 64).permute(1, 2, 0, 3))
             self.vnat[:, :, :S].copy_(v.view(S, Bc, H, 64).permute(1, 2, 0, 3))
             if mask is not None:
                 self.mask[:, :S].copy_(mask)
             else:
                 self.mask[:, :S].zero_()
-        # key (block, half, g, r) of the natural order -> stored position (block, g, half, r), dimension-major
-        self.vt.view(Bc, H, 64, nb, 4, 2, 4).copy_(self.vnat.view(Bc, H, nb, 2, 4, 4, 64).permute(0, 1, 6, 2, 4, 3, 5))
+        # keys: [tile, key lr, half c, k-group lg, 8] -> [tile, c, lg, lr, 8]
+        self.kc.view(Bc, H, 2 * nb, 2, 4, 16, 8).copy_(self.knat.view(Bc, H, 2 * nb, 16, 2, 4, 8).permute(0, 1, 2, 4, 5, 3, 6))
+        # values: key (block, half, g, r) x dimension (tile rt, lr) -> [block, rt, g, lr, (half, r)]
+        self.vt.view(Bc, H, nb, 4, 4, 16, 2, 4).copy_(self.vnat.view(Bc, H, nb, 2, 4, 4, 4, 16).permute(0, 1, 2, 6, 4, 7, 3, 5))
 
 
 def layer_path_takes_packed(dec):

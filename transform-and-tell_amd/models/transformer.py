@@ -605,7 +605,7 @@ class CaptionModel(Model):
             # (measured, B = 32: packed 28.6 -> 22.6-24.9 us per launch at beam 4; with ONE hypothesis per sample the VALU kernel on
             #  the head-major cache is the faster one, 18.7 against 20.4 us - packed from two hypotheses per sample on)
             n_cached = kv[0][names[0]][0].shape[1] if kv[0][names[0]][0].dim() == 3 else B
-            several = B >= 2 * max(int(n_cached), 1)
+            several = B >= _dec.PACKED_MIN_HYP * max(int(n_cached), 1)
             layer_pk = (B > _dec.MAX_ROWS and dtype == torch.bfloat16 and bool(h['state'].get('_ring')) and
                         _dec.layer_path_takes_packed(dec))     # (the layer-by-layer step above MAX_ROWS rows)
             if _dec.KV_PACKED and several and (hm or layer_pk):
