@@ -586,7 +586,11 @@ static int skinny_mfma_launch(SkinnyArgs a, int n_prob, hipStream_t stream) {
       if (ns && ns % 2 == 0) return skinny_mfma_launch<RT, ACT, 2, FOLD, NW, true>(a, n_prob, stream);
     } else {
       // (128 rows = four row groups = 1024 workgroups, two resident per CU with these registers: a two-stage variant at
-      //  118 registers - four per CU, the whole grid resident at once - measured the same, beam-4 step 489.8 vs 488.4 us)
+      //  118 registers - four per CU, the whole grid resident at once - measured the same, beam-4 step 489.8 vs 488.4 us.  So did
+  //  64 / 32 COLUMNS per workgroup where a launch has 1024 / 512 tiles - the activation rows staged once for four column
+  //  tiles, 256 workgroups, half the bytes per CU: with two stages in flight 479.9 us against 475.7, with all four 488.9
+  //  against 476.6; 128 greedy rows 642-645 against 633.  Not kept: what makes a 128-row launch take 9-12 us where 32 rows
+  //  take 5-7 is neither residency nor the bytes through a CU nor the number of dependent round trips.)
       if (ns && ns % 8 == 0) return skinny_mfma_launch<RT, ACT, 8, FOLD, NW, true>(a, n_prob, stream);
       if (ns && ns % 4 == 0) return skinny_mfma_launch<RT, ACT, 4, FOLD, NW, true>(a, n_prob, stream);
     }
@@ -1529,15 +1533,14 @@ __global__ __launch_bounds__(64) void beam_update_kernel(const int* __restrict__
   // the ancestor table of the DynamicConv rings (dynconv_step_kernel): this sample's K columns, before the update
   if (back)
     for (int e = t; e < n_back * K; e += 64) s_back[e] = back[(long)(e / K) * M + b * K + e % K];
-  if (counter && b == 0 && t == 0) *counter = step;            // position offset of the NEXT replay of a captured step: (step + 1) - 1
   // the histories of the sample's K hypotheses into LDS FIRST: they do not depend on the selection below, whose K rounds of
   // shuffles then run under these loads (round 6: the launch was a chain of four dependent memory round trips + two loops with
   // an integer division per element; 15 us at K = 4)
+  // (whole rows, L and L - 1 columns: the trip counts must not hang on `step`, a value this launch first has to load - with
+  //  step + 2 columns the history loads queued behind that round trip; 15.7 -> 13.1 us)
   const int Lp = L - 1, nc = step + 2 < L ? step + 2 : L, ncp = step + 1 < Lp ? step + 1 : Lp;
-  for (int r = 0; r < K; ++r) {
-    for (int c = t; c < nc; c += 64) s_seq[r * L + c] = seqs[(long)b * K * L + r * L + c];
-    for (int c = t; c < ncp; c += 64) s_lp[r * Lp + c] = lps[(long)b * K * Lp + r * Lp + c];
-  }
+  for (int c = t; c < K * L; c += 64) s_seq[c] = seqs[(long)b * K * L + c];
+  for (int c = t; c < K * Lp; c += 64) s_lp[c] = lps[(long)b * K * Lp + c];
   const int j = t / K, m = t % K;
   float score = -INFINITY;
   int token = pad;
@@ -1594,6 +1597,7 @@ __global__ __launch_bounds__(64) void beam_update_kernel(const int* __restrict__
       const int j = e / K, r = e % K;
       back[(long)j * M + b * K + r] = j == 0 ? b * K + s_parent[r] : s_back[(j - 1) * K + s_parent[r]];
     }
+  if (counter && b == 0 && t == 0) *counter = step;            // position offset of the NEXT replay of a captured step: (step + 1) - 1
 }
 // tk int32 / lp fp32 [B,K,K] (the K best continuations of every hypothesis, best first), cum fp32 [B,K], finished uint8
 // [B,K], seqs int64 [B,K,L], lps fp32 [B,K,L-1] - all updated in place -, cur int64 [B*K] (next input tokens), rows
