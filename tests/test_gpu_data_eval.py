@@ -178,3 +178,42 @@ def test_evaluate_forward_through_lanes_equals_forward_batch_by_batch(beam):
         assert (model.n_samples, model.n_batches, dict(model.sample_history)) == want
     finally:
         tell_amd.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize('beam', [1, 4])
+def test_several_decode_steps_per_graph_replay_equal_one_step_per_replay(beam):
+    """From its first all-finished test on, a generation loop replays ONE graph that holds `check_every` consecutive decode
+    steps (CaptionModel._decode_stepper: step.multi - the bookkeeping launch that ends a recorded step leaves the next
+    step's position offset in the device counter, so recorded steps chain on the device as single replays do).  Ids and
+    log-probabilities must equal the one-step-per-replay loop bit for bit, over two generations of the same stepper (the
+    second replays every graph from its first token on), and the multi-step graph must really have been recorded."""
+    import tell_amd
+    from tell_amd.build import build_model
+    from tell_amd.data import synthetic_batch
+    from tell_amd.models import transformer as tr
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    keep = tr.MULTI_STEP_GRAPHS
+    try:
+        torch.manual_seed(0)
+        model = build_model('faces_objects').to(DEV).eval()       # (full size: the step with in-graph bookkeeping; random
+        batches = [synthetic_batch(4, 64, 9, True, seed=71 + i, device=DEV) for i in range(2)]   # weights never emit </s>: 100 steps)
+
+        def clone(b):
+            return {k: (dict(v) if isinstance(v, dict) else v.clone()) for k, v in b.items()}
+        tr.MULTI_STEP_GRAPHS = False
+        single = [model.generate(**clone(b), beam_size=beam) for b in batches]
+        torch.cuda.synchronize()
+        model.__dict__['_decode_graphs'].clear()
+        tr.MULTI_STEP_GRAPHS = True
+        for rep in range(2):
+            for i, b in enumerate(batches):
+                out = model.generate(**clone(b), beam_size=beam)
+                torch.cuda.synchronize()
+                assert torch.equal(out['gen_ids'], single[i]['gen_ids']), (rep, i)
+                assert torch.equal(out['log_probs'], single[i]['log_probs']), (rep, i)
+        recorded = [k for h in model.__dict__['_decode_graphs'].values() for k in h if isinstance(k, tuple) and k[:1] == ('multi',) and len(k) == 2]
+        assert recorded and all(h[k] for h in model.__dict__['_decode_graphs'].values() for k in recorded if k in h), \
+            [h.get('multi_error') for h in model.__dict__['_decode_graphs'].values()]
+    finally:
+        tr.MULTI_STEP_GRAPHS = keep
+        tell_amd.set_compute_dtype(torch.float32)

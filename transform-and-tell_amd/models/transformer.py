@@ -10,6 +10,9 @@ import torch.nn as nn
 from .. import graphs, ops, streams
 from ..common.registrable import Registrable
 
+# decode steps per graph replay once a generation loop is past its first all-finished test (CaptionModel._decode_stepper: multi)
+MULTI_STEP_GRAPHS = os.environ.get('TELL_MULTI_STEP_GRAPHS', '1') != '0'
+
 
 _OVERLAP = os.environ.get('TELL_ENCODER_OVERLAP', '1') != '0'
 # where the PREFETCHED ResNet pass of the next batch is enqueued: 'own' = its side stream (three streams share the chip),
@@ -511,12 +514,17 @@ class CaptionModel(Model):
                 tok, lp = out
                 ops.call('tell_greedy_update', tok.reshape(B), lp.reshape(B), fin8, ids, ids.stride(0), lps, lps.stride(0),
                          done_step, step.cur, B, int(i), int(eos), inv_temp, step.counter_out, step_dev)
-        for i in range(gen_len if fused else 0):
+        i = 0
+        while fused and i < gen_len:
             # (the bookkeeping launch of step i - 1 left the position offset of step i in the device counter: no fill launch;
-            #  the host's part of a step is ONE graph replay)
-            step(i, None, counter_set=i > 0, post=book)
-            yield i
-            if (i + 1) % check_every == 0 and bool(fin8.all()):
+            #  the host's part of a step is ONE graph replay - and from the first all-finished test on, of `check_every` steps)
+            n = check_every if (i >= check_every and i % check_every == 0 and i + check_every <= gen_len) else 1
+            if n == 1 or not step.multi(i, n, book):
+                n = 1
+                step(i, None, counter_set=i > 0, post=book)
+            i += n
+            yield i - 1
+            if i % check_every == 0 and bool(fin8.all()):
                 break
         for i in range(0 if fused else gen_len):
             tok, lp = step(i, cur)
@@ -665,6 +673,9 @@ class CaptionModel(Model):
                 return eager(i, post)                             # warm step(s) before the capture, or fallback
             if h['graph'] is None:                                # i == 1: the host position state is 1 now
                 inside = post is not None and h['ig']
+                # the host's part of the step's position state as THIS capture sees it (step.multi records further steps
+                # with the same constants: the device counter is what moves a recorded step along)
+                h['host_ints'] = {k_: v_ for k_, v_ in h['state'].items() if isinstance(v_, int) and not isinstance(v_, bool)}
                 try:
                     g = torch.cuda.CUDAGraph()
                     try:
@@ -698,6 +709,44 @@ class CaptionModel(Model):
                 post(h['out'], i, None)
             return h['out']
 
+        def multi(i, n, post):
+            """Steps i .. i + n - 1 as ONE graph replay (n consecutive steps recorded into one graph: the bookkeeping launch
+            that ends a recorded step leaves the position offset of the next one in the device counter, so the steps chain
+            on the device exactly as n single replays would - what goes is the per-replay cost between them, ~25 us of a
+            360-490 us step).  Needs the single-step graph with in-graph bookkeeping (captured at step 1) and the counter
+            already set by step i - 1's bookkeeping launch.  -> False: not available, issue the steps one by one."""
+            if not h.get('graph') or not h.get('graph_has_post') or post is None or i < 2 or not MULTI_STEP_GRAPHS:
+                return False
+            key = ('multi', int(n))
+            g = h.get(key)
+            if g is None:
+                saved = {k_: h['state'].get(k_) for k_ in h['host_ints']}
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    try:
+                        ops.call('tell_set_rng_step_ptr', c_cur)
+                        ops.call('tell_set_pos_step_ptr', c_cur)
+                        ops.call('tell_set_pos_next_ptr', c_next)
+                        with graphs.no_gc(), ops.hip.tile_slots() as held, torch.cuda.graph(g):
+                            with ops.hip.bound_stream():
+                                for j in range(int(n)):
+                                    h['state'].update(h['host_ints'])   # the constants of the single-step capture
+                                    post(run(), i + j, c_cur)
+                        h[key + ('slots',)] = held
+                    finally:
+                        ops.call('tell_set_rng_step_ptr', None)
+                        ops.call('tell_set_pos_step_ptr', None)
+                        ops.call('tell_set_pos_next_ptr', None)
+                        h['state'].update(saved)
+                    h[key] = g
+                except Exception as exc:                          # noqa: BLE001 - keep the single-step replays
+                    h[key], h['multi_error'] = False, repr(exc)
+                    return False
+            if g is False:
+                return False
+            g.replay()
+            return True
+
         def book(kind, make):
             if kind not in h['book']:
                 h['book'][kind] = make()
@@ -717,6 +766,7 @@ class CaptionModel(Model):
             for s in bufs:
                 s.copy_(s.index_select(1, rows))
         step.reorder = reorder
+        step.multi = multi
         step.cur = h['cur']
         step.book = book
         step.counter_out = c_out                                  # (base 1: the offset of step i is i - 1)
@@ -778,16 +828,21 @@ class CaptionModel(Model):
                 tk, lp = out
                 ops.call('tell_beam_update', tk, lp, cum, fin8, seqs, lps, step.cur, rows, B, K, gen_len + 1, int(i), int(pad),
                          int(eos), inv_temp, step.back, step.back.shape[0] if ring else 0, step.counter_out, step_dev)
-            for i in range(gen_len):
+            i = 0
+            while i < gen_len:
                 # (time-ordered buffers - fp32 parity mode: the bookkeeping stays a host-side launch and one more launch
                 #  re-orders every layer's rows by parent)
-                out = step(i, None, counter_set=i > 0, post=book if ring else None)
-                if not ring:
-                    book(out, i, None)
-                    step.reorder(rows, K)
-                yield i
-                if (i + 1) % check_every == 0 and bool(fin8.all()):
-                    n_steps = i + 1
+                n = check_every if (ring and i >= check_every and i % check_every == 0 and i + check_every <= gen_len) else 1
+                if n == 1 or not step.multi(i, n, book):
+                    n = 1
+                    out = step(i, None, counter_set=i > 0, post=book if ring else None)
+                    if not ring:
+                        book(out, i, None)
+                        step.reorder(rows, K)
+                i += n
+                yield i - 1
+                if i % check_every == 0 and bool(fin8.all()):
+                    n_steps = i
                     break
         for i in range(0 if fused else gen_len):
             # each hypothesis contributes its own K best tokens (the best K of K x V always lie among them)
