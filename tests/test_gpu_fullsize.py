@@ -431,13 +431,14 @@ def test_full_size_beam4_matches_oracle_definition_fp32():
             assert torch.allclose(lp.sum(1).cpu(), ref_score, rtol=1e-4, atol=5e-4), (lp.sum(1), ref_score)
 
 
-@pytest.mark.parametrize('kind,beams', [('faces_objects', 1), ('faces_objects', 4), ('faces_objects', 16), ('flattened', 4)])
+@pytest.mark.parametrize('kind,beams', [('faces_objects', 1), ('faces_objects', 4), ('faces_objects', 16), ('faces_objects', 56),
+                                        ('flattened', 4)])
 def test_fused_decode_step_matches_layer_by_layer_step_and_fp32(kind, beams):
     """The generation step as weight-streaming launches (tell_amd/decode.py, csrc/decode.hip: skinny linears with
     LayerNorm prologues, DynamicConv step, grouped one-query attention) against (a) the layer-by-layer bf16 step it
     replaces and (b) the fp32 full-sequence decoder (itself bit-exact-greedy against the oracle above), teacher-forced
-    on the oracle's tokens.  beams > 1: the hypotheses of a sample (rows b*beams + j) share its K/V cache; M = 64 rows
-    (beams = 16) runs the 128-row kernel geometry."""
+    on the oracle's tokens.  beams > 1: the hypotheses of a sample (rows b*beams + j) share its K/V cache; beams = 16 / 56:
+    64 / 224 rows = two / seven 32-row groups per column tile (the step takes up to decode.MAX_ROWS = 256 rows)."""
     import tell_amd
     from tell_amd import decode
     from tell_amd.build import build_decoder
@@ -459,7 +460,7 @@ def test_fused_decode_step_matches_layer_by_layer_step_and_fp32(kind, beams):
     dctx = _to_dev(ctx, torch.bfloat16)
     outs = {}
     prev, prev_rows = decode.ENABLED, decode.MAX_ROWS
-    decode.MAX_ROWS = 128
+    decode.MAX_ROWS = 256
     try:
         with torch.no_grad():
             kv = dec.project_contexts(dctx)
@@ -494,6 +495,7 @@ def test_layer_by_layer_decode_step_above_128_rows_matches_fp32():
     from tell_amd import decode
     from tell_amd.build import build_decoder
     kind, beams, STEPS = 'faces_objects', 48, 6
+    prev_rows, decode.MAX_ROWS = decode.MAX_ROWS, 128          # (the default is 256 since round 6: pin the layer path for 192 rows)
     o = _oracle(kind)
     ctx, ids, _ = o['inputs']
     seq = ids[:, :STEPS].to(DEV)
@@ -532,6 +534,7 @@ def test_layer_by_layer_decode_step_above_128_rows_matches_fp32():
     assert err < BF16_OUT, err
     r = out.view(B, beams, STEPS, -1)
     assert torch.equal(r, r[:, :1].expand_as(r))
+    decode.MAX_ROWS = prev_rows
     joined = ' '.join(names)
     assert 'dynconv_step_kernel' in joined and 'attn_decode_kernel' in joined, joined
 

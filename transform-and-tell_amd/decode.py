@@ -18,9 +18,11 @@ from . import hip as hip_mod
 from .hip import call
 
 ENABLED = os.environ.get('TELL_DECODE_FUSED', '1') != '0'       # A/B aid: 0 = the layer-by-layer step
-# rows (batch x beam) up to which the weight-streaming step is used (measured at 32 and 128 rows: 0.51 / 1.07 ms per step
-# against 0.83 / 1.29 ms layer by layer); larger batches are GEMM-shaped again
-MAX_ROWS = int(os.environ.get('TELL_DECODE_ROWS', '128'))
+# rows (batch x beam) up to which the weight-streaming step is used (round 3, at 32 and 128 rows: 0.51 / 1.07 ms per step
+# against 0.83 / 1.29 ms layer by layer); larger batches are GEMM-shaped again.  Round 6 (operands staged through LDS,
+# 32-row workgroups for any row count): 256 rows 804 -> 752 us (beam 4 at 64 captions per batch), 1169 -> 1081 us (256 greedy
+# rows); 512 rows 1042 -> 1266 us - the limit is 256 now.
+MAX_ROWS = int(os.environ.get('TELL_DECODE_ROWS', '256'))
 
 
 # LayerNorms of the step FOLDED into their consumers (round 5): the producer of a pre-norm `residual + branch` leaves it in
