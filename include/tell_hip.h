@@ -367,10 +367,13 @@ int tell_dynconv_step(const void* x, void* hist, const void* wt, void* y, int M,
  * cache), mask[c] [B / beams, S[c]] uint8 or NULL, bias_k[c] / bias_v[c] [H*64] (:355-364) or NULL, has_zero: the zero
  * row (:416-421).  bf16, q pre-scaled, S <= 2048 (S = 0 allowed with a bias / zero row: the empty context :349-374). */
 /* The same attention over a PACKED cache, on the matrix cores (the generation loop owns its cache's layout):
- *   kc [B/beams, H, Sp, 64] bf16 keys, head-major; the learned bias_k row and the zero row (multi_head.py:355-364, :416-421)
- *      are stored as keys S and S + 1, rows up to Sp (a multiple of 32) are zero;
- *   vt [B/beams, H, 64, Sp] bf16 values TRANSPOSED, keys permuted inside every block of 32 (stored position 8 g + j holds key
- *      4 g + j for j < 4, key 16 + 4 g + j - 4 for j >= 4: the keys whose scores an MFMA accumulator leaves in k-group g);
+ *   both operands in MFMA FRAGMENT ORDER (a wave-wide 16-byte load reads one contiguous KB); the learned bias_k / bias_v row
+ *      and the zero row (multi_head.py:355-364, :416-421) are keys S and S + 1, keys up to Sp (a multiple of 32) are zero;
+ *   kc [B/beams, H, Sp/16, 2, 64, 8] bf16 keys: per tile of 16 keys and half c of the head width, lane l holds elements
+ *      c * 32 + (l >> 4) * 8 .. + 7 of key l & 15;
+ *   vt [B/beams, H, Sp/32, 4, 64, 8] bf16 values TRANSPOSED: per block of 32 keys and tile rt of 16 dimensions, lane l holds
+ *      dimension rt * 16 + (l & 15) of the keys 4 g + j (j < 4) and 16 + 4 g + j - 4 (j >= 4), g = l >> 4 - the keys whose scores
+ *      an MFMA accumulator leaves in k-group g (host mirror: transform-and-tell_amd/decode.py PackedKV.fill);
  *   mask [B/beams, Sp] uint8, 1 = masked (context padding and every position past S + 1).
  * q[c] bf16 [B, H*64] projected and scaled, out[c] bf16 [B, H*64]; head width 64; the beams hypotheses of a sample are
  * columns of one MFMA (any beams).  HOST arrays of n_ctx <= 4 entries. */
