@@ -591,6 +591,8 @@ static int skinny_mfma_launch(SkinnyArgs a, int n_prob, hipStream_t stream) {
   //  tiles, 256 workgroups, half the bytes per CU: with two stages in flight 479.9 us against 475.7, with all four 488.9
   //  against 476.6; 128 greedy rows 642-645 against 633.  Not kept: what makes a 128-row launch take 9-12 us where 32 rows
   //  take 5-7 is neither residency nor the bytes through a CU nor the number of dependent round trips.)
+      // (K = 4096 - sixteen stages per wave, two dependent rounds of eight - as EIGHT waves x K / 8 with all eight stages
+      //  of a wave in flight: 256 registers and spills, greedy step 363.5 -> 386.3 us, beam 4 474.9 -> 496.9; not kept)
       if (ns && ns % 8 == 0) return skinny_mfma_launch<RT, ACT, 8, FOLD, NW, true>(a, n_prob, stream);
       if (ns && ns % 4 == 0) return skinny_mfma_launch<RT, ACT, 4, FOLD, NW, true>(a, n_prob, stream);
     }
