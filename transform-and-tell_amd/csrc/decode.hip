@@ -590,7 +590,10 @@ static int skinny_mfma_launch(SkinnyArgs a, int n_prob, hipStream_t stream) {
   //  64 / 32 COLUMNS per workgroup where a launch has 1024 / 512 tiles - the activation rows staged once for four column
   //  tiles, 256 workgroups, half the bytes per CU: with two stages in flight 479.9 us against 475.7, with all four 488.9
   //  against 476.6; 128 greedy rows 642-645 against 633.  Not kept: what makes a 128-row launch take 9-12 us where 32 rows
-  //  take 5-7 is neither residency nor the bytes through a CU nor the number of dependent round trips.)
+  //  take 5-7 is neither residency nor the bytes through a CU nor the number of dependent round trips.  Nor where the row
+  //  groups of a column tile run: dispatch index L -> tile (L / 8G) * 8 + L % 8, row group (L / 8) % G puts the G groups of
+  //  a tile on ONE XCD within 8 G consecutive dispatches - HBM traffic of the beam-4 step unchanged to five digits (956.24
+  //  MB), step 484 -> 498 us.)
       // (K = 4096 - sixteen stages per wave, two dependent rounds of eight - as EIGHT waves x K / 8 with all eight stages
       //  of a wave in flight: 256 registers and spills, greedy step 363.5 -> 386.3 us, beam 4 474.9 -> 496.9; not kept)
       if (ns && ns % 8 == 0) return skinny_mfma_launch<RT, ACT, 8, FOLD, NW, true>(a, n_prob, stream);
