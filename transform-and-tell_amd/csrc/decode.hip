@@ -1312,7 +1312,8 @@ __global__ __launch_bounds__(256) void attn_decode_packed_kernel(AttnPkArgs g) {
   for (int rt = 0; rt < 4; ++rt) acc_o[rt] = c4{0.f, 0.f, 0.f, 0.f};
   float m = -INFINITY, l = 0.f;
   // (Measured and not kept, fragment-order cache: TWO blocks of a wave in flight, refill loads unconditional - 156 registers, two waves
-  //  per SIMD: beam-4 step 476 -> 487 us.)
+  //  per SIMD: beam-4 step 476 -> 487 us; EIGHT waves per workgroup - the article's 17 blocks in 2-3 iterations per wave instead
+  //  of 4-5: 488 us.)
   // (Measured and not kept: PAIRS of adjacent blocks per wave and iteration - the 16-byte loads of a V^T row then cover whole
   //  128-byte lines, 16 loads per lane in flight - 22.6-24.9 -> 24.5-26.1 us per launch at beam 4, 20.4 -> 21.5 with one hypothesis.)
   sk_u4 kf[2][2], vf[4];
