@@ -1471,3 +1471,51 @@ def test_skinny_linear_reduction_shared_between_workgroups(M):
             bad += int(not torch.equal(b, first[1][i]))
         side_stream.synchronize()
         assert bad == 0, (M, nseg, bad)
+
+
+def test_packed_attention_cache_layout_is_the_documented_fragment_order():
+    """include/tell_hip.h (tell_attn_decode_packed) documents the cache the kernel reads: kc [Bs, H, Sp/16, 2, 64 lanes, 8] with lane
+    l = key l & 15 of the tile, elements c * 32 + (l >> 4) * 8 ..; vt [Bs, H, Sp/32, 4, 64 lanes, 8] with lane l = dimension rt * 16 +
+    (l & 15), keys 4 g + j (j < 4) | 16 + 4 g + j - 4 of k-group g = l >> 4; bias row and zero row as keys S, S + 1; the rest zero;
+    mask 1 past S + 1.  decode.PackedKV.fill is the host mirror of that layout: element by element against the formula."""
+    import tell_amd
+    from tell_amd import decode
+    tell_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        g = torch.Generator().manual_seed(5)
+
+        class Mod:
+            num_heads = 3
+            bias_k = torch.randn(1, 1, 192, generator=g).to(DEV)
+            bias_v = torch.randn(1, 1, 192, generator=g).to(DEV)
+        S, Bc, H = 45, 2, 3
+        pk = decode.PackedKV(Mod, S, Bc, DEV)
+        assert pk.Sp == 64
+        k = torch.randn(S, Bc, H * 64, generator=g).to(DEV, torch.bfloat16)
+        v = torch.randn(S, Bc, H * 64, generator=g).to(DEV, torch.bfloat16)
+        mask = (torch.rand(Bc, S, generator=g) < 0.2).to(DEV)
+        pk.fill(k, v, mask)
+        knat = torch.zeros(Bc, H, pk.Sp, 64, dtype=torch.bfloat16, device=DEV)
+        vnat = torch.zeros_like(knat)
+        knat[:, :, :S] = k.view(S, Bc, H, 64).permute(1, 2, 0, 3)
+        vnat[:, :, :S] = v.view(S, Bc, H, 64).permute(1, 2, 0, 3)
+        knat[:, :, S] = Mod.bias_k.view(H, 64).bfloat16()
+        vnat[:, :, S] = Mod.bias_v.view(H, 64).bfloat16()
+        kc = pk.kc.view(Bc, H, pk.Sp // 16, 2, 64, 8).cpu()
+        vt = pk.vt.view(Bc, H, pk.Sp // 32, 4, 64, 8).cpu()
+        kn, vn = knat.cpu(), vnat.cpu()
+        for lane in (0, 5, 17, 31, 48, 63):
+            lr, lg = lane & 15, lane >> 4
+            for tile in range(pk.Sp // 16):
+                for c in range(2):
+                    assert torch.equal(kc[:, :, tile, c, lane], kn[:, :, tile * 16 + lr, c * 32 + lg * 8:c * 32 + lg * 8 + 8]), (lane, tile, c)
+            for blk in range(pk.Sp // 32):
+                for rt in range(4):
+                    keys = [blk * 32 + 4 * lg + j for j in range(4)] + [blk * 32 + 16 + 4 * lg + j for j in range(4)]
+                    assert torch.equal(vt[:, :, blk, rt, lane], vn[:, :, keys, rt * 16 + lr]), (lane, blk, rt)
+        want_mask = torch.ones(Bc, pk.Sp, dtype=torch.uint8)
+        want_mask[:, :S] = mask.cpu().to(torch.uint8)
+        want_mask[:, S:S + 2] = 0
+        assert torch.equal(pk.mask.cpu(), want_mask)
+    finally:
+        tell_amd.set_compute_dtype(torch.float32)
