@@ -870,10 +870,40 @@ __global__ __launch_bounds__(256) void dynconv_step_kernel(const uint16_t* __res
   const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const int m0 = blockIdx.y * R;
-  const int t = t_host + (step_dev ? (int)*step_dev : 0);
-  // ---- tap-sum role of this thread: row r, channels c0 .. c0 + VEC - 1 of the head
-  const int r = tid / TPR, c0 = (tid % TPR) * VEC, m = m0 + r;
+  // ---- what does not depend on the step index is requested FIRST (the history loads further down wait for `t`, a value this
+  // launch has to load, and, issued in front, held everything else back behind that round trip): the ancestor slots of this
+  // thread's row - oldest, so that the history loads wait for them alone -, then the operands of the tap logits
+  const int r = tid / TPR, c0 = (tid % TPR) * VEC, m = m0 + r;           // tap-sum role: row r, channels c0 .. of the head
   const bool live = m < M;
+  const int mm = live ? m : M - 1;
+  int slots[HAS_BACK ? KB - 1 : 1];
+  if constexpr (HAS_BACK) {
+    const int* bk = back + mm;
+#pragma clang loop unroll(full)
+    for (int j = 1; j < KB; ++j) {
+      slots[j - 1] = *bk;
+      bk = j + 1 < K ? bk + M : bk;
+    }
+  }
+  // ---- tap logits of the R rows: [16 (R live), C] . [32 (K live), C]^T, C split over the waves
+  const int ma = m0 + (lr < R ? lr : R - 1);
+  const uint16_t* ap = x + (long)(ma < M ? ma : M - 1) * C + wave * (C / 4) + lg * 8;
+  const uint16_t* bp[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int tap = ct * 16 + lr;
+    bp[ct] = wt + (long)(h * K + (tap < K ? tap : K - 1)) * C + wave * (C / 4) + lg * 8;
+  }
+  sk_u4 fa[NK], fb[2][NK];
+  constexpr bool two = KB > 16;                                        // (K <= 16: the second column tile has no live tap)
+#pragma unroll
+  for (int i = 0; i < NK; ++i) {
+    fb[0][i] = *reinterpret_cast<const sk_u4*>(bp[0] + i * 32);
+    fb[1][i] = sk_u4{0u, 0u, 0u, 0u};
+    if (two) fb[1][i] = *reinterpret_cast<const sk_u4*>(bp[1] + i * 32);
+    fa[i] = *reinterpret_cast<const sk_u4*>(ap + i * 32);
+  }
+  const int t = t_host + (step_dev ? (int)*step_dev : 0);
   const int ch = h * 64 + c0;
   // (plain 32-bit registers: lo = channels 0 / 0-1, hi = channels 2-3 when a thread owns four)
   uint32_t hlo[KB - 1], hhi[KB - 1];
@@ -885,41 +915,20 @@ __global__ __launch_bounds__(256) void dynconv_step_kernel(const uint16_t* __res
   };
   // (branch-free: a dead tap j >= K re-reads the row of tap K - 1 and gets weight 0 below, a dead row m >= M reads row M - 1
   //  and stores nothing - 31 guarded loads made the register allocator spill every fragment around 31 branches)
-  const int mm = live ? m : M - 1;
   int pl = (t - 1) % K;
   pl = pl < 0 ? pl + K : pl;
-  const int* bk = back + mm;
 #pragma clang loop unroll(full)
   for (int j = 1; j < KB; ++j) {
     int slot = mm;
-    if constexpr (HAS_BACK) slot = *bk;
+    if constexpr (HAS_BACK) slot = slots[j - 1];
     hhi[j - 1] = 0u;
     fetch(hist + pl * plane + (long)slot * C + ch, hlo[j - 1], hhi[j - 1]);
     const bool more = j + 1 < K;
     pl = more ? (pl == 0 ? K - 1 : pl - 1) : pl;
-    if constexpr (HAS_BACK) bk = more ? bk + M : bk;
   }
   uint32_t clo = 0u, chi = 0u;
   fetch(x + (long)mm * C + ch, clo, chi);
-  // ---- tap logits of the R rows: [16 (R live), C] . [32 (K live), C]^T, C split over the waves
   {
-    const int ma = m0 + (lr < R ? lr : R - 1);
-    const uint16_t* ap = x + (long)(ma < M ? ma : M - 1) * C + wave * (C / 4) + lg * 8;
-    const uint16_t* bp[2];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const int tap = ct * 16 + lr;
-      bp[ct] = wt + (long)(h * K + (tap < K ? tap : K - 1)) * C + wave * (C / 4) + lg * 8;
-    }
-    sk_u4 fa[NK], fb[2][NK];
-    constexpr bool two = KB > 16;                                        // (K <= 16: the second column tile has no live tap)
-#pragma unroll
-    for (int i = 0; i < NK; ++i) {
-      fb[0][i] = *reinterpret_cast<const sk_u4*>(bp[0] + i * 32);
-      fb[1][i] = sk_u4{0u, 0u, 0u, 0u};
-      if (two) fb[1][i] = *reinterpret_cast<const sk_u4*>(bp[1] + i * 32);
-      fa[i] = *reinterpret_cast<const sk_u4*>(ap + i * 32);
-    }
     typedef float c4 __attribute__((ext_vector_type(4)));
     c4 acc[2] = {c4{0.f, 0.f, 0.f, 0.f}, c4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
