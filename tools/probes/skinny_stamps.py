@@ -7,7 +7,8 @@ last graph replay of a generation leaves one consistent step in the buffer.  Per
   dur     first workgroup entry -> last workgroup exit
   gap     last exit of the PREVIOUS skinny launch -> first entry of this one (other kernels in between are named by count only)
   ramp    first entry -> last entry (how long the dispatcher takes to get every workgroup on a CU)
-  life    mean workgroup lifetime, split into K loop and epilogue
+  life    mean workgroup lifetime, split into K loop and epilogue; the epilogue again into e:lds (partial tiles into LDS + the
+          barrier), e:sum (the sums over the waves, row statistics) and e:out (residual arithmetic + stores + exit)
   p50/p90/max lifetimes, workgroups per XCD
 
 usage: python tools/probes/skinny_stamps.py [--beam 4] [--batch 32]
@@ -64,14 +65,15 @@ def main():
         code = 'RT%d act%d U%d%s%s' % (t & 255, (t >> 8) & 255, (t >> 16) & 255, ' fold' if (t >> 24) & 1 else '', ' split' if (t >> 25) & 1 else '')
         w = s[i, 1:1 + n].astype(np.int64)
         rows.append(dict(slot=i, grid=(gx, gy, gz), M=M, N=N, K=K, code=code, cn=int(s[i, 0, 3]), t0=w[:, 0], t1=w[:, 1], t2=w[:, 2],
-                         xcc=(w[:, 3] >> 32) & 0xf, hw=w[:, 3] & 0xffffffff))
+                         xcc=(w[:, 3] >> 32) & 0xf, hw=w[:, 3] & 0xffff, d_sync=(w[:, 3] >> 36) & 0xfff, d_calc=(w[:, 3] >> 48) & 0xfff))
     rows.sort(key=lambda r: r['t0'].min())
     # the last replay: the launches whose stamps lie within one step of the newest one
     newest = max(r['t2'].max() for r in rows)
     rows = [r for r in rows if newest - r['t0'].min() < 100000]           # 1 ms in 10 ns ticks
     print('# %d skinny launches of the last replayed step (beam %d, %d rows); times in us (wall clock, 10 ns ticks)' % (len(rows), args.beam, args.batch * args.beam))
-    print('%-22s %-16s %5s %5s %5s | %6s %6s %6s | %6s %6s %6s | %6s %6s %6s | %s' % (
-        'kernel', 'grid', 'M', 'N', 'K', 'dur', 'gap', 'ramp', 'life', 'kloop', 'epi', 'p50', 'p90', 'max', 'wg/xcd  distinct CUs'))
+    print('%-22s %-16s %5s %5s %5s | %6s %6s %6s | %6s %6s %6s | %6s %6s %6s | %5s %5s %5s | %s' % (
+        'kernel', 'grid', 'M', 'N', 'K', 'dur', 'gap', 'ramp', 'life', 'kloop', 'epi', 'p50', 'p90', 'max', 'e:lds', 'e:sum', 'e:out',
+        'wg/xcd  distinct CUs'))
     prev_end = None
     tot = dict(dur=0.0, gap=0.0, ramp=0.0, life=0.0)
     for r in rows:
@@ -84,9 +86,10 @@ def main():
         ep = (t2 - t1).mean() / 100.0
         per = np.bincount(r['xcc'].astype(np.int64), minlength=8)
         cu = len(set(zip(r['xcc'].tolist(), ((r['hw'] >> 8) & 0xf).tolist(), ((r['hw'] >> 13) & 0x7).tolist(), ((r['hw'] >> 12) & 1).tolist())))
-        print('%-22s %-16s %5d %5d %5d | %6.2f %6.2f %6.2f | %6.2f %6.2f %6.2f | %6.2f %6.2f %6.2f | %s  %d' % (
+        e_lds, e_sum = r['d_sync'].mean() / 100.0, r['d_calc'].mean() / 100.0     # epilogue: partial tiles to LDS + barrier | sums
+        print('%-22s %-16s %5d %5d %5d | %6.2f %6.2f %6.2f | %6.2f %6.2f %6.2f | %6.2f %6.2f %6.2f | %5.2f %5.2f %5.2f | %s  %d' % (
             r['code'], 'x'.join(map(str, r['grid'])) + ' cn%d' % r['cn'], r['M'], r['N'], r['K'], dur, gap, ramp, life.mean(), kl, ep,
-            np.percentile(life, 50), np.percentile(life, 90), life.max(), '/'.join(map(str, per)), cu))
+            np.percentile(life, 50), np.percentile(life, 90), life.max(), e_lds, e_sum, ep - e_lds - e_sum, '/'.join(map(str, per)), cu))
         prev_end = t2.max()
         tot['dur'] += dur
         tot['ramp'] += ramp

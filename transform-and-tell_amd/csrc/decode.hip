@@ -212,14 +212,19 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
   const int tid = threadIdx.x, prob = blockIdx.y, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
 #ifdef TELL_PROBES
-  unsigned long long st0 = 0, st1 = 0;
+  unsigned long long st0 = 0, st1 = 0, st_sync = 0, st_calc = 0;
   if (p.stamp) st0 = wall_clock64();
   auto stamp_out = [&]() {
     if (!p.stamp || tid != 0) return;
     const long wg = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     unsigned long long* s = p.stamp + (1 + wg) * 4;
-    s[0] = st0; s[1] = st1; s[2] = wall_clock64(); s[3] = __builtin_amdgcn_s_getreg((31 << 11) | 4 /* HW_ID, 32 bits */) |
-                                                          ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20 /* XCC_ID, 4 bits */) << 32);
+    s[0] = st0; s[1] = st1; s[2] = wall_clock64();
+    // word 3: XCC_ID (4 bits) | HW_ID CU / SH / SE bits (8 .. 15) | ticks from the end of the K loop to the barrier behind the partial
+    // tiles (12 bits) | ticks from there to the last epilogue value computed, stores not yet issued (12 bits)
+    const unsigned long long hw = __builtin_amdgcn_s_getreg((31 << 11) | 4 /* HW_ID, 32 bits */);
+    const unsigned long long d1 = st_sync > st1 ? (st_sync - st1 < 4095 ? st_sync - st1 : 4095) : 0;
+    const unsigned long long d2 = st_calc > st_sync ? (st_calc - st_sync < 4095 ? st_calc - st_sync : 4095) : 0;
+    s[3] = (hw & 0xff00ull) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20 /* XCC_ID, 4 bits */) << 32) | (d1 << 36) | (d2 << 48);
     if (wg == 0) {
       p.stamp[0] = gridDim.x | ((unsigned long long)gridDim.y << 16) | ((unsigned long long)gridDim.z << 32);
       p.stamp[1] = (unsigned long long)p.M | ((unsigned long long)p.N << 20) | ((unsigned long long)p.K << 40);
@@ -448,7 +453,14 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
     }
   }
   __syncthreads();
+#ifdef TELL_PROBES
+  if (p.stamp) st_sync = wall_clock64();
+#endif
   const int nseg = FOLD ? K / p.seg : 1, wps = NW / nseg;              // segments of the row, waves per segment
+  // (1 / seg as a factor where seg is a power of two - then the product IS the quotient, bit for bit: two divisions per
+  //  closed segment and output element were a third of the folded epilogue's instructions)
+  const bool seg_pow2 = (p.seg & (p.seg - 1)) == 0;
+  const float inv_seg = 1.f / (float)p.seg;
   (void)rst;
   const int lw = __builtin_ctz(wps);                                   // log2 of the waves per segment
   float sv[SPLIT ? EPI : 1], sg2[SPLIT && ACT == 2 ? EPI : 1];
@@ -472,8 +484,9 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
         sa += wst[((long)w * MT + r) * 2]; sb += wst[((long)w * MT + r) * 2 + 1];
         if (((w + 1) & (wps - 1)) == 0) {
           const int sg = w >> lw;
-          const float mu = sa / (float)p.seg;
-          float var = sb / (float)p.seg - mu * mu;
+          const float mu = seg_pow2 ? __fmul_rn(sa, inv_seg) : sa / (float)p.seg;
+          const float ex2 = seg_pow2 ? __fmul_rn(sb, inv_seg) : sb / (float)p.seg;   // (rounded like the quotient: no contraction)
+          float var = ex2 - mu * mu;
           var = var > 0.f ? var : 0.f;
           const float rs = rsqrtf(var + p.eps);
           const float ps0 = sg == 0 ? pre_s[0][0] : sg == 1 ? pre_s[1][0] : sg == 2 ? pre_s[2][0] : pre_s[3][0];
@@ -502,6 +515,9 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs p) {
                (red[((long)6 * MT + r) * CW + 16 + c] + red[((long)7 * MT + r) * CW + 16 + c]);
       }
     }
+#ifdef TELL_PROBES
+    if (p.stamp && e == EPI - 1) { asm volatile("" ::"v"(v)); st_calc = wall_clock64(); }
+#endif
     if constexpr (SPLIT) { sv[e] = v; if constexpr (ACT == 2) sg2[e] = g; }
     else skinny_epilogue(p, prob, m, n, v, g, ACT, PRE ? &pre[e] : nullptr);
   }
