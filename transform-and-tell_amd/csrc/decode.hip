@@ -6,9 +6,10 @@
 // dependent K tiles, split-K partials folded by a second launch, GLU / dropout / LayerNorm / concatenation launches in
 // between - at 5-8 % of the HBM roofline.  Here a layer is 12 launches:
 //   skinny_mfma_kernel   out[M,N] = epilogue(in[M,K] . W[N,K]^T): a workgroup owns 32 rows x 4-16 output columns and the
-//                        whole reduction (no partial sums in memory, deterministic); its 4 waves split K and load
-//                        their MFMA fragments straight from memory (no LDS staging, no barrier before the first
-//                        MFMA: the weight matrix is streamed exactly once with one round trip per wave).
+//                        whole reduction (no partial sums in memory, deterministic); its 4 waves split K.  Rounds 3-5:
+//                        MFMA fragments loaded straight from memory (no LDS staging, no barrier before the first MFMA);
+//                        round 6: every wave stages 8 rows x 128 bytes per load instruction through its own slice of
+//                        LDS - the fragment-order access kept the address unit, not the memory, busy (STAGED, below).
 //                        Epilogues: bias, scale, ReLU, GLU (the gate column j + N travels with column j), residual
 //                        (bf16 rows, fp32 rows, or LayerNorm of fp32 rows rebuilt from row statistics), bf16 or fp32
 //                        output (+ a bf16 copy of the trailing columns).  Up to 4 problems per launch (the query /
